@@ -1,0 +1,231 @@
+/*
+ * lattigo_ring.h -- C ABI of the MI355X-native `ring` hot path.
+ *
+ * This is the drop-in boundary for Lattigo v1.3.1's `ring` package
+ * (github.com/ldsec/lattigo/ring).  The reference has no FFI of its own: bfv/ckks
+ * call methods on *ring.Context, *ring.FastBasisExtender and *ring.Decomposer
+ * directly.  A Go shim package with the same exported identifiers forwards each
+ * method to the entry point below that names it (see INTEGRATION.md for the cgo
+ * stub).  Every entry point cites the reference symbol it replaces
+ * (path:line relative to the Lattigo tree).
+ *
+ * Conventions
+ *  - plain C, opaque handles, pointers and sizes only; no exceptions or aborts cross
+ *    the boundary.  Every function returns an lr_status (0 = ok).
+ *  - a handle is bound to one HIP device and one HIP stream.  Calls are asynchronous
+ *    on that stream unless the name ends in _host or the doc says "synchronises".
+ *    Distinct handles may be used from distinct threads; one handle is single-threaded,
+ *    like the reference's evaluators (examples/dbfv/psi/psi.go:221).
+ *  - lr_poly is a device-resident batch of polynomials laid out (poly, limb, coeff)-major:
+ *        coeff(b, i, j) = base[(b * limbs + i) * N + j]          uint64
+ *    i.e. the dense image of `batch` Go values `Poly.Coeffs [][]uint64`
+ *    (ring/ring_object.go:11-13).  Every operation applies to all polys of the batch;
+ *    an operand with batch == 1 is broadcast (shared keys / constants).
+ *  - "level" has the reference's meaning: limbs 0..level are touched, the rest ignored
+ *    (ring/ntt.go:11, ring/ring.go:20).  Passing more limbs than a poly owns is
+ *    LR_ERR_SHAPE (Go would panic with an index error).
+ *  - in == out aliasing is legal wherever the reference allows it (everywhere).
+ *  - results are bit-identical to the reference on the same inputs.
+ */
+#ifndef LATTIGO_RING_H
+#define LATTIGO_RING_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum lr_status {
+    LR_OK = 0,
+    LR_ERR_INVALID_DEGREE = 1, /* N not a power of two: ring/ring_context.go:71-73 (panic in Go)            */
+    LR_ERR_NOT_NTT_FRIENDLY = 2, /* "provided modulus does not allow NTT": ring/ring_context.go:141-146     */
+    LR_ERR_SHAPE = 3,          /* limb/batch/N mismatch (Go: index-out-of-range panic)                       */
+    LR_ERR_ARG = 4,            /* null handle, bad enum, unsupported parameter                               */
+    LR_ERR_HIP = 5,            /* HIP runtime failure; see lr_last_error_string()                            */
+    LR_ERR_UNSUPPORTED = 6     /* size outside what the kernels are built for                                */
+} lr_status;
+
+typedef struct lr_context lr_context;       /* ring.Context           ring/ring_context.go:18-51            */
+typedef struct lr_poly lr_poly;             /* batch of ring.Poly     ring/ring_object.go:11-13             */
+typedef struct lr_bext lr_bext;             /* ring.FastBasisExtender ring/ring_basis_extension.go:9-18     */
+typedef struct lr_decomposer lr_decomposer; /* ring.Decomposer        ring/ring_basis_extension.go:398-407  */
+typedef struct lr_ckks_plan lr_ckks_plan;   /* scratch pools + tables of ckks.evaluator, ckks/evaluator.go:63-97 */
+
+const char *lr_last_error_string(void);     /* thread-local, never NULL */
+int lr_device_count(int *count);
+/* version / build info: "lattigo_ring <ver> gfx950 hip" */
+const char *lr_build_info(void);
+
+/* ------------------------------------------------------------------ Context ---------- */
+/* ring.NewContextWithParams = SetParameters + GenNTTParams (ring/ring_context.go:60,68,129).
+ * Computes every constant and psi table on the host exactly as the reference does
+ * (incl. primitiveRoot's search order, ring/utils.go:182) and uploads them to `device`. */
+int lr_context_create(uint64_t N, const uint64_t *moduli, int n_moduli, int device, lr_context **out);
+int lr_context_destroy(lr_context *ctx);
+/* use an externally owned hipStream_t (e.g. torch's current stream); NULL = the context's own */
+int lr_context_set_stream(lr_context *ctx, void *hip_stream);
+int lr_context_sync(lr_context *ctx);       /* hipStreamSynchronize on the context's stream */
+int lr_context_info(const lr_context *ctx, uint64_t *N, int *n_moduli, int *device);
+
+/* Read-back of the precomputed constants, for parity tests; mirrors the getters
+ * GetBredParams/GetMredParams/GetPsi/GetPsiInv/GetNttPsi/GetNttPsiInv/GetNttNInv
+ * (ring/ring_context.go:253-285).  dst is host memory of the stated element count. */
+typedef enum lr_table {
+    LR_TAB_MODULUS = 0,    /* [L]                                  */
+    LR_TAB_BRED = 1,       /* [L][2] = {hi, lo} of floor(2^128/q)  */
+    LR_TAB_MRED = 2,       /* [L]    q^-1 mod 2^64                 */
+    LR_TAB_PSI_MONT = 3,   /* [L]                                  */
+    LR_TAB_PSI_INV_MONT = 4, /* [L]                                */
+    LR_TAB_NTT_PSI = 5,    /* [L][N] bit-reversed, Montgomery form */
+    LR_TAB_NTT_PSI_INV = 6,/* [L][N]                               */
+    LR_TAB_NTT_N_INV = 7,  /* [L]                                  */
+    LR_TAB_RESCALE = 8,    /* [L][L] row j-1, col i (i<j): rescaleParams[j-1][i], ring_context.go:148-158 */
+    LR_TAB_MASK = 9        /* [L]                                  */
+} lr_table;
+int lr_context_get_table(const lr_context *ctx, int which, uint64_t *dst, size_t dst_count);
+
+/* ------------------------------------------------------------------ Poly ------------- */
+/* Context.NewPoly / NewPolyLvl (ring/ring_context.go:288,300), for `batch` polys at once; zero-filled. */
+int lr_poly_alloc(lr_context *ctx, int limbs, int batch, lr_poly **out);
+/* wrap caller-owned device memory (e.g. a torch uint64/int64 tensor) without copying */
+int lr_poly_wrap(lr_context *ctx, void *device_ptr, int limbs, int batch, lr_poly **out);
+int lr_poly_free(lr_poly *p);
+int lr_poly_info(const lr_poly *p, uint64_t *N, int *limbs, int *batch, void **device_ptr);
+/* Go boundary: gather from / scatter to the per-limb slices of one Poly ([][]uint64 cannot be
+ * passed through cgo as a whole; the shim passes `limbs` pinned *uint64).  Synchronises. */
+int lr_poly_upload(lr_poly *p, int batch_index, const uint64_t *const *limb_ptrs, int limbs);
+int lr_poly_download(const lr_poly *p, int batch_index, uint64_t *const *limb_ptrs, int limbs);
+/* dense host image [batch][limbs][N].  Synchronises. */
+int lr_poly_upload_dense(lr_poly *p, const uint64_t *host, size_t count);
+int lr_poly_download_dense(const lr_poly *p, uint64_t *host, size_t count);
+int lr_poly_zero(lr_poly *p);               /* Poly.Zero, ring/ring_object.go:60 */
+/* Rescale re-slices its argument (`p0.Coeffs = p0.Coeffs[:level]`, ring/ring_scaling.go:33);
+ * the device buffer keeps its stride, only the logical limb count changes. */
+int lr_poly_set_limbs(lr_poly *p, int limbs);
+
+/* ------------------------------------------------------------------ NTT -------------- */
+/* Context.NTTLvl / Context.NTT (ring/ntt.go:11,4): forward negacyclic NTT of limbs 0..level of
+ * every poly in the batch; natural order in, bit-reversed order out, canonical output [0,q).
+ * Accepts any uint64 input the reference accepts (values >= q, see ring/ring_scaling.go:19,102). */
+int lr_ntt(lr_context *ctx, int level, const lr_poly *in, lr_poly *out);
+/* Context.InvNTTLvl / Context.InvNTT (ring/ntt.go:25,18). */
+int lr_intt(lr_context *ctx, int level, const lr_poly *in, lr_poly *out);
+/* package-level ring.NTT / ring.InvNTT on ONE limb under modulus index `mod_index`
+ * (ring/ntt.go:53,89): in/out limb index select rows of the polys.  Used by callers that
+ * transform a foreign limb under another limb's modulus (ring/ring_scaling.go:19,105). */
+int lr_ntt_limb(lr_context *ctx, int mod_index, const lr_poly *in, int in_limb, lr_poly *out, int out_limb);
+int lr_intt_limb(lr_context *ctx, int mod_index, const lr_poly *in, int in_limb, lr_poly *out, int out_limb);
+/* literal drop-in for a Go `Context.NTT(p1, p2)` call on host slices: upload, transform,
+ * download.  Synchronises. */
+int lr_ntt_host(lr_context *ctx, int level, const uint64_t *const *in_limbs, uint64_t *const *out_limbs);
+int lr_intt_host(lr_context *ctx, int level, const uint64_t *const *in_limbs, uint64_t *const *out_limbs);
+
+/* ------------------------------------------------------------------ coefficient-wise -- */
+/* One entry point for the whole ring/ring.go family; `op` selects the method. */
+typedef enum lr_ewise_op {
+    LR_ADD = 0,                 /* Add/AddLvl                       ring/ring.go:10,20   */
+    LR_ADD_NOMOD = 1,           /* AddNoMod/AddNoModLvl             :32,42               */
+    LR_SUB = 2,                 /* Sub/SubLvl                       :54,64               */
+    LR_SUB_NOMOD = 3,           /* SubNoMod/SubNoModLvl             :77,87               */
+    LR_NEG = 4,                 /* Neg/NegLvl                       :100,110             */
+    LR_REDUCE = 5,              /* Reduce/ReduceLvl                 :122,133             */
+    LR_MUL_COEFFS = 6,          /* MulCoeffs (Barrett)              :187                 */
+    LR_MUL_COEFFS_AND_ADD = 7,  /* MulCoeffsAndAdd                  :198                 */
+    LR_MUL_COEFFS_AND_ADD_NOMOD = 8, /* MulCoeffsAndAddNoMod        :209                 */
+    LR_MUL_COEFFS_CONSTANT = 9, /* MulCoeffsConstant                :335                 */
+    LR_MUL_MONT = 10,           /* MulCoeffsMontgomery(Lvl)         :221,233             */
+    LR_MUL_MONT_AND_ADD = 11,   /* MulCoeffsMontgomeryAndAdd(Lvl)   :247,259             */
+    LR_MUL_MONT_AND_ADD_NOMOD = 12, /* ...AndAddNoMod(Lvl)          :273,285             */
+    LR_MUL_MONT_CONSTANT_AND_ADD_NOMOD = 13, /* ...ConstantAndAddNoModLvl :297           */
+    LR_MUL_MONT_AND_SUB = 14,   /* MulCoeffsMontgomeryAndSub        :311                 */
+    LR_MUL_MONT_AND_SUB_NOMOD = 15, /* ...AndSubNoMod               :323                 */
+    LR_MUL_MONT_CONSTANT = 16,  /* MulCoeffsMontgomeryConstant      :347                 */
+    LR_MFORM = 17,              /* MForm/MFormLvl                   :583,595             */
+    LR_INV_MFORM = 18,          /* InvMForm                         :610                 */
+    LR_MUL_SCALAR = 19,         /* MulScalar/MulScalarLvl           :513,526  scalars[0]            */
+    LR_MUL_SCALAR_LIMBS = 20,   /* MulScalarBigint(Lvl)             :541,557  scalars[i] = s mod qi */
+    LR_ADD_SCALAR_LIMBS = 21,   /* AddScalarBigint                  :477      (writes its 1st arg)  */
+    LR_SUB_SCALAR_LIMBS = 22,   /* SubScalarBigint                  :500      (writes its 1st arg)  */
+    LR_COPY = 23,               /* Copy/CopyLvl                     ring/ring_object.go:85,98       */
+    LR_MUL_BY_POW2 = 24,        /* MulByPow2/MulByPow2Lvl           ring/ring.go:629,645 scalars[0] */
+    LR_EWISE_OP_COUNT = 25
+} lr_ewise_op;
+/* out <- op(a, b) (accumulating ops read out as well).  b may be NULL for 2-operand ops.
+ * scalars: host pointer, 1 value (MUL_SCALAR, MUL_BY_POW2) or level+1 values (*_LIMBS). */
+int lr_ewise(lr_context *ctx, int op, int level, const lr_poly *a, const lr_poly *b, lr_poly *out,
+             const uint64_t *scalars);
+
+/* ------------------------------------------------------------------ basis extension --- */
+/* NewFastBasisExtender(contextQ, contextP), ring/ring_basis_extension.go:57 */
+int lr_bext_create(lr_context *ctxQ, lr_context *ctxP, lr_bext **out);
+int lr_bext_destroy(lr_bext *b);
+/* ModUpSplitQP (:147): p1 over Q[0..level] -> p2 over all of P.  Coefficient domain. */
+int lr_modup_split_qp(lr_bext *b, int level, const lr_poly *p1, lr_poly *p2);
+/* ModUpSplitPQ (:154): p1 over P[0..level] -> p2 over all of Q. */
+int lr_modup_split_pq(lr_bext *b, int level, const lr_poly *p1, lr_poly *p2);
+/* ModDownNTTPQ (:163): p1 over Q||P (|Q|+|P| limbs, NTT domain; its P limbs are left in the
+ * coefficient domain, as in Go) -> p2 over Q[0..level]. */
+int lr_moddown_ntt_pq(lr_bext *b, int level, lr_poly *p1, lr_poly *p2);
+/* ModDownSplitedNTTPQ (:207): (p1Q, p1P) NTT domain -> p2; p1P is left in the coefficient domain. */
+int lr_moddown_split_ntt_pq(lr_bext *b, int level, const lr_poly *p1Q, lr_poly *p1P, lr_poly *p2);
+/* ModDownPQ (:248): p1 over Q[0..level]||P, coefficient domain. */
+int lr_moddown_pq(lr_bext *b, int level, const lr_poly *p1, lr_poly *p2);
+/* ModDownSplitedPQ (:281) */
+int lr_moddown_split_pq(lr_bext *b, int level, const lr_poly *p1Q, const lr_poly *p1P, lr_poly *p2);
+/* ModDownSplitedQP (:314): divide by Q, result over P[0..levelP]. */
+int lr_moddown_split_qp(lr_bext *b, int levelQ, int levelP, const lr_poly *p1Q, const lr_poly *p1P, lr_poly *p2);
+/* tables for parity tests: 0 = modDownParamsPQ [|Q|], 1 = modDownParamsQP [|P|] (:39-53) */
+int lr_bext_get_table(const lr_bext *b, int which, uint64_t *dst, size_t dst_count);
+
+/* NewDecomposer(Q, P), :415 */
+int lr_decomposer_create(lr_context *ctxQ, lr_context *ctxP, lr_decomposer **out);
+int lr_decomposer_destroy(lr_decomposer *d);
+/* Decompose (:476): p0 over Q (coefficient domain) -> p1 over Q[0..level]||P. */
+int lr_decompose(lr_decomposer *d, int level, int crt_decomp_level, const lr_poly *p0, lr_poly *p1);
+/* DecomposeAndSplit (:601): -> p1Q over Q[0..level], p1P over P. */
+int lr_decompose_and_split(lr_decomposer *d, int level, int crt_decomp_level, const lr_poly *p0,
+                           lr_poly *p1Q, lr_poly *p1P);
+
+/* ------------------------------------------------------------------ RNS rescale ------- */
+/* In place on p0 (limbs = level+1); on return p0 owns one limb less (see lr_poly_set_limbs).
+ * DivFloorByLastModulusNTT (ring/ring_scaling.go:9), DivFloorByLastModulus (:37),
+ * DivRoundByLastModulusNTT (:72), DivRoundByLastModulus (:117). */
+int lr_div_floor_by_last_modulus_ntt(lr_context *ctx, lr_poly *p0);
+int lr_div_floor_by_last_modulus(lr_context *ctx, lr_poly *p0);
+int lr_div_round_by_last_modulus_ntt(lr_context *ctx, lr_poly *p0);
+int lr_div_round_by_last_modulus(lr_context *ctx, lr_poly *p0);
+/* ...Many / ...ManyNTT (:58,65,153,160) */
+int lr_div_floor_by_last_modulus_many(lr_context *ctx, lr_poly *p0, int nb_rescales, int ntt_domain);
+int lr_div_round_by_last_modulus_many(lr_context *ctx, lr_poly *p0, int nb_rescales, int ntt_domain);
+
+/* ------------------------------------------------------------------ caller sequences -- */
+/* The ring-level call sequence of ckks.Evaluator, kept on the device for a whole batch.
+ * lr_ckks_plan owns what ckks.NewEvaluator builds: FastBasisExtender, Decomposer and the
+ * scratch pools (ckks/evaluator.go:81-112). */
+int lr_ckks_plan_create(lr_context *ctxQ, lr_context *ctxP, int max_batch, lr_ckks_plan **out);
+int lr_ckks_plan_destroy(lr_ckks_plan *plan);
+/* switchKeysInPlace (ckks/evaluator.go:1475): cx over Q[0..level], NTT domain;
+ * evk = SwitchingKey.evakey as one poly, batch = beta*2, limbs = |Q|+|P|
+ * (ckks/keygen.go:68-70: evakey[i][0], evakey[i][1] in NTT + Montgomery form);
+ * p0, p1 over Q[0..level] receive the two key-switched components. */
+int lr_ckks_switch_keys(lr_ckks_plan *plan, int level, const lr_poly *cx, const lr_poly *evk,
+                        lr_poly *p0, lr_poly *p1);
+/* MulRelin (ckks/evaluator.go:1016), ciphertext x ciphertext, with evaluation key.
+ * ct0_c0/ct0_c1 etc. are the degree-0/1 components (Ciphertext.Value()[0], [1]). */
+int lr_ckks_mulrelin(lr_ckks_plan *plan, int level, const lr_poly *ct0_c0, const lr_poly *ct0_c1,
+                     const lr_poly *ct1_c0, const lr_poly *ct1_c1, const lr_poly *evk,
+                     lr_poly *out_c0, lr_poly *out_c1);
+/* Rescale, one level (ckks/evaluator.go:933-968 inner loop): DivRoundByLastModulusNTT on both components. */
+int lr_ckks_rescale(lr_ckks_plan *plan, lr_poly *c0, lr_poly *c1);
+
+/* ------------------------------------------------------------------ measurement ------- */
+/* HIP events on the context's stream (bench.py's roofline leg). */
+int lr_timer_start(lr_context *ctx);
+int lr_timer_stop(lr_context *ctx, float *elapsed_ms);   /* synchronises on the stop event */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LATTIGO_RING_H */

@@ -1,0 +1,1226 @@
+// lr_abi.cpp -- the C ABI of include/lattigo_ring.h: handles, shape checks, and the composition
+// of the HIP kernels into the reference's ring.Context / FastBasisExtender / Decomposer methods
+// and the ckks.Evaluator call sequences.  No CPU fallback exists: every arithmetic entry point
+// launches gfx950 kernels and fails with LR_ERR_HIP when no device is available.
+#include "lattigo_ring.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <memory>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "lr_device.hpp"
+#include "lr_precompute.hpp"
+
+using namespace lr;
+
+namespace {
+
+thread_local std::string g_error = "";
+
+int fail(int code, const std::string &msg) {
+    g_error = msg;
+    return code;
+}
+
+#define LR_HIP(expr)                                                                              \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess) return fail(LR_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+#define LR_TRY(expr)            \
+    do {                        \
+        int rc_ = (expr);       \
+        if (rc_ != LR_OK) return rc_; \
+    } while (0)
+
+template <class T>
+int to_device(T **dst, const T *src, size_t count) {
+    *dst = nullptr;
+    if (count == 0) return LR_OK;
+    LR_HIP(hipMalloc((void **)dst, count * sizeof(T)));
+    LR_HIP(hipMemcpy(*dst, src, count * sizeof(T), hipMemcpyHostToDevice));
+    return LR_OK;
+}
+
+unsigned log2_exact(u64 n) {
+    unsigned l = 0;
+    while ((1ull << l) < n) ++l;
+    return l;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------
+// handles
+// ------------------------------------------------------------------------------------------
+struct lr_context {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    HostContext h;
+    LimbParams *d_lp = nullptr;
+    Twiddle *d_fwd = nullptr;
+    Twiddle *d_inv = nullptr;
+    u64 *d_rescale = nullptr;   // [L][L]
+    u64 *scratch = nullptr;     // rescale temporaries, grown on demand
+    size_t scratch_words = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+struct lr_poly {
+    lr_context *ctx = nullptr;
+    u64 *d = nullptr;
+    bool owned = false;
+    int limbs = 0;        // logical limb count (rescale shrinks it)
+    int alloc_limbs = 0;  // stride, fixed at allocation
+    int batch = 0;
+    long long stride() const { return (long long)alloc_limbs * (long long)ctx->h.N; }
+};
+
+namespace {
+
+struct DevModup {
+    HostModup h;
+    u64 *Q = nullptr, *mredQ = nullptr, *qib = nullptr, *P = nullptr, *mredP = nullptr, *bredP_hi = nullptr,
+        *qispj = nullptr, *qpj_inv = nullptr;
+    int init(const std::vector<u64> &Qv, const std::vector<u64> &Pv) {
+        h = build_modup(Qv, Pv);
+        std::vector<u64> bh(h.P.size());
+        for (size_t j = 0; j < bh.size(); ++j) bh[j] = h.bredP[j].hi;
+        LR_TRY(to_device(&Q, h.Q.data(), h.Q.size()));
+        LR_TRY(to_device(&mredQ, h.mredQ.data(), h.mredQ.size()));
+        LR_TRY(to_device(&qib, h.qib_mont.data(), h.qib_mont.size()));
+        LR_TRY(to_device(&P, h.P.data(), h.P.size()));
+        LR_TRY(to_device(&mredP, h.mredP.data(), h.mredP.size()));
+        LR_TRY(to_device(&bredP_hi, bh.data(), bh.size()));
+        LR_TRY(to_device(&qispj, h.qispj_mont.data(), h.qispj_mont.size()));
+        LR_TRY(to_device(&qpj_inv, h.qpj_inv.data(), h.qpj_inv.size()));
+        return LR_OK;
+    }
+    ExtTables tables() const {
+        ExtTables t;
+        t.nQ = (int)h.Q.size();
+        t.nP = (int)h.P.size();
+        t.Q = Q; t.mredQ = mredQ; t.qib_mont = qib; t.P = P; t.mredP = mredP; t.bredP_hi = bredP_hi;
+        t.qispj_mont = qispj; t.qpj_inv = qpj_inv;
+        return t;
+    }
+    ~DevModup() {
+        for (u64 *p : {Q, mredQ, qib, P, mredP, bredP_hi, qispj, qpj_inv})
+            if (p) (void)hipFree(p);
+    }
+};
+
+// a grow-on-demand device buffer
+struct Pool {
+    u64 *d = nullptr;
+    size_t words = 0;
+    int ensure(lr_context *c, size_t need) {
+        if (need <= words) return LR_OK;
+        LR_HIP(hipStreamSynchronize(c->stream));
+        if (d) LR_HIP(hipFree(d));
+        d = nullptr;
+        words = 0;
+        LR_HIP(hipMalloc((void **)&d, need * sizeof(u64)));
+        words = need;
+        return LR_OK;
+    }
+    ~Pool() {
+        if (d) (void)hipFree(d);
+    }
+};
+
+}  // namespace
+
+struct lr_bext {
+    lr_context *cQ = nullptr, *cP = nullptr;
+    DevModup qp, pq;
+    std::vector<u64> moddown_pq, moddown_qp;  // host copies (Montgomery form)
+    u64 *d_moddown_pq = nullptr, *d_moddown_qp = nullptr;
+    Pool poolQ, poolP;
+    ~lr_bext() {
+        if (d_moddown_pq) (void)hipFree(d_moddown_pq);
+        if (d_moddown_qp) (void)hipFree(d_moddown_qp);
+    }
+};
+
+struct lr_decomposer {
+    lr_context *cQ = nullptr, *cP = nullptr;
+    int nQ = 0, nP = 0, alpha = 0, beta = 0;
+    std::vector<int> xalpha;
+    std::vector<std::vector<std::unique_ptr<DevModup>>> modup;  // [beta][xalpha-1]
+};
+
+struct lr_ckks_plan {
+    lr_context *cQ = nullptr, *cP = nullptr;
+    lr_bext *bext = nullptr;
+    lr_decomposer *dec = nullptr;
+    int max_batch = 0;
+    Pool c2QiQ, c2QiP, pool2P, pool3P, c2, c00, c01, c0, c1, c2x, q1, q2;
+};
+
+// ------------------------------------------------------------------------------------------
+// misc
+// ------------------------------------------------------------------------------------------
+extern "C" const char *lr_last_error_string(void) { return g_error.c_str(); }
+
+extern "C" const char *lr_build_info(void) { return "lattigo_ring 0.1 gfx950 hip"; }
+
+extern "C" int lr_device_count(int *count) {
+    if (!count) return fail(LR_ERR_ARG, "count is null");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        *count = 0;
+        return fail(LR_ERR_HIP, std::string("hipGetDeviceCount: ") + hipGetErrorString(e));
+    }
+    *count = n;
+    return LR_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// Context
+// ------------------------------------------------------------------------------------------
+extern "C" int lr_context_create(uint64_t N, const uint64_t *moduli, int n_moduli, int device, lr_context **out) {
+    if (!out) return fail(LR_ERR_ARG, "out is null");
+    *out = nullptr;
+    if (!moduli || n_moduli <= 0 || n_moduli > kMaxLimbs) return fail(LR_ERR_ARG, "bad modulus list (1..64 moduli)");
+    std::unique_ptr<lr_context> c(new (std::nothrow) lr_context());
+    if (!c) return fail(LR_ERR_ARG, "out of host memory");
+    const int rc = build_context(N, moduli, n_moduli, c->h);
+    if (rc == 2) return fail(LR_ERR_INVALID_DEGREE, "invalid ring degree (must be a power of 2)");
+    if (rc == 1) return fail(LR_ERR_NOT_NTT_FRIENDLY, "warning : provided modulus does not allow NTT");
+    for (u64 q : c->h.q)
+        if (q >> 61) return fail(LR_ERR_UNSUPPORTED, "modulus must be below 2^61 (the reference's lazy NTT has the same limit)");
+    c->device = device;
+    LR_HIP(hipSetDevice(device));
+    LR_HIP(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+    c->stream = c->own_stream;
+    LR_HIP(hipEventCreate(&c->ev0));
+    LR_HIP(hipEventCreate(&c->ev1));
+
+    const int L = n_moduli;
+    std::vector<LimbParams> lp(L);
+    std::vector<Twiddle> fwd((size_t)L * N), inv((size_t)L * N);
+    for (int i = 0; i < L; ++i) {
+        const u64 q = c->h.q[i], qinv = c->h.mred[i];
+        LimbParams &p = lp[i];
+        p.q = q;
+        p.qinv = qinv;
+        p.bred_hi = c->h.bred[i].hi;
+        p.bred_lo = c->h.bred[i].lo;
+        p.n_inv_mont = c->h.n_inv[i];
+        p.n_inv = inv_mform(c->h.n_inv[i], q, qinv);
+        p.n_inv_shoup = shoup_companion(p.n_inv, q);
+        p.pad = 0;
+        for (u64 j = 0; j < N; ++j) {
+            const u64 wf = inv_mform(c->h.ntt_psi[(size_t)i * N + j], q, qinv);
+            const u64 wi = inv_mform(c->h.ntt_psi_inv[(size_t)i * N + j], q, qinv);
+            fwd[(size_t)i * N + j] = make_ulonglong2(wf, shoup_companion(wf, q));
+            inv[(size_t)i * N + j] = make_ulonglong2(wi, shoup_companion(wi, q));
+        }
+    }
+    LR_TRY(to_device(&c->d_lp, lp.data(), lp.size()));
+    LR_TRY(to_device(&c->d_fwd, fwd.data(), fwd.size()));
+    LR_TRY(to_device(&c->d_inv, inv.data(), inv.size()));
+    LR_TRY(to_device(&c->d_rescale, c->h.rescale.data(), c->h.rescale.size()));
+    *out = c.release();
+    return LR_OK;
+}
+
+extern "C" int lr_context_destroy(lr_context *c) {
+    if (!c) return LR_OK;
+    (void)hipSetDevice(c->device);
+    if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
+    for (void *p : {(void *)c->d_lp, (void *)c->d_fwd, (void *)c->d_inv, (void *)c->d_rescale, (void *)c->scratch})
+        if (p) (void)hipFree(p);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+    return LR_OK;
+}
+
+extern "C" int lr_context_set_stream(lr_context *c, void *hip_stream) {
+    if (!c) return fail(LR_ERR_ARG, "null context");
+    c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    return LR_OK;
+}
+
+extern "C" int lr_context_sync(lr_context *c) {
+    if (!c) return fail(LR_ERR_ARG, "null context");
+    LR_HIP(hipSetDevice(c->device));
+    LR_HIP(hipStreamSynchronize(c->stream));
+    return LR_OK;
+}
+
+extern "C" int lr_context_info(const lr_context *c, uint64_t *N, int *n_moduli, int *device) {
+    if (!c) return fail(LR_ERR_ARG, "null context");
+    if (N) *N = c->h.N;
+    if (n_moduli) *n_moduli = c->h.L();
+    if (device) *device = c->device;
+    return LR_OK;
+}
+
+extern "C" int lr_context_get_table(const lr_context *c, int which, uint64_t *dst, size_t dst_count) {
+    if (!c || !dst) return fail(LR_ERR_ARG, "null argument");
+    const HostContext &h = c->h;
+    const size_t L = (size_t)h.L();
+    std::vector<u64> tmp;
+    const std::vector<u64> *src = nullptr;
+    switch (which) {
+    case LR_TAB_MODULUS: src = &h.q; break;
+    case LR_TAB_MRED: src = &h.mred; break;
+    case LR_TAB_PSI_MONT: src = &h.psi_mont; break;
+    case LR_TAB_PSI_INV_MONT: src = &h.psi_inv_mont; break;
+    case LR_TAB_NTT_PSI: src = &h.ntt_psi; break;
+    case LR_TAB_NTT_PSI_INV: src = &h.ntt_psi_inv; break;
+    case LR_TAB_NTT_N_INV: src = &h.n_inv; break;
+    case LR_TAB_RESCALE: src = &h.rescale; break;
+    case LR_TAB_MASK: src = &h.mask; break;
+    case LR_TAB_BRED:
+        tmp.resize(2 * L);
+        for (size_t i = 0; i < L; ++i) {
+            tmp[2 * i] = h.bred[i].hi;
+            tmp[2 * i + 1] = h.bred[i].lo;
+        }
+        src = &tmp;
+        break;
+    default: return fail(LR_ERR_ARG, "unknown table id");
+    }
+    if (dst_count != src->size()) return fail(LR_ERR_SHAPE, "table size mismatch");
+    std::memcpy(dst, src->data(), src->size() * sizeof(u64));
+    return LR_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// Poly
+// ------------------------------------------------------------------------------------------
+extern "C" int lr_poly_alloc(lr_context *c, int limbs, int batch, lr_poly **out) {
+    if (!c || !out) return fail(LR_ERR_ARG, "null argument");
+    *out = nullptr;
+    if (limbs <= 0 || limbs > kMaxLimbs || batch <= 0) return fail(LR_ERR_SHAPE, "limbs must be 1..64 and batch >= 1");
+    LR_HIP(hipSetDevice(c->device));
+    std::unique_ptr<lr_poly> p(new lr_poly());
+    p->ctx = c;
+    p->limbs = p->alloc_limbs = limbs;
+    p->batch = batch;
+    p->owned = true;
+    const size_t bytes = (size_t)batch * limbs * c->h.N * sizeof(u64);
+    LR_HIP(hipMalloc((void **)&p->d, bytes));
+    LR_HIP(hipMemsetAsync(p->d, 0, bytes, c->stream));
+    *out = p.release();
+    return LR_OK;
+}
+
+extern "C" int lr_poly_wrap(lr_context *c, void *device_ptr, int limbs, int batch, lr_poly **out) {
+    if (!c || !out || !device_ptr) return fail(LR_ERR_ARG, "null argument");
+    *out = nullptr;
+    if (limbs <= 0 || limbs > kMaxLimbs || batch <= 0) return fail(LR_ERR_SHAPE, "limbs must be 1..64 and batch >= 1");
+    if (((uintptr_t)device_ptr & 15) != 0) return fail(LR_ERR_ARG, "device pointer must be 16-byte aligned");
+    lr_poly *p = new lr_poly();
+    p->ctx = c;
+    p->d = (u64 *)device_ptr;
+    p->limbs = p->alloc_limbs = limbs;
+    p->batch = batch;
+    p->owned = false;
+    *out = p;
+    return LR_OK;
+}
+
+extern "C" int lr_poly_free(lr_poly *p) {
+    if (!p) return LR_OK;
+    if (p->owned && p->d) {
+        (void)hipSetDevice(p->ctx->device);
+        (void)hipStreamSynchronize(p->ctx->stream);
+        (void)hipFree(p->d);
+    }
+    delete p;
+    return LR_OK;
+}
+
+extern "C" int lr_poly_info(const lr_poly *p, uint64_t *N, int *limbs, int *batch, void **device_ptr) {
+    if (!p) return fail(LR_ERR_ARG, "null poly");
+    if (N) *N = p->ctx->h.N;
+    if (limbs) *limbs = p->limbs;
+    if (batch) *batch = p->batch;
+    if (device_ptr) *device_ptr = p->d;
+    return LR_OK;
+}
+
+extern "C" int lr_poly_set_limbs(lr_poly *p, int limbs) {
+    if (!p) return fail(LR_ERR_ARG, "null poly");
+    if (limbs < 0 || limbs > p->alloc_limbs) return fail(LR_ERR_SHAPE, "limb count exceeds the allocation");
+    p->limbs = limbs;
+    return LR_OK;
+}
+
+extern "C" int lr_poly_zero(lr_poly *p) {
+    if (!p) return fail(LR_ERR_ARG, "null poly");
+    LR_HIP(hipSetDevice(p->ctx->device));
+    LR_HIP(hipMemsetAsync(p->d, 0, (size_t)p->batch * p->stride() * sizeof(u64), p->ctx->stream));
+    return LR_OK;
+}
+
+extern "C" int lr_poly_upload(lr_poly *p, int batch_index, const uint64_t *const *limb_ptrs, int limbs) {
+    if (!p || !limb_ptrs) return fail(LR_ERR_ARG, "null argument");
+    if (batch_index < 0 || batch_index >= p->batch || limbs < 0 || limbs > p->limbs)
+        return fail(LR_ERR_SHAPE, "upload: batch index or limb count out of range");
+    lr_context *c = p->ctx;
+    LR_HIP(hipSetDevice(c->device));
+    const size_t row = c->h.N * sizeof(u64);
+    for (int i = 0; i < limbs; ++i) {
+        if (!limb_ptrs[i]) return fail(LR_ERR_ARG, "null limb pointer");
+        LR_HIP(hipMemcpyAsync(p->d + batch_index * p->stride() + (long long)i * c->h.N, limb_ptrs[i], row,
+                              hipMemcpyHostToDevice, c->stream));
+    }
+    LR_HIP(hipStreamSynchronize(c->stream));
+    return LR_OK;
+}
+
+extern "C" int lr_poly_download(const lr_poly *p, int batch_index, uint64_t *const *limb_ptrs, int limbs) {
+    if (!p || !limb_ptrs) return fail(LR_ERR_ARG, "null argument");
+    if (batch_index < 0 || batch_index >= p->batch || limbs < 0 || limbs > p->limbs)
+        return fail(LR_ERR_SHAPE, "download: batch index or limb count out of range");
+    lr_context *c = p->ctx;
+    LR_HIP(hipSetDevice(c->device));
+    const size_t row = c->h.N * sizeof(u64);
+    for (int i = 0; i < limbs; ++i) {
+        if (!limb_ptrs[i]) return fail(LR_ERR_ARG, "null limb pointer");
+        LR_HIP(hipMemcpyAsync(limb_ptrs[i], p->d + batch_index * p->stride() + (long long)i * c->h.N, row,
+                              hipMemcpyDeviceToHost, c->stream));
+    }
+    LR_HIP(hipStreamSynchronize(c->stream));
+    return LR_OK;
+}
+
+static int dense_copy(const lr_poly *p, u64 *host, const u64 *host_src, size_t count) {
+    lr_context *c = p->ctx;
+    const size_t N = c->h.N;
+    if (count != (size_t)p->batch * p->limbs * N) return fail(LR_ERR_SHAPE, "dense copy: element count != batch*limbs*N");
+    LR_HIP(hipSetDevice(c->device));
+    LR_HIP(hipStreamSynchronize(c->stream));
+    // logical limbs per poly; the device stride is larger after a rescale re-sliced the poly
+    const size_t chunk = (size_t)p->limbs * N;
+    const int pieces = p->limbs == p->alloc_limbs ? 1 : p->batch;
+    const size_t piece = p->limbs == p->alloc_limbs ? count : chunk;
+    for (int b = 0; b < pieces; ++b) {
+        u64 *dev = p->d + (long long)b * p->stride();
+        if (host_src)
+            LR_HIP(hipMemcpy(dev, host_src + (size_t)b * chunk, piece * sizeof(u64), hipMemcpyHostToDevice));
+        else
+            LR_HIP(hipMemcpy(host + (size_t)b * chunk, dev, piece * sizeof(u64), hipMemcpyDeviceToHost));
+    }
+    return LR_OK;
+}
+
+extern "C" int lr_poly_upload_dense(lr_poly *p, const uint64_t *host, size_t count) {
+    if (!p || !host) return fail(LR_ERR_ARG, "null argument");
+    return dense_copy(p, nullptr, host, count);
+}
+
+extern "C" int lr_poly_download_dense(const lr_poly *p, uint64_t *host, size_t count) {
+    if (!p || !host) return fail(LR_ERR_ARG, "null argument");
+    return dense_copy(p, host, nullptr, count);
+}
+
+// ------------------------------------------------------------------------------------------
+// NTT
+// ------------------------------------------------------------------------------------------
+namespace {
+
+struct Rows {  // a strided view of rows inside a batch buffer
+    u64 *base;
+    long long stride;  // between batch polys
+    int limb0, step;
+};
+
+int run_ntt(lr_context *c, bool inverse, Rows in, Rows out, int mod0, int mod_step, int count, int batch) {
+    if (count <= 0 || batch <= 0) return LR_OK;
+    const unsigned logn = c->h.logN;
+    if (logn < 1 || logn > 15)
+        return fail(LR_ERR_UNSUPPORTED, "NTT kernels cover 2 <= N <= 2^15 in this build");
+    NttLaunch a;
+    a.in = in.base;
+    a.out = out.base;
+    a.in_poly_stride = in.stride;
+    a.out_poly_stride = out.stride;
+    a.in_limb0 = in.limb0;
+    a.in_limb_step = in.step;
+    a.out_limb0 = out.limb0;
+    a.out_limb_step = out.step;
+    a.mod0 = mod0;
+    a.mod_step = mod_step;
+    a.n_items = count;
+    a.batch = batch;
+    a.lp = c->d_lp;
+    a.tw = inverse ? c->d_inv : c->d_fwd;
+    LR_HIP(launch_ntt(a, (int)logn, inverse, c->stream));
+    return LR_OK;
+}
+
+int check_pair(const lr_context *c, int level, const lr_poly *in, const lr_poly *out) {
+    if (!c || !in || !out) return fail(LR_ERR_ARG, "null argument");
+    if (in->ctx->h.N != c->h.N || out->ctx->h.N != c->h.N) return fail(LR_ERR_SHAPE, "ring degree mismatch");
+    if (level < 0 || level + 1 > c->h.L()) return fail(LR_ERR_SHAPE, "level exceeds the context's modulus count");
+    if (level + 1 > in->limbs || level + 1 > out->limbs) return fail(LR_ERR_SHAPE, "poly has fewer limbs than level+1");
+    if (in->batch != out->batch && in->batch != 1) return fail(LR_ERR_SHAPE, "batch mismatch");
+    return LR_OK;
+}
+
+Rows rows_of(const lr_poly *p, int limb0 = 0, int step = 1, bool broadcast_ok = false, int target_batch = 0) {
+    Rows r;
+    r.base = p->d;
+    r.stride = (broadcast_ok && p->batch == 1 && target_batch > 1) ? 0 : p->stride();
+    r.limb0 = limb0;
+    r.step = step;
+    return r;
+}
+
+}  // namespace
+
+extern "C" int lr_ntt(lr_context *c, int level, const lr_poly *in, lr_poly *out) {
+    LR_TRY(check_pair(c, level, in, out));
+    if (in->batch != out->batch) return fail(LR_ERR_SHAPE, "batch mismatch");
+    LR_HIP(hipSetDevice(c->device));
+    return run_ntt(c, false, rows_of(in), rows_of(out), 0, 1, level + 1, out->batch);
+}
+
+extern "C" int lr_intt(lr_context *c, int level, const lr_poly *in, lr_poly *out) {
+    LR_TRY(check_pair(c, level, in, out));
+    if (in->batch != out->batch) return fail(LR_ERR_SHAPE, "batch mismatch");
+    LR_HIP(hipSetDevice(c->device));
+    return run_ntt(c, true, rows_of(in), rows_of(out), 0, 1, level + 1, out->batch);
+}
+
+static int ntt_limb(lr_context *c, bool inverse, int mod_index, const lr_poly *in, int in_limb, lr_poly *out, int out_limb) {
+    if (!c || !in || !out) return fail(LR_ERR_ARG, "null argument");
+    if (mod_index < 0 || mod_index >= c->h.L()) return fail(LR_ERR_SHAPE, "modulus index out of range");
+    if (in_limb < 0 || in_limb >= in->limbs || out_limb < 0 || out_limb >= out->limbs)
+        return fail(LR_ERR_SHAPE, "limb index out of range");
+    if (in->batch != out->batch) return fail(LR_ERR_SHAPE, "batch mismatch");
+    LR_HIP(hipSetDevice(c->device));
+    return run_ntt(c, inverse, rows_of(in, in_limb, 0), rows_of(out, out_limb, 0), mod_index, 0, 1, out->batch);
+}
+
+extern "C" int lr_ntt_limb(lr_context *c, int mod_index, const lr_poly *in, int in_limb, lr_poly *out, int out_limb) {
+    return ntt_limb(c, false, mod_index, in, in_limb, out, out_limb);
+}
+extern "C" int lr_intt_limb(lr_context *c, int mod_index, const lr_poly *in, int in_limb, lr_poly *out, int out_limb) {
+    return ntt_limb(c, true, mod_index, in, in_limb, out, out_limb);
+}
+
+static int ntt_host(lr_context *c, bool inverse, int level, const uint64_t *const *in_limbs, uint64_t *const *out_limbs) {
+    if (!c || !in_limbs || !out_limbs) return fail(LR_ERR_ARG, "null argument");
+    if (level < 0 || level + 1 > c->h.L()) return fail(LR_ERR_SHAPE, "level exceeds the context's modulus count");
+    lr_poly *tmp = nullptr;
+    LR_TRY(lr_poly_alloc(c, level + 1, 1, &tmp));
+    int rc = lr_poly_upload(tmp, 0, in_limbs, level + 1);
+    if (rc == LR_OK) rc = inverse ? lr_intt(c, level, tmp, tmp) : lr_ntt(c, level, tmp, tmp);
+    if (rc == LR_OK) rc = lr_poly_download(tmp, 0, out_limbs, level + 1);
+    lr_poly_free(tmp);
+    return rc;
+}
+
+extern "C" int lr_ntt_host(lr_context *c, int level, const uint64_t *const *in_limbs, uint64_t *const *out_limbs) {
+    return ntt_host(c, false, level, in_limbs, out_limbs);
+}
+extern "C" int lr_intt_host(lr_context *c, int level, const uint64_t *const *in_limbs, uint64_t *const *out_limbs) {
+    return ntt_host(c, true, level, in_limbs, out_limbs);
+}
+
+// ------------------------------------------------------------------------------------------
+// coefficient-wise
+// ------------------------------------------------------------------------------------------
+namespace {
+
+bool op_reads_b(int op) {
+    return op == LR_ADD || op == LR_ADD_NOMOD || op == LR_SUB || op == LR_SUB_NOMOD ||
+           (op >= LR_MUL_COEFFS && op <= LR_MUL_MONT_CONSTANT);
+}
+
+// raw form used by the pipelines: pointers are already offset to limb 0 of the operands
+int run_ewise(lr_context *c, int op, int limbs, int batch, const u64 *a, long long a_stride, const u64 *b,
+              long long b_stride, u64 *out, long long out_stride, const LimbScalars *sc, int lp_offset = 0) {
+    EwiseLaunch L;
+    L.a = a;
+    L.b = b;
+    L.out = out;
+    L.a_stride = a_stride;
+    L.b_stride = b_stride;
+    L.out_stride = out_stride;
+    L.n = (int)c->h.N;
+    L.lp = c->d_lp + lp_offset;
+    L.has_scalars = sc ? 1 : 0;
+    if (sc) L.scalars = *sc;
+    LR_HIP(launch_ewise(op, L, limbs, batch, c->stream));
+    return LR_OK;
+}
+
+}  // namespace
+
+extern "C" int lr_ewise(lr_context *c, int op, int level, const lr_poly *a, const lr_poly *b, lr_poly *out,
+                        const uint64_t *scalars) {
+    if (!c || !a || !out) return fail(LR_ERR_ARG, "null argument");
+    if (op < 0 || op >= LR_EWISE_OP_COUNT) return fail(LR_ERR_ARG, "unknown coefficient-wise op");
+    LR_TRY(check_pair(c, level, a, out));
+    const bool needs_b = op_reads_b(op);
+    if (needs_b) {
+        if (!b) return fail(LR_ERR_ARG, "this op needs a second operand");
+        LR_TRY(check_pair(c, level, b, out));
+    }
+    if (c->h.N < 2) return fail(LR_ERR_UNSUPPORTED, "N must be at least 2");
+    LR_HIP(hipSetDevice(c->device));
+    LimbScalars sc;
+    const LimbScalars *scp = nullptr;
+    const int limbs = level + 1;
+    if (op == LR_MUL_SCALAR || op == LR_MUL_SCALAR_LIMBS || op == LR_ADD_SCALAR_LIMBS || op == LR_SUB_SCALAR_LIMBS ||
+        op == LR_MUL_BY_POW2) {
+        if (!scalars) return fail(LR_ERR_ARG, "this op needs scalars");
+        for (int i = 0; i < limbs; ++i) {
+            const u64 q = c->h.q[i];
+            const BarrettConst bc = c->h.bred[i];
+            switch (op) {
+            case LR_MUL_SCALAR: sc.v[i] = mform(bred_add(scalars[0], q, bc.hi), q, bc.hi, bc.lo); break;      // ring.go:516
+            case LR_MUL_SCALAR_LIMBS: sc.v[i] = mform(bred_add(scalars[i], q, bc.hi), q, bc.hi, bc.lo); break; // ring.go:547
+            case LR_MUL_BY_POW2: sc.v[i] = scalars[0]; break;
+            default: sc.v[i] = scalars[i]; break;
+            }
+        }
+        scp = &sc;
+    }
+    const int batch = out->batch;
+    const long long as = (a->batch == 1 && batch > 1) ? 0 : a->stride();
+    const long long bs = (b && b->batch == 1 && batch > 1) ? 0 : (b ? b->stride() : 0);
+    if (op == LR_MUL_BY_POW2 && a->d == out->d) {
+        // MulByPow2 in place: the reference first overwrites p2 with MForm(p1), ring/ring.go:630
+        LR_TRY(run_ewise(c, LR_MFORM, limbs, batch, a->d, as, nullptr, 0, out->d, out->stride(), nullptr));
+    }
+    return run_ewise(c, op, limbs, batch, a->d, as, needs_b ? b->d : nullptr, bs, out->d, out->stride(), scp);
+}
+
+// ------------------------------------------------------------------------------------------
+// basis extension
+// ------------------------------------------------------------------------------------------
+namespace {
+
+int run_ext(lr_context *c, const DevModup &m, int n_in, Rows in, int batch, ExtSegment s0, ExtSegment s1) {
+    if (n_in < 1 || n_in > 40 || n_in > (int)m.h.Q.size()) return fail(LR_ERR_UNSUPPORTED, "basis extension from 1..40 limbs");
+    ExtLaunch L;
+    L.t = m.tables();
+    L.in = in.base;
+    L.in_stride = in.stride;
+    L.in_limb0 = in.limb0;
+    L.n = (int)c->h.N;
+    L.seg[0] = s0;
+    L.seg[1] = s1;
+    LR_HIP(launch_ext(L, n_in, batch, c->stream));
+    return LR_OK;
+}
+
+ExtSegment segment(u64 *out, long long stride, int limb0, int col0, int count) {
+    ExtSegment s;
+    s.out = out;
+    s.stride = stride;
+    s.limb0 = limb0;
+    s.col0 = col0;
+    s.count = count;
+    return s;
+}
+
+int run_submul(lr_context *c, int limbs, int batch, const u64 *a, long long a_stride, const u64 *b, long long b_stride,
+               long long b_row_stride, u64 *out, long long out_stride, const u64 *d_consts, bool reduce_b,
+               const LimbScalars *addend) {
+    SubMulLaunch L;
+    L.a = a;
+    L.b = b;
+    L.out = out;
+    L.a_stride = a_stride;
+    L.b_stride = b_stride;
+    L.out_stride = out_stride;
+    L.b_row_stride = b_row_stride;
+    L.n = (int)c->h.N;
+    L.lp = c->d_lp;
+    L.consts = d_consts;
+    L.reduce_b = reduce_b ? 1 : 0;
+    if (addend) L.addend = *addend;
+    else std::memset(&L.addend, 0, sizeof(L.addend));
+    LR_HIP(launch_submul(L, limbs, batch, c->stream));
+    return LR_OK;
+}
+
+int same_degree(const lr_context *a, const lr_context *b) {
+    if (a->h.N != b->h.N) return fail(LR_ERR_SHAPE, "contexts have different ring degrees");
+    if (a->device != b->device) return fail(LR_ERR_ARG, "contexts live on different devices");
+    return LR_OK;
+}
+
+}  // namespace
+
+extern "C" int lr_bext_create(lr_context *cQ, lr_context *cP, lr_bext **out) {
+    if (!cQ || !cP || !out) return fail(LR_ERR_ARG, "null argument");
+    *out = nullptr;
+    LR_TRY(same_degree(cQ, cP));
+    LR_HIP(hipSetDevice(cQ->device));
+    std::unique_ptr<lr_bext> b(new lr_bext());
+    b->cQ = cQ;
+    b->cP = cP;
+    LR_TRY(b->qp.init(cQ->h.q, cP->h.q));
+    LR_TRY(b->pq.init(cP->h.q, cQ->h.q));
+    b->moddown_pq = build_moddown(cQ->h, cP->h);  // genModDownParams(contextQ, contextP), ring_basis_extension.go:66
+    b->moddown_qp = build_moddown(cP->h, cQ->h);  // :67
+    LR_TRY(to_device(&b->d_moddown_pq, b->moddown_pq.data(), b->moddown_pq.size()));
+    LR_TRY(to_device(&b->d_moddown_qp, b->moddown_qp.data(), b->moddown_qp.size()));
+    *out = b.release();
+    return LR_OK;
+}
+
+extern "C" int lr_bext_destroy(lr_bext *b) {
+    if (!b) return LR_OK;
+    (void)hipSetDevice(b->cQ->device);
+    (void)hipStreamSynchronize(b->cQ->stream);
+    delete b;
+    return LR_OK;
+}
+
+extern "C" int lr_bext_get_table(const lr_bext *b, int which, uint64_t *dst, size_t dst_count) {
+    if (!b || !dst) return fail(LR_ERR_ARG, "null argument");
+    const std::vector<u64> &src = which == 0 ? b->moddown_pq : b->moddown_qp;
+    if (which < 0 || which > 1) return fail(LR_ERR_ARG, "unknown table id");
+    if (dst_count != src.size()) return fail(LR_ERR_SHAPE, "table size mismatch");
+    std::memcpy(dst, src.data(), src.size() * sizeof(u64));
+    return LR_OK;
+}
+
+extern "C" int lr_modup_split_qp(lr_bext *b, int level, const lr_poly *p1, lr_poly *p2) {
+    if (!b || !p1 || !p2) return fail(LR_ERR_ARG, "null argument");
+    const int nP = b->cP->h.L();
+    if (level < 0 || level + 1 > b->cQ->h.L() || level + 1 > p1->limbs || nP > p2->limbs)
+        return fail(LR_ERR_SHAPE, "ModUpSplitQP: limb counts");
+    if (p1->batch != p2->batch) return fail(LR_ERR_SHAPE, "batch mismatch");
+    LR_HIP(hipSetDevice(b->cQ->device));
+    return run_ext(b->cQ, b->qp, level + 1, rows_of(p1), p2->batch, segment(p2->d, p2->stride(), 0, 0, nP),
+                   segment(nullptr, 0, 0, 0, 0));
+}
+
+extern "C" int lr_modup_split_pq(lr_bext *b, int level, const lr_poly *p1, lr_poly *p2) {
+    if (!b || !p1 || !p2) return fail(LR_ERR_ARG, "null argument");
+    const int nQ = b->cQ->h.L();
+    if (level < 0 || level + 1 > b->cP->h.L() || level + 1 > p1->limbs || nQ > p2->limbs)
+        return fail(LR_ERR_SHAPE, "ModUpSplitPQ: limb counts");
+    if (p1->batch != p2->batch) return fail(LR_ERR_SHAPE, "batch mismatch");
+    LR_HIP(hipSetDevice(b->cQ->device));
+    return run_ext(b->cQ, b->pq, level + 1, rows_of(p1), p2->batch, segment(p2->d, p2->stride(), 0, 0, nQ),
+                   segment(nullptr, 0, 0, 0, 0));
+}
+
+namespace {
+
+// shared tail of the four ModDown...PQ variants: P part (coefficient domain, rows p_limb0.. of pP)
+// -> poolQ[0..level] by modUpExact, optional NTT, then p2 = MRed(p1Q + (q - pool), P^-1)
+int moddown_pq_core(lr_bext *b, int level, const u64 *p1Q, long long p1Q_stride, Rows pP, int batch, lr_poly *p2, bool ntt) {
+    lr_context *cQ = b->cQ;
+    const int nP = b->cP->h.L();
+    const long long pool_stride = (long long)cQ->h.L() * (long long)cQ->h.N;
+    LR_TRY(b->poolQ.ensure(cQ, (size_t)batch * pool_stride));
+    LR_TRY(run_ext(cQ, b->pq, nP, pP, batch, segment(b->poolQ.d, pool_stride, 0, 0, level + 1), segment(nullptr, 0, 0, 0, 0)));
+    if (ntt) {
+        Rows pr{b->poolQ.d, pool_stride, 0, 1};
+        LR_TRY(run_ntt(cQ, false, pr, pr, 0, 1, level + 1, batch));
+    }
+    return run_submul(cQ, level + 1, batch, p1Q, p1Q_stride, b->poolQ.d, pool_stride, (long long)cQ->h.N, p2->d,
+                      p2->stride(), b->d_moddown_pq, false, nullptr);
+}
+
+}  // namespace
+
+extern "C" int lr_moddown_ntt_pq(lr_bext *b, int level, lr_poly *p1, lr_poly *p2) {
+    if (!b || !p1 || !p2) return fail(LR_ERR_ARG, "null argument");
+    const int nQ = b->cQ->h.L(), nP = b->cP->h.L();
+    if (level < 0 || level + 1 > nQ || p1->limbs < nQ + nP || p2->limbs < level + 1)
+        return fail(LR_ERR_SHAPE, "ModDownNTTPQ: limb counts");
+    if (p1->batch != p2->batch) return fail(LR_ERR_SHAPE, "batch mismatch");
+    LR_HIP(hipSetDevice(b->cQ->device));
+    Rows pP = rows_of(p1, nQ, 1);
+    LR_TRY(run_ntt(b->cP, true, pP, pP, 0, 1, nP, p1->batch));  // ring_basis_extension.go:172-174
+    return moddown_pq_core(b, level, p1->d, p1->stride(), pP, p1->batch, p2, true);
+}
+
+extern "C" int lr_moddown_split_ntt_pq(lr_bext *b, int level, const lr_poly *p1Q, lr_poly *p1P, lr_poly *p2) {
+    if (!b || !p1Q || !p1P || !p2) return fail(LR_ERR_ARG, "null argument");
+    const int nQ = b->cQ->h.L(), nP = b->cP->h.L();
+    if (level < 0 || level + 1 > nQ || p1Q->limbs < level + 1 || p1P->limbs < nP || p2->limbs < level + 1)
+        return fail(LR_ERR_SHAPE, "ModDownSplitedNTTPQ: limb counts");
+    if (p1Q->batch != p2->batch || p1P->batch != p2->batch) return fail(LR_ERR_SHAPE, "batch mismatch");
+    LR_HIP(hipSetDevice(b->cQ->device));
+    Rows pP = rows_of(p1P);
+    LR_TRY(run_ntt(b->cP, true, pP, pP, 0, 1, nP, p2->batch));  // :215
+    return moddown_pq_core(b, level, p1Q->d, p1Q->stride(), pP, p2->batch, p2, true);
+}
+
+extern "C" int lr_moddown_pq(lr_bext *b, int level, const lr_poly *p1, lr_poly *p2) {
+    if (!b || !p1 || !p2) return fail(LR_ERR_ARG, "null argument");
+    const int nQ = b->cQ->h.L(), nP = b->cP->h.L();
+    if (level < 0 || level + 1 > nQ || p1->limbs < level + 1 + nP || p2->limbs < level + 1)
+        return fail(LR_ERR_SHAPE, "ModDownPQ: limb counts");
+    if (p1->batch != p2->batch) return fail(LR_ERR_SHAPE, "batch mismatch");
+    LR_HIP(hipSetDevice(b->cQ->device));
+    return moddown_pq_core(b, level, p1->d, p1->stride(), rows_of(p1, level + 1, 1), p1->batch, p2, false);
+}
+
+extern "C" int lr_moddown_split_pq(lr_bext *b, int level, const lr_poly *p1Q, const lr_poly *p1P, lr_poly *p2) {
+    if (!b || !p1Q || !p1P || !p2) return fail(LR_ERR_ARG, "null argument");
+    const int nQ = b->cQ->h.L(), nP = b->cP->h.L();
+    if (level < 0 || level + 1 > nQ || p1Q->limbs < level + 1 || p1P->limbs < nP || p2->limbs < level + 1)
+        return fail(LR_ERR_SHAPE, "ModDownSplitedPQ: limb counts");
+    if (p1Q->batch != p2->batch || p1P->batch != p2->batch) return fail(LR_ERR_SHAPE, "batch mismatch");
+    LR_HIP(hipSetDevice(b->cQ->device));
+    return moddown_pq_core(b, level, p1Q->d, p1Q->stride(), rows_of(p1P), p2->batch, p2, false);
+}
+
+extern "C" int lr_moddown_split_qp(lr_bext *b, int levelQ, int levelP, const lr_poly *p1Q, const lr_poly *p1P, lr_poly *p2) {
+    if (!b || !p1Q || !p1P || !p2) return fail(LR_ERR_ARG, "null argument");
+    lr_context *cP = b->cP;
+    const int nQ = b->cQ->h.L(), nP = cP->h.L();
+    if (levelQ < 0 || levelQ + 1 > nQ || levelP < 0 || levelP + 1 > nP || p1Q->limbs < levelQ + 1 ||
+        p1P->limbs < levelP + 1 || p2->limbs < levelP + 1)
+        return fail(LR_ERR_SHAPE, "ModDownSplitedQP: limb counts");
+    if (p1Q->batch != p2->batch || p1P->batch != p2->batch) return fail(LR_ERR_SHAPE, "batch mismatch");
+    LR_HIP(hipSetDevice(cP->device));
+    const int batch = p2->batch;
+    const long long pool_stride = (long long)nP * (long long)cP->h.N;
+    LR_TRY(b->poolP.ensure(cP, (size_t)batch * pool_stride));
+    // ModUpSplitQP(levelQ, p1Q, polypool), :332
+    LR_TRY(run_ext(b->cQ, b->qp, levelQ + 1, rows_of(p1Q), batch, segment(b->poolP.d, pool_stride, 0, 0, nP),
+                   segment(nullptr, 0, 0, 0, 0)));
+    return run_submul(cP, levelP + 1, batch, p1P->d, p1P->stride(), b->poolP.d, pool_stride, (long long)cP->h.N, p2->d,
+                      p2->stride(), b->d_moddown_qp, false, nullptr);
+}
+
+// ------------------------------------------------------------------------------------------
+// Decomposer
+// ------------------------------------------------------------------------------------------
+extern "C" int lr_decomposer_create(lr_context *cQ, lr_context *cP, lr_decomposer **out) {
+    if (!cQ || !cP || !out) return fail(LR_ERR_ARG, "null argument");
+    *out = nullptr;
+    LR_TRY(same_degree(cQ, cP));
+    LR_HIP(hipSetDevice(cQ->device));
+    std::unique_ptr<lr_decomposer> d(new lr_decomposer());
+    d->cQ = cQ;
+    d->cP = cP;
+    const std::vector<u64> &Q = cQ->h.q, &P = cP->h.q;
+    d->nQ = (int)Q.size();
+    d->nP = (int)P.size();
+    d->alpha = d->nP;
+    d->beta = (d->nQ + d->alpha - 1) / d->alpha;  // ceil(len(Q)/alpha), ring_basis_extension.go:433
+    d->xalpha.assign(d->beta, d->alpha);
+    if (d->nQ % d->alpha != 0) d->xalpha[d->beta - 1] = d->nQ % d->alpha;
+    std::vector<u64> QP(Q);
+    QP.insert(QP.end(), P.begin(), P.end());
+    d->modup.resize(d->beta);
+    for (int i = 0; i < d->beta; ++i) {
+        for (int j = 0; j + 1 < d->xalpha[i]; ++j) {
+            std::vector<u64> Qi(Q.begin() + (size_t)i * d->alpha, Q.begin() + (size_t)i * d->alpha + j + 2);
+            std::unique_ptr<DevModup> m(new DevModup());
+            LR_TRY(m->init(Qi, QP));
+            d->modup[i].push_back(std::move(m));
+        }
+    }
+    *out = d.release();
+    return LR_OK;
+}
+
+extern "C" int lr_decomposer_destroy(lr_decomposer *d) {
+    if (!d) return LR_OK;
+    (void)hipSetDevice(d->cQ->device);
+    (void)hipStreamSynchronize(d->cQ->stream);
+    delete d;
+    return LR_OK;
+}
+
+namespace {
+
+// Decompose (split == false, outP ignored) / DecomposeAndSplit.  in: rows of p0 (coefficient domain).
+int decompose_core(lr_decomposer *d, int level, int crt, Rows in, int batch, u64 *outQ, long long outQ_stride, u64 *outP,
+                   long long outP_stride, bool split) {
+    lr_context *c = d->cQ;
+    if (crt < 0 || crt >= d->beta) return fail(LR_ERR_SHAPE, "crtDecompLevel out of range");
+    if (level < 0 || level + 1 > d->nQ) return fail(LR_ERR_SHAPE, "level out of range");
+    const int alphai = d->xalpha[crt];
+    const int st = crt * d->alpha, ed = st + alphai;
+    if (st > level) return fail(LR_ERR_SHAPE, "digit lies above the level");
+    const int n = (int)c->h.N;
+    if ((ed > level + 1 && (level + 1) % d->nP == 1) || alphai == 1) {
+        // no reconstruction needed: every target limb receives limb p0idxst, :490-497 / :613-623
+        RowAddLaunch L;
+        L.in = in.base + (long long)(in.limb0 + st) * n;
+        L.in_stride = in.stride;
+        L.n = n;
+        L.q = 0;
+        std::memset(&L.adds, 0, sizeof(L.adds));
+        L.out = outQ;
+        L.out_stride = outQ_stride;
+        LR_HIP(launch_rowadd(L, split ? level + 1 : level + 1 + d->nP, batch, c->stream));
+        if (split) {
+            L.out = outP;
+            L.out_stride = outP_stride;
+            LR_HIP(launch_rowadd(L, d->nP, batch, c->stream));
+        }
+        return LR_OK;
+    }
+    int index;
+    if (level >= alphai + crt * d->alpha) index = alphai - 2;
+    else index = (level - 1) % d->alpha;
+    const DevModup &m = *d->modup[crt][index];
+    Rows digit = in;
+    digit.limb0 = in.limb0 + st;
+    // rows 0..level take table columns 0..level (the own-digit rows are rewritten by the
+    // "index greater" loop of the reference, :571 / :687, so the copy at :553 / :669 is dead);
+    // the special primes take columns nQ.., written to the P poly or to rows level+1.. of p1.
+    ExtSegment sq = segment(outQ, outQ_stride, 0, 0, level + 1);
+    ExtSegment sp = split ? segment(outP, outP_stride, 0, d->nQ, d->nP) : segment(outQ, outQ_stride, level + 1, d->nQ, d->nP);
+    return run_ext(c, m, index + 2, digit, batch, sq, sp);
+}
+
+}  // namespace
+
+extern "C" int lr_decompose(lr_decomposer *d, int level, int crt, const lr_poly *p0, lr_poly *p1) {
+    if (!d || !p0 || !p1) return fail(LR_ERR_ARG, "null argument");
+    if (p0->limbs < level + 1 || p1->limbs < level + 1 + d->nP) return fail(LR_ERR_SHAPE, "Decompose: limb counts");
+    if (p0->batch != p1->batch) return fail(LR_ERR_SHAPE, "batch mismatch");
+    LR_HIP(hipSetDevice(d->cQ->device));
+    return decompose_core(d, level, crt, rows_of(p0), p1->batch, p1->d, p1->stride(), nullptr, 0, false);
+}
+
+extern "C" int lr_decompose_and_split(lr_decomposer *d, int level, int crt, const lr_poly *p0, lr_poly *p1Q, lr_poly *p1P) {
+    if (!d || !p0 || !p1Q || !p1P) return fail(LR_ERR_ARG, "null argument");
+    if (p0->limbs < level + 1 || p1Q->limbs < level + 1 || p1P->limbs < d->nP)
+        return fail(LR_ERR_SHAPE, "DecomposeAndSplit: limb counts");
+    if (p0->batch != p1Q->batch || p0->batch != p1P->batch) return fail(LR_ERR_SHAPE, "batch mismatch");
+    LR_HIP(hipSetDevice(d->cQ->device));
+    return decompose_core(d, level, crt, rows_of(p0), p1Q->batch, p1Q->d, p1Q->stride(), p1P->d, p1P->stride(), true);
+}
+
+// ------------------------------------------------------------------------------------------
+// RNS rescale (ring/ring_scaling.go:9-164)
+// ------------------------------------------------------------------------------------------
+namespace {
+
+int ensure_scratch(lr_context *c, size_t words) {
+    if (words <= c->scratch_words) return LR_OK;
+    LR_HIP(hipStreamSynchronize(c->stream));
+    if (c->scratch) LR_HIP(hipFree(c->scratch));
+    c->scratch = nullptr;
+    c->scratch_words = 0;
+    LR_HIP(hipMalloc((void **)&c->scratch, words * sizeof(u64)));
+    c->scratch_words = words;
+    return LR_OK;
+}
+
+int check_rescale(lr_context *c, lr_poly *p0) {
+    if (!c || !p0) return fail(LR_ERR_ARG, "null argument");
+    if (p0->ctx->h.N != c->h.N) return fail(LR_ERR_SHAPE, "ring degree mismatch");
+    if (p0->limbs < 2) return fail(LR_ERR_SHAPE, "cannot divide by the last modulus of a 1-limb polynomial");
+    if (p0->limbs > c->h.L()) return fail(LR_ERR_SHAPE, "poly has more limbs than the context has moduli");
+    return LR_OK;
+}
+
+// round == true adds the pHalf centring of :83-89 / :125-129
+int rescale_coeff_domain(lr_context *c, lr_poly *p0, bool round) {
+    const int level = p0->limbs - 1, n = (int)c->h.N, batch = p0->batch;
+    u64 *last = p0->d + (long long)level * n;
+    LimbScalars add;
+    std::memset(&add, 0, sizeof(add));
+    if (round) {
+        const u64 pj = c->h.q[level], phalf = (pj - 1) >> 1;
+        RowAddLaunch L;
+        L.in = last;
+        L.out = last;
+        L.in_stride = L.out_stride = p0->stride();
+        L.n = n;
+        L.q = pj;
+        std::memset(&L.adds, 0, sizeof(L.adds));
+        L.adds.v[0] = phalf;
+        LR_HIP(launch_rowadd(L, 1, batch, c->stream));
+        for (int i = 0; i < level; ++i) add.v[i] = c->h.q[i] - bred_add(phalf, c->h.q[i], c->h.bred[i].hi);  // pHalfNegQi
+    }
+    LR_TRY(run_submul(c, level, batch, p0->d, p0->stride(), last, p0->stride(), 0, p0->d, p0->stride(),
+                      c->d_rescale + (size_t)(level - 1) * c->h.L(), true, &add));
+    p0->limbs = level;
+    return LR_OK;
+}
+
+int rescale_ntt_domain(lr_context *c, lr_poly *p0, bool round) {
+    const int level = p0->limbs - 1, n = (int)c->h.N, batch = p0->batch;
+    const long long tmp_stride = (long long)level * n;
+    LR_TRY(ensure_scratch(c, (size_t)batch * tmp_stride));
+    Rows last{p0->d, p0->stride(), level, 0};
+    LR_TRY(run_ntt(c, true, last, last, level, 0, 1, batch));  // :15 / :80
+    Rows tmp{c->scratch, tmp_stride, 0, 1};
+    if (round) {
+        const u64 pj = c->h.q[level], phalf = (pj - 1) >> 1;
+        RowAddLaunch L;
+        L.in = p0->d + (long long)level * n;
+        L.out = p0->d + (long long)level * n;
+        L.in_stride = L.out_stride = p0->stride();
+        L.n = n;
+        L.q = pj;
+        std::memset(&L.adds, 0, sizeof(L.adds));
+        L.adds.v[0] = phalf;
+        LR_HIP(launch_rowadd(L, 1, batch, c->stream));            // :87-89
+        RowAddLaunch M;
+        M.in = p0->d + (long long)level * n;
+        M.in_stride = p0->stride();
+        M.out = c->scratch;
+        M.out_stride = tmp_stride;
+        M.n = n;
+        M.q = 0;
+        std::memset(&M.adds, 0, sizeof(M.adds));
+        for (int i = 0; i < level; ++i) M.adds.v[i] = c->h.q[i] - bred_add(phalf, c->h.q[i], c->h.bred[i].hi);
+        LR_HIP(launch_rowadd(M, level, batch, c->stream));        // :101-103
+        LR_TRY(run_ntt(c, false, tmp, tmp, 0, 1, level, batch));  // :105
+    } else {
+        LR_TRY(run_ntt(c, false, last, tmp, 0, 1, level, batch));  // :19: NTT of the last limb under modulus i
+    }
+    LR_TRY(run_submul(c, level, batch, p0->d, p0->stride(), c->scratch, tmp_stride, (long long)n, p0->d, p0->stride(),
+                      c->d_rescale + (size_t)(level - 1) * c->h.L(), false, nullptr));
+    p0->limbs = level;
+    return LR_OK;
+}
+
+}  // namespace
+
+extern "C" int lr_div_floor_by_last_modulus_ntt(lr_context *c, lr_poly *p0) {
+    LR_TRY(check_rescale(c, p0));
+    LR_HIP(hipSetDevice(c->device));
+    return rescale_ntt_domain(c, p0, false);
+}
+extern "C" int lr_div_floor_by_last_modulus(lr_context *c, lr_poly *p0) {
+    LR_TRY(check_rescale(c, p0));
+    LR_HIP(hipSetDevice(c->device));
+    return rescale_coeff_domain(c, p0, false);
+}
+extern "C" int lr_div_round_by_last_modulus_ntt(lr_context *c, lr_poly *p0) {
+    LR_TRY(check_rescale(c, p0));
+    LR_HIP(hipSetDevice(c->device));
+    return rescale_ntt_domain(c, p0, true);
+}
+extern "C" int lr_div_round_by_last_modulus(lr_context *c, lr_poly *p0) {
+    LR_TRY(check_rescale(c, p0));
+    LR_HIP(hipSetDevice(c->device));
+    return rescale_coeff_domain(c, p0, true);
+}
+
+static int rescale_many(lr_context *c, lr_poly *p0, int nb, int ntt_domain, bool round) {
+    LR_TRY(check_rescale(c, p0));
+    if (nb < 0 || nb >= p0->limbs) return fail(LR_ERR_SHAPE, "nbRescales must be below the limb count");
+    LR_HIP(hipSetDevice(c->device));
+    Rows r = rows_of(p0);
+    if (ntt_domain) LR_TRY(run_ntt(c, true, r, r, 0, 1, p0->limbs, p0->batch));   // :59 / :154
+    for (int k = 0; k < nb; ++k) LR_TRY(rescale_coeff_domain(c, p0, round));
+    if (ntt_domain) LR_TRY(run_ntt(c, false, r, r, 0, 1, p0->limbs, p0->batch));  // :61 / :156
+    return LR_OK;
+}
+extern "C" int lr_div_floor_by_last_modulus_many(lr_context *c, lr_poly *p0, int nb, int ntt_domain) {
+    return rescale_many(c, p0, nb, ntt_domain, false);
+}
+extern "C" int lr_div_round_by_last_modulus_many(lr_context *c, lr_poly *p0, int nb, int ntt_domain) {
+    return rescale_many(c, p0, nb, ntt_domain, true);
+}
+
+// ------------------------------------------------------------------------------------------
+// ckks.Evaluator call sequences
+// ------------------------------------------------------------------------------------------
+extern "C" int lr_ckks_plan_create(lr_context *cQ, lr_context *cP, int max_batch, lr_ckks_plan **out) {
+    if (!cQ || !cP || !out) return fail(LR_ERR_ARG, "null argument");
+    *out = nullptr;
+    if (max_batch < 1) return fail(LR_ERR_ARG, "max_batch must be >= 1");
+    LR_TRY(same_degree(cQ, cP));
+    std::unique_ptr<lr_ckks_plan> p(new lr_ckks_plan());
+    p->cQ = cQ;
+    p->cP = cP;
+    p->max_batch = max_batch;
+    LR_TRY(lr_bext_create(cQ, cP, &p->bext));
+    int rc = lr_decomposer_create(cQ, cP, &p->dec);
+    if (rc != LR_OK) {
+        lr_bext_destroy(p->bext);
+        return rc;
+    }
+    *out = p.release();
+    return LR_OK;
+}
+
+extern "C" int lr_ckks_plan_destroy(lr_ckks_plan *p) {
+    if (!p) return LR_OK;
+    (void)hipSetDevice(p->cQ->device);
+    (void)hipStreamSynchronize(p->cQ->stream);
+    lr_bext_destroy(p->bext);
+    lr_decomposer_destroy(p->dec);
+    delete p;
+    return LR_OK;
+}
+
+namespace {
+
+// switchKeysInPlace, ckks/evaluator.go:1475-1558, on raw buffers: cx/p0/p1 have `q_stride` between batch polys
+int switch_keys_core(lr_ckks_plan *pl, int level, int batch, const u64 *cx, long long cx_stride, const lr_poly *evk, u64 *p0,
+                     long long p0_stride, u64 *p1, long long p1_stride) {
+    lr_context *cQ = pl->cQ, *cP = pl->cP;
+    lr_decomposer *dec = pl->dec;
+    const int nQ = cQ->h.L(), nP = cP->h.L(), n = (int)cQ->h.N;
+    const int alpha = dec->alpha;
+    const int beta = (level + 1 + alpha - 1) / alpha;  // :1508
+    if (evk->batch < 2 * beta || evk->limbs < nQ + nP) return fail(LR_ERR_SHAPE, "evaluation key: need batch >= 2*beta and |Q|+|P| limbs");
+    const long long sQ = (long long)nQ * n, sP = (long long)nP * n;
+    LR_TRY(pl->c2QiQ.ensure(cQ, (size_t)batch * sQ));
+    LR_TRY(pl->c2.ensure(cQ, (size_t)batch * sQ));
+    LR_TRY(pl->c2QiP.ensure(cQ, (size_t)batch * sP));
+    LR_TRY(pl->pool2P.ensure(cQ, (size_t)batch * sP));
+    LR_TRY(pl->pool3P.ensure(cQ, (size_t)batch * sP));
+    hipStream_t st = cQ->stream;
+    // poolQ[i].Zero(), poolP[i].Zero(), :1481-1487
+    const size_t live = (size_t)(level + 1) * n;
+    for (int k = 0; k < 2; ++k) {
+        u64 *pz = k == 0 ? p0 : p1;
+        const long long zs = k == 0 ? p0_stride : p1_stride;
+        if ((size_t)zs == live) {
+            LR_HIP(hipMemsetAsync(pz, 0, (size_t)batch * live * sizeof(u64), st));
+        } else {
+            for (int b = 0; b < batch; ++b) LR_HIP(hipMemsetAsync(pz + b * zs, 0, live * sizeof(u64), st));
+        }
+    }
+    LR_HIP(hipMemsetAsync(pl->pool2P.d, 0, (size_t)batch * sP * sizeof(u64), st));
+    LR_HIP(hipMemsetAsync(pl->pool3P.d, 0, (size_t)batch * sP * sizeof(u64), st));
+
+    Rows cxr{const_cast<u64 *>(cx), cx_stride, 0, 1};
+    Rows c2r{pl->c2.d, sQ, 0, 1};
+    LR_TRY(run_ntt(cQ, true, cxr, c2r, 0, 1, level + 1, batch));  // :1503
+    int reduce = 0;
+    for (int i = 0; i < beta; ++i) {
+        // decomposeAndSplitNTT, :1561-1591
+        LR_TRY(decompose_core(dec, level, i, c2r, batch, pl->c2QiQ.d, sQ, pl->c2QiP.d, sP, true));
+        const int d0 = i * alpha;
+        int d1 = d0 + dec->xalpha[i];
+        if (d1 > level + 1) d1 = level + 1;
+        // own-digit limbs are taken from the NTT-domain input (:1579-1584)
+        LR_TRY(run_ewise(cQ, LR_COPY, d1 - d0, batch, cx + (long long)d0 * n, cx_stride, nullptr, 0,
+                         pl->c2QiQ.d + (long long)d0 * n, sQ, nullptr, d0));
+        Rows lo{pl->c2QiQ.d, sQ, 0, 1};
+        LR_TRY(run_ntt(cQ, false, lo, lo, 0, 1, d0, batch));                     // limbs below the digit
+        Rows hi{pl->c2QiQ.d, sQ, d1, 1};
+        LR_TRY(run_ntt(cQ, false, hi, hi, d1, 1, level + 1 - d1, batch));        // limbs above the digit
+        Rows pr{pl->c2QiP.d, sP, 0, 1};
+        LR_TRY(run_ntt(cP, false, pr, pr, 0, 1, nP, batch));                     // :1590
+        const u64 *k0 = evk->d + (long long)(2 * i) * evk->stride();
+        const u64 *k1 = evk->d + (long long)(2 * i + 1) * evk->stride();
+        LR_TRY(run_ewise(cQ, LR_MUL_MONT_AND_ADD_NOMOD, level + 1, batch, k0, 0, pl->c2QiQ.d, sQ, p0, p0_stride, nullptr));  // :1515
+        LR_TRY(run_ewise(cQ, LR_MUL_MONT_AND_ADD_NOMOD, level + 1, batch, k1, 0, pl->c2QiQ.d, sQ, p1, p1_stride, nullptr));  // :1516
+        LR_TRY(run_ewise(cP, LR_MUL_MONT_AND_ADD_NOMOD, nP, batch, k0 + (long long)nQ * n, 0, pl->c2QiP.d, sP, pl->pool2P.d, sP, nullptr));  // :1519-1534
+        LR_TRY(run_ewise(cP, LR_MUL_MONT_AND_ADD_NOMOD, nP, batch, k1 + (long long)nQ * n, 0, pl->c2QiP.d, sP, pl->pool3P.d, sP, nullptr));
+        if ((reduce & 7) == 1) {  // :1536-1541
+            LR_TRY(run_ewise(cQ, LR_REDUCE, level + 1, batch, p0, p0_stride, nullptr, 0, p0, p0_stride, nullptr));
+            LR_TRY(run_ewise(cQ, LR_REDUCE, level + 1, batch, p1, p1_stride, nullptr, 0, p1, p1_stride, nullptr));
+            LR_TRY(run_ewise(cP, LR_REDUCE, nP, batch, pl->pool2P.d, sP, nullptr, 0, pl->pool2P.d, sP, nullptr));
+            LR_TRY(run_ewise(cP, LR_REDUCE, nP, batch, pl->pool3P.d, sP, nullptr, 0, pl->pool3P.d, sP, nullptr));
+        }
+        ++reduce;
+    }
+    if (((reduce - 1) & 7) != 1) {  // :1547-1552
+        LR_TRY(run_ewise(cQ, LR_REDUCE, level + 1, batch, p0, p0_stride, nullptr, 0, p0, p0_stride, nullptr));
+        LR_TRY(run_ewise(cQ, LR_REDUCE, level + 1, batch, p1, p1_stride, nullptr, 0, p1, p1_stride, nullptr));
+        LR_TRY(run_ewise(cP, LR_REDUCE, nP, batch, pl->pool2P.d, sP, nullptr, 0, pl->pool2P.d, sP, nullptr));
+        LR_TRY(run_ewise(cP, LR_REDUCE, nP, batch, pl->pool3P.d, sP, nullptr, 0, pl->pool3P.d, sP, nullptr));
+    }
+    // ModDownSplitedNTTPQ x2, :1556-1557
+    lr_bext *bx = pl->bext;
+    for (int k = 0; k < 2; ++k) {
+        u64 *pq = k == 0 ? p0 : p1;
+        const long long pqs = k == 0 ? p0_stride : p1_stride;
+        u64 *pp = k == 0 ? pl->pool2P.d : pl->pool3P.d;
+        Rows pr{pp, sP, 0, 1};
+        LR_TRY(run_ntt(cP, true, pr, pr, 0, 1, nP, batch));
+        LR_TRY(bx->poolQ.ensure(cQ, (size_t)batch * sQ));
+        LR_TRY(run_ext(cQ, bx->pq, nP, pr, batch, segment(bx->poolQ.d, sQ, 0, 0, level + 1), segment(nullptr, 0, 0, 0, 0)));
+        Rows qr{bx->poolQ.d, sQ, 0, 1};
+        LR_TRY(run_ntt(cQ, false, qr, qr, 0, 1, level + 1, batch));
+        LR_TRY(run_submul(cQ, level + 1, batch, pq, pqs, bx->poolQ.d, sQ, (long long)n, pq, pqs, bx->d_moddown_pq, false, nullptr));
+    }
+    return LR_OK;
+}
+
+int check_ct(const lr_ckks_plan *pl, int level, const lr_poly *p, int batch) {
+    if (!p) return fail(LR_ERR_ARG, "null poly");
+    if (p->ctx->h.N != pl->cQ->h.N) return fail(LR_ERR_SHAPE, "ring degree mismatch");
+    if (p->limbs < level + 1) return fail(LR_ERR_SHAPE, "poly has fewer limbs than level+1");
+    if (p->batch != batch) return fail(LR_ERR_SHAPE, "batch mismatch");
+    return LR_OK;
+}
+
+}  // namespace
+
+extern "C" int lr_ckks_switch_keys(lr_ckks_plan *pl, int level, const lr_poly *cx, const lr_poly *evk, lr_poly *p0, lr_poly *p1) {
+    if (!pl || !cx || !evk || !p0 || !p1) return fail(LR_ERR_ARG, "null argument");
+    if (level < 0 || level + 1 > pl->cQ->h.L()) return fail(LR_ERR_SHAPE, "level out of range");
+    const int batch = cx->batch;
+    if (batch > pl->max_batch) return fail(LR_ERR_SHAPE, "batch exceeds the plan's max_batch");
+    LR_TRY(check_ct(pl, level, cx, batch));
+    LR_TRY(check_ct(pl, level, p0, batch));
+    LR_TRY(check_ct(pl, level, p1, batch));
+    LR_HIP(hipSetDevice(pl->cQ->device));
+    return switch_keys_core(pl, level, batch, cx->d, cx->stride(), evk, p0->d, p0->stride(), p1->d, p1->stride());
+}
+
+extern "C" int lr_ckks_mulrelin(lr_ckks_plan *pl, int level, const lr_poly *a0, const lr_poly *a1, const lr_poly *b0,
+                                const lr_poly *b1, const lr_poly *evk, lr_poly *o0, lr_poly *o1) {
+    if (!pl || !a0 || !a1 || !b0 || !b1 || !evk || !o0 || !o1) return fail(LR_ERR_ARG, "null argument");
+    if (level < 0 || level + 1 > pl->cQ->h.L()) return fail(LR_ERR_SHAPE, "level out of range");
+    const int batch = a0->batch;
+    if (batch > pl->max_batch) return fail(LR_ERR_SHAPE, "batch exceeds the plan's max_batch");
+    for (const lr_poly *p : {a0, a1, b0, b1, (const lr_poly *)o0, (const lr_poly *)o1}) LR_TRY(check_ct(pl, level, p, batch));
+    lr_context *cQ = pl->cQ;
+    LR_HIP(hipSetDevice(cQ->device));
+    const int n = (int)cQ->h.N, L1 = level + 1;
+    const long long s = (long long)L1 * n;
+    for (Pool *p : {&pl->c00, &pl->c01, &pl->c0, &pl->c1, &pl->c2x, &pl->q1, &pl->q2}) LR_TRY(p->ensure(cQ, (size_t)batch * s));
+    // ckks/evaluator.go:1080-1095
+    LR_TRY(run_ewise(cQ, LR_MFORM, L1, batch, a0->d, a0->stride(), nullptr, 0, pl->c00.d, s, nullptr));
+    LR_TRY(run_ewise(cQ, LR_MFORM, L1, batch, a1->d, a1->stride(), nullptr, 0, pl->c01.d, s, nullptr));
+    LR_TRY(run_ewise(cQ, LR_MUL_MONT, L1, batch, pl->c00.d, s, b0->d, b0->stride(), pl->c0.d, s, nullptr));
+    LR_TRY(run_ewise(cQ, LR_MUL_MONT, L1, batch, pl->c00.d, s, b1->d, b1->stride(), pl->c1.d, s, nullptr));
+    LR_TRY(run_ewise(cQ, LR_MUL_MONT_AND_ADD, L1, batch, pl->c01.d, s, b0->d, b0->stride(), pl->c1.d, s, nullptr));
+    LR_TRY(run_ewise(cQ, LR_MUL_MONT, L1, batch, pl->c01.d, s, b1->d, b1->stride(), pl->c2x.d, s, nullptr));
+    LR_TRY(switch_keys_core(pl, level, batch, pl->c2x.d, s, evk, pl->q1.d, s, pl->q2.d, s));          // :1101
+    LR_TRY(run_ewise(cQ, LR_ADD, L1, batch, pl->c0.d, s, pl->q1.d, s, o0->d, o0->stride(), nullptr));  // :1103
+    LR_TRY(run_ewise(cQ, LR_ADD, L1, batch, pl->c1.d, s, pl->q2.d, s, o1->d, o1->stride(), nullptr));  // :1104
+    return LR_OK;
+}
+
+extern "C" int lr_ckks_rescale(lr_ckks_plan *pl, lr_poly *c0, lr_poly *c1) {
+    if (!pl || !c0 || !c1) return fail(LR_ERR_ARG, "null argument");
+    LR_TRY(lr_div_round_by_last_modulus_ntt(pl->cQ, c0));  // ckks/evaluator.go:958-960
+    return lr_div_round_by_last_modulus_ntt(pl->cQ, c1);
+}
+
+// ------------------------------------------------------------------------------------------
+// measurement
+// ------------------------------------------------------------------------------------------
+extern "C" int lr_timer_start(lr_context *c) {
+    if (!c) return fail(LR_ERR_ARG, "null context");
+    LR_HIP(hipSetDevice(c->device));
+    LR_HIP(hipEventRecord(c->ev0, c->stream));
+    return LR_OK;
+}
+
+extern "C" int lr_timer_stop(lr_context *c, float *elapsed_ms) {
+    if (!c || !elapsed_ms) return fail(LR_ERR_ARG, "null argument");
+    LR_HIP(hipSetDevice(c->device));
+    LR_HIP(hipEventRecord(c->ev1, c->stream));
+    LR_HIP(hipEventSynchronize(c->ev1));
+    LR_HIP(hipEventElapsedTime(elapsed_ms, c->ev0, c->ev1));
+    return LR_OK;
+}

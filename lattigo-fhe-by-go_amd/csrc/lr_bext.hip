@@ -1,0 +1,73 @@
+// lr_bext.hip -- RNS fast basis extension (HPS, eprint 2018/117) for gfx950.
+//
+// One kernel serves modUpExact (ring/ring_basis_extension.go:352-393) and the three copies of
+// its body inside Decompose / DecomposeAndSplit (:547-594, :663-710): one thread per
+// coefficient column computes y_i = x_i * (Q/q_i)^-1 mod q_i and the float64 correction index
+// v = floor(sum y_i / q_i) ONCE, then walks the output limbs.  The float path is the
+// reference's, operation for operation: uint64->double (round to nearest even), IEEE
+// division, left-to-right accumulation, truncation; this file is compiled
+// with -ffp-contract=off and without fast-math.  All table constants are wave-uniform and
+// come in through scalar loads.
+#include "lr_device.hpp"
+
+namespace lr {
+
+
+
+
+template <int NIN>
+__global__ __launch_bounds__(256) void ext_kernel(ExtLaunch L) {
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    if (x >= L.n) return;
+    const long long b = blockIdx.y;
+    const u64 *in = L.in + b * L.in_stride + (long long)L.in_limb0 * L.n + x;
+    u64 y[NIN];
+    double vi = 0.0;
+#pragma unroll
+    for (int i = 0; i < NIN; ++i) {
+        const u64 qi = L.t.Q[i];
+        y[i] = mred(in[(long long)i * L.n], L.t.qib_mont[i], qi, L.t.mredQ[i]);
+        vi += (double)y[i] / (double)qi;
+    }
+    const u64 v = (u64)vi;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const ExtSegment sg = L.seg[s];
+        u64 *out = sg.out + b * sg.stride + (long long)sg.limb0 * L.n + x;
+        for (int jj = 0; jj < sg.count; ++jj) {
+            const int col = sg.col0 + jj;
+            const u64 pj = L.t.P[col], pinv = L.t.mredP[col], bh = L.t.bredP_hi[col];
+            u64 acc = 0;
+#pragma unroll
+            for (int i = 0; i < NIN; ++i) {
+                acc += mred(y[i], L.t.qispj_mont[(long long)i * L.t.nP + col], pj, pinv);
+                if ((i & 7) == 6) acc = bred_add(acc, pj, bh);
+            }
+            out[(long long)jj * L.n] = bred_add(acc + L.t.qpj_inv[(long long)col * (L.t.nQ + 1) + v], pj, bh);
+        }
+    }
+}
+
+template <int NIN>
+static hipError_t launch_n(const ExtLaunch &L, int batch, hipStream_t stream) {
+    const dim3 grid((unsigned)((L.n + 255) / 256), (unsigned)batch), block(256);
+    hipLaunchKernelGGL(ext_kernel<NIN>, grid, block, 0, stream, L);
+    return hipGetLastError();
+}
+
+hipError_t launch_ext(const ExtLaunch &L, int n_in, int batch, hipStream_t stream) {
+    if (batch <= 0) return hipSuccess;
+    switch (n_in) {
+#define LR_EXT(K) \
+    case K: return launch_n<K>(L, batch, stream);
+        LR_EXT(1) LR_EXT(2) LR_EXT(3) LR_EXT(4) LR_EXT(5) LR_EXT(6) LR_EXT(7) LR_EXT(8)
+        LR_EXT(9) LR_EXT(10) LR_EXT(11) LR_EXT(12) LR_EXT(13) LR_EXT(14) LR_EXT(15) LR_EXT(16)
+        LR_EXT(17) LR_EXT(18) LR_EXT(19) LR_EXT(20) LR_EXT(21) LR_EXT(22) LR_EXT(23) LR_EXT(24)
+        LR_EXT(25) LR_EXT(26) LR_EXT(27) LR_EXT(28) LR_EXT(29) LR_EXT(30) LR_EXT(31) LR_EXT(32)
+        LR_EXT(33) LR_EXT(34) LR_EXT(35) LR_EXT(36) LR_EXT(37) LR_EXT(38) LR_EXT(39) LR_EXT(40)
+#undef LR_EXT
+    default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace lr

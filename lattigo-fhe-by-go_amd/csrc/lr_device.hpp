@@ -1,0 +1,114 @@
+// lr_device.hpp -- device-side parameter blocks and launch plumbing shared by the kernel files.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "lr_arith.hpp"
+
+namespace lr {
+
+// per-modulus constants, one entry per limb of a context (device array)
+struct LimbParams {
+    u64 q;
+    u64 qinv;        // q^-1 mod 2^64              (mredParams)
+    u64 bred_hi;     // floor(2^128/q) >> 64       (bredParams[0])
+    u64 bred_lo;     //                            (bredParams[1])
+    u64 n_inv_mont;  // Go's nttNInv (Montgomery form of N^-1)
+    u64 n_inv;       // N^-1 mod q, plain
+    u64 n_inv_shoup; // floor(n_inv * 2^64 / q)
+    u64 pad;
+};
+
+constexpr int kMaxLimbs = 64;
+// small per-limb host values travelling in the kernel-argument segment (no host->device copy)
+struct LimbScalars { u64 v[kMaxLimbs]; };
+
+// a twiddle factor in the kernels' internal form: x = psi power (plain domain), y = floor(x*2^64/q)
+typedef ulonglong2 Twiddle;
+
+// Addressing of one NTT launch.  Work item (b, i): batch element b, i-th limb of the launch.
+struct NttLaunch {
+    const u64 *in;
+    u64 *out;
+    long long in_poly_stride;   // u64 elements between consecutive batch polys
+    long long out_poly_stride;
+    int in_limb0, in_limb_step;   // input row  = in_limb0  + i * in_limb_step
+    int out_limb0, out_limb_step; // output row = out_limb0 + i * out_limb_step
+    int mod0, mod_step;           // modulus    = mod0      + i * mod_step
+    int n_items;                  // limbs per poly in this launch
+    int batch;
+    const LimbParams *lp;       // [L]
+    const Twiddle *tw;          // [L][N] forward or inverse table
+};
+
+// ---- coefficient-wise launches (lr_ewise.hip) ----
+struct EwiseLaunch {
+    const u64 *a;
+    const u64 *b;
+    u64 *out;
+    long long a_stride, b_stride, out_stride;  // u64 elements between batch polys (0 = broadcast)
+    int n;                                      // ring degree
+    const LimbParams *lp;
+    int has_scalars;
+    LimbScalars scalars;                        // per limb, pre-processed per op on the host
+};
+
+// out = MRed(a + (q - b), consts[limb])
+struct SubMulLaunch {
+    const u64 *a;
+    const u64 *b;
+    u64 *out;
+    long long a_stride, b_stride, out_stride;
+    long long b_row_stride;  // n, or 0 when every limb subtracts the same row (the last limb, ring_scaling.go:41)
+    int n;
+    const LimbParams *lp;
+    const u64 *consts;  // device [limbs], Montgomery form
+    int reduce_b;       // 1: b is first reduced with BRedAdd (coefficient-domain rescale, ring_scaling.go:50,146)
+    LimbScalars addend; // b + addend[limb] before the reduction (pHalfNegQi); zeros when unused
+};
+
+// out_row[r] = in + adds[r] (optionally CRed)
+struct RowAddLaunch {
+    const u64 *in;   // one row per batch poly
+    u64 *out;
+    long long in_stride, out_stride;
+    int n;
+    u64 q;           // 0: no reduction
+    LimbScalars adds; // per output row
+};
+
+// ---- basis extension (lr_bext.hip) ----
+struct ExtTables {        // device pointers; modupParams of ring_basis_extension.go:19-37
+    int nQ, nP;
+    const u64 *Q;         // [nQ]
+    const u64 *mredQ;     // [nQ]
+    const u64 *qib_mont;  // [nQ]
+    const u64 *P;         // [nP]
+    const u64 *mredP;     // [nP]
+    const u64 *bredP_hi;  // [nP]
+    const u64 *qispj_mont;// [nQ][nP]
+    const u64 *qpj_inv;   // [nP][nQ+1]
+};
+
+struct ExtSegment {       // rows [limb0, limb0+count) of `out` receive table columns [col0, col0+count)
+    u64 *out;
+    long long stride;     // u64 elements between batch polys
+    int limb0, col0, count;
+};
+
+struct ExtLaunch {
+    ExtTables t;
+    const u64 *in;
+    long long in_stride;
+    int in_limb0;
+    int n;
+    ExtSegment seg[2];
+};
+
+// host launchers (defined next to their kernels)
+hipError_t launch_ntt(const NttLaunch &a, int logn, bool inverse, hipStream_t stream);
+hipError_t launch_ewise(int op, const EwiseLaunch &L, int limbs, int batch, hipStream_t stream);
+hipError_t launch_submul(const SubMulLaunch &L, int limbs, int batch, hipStream_t stream);
+hipError_t launch_rowadd(const RowAddLaunch &L, int rows, int batch, hipStream_t stream);
+hipError_t launch_ext(const ExtLaunch &L, int n_in, int batch, hipStream_t stream);
+
+}  // namespace lr

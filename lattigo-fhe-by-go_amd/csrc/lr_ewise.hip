@@ -1,0 +1,183 @@
+// lr_ewise.hip -- the coefficient-wise family of ring/ring.go as one templated streaming kernel.
+//
+// HBM-bound (16-24 B per coefficient): 16 B per lane per access, limb index on blockIdx.y so the
+// per-modulus constants are wave-uniform (SGPRs), batch on blockIdx.z.  An operand whose batch
+// is 1 is broadcast (poly stride 0).
+#include "lattigo_ring.h"
+#include "lr_device.hpp"
+
+namespace lr {
+
+
+template <int OP>
+LR_D u64 apply(u64 x, u64 y, u64 z, const LimbParams &lp, u64 s) {
+    const u64 q = lp.q;
+    if constexpr (OP == LR_ADD) return cred(x + y, q);
+    if constexpr (OP == LR_ADD_NOMOD) return x + y;
+    if constexpr (OP == LR_SUB) return cred((x + q) - y, q);
+    if constexpr (OP == LR_SUB_NOMOD) return (x + q) - y;
+    if constexpr (OP == LR_NEG) return q - x;
+    if constexpr (OP == LR_REDUCE) return bred_add(x, q, lp.bred_hi);
+    if constexpr (OP == LR_MUL_COEFFS) return bred(x, y, q, lp.bred_hi, lp.bred_lo);
+    if constexpr (OP == LR_MUL_COEFFS_AND_ADD) return cred(z + bred(x, y, q, lp.bred_hi, lp.bred_lo), q);
+    if constexpr (OP == LR_MUL_COEFFS_AND_ADD_NOMOD) return z + bred(x, y, q, lp.bred_hi, lp.bred_lo);
+    if constexpr (OP == LR_MUL_COEFFS_CONSTANT) return bred_constant(x, y, q, lp.bred_hi, lp.bred_lo);
+    if constexpr (OP == LR_MUL_MONT) return mred(x, y, q, lp.qinv);
+    if constexpr (OP == LR_MUL_MONT_AND_ADD) return cred(z + mred(x, y, q, lp.qinv), q);
+    if constexpr (OP == LR_MUL_MONT_AND_ADD_NOMOD) return z + mred(x, y, q, lp.qinv);
+    if constexpr (OP == LR_MUL_MONT_CONSTANT_AND_ADD_NOMOD) return z + mred_constant(x, y, q, lp.qinv);
+    if constexpr (OP == LR_MUL_MONT_AND_SUB) return cred(z + (q - mred(x, y, q, lp.qinv)), q);
+    if constexpr (OP == LR_MUL_MONT_AND_SUB_NOMOD) return z + (q - mred(x, y, q, lp.qinv));
+    if constexpr (OP == LR_MUL_MONT_CONSTANT) return mred_constant(x, y, q, lp.qinv);
+    if constexpr (OP == LR_MFORM) return mform(x, q, lp.bred_hi, lp.bred_lo);
+    if constexpr (OP == LR_INV_MFORM) return inv_mform(x, q, lp.qinv);
+    if constexpr (OP == LR_MUL_SCALAR || OP == LR_MUL_SCALAR_LIMBS) return mred(x, s, q, lp.qinv);
+    if constexpr (OP == LR_ADD_SCALAR_LIMBS) return cred(x + s, q);
+    if constexpr (OP == LR_SUB_SCALAR_LIMBS) return cred(x + (q - s), q);
+    if constexpr (OP == LR_COPY) return x;
+    if constexpr (OP == LR_MUL_BY_POW2) return power_of_2(x, s, q, lp.qinv);
+    return 0;
+}
+
+constexpr bool reads_b(int op) {
+    return op == LR_ADD || op == LR_ADD_NOMOD || op == LR_SUB || op == LR_SUB_NOMOD ||
+           (op >= LR_MUL_COEFFS && op <= LR_MUL_MONT_CONSTANT);
+}
+constexpr bool reads_out(int op) {
+    return op == LR_MUL_COEFFS_AND_ADD || op == LR_MUL_COEFFS_AND_ADD_NOMOD || op == LR_MUL_MONT_AND_ADD ||
+           op == LR_MUL_MONT_AND_ADD_NOMOD || op == LR_MUL_MONT_CONSTANT_AND_ADD_NOMOD ||
+           op == LR_MUL_MONT_AND_SUB || op == LR_MUL_MONT_AND_SUB_NOMOD;
+}
+
+// grid: x = coefficient pairs / 256, y = limb, z = batch
+template <int OP>
+__global__ __launch_bounds__(256) void ewise_kernel(EwiseLaunch L) {
+    const int limb = blockIdx.y;
+    const long long b = blockIdx.z;
+    const LimbParams lp = L.lp[limb];
+    const u64 s = L.has_scalars ? L.scalars.v[limb] : 0;
+    const long long row = (long long)limb * L.n;
+    const ulonglong2 *pa = reinterpret_cast<const ulonglong2 *>(L.a + b * L.a_stride + row);
+    const ulonglong2 *pb = reads_b(OP) ? reinterpret_cast<const ulonglong2 *>(L.b + b * L.b_stride + row) : nullptr;
+    ulonglong2 *po = reinterpret_cast<ulonglong2 *>(L.out + b * L.out_stride + row);
+    const int pairs = L.n >> 1;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < pairs; e += gridDim.x * 256) {
+        const ulonglong2 x = pa[e];
+        ulonglong2 y = make_ulonglong2(0, 0), z = make_ulonglong2(0, 0);
+        if constexpr (reads_b(OP)) y = pb[e];
+        if constexpr (reads_out(OP)) z = po[e];
+        po[e] = make_ulonglong2(apply<OP>(x.x, y.x, z.x, lp, s), apply<OP>(x.y, y.y, z.y, lp, s));
+    }
+}
+
+// odd degree fallback is impossible (N is a power of two >= 2)
+
+template <int OP>
+static hipError_t launch_one(const EwiseLaunch &L, int limbs, int batch, hipStream_t stream) {
+    const int pairs = L.n >> 1;
+    int gx = (pairs + 255) / 256;
+    if (gx > 64) gx = 64;
+    if (gx < 1) gx = 1;
+    const dim3 grid((unsigned)gx, (unsigned)limbs, (unsigned)batch), block(256);
+    hipLaunchKernelGGL(ewise_kernel<OP>, grid, block, 0, stream, L);
+    return hipGetLastError();
+}
+
+hipError_t launch_ewise(int op, const EwiseLaunch &L, int limbs, int batch, hipStream_t stream) {
+    if (limbs <= 0 || batch <= 0) return hipSuccess;
+    switch (op) {
+#define LR_CASE(OPNAME) \
+    case OPNAME: return launch_one<OPNAME>(L, limbs, batch, stream);
+        LR_CASE(LR_ADD)
+        LR_CASE(LR_ADD_NOMOD)
+        LR_CASE(LR_SUB)
+        LR_CASE(LR_SUB_NOMOD)
+        LR_CASE(LR_NEG)
+        LR_CASE(LR_REDUCE)
+        LR_CASE(LR_MUL_COEFFS)
+        LR_CASE(LR_MUL_COEFFS_AND_ADD)
+        LR_CASE(LR_MUL_COEFFS_AND_ADD_NOMOD)
+        LR_CASE(LR_MUL_COEFFS_CONSTANT)
+        LR_CASE(LR_MUL_MONT)
+        LR_CASE(LR_MUL_MONT_AND_ADD)
+        LR_CASE(LR_MUL_MONT_AND_ADD_NOMOD)
+        LR_CASE(LR_MUL_MONT_CONSTANT_AND_ADD_NOMOD)
+        LR_CASE(LR_MUL_MONT_AND_SUB)
+        LR_CASE(LR_MUL_MONT_AND_SUB_NOMOD)
+        LR_CASE(LR_MUL_MONT_CONSTANT)
+        LR_CASE(LR_MFORM)
+        LR_CASE(LR_INV_MFORM)
+        LR_CASE(LR_MUL_SCALAR)
+        LR_CASE(LR_MUL_SCALAR_LIMBS)
+        LR_CASE(LR_ADD_SCALAR_LIMBS)
+        LR_CASE(LR_SUB_SCALAR_LIMBS)
+        LR_CASE(LR_COPY)
+        LR_CASE(LR_MUL_BY_POW2)
+#undef LR_CASE
+    default: return hipErrorInvalidValue;
+    }
+}
+
+// ---- fused tails used by ModDown / rescale: out = MRed(a + (q - b), c[limb]) --------------
+// ring/ring_basis_extension.go:196-199,237-239,270-272 and ring/ring_scaling.go:28-30,108-110
+
+__global__ __launch_bounds__(256) void submul_kernel(SubMulLaunch L) {
+    const int limb = blockIdx.y;
+    const long long b = blockIdx.z;
+    const LimbParams lp = L.lp[limb];
+    const u64 c = L.consts[limb];
+    const u64 add = L.addend.v[limb];
+    const long long row = (long long)limb * L.n;
+    const ulonglong2 *pa = reinterpret_cast<const ulonglong2 *>(L.a + b * L.a_stride + row);
+    const ulonglong2 *pb = reinterpret_cast<const ulonglong2 *>(L.b + b * L.b_stride + (long long)limb * L.b_row_stride);
+    ulonglong2 *po = reinterpret_cast<ulonglong2 *>(L.out + b * L.out_stride + row);
+    const int pairs = L.n >> 1;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < pairs; e += gridDim.x * 256) {
+        const ulonglong2 x = pa[e];
+        ulonglong2 y = pb[e];
+        if (L.reduce_b) {
+            y.x = bred_add(y.x + add, lp.q, lp.bred_hi);
+            y.y = bred_add(y.y + add, lp.q, lp.bred_hi);
+        }
+        po[e] = make_ulonglong2(mred(x.x + (lp.q - y.x), c, lp.q, lp.qinv), mred(x.y + (lp.q - y.y), c, lp.q, lp.qinv));
+    }
+}
+
+hipError_t launch_submul(const SubMulLaunch &L, int limbs, int batch, hipStream_t stream) {
+    if (limbs <= 0 || batch <= 0) return hipSuccess;
+    const int pairs = L.n >> 1;
+    int gx = (pairs + 255) / 256;
+    if (gx > 64) gx = 64;
+    if (gx < 1) gx = 1;
+    const dim3 grid((unsigned)gx, (unsigned)limbs, (unsigned)batch), block(256);
+    hipLaunchKernelGGL(submul_kernel, grid, block, 0, stream, L);
+    return hipGetLastError();
+}
+
+// ---- single-limb helpers for rescale ---------------------------------------------------------
+// out[j] = CRed(in[j] + add, q) on one row (ring_scaling.go:87-89,127-129), or
+// out_row_i[j] = in[j] + add_i (no reduction; ring_scaling.go:101-103) for i < limbs
+
+__global__ __launch_bounds__(256) void rowadd_kernel(RowAddLaunch L) {
+    const int row = blockIdx.y;
+    const long long b = blockIdx.z;
+    const u64 add = L.adds.v[row];
+    const u64 *pi = L.in + b * L.in_stride;
+    u64 *po = L.out + b * L.out_stride + (long long)row * L.n;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < L.n; e += gridDim.x * 256) {
+        u64 v = pi[e] + add;
+        if (L.q) v = cred(v, L.q);
+        po[e] = v;
+    }
+}
+
+hipError_t launch_rowadd(const RowAddLaunch &L, int rows, int batch, hipStream_t stream) {
+    if (rows <= 0 || batch <= 0) return hipSuccess;
+    int gx = (L.n + 255) / 256;
+    if (gx > 64) gx = 64;
+    const dim3 grid((unsigned)gx, (unsigned)rows, (unsigned)batch), block(256);
+    hipLaunchKernelGGL(rowadd_kernel, grid, block, 0, stream, L);
+    return hipGetLastError();
+}
+
+}  // namespace lr

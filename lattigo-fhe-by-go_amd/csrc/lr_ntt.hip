@@ -1,0 +1,364 @@
+// lr_ntt.hip -- negacyclic NTT / InvNTT kernels for gfx950 (MI355X).
+//
+// Replaces the per-limb loops of ring/ntt.go:4-29 (Context.NTT/NTTLvl/InvNTT/InvNTTLvl) and
+// the cores NTT (:53) / InvNTT (:89).  Same transform, same psi tables, canonical outputs, so
+// results are bit-identical; the internal butterfly is our own (Shoup/Harvey lazy form,
+// lr_arith.hpp) because only the canonical output is observable.
+//
+// Design (one workgroup = one limb of one polynomial, HBM traffic = 16*N bytes per limb):
+//   index bit p of a coefficient is consumed by stage logN-1-p (forward: high bits first).
+//   pass A   : each thread owns the 2^A coefficients {k*S + t} (S = N / 2^A = blockDim), loads
+//              them coalesced straight from HBM and runs the top A stages in registers with
+//              wave-uniform twiddles (scalar loads).
+//   LDS pass : the remaining bits are consumed 3-4 at a time; the limb (or, for N = 2^15, one
+//              half of it while the other half stays parked in registers) lives in LDS,
+//              padded by 16 B per 16 coefficients so that every pass is bank-conflict free.
+//   copy-out : canonical reduction fused with a coalesced 16 B/lane store.
+// The inverse transform is the mirror image (copy-in, LDS passes low bits first, pass A last,
+// scaling by N^-1 fused into the final store).
+#include "lr_device.hpp"
+
+namespace lr {
+
+// ------------------------------------------------------------------------------------------
+// butterflies.  Forward keeps values in [0, 8q), inverse in [0, 4q); q < 2^61 so 8q < 2^64.
+// ------------------------------------------------------------------------------------------
+LR_D void fwd_bfly(u64 &U, u64 &V, u64 w, u64 ws, u64 q, u64 q4) {
+    const u64 u = U >= q4 ? U - q4 : U;            // [0,4q)
+    const u64 v = mul_shoup_lazy(V, w, ws, q);     // [0,4q) for any 64-bit V
+    U = u + v;                                     // [0,8q)
+    V = u + q4 - v;                                // (0,8q)
+}
+
+LR_D void inv_bfly(u64 &U, u64 &V, u64 w, u64 ws, u64 q, u64 q4) {
+    const u64 s = U + V;                           // [0,8q)
+    const u64 t = U + q4 - V;                      // (0,8q)
+    U = s >= q4 ? s - q4 : s;                      // [0,4q)
+    V = mul_shoup_lazy(t, w, ws, q);               // [0,4q)
+}
+
+LR_D u64 canon_from_8q(u64 x, u64 q) {
+    const u64 q4 = q << 2, q2 = q << 1;
+    x = x >= q4 ? x - q4 : x;
+    x = x >= q2 ? x - q2 : x;
+    return x >= q ? x - q : x;
+}
+LR_D u64 canon_from_4q(u64 x, u64 q) {
+    const u64 q2 = q << 1;
+    x = x >= q2 ? x - q2 : x;
+    return x >= q ? x - q : x;
+}
+
+// R stages over the R index bits [plo, plo+R) held in registers: x[k] has bit pattern k there.
+// H = 2^(logN - plo - R) + (index bits above plo+R): the heap position of the block's twiddle;
+// the stage over bit plo+b uses twiddles (H << (R-1-b)) + j, j = k >> (b+1).
+template <int R>
+LR_D void fwd_stages(u64 (&x)[1 << R], const Twiddle *__restrict__ tw, u32 H, u64 q, u64 q4) {
+#pragma unroll
+    for (int b = R - 1; b >= 0; --b) {
+        const int c = R - 1 - b;
+#pragma unroll
+        for (int j = 0; j < (1 << c); ++j) {
+            const Twiddle w = tw[(H << c) + j];
+#pragma unroll
+            for (int i = 0; i < (1 << b); ++i) {
+                const int k0 = (j << (b + 1)) | i;
+                fwd_bfly(x[k0], x[k0 | (1 << b)], w.x, w.y, q, q4);
+            }
+        }
+    }
+}
+
+template <int R>
+LR_D void inv_stages(u64 (&x)[1 << R], const Twiddle *__restrict__ tw, u32 H, u64 q, u64 q4) {
+#pragma unroll
+    for (int b = 0; b < R; ++b) {
+        const int c = R - 1 - b;
+#pragma unroll
+        for (int j = 0; j < (1 << c); ++j) {
+            const Twiddle w = tw[(H << c) + j];
+#pragma unroll
+            for (int i = 0; i < (1 << b); ++i) {
+                const int k0 = (j << (b + 1)) | i;
+                inv_bfly(x[k0], x[k0 | (1 << b)], w.x, w.y, q, q4);
+            }
+        }
+    }
+}
+
+// LDS image: 16 B of padding after every 16 coefficients (144-B rows)
+LR_D int lds_slot(int i) { return i + ((i >> 4) << 1); }
+constexpr int lds_words(int m) { return m + ((m >> 4) << 1); }
+
+// per-size plan: LOGT = log2(blockDim), A = bits consumed by pass A, HALVES = LDS residency
+// rounds, then the LDS passes (forward order, high bits first) consuming the remaining bits.
+template <int LOGN> struct Plan;
+template <> struct Plan<15> { static constexpr int LOGT = 10, A = 5, HALVES = 2, P0 = 3, P1 = 3, P2 = 4; };
+template <> struct Plan<14> { static constexpr int LOGT = 10, A = 4, HALVES = 1, P0 = 3, P1 = 3, P2 = 4; };
+template <> struct Plan<13> { static constexpr int LOGT = 9,  A = 4, HALVES = 1, P0 = 3, P1 = 2, P2 = 4; };
+template <> struct Plan<12> { static constexpr int LOGT = 8,  A = 4, HALVES = 1, P0 = 0, P1 = 4, P2 = 4; };
+
+// one forward LDS pass over bits [PLO, PLO+R) of the M resident coefficients
+template <int LOGN, int M, int T, int R, int PLO>
+LR_D void fwd_lds_pass(u64 *lds, const Twiddle *__restrict__ tw, int res_base, int t, u64 q, u64 q4) {
+    if constexpr (R > 0) {
+        constexpr int NT = M >> R;
+#pragma unroll
+        for (int u = t; u < NT; u += T) {
+            const int u_lo = u & ((1 << PLO) - 1), u_hi = u >> PLO;
+            const int base = (u_hi << (PLO + R)) | u_lo;
+            u32 H = (1u << (LOGN - PLO - R)) + (u32)(res_base >> (PLO + R)) + (u32)u_hi;
+            if constexpr (PLO >= 6) H = __builtin_amdgcn_readfirstlane(H);  // wave-uniform: scalar twiddle loads
+            u64 y[1 << R];
+            if constexpr (PLO == 0) {
+                const ulonglong2 *p = reinterpret_cast<const ulonglong2 *>(lds + lds_slot(base));
+#pragma unroll
+                for (int k = 0; k < (1 << R); k += 2) {
+                    const ulonglong2 v = p[(k >> 1) + (k >> 4)];
+                    y[k] = v.x;
+                    y[k + 1] = v.y;
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < (1 << R); ++k) y[k] = lds[lds_slot(base + (k << PLO))];
+            }
+            fwd_stages<R>(y, tw, H, q, q4);
+            if constexpr (PLO == 0) {
+                ulonglong2 *p = reinterpret_cast<ulonglong2 *>(lds + lds_slot(base));
+#pragma unroll
+                for (int k = 0; k < (1 << R); k += 2) p[(k >> 1) + (k >> 4)] = make_ulonglong2(y[k], y[k + 1]);
+            } else {
+#pragma unroll
+                for (int k = 0; k < (1 << R); ++k) lds[lds_slot(base + (k << PLO))] = y[k];
+            }
+        }
+        __syncthreads();
+    }
+}
+
+template <int LOGN, int M, int T, int R, int PLO>
+LR_D void inv_lds_pass(u64 *lds, const Twiddle *__restrict__ tw, int res_base, int t, u64 q, u64 q4) {
+    if constexpr (R > 0) {
+        constexpr int NT = M >> R;
+#pragma unroll
+        for (int u = t; u < NT; u += T) {
+            const int u_lo = u & ((1 << PLO) - 1), u_hi = u >> PLO;
+            const int base = (u_hi << (PLO + R)) | u_lo;
+            u32 H = (1u << (LOGN - PLO - R)) + (u32)(res_base >> (PLO + R)) + (u32)u_hi;
+            if constexpr (PLO >= 6) H = __builtin_amdgcn_readfirstlane(H);
+            u64 y[1 << R];
+            if constexpr (PLO == 0) {
+                const ulonglong2 *p = reinterpret_cast<const ulonglong2 *>(lds + lds_slot(base));
+#pragma unroll
+                for (int k = 0; k < (1 << R); k += 2) {
+                    const ulonglong2 v = p[(k >> 1) + (k >> 4)];
+                    y[k] = v.x;
+                    y[k + 1] = v.y;
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < (1 << R); ++k) y[k] = lds[lds_slot(base + (k << PLO))];
+            }
+            inv_stages<R>(y, tw, H, q, q4);
+            if constexpr (PLO == 0) {
+                ulonglong2 *p = reinterpret_cast<ulonglong2 *>(lds + lds_slot(base));
+#pragma unroll
+                for (int k = 0; k < (1 << R); k += 2) p[(k >> 1) + (k >> 4)] = make_ulonglong2(y[k], y[k + 1]);
+            } else {
+#pragma unroll
+                for (int k = 0; k < (1 << R); ++k) lds[lds_slot(base + (k << PLO))] = y[k];
+            }
+        }
+        __syncthreads();
+    }
+}
+
+struct Item {
+    const u64 *src;
+    u64 *dst;
+    const Twiddle *tw;
+    LimbParams lp;
+};
+
+LR_D Item locate(const NttLaunch &a, int n) {
+    const int item = blockIdx.x % a.n_items, b = blockIdx.x / a.n_items;
+    const int mod = a.mod0 + item * a.mod_step;
+    Item it;
+    it.src = a.in + (long long)b * a.in_poly_stride + (long long)(a.in_limb0 + item * a.in_limb_step) * n;
+    it.dst = a.out + (long long)b * a.out_poly_stride + (long long)(a.out_limb0 + item * a.out_limb_step) * n;
+    it.tw = a.tw + (long long)mod * n;
+    it.lp = a.lp[mod];
+    return it;
+}
+
+// ------------------------------------------------------------------------------------------
+// forward, 2^12 <= N <= 2^15
+// ------------------------------------------------------------------------------------------
+template <int LOGN>
+__global__ __launch_bounds__(1 << Plan<LOGN>::LOGT) void ntt_fwd_kernel(NttLaunch a) {
+    using P = Plan<LOGN>;
+    constexpr int N = 1 << LOGN, T = 1 << P::LOGT, A = P::A, RA = 1 << A, S = N >> A;
+    constexpr int HALVES = P::HALVES, M = N / HALVES, RH = RA / HALVES;
+    static_assert(S == T, "one column per thread");
+    static_assert(A + P::P0 + P::P1 + P::P2 == LOGN, "bit budget");
+    extern __shared__ __align__(16) u64 lds[];
+
+    const Item it = locate(a, N);
+    const u64 q = it.lp.q, q4 = q << 2;
+    const int t = threadIdx.x;
+
+    u64 x[RA];
+#pragma unroll
+    for (int k = 0; k < RA; ++k) x[k] = it.src[k * S + t];
+    // The first stage needs U < 8q; V may be any 64-bit value.  The reference accepts inputs
+    // >= q (ring/ring_scaling.go:19,102), so the U operands are reduced exactly.
+#pragma unroll
+    for (int k = 0; k < RA / 2; ++k) x[k] = bred_add(x[k], q, it.lp.bred_hi);
+    fwd_stages<A>(x, it.tw, 1u, q, q4);
+
+#pragma unroll
+    for (int half = 0; half < HALVES; ++half) {
+#pragma unroll
+        for (int kk = 0; kk < RH; ++kk) lds[lds_slot(kk * S + t)] = x[half * RH + kk];
+        __syncthreads();
+        const int res_base = half * M;
+        fwd_lds_pass<LOGN, M, T, P::P0, P::P1 + P::P2>(lds, it.tw, res_base, t, q, q4);
+        fwd_lds_pass<LOGN, M, T, P::P1, P::P2>(lds, it.tw, res_base, t, q, q4);
+        fwd_lds_pass<LOGN, M, T, P::P2, 0>(lds, it.tw, res_base, t, q, q4);
+        // copy-out: canonical reduction + coalesced 16-B stores
+        ulonglong2 *dst2 = reinterpret_cast<ulonglong2 *>(it.dst + res_base);
+#pragma unroll
+        for (int e = t; e < M / 2; e += T) {
+            const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(lds + lds_slot(2 * e));
+            dst2[e] = make_ulonglong2(canon_from_8q(v.x, q), canon_from_8q(v.y, q));
+        }
+        if (half + 1 < HALVES) __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// inverse, 2^12 <= N <= 2^15.  Inputs must be < 4q (the reference's own InvButterfly,
+// ring/ntt.go:43-50, is only congruence-preserving for inputs <= 2q: U+2Q-V must not wrap).
+// ------------------------------------------------------------------------------------------
+template <int LOGN>
+__global__ __launch_bounds__(1 << Plan<LOGN>::LOGT) void ntt_inv_kernel(NttLaunch a) {
+    using P = Plan<LOGN>;
+    constexpr int N = 1 << LOGN, T = 1 << P::LOGT, A = P::A, RA = 1 << A, S = N >> A;
+    constexpr int HALVES = P::HALVES, M = N / HALVES, RH = RA / HALVES;
+    extern __shared__ __align__(16) u64 lds[];
+
+    const Item it = locate(a, N);
+    const u64 q = it.lp.q, q4 = q << 2;
+    const int t = threadIdx.x;
+
+    u64 x[RA];
+#pragma unroll
+    for (int half = 0; half < HALVES; ++half) {
+        const int res_base = half * M;
+        const ulonglong2 *src2 = reinterpret_cast<const ulonglong2 *>(it.src + res_base);
+#pragma unroll
+        for (int e = t; e < M / 2; e += T)
+            *reinterpret_cast<ulonglong2 *>(lds + lds_slot(2 * e)) = src2[e];
+        __syncthreads();
+        inv_lds_pass<LOGN, M, T, P::P2, 0>(lds, it.tw, res_base, t, q, q4);
+        inv_lds_pass<LOGN, M, T, P::P1, P::P2>(lds, it.tw, res_base, t, q, q4);
+        inv_lds_pass<LOGN, M, T, P::P0, P::P1 + P::P2>(lds, it.tw, res_base, t, q, q4);
+#pragma unroll
+        for (int kk = 0; kk < RH; ++kk) x[half * RH + kk] = lds[lds_slot(kk * S + t)];
+        if (half + 1 < HALVES) __syncthreads();
+    }
+    inv_stages<A>(x, it.tw, 1u, q, q4);
+    // MRed(x, nttNInv) of ring/ntt.go:136-138 == x * N^-1 mod q, canonical
+#pragma unroll
+    for (int k = 0; k < RA; ++k)
+        it.dst[k * S + t] = canon_from_4q(mul_shoup_lazy(x[k], it.lp.n_inv, it.lp.n_inv_shoup, q), q);
+}
+
+// ------------------------------------------------------------------------------------------
+// small degrees (2 <= N <= 2^11): whole limb in LDS, one radix-2 stage per barrier.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ntt_small_kernel(NttLaunch a, int logn, int inverse) {
+    extern __shared__ __align__(16) u64 lds[];
+    const int n = 1 << logn;
+    const Item it = locate(a, n);
+    const u64 q = it.lp.q, q4 = q << 2;
+    const int t = threadIdx.x;
+    if (!inverse) {
+        for (int e = t; e < n; e += 256) lds[e] = bred_add(it.src[e], q, it.lp.bred_hi);
+        __syncthreads();
+        for (int p = logn - 1; p >= 0; --p) {
+            for (int bf = t; bf < n / 2; bf += 256) {
+                const int i = bf >> p, jj = bf & ((1 << p) - 1);
+                const int j = (i << (p + 1)) | jj;
+                const Twiddle w = it.tw[(1 << (logn - 1 - p)) + i];
+                u64 U = lds[j], V = lds[j + (1 << p)];
+                fwd_bfly(U, V, w.x, w.y, q, q4);
+                lds[j] = U;
+                lds[j + (1 << p)] = V;
+            }
+            __syncthreads();
+        }
+        for (int e = t; e < n; e += 256) it.dst[e] = canon_from_8q(lds[e], q);
+    } else {
+        for (int e = t; e < n; e += 256) lds[e] = it.src[e];
+        __syncthreads();
+        for (int p = 0; p < logn; ++p) {
+            for (int bf = t; bf < n / 2; bf += 256) {
+                const int i = bf >> p, jj = bf & ((1 << p) - 1);
+                const int j = (i << (p + 1)) | jj;
+                const Twiddle w = it.tw[(1 << (logn - 1 - p)) + i];
+                u64 U = lds[j], V = lds[j + (1 << p)];
+                inv_bfly(U, V, w.x, w.y, q, q4);
+                lds[j] = U;
+                lds[j + (1 << p)] = V;
+            }
+            __syncthreads();
+        }
+        for (int e = t; e < n; e += 256)
+            it.dst[e] = canon_from_4q(mul_shoup_lazy(lds[e], it.lp.n_inv, it.lp.n_inv_shoup, q), q);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// host launchers
+// ------------------------------------------------------------------------------------------
+template <int LOGN>
+static hipError_t launch_big(const NttLaunch &a, bool inverse, hipStream_t stream) {
+    using P = Plan<LOGN>;
+    constexpr int M = (1 << LOGN) / P::HALVES;
+    constexpr size_t lds_bytes = (size_t)lds_words(M) * sizeof(u64);
+    static bool configured[2] = {false, false};
+    auto fwd = ntt_fwd_kernel<LOGN>;
+    auto inv = ntt_inv_kernel<LOGN>;
+    const void *fn = inverse ? (const void *)inv : (const void *)fwd;
+    if (!configured[inverse ? 1 : 0]) {
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) return e;
+        configured[inverse ? 1 : 0] = true;
+    }
+    const dim3 grid((unsigned)(a.n_items * a.batch)), block(1u << P::LOGT);
+    if (inverse)
+        hipLaunchKernelGGL(inv, grid, block, lds_bytes, stream, a);
+    else
+        hipLaunchKernelGGL(fwd, grid, block, lds_bytes, stream, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_ntt(const NttLaunch &a, int logn, bool inverse, hipStream_t stream) {
+    if (a.n_items <= 0 || a.batch <= 0) return hipSuccess;
+    switch (logn) {
+    case 15: return launch_big<15>(a, inverse, stream);
+    case 14: return launch_big<14>(a, inverse, stream);
+    case 13: return launch_big<13>(a, inverse, stream);
+    case 12: return launch_big<12>(a, inverse, stream);
+    default: break;
+    }
+    if (logn >= 1 && logn <= 11) {
+        const dim3 grid((unsigned)(a.n_items * a.batch)), block(256);
+        hipLaunchKernelGGL(ntt_small_kernel, grid, block, sizeof(u64) << logn, stream, a, logn, inverse ? 1 : 0);
+        return hipGetLastError();
+    }
+    return hipErrorInvalidValue;
+}
+
+}  // namespace lr

@@ -1,0 +1,422 @@
+"""Host-side mirror of Lattigo's ``ring`` package over the C ABI (include/lattigo_ring.h).
+
+Same exported names, argument order and meaning as the reference (github.com/ldsec/lattigo/ring,
+v1.3.1) so that code and tests written against ``ring.Context`` read the same:
+
+    ctx = ring.NewContextWithParams(N, moduli)      # ring/ring_context.go:60
+    p = ctx.NewPoly()                               # ring/ring_context.go:288
+    ctx.NTT(p, p)                                   # ring/ntt.go:4
+    ctx.MulCoeffsMontgomery(a, b, c)                # ring/ring.go:221
+
+Differences forced by the device boundary: a ``Poly`` is a *batch* of polynomials resident in
+HBM ((poly, limb, coeff)-major uint64); ``Poly.set``/``Poly.get`` move numpy arrays of shape
+[batch, limbs, N] (or [limbs, N] when batch == 1).  Errors the reference reports by panicking
+are raised as ``LatticeRingError``.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _native as nat
+from ._native import LatticeRingError, check, lib
+
+# lr_ewise_op (include/lattigo_ring.h)
+OPS = ["ADD", "ADD_NOMOD", "SUB", "SUB_NOMOD", "NEG", "REDUCE", "MUL_COEFFS", "MUL_COEFFS_AND_ADD",
+       "MUL_COEFFS_AND_ADD_NOMOD", "MUL_COEFFS_CONSTANT", "MUL_MONT", "MUL_MONT_AND_ADD",
+       "MUL_MONT_AND_ADD_NOMOD", "MUL_MONT_CONSTANT_AND_ADD_NOMOD", "MUL_MONT_AND_SUB",
+       "MUL_MONT_AND_SUB_NOMOD", "MUL_MONT_CONSTANT", "MFORM", "INV_MFORM", "MUL_SCALAR",
+       "MUL_SCALAR_LIMBS", "ADD_SCALAR_LIMBS", "SUB_SCALAR_LIMBS", "COPY", "MUL_BY_POW2"]
+OP = {n: i for i, n in enumerate(OPS)}
+
+TAB = {"MODULUS": 0, "BRED": 1, "MRED": 2, "PSI_MONT": 3, "PSI_INV_MONT": 4, "NTT_PSI": 5, "NTT_PSI_INV": 6,
+       "NTT_N_INV": 7, "RESCALE": 8, "MASK": 9}
+
+
+def _u64(vals):
+    vals = [int(v) for v in vals]
+    return (C.c_uint64 * len(vals))(*vals)
+
+
+class Poly:
+    """ring.Poly (ring/ring_object.go:11-13), as a device-resident batch."""
+
+    def __init__(self, ctx, limbs, batch=1, _handle=None):
+        self.ctx = ctx
+        self.N = ctx.N
+        self.alloc_limbs = limbs
+        self.batch = batch
+        if _handle is None:
+            h = C.c_void_p()
+            check(lib().lr_poly_alloc(ctx.h, limbs, batch, C.byref(h)))
+            _handle = h
+        self.h = _handle
+
+    # --- reference accessors -----------------------------------------------------------
+    def GetLenModuli(self):  # ring/ring_object.go:55
+        n = C.c_int()
+        check(lib().lr_poly_info(self.h, None, C.byref(n), None, None))
+        return n.value
+
+    def GetDegree(self):  # ring/ring_object.go:50
+        return self.N
+
+    def Zero(self):  # ring/ring_object.go:60
+        check(lib().lr_poly_zero(self.h))
+
+    @property
+    def limbs(self):
+        return self.GetLenModuli()
+
+    @property
+    def device_ptr(self):
+        p = C.c_void_p()
+        check(lib().lr_poly_info(self.h, None, None, None, C.byref(p)))
+        return p.value
+
+    # --- data movement -----------------------------------------------------------------
+    def set(self, arr):
+        a = np.ascontiguousarray(arr, dtype=np.uint64)
+        limbs = self.limbs
+        if a.ndim == 2:
+            a = a[None]
+        if a.shape != (self.batch, limbs, self.N):
+            raise LatticeRingError(3, "expected shape %s, got %s" % ((self.batch, limbs, self.N), a.shape))
+        check(lib().lr_poly_upload_dense(self.h, a.ctypes.data_as(C.c_void_p), a.size))
+        return self
+
+    def get(self):
+        limbs = self.limbs
+        out = np.empty((self.batch, limbs, self.N), dtype=np.uint64)
+        check(lib().lr_poly_download_dense(self.h, out.ctypes.data_as(C.c_void_p), out.size))
+        return out[0] if self.batch == 1 else out
+
+    def set_limb_slices(self, batch_index, limb_arrays):
+        """Go boundary form: one independent array per limb (``[][]uint64``)."""
+        arrs = [np.ascontiguousarray(x, dtype=np.uint64) for x in limb_arrays]
+        ptrs = (nat.u64p * len(arrs))(*[x.ctypes.data_as(nat.u64p) for x in arrs])
+        check(lib().lr_poly_upload(self.h, batch_index, ptrs, len(arrs)))
+
+    def get_limb_slices(self, batch_index, limbs=None):
+        limbs = self.limbs if limbs is None else limbs
+        arrs = [np.empty(self.N, dtype=np.uint64) for _ in range(limbs)]
+        ptrs = (nat.u64p * limbs)(*[x.ctypes.data_as(nat.u64p) for x in arrs])
+        check(lib().lr_poly_download(self.h, batch_index, ptrs, limbs))
+        return arrs
+
+    def CopyNew(self):  # ring/ring_object.go:67
+        p = Poly(self.ctx, self.alloc_limbs, self.batch)
+        check(lib().lr_poly_set_limbs(p.h, self.limbs))
+        self.ctx._ew("COPY", self.limbs - 1, self, None, p)
+        return p
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                lib().lr_poly_free(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+
+class Context:
+    """ring.Context (ring/ring_context.go:18-51)."""
+
+    def __init__(self, N, Moduli, device=0):
+        self.N = int(N)
+        self.Modulus = [int(m) for m in Moduli]
+        self.device = device
+        h = C.c_void_p()
+        check(lib().lr_context_create(self.N, _u64(self.Modulus), len(self.Modulus), device, C.byref(h)))
+        self.h = h
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                lib().lr_context_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    # --- getters (ring/ring_context.go:253-285) ----------------------------------------------
+    def _table(self, name, shape):
+        out = np.empty(shape, dtype=np.uint64)
+        check(lib().lr_context_get_table(self.h, TAB[name], out.ctypes.data_as(nat.u64p), out.size))
+        return out
+
+    def GetBredParams(self):
+        return self._table("BRED", (len(self.Modulus), 2))
+
+    def GetMredParams(self):
+        return self._table("MRED", (len(self.Modulus),))
+
+    def GetPsi(self):
+        return self._table("PSI_MONT", (len(self.Modulus),))
+
+    def GetPsiInv(self):
+        return self._table("PSI_INV_MONT", (len(self.Modulus),))
+
+    def GetNttPsi(self):
+        return self._table("NTT_PSI", (len(self.Modulus), self.N))
+
+    def GetNttPsiInv(self):
+        return self._table("NTT_PSI_INV", (len(self.Modulus), self.N))
+
+    def GetNttNInv(self):
+        return self._table("NTT_N_INV", (len(self.Modulus),))
+
+    def GetRescaleParams(self):
+        return self._table("RESCALE", (len(self.Modulus), len(self.Modulus)))
+
+    def Sync(self):
+        check(lib().lr_context_sync(self.h))
+
+    def SetStream(self, stream_ptr):
+        check(lib().lr_context_set_stream(self.h, C.c_void_p(stream_ptr)))
+
+    # --- allocation (ring/ring_context.go:288,300) -------------------------------------------
+    def NewPoly(self, batch=1):
+        return Poly(self, len(self.Modulus), batch)
+
+    def NewPolyLvl(self, level, batch=1):
+        return Poly(self, level + 1, batch)
+
+    # --- NTT (ring/ntt.go:4-29) ---------------------------------------------------------------
+    def NTT(self, p1, p2):
+        check(lib().lr_ntt(self.h, len(self.Modulus) - 1, p1.h, p2.h))
+
+    def NTTLvl(self, level, p1, p2):
+        check(lib().lr_ntt(self.h, level, p1.h, p2.h))
+
+    def InvNTT(self, p1, p2):
+        check(lib().lr_intt(self.h, len(self.Modulus) - 1, p1.h, p2.h))
+
+    def InvNTTLvl(self, level, p1, p2):
+        check(lib().lr_intt(self.h, level, p1.h, p2.h))
+
+    def NTTLimb(self, mod_index, p1, limb1, p2, limb2):  # package-level ring.NTT (ring/ntt.go:53)
+        check(lib().lr_ntt_limb(self.h, mod_index, p1.h, limb1, p2.h, limb2))
+
+    def InvNTTLimb(self, mod_index, p1, limb1, p2, limb2):  # ring.InvNTT (ring/ntt.go:89)
+        check(lib().lr_intt_limb(self.h, mod_index, p1.h, limb1, p2.h, limb2))
+
+    def NTTHost(self, limb_arrays):
+        """Literal Go call shape: per-limb host slices in, per-limb host slices out."""
+        ins = [np.ascontiguousarray(x, dtype=np.uint64) for x in limb_arrays]
+        outs = [np.empty(self.N, dtype=np.uint64) for _ in ins]
+        pi = (nat.u64p * len(ins))(*[x.ctypes.data_as(nat.u64p) for x in ins])
+        po = (nat.u64p * len(ins))(*[x.ctypes.data_as(nat.u64p) for x in outs])
+        check(lib().lr_ntt_host(self.h, len(ins) - 1, pi, po))
+        return outs
+
+    def InvNTTHost(self, limb_arrays):
+        ins = [np.ascontiguousarray(x, dtype=np.uint64) for x in limb_arrays]
+        outs = [np.empty(self.N, dtype=np.uint64) for _ in ins]
+        pi = (nat.u64p * len(ins))(*[x.ctypes.data_as(nat.u64p) for x in ins])
+        po = (nat.u64p * len(ins))(*[x.ctypes.data_as(nat.u64p) for x in outs])
+        check(lib().lr_intt_host(self.h, len(ins) - 1, pi, po))
+        return outs
+
+    # --- coefficient-wise family (ring/ring.go) ------------------------------------------------
+    def _ew(self, op, level, a, b, out, scalars=None):
+        sc = None if scalars is None else _u64(scalars)
+        check(lib().lr_ewise(self.h, OP[op], level, a.h, None if b is None else b.h, out.h, sc))
+
+    def _full(self):
+        return len(self.Modulus) - 1
+
+    def Add(self, p1, p2, p3): self._ew("ADD", self._full(), p1, p2, p3)
+    def AddLvl(self, level, p1, p2, p3): self._ew("ADD", level, p1, p2, p3)
+    def AddNoMod(self, p1, p2, p3): self._ew("ADD_NOMOD", self._full(), p1, p2, p3)
+    def AddNoModLvl(self, level, p1, p2, p3): self._ew("ADD_NOMOD", level, p1, p2, p3)
+    def Sub(self, p1, p2, p3): self._ew("SUB", self._full(), p1, p2, p3)
+    def SubLvl(self, level, p1, p2, p3): self._ew("SUB", level, p1, p2, p3)
+    def SubNoMod(self, p1, p2, p3): self._ew("SUB_NOMOD", self._full(), p1, p2, p3)
+    def SubNoModLvl(self, level, p1, p2, p3): self._ew("SUB_NOMOD", level, p1, p2, p3)
+    def Neg(self, p1, p2): self._ew("NEG", self._full(), p1, None, p2)
+    def NegLvl(self, level, p1, p2): self._ew("NEG", level, p1, None, p2)
+    def Reduce(self, p1, p2): self._ew("REDUCE", self._full(), p1, None, p2)
+    def ReduceLvl(self, level, p1, p2): self._ew("REDUCE", level, p1, None, p2)
+    def MulCoeffs(self, p1, p2, p3): self._ew("MUL_COEFFS", self._full(), p1, p2, p3)
+    def MulCoeffsAndAdd(self, p1, p2, p3): self._ew("MUL_COEFFS_AND_ADD", self._full(), p1, p2, p3)
+    def MulCoeffsAndAddNoMod(self, p1, p2, p3): self._ew("MUL_COEFFS_AND_ADD_NOMOD", self._full(), p1, p2, p3)
+    def MulCoeffsConstant(self, p1, p2, p3): self._ew("MUL_COEFFS_CONSTANT", self._full(), p1, p2, p3)
+    def MulCoeffsMontgomery(self, p1, p2, p3): self._ew("MUL_MONT", self._full(), p1, p2, p3)
+    def MulCoeffsMontgomeryLvl(self, level, p1, p2, p3): self._ew("MUL_MONT", level, p1, p2, p3)
+    def MulCoeffsMontgomeryAndAdd(self, p1, p2, p3): self._ew("MUL_MONT_AND_ADD", self._full(), p1, p2, p3)
+    def MulCoeffsMontgomeryAndAddLvl(self, level, p1, p2, p3): self._ew("MUL_MONT_AND_ADD", level, p1, p2, p3)
+    def MulCoeffsMontgomeryAndAddNoMod(self, p1, p2, p3): self._ew("MUL_MONT_AND_ADD_NOMOD", self._full(), p1, p2, p3)
+    def MulCoeffsMontgomeryAndAddNoModLvl(self, level, p1, p2, p3): self._ew("MUL_MONT_AND_ADD_NOMOD", level, p1, p2, p3)
+    def MulCoeffsMontgomeryConstantAndAddNoModLvl(self, level, p1, p2, p3):
+        self._ew("MUL_MONT_CONSTANT_AND_ADD_NOMOD", level, p1, p2, p3)
+    def MulCoeffsMontgomeryAndSub(self, p1, p2, p3): self._ew("MUL_MONT_AND_SUB", self._full(), p1, p2, p3)
+    def MulCoeffsMontgomeryAndSubNoMod(self, p1, p2, p3): self._ew("MUL_MONT_AND_SUB_NOMOD", self._full(), p1, p2, p3)
+    def MulCoeffsMontgomeryConstant(self, p1, p2, p3): self._ew("MUL_MONT_CONSTANT", self._full(), p1, p2, p3)
+    def MForm(self, p1, p2): self._ew("MFORM", self._full(), p1, None, p2)
+    def MFormLvl(self, level, p1, p2): self._ew("MFORM", level, p1, None, p2)
+    def InvMForm(self, p1, p2): self._ew("INV_MFORM", self._full(), p1, None, p2)
+    def MulScalar(self, p1, scalar, p2): self._ew("MUL_SCALAR", self._full(), p1, None, p2, [scalar])
+    def MulScalarLvl(self, level, p1, scalar, p2): self._ew("MUL_SCALAR", level, p1, None, p2, [scalar])
+    def Copy(self, p0, p1): self._ew("COPY", self._full(), p0, None, p1)
+    def CopyLvl(self, level, p0, p1): self._ew("COPY", level, p0, None, p1)
+    def MulByPow2(self, p1, pow2, p2): self._ew("MUL_BY_POW2", self._full(), p1, None, p2, [pow2])
+    def MulByPow2Lvl(self, level, p1, pow2, p2): self._ew("MUL_BY_POW2", level, p1, None, p2, [pow2])
+
+    def MulScalarBigint(self, p1, scalar, p2):  # ring/ring.go:541
+        self._ew("MUL_SCALAR_LIMBS", self._full(), p1, None, p2, [int(scalar) % q for q in self.Modulus])
+
+    def MulScalarBigintLvl(self, level, p1, scalar, p2):  # ring/ring.go:557
+        self._ew("MUL_SCALAR_LIMBS", level, p1, None, p2, [int(scalar) % q for q in self.Modulus[:level + 1]])
+
+    def AddScalarBigint(self, p1, scalar, p2):
+        # the reference writes into p1, not p2 (ring/ring.go:482: p1tmp, p2tmp := p1.Coeffs[i], p1.Coeffs[i])
+        self._ew("ADD_SCALAR_LIMBS", self._full(), p1, None, p1, [int(scalar) % q for q in self.Modulus])
+
+    def SubScalarBigint(self, p1, scalar, p2):  # ring/ring.go:500, same quirk
+        self._ew("SUB_SCALAR_LIMBS", self._full(), p1, None, p1, [int(scalar) % q for q in self.Modulus])
+
+    def MulPolyMontgomery(self, p1, p2, p3):  # ring/ring.go:370
+        a, b = self.NewPoly(p1.batch), self.NewPoly(p1.batch)
+        self.NTT(p1, a)
+        self.NTT(p2, b)
+        self.MulCoeffsMontgomery(a, b, p3)
+        self.InvNTT(p3, p3)
+
+    # --- RNS rescale (ring/ring_scaling.go:9-164) ----------------------------------------------
+    def DivFloorByLastModulusNTT(self, p0): check(lib().lr_div_floor_by_last_modulus_ntt(self.h, p0.h))
+    def DivFloorByLastModulus(self, p0): check(lib().lr_div_floor_by_last_modulus(self.h, p0.h))
+    def DivRoundByLastModulusNTT(self, p0): check(lib().lr_div_round_by_last_modulus_ntt(self.h, p0.h))
+    def DivRoundByLastModulus(self, p0): check(lib().lr_div_round_by_last_modulus(self.h, p0.h))
+    def DivFloorByLastModulusMany(self, p0, nb): check(lib().lr_div_floor_by_last_modulus_many(self.h, p0.h, nb, 0))
+    def DivFloorByLastModulusManyNTT(self, p0, nb): check(lib().lr_div_floor_by_last_modulus_many(self.h, p0.h, nb, 1))
+    def DivRoundByLastModulusMany(self, p0, nb): check(lib().lr_div_round_by_last_modulus_many(self.h, p0.h, nb, 0))
+    def DivRoundByLastModulusManyNTT(self, p0, nb): check(lib().lr_div_round_by_last_modulus_many(self.h, p0.h, nb, 1))
+
+    # --- measurement -------------------------------------------------------------------------
+    def TimerStart(self):
+        check(lib().lr_timer_start(self.h))
+
+    def TimerStop(self):
+        ms = C.c_float()
+        check(lib().lr_timer_stop(self.h, C.byref(ms)))
+        return ms.value
+
+
+def NewContextWithParams(N, Moduli, device=0):
+    """ring.NewContextWithParams (ring/ring_context.go:60).  Raises LatticeRingError
+    LR_ERR_NOT_NTT_FRIENDLY where the reference returns its error value."""
+    return Context(N, Moduli, device)
+
+
+class FastBasisExtender:
+    """ring.FastBasisExtender (ring/ring_basis_extension.go:9-74)."""
+
+    def __init__(self, contextQ, contextP):
+        self.contextQ, self.contextP = contextQ, contextP
+        h = C.c_void_p()
+        check(lib().lr_bext_create(contextQ.h, contextP.h, C.byref(h)))
+        self.h = h
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                lib().lr_bext_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def ModDownParamsPQ(self):
+        out = np.empty(len(self.contextQ.Modulus), dtype=np.uint64)
+        check(lib().lr_bext_get_table(self.h, 0, out.ctypes.data_as(nat.u64p), out.size))
+        return out
+
+    def ModDownParamsQP(self):
+        out = np.empty(len(self.contextP.Modulus), dtype=np.uint64)
+        check(lib().lr_bext_get_table(self.h, 1, out.ctypes.data_as(nat.u64p), out.size))
+        return out
+
+    def ModUpSplitQP(self, level, p1, p2): check(lib().lr_modup_split_qp(self.h, level, p1.h, p2.h))
+    def ModUpSplitPQ(self, level, p1, p2): check(lib().lr_modup_split_pq(self.h, level, p1.h, p2.h))
+    def ModDownNTTPQ(self, level, p1, p2): check(lib().lr_moddown_ntt_pq(self.h, level, p1.h, p2.h))
+    def ModDownSplitedNTTPQ(self, level, p1Q, p1P, p2): check(lib().lr_moddown_split_ntt_pq(self.h, level, p1Q.h, p1P.h, p2.h))
+    def ModDownPQ(self, level, p1, p2): check(lib().lr_moddown_pq(self.h, level, p1.h, p2.h))
+    def ModDownSplitedPQ(self, level, p1Q, p1P, p2): check(lib().lr_moddown_split_pq(self.h, level, p1Q.h, p1P.h, p2.h))
+    def ModDownSplitedQP(self, levelQ, levelP, p1Q, p1P, p2):
+        check(lib().lr_moddown_split_qp(self.h, levelQ, levelP, p1Q.h, p1P.h, p2.h))
+
+
+def NewFastBasisExtender(contextQ, contextP):
+    return FastBasisExtender(contextQ, contextP)
+
+
+class Decomposer:
+    """ring.Decomposer (ring/ring_basis_extension.go:398-472).  The reference constructor takes the
+    modulus lists; here the two contexts (which carry them) so the handle knows its device."""
+
+    def __init__(self, contextQ, contextP):
+        self.contextQ, self.contextP = contextQ, contextP
+        h = C.c_void_p()
+        check(lib().lr_decomposer_create(contextQ.h, contextP.h, C.byref(h)))
+        self.h = h
+        nQ, nP = len(contextQ.Modulus), len(contextP.Modulus)
+        self.alpha = nP
+        self.beta = -(-nQ // nP)
+        self.xalpha = [nP] * self.beta
+        if nQ % nP:
+            self.xalpha[-1] = nQ % nP
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                lib().lr_decomposer_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def Xalpha(self):
+        return list(self.xalpha)
+
+    def Decompose(self, level, crtDecompLevel, p0, p1):
+        check(lib().lr_decompose(self.h, level, crtDecompLevel, p0.h, p1.h))
+
+    def DecomposeAndSplit(self, level, crtDecompLevel, p0, p1Q, p1P):
+        check(lib().lr_decompose_and_split(self.h, level, crtDecompLevel, p0.h, p1Q.h, p1P.h))
+
+
+def NewDecomposer(contextQ, contextP):
+    return Decomposer(contextQ, contextP)
+
+
+class CkksPlan:
+    """What ckks.NewEvaluator builds around the ring (ckks/evaluator.go:81-112) plus the
+    MulRelin / switchKeysInPlace / Rescale call sequences (:1016, :1475, :933), device-resident."""
+
+    def __init__(self, contextQ, contextP, max_batch=1):
+        self.contextQ, self.contextP = contextQ, contextP
+        h = C.c_void_p()
+        check(lib().lr_ckks_plan_create(contextQ.h, contextP.h, max_batch, C.byref(h)))
+        self.h = h
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                lib().lr_ckks_plan_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def NewSwitchingKey(self, batch=1):
+        """Storage for SwitchingKey.evakey (ckks/keygen.go:68-70): beta x 2 polys over Q||P."""
+        nQ, nP = len(self.contextQ.Modulus), len(self.contextP.Modulus)
+        beta = -(-nQ // nP)
+        return Poly(self.contextQ, nQ + nP, 2 * beta)
+
+    def SwitchKeysInPlace(self, level, cx, evakey, p0, p1):
+        check(lib().lr_ckks_switch_keys(self.h, level, cx.h, evakey.h, p0.h, p1.h))
+
+    def MulRelin(self, level, ct0, ct1, evakey, ctOut):
+        """ct0, ct1, ctOut: pairs (value[0], value[1]) of Poly."""
+        check(lib().lr_ckks_mulrelin(self.h, level, ct0[0].h, ct0[1].h, ct1[0].h, ct1[1].h, evakey.h,
+                                     ctOut[0].h, ctOut[1].h))
+
+    def Rescale(self, ct):
+        check(lib().lr_ckks_rescale(self.h, ct[0].h, ct[1].h))

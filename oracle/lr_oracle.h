@@ -1,0 +1,189 @@
+/*
+ * lr_oracle.h -- CPU restatement of Lattigo v1.3.1's `ring` hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing in the product (lattigo-fhe-by-go_amd/,
+ * include/) may include, link or call this.  Only tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg use it, and there only as the checker / the
+ * timed CPU baseline.
+ *
+ * Every function cites the reference file:line (relative to the Lattigo tree)
+ * whose arithmetic it restates.  Parity status: PINNED -- the 14 golden limb
+ * vectors of ring/test_data (copied as data into tests/golden/) are reproduced on
+ * every coefficient, plus the big-integer identities of ring/ring_test.go
+ * (see tests/test_oracle_*.py).
+ *
+ * Layout: a polynomial is a dense uint64 array [limb][N] (limb-major), the
+ * contiguous image of Go's `Poly.Coeffs [][]uint64` (ring/ring_object.go:11-13).
+ */
+#ifndef LR_ORACLE_H
+#define LR_ORACLE_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- scalar primitives: ring/modular_reduction.go ------------------------- */
+uint64_t oc_mred_params(uint64_t q);                               /* :53  */
+void     oc_bred_params(uint64_t q, uint64_t u[2]);                /* :97  */
+uint64_t oc_mform(uint64_t a, uint64_t q, const uint64_t u[2]);    /* :15  */
+uint64_t oc_mform_constant(uint64_t a, uint64_t q, const uint64_t u[2]); /* :26 */
+uint64_t oc_inv_mform(uint64_t a, uint64_t q, uint64_t qinv);      /* :34  */
+uint64_t oc_mred(uint64_t x, uint64_t y, uint64_t q, uint64_t qinv);          /* :70 */
+uint64_t oc_mred_constant(uint64_t x, uint64_t y, uint64_t q, uint64_t qinv); /* :83 */
+uint64_t oc_bred_add(uint64_t x, uint64_t q, const uint64_t u[2]);            /* :112 */
+uint64_t oc_bred_add_constant(uint64_t x, uint64_t q, const uint64_t u[2]);   /* :123 */
+uint64_t oc_bred(uint64_t x, uint64_t y, uint64_t q, const uint64_t u[2]);    /* :133 */
+uint64_t oc_bred_constant(uint64_t x, uint64_t y, uint64_t q, const uint64_t u[2]); /* :172 */
+uint64_t oc_cred(uint64_t a, uint64_t q);                          /* :211 */
+
+/* ---- ring/utils.go -------------------------------------------------------- */
+uint64_t oc_power_of_2(uint64_t x, uint64_t n, uint64_t q, uint64_t qinv); /* :8 */
+uint64_t oc_mod_exp(uint64_t x, uint64_t e, uint64_t p);           /* :25  */
+int      oc_is_prime(uint64_t n);                                  /* :75  */
+uint64_t oc_primitive_root(uint64_t q);                            /* :182 */
+int      oc_get_factors(uint64_t n, uint64_t *out, int cap);       /* :251 */
+int      oc_generate_ntt_primes(uint64_t logQ, uint64_t logN, uint64_t levels, uint64_t *out); /* :133 */
+uint64_t oc_bit_reverse64(uint64_t index, uint64_t bitlen);        /* utils/utils.go:58 */
+
+/* ---- Context: ring/ring_context.go:18-209 --------------------------------- */
+typedef struct oc_context {
+    uint64_t  N;
+    int       L;
+    uint64_t *q;           /* Modulus            */
+    uint64_t *mask;        /* :84                */
+    uint64_t *bred;        /* [L][2] = {hi, lo}  */
+    uint64_t *mred;        /* [L]                */
+    uint64_t *rescale;     /* [L][L]: rescale[(j-1)*L + i], i<j  (:148-158) */
+    uint64_t *psi_mont;    /* [L]                */
+    uint64_t *psi_inv_mont;/* [L]                */
+    uint64_t *ntt_psi;     /* [L][N]             */
+    uint64_t *ntt_psi_inv; /* [L][N]             */
+    uint64_t *n_inv;       /* [L]                */
+} oc_context;
+
+/* NewContextWithParams (:60).  Returns 0 ok, 1 = "provided modulus does not allow NTT"
+ * (:141-146), 2 = invalid ring degree (:71-73 panics in Go). */
+int  oc_context_new(uint64_t N, const uint64_t *moduli, int L, oc_context **out);
+void oc_context_free(oc_context *c);
+
+/* ---- NTT: ring/ntt.go ----------------------------------------------------- */
+void oc_ntt_limb(const uint64_t *in, uint64_t *out, uint64_t N, const uint64_t *ntt_psi,
+                 uint64_t q, uint64_t qinv, const uint64_t bred[2]);            /* :53 */
+void oc_intt_limb(const uint64_t *in, uint64_t *out, uint64_t N, const uint64_t *ntt_psi_inv,
+                  uint64_t n_inv, uint64_t q, uint64_t qinv);                   /* :89 */
+void oc_ntt_lvl(const oc_context *c, int level, const uint64_t *in, uint64_t *out);  /* :11 */
+void oc_intt_lvl(const oc_context *c, int level, const uint64_t *in, uint64_t *out); /* :25 */
+
+/* ---- coefficient-wise family: ring/ring.go -------------------------------- */
+enum oc_ewise_op {
+    OC_ADD = 0,               /* :10,20   p3 = CRed(p1+p2)                       */
+    OC_ADD_NOMOD,             /* :32,42                                          */
+    OC_SUB,                   /* :54,64   p3 = CRed(p1+q-p2)                     */
+    OC_SUB_NOMOD,             /* :77,87                                          */
+    OC_NEG,                   /* :100,110 p2 = q-p1                              */
+    OC_REDUCE,                /* :122,133 p2 = BRedAdd(p1)                       */
+    OC_MUL_COEFFS,            /* :187     BRed                                   */
+    OC_MUL_COEFFS_AND_ADD,    /* :198                                            */
+    OC_MUL_COEFFS_AND_ADD_NOMOD, /* :209                                         */
+    OC_MUL_COEFFS_CONSTANT,   /* :335     BRedConstant                           */
+    OC_MUL_MONT,              /* :221,233 MRed                                   */
+    OC_MUL_MONT_AND_ADD,      /* :247,259                                        */
+    OC_MUL_MONT_AND_ADD_NOMOD,/* :273,285                                        */
+    OC_MUL_MONT_CONSTANT_AND_ADD_NOMOD, /* :297                                  */
+    OC_MUL_MONT_AND_SUB,      /* :311                                            */
+    OC_MUL_MONT_AND_SUB_NOMOD,/* :323                                            */
+    OC_MUL_MONT_CONSTANT,     /* :347                                            */
+    OC_MFORM,                 /* :583,595                                        */
+    OC_INV_MFORM,             /* :610                                            */
+    OC_MUL_SCALAR,            /* :513,526 (scalar: one u64 for all limbs)        */
+    OC_MUL_SCALAR_LIMBS,      /* :541,557 MulScalarBigint: per-limb scalar mod qi*/
+    OC_ADD_SCALAR_LIMBS,      /* :477     AddScalarBigint (in place on p1)       */
+    OC_SUB_SCALAR_LIMBS,      /* :500     SubScalarBigint (in place on p1)       */
+    OC_COPY,                  /* ring_object.go:85,98                            */
+    OC_MUL_BY_POW2,           /* :629,645 scalar = pow2                          */
+    OC_EWISE_COUNT
+};
+/* a, b, out: [level+1][N] limb-major.  scalars: NULL, or one u64 (MUL_SCALAR,
+ * MUL_BY_POW2) or level+1 u64 (the *_LIMBS ops). */
+void oc_ewise(const oc_context *c, int op, int level, const uint64_t *a, const uint64_t *b,
+              uint64_t *out, const uint64_t *scalars);
+
+/* ---- basis extension: ring/ring_basis_extension.go ------------------------ */
+typedef struct oc_modup_params {     /* modupParams :19-37, built by :76-142 */
+    int nQ, nP;
+    uint64_t *Q, *P;
+    uint64_t *qib_mont;      /* [nQ]                                  */
+    uint64_t *qispj_mont;    /* [nQ][nP]                              */
+    uint64_t *qpj_inv;       /* [nP][nQ+1]                            */
+    uint64_t *bredQ, *bredP; /* [n][2]                                */
+    uint64_t *mredQ, *mredP;
+} oc_modup_params;
+oc_modup_params *oc_modup_params_new(const uint64_t *Q, int nQ, const uint64_t *P, int nP); /* :76 */
+void oc_modup_params_free(oc_modup_params *p);
+/* modUpExact (:352): in = [n_in][N], out = [n_out][N]; n_in <= nQ, n_out <= nP */
+void oc_modup_exact(const oc_modup_params *p, const uint64_t *in, int n_in, uint64_t *out, int n_out, uint64_t N);
+
+typedef struct oc_bext {             /* FastBasisExtender :9-18 */
+    const oc_context *cQ, *cP;
+    oc_modup_params *qp, *pq;
+    uint64_t *moddown_pq;    /* [|Q|]  (P^-1 mod q_i, Montgomery)  :39 with (contextQ, contextP) */
+    uint64_t *moddown_qp;    /* [|P|]  (Q^-1 mod p_j, Montgomery)                                */
+    uint64_t *poolQ, *poolP; /* scratch polys                                                    */
+} oc_bext;
+oc_bext *oc_bext_new(const oc_context *cQ, const oc_context *cP);        /* :57  */
+void oc_bext_free(oc_bext *b);
+void oc_modup_split_qp(oc_bext *b, int level, const uint64_t *p1, uint64_t *p2);   /* :147 */
+void oc_modup_split_pq(oc_bext *b, int level, const uint64_t *p1, uint64_t *p2);   /* :154 */
+/* p1 = [|Q|+|P|][N] (mutated: its P part is taken out of the NTT domain), p2 = [level+1][N] */
+void oc_moddown_ntt_pq(oc_bext *b, int level, uint64_t *p1, uint64_t *p2);         /* :163 */
+void oc_moddown_split_ntt_pq(oc_bext *b, int level, const uint64_t *p1Q, uint64_t *p1P, uint64_t *p2); /* :207 */
+void oc_moddown_pq(oc_bext *b, int level, const uint64_t *p1, uint64_t *p2);       /* :248 */
+void oc_moddown_split_pq(oc_bext *b, int level, const uint64_t *p1Q, const uint64_t *p1P, uint64_t *p2); /* :281 */
+void oc_moddown_split_qp(oc_bext *b, int levelQ, int levelP, const uint64_t *p1Q, const uint64_t *p1P, uint64_t *p2); /* :314 */
+
+typedef struct oc_decomposer {       /* Decomposer :398-407 */
+    int nQ, nP, alpha, beta;
+    int *xalpha;
+    oc_modup_params ***modup;        /* [beta][xalpha[i]-1] */
+} oc_decomposer;
+oc_decomposer *oc_decomposer_new(const uint64_t *Q, int nQ, const uint64_t *P, int nP);  /* :415 */
+void oc_decomposer_free(oc_decomposer *d);
+/* Decompose (:476): p0 = [>=level+1][N], p1 = [level+1+nP][N] */
+void oc_decompose(const oc_decomposer *d, int level, int crt, const uint64_t *p0, uint64_t *p1, uint64_t N);
+/* DecomposeAndSplit (:601): p1Q = [level+1][N], p1P = [nP][N] */
+void oc_decompose_and_split(const oc_decomposer *d, int level, int crt, const uint64_t *p0,
+                            uint64_t *p1Q, uint64_t *p1P, uint64_t N);
+
+/* ---- RNS rescale: ring/ring_scaling.go:9-164 ------------------------------ */
+/* p0 = [nlimbs][N] in place; afterwards only the first nlimbs-1 limbs are meaningful
+ * (Go re-slices p0.Coeffs = p0.Coeffs[:level]). */
+void oc_div_floor_by_last_modulus_ntt(const oc_context *c, uint64_t *p0, int nlimbs);  /* :9   */
+void oc_div_floor_by_last_modulus(const oc_context *c, uint64_t *p0, int nlimbs);      /* :37  */
+void oc_div_round_by_last_modulus_ntt(const oc_context *c, uint64_t *p0, int nlimbs);  /* :72  */
+void oc_div_round_by_last_modulus(const oc_context *c, uint64_t *p0, int nlimbs);      /* :117 */
+void oc_div_floor_by_last_modulus_many(const oc_context *c, uint64_t *p0, int nlimbs, int nb, int ntt);  /* :58,65   */
+void oc_div_round_by_last_modulus_many(const oc_context *c, uint64_t *p0, int nlimbs, int nb, int ntt);  /* :153,160 */
+
+/* ---- caller sequences: ckks/evaluator.go --------------------- */
+typedef struct oc_ckks_plan {
+    const oc_context *cQ, *cP;
+    oc_bext *bext;
+    oc_decomposer *dec;
+    int alpha;
+} oc_ckks_plan;
+oc_ckks_plan *oc_ckks_plan_new(const oc_context *cQ, const oc_context *cP);
+void oc_ckks_plan_free(oc_ckks_plan *p);
+/* switchKeysInPlace (:1475).  cx = [level+1][N] NTT domain.  evk = [beta][2][|Q|+|P|][N]
+ * (NTT + Montgomery, ckks/keygen.go:68-70).  p0, p1 = [level+1][N] outputs. */
+void oc_ckks_switch_keys(oc_ckks_plan *p, int level, const uint64_t *cx, const uint64_t *evk,
+                         uint64_t *p0, uint64_t *p1);
+/* MulRelin (:1016), degree-1 x degree-1, regular (non-squaring) case with evaluation key.
+ * ct0, ct1, out = [2][level+1][N]. */
+void oc_ckks_mulrelin(oc_ckks_plan *p, int level, const uint64_t *ct0, const uint64_t *ct1,
+                      const uint64_t *evk, uint64_t *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
