@@ -1,0 +1,184 @@
+"""Parity of the HIP NTT/InvNTT path (through the C ABI) against the reference's golden vectors
+and the CPU oracle.  Integer work: the bar is bit-exact."""
+import numpy as np
+import pytest
+
+from conftest import GOLDEN_SIZES, golden_pair
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("n", GOLDEN_SIZES)
+def test_ntt_reference_vectors(gpu_pkg, n):
+    # ring/ntt_test.go:101-142 on the device, every coefficient
+    ring = gpu_pkg.ring
+    N, moduli, x, want = golden_pair(n)
+    ctx = ring.NewContextWithParams(N, moduli)
+    p = ctx.NewPoly().set(x)
+    ctx.NTT(p, p)
+    assert np.array_equal(p.get(), want)
+    ctx.InvNTT(p, p)
+    assert np.array_equal(p.get(), x)
+
+
+def test_context_tables_match_oracle(gpu_pkg, oracle):
+    N, moduli = gpu_pkg.params.DefaultParamsQi(13)
+    ctx = gpu_pkg.ring.NewContextWithParams(N, moduli)
+    oc = oracle.Context(N, moduli)
+    assert np.array_equal(ctx.GetNttPsi(), oc.ntt_psi)
+    assert np.array_equal(ctx.GetNttPsiInv(), oc.ntt_psi_inv)
+    assert np.array_equal(ctx.GetNttNInv(), oc.n_inv)
+    assert np.array_equal(ctx.GetBredParams(), oc.bred)
+    assert np.array_equal(ctx.GetMredParams(), oc.mred)
+    assert np.array_equal(ctx.GetPsi(), oc.psi_mont)
+    assert np.array_equal(ctx.GetPsiInv(), oc.psi_inv_mont)
+    assert np.array_equal(ctx.GetRescaleParams(), oc.rescale)
+
+
+@pytest.mark.parametrize("logn,limbs,batch", [(1, 1, 2), (3, 2, 3), (10, 2, 2), (11, 3, 2), (12, 2, 3), (13, 4, 2),
+                                              (14, 8, 2), (15, 16, 2)])
+def test_ntt_vs_oracle(gpu_pkg, oracle, logn, limbs, batch):
+    N = 1 << logn
+    moduli = list(gpu_pkg.params.Qi60()[-limbs:])
+    ctx = gpu_pkg.ring.NewContextWithParams(N, moduli)
+    oc = oracle.Context(N, moduli)
+    x = gpu_pkg.sampling.uniform_poly(moduli, N, batch, seed=100 + logn)
+    p, r = ctx.NewPoly(batch).set(x), ctx.NewPoly(batch)
+    ctx.NTT(p, r)                      # out of place
+    got = r.get().reshape(batch, limbs, N)
+    for b in range(batch):
+        assert np.array_equal(got[b], oc.ntt(x[b])), (logn, b)
+    ctx.InvNTT(r, r)                   # in place
+    assert np.array_equal(r.get().reshape(batch, limbs, N), x)
+    assert np.array_equal(p.get().reshape(batch, limbs, N), x)   # input untouched
+
+
+@pytest.mark.parametrize("logn", [10, 12, 14, 15])
+def test_ntt_accepts_unreduced_and_full_range_input(gpu_pkg, oracle, logn):
+    """The reference feeds values >= q into NTT (ring/ring_scaling.go:19,102-105); the result is the
+    canonical transform of the input mod q.  Full 64-bit inputs included."""
+    N = 1 << logn
+    moduli = [gpu_pkg.params.Qi60()[-1], 1099512938497 if logn <= 15 else 0, gpu_pkg.params.Pi60()[5]]
+    ctx = gpu_pkg.ring.NewContextWithParams(N, moduli)
+    oc = oracle.Context(N, moduli)
+    x = gpu_pkg.sampling.random_u64((1, len(moduli), N), seed=logn)
+    x[0, :, :4] = np.uint64(0xFFFFFFFFFFFFFFFF)
+    x[0, :, 4:8] = 0
+    p = ctx.NewPoly().set(x[0])
+    ctx.NTT(p, p)
+    reduced = np.array([[int(v) % q for v in x[0, i]] for i, q in enumerate(moduli)], dtype=np.uint64)
+    want = oc.ntt(reduced)
+    assert np.array_equal(p.get(), want)
+
+
+@pytest.mark.parametrize("logn", [9, 12, 13])
+def test_intt_accepts_lazy_range(gpu_pkg, oracle, logn):
+    """InvNTT on inputs in [q, 2q) (the reference's safe domain is [0, 2q])."""
+    N = 1 << logn
+    moduli = list(gpu_pkg.params.Qi60()[-2:])
+    ctx = gpu_pkg.ring.NewContextWithParams(N, moduli)
+    oc = oracle.Context(N, moduli)
+    x = gpu_pkg.sampling.uniform_poly(moduli, N, 1, seed=3)[0]
+    y = x.copy()
+    for i, q in enumerate(moduli):
+        y[i, ::2] += np.uint64(q)
+    p = ctx.NewPoly().set(y)
+    ctx.InvNTT(p, p)
+    assert np.array_equal(p.get(), oc.intt(x))
+    assert np.array_equal(oc.intt(y), oc.intt(x))
+
+
+def test_ntt_lvl_touches_only_its_limbs(gpu_pkg, oracle):
+    N, moduli = gpu_pkg.params.DefaultParamsQi(13)
+    ctx = gpu_pkg.ring.NewContextWithParams(N, moduli)
+    oc = oracle.Context(N, moduli)
+    x = gpu_pkg.sampling.uniform_poly(moduli, N, 2, seed=8)
+    p = ctx.NewPoly(2).set(x)
+    ctx.NTTLvl(1, p, p)
+    got = p.get()
+    for b in range(2):
+        assert np.array_equal(got[b, :2], oc.ntt(x[b, :2], level=1)[:2])
+        assert np.array_equal(got[b, 2:], x[b, 2:])
+
+
+def test_ntt_limb_under_foreign_modulus(gpu_pkg, oracle):
+    """package-level ring.NTT on one limb under another limb's modulus (ring/ring_scaling.go:19)."""
+    N, moduli = gpu_pkg.params.DefaultParamsQi(12)
+    moduli = moduli + [gpu_pkg.params.Pi60()[0]]
+    ctx = gpu_pkg.ring.NewContextWithParams(N, moduli)
+    oc = oracle.Context(N, moduli)
+    x = gpu_pkg.sampling.uniform_poly(moduli, N, 1, seed=4)[0]
+    p, r = ctx.NewPoly().set(x), ctx.NewPoly()
+    ctx.NTTLimb(2, p, 0, r, 1)     # limb 0 (values < q0, some >= q2) transformed under modulus 2 into row 1
+    want = np.empty(N, dtype=np.uint64)
+    lib = oracle.lib()
+    lib.oc_ntt_limb(x[0].ctypes.data, want.ctypes.data, N, oc.ntt_psi[2].ctypes.data, moduli[2], int(oc.mred[2]),
+                    (oracle.u64 * 2)(*[int(v) for v in oc.bred[2]]))
+    assert np.array_equal(r.get()[1], want)
+
+
+def test_go_boundary_limb_slices(gpu_pkg, oracle):
+    """lr_poly_upload/download and lr_ntt_host take Go's [][]uint64 shape: one pointer per limb."""
+    N, moduli = gpu_pkg.params.DefaultParamsQi(12)
+    ctx = gpu_pkg.ring.NewContextWithParams(N, moduli)
+    oc = oracle.Context(N, moduli)
+    x = gpu_pkg.sampling.uniform_poly(moduli, N, 1, seed=21)[0]
+    outs = ctx.NTTHost([x[0].copy(), x[1].copy()])
+    assert np.array_equal(np.stack(outs), oc.ntt(x))
+    back = ctx.InvNTTHost(outs)
+    assert np.array_equal(np.stack(back), x)
+    p = ctx.NewPoly(2)
+    p.set_limb_slices(1, [x[0], x[1]])
+    assert np.array_equal(np.stack(p.get_limb_slices(1)), x)
+    assert np.array_equal(p.get()[0], np.zeros_like(x))
+
+
+def test_shape_errors(gpu_pkg):
+    ring = gpu_pkg.ring
+    N, moduli = gpu_pkg.params.DefaultParamsQi(12)
+    ctx = ring.NewContextWithParams(N, moduli)
+    short = ctx.NewPolyLvl(0)
+    full = ctx.NewPoly()
+    with pytest.raises(ring.LatticeRingError) as e:
+        ctx.NTT(short, full)           # Go: index out of range panic
+    assert e.value.code == 3
+    with pytest.raises(ring.LatticeRingError):
+        ring.NewContextWithParams(N, [moduli[0] + 2])
+
+
+def test_full_size_properties_r15(gpu_pkg):
+    """BASELINE headline ring R15 (N = 2^15, 16 x 60-bit limbs), batch 8: size-independent properties --
+    round trip, linearity, and the convolution theorem against a sparse negacyclic product."""
+    N, moduli = gpu_pkg.params.DefaultParamsQi(15)
+    ctx = gpu_pkg.ring.NewContextWithParams(N, moduli)
+    B = 8
+    x = gpu_pkg.sampling.uniform_poly(moduli, N, B, seed=1)
+    y = gpu_pkg.sampling.uniform_poly(moduli, N, B, seed=2)
+    px, py, ps = ctx.NewPoly(B).set(x), ctx.NewPoly(B).set(y), ctx.NewPoly(B)
+    ctx.Add(px, py, ps)
+    ctx.NTT(px, px)
+    ctx.NTT(py, py)
+    ctx.NTT(ps, ps)
+    chk = ctx.NewPoly(B)
+    ctx.Add(px, py, chk)
+    assert np.array_equal(chk.get(), ps.get())                       # NTT(x + y) = NTT(x) + NTT(y)
+    out = px.get()
+    assert all(int(out[:, i].max()) < q for i, q in enumerate(moduli))  # canonical
+    ctx.InvNTT(px, px)
+    assert np.array_equal(px.get(), x)                               # round trip
+    # x * X^k via the NTT == negacyclic shift
+    k = 12345
+    mono = np.zeros((B, len(moduli), N), dtype=np.uint64)
+    mono[:, :, k] = 1
+    pm = ctx.NewPoly(B).set(mono)
+    ctx.NTT(pm, pm)
+    ctx.MForm(pm, pm)
+    ctx.NTT(px, px)
+    ctx.MulCoeffsMontgomery(px, pm, px)
+    ctx.InvNTT(px, px)
+    want = np.empty_like(x)
+    want[:, :, k:] = x[:, :, :N - k]
+    for i, q in enumerate(moduli):
+        wrapped = x[:, i, N - k:]
+        want[:, i, :k] = np.where(wrapped == 0, 0, np.uint64(q) - wrapped)
+    assert np.array_equal(px.get(), want)

@@ -1,0 +1,227 @@
+"""Parity of the coefficient-wise family, basis extension, decomposer and RNS rescale (HIP path through
+the C ABI) against the CPU oracle on the same seeded inputs.  Bit-exact."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+THREE_OPERAND = ["ADD", "ADD_NOMOD", "SUB", "SUB_NOMOD", "MUL_COEFFS", "MUL_COEFFS_AND_ADD",
+                 "MUL_COEFFS_AND_ADD_NOMOD", "MUL_COEFFS_CONSTANT", "MUL_MONT", "MUL_MONT_AND_ADD",
+                 "MUL_MONT_AND_ADD_NOMOD", "MUL_MONT_CONSTANT_AND_ADD_NOMOD", "MUL_MONT_AND_SUB",
+                 "MUL_MONT_AND_SUB_NOMOD", "MUL_MONT_CONSTANT"]
+TWO_OPERAND = ["NEG", "REDUCE", "MFORM", "INV_MFORM", "COPY"]
+
+
+def _setup(gpu_pkg, oracle, logn=12, limbs=3, batch=2, seed=1):
+    N = 1 << logn
+    moduli = list(gpu_pkg.params.Qi60()[-limbs:])
+    ctx = gpu_pkg.ring.NewContextWithParams(N, moduli)
+    oc = oracle.Context(N, moduli)
+    mk = lambda s: gpu_pkg.sampling.uniform_poly(moduli, N, batch, seed=seed * 10 + s)
+    return N, moduli, ctx, oc, mk
+
+
+@pytest.mark.parametrize("op", THREE_OPERAND)
+def test_three_operand_ops(gpu_pkg, oracle, op):
+    N, moduli, ctx, oc, mk = _setup(gpu_pkg, oracle)
+    a, b, c = mk(1), mk(2), mk(3)
+    pa, pb, pc = ctx.NewPoly(2).set(a), ctx.NewPoly(2).set(b), ctx.NewPoly(2).set(c)
+    ctx._ew(op, len(moduli) - 1, pa, pb, pc)
+    got = pc.get()
+    for i in range(2):
+        assert np.array_equal(got[i], oc.ewise(op, a[i], b[i], out=c[i])), op
+
+
+@pytest.mark.parametrize("op", TWO_OPERAND)
+def test_two_operand_ops(gpu_pkg, oracle, op):
+    N, moduli, ctx, oc, mk = _setup(gpu_pkg, oracle)
+    a = gpu_pkg.sampling.random_u64((2, len(moduli), N), seed=5) if op == "REDUCE" else mk(1)
+    pa, pc = ctx.NewPoly(2).set(a), ctx.NewPoly(2)
+    ctx._ew(op, len(moduli) - 1, pa, None, pc)
+    got = pc.get()
+    for i in range(2):
+        assert np.array_equal(got[i], oc.ewise(op, a[i])), op
+
+
+def test_level_and_broadcast(gpu_pkg, oracle):
+    """...Lvl variants leave the upper limbs alone; a batch-1 operand is broadcast."""
+    N, moduli, ctx, oc, mk = _setup(gpu_pkg, oracle, limbs=4, batch=3)
+    a, c = mk(1), mk(3)
+    key = mk(2)[:1]
+    pa, pk, pc = ctx.NewPoly(3).set(a), ctx.NewPoly(1).set(key[0]), ctx.NewPoly(3).set(c)
+    ctx.MulCoeffsMontgomeryAndAddNoModLvl(1, pk, pa, pc)
+    got = pc.get()
+    for i in range(3):
+        want = oc.ewise("MUL_MONT_AND_ADD_NOMOD", key[0], a[i], out=c[i], level=1)
+        assert np.array_equal(got[i, :2], want[:2])
+        assert np.array_equal(got[i, 2:], c[i, 2:])
+
+
+def test_scalar_ops(gpu_pkg, oracle):
+    N, moduli, ctx, oc, mk = _setup(gpu_pkg, oracle)
+    a = mk(1)
+    pa, pc = ctx.NewPoly(2).set(a), ctx.NewPoly(2)
+    ctx.MulScalar(pa, 0xFFFFFFFFFFFFFFF1, pc)
+    assert np.array_equal(pc.get()[1], oc.ewise("MUL_SCALAR", a[1], scalars=[0xFFFFFFFFFFFFFFF1]))
+    big = (1 << 150) + 977
+    ctx.MulScalarBigint(pa, big, pc)
+    want = np.array([[int(v) * big % m for v in a[0, i]] for i, m in enumerate(moduli)], dtype=np.uint64)
+    assert np.array_equal(pc.get()[0], want)
+    # AddScalarBigint / SubScalarBigint write into their FIRST argument (ring/ring.go:482,505)
+    ctx.AddScalarBigint(pa, big, pc)
+    assert np.array_equal(pa.get()[0], oc.ewise("ADD_SCALAR_LIMBS", a[0], scalars=[big % m for m in moduli]))
+    ctx.SubScalarBigint(pa, big, pc)
+    assert np.array_equal(pa.get(), a)
+    ctx.MulByPow2(pa, 13, pc)
+    assert np.array_equal(pc.get()[0], oc.ewise("MUL_BY_POW2", a[0], scalars=[13]))
+
+
+def test_mulpoly_vs_schoolbook_small(gpu_pkg):
+    # testMulPoly, ring/ring_test.go:503-548
+    N, moduli = 64, [576460752303439873, 576460752303702017]
+    ctx = gpu_pkg.ring.NewContextWithParams(N, moduli)
+    a = gpu_pkg.sampling.uniform_poly(moduli, N, 1, seed=5)[0]
+    b = gpu_pkg.sampling.uniform_poly(moduli, N, 1, seed=6)[0]
+    pa, pb, pc = ctx.NewPoly().set(a), ctx.NewPoly().set(b), ctx.NewPoly()
+    ctx.MForm(pa, pa)
+    ctx.MulPolyMontgomery(pa, pb, pc)
+    got = pc.get()
+    for i, q in enumerate(moduli):
+        want = [0] * N
+        for x in range(N):
+            for y in range(N):
+                k = x + y
+                t = int(a[i, x]) * int(b[i, y])
+                if k < N:
+                    want[k] = (want[k] + t) % q
+                else:
+                    want[k - N] = (want[k - N] - t) % q
+        assert [int(v) for v in got[i]] == want
+
+
+@pytest.mark.parametrize("nq,np_,logn", [(2, 2, 12), (16, 16, 12), (3, 18, 10), (6, 6, 13), (18, 3, 11)])
+def test_modup(gpu_pkg, oracle, nq, np_, logn):
+    N = 1 << logn
+    Q, P = list(gpu_pkg.params.Qi60()[-nq:]), list(gpu_pkg.params.Pi60()[-np_:])
+    ring = gpu_pkg.ring
+    cQ, cP = ring.NewContextWithParams(N, Q), ring.NewContextWithParams(N, P)
+    be = ring.NewFastBasisExtender(cQ, cP)
+    obe = oracle.BasisExtender(oracle.Context(N, Q), oracle.Context(N, P))
+    assert np.array_equal(be.ModDownParamsPQ(), obe.moddown_params_pq)
+    assert np.array_equal(be.ModDownParamsQP(), obe.moddown_params_qp)
+    x = gpu_pkg.sampling.uniform_poly(Q, N, 2, seed=nq)
+    px, pp = cQ.NewPoly(2).set(x), cP.NewPoly(2)
+    be.ModUpSplitQP(nq - 1, px, pp)
+    got = pp.get()
+    for b in range(2):
+        assert np.array_equal(got[b], obe.modup_split_qp(nq - 1, x[b]))
+    y = gpu_pkg.sampling.uniform_poly(P, N, 2, seed=np_ + 50)
+    py, pq = cP.NewPoly(2).set(y), cQ.NewPoly(2)
+    be.ModUpSplitPQ(np_ - 1, py, pq)
+    got = pq.get()
+    for b in range(2):
+        assert np.array_equal(got[b], obe.modup_split_pq(np_ - 1, y[b]))
+    if nq > 2:   # a lower level uses fewer input limbs with the full-basis tables (reference behaviour)
+        be.ModUpSplitQP(nq - 2, px, pp)
+        assert np.array_equal(pp.get()[0], obe.modup_split_qp(nq - 2, x[0]))
+
+
+@pytest.mark.parametrize("nq,np_,level", [(4, 2, 3), (4, 2, 1), (18, 3, 17)])
+def test_moddown_variants(gpu_pkg, oracle, nq, np_, level):
+    N = 1 << 11
+    Q, P = list(gpu_pkg.params.Qi60()[-nq:]), list(gpu_pkg.params.Pi60()[-np_:])
+    ring = gpu_pkg.ring
+    cQ, cP = ring.NewContextWithParams(N, Q), ring.NewContextWithParams(N, P)
+    be = ring.NewFastBasisExtender(cQ, cP)
+    ocQ, ocP = oracle.Context(N, Q), oracle.Context(N, P)
+    obe = oracle.BasisExtender(ocQ, ocP)
+    xq = gpu_pkg.sampling.uniform_poly(Q, N, 2, seed=1)
+    xp = gpu_pkg.sampling.uniform_poly(P, N, 2, seed=2)
+    pq, pp, out = cQ.NewPoly(2).set(xq), cP.NewPoly(2).set(xp), cQ.NewPolyLvl(level, 2)
+    be.ModDownSplitedPQ(level, pq, pp, out)
+    for b in range(2):
+        assert np.array_equal(out.get()[b], obe.moddown_split_pq(level, xq[b], xp[b]))
+    be.ModDownSplitedNTTPQ(level, pq, pp, out)
+    for b in range(2):
+        assert np.array_equal(out.get()[b], obe.moddown_split_ntt_pq(level, xq[b], xp[b]))
+        assert np.array_equal(pp.get()[b], ocP.intt(xp[b]))       # p1P is left in the coefficient domain
+    # joined forms
+    joined = np.concatenate([xq, xp], axis=1)
+    pj = ring.Poly(cQ, nq + np_, 2).set(joined)
+    be.ModDownNTTPQ(level, pj, out)
+    for b in range(2):
+        assert np.array_equal(out.get()[b], obe.moddown_ntt_pq(level, joined[b]))
+    joined_lvl = np.concatenate([xq[:, :level + 1], xp], axis=1)
+    pjl = ring.Poly(cQ, level + 1 + np_, 2).set(joined_lvl)
+    be.ModDownPQ(level, pjl, out)
+    for b in range(2):
+        assert np.array_equal(out.get()[b], obe.moddown_pq(level, joined_lvl[b]))
+    # divide by Q, result over P (bfv/evaluator.go:450)
+    outp = cP.NewPoly(2)
+    be.ModDownSplitedQP(level, np_ - 1, pq, cP.NewPoly(2).set(xp), outp)
+    for b in range(2):
+        assert np.array_equal(outp.get()[b], obe.moddown_split_qp(level, np_ - 1, xq[b], xp[b]))
+
+
+@pytest.mark.parametrize("nq,np_,level", [(6, 2, 5), (6, 2, 4), (6, 2, 2), (7, 3, 6), (7, 3, 3), (5, 1, 4), (18, 3, 17),
+                                          (18, 3, 9)])
+def test_decomposer(gpu_pkg, oracle, nq, np_, level):
+    N = 1 << 10
+    Q, P = list(gpu_pkg.params.Qi60()[-nq:]), list(gpu_pkg.params.Pi60()[-np_:])
+    ring = gpu_pkg.ring
+    cQ, cP = ring.NewContextWithParams(N, Q), ring.NewContextWithParams(N, P)
+    dec = ring.NewDecomposer(cQ, cP)
+    odec = oracle.Decomposer(Q, P)
+    x = gpu_pkg.sampling.uniform_poly(Q, N, 2, seed=level)
+    px = cQ.NewPoly(2).set(x)
+    beta = -(-(level + 1) // np_)
+    for crt in range(beta):
+        oq, op = cQ.NewPolyLvl(level, 2), cP.NewPoly(2)
+        dec.DecomposeAndSplit(level, crt, px, oq, op)
+        oj = ring.Poly(cQ, level + 1 + np_, 2)
+        dec.Decompose(level, crt, px, oj)
+        for b in range(2):
+            wq, wp = odec.decompose_and_split(level, crt, x[b])
+            assert np.array_equal(oq.get()[b], wq), (crt, b)
+            assert np.array_equal(op.get()[b], wp), (crt, b)
+            assert np.array_equal(oj.get()[b], odec.decompose(level, crt, x[b])), (crt, b)
+
+
+@pytest.mark.parametrize("name", ["DivFloorByLastModulusNTT", "DivFloorByLastModulus", "DivRoundByLastModulusNTT",
+                                  "DivRoundByLastModulus"])
+@pytest.mark.parametrize("logn", [10, 12])
+def test_rescale(gpu_pkg, oracle, name, logn):
+    N = 1 << logn
+    _, Q, _ = gpu_pkg.params.ckks_moduli("PN15QP880")      # 50-bit q0, 40-bit q1..: mixed sizes (values >= q_i occur)
+    Q = Q[:5]
+    ctx = gpu_pkg.ring.NewContextWithParams(N, Q)
+    oc = oracle.Context(N, Q)
+    x = gpu_pkg.sampling.uniform_poly(Q, N, 2, seed=9)
+    p = ctx.NewPoly(2).set(x)
+    getattr(ctx, name)(p)
+    oname = {"DivFloorByLastModulusNTT": "oc_div_floor_by_last_modulus_ntt", "DivFloorByLastModulus": "oc_div_floor_by_last_modulus",
+             "DivRoundByLastModulusNTT": "oc_div_round_by_last_modulus_ntt", "DivRoundByLastModulus": "oc_div_round_by_last_modulus"}[name]
+    assert p.GetLenModuli() == len(Q) - 1                  # p0.Coeffs = p0.Coeffs[:level]
+    got = p.get()
+    for b in range(2):
+        assert np.array_equal(got[b], oc.rescale_op(oname, x[b])), name
+    # a second rescale on the shrunk poly
+    getattr(ctx, name)(p)
+    got = p.get()
+    for b in range(2):
+        assert np.array_equal(got[b], oc.rescale_op(oname, oc.rescale_op(oname, x[b])))
+
+
+@pytest.mark.parametrize("ntt", [False, True])
+@pytest.mark.parametrize("rounding", ["Floor", "Round"])
+def test_rescale_many(gpu_pkg, oracle, ntt, rounding):
+    N = 1 << 11
+    Q = list(gpu_pkg.params.Qi60()[-5:])
+    ctx = gpu_pkg.ring.NewContextWithParams(N, Q)
+    oc = oracle.Context(N, Q)
+    x = gpu_pkg.sampling.uniform_poly(Q, N, 2, seed=4)
+    p = ctx.NewPoly(2).set(x)
+    getattr(ctx, "Div%sByLastModulusMany%s" % (rounding, "NTT" if ntt else ""))(p, 3)
+    got = p.get()
+    for b in range(2):
+        assert np.array_equal(got[b], oc.rescale_op("oc_div_%s_by_last_modulus_many" % rounding.lower(), x[b], nb=3, ntt=ntt))

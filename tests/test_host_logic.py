@@ -1,0 +1,40 @@
+"""Host-side logic that needs no device: parameter generation, sampling, sharding."""
+import numpy as np
+
+import bench
+
+
+def test_sampling_is_reproducible_and_in_range(pkg):
+    mod = list(pkg.params.Qi60()[-2:]) + [1099512938497]
+    a = pkg.sampling.uniform_poly(mod, 512, batch=3, seed=7)
+    b = pkg.sampling.uniform_poly(mod, 512, batch=3, seed=7)
+    assert np.array_equal(a, b)
+    for i, q in enumerate(mod):
+        assert int(a[:, i].max()) < q
+    assert not np.array_equal(a[0], a[1])
+    # uses the top bits too: mean close to q/2
+    assert abs(float(a[:, 0].astype(np.float64).mean()) / mod[0] - 0.5) < 0.05
+
+
+def test_ring_presets(pkg):
+    N, Q = pkg.params.DefaultParamsQi(15)
+    assert N == 1 << 15 and len(Q) == 16 and Q[-1] == 1152921504050839553
+    N, P = pkg.params.DefaultParamsPi(14)
+    assert N == 1 << 14 and len(P) == 8
+
+
+def test_shard_units_partitions_the_batch():
+    for total in (1, 7, 256, 1024):
+        for world in (1, 2, 3, 8):
+            parts = [bench.shard_units(total, r, world) for r in range(world)]
+            assert sum(n for _, n in parts) == total
+            pos = 0
+            for start, n in parts:
+                assert start == pos
+                pos += n
+            assert max(n for _, n in parts) - min(n for _, n in parts) <= 1
+
+
+def test_algorithmic_bytes():
+    # limb-NTT = 16*N bytes; R15 poly-NTT = 8 MiB
+    assert bench.ntt_bytes(1 << 15, 16) == 8 << 20
