@@ -90,7 +90,7 @@ def cpu_baseline_ntt(N, moduli, target_seconds=12.0):
     one(0)
     t_one = time.perf_counter() - t0
     per_thread = max(1, int(target_seconds / max(t_one, 1e-6)))
-    per_thread = min(per_thread, 64)
+    per_thread = min(per_thread, 8192)
 
     def work(i):
         for _ in range(per_thread):

@@ -7,7 +7,9 @@
 #include <hip/hip_runtime.h>
 
 #include <cstring>
+#include <map>
 #include <memory>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -47,10 +49,22 @@ int to_device(T **dst, const T *src, size_t count) {
     return LR_OK;
 }
 
-unsigned log2_exact(u64 n) {
-    unsigned l = 0;
-    while ((1ull << l) < n) ++l;
-    return l;
+// One stream per device, shared by every handle on that device and never destroyed: operations of
+// related handles (contextQ / contextP / basis extender / plan) are ordered by construction, and a
+// poly can be released safely whatever order a garbage-collected host language frees handles in.
+hipStream_t shared_stream(int device) {
+    static std::mutex mu;
+    static std::map<int, hipStream_t> streams;
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = streams.find(device);
+    if (it != streams.end()) return it->second;
+    hipStream_t s = nullptr;
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    streams[device] = s;
+    return s;
 }
 
 }  // namespace
@@ -60,8 +74,7 @@ unsigned log2_exact(u64 n) {
 // ------------------------------------------------------------------------------------------
 struct lr_context {
     int device = 0;
-    hipStream_t own_stream = nullptr;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;  // the device's shared stream unless lr_context_set_stream replaced it
     HostContext h;
     LimbParams *d_lp = nullptr;
     Twiddle *d_fwd = nullptr;
@@ -73,13 +86,16 @@ struct lr_context {
 };
 
 struct lr_poly {
-    lr_context *ctx = nullptr;
+    lr_context *ctx = nullptr;     // creator; only dereferenced while the caller holds it (operations), never on free
+    int device = 0;
+    u64 N = 0;
+    hipStream_t stream = nullptr;  // the creator's stream at allocation time
     u64 *d = nullptr;
     bool owned = false;
     int limbs = 0;        // logical limb count (rescale shrinks it)
     int alloc_limbs = 0;  // stride, fixed at allocation
     int batch = 0;
-    long long stride() const { return (long long)alloc_limbs * (long long)ctx->h.N; }
+    long long stride() const { return (long long)alloc_limbs * (long long)N; }
 };
 
 namespace {
@@ -138,6 +154,7 @@ struct Pool {
 }  // namespace
 
 struct lr_bext {
+    int device = 0;
     lr_context *cQ = nullptr, *cP = nullptr;
     DevModup qp, pq;
     std::vector<u64> moddown_pq, moddown_qp;  // host copies (Montgomery form)
@@ -150,6 +167,7 @@ struct lr_bext {
 };
 
 struct lr_decomposer {
+    int device = 0;
     lr_context *cQ = nullptr, *cP = nullptr;
     int nQ = 0, nP = 0, alpha = 0, beta = 0;
     std::vector<int> xalpha;
@@ -157,6 +175,7 @@ struct lr_decomposer {
 };
 
 struct lr_ckks_plan {
+    int device = 0;
     lr_context *cQ = nullptr, *cP = nullptr;
     lr_bext *bext = nullptr;
     lr_decomposer *dec = nullptr;
@@ -199,8 +218,8 @@ extern "C" int lr_context_create(uint64_t N, const uint64_t *moduli, int n_modul
         if (q >> 61) return fail(LR_ERR_UNSUPPORTED, "modulus must be below 2^61 (the reference's lazy NTT has the same limit)");
     c->device = device;
     LR_HIP(hipSetDevice(device));
-    LR_HIP(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
-    c->stream = c->own_stream;
+    c->stream = shared_stream(device);
+    if (!c->stream) return fail(LR_ERR_HIP, "could not create the device stream");
     LR_HIP(hipEventCreate(&c->ev0));
     LR_HIP(hipEventCreate(&c->ev1));
 
@@ -236,19 +255,18 @@ extern "C" int lr_context_create(uint64_t N, const uint64_t *moduli, int n_modul
 extern "C" int lr_context_destroy(lr_context *c) {
     if (!c) return LR_OK;
     (void)hipSetDevice(c->device);
-    if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
+    (void)hipStreamSynchronize(shared_stream(c->device));
     for (void *p : {(void *)c->d_lp, (void *)c->d_fwd, (void *)c->d_inv, (void *)c->d_rescale, (void *)c->scratch})
         if (p) (void)hipFree(p);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
-    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
     return LR_OK;
 }
 
 extern "C" int lr_context_set_stream(lr_context *c, void *hip_stream) {
     if (!c) return fail(LR_ERR_ARG, "null context");
-    c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    c->stream = hip_stream ? (hipStream_t)hip_stream : shared_stream(c->device);
     return LR_OK;
 }
 
@@ -308,6 +326,9 @@ extern "C" int lr_poly_alloc(lr_context *c, int limbs, int batch, lr_poly **out)
     LR_HIP(hipSetDevice(c->device));
     std::unique_ptr<lr_poly> p(new lr_poly());
     p->ctx = c;
+    p->device = c->device;
+    p->N = c->h.N;
+    p->stream = c->stream;
     p->limbs = p->alloc_limbs = limbs;
     p->batch = batch;
     p->owned = true;
@@ -325,6 +346,9 @@ extern "C" int lr_poly_wrap(lr_context *c, void *device_ptr, int limbs, int batc
     if (((uintptr_t)device_ptr & 15) != 0) return fail(LR_ERR_ARG, "device pointer must be 16-byte aligned");
     lr_poly *p = new lr_poly();
     p->ctx = c;
+    p->device = c->device;
+    p->N = c->h.N;
+    p->stream = c->stream;
     p->d = (u64 *)device_ptr;
     p->limbs = p->alloc_limbs = limbs;
     p->batch = batch;
@@ -336,9 +360,10 @@ extern "C" int lr_poly_wrap(lr_context *c, void *device_ptr, int limbs, int batc
 extern "C" int lr_poly_free(lr_poly *p) {
     if (!p) return LR_OK;
     if (p->owned && p->d) {
-        (void)hipSetDevice(p->ctx->device);
-        (void)hipStreamSynchronize(p->ctx->stream);
+        (void)hipSetDevice(p->device);
+        (void)hipStreamSynchronize(shared_stream(p->device));
         (void)hipFree(p->d);
+        (void)hipGetLastError();
     }
     delete p;
     return LR_OK;
@@ -346,7 +371,7 @@ extern "C" int lr_poly_free(lr_poly *p) {
 
 extern "C" int lr_poly_info(const lr_poly *p, uint64_t *N, int *limbs, int *batch, void **device_ptr) {
     if (!p) return fail(LR_ERR_ARG, "null poly");
-    if (N) *N = p->ctx->h.N;
+    if (N) *N = p->N;
     if (limbs) *limbs = p->limbs;
     if (batch) *batch = p->batch;
     if (device_ptr) *device_ptr = p->d;
@@ -362,8 +387,8 @@ extern "C" int lr_poly_set_limbs(lr_poly *p, int limbs) {
 
 extern "C" int lr_poly_zero(lr_poly *p) {
     if (!p) return fail(LR_ERR_ARG, "null poly");
-    LR_HIP(hipSetDevice(p->ctx->device));
-    LR_HIP(hipMemsetAsync(p->d, 0, (size_t)p->batch * p->stride() * sizeof(u64), p->ctx->stream));
+    LR_HIP(hipSetDevice(p->device));
+    LR_HIP(hipMemsetAsync(p->d, 0, (size_t)p->batch * p->stride() * sizeof(u64), p->stream));
     return LR_OK;
 }
 
@@ -371,15 +396,14 @@ extern "C" int lr_poly_upload(lr_poly *p, int batch_index, const uint64_t *const
     if (!p || !limb_ptrs) return fail(LR_ERR_ARG, "null argument");
     if (batch_index < 0 || batch_index >= p->batch || limbs < 0 || limbs > p->limbs)
         return fail(LR_ERR_SHAPE, "upload: batch index or limb count out of range");
-    lr_context *c = p->ctx;
-    LR_HIP(hipSetDevice(c->device));
-    const size_t row = c->h.N * sizeof(u64);
+    LR_HIP(hipSetDevice(p->device));
+    const size_t row = p->N * sizeof(u64);
     for (int i = 0; i < limbs; ++i) {
         if (!limb_ptrs[i]) return fail(LR_ERR_ARG, "null limb pointer");
-        LR_HIP(hipMemcpyAsync(p->d + batch_index * p->stride() + (long long)i * c->h.N, limb_ptrs[i], row,
-                              hipMemcpyHostToDevice, c->stream));
+        LR_HIP(hipMemcpyAsync(p->d + batch_index * p->stride() + (long long)i * p->N, limb_ptrs[i], row,
+                              hipMemcpyHostToDevice, p->stream));
     }
-    LR_HIP(hipStreamSynchronize(c->stream));
+    LR_HIP(hipStreamSynchronize(p->stream));
     return LR_OK;
 }
 
@@ -387,24 +411,22 @@ extern "C" int lr_poly_download(const lr_poly *p, int batch_index, uint64_t *con
     if (!p || !limb_ptrs) return fail(LR_ERR_ARG, "null argument");
     if (batch_index < 0 || batch_index >= p->batch || limbs < 0 || limbs > p->limbs)
         return fail(LR_ERR_SHAPE, "download: batch index or limb count out of range");
-    lr_context *c = p->ctx;
-    LR_HIP(hipSetDevice(c->device));
-    const size_t row = c->h.N * sizeof(u64);
+    LR_HIP(hipSetDevice(p->device));
+    const size_t row = p->N * sizeof(u64);
     for (int i = 0; i < limbs; ++i) {
         if (!limb_ptrs[i]) return fail(LR_ERR_ARG, "null limb pointer");
-        LR_HIP(hipMemcpyAsync(limb_ptrs[i], p->d + batch_index * p->stride() + (long long)i * c->h.N, row,
-                              hipMemcpyDeviceToHost, c->stream));
+        LR_HIP(hipMemcpyAsync(limb_ptrs[i], p->d + batch_index * p->stride() + (long long)i * p->N, row,
+                              hipMemcpyDeviceToHost, p->stream));
     }
-    LR_HIP(hipStreamSynchronize(c->stream));
+    LR_HIP(hipStreamSynchronize(p->stream));
     return LR_OK;
 }
 
 static int dense_copy(const lr_poly *p, u64 *host, const u64 *host_src, size_t count) {
-    lr_context *c = p->ctx;
-    const size_t N = c->h.N;
+    const size_t N = p->N;
     if (count != (size_t)p->batch * p->limbs * N) return fail(LR_ERR_SHAPE, "dense copy: element count != batch*limbs*N");
-    LR_HIP(hipSetDevice(c->device));
-    LR_HIP(hipStreamSynchronize(c->stream));
+    LR_HIP(hipSetDevice(p->device));
+    LR_HIP(hipStreamSynchronize(p->stream));
     // logical limbs per poly; the device stride is larger after a rescale re-sliced the poly
     const size_t chunk = (size_t)p->limbs * N;
     const int pieces = p->limbs == p->alloc_limbs ? 1 : p->batch;
@@ -466,7 +488,7 @@ int run_ntt(lr_context *c, bool inverse, Rows in, Rows out, int mod0, int mod_st
 
 int check_pair(const lr_context *c, int level, const lr_poly *in, const lr_poly *out) {
     if (!c || !in || !out) return fail(LR_ERR_ARG, "null argument");
-    if (in->ctx->h.N != c->h.N || out->ctx->h.N != c->h.N) return fail(LR_ERR_SHAPE, "ring degree mismatch");
+    if (in->N != c->h.N || out->N != c->h.N) return fail(LR_ERR_SHAPE, "ring degree mismatch");
     if (level < 0 || level + 1 > c->h.L()) return fail(LR_ERR_SHAPE, "level exceeds the context's modulus count");
     if (level + 1 > in->limbs || level + 1 > out->limbs) return fail(LR_ERR_SHAPE, "poly has fewer limbs than level+1");
     if (in->batch != out->batch && in->batch != 1) return fail(LR_ERR_SHAPE, "batch mismatch");
@@ -670,6 +692,7 @@ extern "C" int lr_bext_create(lr_context *cQ, lr_context *cP, lr_bext **out) {
     std::unique_ptr<lr_bext> b(new lr_bext());
     b->cQ = cQ;
     b->cP = cP;
+    b->device = cQ->device;
     LR_TRY(b->qp.init(cQ->h.q, cP->h.q));
     LR_TRY(b->pq.init(cP->h.q, cQ->h.q));
     b->moddown_pq = build_moddown(cQ->h, cP->h);  // genModDownParams(contextQ, contextP), ring_basis_extension.go:66
@@ -682,8 +705,8 @@ extern "C" int lr_bext_create(lr_context *cQ, lr_context *cP, lr_bext **out) {
 
 extern "C" int lr_bext_destroy(lr_bext *b) {
     if (!b) return LR_OK;
-    (void)hipSetDevice(b->cQ->device);
-    (void)hipStreamSynchronize(b->cQ->stream);
+    (void)hipSetDevice(b->device);
+    (void)hipStreamSynchronize(shared_stream(b->device));
     delete b;
     return LR_OK;
 }
@@ -813,6 +836,7 @@ extern "C" int lr_decomposer_create(lr_context *cQ, lr_context *cP, lr_decompose
     std::unique_ptr<lr_decomposer> d(new lr_decomposer());
     d->cQ = cQ;
     d->cP = cP;
+    d->device = cQ->device;
     const std::vector<u64> &Q = cQ->h.q, &P = cP->h.q;
     d->nQ = (int)Q.size();
     d->nP = (int)P.size();
@@ -837,8 +861,8 @@ extern "C" int lr_decomposer_create(lr_context *cQ, lr_context *cP, lr_decompose
 
 extern "C" int lr_decomposer_destroy(lr_decomposer *d) {
     if (!d) return LR_OK;
-    (void)hipSetDevice(d->cQ->device);
-    (void)hipStreamSynchronize(d->cQ->stream);
+    (void)hipSetDevice(d->device);
+    (void)hipStreamSynchronize(shared_stream(d->device));
     delete d;
     return LR_OK;
 }
@@ -924,7 +948,7 @@ int ensure_scratch(lr_context *c, size_t words) {
 
 int check_rescale(lr_context *c, lr_poly *p0) {
     if (!c || !p0) return fail(LR_ERR_ARG, "null argument");
-    if (p0->ctx->h.N != c->h.N) return fail(LR_ERR_SHAPE, "ring degree mismatch");
+    if (p0->N != c->h.N) return fail(LR_ERR_SHAPE, "ring degree mismatch");
     if (p0->limbs < 2) return fail(LR_ERR_SHAPE, "cannot divide by the last modulus of a 1-limb polynomial");
     if (p0->limbs > c->h.L()) return fail(LR_ERR_SHAPE, "poly has more limbs than the context has moduli");
     return LR_OK;
@@ -1044,6 +1068,7 @@ extern "C" int lr_ckks_plan_create(lr_context *cQ, lr_context *cP, int max_batch
     std::unique_ptr<lr_ckks_plan> p(new lr_ckks_plan());
     p->cQ = cQ;
     p->cP = cP;
+    p->device = cQ->device;
     p->max_batch = max_batch;
     LR_TRY(lr_bext_create(cQ, cP, &p->bext));
     int rc = lr_decomposer_create(cQ, cP, &p->dec);
@@ -1057,8 +1082,8 @@ extern "C" int lr_ckks_plan_create(lr_context *cQ, lr_context *cP, int max_batch
 
 extern "C" int lr_ckks_plan_destroy(lr_ckks_plan *p) {
     if (!p) return LR_OK;
-    (void)hipSetDevice(p->cQ->device);
-    (void)hipStreamSynchronize(p->cQ->stream);
+    (void)hipSetDevice(p->device);
+    (void)hipStreamSynchronize(shared_stream(p->device));
     lr_bext_destroy(p->bext);
     lr_decomposer_destroy(p->dec);
     delete p;
@@ -1155,7 +1180,7 @@ int switch_keys_core(lr_ckks_plan *pl, int level, int batch, const u64 *cx, long
 
 int check_ct(const lr_ckks_plan *pl, int level, const lr_poly *p, int batch) {
     if (!p) return fail(LR_ERR_ARG, "null poly");
-    if (p->ctx->h.N != pl->cQ->h.N) return fail(LR_ERR_SHAPE, "ring degree mismatch");
+    if (p->N != pl->cQ->h.N) return fail(LR_ERR_SHAPE, "ring degree mismatch");
     if (p->limbs < level + 1) return fail(LR_ERR_SHAPE, "poly has fewer limbs than level+1");
     if (p->batch != batch) return fail(LR_ERR_SHAPE, "batch mismatch");
     return LR_OK;

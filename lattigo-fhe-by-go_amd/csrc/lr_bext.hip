@@ -51,6 +51,7 @@ __global__ __launch_bounds__(256) void ext_kernel(ExtLaunch L) {
 template <int NIN>
 static hipError_t launch_n(const ExtLaunch &L, int batch, hipStream_t stream) {
     const dim3 grid((unsigned)((L.n + 255) / 256), (unsigned)batch), block(256);
+    (void)hipGetLastError();  // drop stale (non-sticky) errors of unrelated earlier calls
     hipLaunchKernelGGL(ext_kernel<NIN>, grid, block, 0, stream, L);
     return hipGetLastError();
 }

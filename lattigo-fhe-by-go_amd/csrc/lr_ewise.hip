@@ -79,6 +79,7 @@ static hipError_t launch_one(const EwiseLaunch &L, int limbs, int batch, hipStre
     if (gx > 64) gx = 64;
     if (gx < 1) gx = 1;
     const dim3 grid((unsigned)gx, (unsigned)limbs, (unsigned)batch), block(256);
+    (void)hipGetLastError();  // drop stale (non-sticky) errors of unrelated earlier calls
     hipLaunchKernelGGL(ewise_kernel<OP>, grid, block, 0, stream, L);
     return hipGetLastError();
 }
@@ -150,6 +151,7 @@ hipError_t launch_submul(const SubMulLaunch &L, int limbs, int batch, hipStream_
     if (gx > 64) gx = 64;
     if (gx < 1) gx = 1;
     const dim3 grid((unsigned)gx, (unsigned)limbs, (unsigned)batch), block(256);
+    (void)hipGetLastError();  // drop stale (non-sticky) errors of unrelated earlier calls
     hipLaunchKernelGGL(submul_kernel, grid, block, 0, stream, L);
     return hipGetLastError();
 }
@@ -176,6 +178,7 @@ hipError_t launch_rowadd(const RowAddLaunch &L, int rows, int batch, hipStream_t
     int gx = (L.n + 255) / 256;
     if (gx > 64) gx = 64;
     const dim3 grid((unsigned)gx, (unsigned)rows, (unsigned)batch), block(256);
+    (void)hipGetLastError();  // drop stale (non-sticky) errors of unrelated earlier calls
     hipLaunchKernelGGL(rowadd_kernel, grid, block, 0, stream, L);
     return hipGetLastError();
 }

@@ -337,6 +337,7 @@ static hipError_t launch_big(const NttLaunch &a, bool inverse, hipStream_t strea
         configured[inverse ? 1 : 0] = true;
     }
     const dim3 grid((unsigned)(a.n_items * a.batch)), block(1u << P::LOGT);
+    (void)hipGetLastError();  // drop stale (non-sticky) errors of unrelated earlier calls
     if (inverse)
         hipLaunchKernelGGL(inv, grid, block, lds_bytes, stream, a);
     else
@@ -355,7 +356,8 @@ hipError_t launch_ntt(const NttLaunch &a, int logn, bool inverse, hipStream_t st
     }
     if (logn >= 1 && logn <= 11) {
         const dim3 grid((unsigned)(a.n_items * a.batch)), block(256);
-        hipLaunchKernelGGL(ntt_small_kernel, grid, block, sizeof(u64) << logn, stream, a, logn, inverse ? 1 : 0);
+        (void)hipGetLastError();  // drop stale (non-sticky) errors of unrelated earlier calls
+    hipLaunchKernelGGL(ntt_small_kernel, grid, block, sizeof(u64) << logn, stream, a, logn, inverse ? 1 : 0);
         return hipGetLastError();
     }
     return hipErrorInvalidValue;
