@@ -6,6 +6,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -79,10 +80,13 @@ struct lr_context {
     LimbParams *d_lp = nullptr;
     Twiddle *d_fwd = nullptr;
     Twiddle *d_inv = nullptr;
+    Twiddle *d_fwd_fin = nullptr;  // lane-transposed tables of the last four stages, [L][15][N/16]
+    Twiddle *d_inv_fin = nullptr;
     u64 *d_rescale = nullptr;   // [L][L]
     u64 *scratch = nullptr;     // rescale temporaries, grown on demand
     size_t scratch_words = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    int ntt_mode = 0;           // lazy-correction cadence allowed by the largest modulus (lr_ntt.hip)
 };
 
 struct lr_poly {
@@ -217,6 +221,12 @@ extern "C" int lr_context_create(uint64_t N, const uint64_t *moduli, int n_modul
     for (u64 q : c->h.q)
         if (q >> 61) return fail(LR_ERR_UNSUPPORTED, "modulus must be below 2^61 (the reference's lazy NTT has the same limit)");
     c->device = device;
+    {
+        u64 qmax = 0;
+        for (u64 q : c->h.q) qmax = q > qmax ? q : qmax;
+        c->ntt_mode = qmax < (1ull << 57) ? 2 : (qmax <= (1ull << 60) ? 1 : 0);
+        if (const char *force = std::getenv("LR_NTT_MODE")) c->ntt_mode = std::atoi(force) < c->ntt_mode ? std::atoi(force) : c->ntt_mode;
+    }
     LR_HIP(hipSetDevice(device));
     c->stream = shared_stream(device);
     if (!c->stream) return fail(LR_ERR_HIP, "could not create the device stream");
@@ -245,6 +255,21 @@ extern "C" int lr_context_create(uint64_t N, const uint64_t *moduli, int n_modul
         }
     }
     LR_TRY(to_device(&c->d_lp, lp.data(), lp.size()));
+    if (N >= 4096) {
+        const size_t blocks = N >> 4;
+        std::vector<Twiddle> ffin((size_t)L * 15 * blocks), ifin((size_t)L * 15 * blocks);
+        for (int i = 0; i < L; ++i)
+            for (int cc = 0; cc < 4; ++cc)
+                for (int j = 0; j < (1 << cc); ++j)
+                    for (size_t bk = 0; bk < blocks; ++bk) {
+                        const size_t src = (size_t)i * N + (((blocks + bk) << cc) + j);
+                        const size_t dst = ((size_t)i * 15 + ((1u << cc) - 1 + j)) * blocks + bk;
+                        ffin[dst] = fwd[src];
+                        ifin[dst] = inv[src];
+                    }
+        LR_TRY(to_device(&c->d_fwd_fin, ffin.data(), ffin.size()));
+        LR_TRY(to_device(&c->d_inv_fin, ifin.data(), ifin.size()));
+    }
     LR_TRY(to_device(&c->d_fwd, fwd.data(), fwd.size()));
     LR_TRY(to_device(&c->d_inv, inv.data(), inv.size()));
     LR_TRY(to_device(&c->d_rescale, c->h.rescale.data(), c->h.rescale.size()));
@@ -256,7 +281,7 @@ extern "C" int lr_context_destroy(lr_context *c) {
     if (!c) return LR_OK;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(shared_stream(c->device));
-    for (void *p : {(void *)c->d_lp, (void *)c->d_fwd, (void *)c->d_inv, (void *)c->d_rescale, (void *)c->scratch})
+    for (void *p : {(void *)c->d_lp, (void *)c->d_fwd, (void *)c->d_inv, (void *)c->d_fwd_fin, (void *)c->d_inv_fin, (void *)c->d_rescale, (void *)c->scratch})
         if (p) (void)hipFree(p);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -482,7 +507,8 @@ int run_ntt(lr_context *c, bool inverse, Rows in, Rows out, int mod0, int mod_st
     a.batch = batch;
     a.lp = c->d_lp;
     a.tw = inverse ? c->d_inv : c->d_fwd;
-    LR_HIP(launch_ntt(a, (int)logn, inverse, c->stream));
+    a.tw_fin = inverse ? c->d_inv_fin : c->d_fwd_fin;
+    LR_HIP(launch_ntt(a, (int)logn, inverse, c->ntt_mode, c->stream));
     return LR_OK;
 }
 

@@ -106,12 +106,36 @@ LR_HD u64 power_of_2(u64 x, u64 n, u64 q, u64 qinv) {
 // reference's bit for bit.  9 32-bit multiplies instead of MRedConstant's 11.
 // ---------------------------------------------------------------------------------------
 LR_HD u64 mul_shoup_lazy(u64 v, u64 w, u64 ws, u64 q) {
+    const u32 v0 = (u32)v, v1 = (u32)(v >> 32), s0 = (u32)ws, s1 = (u32)(ws >> 32);
 #if defined(__HIP_DEVICE_COMPILE__)
-    u32 v0 = (u32)v, v1 = (u32)(v >> 32), s0 = (u32)ws, s1 = (u32)(ws >> 32);
-    u64 qhat = (u64)v1 * s1 + (u64)__umulhi(v1, s0) + (u64)__umulhi(v0, s1);
+    const u64 qhat = (u64)v1 * s1 + (u64)__umulhi(v1, s0) + (u64)__umulhi(v0, s1);
+    // v*w - qhat*q (mod 2^64) as multiply-accumulate chains on the negated modulus: the 64-bit
+    // accumulate of v_mad_u64_u32 absorbs the additions (2 fewer VALU ops than mul/mul/sub)
+    const u64 nq = 0 - q;
+    const u32 w0 = (u32)w, w1 = (u32)(w >> 32), n0 = (u32)nq, n1 = (u32)(nq >> 32);
+    const u32 h0 = (u32)qhat, h1 = (u32)(qhat >> 32);
+    u64 acc = (u64)v0 * w0;
+    acc = (u64)h0 * n0 + acc;
+    u32 hi = (u32)(acc >> 32);
+    hi = (u32)((u64)v0 * w1 + hi);
+    hi = (u32)((u64)v1 * w0 + hi);
+    hi = (u32)((u64)h0 * n1 + hi);
+    hi = (u32)((u64)h1 * n0 + hi);
+    return ((u64)hi << 32) | (u32)acc;
 #else
-    u32 v0 = (u32)v, v1 = (u32)(v >> 32), s0 = (u32)ws, s1 = (u32)(ws >> 32);
-    u64 qhat = (u64)v1 * s1 + (((u64)v1 * s0) >> 32) + (((u64)v0 * s1) >> 32);
+    const u64 qhat = (u64)v1 * s1 + (((u64)v1 * s0) >> 32) + (((u64)v0 * s1) >> 32);
+    return v * w - qhat * q;
+#endif
+}
+
+// same contract, written as two low products and a subtraction: two more VALU ops but fewer live
+// 64-bit temporaries (used where the kernel is register-starved)
+LR_HD u64 mul_shoup_lazy_lowreg(u64 v, u64 w, u64 ws, u64 q) {
+    const u32 v0 = (u32)v, v1 = (u32)(v >> 32), s0 = (u32)ws, s1 = (u32)(ws >> 32);
+#if defined(__HIP_DEVICE_COMPILE__)
+    const u64 qhat = (u64)v1 * s1 + (u64)__umulhi(v1, s0) + (u64)__umulhi(v0, s1);
+#else
+    const u64 qhat = (u64)v1 * s1 + (((u64)v1 * s0) >> 32) + (((u64)v0 * s1) >> 32);
 #endif
     return v * w - qhat * q;
 }

@@ -38,6 +38,7 @@ struct NttLaunch {
     int batch;
     const LimbParams *lp;       // [L]
     const Twiddle *tw;          // [L][N] forward or inverse table
+    const Twiddle *tw_fin;      // [L][15][N/16] lane-transposed copy of the last four stages (N >= 2^12), or null
 };
 
 // ---- coefficient-wise launches (lr_ewise.hip) ----
@@ -105,7 +106,8 @@ struct ExtLaunch {
 };
 
 // host launchers (defined next to their kernels)
-hipError_t launch_ntt(const NttLaunch &a, int logn, bool inverse, hipStream_t stream);
+// mode: lazy-correction cadence of the forward butterflies (lr_ntt.hip): 0 = q < 2^61, 1 = q <= 2^60, 2 = q < 2^57
+hipError_t launch_ntt(const NttLaunch &a, int logn, bool inverse, int mode, hipStream_t stream);
 hipError_t launch_ewise(int op, const EwiseLaunch &L, int limbs, int batch, hipStream_t stream);
 hipError_t launch_submul(const SubMulLaunch &L, int limbs, int batch, hipStream_t stream);
 hipError_t launch_rowadd(const RowAddLaunch &L, int rows, int batch, hipStream_t stream);

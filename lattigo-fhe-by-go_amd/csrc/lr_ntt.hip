@@ -21,66 +21,102 @@
 namespace lr {
 
 // ------------------------------------------------------------------------------------------
-// butterflies.  Forward keeps values in [0, 8q), inverse in [0, 4q); q < 2^61 so 8q < 2^64.
+// butterflies.
+//
+// Forward (Cooley-Tukey): X = U + V*w, Y = U - V*w + 4q with V*w in [0,4q) for ANY 64-bit V
+// (mul_shoup_lazy), so every stage grows the bound of a value by at most 4q and only U ever
+// needs correcting.  How often depends on the head-room above q (MODE, chosen per context):
+//   MODE 0  q < 2^61 : cond-subtract 4q before every stage          values stay in [0, 8q)
+//   MODE 1  q <= 2^60: cond-subtract 8q before every second stage   values stay in [0, 16q)
+//   MODE 2  q < 2^57 : never (at most 4*logN+1 <= 65 multiples of q accumulate < 2^64)
+// Inverse (Gentleman-Sande): X = U + V doubles the bound, so it is corrected every stage:
+// values stay in [0, 4q).
 // ------------------------------------------------------------------------------------------
-LR_D void fwd_bfly(u64 &U, u64 &V, u64 w, u64 ws, u64 q, u64 q4) {
-    const u64 u = U >= q4 ? U - q4 : U;            // [0,4q)
-    const u64 v = mul_shoup_lazy(V, w, ws, q);     // [0,4q) for any 64-bit V
-    U = u + v;                                     // [0,8q)
-    V = u + q4 - v;                                // (0,8q)
+template <int MODE, bool LOWREG = false>
+LR_D void fwd_bfly(u64 &U, u64 &V, u64 w, u64 ws, u64 q, u64 q4, bool correct) {
+    u64 u = U;
+    if (MODE == 0) {
+        u = u >= q4 ? u - q4 : u;                  // [0,8q) -> [0,4q)
+    } else if (MODE == 1) {
+        const u64 q8 = q4 << 1;
+        if (correct) u = u >= q8 ? u - q8 : u;     // [0,16q) -> [0,8q)
+    }
+    const u64 v = LOWREG ? mul_shoup_lazy_lowreg(V, w, ws, q) : mul_shoup_lazy(V, w, ws, q);  // [0,4q) for any 64-bit V
+    U = u + v;
+    V = u + q4 - v;
 }
 
+template <bool LOWREG = false>
 LR_D void inv_bfly(u64 &U, u64 &V, u64 w, u64 ws, u64 q, u64 q4) {
     const u64 s = U + V;                           // [0,8q)
     const u64 t = U + q4 - V;                      // (0,8q)
     U = s >= q4 ? s - q4 : s;                      // [0,4q)
-    V = mul_shoup_lazy(t, w, ws, q);               // [0,4q)
+    V = LOWREG ? mul_shoup_lazy_lowreg(t, w, ws, q) : mul_shoup_lazy(t, w, ws, q);  // [0,4q)
 }
 
-LR_D u64 canon_from_8q(u64 x, u64 q) {
-    const u64 q4 = q << 2, q2 = q << 1;
-    x = x >= q4 ? x - q4 : x;
-    x = x >= q2 ? x - q2 : x;
-    return x >= q ? x - q : x;
-}
 LR_D u64 canon_from_4q(u64 x, u64 q) {
     const u64 q2 = q << 1;
     x = x >= q2 ? x - q2 : x;
     return x >= q ? x - q : x;
 }
 
+// canonical representative after the last forward stage
+template <int MODE>
+LR_D u64 fwd_canon(u64 x, const LimbParams &lp) {
+    const u64 q = lp.q;
+    if (MODE == 2) return bred_add(x, q, lp.bred_hi);   // exact for any 64-bit x
+    const u64 q4 = q << 2;
+    if (MODE == 1) {
+        const u64 q8 = q << 3;
+        x = x >= q8 ? x - q8 : x;
+    }
+    x = x >= q4 ? x - q4 : x;
+    return canon_from_4q(x, q);
+}
+
 // R stages over the R index bits [plo, plo+R) held in registers: x[k] has bit pattern k there.
 // H = 2^(logN - plo - R) + (index bits above plo+R): the heap position of the block's twiddle;
 // the stage over bit plo+b uses twiddles (H << (R-1-b)) + j, j = k >> (b+1).
-template <int R>
+// S0 = global index of the first of these stages (stage s consumes index bit logN-1-s); in
+// MODE 1 the even stages s >= 2 correct.  FENCE keeps the compiler from hoisting every
+// stage's per-lane twiddle loads to the top (register pressure).
+// FIN_STRIDE > 0: twiddles come from the lane-transposed table of the last four stages,
+// entry [slot = 2^c - 1 + j][block] with FIN_STRIDE = N/16 blocks and H = the block index:
+// consecutive lanes read consecutive 16-byte entries.
+template <int R, int MODE, int S0, bool FENCE, int GROUP = 0, int FIN_STRIDE = 0, bool LOWREG = false>
 LR_D void fwd_stages(u64 (&x)[1 << R], const Twiddle *__restrict__ tw, u32 H, u64 q, u64 q4) {
 #pragma unroll
     for (int b = R - 1; b >= 0; --b) {
         const int c = R - 1 - b;
+        const int s = S0 + c;
+        const bool correct = (s >= 2) && ((s & 1) == 0);
 #pragma unroll
         for (int j = 0; j < (1 << c); ++j) {
-            const Twiddle w = tw[(H << c) + j];
+            const Twiddle w = FIN_STRIDE > 0 ? tw[((1 << c) - 1 + j) * FIN_STRIDE + H] : tw[(H << c) + j];
 #pragma unroll
             for (int i = 0; i < (1 << b); ++i) {
                 const int k0 = (j << (b + 1)) | i;
-                fwd_bfly(x[k0], x[k0 | (1 << b)], w.x, w.y, q, q4);
+                fwd_bfly<MODE, LOWREG>(x[k0], x[k0 | (1 << b)], w.x, w.y, q, q4, correct);
+                // GROUP > 0: let at most GROUP butterflies interleave (bounds the live temporaries)
+                if (GROUP > 0 && ((j * (1 << b) + i + 1) % GROUP) == 0) __builtin_amdgcn_sched_barrier(0);
             }
         }
+        if (FENCE && b > 0) __builtin_amdgcn_sched_barrier(0);
     }
 }
 
-template <int R>
+template <int R, int FIN_STRIDE = 0, bool LOWREG = false>
 LR_D void inv_stages(u64 (&x)[1 << R], const Twiddle *__restrict__ tw, u32 H, u64 q, u64 q4) {
 #pragma unroll
     for (int b = 0; b < R; ++b) {
         const int c = R - 1 - b;
 #pragma unroll
         for (int j = 0; j < (1 << c); ++j) {
-            const Twiddle w = tw[(H << c) + j];
+            const Twiddle w = FIN_STRIDE > 0 ? tw[((1 << c) - 1 + j) * FIN_STRIDE + H] : tw[(H << c) + j];
 #pragma unroll
             for (int i = 0; i < (1 << b); ++i) {
                 const int k0 = (j << (b + 1)) | i;
-                inv_bfly(x[k0], x[k0 | (1 << b)], w.x, w.y, q, q4);
+                inv_bfly<LOWREG>(x[k0], x[k0 | (1 << b)], w.x, w.y, q, q4);
             }
         }
     }
@@ -99,8 +135,9 @@ template <> struct Plan<13> { static constexpr int LOGT = 9,  A = 4, HALVES = 1,
 template <> struct Plan<12> { static constexpr int LOGT = 8,  A = 4, HALVES = 1, P0 = 0, P1 = 4, P2 = 4; };
 
 // one forward LDS pass over bits [PLO, PLO+R) of the M resident coefficients
-template <int LOGN, int M, int T, int R, int PLO>
-LR_D void fwd_lds_pass(u64 *lds, const Twiddle *__restrict__ tw, int res_base, int t, u64 q, u64 q4) {
+template <int LOGN, int M, int T, int R, int PLO, int MODE, int GROUP = 0, bool LOWREG = false>
+LR_D void fwd_lds_pass(u64 *lds, const Twiddle *__restrict__ tw, const Twiddle *__restrict__ tw_fin, int res_base, int t,
+                       u64 q, u64 q4) {
     if constexpr (R > 0) {
         constexpr int NT = M >> R;
 #pragma unroll
@@ -122,7 +159,10 @@ LR_D void fwd_lds_pass(u64 *lds, const Twiddle *__restrict__ tw, int res_base, i
 #pragma unroll
                 for (int k = 0; k < (1 << R); ++k) y[k] = lds[lds_slot(base + (k << PLO))];
             }
-            fwd_stages<R>(y, tw, H, q, q4);
+            if constexpr (PLO == 0 && R == 4)
+                fwd_stages<R, MODE, LOGN - PLO - R, true, GROUP, (1 << (LOGN - 4)), LOWREG>(y, tw_fin, (u32)((res_base >> 4) + u), q, q4);
+            else
+                fwd_stages<R, MODE, LOGN - PLO - R, (PLO < 6 && R >= 4), GROUP, 0, LOWREG>(y, tw, H, q, q4);
             if constexpr (PLO == 0) {
                 ulonglong2 *p = reinterpret_cast<ulonglong2 *>(lds + lds_slot(base));
 #pragma unroll
@@ -136,8 +176,9 @@ LR_D void fwd_lds_pass(u64 *lds, const Twiddle *__restrict__ tw, int res_base, i
     }
 }
 
-template <int LOGN, int M, int T, int R, int PLO>
-LR_D void inv_lds_pass(u64 *lds, const Twiddle *__restrict__ tw, int res_base, int t, u64 q, u64 q4) {
+template <int LOGN, int M, int T, int R, int PLO, bool LOWREG = false>
+LR_D void inv_lds_pass(u64 *lds, const Twiddle *__restrict__ tw, const Twiddle *__restrict__ tw_fin, int res_base, int t,
+                       u64 q, u64 q4) {
     if constexpr (R > 0) {
         constexpr int NT = M >> R;
 #pragma unroll
@@ -159,7 +200,10 @@ LR_D void inv_lds_pass(u64 *lds, const Twiddle *__restrict__ tw, int res_base, i
 #pragma unroll
                 for (int k = 0; k < (1 << R); ++k) y[k] = lds[lds_slot(base + (k << PLO))];
             }
-            inv_stages<R>(y, tw, H, q, q4);
+            if constexpr (PLO == 0 && R == 4)
+                inv_stages<R, (1 << (LOGN - 4)), LOWREG>(y, tw_fin, (u32)((res_base >> 4) + u), q, q4);
+            else
+                inv_stages<R, 0, LOWREG>(y, tw, H, q, q4);
             if constexpr (PLO == 0) {
                 ulonglong2 *p = reinterpret_cast<ulonglong2 *>(lds + lds_slot(base));
 #pragma unroll
@@ -177,6 +221,7 @@ struct Item {
     const u64 *src;
     u64 *dst;
     const Twiddle *tw;
+    const Twiddle *tw_fin;
     LimbParams lp;
 };
 
@@ -187,6 +232,7 @@ LR_D Item locate(const NttLaunch &a, int n) {
     it.src = a.in + (long long)b * a.in_poly_stride + (long long)(a.in_limb0 + item * a.in_limb_step) * n;
     it.dst = a.out + (long long)b * a.out_poly_stride + (long long)(a.out_limb0 + item * a.out_limb_step) * n;
     it.tw = a.tw + (long long)mod * n;
+    it.tw_fin = a.tw_fin ? a.tw_fin + (long long)mod * (15 * (n >> 4)) : nullptr;
     it.lp = a.lp[mod];
     return it;
 }
@@ -194,8 +240,8 @@ LR_D Item locate(const NttLaunch &a, int n) {
 // ------------------------------------------------------------------------------------------
 // forward, 2^12 <= N <= 2^15
 // ------------------------------------------------------------------------------------------
-template <int LOGN>
-__global__ __launch_bounds__(1 << Plan<LOGN>::LOGT) void ntt_fwd_kernel(NttLaunch a) {
+template <int LOGN, int MODE>
+__global__ __launch_bounds__(1 << Plan<LOGN>::LOGT, 4) void ntt_fwd_kernel(NttLaunch a) {
     using P = Plan<LOGN>;
     constexpr int N = 1 << LOGN, T = 1 << P::LOGT, A = P::A, RA = 1 << A, S = N >> A;
     constexpr int HALVES = P::HALVES, M = N / HALVES, RH = RA / HALVES;
@@ -214,7 +260,7 @@ __global__ __launch_bounds__(1 << Plan<LOGN>::LOGT) void ntt_fwd_kernel(NttLaunc
     // >= q (ring/ring_scaling.go:19,102), so the U operands are reduced exactly.
 #pragma unroll
     for (int k = 0; k < RA / 2; ++k) x[k] = bred_add(x[k], q, it.lp.bred_hi);
-    fwd_stages<A>(x, it.tw, 1u, q, q4);
+    fwd_stages<A, MODE, 0, false, (HALVES > 1 ? 4 : 0), 0, (HALVES > 1)>(x, it.tw, 1u, q, q4);
 
 #pragma unroll
     for (int half = 0; half < HALVES; ++half) {
@@ -222,15 +268,15 @@ __global__ __launch_bounds__(1 << Plan<LOGN>::LOGT) void ntt_fwd_kernel(NttLaunc
         for (int kk = 0; kk < RH; ++kk) lds[lds_slot(kk * S + t)] = x[half * RH + kk];
         __syncthreads();
         const int res_base = half * M;
-        fwd_lds_pass<LOGN, M, T, P::P0, P::P1 + P::P2>(lds, it.tw, res_base, t, q, q4);
-        fwd_lds_pass<LOGN, M, T, P::P1, P::P2>(lds, it.tw, res_base, t, q, q4);
-        fwd_lds_pass<LOGN, M, T, P::P2, 0>(lds, it.tw, res_base, t, q, q4);
+        fwd_lds_pass<LOGN, M, T, P::P0, P::P1 + P::P2, MODE, 0, (HALVES > 1)>(lds, it.tw, it.tw_fin, res_base, t, q, q4);
+        fwd_lds_pass<LOGN, M, T, P::P1, P::P2, MODE, 0, (HALVES > 1)>(lds, it.tw, it.tw_fin, res_base, t, q, q4);
+        fwd_lds_pass<LOGN, M, T, P::P2, 0, MODE, (HALVES > 1 ? 4 : 0), (HALVES > 1)>(lds, it.tw, it.tw_fin, res_base, t, q, q4);
         // copy-out: canonical reduction + coalesced 16-B stores
         ulonglong2 *dst2 = reinterpret_cast<ulonglong2 *>(it.dst + res_base);
 #pragma unroll
         for (int e = t; e < M / 2; e += T) {
             const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(lds + lds_slot(2 * e));
-            dst2[e] = make_ulonglong2(canon_from_8q(v.x, q), canon_from_8q(v.y, q));
+            dst2[e] = make_ulonglong2(fwd_canon<MODE>(v.x, it.lp), fwd_canon<MODE>(v.y, it.lp));
         }
         if (half + 1 < HALVES) __syncthreads();
     }
@@ -241,7 +287,7 @@ __global__ __launch_bounds__(1 << Plan<LOGN>::LOGT) void ntt_fwd_kernel(NttLaunc
 // ring/ntt.go:43-50, is only congruence-preserving for inputs <= 2q: U+2Q-V must not wrap).
 // ------------------------------------------------------------------------------------------
 template <int LOGN>
-__global__ __launch_bounds__(1 << Plan<LOGN>::LOGT) void ntt_inv_kernel(NttLaunch a) {
+__global__ __launch_bounds__(1 << Plan<LOGN>::LOGT, 4) void ntt_inv_kernel(NttLaunch a) {
     using P = Plan<LOGN>;
     constexpr int N = 1 << LOGN, T = 1 << P::LOGT, A = P::A, RA = 1 << A, S = N >> A;
     constexpr int HALVES = P::HALVES, M = N / HALVES, RH = RA / HALVES;
@@ -260,14 +306,14 @@ __global__ __launch_bounds__(1 << Plan<LOGN>::LOGT) void ntt_inv_kernel(NttLaunc
         for (int e = t; e < M / 2; e += T)
             *reinterpret_cast<ulonglong2 *>(lds + lds_slot(2 * e)) = src2[e];
         __syncthreads();
-        inv_lds_pass<LOGN, M, T, P::P2, 0>(lds, it.tw, res_base, t, q, q4);
-        inv_lds_pass<LOGN, M, T, P::P1, P::P2>(lds, it.tw, res_base, t, q, q4);
-        inv_lds_pass<LOGN, M, T, P::P0, P::P1 + P::P2>(lds, it.tw, res_base, t, q, q4);
+        inv_lds_pass<LOGN, M, T, P::P2, 0, (HALVES > 1)>(lds, it.tw, it.tw_fin, res_base, t, q, q4);
+        inv_lds_pass<LOGN, M, T, P::P1, P::P2, (HALVES > 1)>(lds, it.tw, it.tw_fin, res_base, t, q, q4);
+        inv_lds_pass<LOGN, M, T, P::P0, P::P1 + P::P2, (HALVES > 1)>(lds, it.tw, it.tw_fin, res_base, t, q, q4);
 #pragma unroll
         for (int kk = 0; kk < RH; ++kk) x[half * RH + kk] = lds[lds_slot(kk * S + t)];
         if (half + 1 < HALVES) __syncthreads();
     }
-    inv_stages<A>(x, it.tw, 1u, q, q4);
+    inv_stages<A, 0, (HALVES > 1)>(x, it.tw, 1u, q, q4);
     // MRed(x, nttNInv) of ring/ntt.go:136-138 == x * N^-1 mod q, canonical
 #pragma unroll
     for (int k = 0; k < RA; ++k)
@@ -292,13 +338,13 @@ __global__ __launch_bounds__(256) void ntt_small_kernel(NttLaunch a, int logn, i
                 const int j = (i << (p + 1)) | jj;
                 const Twiddle w = it.tw[(1 << (logn - 1 - p)) + i];
                 u64 U = lds[j], V = lds[j + (1 << p)];
-                fwd_bfly(U, V, w.x, w.y, q, q4);
+                fwd_bfly<0>(U, V, w.x, w.y, q, q4, true);
                 lds[j] = U;
                 lds[j + (1 << p)] = V;
             }
             __syncthreads();
         }
-        for (int e = t; e < n; e += 256) it.dst[e] = canon_from_8q(lds[e], q);
+        for (int e = t; e < n; e += 256) it.dst[e] = fwd_canon<0>(lds[e], it.lp);
     } else {
         for (int e = t; e < n; e += 256) lds[e] = it.src[e];
         __syncthreads();
@@ -308,7 +354,7 @@ __global__ __launch_bounds__(256) void ntt_small_kernel(NttLaunch a, int logn, i
                 const int j = (i << (p + 1)) | jj;
                 const Twiddle w = it.tw[(1 << (logn - 1 - p)) + i];
                 u64 U = lds[j], V = lds[j + (1 << p)];
-                inv_bfly(U, V, w.x, w.y, q, q4);
+                inv_bfly<false>(U, V, w.x, w.y, q, q4);
                 lds[j] = U;
                 lds[j + (1 << p)] = V;
             }
@@ -322,36 +368,59 @@ __global__ __launch_bounds__(256) void ntt_small_kernel(NttLaunch a, int logn, i
 // ------------------------------------------------------------------------------------------
 // host launchers
 // ------------------------------------------------------------------------------------------
-template <int LOGN>
-static hipError_t launch_big(const NttLaunch &a, bool inverse, hipStream_t stream) {
+template <int LOGN, int MODE>
+static hipError_t launch_fwd(const NttLaunch &a, hipStream_t stream) {
     using P = Plan<LOGN>;
     constexpr int M = (1 << LOGN) / P::HALVES;
     constexpr size_t lds_bytes = (size_t)lds_words(M) * sizeof(u64);
-    static bool configured[2] = {false, false};
-    auto fwd = ntt_fwd_kernel<LOGN>;
-    auto inv = ntt_inv_kernel<LOGN>;
-    const void *fn = inverse ? (const void *)inv : (const void *)fwd;
-    if (!configured[inverse ? 1 : 0]) {
-        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    static bool configured = false;
+    auto fn = ntt_fwd_kernel<LOGN, MODE>;
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) return e;
-        configured[inverse ? 1 : 0] = true;
+        configured = true;
     }
     const dim3 grid((unsigned)(a.n_items * a.batch)), block(1u << P::LOGT);
     (void)hipGetLastError();  // drop stale (non-sticky) errors of unrelated earlier calls
-    if (inverse)
-        hipLaunchKernelGGL(inv, grid, block, lds_bytes, stream, a);
-    else
-        hipLaunchKernelGGL(fwd, grid, block, lds_bytes, stream, a);
+    hipLaunchKernelGGL(fn, grid, block, lds_bytes, stream, a);
     return hipGetLastError();
 }
 
-hipError_t launch_ntt(const NttLaunch &a, int logn, bool inverse, hipStream_t stream) {
+template <int LOGN>
+static hipError_t launch_inv(const NttLaunch &a, hipStream_t stream) {
+    using P = Plan<LOGN>;
+    constexpr int M = (1 << LOGN) / P::HALVES;
+    constexpr size_t lds_bytes = (size_t)lds_words(M) * sizeof(u64);
+    static bool configured = false;
+    auto fn = ntt_inv_kernel<LOGN>;
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) return e;
+        configured = true;
+    }
+    const dim3 grid((unsigned)(a.n_items * a.batch)), block(1u << P::LOGT);
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(fn, grid, block, lds_bytes, stream, a);
+    return hipGetLastError();
+}
+
+template <int LOGN>
+static hipError_t launch_big(const NttLaunch &a, bool inverse, int mode, hipStream_t stream) {
+    if (inverse) return launch_inv<LOGN>(a, stream);
+    switch (mode) {
+    case 2: return launch_fwd<LOGN, 2>(a, stream);
+    case 1: return launch_fwd<LOGN, 1>(a, stream);
+    default: return launch_fwd<LOGN, 0>(a, stream);
+    }
+}
+
+hipError_t launch_ntt(const NttLaunch &a, int logn, bool inverse, int mode, hipStream_t stream) {
     if (a.n_items <= 0 || a.batch <= 0) return hipSuccess;
     switch (logn) {
-    case 15: return launch_big<15>(a, inverse, stream);
-    case 14: return launch_big<14>(a, inverse, stream);
-    case 13: return launch_big<13>(a, inverse, stream);
-    case 12: return launch_big<12>(a, inverse, stream);
+    case 15: return launch_big<15>(a, inverse, mode, stream);
+    case 14: return launch_big<14>(a, inverse, mode, stream);
+    case 13: return launch_big<13>(a, inverse, mode, stream);
+    case 12: return launch_big<12>(a, inverse, mode, stream);
     default: break;
     }
     if (logn >= 1 && logn <= 11) {
