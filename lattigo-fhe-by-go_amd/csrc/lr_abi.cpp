@@ -222,10 +222,19 @@ extern "C" int lr_context_create(uint64_t N, const uint64_t *moduli, int n_modul
         if (q >> 61) return fail(LR_ERR_UNSUPPORTED, "modulus must be below 2^61 (the reference's lazy NTT has the same limit)");
     c->device = device;
     {
-        u64 qmax = 0;
-        for (u64 q : c->h.q) qmax = q > qmax ? q : qmax;
-        c->ntt_mode = qmax < (1ull << 57) ? 2 : (qmax <= (1ull << 60) ? 1 : 0);
-        if (const char *force = std::getenv("LR_NTT_MODE")) c->ntt_mode = std::atoi(force) < c->ntt_mode ? std::atoi(force) : c->ntt_mode;
+        u64 qmax = 0, qmin = ~(u64)0;
+        for (u64 q : c->h.q) {
+            qmax = q > qmax ? q : qmax;
+            qmin = q < qmin ? q : qmin;
+        }
+        if (qmax < (1ull << 57)) c->ntt_mode = 2;
+        else if (qmin >= (1ull << 57)) c->ntt_mode = qmax <= (1ull << 60) ? 1 : 0;
+        else c->ntt_mode = 3;                         // mixed sizes: generic path
+        if (const char *force = std::getenv("LR_NTT_MODE")) {
+            const int f = std::atoi(force);           // testing aid: 0 and 3 are always valid where 1 is
+            if ((f == 0 && c->ntt_mode == 1) || f == 3) c->ntt_mode = f;
+        }
+        if (qmin >= (1ull << 32)) c->ntt_mode |= 256;
     }
     LR_HIP(hipSetDevice(device));
     c->stream = shared_stream(device);
@@ -246,7 +255,14 @@ extern "C" int lr_context_create(uint64_t N, const uint64_t *moduli, int n_modul
         p.n_inv_mont = c->h.n_inv[i];
         p.n_inv = inv_mform(c->h.n_inv[i], q, qinv);
         p.n_inv_shoup = shoup_companion(p.n_inv, q);
-        p.pad = 0;
+        {
+            const u64 qh = (q >> 32) + 1;
+            unsigned g = 0;
+            while ((qh >> (g + 1)) != 0) ++g;  // bitlen(qh) - 1
+            const u64 m = ((u64)1 << (32 + g)) / qh;
+            p.red_m = m > 0xFFFFFFFFull ? 0xFFFFFFFFu : (u32)m;
+            p.red_g = g;
+        }
         for (u64 j = 0; j < N; ++j) {
             const u64 wf = inv_mform(c->h.ntt_psi[(size_t)i * N + j], q, qinv);
             const u64 wi = inv_mform(c->h.ntt_psi_inv[(size_t)i * N + j], q, qinv);

@@ -15,7 +15,10 @@ struct LimbParams {
     u64 n_inv_mont;  // Go's nttNInv (Montgomery form of N^-1)
     u64 n_inv;       // N^-1 mod q, plain
     u64 n_inv_shoup; // floor(n_inv * 2^64 / q)
-    u64 pad;
+    // quotient estimate for values < 2^64 when q >= 2^57 (lr_ntt.hip, est_quotient): with
+    // qh = (q >> 32) + 1, red_m = min(floor(2^(32+red_g) / qh), 2^32-1), red_g = bitlen(qh) - 1
+    u32 red_m;
+    u32 red_g;
 };
 
 constexpr int kMaxLimbs = 64;

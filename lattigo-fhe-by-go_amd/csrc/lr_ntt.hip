@@ -29,28 +29,49 @@ namespace lr {
 //   MODE 0  q < 2^61 : cond-subtract 4q before every stage          values stay in [0, 8q)
 //   MODE 1  q <= 2^60: cond-subtract 8q before every second stage   values stay in [0, 16q)
 //   MODE 2  q < 2^57 : never (at most 4*logN+1 <= 65 multiples of q accumulate < 2^64)
+//   MODE 3  any mix of sizes below 2^61: as MODE 0 with plain 64-bit compares and Barrett reductions
+//   (MODE 0/1 additionally assume q >= 2^57 for their one-multiply quotient estimates)
 // Inverse (Gentleman-Sande): X = U + V doubles the bound, so it is corrected every stage:
 // values stay in [0, 4q).
 // ------------------------------------------------------------------------------------------
+// x in [0, 2m) -> x mod m, for 2^59 <= m <= 2^63: after d = x - m the two candidates differ in their
+// high words (m >= 2^32) and d wraps above 2^63 when x < m, so one 32-bit compare of the high words
+// decides (add + cmp + 2 cndmask instead of the compiler's cmp64 + 2 cndmask + sub + subb).
+LR_D u64 csub_hi(u64 x, u64 m) {
+    const u64 d = x - m;
+    return (u32)(d >> 32) < (u32)(x >> 32) ? d : x;
+}
+
+// floor(x / q) under-estimated by at most 1, for any 64-bit x and 2^57 <= q < 2^61
+LR_D u32 est_quotient(u64 x, const LimbParams &lp) { return __umulhi((u32)(x >> 32), lp.red_m) >> lp.red_g; }
+
+// x - k*q with k < 2^8
+LR_D u64 sub_kq(u64 x, u32 k, u64 q) {
+    u64 kq = (u64)k * (u32)q;
+    kq += (u64)(k * (u32)(q >> 32)) << 32;
+    return x - kq;
+}
+
 template <int MODE, bool LOWREG = false>
 LR_D void fwd_bfly(u64 &U, u64 &V, u64 w, u64 ws, u64 q, u64 q4, bool correct) {
     u64 u = U;
     if (MODE == 0) {
-        u = u >= q4 ? u - q4 : u;                  // [0,8q) -> [0,4q)
+        u = csub_hi(u, q4);                        // [0,8q) -> [0,4q)
     } else if (MODE == 1) {
-        const u64 q8 = q4 << 1;
-        if (correct) u = u >= q8 ? u - q8 : u;     // [0,16q) -> [0,8q)
+        if (correct) u = csub_hi(u, q4 << 1);      // [0,16q) -> [0,8q)
+    } else if (MODE == 3) {
+        u = u >= q4 ? u - q4 : u;                  // any q < 2^61 (mixed-size contexts)
     }
     const u64 v = LOWREG ? mul_shoup_lazy_lowreg(V, w, ws, q) : mul_shoup_lazy(V, w, ws, q);  // [0,4q) for any 64-bit V
     U = u + v;
     V = u + q4 - v;
 }
 
-template <bool LOWREG = false>
+template <bool LOWREG = false, bool BIGQ = false>
 LR_D void inv_bfly(u64 &U, u64 &V, u64 w, u64 ws, u64 q, u64 q4) {
     const u64 s = U + V;                           // [0,8q)
     const u64 t = U + q4 - V;                      // (0,8q)
-    U = s >= q4 ? s - q4 : s;                      // [0,4q)
+    U = BIGQ ? csub_hi(s, q4) : (s >= q4 ? s - q4 : s);   // [0,4q); csub_hi needs 2^32 <= 4q < 2^63
     V = LOWREG ? mul_shoup_lazy_lowreg(t, w, ws, q) : mul_shoup_lazy(t, w, ws, q);  // [0,4q)
 }
 
@@ -65,13 +86,22 @@ template <int MODE>
 LR_D u64 fwd_canon(u64 x, const LimbParams &lp) {
     const u64 q = lp.q;
     if (MODE == 2) return bred_add(x, q, lp.bred_hi);   // exact for any 64-bit x
-    const u64 q4 = q << 2;
-    if (MODE == 1) {
-        const u64 q8 = q << 3;
-        x = x >= q8 ? x - q8 : x;
+    if (MODE == 3) {
+        const u64 q4 = q << 2;
+        x = x >= q4 ? x - q4 : x;
+        return canon_from_4q(x, q);
     }
-    x = x >= q4 ? x - q4 : x;
-    return canon_from_4q(x, q);
+    // q >= 2^57: one multiply estimates the quotient to within 1, then a single conditional subtract
+    const u64 r = sub_kq(x, est_quotient(x, lp), q);     // [0, 2q)
+    const u64 d = r - q;
+    return (long long)d < 0 ? r : d;
+}
+
+// first-stage U operands: any 64-bit value -> congruent value the lazy invariant accepts
+template <int MODE>
+LR_D u64 fwd_input(u64 x, const LimbParams &lp) {
+    if (MODE == 2 || MODE == 3) return bred_add_constant(x, lp.q, lp.bred_hi);   // [0, 2q)
+    return sub_kq(x, est_quotient(x, lp), lp.q);                   // [0, 2q)
 }
 
 // R stages over the R index bits [plo, plo+R) held in registers: x[k] has bit pattern k there.
@@ -98,14 +128,16 @@ LR_D void fwd_stages(u64 (&x)[1 << R], const Twiddle *__restrict__ tw, u32 H, u6
                 const int k0 = (j << (b + 1)) | i;
                 fwd_bfly<MODE, LOWREG>(x[k0], x[k0 | (1 << b)], w.x, w.y, q, q4, correct);
                 // GROUP > 0: let at most GROUP butterflies interleave (bounds the live temporaries)
-                if (GROUP > 0 && ((j * (1 << b) + i + 1) % GROUP) == 0) __builtin_amdgcn_sched_barrier(0);
+                if constexpr (GROUP > 0) {
+                    if (((j * (1 << b) + i + 1) % GROUP) == 0) __builtin_amdgcn_sched_barrier(0);
+                }
             }
         }
         if (FENCE && b > 0) __builtin_amdgcn_sched_barrier(0);
     }
 }
 
-template <int R, int FIN_STRIDE = 0, bool LOWREG = false>
+template <int R, int FIN_STRIDE = 0, bool LOWREG = false, bool BIGQ = false>
 LR_D void inv_stages(u64 (&x)[1 << R], const Twiddle *__restrict__ tw, u32 H, u64 q, u64 q4) {
 #pragma unroll
     for (int b = 0; b < R; ++b) {
@@ -116,7 +148,7 @@ LR_D void inv_stages(u64 (&x)[1 << R], const Twiddle *__restrict__ tw, u32 H, u6
 #pragma unroll
             for (int i = 0; i < (1 << b); ++i) {
                 const int k0 = (j << (b + 1)) | i;
-                inv_bfly<LOWREG>(x[k0], x[k0 | (1 << b)], w.x, w.y, q, q4);
+                inv_bfly<LOWREG, BIGQ>(x[k0], x[k0 | (1 << b)], w.x, w.y, q, q4);
             }
         }
     }
@@ -147,8 +179,12 @@ LR_D void fwd_lds_pass(u64 *lds, const Twiddle *__restrict__ tw, const Twiddle *
             u32 H = (1u << (LOGN - PLO - R)) + (u32)(res_base >> (PLO + R)) + (u32)u_hi;
             if constexpr (PLO >= 6) H = __builtin_amdgcn_readfirstlane(H);  // wave-uniform: scalar twiddle loads
             u64 y[1 << R];
+            // the padded image is linear in k: slot(base + k*2^PLO) = slot(base) + k*(2^PLO + 2^(PLO-3)) for PLO >= 4
+            u64 *const row = lds + lds_slot(base);
+            constexpr int KSTRIDE = PLO >= 4 ? (1 << PLO) + (1 << (PLO - 3)) : 0;
+            static_assert(PLO == 0 || PLO >= 4, "pass layout");
             if constexpr (PLO == 0) {
-                const ulonglong2 *p = reinterpret_cast<const ulonglong2 *>(lds + lds_slot(base));
+                const ulonglong2 *p = reinterpret_cast<const ulonglong2 *>(row);
 #pragma unroll
                 for (int k = 0; k < (1 << R); k += 2) {
                     const ulonglong2 v = p[(k >> 1) + (k >> 4)];
@@ -157,26 +193,26 @@ LR_D void fwd_lds_pass(u64 *lds, const Twiddle *__restrict__ tw, const Twiddle *
                 }
             } else {
 #pragma unroll
-                for (int k = 0; k < (1 << R); ++k) y[k] = lds[lds_slot(base + (k << PLO))];
+                for (int k = 0; k < (1 << R); ++k) y[k] = row[k * KSTRIDE];
             }
             if constexpr (PLO == 0 && R == 4)
                 fwd_stages<R, MODE, LOGN - PLO - R, true, GROUP, (1 << (LOGN - 4)), LOWREG>(y, tw_fin, (u32)((res_base >> 4) + u), q, q4);
             else
                 fwd_stages<R, MODE, LOGN - PLO - R, (PLO < 6 && R >= 4), GROUP, 0, LOWREG>(y, tw, H, q, q4);
             if constexpr (PLO == 0) {
-                ulonglong2 *p = reinterpret_cast<ulonglong2 *>(lds + lds_slot(base));
+                ulonglong2 *p = reinterpret_cast<ulonglong2 *>(row);
 #pragma unroll
                 for (int k = 0; k < (1 << R); k += 2) p[(k >> 1) + (k >> 4)] = make_ulonglong2(y[k], y[k + 1]);
             } else {
 #pragma unroll
-                for (int k = 0; k < (1 << R); ++k) lds[lds_slot(base + (k << PLO))] = y[k];
+                for (int k = 0; k < (1 << R); ++k) row[k * KSTRIDE] = y[k];
             }
         }
         __syncthreads();
     }
 }
 
-template <int LOGN, int M, int T, int R, int PLO, bool LOWREG = false>
+template <int LOGN, int M, int T, int R, int PLO, bool LOWREG = false, bool BIGQ = false>
 LR_D void inv_lds_pass(u64 *lds, const Twiddle *__restrict__ tw, const Twiddle *__restrict__ tw_fin, int res_base, int t,
                        u64 q, u64 q4) {
     if constexpr (R > 0) {
@@ -188,8 +224,12 @@ LR_D void inv_lds_pass(u64 *lds, const Twiddle *__restrict__ tw, const Twiddle *
             u32 H = (1u << (LOGN - PLO - R)) + (u32)(res_base >> (PLO + R)) + (u32)u_hi;
             if constexpr (PLO >= 6) H = __builtin_amdgcn_readfirstlane(H);
             u64 y[1 << R];
+            // the padded image is linear in k: slot(base + k*2^PLO) = slot(base) + k*(2^PLO + 2^(PLO-3)) for PLO >= 4
+            u64 *const row = lds + lds_slot(base);
+            constexpr int KSTRIDE = PLO >= 4 ? (1 << PLO) + (1 << (PLO - 3)) : 0;
+            static_assert(PLO == 0 || PLO >= 4, "pass layout");
             if constexpr (PLO == 0) {
-                const ulonglong2 *p = reinterpret_cast<const ulonglong2 *>(lds + lds_slot(base));
+                const ulonglong2 *p = reinterpret_cast<const ulonglong2 *>(row);
 #pragma unroll
                 for (int k = 0; k < (1 << R); k += 2) {
                     const ulonglong2 v = p[(k >> 1) + (k >> 4)];
@@ -198,19 +238,19 @@ LR_D void inv_lds_pass(u64 *lds, const Twiddle *__restrict__ tw, const Twiddle *
                 }
             } else {
 #pragma unroll
-                for (int k = 0; k < (1 << R); ++k) y[k] = lds[lds_slot(base + (k << PLO))];
+                for (int k = 0; k < (1 << R); ++k) y[k] = row[k * KSTRIDE];
             }
             if constexpr (PLO == 0 && R == 4)
-                inv_stages<R, (1 << (LOGN - 4)), LOWREG>(y, tw_fin, (u32)((res_base >> 4) + u), q, q4);
+                inv_stages<R, (1 << (LOGN - 4)), LOWREG, BIGQ>(y, tw_fin, (u32)((res_base >> 4) + u), q, q4);
             else
-                inv_stages<R, 0, LOWREG>(y, tw, H, q, q4);
+                inv_stages<R, 0, LOWREG, BIGQ>(y, tw, H, q, q4);
             if constexpr (PLO == 0) {
-                ulonglong2 *p = reinterpret_cast<ulonglong2 *>(lds + lds_slot(base));
+                ulonglong2 *p = reinterpret_cast<ulonglong2 *>(row);
 #pragma unroll
                 for (int k = 0; k < (1 << R); k += 2) p[(k >> 1) + (k >> 4)] = make_ulonglong2(y[k], y[k + 1]);
             } else {
 #pragma unroll
-                for (int k = 0; k < (1 << R); ++k) lds[lds_slot(base + (k << PLO))] = y[k];
+                for (int k = 0; k < (1 << R); ++k) row[k * KSTRIDE] = y[k];
             }
         }
         __syncthreads();
@@ -255,17 +295,20 @@ __global__ __launch_bounds__(1 << Plan<LOGN>::LOGT, 4) void ntt_fwd_kernel(NttLa
 
     u64 x[RA];
 #pragma unroll
-    for (int k = 0; k < RA; ++k) x[k] = it.src[k * S + t];
+    for (int k = 0; k < RA; ++k) x[k] = (it.src + k * S)[t];   // uniform row base (SGPR) + one lane offset
     // The first stage needs U < 8q; V may be any 64-bit value.  The reference accepts inputs
     // >= q (ring/ring_scaling.go:19,102), so the U operands are reduced exactly.
 #pragma unroll
-    for (int k = 0; k < RA / 2; ++k) x[k] = bred_add(x[k], q, it.lp.bred_hi);
+    for (int k = 0; k < RA / 2; ++k) x[k] = fwd_input<MODE>(x[k], it.lp);
     fwd_stages<A, MODE, 0, false, (HALVES > 1 ? 4 : 0), 0, (HALVES > 1)>(x, it.tw, 1u, q, q4);
 
 #pragma unroll
     for (int half = 0; half < HALVES; ++half) {
+        {
+            u64 *const col = lds + lds_slot(t);
 #pragma unroll
-        for (int kk = 0; kk < RH; ++kk) lds[lds_slot(kk * S + t)] = x[half * RH + kk];
+            for (int kk = 0; kk < RH; ++kk) col[kk * (S + S / 8)] = x[half * RH + kk];
+        }
         __syncthreads();
         const int res_base = half * M;
         fwd_lds_pass<LOGN, M, T, P::P0, P::P1 + P::P2, MODE, 0, (HALVES > 1)>(lds, it.tw, it.tw_fin, res_base, t, q, q4);
@@ -273,10 +316,11 @@ __global__ __launch_bounds__(1 << Plan<LOGN>::LOGT, 4) void ntt_fwd_kernel(NttLa
         fwd_lds_pass<LOGN, M, T, P::P2, 0, MODE, (HALVES > 1 ? 4 : 0), (HALVES > 1)>(lds, it.tw, it.tw_fin, res_base, t, q, q4);
         // copy-out: canonical reduction + coalesced 16-B stores
         ulonglong2 *dst2 = reinterpret_cast<ulonglong2 *>(it.dst + res_base);
+        const u64 *const pair = lds + lds_slot(2 * t);
 #pragma unroll
-        for (int e = t; e < M / 2; e += T) {
-            const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(lds + lds_slot(2 * e));
-            dst2[e] = make_ulonglong2(fwd_canon<MODE>(v.x, it.lp), fwd_canon<MODE>(v.y, it.lp));
+        for (int i = 0; i < M / (2 * T); ++i) {   // element pair e = t + i*T; slot(2e) = slot(2t) + i*(2T + 2T/8)
+            const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(pair + i * (2 * T + T / 4));
+            (dst2 + i * T)[t] = make_ulonglong2(fwd_canon<MODE>(v.x, it.lp), fwd_canon<MODE>(v.y, it.lp));
         }
         if (half + 1 < HALVES) __syncthreads();
     }
@@ -286,7 +330,7 @@ __global__ __launch_bounds__(1 << Plan<LOGN>::LOGT, 4) void ntt_fwd_kernel(NttLa
 // inverse, 2^12 <= N <= 2^15.  Inputs must be < 4q (the reference's own InvButterfly,
 // ring/ntt.go:43-50, is only congruence-preserving for inputs <= 2q: U+2Q-V must not wrap).
 // ------------------------------------------------------------------------------------------
-template <int LOGN>
+template <int LOGN, bool BIGQ>
 __global__ __launch_bounds__(1 << Plan<LOGN>::LOGT, 4) void ntt_inv_kernel(NttLaunch a) {
     using P = Plan<LOGN>;
     constexpr int N = 1 << LOGN, T = 1 << P::LOGT, A = P::A, RA = 1 << A, S = N >> A;
@@ -302,22 +346,26 @@ __global__ __launch_bounds__(1 << Plan<LOGN>::LOGT, 4) void ntt_inv_kernel(NttLa
     for (int half = 0; half < HALVES; ++half) {
         const int res_base = half * M;
         const ulonglong2 *src2 = reinterpret_cast<const ulonglong2 *>(it.src + res_base);
+        u64 *const pair = lds + lds_slot(2 * t);
 #pragma unroll
-        for (int e = t; e < M / 2; e += T)
-            *reinterpret_cast<ulonglong2 *>(lds + lds_slot(2 * e)) = src2[e];
+        for (int i = 0; i < M / (2 * T); ++i)
+            *reinterpret_cast<ulonglong2 *>(pair + i * (2 * T + T / 4)) = (src2 + i * T)[t];
         __syncthreads();
-        inv_lds_pass<LOGN, M, T, P::P2, 0, (HALVES > 1)>(lds, it.tw, it.tw_fin, res_base, t, q, q4);
-        inv_lds_pass<LOGN, M, T, P::P1, P::P2, (HALVES > 1)>(lds, it.tw, it.tw_fin, res_base, t, q, q4);
-        inv_lds_pass<LOGN, M, T, P::P0, P::P1 + P::P2, (HALVES > 1)>(lds, it.tw, it.tw_fin, res_base, t, q, q4);
+        inv_lds_pass<LOGN, M, T, P::P2, 0, (HALVES > 1), BIGQ>(lds, it.tw, it.tw_fin, res_base, t, q, q4);
+        inv_lds_pass<LOGN, M, T, P::P1, P::P2, (HALVES > 1), BIGQ>(lds, it.tw, it.tw_fin, res_base, t, q, q4);
+        inv_lds_pass<LOGN, M, T, P::P0, P::P1 + P::P2, (HALVES > 1), BIGQ>(lds, it.tw, it.tw_fin, res_base, t, q, q4);
+        {
+            const u64 *const col = lds + lds_slot(t);
 #pragma unroll
-        for (int kk = 0; kk < RH; ++kk) x[half * RH + kk] = lds[lds_slot(kk * S + t)];
+            for (int kk = 0; kk < RH; ++kk) x[half * RH + kk] = col[kk * (S + S / 8)];
+        }
         if (half + 1 < HALVES) __syncthreads();
     }
-    inv_stages<A, 0, (HALVES > 1)>(x, it.tw, 1u, q, q4);
+    inv_stages<A, 0, (HALVES > 1), BIGQ>(x, it.tw, 1u, q, q4);
     // MRed(x, nttNInv) of ring/ntt.go:136-138 == x * N^-1 mod q, canonical
 #pragma unroll
     for (int k = 0; k < RA; ++k)
-        it.dst[k * S + t] = canon_from_4q(mul_shoup_lazy(x[k], it.lp.n_inv, it.lp.n_inv_shoup, q), q);
+        (it.dst + k * S)[t] = canon_from_4q(mul_shoup_lazy(x[k], it.lp.n_inv, it.lp.n_inv_shoup, q), q);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -338,13 +386,13 @@ __global__ __launch_bounds__(256) void ntt_small_kernel(NttLaunch a, int logn, i
                 const int j = (i << (p + 1)) | jj;
                 const Twiddle w = it.tw[(1 << (logn - 1 - p)) + i];
                 u64 U = lds[j], V = lds[j + (1 << p)];
-                fwd_bfly<0>(U, V, w.x, w.y, q, q4, true);
+                fwd_bfly<3>(U, V, w.x, w.y, q, q4, true);
                 lds[j] = U;
                 lds[j + (1 << p)] = V;
             }
             __syncthreads();
         }
-        for (int e = t; e < n; e += 256) it.dst[e] = fwd_canon<0>(lds[e], it.lp);
+        for (int e = t; e < n; e += 256) it.dst[e] = fwd_canon<3>(lds[e], it.lp);
     } else {
         for (int e = t; e < n; e += 256) lds[e] = it.src[e];
         __syncthreads();
@@ -354,7 +402,7 @@ __global__ __launch_bounds__(256) void ntt_small_kernel(NttLaunch a, int logn, i
                 const int j = (i << (p + 1)) | jj;
                 const Twiddle w = it.tw[(1 << (logn - 1 - p)) + i];
                 u64 U = lds[j], V = lds[j + (1 << p)];
-                inv_bfly<false>(U, V, w.x, w.y, q, q4);
+                inv_bfly<false, false>(U, V, w.x, w.y, q, q4);
                 lds[j] = U;
                 lds[j + (1 << p)] = V;
             }
@@ -386,13 +434,13 @@ static hipError_t launch_fwd(const NttLaunch &a, hipStream_t stream) {
     return hipGetLastError();
 }
 
-template <int LOGN>
+template <int LOGN, bool BIGQ>
 static hipError_t launch_inv(const NttLaunch &a, hipStream_t stream) {
     using P = Plan<LOGN>;
     constexpr int M = (1 << LOGN) / P::HALVES;
     constexpr size_t lds_bytes = (size_t)lds_words(M) * sizeof(u64);
     static bool configured = false;
-    auto fn = ntt_inv_kernel<LOGN>;
+    auto fn = ntt_inv_kernel<LOGN, BIGQ>;
     if (!configured) {
         hipError_t e = hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) return e;
@@ -406,8 +454,10 @@ static hipError_t launch_inv(const NttLaunch &a, hipStream_t stream) {
 
 template <int LOGN>
 static hipError_t launch_big(const NttLaunch &a, bool inverse, int mode, hipStream_t stream) {
-    if (inverse) return launch_inv<LOGN>(a, stream);
-    switch (mode) {
+    // mode bit 8: every modulus is at least 2^32 (the inverse butterflies may use csub_hi)
+    if (inverse) return (mode & 256) ? launch_inv<LOGN, true>(a, stream) : launch_inv<LOGN, false>(a, stream);
+    switch (mode & 255) {
+    case 3: return launch_fwd<LOGN, 3>(a, stream);
     case 2: return launch_fwd<LOGN, 2>(a, stream);
     case 1: return launch_fwd<LOGN, 1>(a, stream);
     default: return launch_fwd<LOGN, 0>(a, stream);
