@@ -1,0 +1,429 @@
+"""A tiny gfx950 instruction IR with two back ends: assembly text and a numpy SIMT emulator.
+
+The hand-scheduled NTT kernels (gen_ntt.py) are straight-line programs (no branches), so one
+workgroup can be emulated with every VGPR as a numpy vector over the workgroup's threads and
+every SGPR as a vector over its waves.  The emulator covers exactly the instruction subset the
+generator emits and checks the structural rules the assembler will not (even alignment of 64-bit
+VGPR operands, one constant-bus operand per VALU instruction, no read of an unwritten register).
+It does NOT model s_waitcnt / hazards: those are handled by construction in the generator.
+"""
+import numpy as np
+
+WAVE = 64
+
+
+class Reg:
+    __slots__ = ("kind", "idx", "n")
+
+    def __init__(self, kind, idx, n=1):
+        self.kind, self.idx, self.n = kind, idx, n
+
+    def __repr__(self):
+        if self.kind == "vcc":
+            return "vcc"
+        if self.n == 1:
+            return "%s%d" % (self.kind, self.idx)
+        return "%s[%d:%d]" % (self.kind, self.idx, self.idx + self.n - 1)
+
+    def lo(self):
+        return Reg(self.kind, self.idx)
+
+    def hi(self):
+        assert self.n == 2
+        return Reg(self.kind, self.idx + 1)
+
+    def sub(self, i, n=1):
+        assert i + n <= self.n
+        return Reg(self.kind, self.idx + i, n)
+
+
+def v(i, n=1):
+    if n >= 2:
+        assert i % 2 == 0, "VGPR tuples must be even aligned on gfx90a+ (v%d x%d)" % (i, n)
+    return Reg("v", i, n)
+
+
+def s(i, n=1):
+    if n == 2:
+        assert i % 2 == 0, "SGPR pairs must be even aligned"
+    if n >= 4:
+        assert i % 4 == 0, "SGPR quads must be 4-aligned"
+    return Reg("s", i, n)
+
+
+VCC = Reg("vcc", 0, 2)
+
+
+class Program:
+    def __init__(self):
+        self.ins = []
+
+    def emit(self, op, *args, **mods):
+        self.ins.append((op, args, mods))
+
+    def comment(self, text):
+        self.ins.append(("#", (text,), {}))
+
+    # ---- text back end ------------------------------------------------------------------
+    def text(self):
+        out = []
+        for op, args, mods in self.ins:
+            if op == "#":
+                out.append("  ; " + args[0])
+                continue
+            line = "  " + op
+            if args:
+                line += " " + ", ".join(_fmt(a) for a in args)
+            for k, val in mods.items():
+                if k == "offset":
+                    if val:
+                        line += " offset:%d" % val
+                else:
+                    line += " %s" % val
+            out.append(line)
+        return "\n".join(out) + "\n"
+
+    def count(self):
+        c = {}
+        for op, _, _ in self.ins:
+            c[op] = c.get(op, 0) + 1
+        return c
+
+
+def _fmt(a):
+    if isinstance(a, Reg):
+        return repr(a)
+    if isinstance(a, int):
+        return str(a) if -16 <= a <= 64 else hex(a & 0xFFFFFFFF)
+    return str(a)
+
+
+# ------------------------------------------------------------------------------------------
+# emulator
+# ------------------------------------------------------------------------------------------
+class Machine:
+    def __init__(self, threads, lds_bytes, mem_words):
+        self.T = threads
+        self.W = threads // WAVE
+        self.vgpr = np.zeros((256, threads), dtype=np.uint32)
+        self.vdef = np.zeros(256, dtype=bool)
+        self.sgpr = np.zeros((108, self.W), dtype=np.uint32)
+        self.sdef = np.zeros(108, dtype=bool)
+        self.vcc = np.zeros(threads, dtype=bool)
+        self.scarry = {}  # carry-out masks written to SGPR pairs by VALU (per lane), keyed by sgpr idx
+        self.scc = np.zeros(self.W, dtype=bool)
+        self.lds = np.zeros(lds_bytes // 4, dtype=np.uint32)
+        self.mem = np.zeros(mem_words, dtype=np.uint32)  # flat memory, byte address = 4*index
+        self.lane_wave = np.arange(threads) // WAVE
+
+    # -- operand access
+    def rv(self, a, part=0):
+        """32-bit vector value of operand `a` (+part registers)."""
+        if isinstance(a, Reg):
+            if a.kind == "v":
+                assert self.vdef[a.idx + part], "read of unwritten v%d" % (a.idx + part)
+                return self.vgpr[a.idx + part].copy()   # never a view: destinations may alias sources
+            if a.kind == "s":
+                assert self.sdef[a.idx + part], "read of unwritten s%d" % (a.idx + part)
+                return self.sgpr[a.idx + part][self.lane_wave]
+            raise ValueError(a)
+        val = int(a) & 0xFFFFFFFF
+        if part == 1:
+            val = 0xFFFFFFFF if int(a) < 0 else 0
+        return np.full(self.T, val, dtype=np.uint32)
+
+    def rv64(self, a):
+        if isinstance(a, Reg):
+            assert a.n == 2, "64-bit operand expected: %r" % (a,)
+            if a.kind == "v":
+                assert a.idx % 2 == 0
+        return self.rv(a, 0).astype(np.uint64) | (self.rv(a, 1).astype(np.uint64) << np.uint64(32))
+
+    def wv(self, d, val, part=0):
+        assert isinstance(d, Reg) and d.kind == "v"
+        self.vgpr[d.idx + part] = val.astype(np.uint32)
+        self.vdef[d.idx + part] = True
+
+    def wv64(self, d, val):
+        assert d.n == 2 and d.idx % 2 == 0
+        self.wv(d, val & np.uint64(0xFFFFFFFF), 0)
+        self.wv(d, val >> np.uint64(32), 1)
+
+    def rs(self, a, part=0):
+        if isinstance(a, Reg):
+            assert a.kind == "s"
+            assert self.sdef[a.idx + part], "read of unwritten s%d" % (a.idx + part)
+            return self.sgpr[a.idx + part]
+        return np.full(self.W, int(a) & 0xFFFFFFFF, dtype=np.uint32)
+
+    def rs64(self, a):
+        return self.rs(a, 0).astype(np.uint64) | (self.rs(a, 1).astype(np.uint64) << np.uint64(32))
+
+    def ws(self, d, val, part=0):
+        self.sgpr[d.idx + part] = val.astype(np.uint32)
+        self.sdef[d.idx + part] = True
+
+    def _const_bus(self, args):
+        n = set()
+        for a in args:
+            if isinstance(a, Reg) and a.kind == "s":
+                n.add(a.idx)
+            elif isinstance(a, int) and not (-16 <= a <= 64):
+                n.add("lit%d" % a)
+        assert len(n) <= 1, "more than one constant-bus operand: %r" % (args,)
+
+    def _carry_in(self, c):
+        if c.kind == "vcc":
+            return self.vcc
+        return self.scarry[c.idx]
+
+    def _carry_out(self, c, mask):
+        if c.kind == "vcc":
+            self.vcc = mask
+        else:
+            self.scarry[c.idx] = mask
+            self.sdef[c.idx] = self.sdef[c.idx + 1] = True  # value is a lane mask; only used as carry
+
+    # -- memory helpers (addresses in bytes)
+    def _gaddr(self, voff, sbase, offset):
+        base = self.rs64(sbase)[self.lane_wave]
+        return base + self.rv(voff).astype(np.uint64) + np.uint64(offset)
+
+    def run(self, prog):
+        with np.errstate(over="ignore"):
+            for op, args, mods in prog.ins:
+                if op == "#":
+                    continue
+                getattr(self, "i_" + op)(*args, **mods)
+
+    # -- VALU
+    def i_v_mov_b32(self, d, a):
+        self.wv(d, self.rv(a))
+
+    def i_v_mul_hi_u32(self, d, a, b):
+        self._const_bus((a, b))
+        self.wv(d, (self.rv(a).astype(np.uint64) * self.rv(b).astype(np.uint64)) >> np.uint64(32))
+
+    def i_v_mul_lo_u32(self, d, a, b):
+        self._const_bus((a, b))
+        self.wv(d, (self.rv(a).astype(np.uint64) * self.rv(b).astype(np.uint64)) & np.uint64(0xFFFFFFFF))
+
+    def i_v_mad_u64_u32(self, d, sdst, a, b, c):
+        self._const_bus((a, b, c))
+        cval = self.rv64(c) if isinstance(c, Reg) else np.full(self.T, int(c), dtype=np.uint64)
+        self.wv64(d, self.rv(a).astype(np.uint64) * self.rv(b).astype(np.uint64) + cval)
+        self._carry_out(sdst, np.zeros(self.T, dtype=bool))  # carry never consumed
+
+    def i_v_lshl_add_u64(self, d, a, sh, c):
+        self._const_bus((a, c))
+        assert isinstance(sh, int) and 0 <= sh <= 4
+        cval = self.rv64(c) if isinstance(c, Reg) else np.full(self.T, int(c) & 0xFFFFFFFFFFFFFFFF, dtype=np.uint64)
+        self.wv64(d, (self.rv64(a) << np.uint64(sh)) + cval)
+
+    def i_v_add_u32(self, d, a, b):
+        self._const_bus((a, b))
+        self.wv(d, self.rv(a) + self.rv(b))
+
+    def i_v_sub_u32(self, d, a, b):
+        self._const_bus((a, b))
+        self.wv(d, self.rv(a) - self.rv(b))
+
+    def i_v_lshlrev_b32(self, d, sh, a):
+        self._const_bus((sh, a))
+        self.wv(d, self.rv(a) << (self.rv(sh) & np.uint32(31)))
+
+    def i_v_lshrrev_b32(self, d, sh, a):
+        self._const_bus((sh, a))
+        self.wv(d, self.rv(a) >> (self.rv(sh) & np.uint32(31)))
+
+    def i_v_and_b32(self, d, a, b):
+        self._const_bus((a, b))
+        self.wv(d, self.rv(a) & self.rv(b))
+
+    def i_v_or_b32(self, d, a, b):
+        self._const_bus((a, b))
+        self.wv(d, self.rv(a) | self.rv(b))
+
+    def i_v_lshl_add_u32(self, d, a, sh, c):
+        self._const_bus((a, c))
+        self.wv(d, (self.rv(a) << np.uint32(sh)) + self.rv(c))
+
+    def i_v_sub_co_u32(self, d, cout, a, b):
+        self._const_bus((a, b))
+        x, y = self.rv(a), self.rv(b)
+        self.wv(d, x - y)
+        self._carry_out(cout, x < y)
+
+    def i_v_subb_co_u32(self, d, cout, a, b, cin):
+        self._const_bus((a, b))
+        x, y = self.rv(a).astype(np.int64), self.rv(b).astype(np.int64)
+        r = x - y - self._carry_in(cin).astype(np.int64)
+        self.wv(d, (r & 0xFFFFFFFF).astype(np.uint32))
+        self._carry_out(cout, r < 0)
+
+    def i_v_cmp_lt_u32(self, dst, a, b):
+        self._const_bus((a, b))
+        self._carry_out(dst, self.rv(a) < self.rv(b))
+
+    def i_v_cmp_gt_i32(self, dst, a, b):
+        self._const_bus((a, b))
+        self._carry_out(dst, self.rv(a).astype(np.int32) > self.rv(b).astype(np.int32))
+
+    def i_v_cndmask_b32(self, d, a, b, c):
+        self._const_bus((a, b))
+        self.wv(d, np.where(self._carry_in(c), self.rv(b), self.rv(a)))
+
+    def i_v_readfirstlane_b32(self, d, a):
+        self.ws(d, self.rv(a).reshape(self.W, WAVE)[:, 0])
+
+    # -- SALU
+    def i_s_mov_b32(self, d, a):
+        self.ws(d, self.rs(a))
+
+    def i_s_movk_i32(self, d, a):
+        self.ws(d, np.full(self.W, int(a) & 0xFFFFFFFF, dtype=np.uint32))
+
+    def i_s_mov_b64(self, d, a):
+        if isinstance(a, Reg):
+            self.ws(d, self.rs(a, 0), 0)
+            self.ws(d, self.rs(a, 1), 1)
+        else:
+            self.ws(d, np.full(self.W, int(a) & 0xFFFFFFFF, dtype=np.uint32), 0)
+            self.ws(d, np.full(self.W, (int(a) >> 32) & 0xFFFFFFFF if int(a) >= 0 else 0xFFFFFFFF, dtype=np.uint32), 1)
+
+    def i_s_add_u32(self, d, a, b):
+        r = self.rs(a).astype(np.uint64) + self.rs(b).astype(np.uint64)
+        self.ws(d, r & np.uint64(0xFFFFFFFF))
+        self.scc = r >> np.uint64(32) != 0
+
+    def i_s_addc_u32(self, d, a, b):
+        r = self.rs(a).astype(np.uint64) + self.rs(b).astype(np.uint64) + self.scc.astype(np.uint64)
+        self.ws(d, r & np.uint64(0xFFFFFFFF))
+        self.scc = r >> np.uint64(32) != 0
+
+    def i_s_sub_u32(self, d, a, b):
+        x, y = self.rs(a), self.rs(b)
+        self.ws(d, x - y)
+        self.scc = x < y
+
+    def i_s_subb_u32(self, d, a, b):
+        r = self.rs(a).astype(np.int64) - self.rs(b).astype(np.int64) - self.scc.astype(np.int64)
+        self.ws(d, (r & 0xFFFFFFFF).astype(np.uint32))
+        self.scc = r < 0
+
+    def i_s_mul_i32(self, d, a, b):
+        self.ws(d, (self.rs(a).astype(np.uint64) * self.rs(b).astype(np.uint64)) & np.uint64(0xFFFFFFFF))
+
+    def i_s_mul_hi_u32(self, d, a, b):
+        self.ws(d, (self.rs(a).astype(np.uint64) * self.rs(b).astype(np.uint64)) >> np.uint64(32))
+
+    def i_s_lshl_b32(self, d, a, b):
+        self.ws(d, self.rs(a) << (self.rs(b) & np.uint32(31)))
+
+    def i_s_lshr_b32(self, d, a, b):
+        self.ws(d, self.rs(a) >> (self.rs(b) & np.uint32(31)))
+
+    def i_s_and_b32(self, d, a, b):
+        self.ws(d, self.rs(a) & self.rs(b))
+
+    def i_s_or_b32(self, d, a, b):
+        self.ws(d, self.rs(a) | self.rs(b))
+
+    def i_s_lshl_b64(self, d, a, b):
+        r = self.rs64(a) << (self.rs(b).astype(np.uint64) & np.uint64(63))
+        self.ws(d, r & np.uint64(0xFFFFFFFF), 0)
+        self.ws(d, r >> np.uint64(32), 1)
+
+    def _s_load(self, d, base, off, n):
+        addr = self.rs64(base) + (self.rs(off).astype(np.uint64) if isinstance(off, Reg) else np.uint64(off))
+        assert np.all(addr % 4 == 0)
+        idx = (addr // 4).astype(np.int64)
+        for k in range(n):
+            self.ws(d, self.mem[idx + k], k)
+
+    def i_s_load_dword(self, d, base, off):
+        self._s_load(d, base, off, 1)
+
+    def i_s_load_dwordx2(self, d, base, off):
+        self._s_load(d, base, off, 2)
+
+    def i_s_load_dwordx4(self, d, base, off):
+        self._s_load(d, base, off, 4)
+
+    def i_s_load_dwordx8(self, d, base, off):
+        self._s_load(d, base, off, 8)
+
+    def i_s_load_dwordx16(self, d, base, off):
+        self._s_load(d, base, off, 16)
+
+    def i_s_waitcnt(self, *a, **m):
+        pass
+
+    def i_s_barrier(self):
+        pass
+
+    def i_s_nop(self, n):
+        pass
+
+    def i_s_endpgm(self):
+        pass
+
+    # -- VMEM / LDS
+    def _gload(self, d, voff, sbase, n, offset=0):
+        addr = self._gaddr(voff, sbase, offset)
+        assert np.all(addr % (4 * min(n, 4)) == 0), "misaligned global access"
+        idx = (addr // 4).astype(np.int64)
+        for k in range(n):
+            self.wv(d, self.mem[idx + k], k)
+
+    def i_global_load_dwordx2(self, d, voff, sbase, offset=0):
+        assert d.n == 2
+        self._gload(d, voff, sbase, 2, offset)
+
+    def i_global_load_dwordx4(self, d, voff, sbase, offset=0):
+        assert d.n == 4
+        self._gload(d, voff, sbase, 4, offset)
+
+    def i_global_store_dwordx4(self, voff, data, sbase, offset=0):
+        assert data.n == 4
+        addr = self._gaddr(voff, sbase, offset)
+        assert np.all(addr % 16 == 0)
+        idx = (addr // 4).astype(np.int64)
+        for k in range(4):
+            self.mem[idx + k] = self.rv(data, k)
+
+    def i_global_store_dwordx2(self, voff, data, sbase, offset=0):
+        assert data.n == 2
+        addr = self._gaddr(voff, sbase, offset)
+        idx = (addr // 4).astype(np.int64)
+        for k in range(2):
+            self.mem[idx + k] = self.rv(data, k)
+
+    def _lds_idx(self, addr, offset, nbytes):
+        a = self.rv(addr).astype(np.int64) + offset
+        assert 0 <= offset < 65536
+        assert np.all(a % nbytes == 0), "misaligned LDS access"
+        assert np.all(a + nbytes <= self.lds.size * 4), "LDS access out of range"
+        return a // 4
+
+    def i_ds_read_b64(self, d, addr, offset=0):
+        idx = self._lds_idx(addr, offset, 8)
+        for k in range(2):
+            self.wv(d, self.lds[idx + k], k)
+
+    def i_ds_read_b128(self, d, addr, offset=0):
+        assert d.n == 4
+        idx = self._lds_idx(addr, offset, 16)
+        for k in range(4):
+            self.wv(d, self.lds[idx + k], k)
+
+    def i_ds_write_b64(self, addr, data, offset=0):
+        idx = self._lds_idx(addr, offset, 8)
+        for k in range(2):
+            self.lds[idx + k] = self.rv(data, k)
+
+    def i_ds_write_b128(self, addr, data, offset=0):
+        assert data.n == 4
+        idx = self._lds_idx(addr, offset, 16)
+        for k in range(4):
+            self.lds[idx + k] = self.rv(data, k)

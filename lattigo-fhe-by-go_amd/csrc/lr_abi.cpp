@@ -87,6 +87,7 @@ struct lr_context {
     size_t scratch_words = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int ntt_mode = 0;           // lazy-correction cadence allowed by the largest modulus (lr_ntt.hip)
+    bool use_asm = true;        // hand-scheduled assembly NTT where it applies (LR_NO_ASM=1 disables)
 };
 
 struct lr_poly {
@@ -235,6 +236,7 @@ extern "C" int lr_context_create(uint64_t N, const uint64_t *moduli, int n_modul
             if ((f == 0 && c->ntt_mode == 1) || f == 3) c->ntt_mode = f;
         }
         if (qmin >= (1ull << 32)) c->ntt_mode |= 256;
+        c->use_asm = std::getenv("LR_NO_ASM") == nullptr;
     }
     LR_HIP(hipSetDevice(device));
     c->stream = shared_stream(device);
@@ -524,6 +526,10 @@ int run_ntt(lr_context *c, bool inverse, Rows in, Rows out, int mod0, int mod_st
     a.lp = c->d_lp;
     a.tw = inverse ? c->d_inv : c->d_fwd;
     a.tw_fin = inverse ? c->d_inv_fin : c->d_fwd_fin;
+    if (!inverse && (c->ntt_mode & 255) == 1 && c->use_asm && batch <= 65535 && ntt_asm_available((int)logn)) {
+        LR_HIP(launch_ntt_asm(a, (int)logn, c->stream));
+        return LR_OK;
+    }
     LR_HIP(launch_ntt(a, (int)logn, inverse, c->ntt_mode, c->stream));
     return LR_OK;
 }

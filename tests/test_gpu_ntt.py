@@ -182,3 +182,27 @@ def test_full_size_properties_r15(gpu_pkg):
         wrapped = x[:, i, N - k:]
         want[:, i, :k] = np.where(wrapped == 0, 0, np.uint64(q) - wrapped)
     assert np.array_equal(px.get(), want)
+
+
+@pytest.mark.parametrize("logn,limbs", [(14, 3), (15, 2)])
+def test_cxx_and_asm_paths_agree(gpu_pkg, oracle, logn, limbs, monkeypatch):
+    """N = 2^14 / 2^15 with 60-bit moduli run on the hand-scheduled assembly kernel; LR_NO_ASM=1 selects the
+    C++ kernel.  Both must equal the oracle (full-range inputs)."""
+    N = 1 << logn
+    moduli = list(gpu_pkg.params.Qi60()[-limbs:])
+    oc = oracle.Context(N, moduli)
+    x = gpu_pkg.sampling.random_u64((3, limbs, N), seed=77)
+    want = [oc.ntt(np.array([[int(v) % q for v in x[b, i]] for i, q in enumerate(moduli)], dtype=np.uint64)) for b in range(3)]
+    for no_asm in (False, True):
+        if no_asm:
+            monkeypatch.setenv("LR_NO_ASM", "1")
+        else:
+            monkeypatch.delenv("LR_NO_ASM", raising=False)
+        ctx = gpu_pkg.ring.NewContextWithParams(N, moduli)
+        p, r = ctx.NewPoly(3).set(x), ctx.NewPoly(3)
+        ctx.NTT(p, r)
+        got = r.get()
+        for b in range(3):
+            assert np.array_equal(got[b], want[b]), (no_asm, b)
+        ctx.NTT(p, p)      # in place
+        assert np.array_equal(p.get(), got)
