@@ -38,18 +38,23 @@ class Gen:
         self.carry_pos = {}
         # ---- VGPR map
         self.X = [v(2 * k, 2) for k in range(self.RA)]
-        base = 2 * self.RA if self.RA >= 32 else 64
-        self.T0, self.Z1 = v(base + 0), v(base + 1)
-        self.T2, self.Z3 = v(base + 2), v(base + 3)
-        self.T01, self.T23 = v(base + 0, 2), v(base + 2, 2)
-        self.Q = v(base + 4, 2)
-        self.R = v(base + 6, 2)
-        self.C = v(base + 8, 2)
-        self.TID = v(base + 10)
-        self.GOFF = v(base + 11)
-        self.A_ = [v(base + 12 + i) for i in range(4)]
-        self.tw_base = base + 16
-        self.n_tw_slots = 12
+        base = 64
+
+        class TS:
+            """temporaries of one butterfly in flight; two sets so that two butterflies interleave"""
+            def __init__(ts, b, carry):
+                ts.T0, ts.Z1, ts.T2, ts.Z3 = v(b + 0), v(b + 1), v(b + 2), v(b + 3)
+                ts.T01, ts.T23 = v(b + 0, 2), v(b + 2, 2)
+                ts.Q, ts.R, ts.C = v(b + 4, 2), v(b + 6, 2), v(b + 8, 2)
+                ts.CY = carry
+
+        self.ts = [TS(base, VCC), TS(base + 10, s(100, 2))]
+        self.TID = v(base + 20)
+        self.LANE = v(base + 21)
+        self.A_ = [v(base + 22 + i) for i in range(4)]
+        self.GOFF = self.A_[3]        # t*8, recomputed where needed (pass A loads, column exchange)
+        self.tw_base = base + 26
+        self.n_tw_slots = 9
         self.vgpr_count = self.tw_base + 4 * self.n_tw_slots
         assert self.vgpr_count <= 128
         # ---- SGPR map
@@ -72,6 +77,8 @@ class Gen:
             reads.append(args[4])
         if op == "v_cndmask_b32":
             reads.append(args[3])
+        if op == "s_nop":
+            self.pos += int(args[0])
         for r in reads:
             key = repr(r)
             if key in self.carry_pos:
@@ -96,71 +103,85 @@ class Gen:
         return v(self.tw_base + 4 * i, 4)
 
     # ------------------------------------------------------------------ arithmetic macros
-    def modmul(self, V, tw):
-        """R <- V * w - qhat * q (lazy, [0,4q)); tw = (w0, w1, s0, s1) registers (SGPR or VGPR)."""
+    # Each macro returns a list of instructions for one temp set; `zip_emit` interleaves the lists of two
+    # independent items so that consecutive instructions of a wave rarely depend on each other.
+    def ops_modmul(self, ts, V, tw):
+        """ts.R <- V * w - qhat * q (lazy, [0,4q)); tw = (w0, w1, s0, s1) registers (SGPR or VGPR)."""
         w0, w1, s0, s1 = tw
-        e = self.e
-        e("v_mul_hi_u32", self.T0, V.hi(), s0)
-        e("v_mul_hi_u32", self.T2, V.lo(), s1)
-        e("v_mad_u64_u32", self.Q, self.JUNK, V.hi(), s1, self.T01)
-        e("v_mad_u64_u32", self.R, self.JUNK, V.lo(), w0, 0)
-        e("v_mad_u64_u32", self.C, self.JUNK, V.lo(), w1, 0)
-        e("v_lshl_add_u64", self.Q, self.Q, 0, self.T23)
-        e("v_mad_u64_u32", self.C, self.JUNK, V.hi(), w0, self.C)
-        e("v_mad_u64_u32", self.R, self.JUNK, self.Q.lo(), self.NQ.lo(), self.R)
-        e("v_mad_u64_u32", self.C, self.JUNK, self.Q.lo(), self.NQ.hi(), self.C)
-        e("v_mad_u64_u32", self.C, self.JUNK, self.Q.hi(), self.NQ.lo(), self.C)
-        e("v_add_u32", self.R.hi(), self.R.hi(), self.C.lo())
+        J = self.JUNK
+        return [
+            ("v_mul_hi_u32", ts.T0, V.hi(), s0),
+            ("v_mul_hi_u32", ts.T2, V.lo(), s1),
+            ("v_mad_u64_u32", ts.Q, J, V.hi(), s1, ts.T01),
+            ("v_mad_u64_u32", ts.R, J, V.lo(), w0, 0),
+            ("v_mad_u64_u32", ts.C, J, V.lo(), w1, 0),
+            ("v_lshl_add_u64", ts.Q, ts.Q, 0, ts.T23),
+            ("v_mad_u64_u32", ts.C, J, V.hi(), w0, ts.C),
+            ("v_mad_u64_u32", ts.R, J, ts.Q.lo(), self.NQ.lo(), ts.R),
+            ("v_mad_u64_u32", ts.C, J, ts.Q.lo(), self.NQ.hi(), ts.C),
+            ("v_mad_u64_u32", ts.C, J, ts.Q.hi(), self.NQ.lo(), ts.C),
+            ("v_add_u32", ts.R.hi(), ts.R.hi(), ts.C.lo()),
+        ]
 
-    def butterfly(self, U, V, tw, correct):
+    def ops_butterfly(self, ts, U, V, tw, correct):
         """(U, V) <- (U + V*w, U - V*w + 4q); optional U <- U - 8q if U >= 8q first."""
-        e = self.e
+        ops = []
+        mm = self.ops_modmul(ts, V, tw)
         if correct:
-            D = self.C
-            e("v_lshl_add_u64", D, U, 0, self.NQ8)
-            e("v_cmp_lt_u32", VCC, D.hi(), U.hi())
-            e("v_mul_hi_u32", self.T0, V.hi(), tw[2])      # fills the two wait states
-            e("v_mul_hi_u32", self.T2, V.lo(), tw[3])
-            e("v_cndmask_b32", U.lo(), U.lo(), D.lo(), VCC)
-            e("v_cndmask_b32", U.hi(), U.hi(), D.hi(), VCC)
-            w0, w1, s0, s1 = tw
-            e("v_mad_u64_u32", self.Q, self.JUNK, V.hi(), s1, self.T01)
-            e("v_mad_u64_u32", self.R, self.JUNK, V.lo(), w0, 0)
-            e("v_mad_u64_u32", self.C, self.JUNK, V.lo(), w1, 0)
-            e("v_lshl_add_u64", self.Q, self.Q, 0, self.T23)
-            e("v_mad_u64_u32", self.C, self.JUNK, V.hi(), w0, self.C)
-            e("v_mad_u64_u32", self.R, self.JUNK, self.Q.lo(), self.NQ.lo(), self.R)
-            e("v_mad_u64_u32", self.C, self.JUNK, self.Q.lo(), self.NQ.hi(), self.C)
-            e("v_mad_u64_u32", self.C, self.JUNK, self.Q.hi(), self.NQ.lo(), self.C)
-            e("v_add_u32", self.R.hi(), self.R.hi(), self.C.lo())
+            D = ts.C
+            ops += [("v_lshl_add_u64", D, U, 0, self.NQ8),
+                    ("v_cmp_lt_u32", ts.CY, D.hi(), U.hi())]
+            ops += mm[:2]                                   # the two mul_hi sit between compare and select
+            ops += [("v_cndmask_b32", U.lo(), U.lo(), D.lo(), ts.CY),
+                    ("v_cndmask_b32", U.hi(), U.hi(), D.hi(), ts.CY)]
+            ops += mm[2:]
         else:
-            self.modmul(V, tw)
-        e("v_lshl_add_u64", V, U, 0, self.Q4)            # Y = U + 4q ...
-        e("v_lshl_add_u64", U, U, 0, self.R)             # X = U + r
-        e("v_sub_co_u32", V.lo(), VCC, V.lo(), self.R.lo())
-        e("v_subb_co_u32", V.hi(), VCC, V.hi(), self.R.hi(), VCC)   # ... - r
+            ops += mm
+        ops += [("v_lshl_add_u64", V, U, 0, self.Q4),        # Y = U + 4q ...
+                ("v_lshl_add_u64", U, U, 0, ts.R),           # X = U + r
+                ("v_sub_co_u32", V.lo(), ts.CY, V.lo(), ts.R.lo()),
+                ("v_subb_co_u32", V.hi(), ts.CY, V.hi(), ts.R.hi(), ts.CY)]   # ... - r
+        return ops
 
-    def reduce_2q(self, X):
+    def ops_reduce_2q(self, ts, X):
         """X <- X - floor~(X/q) * q in [0, 2q) for any 64-bit X (quotient under-estimated by <= 1)."""
-        e = self.e
-        k = self.T0
-        e("v_mul_hi_u32", k, X.hi(), self.REDM)
-        e("v_lshrrev_b32", k, self.REDG, k)
-        e("v_mad_u64_u32", self.R, self.JUNK, k, self.Qm.lo(), 0)
-        e("v_mul_lo_u32", self.T2, k, self.Qm.hi())
-        e("v_add_u32", self.R.hi(), self.R.hi(), self.T2)
-        e("v_sub_co_u32", X.lo(), VCC, X.lo(), self.R.lo())
-        e("v_subb_co_u32", X.hi(), VCC, X.hi(), self.R.hi(), VCC)
+        k = ts.T0
+        return [
+            ("v_mul_hi_u32", k, X.hi(), self.REDM),
+            ("v_lshrrev_b32", k, self.REDG, k),
+            ("v_mad_u64_u32", ts.R, self.JUNK, k, self.Qm.lo(), 0),
+            ("v_mul_lo_u32", ts.T2, k, self.Qm.hi()),
+            ("v_add_u32", ts.R.hi(), ts.R.hi(), ts.T2),
+            ("v_sub_co_u32", X.lo(), ts.CY, X.lo(), ts.R.lo()),
+            ("v_subb_co_u32", X.hi(), ts.CY, X.hi(), ts.R.hi(), ts.CY),
+        ]
 
-    def canon(self, X):
+    def ops_canon(self, ts, X):
         """X in [0, 16q) -> canonical [0, q)."""
-        e = self.e
-        self.reduce_2q(X)
-        D = self.C
-        e("v_lshl_add_u64", D, X, 0, self.NQ)
-        e("v_cmp_gt_i32", VCC, 0, D.hi())
-        e("v_cndmask_b32", X.lo(), D.lo(), X.lo(), VCC)
-        e("v_cndmask_b32", X.hi(), D.hi(), X.hi(), VCC)
+        D = ts.C
+        return self.ops_reduce_2q(ts, X) + [
+            ("v_lshl_add_u64", D, X, 0, self.NQ),
+            ("v_cmp_gt_i32", ts.CY, 0, D.hi()),
+            ("v_cndmask_b32", X.lo(), D.lo(), X.lo(), ts.CY),
+            ("v_cndmask_b32", X.hi(), D.hi(), X.hi(), ts.CY),
+        ]
+
+    def zip_emit(self, items):
+        """items: list of callables ts -> op list; emitted two at a time, interleaved instruction by instruction"""
+        i = 0
+        while i < len(items):
+            a = items[i](self.ts[0])
+            b = items[i + 1](self.ts[1]) if i + 1 < len(items) else []
+            for k in range(max(len(a), len(b))):
+                if k < len(a):
+                    self.e(*a[k])
+                if k < len(b):
+                    self.e(*b[k])
+            i += 2
+
+    def butterflies(self, blist):
+        """blist: [(U, V, tw, correct)], all independent"""
+        self.zip_emit([(lambda ts, x=x: self.ops_butterfly(ts, *x)) for x in blist])
 
     def correct_flag(self, stage):
         return stage >= 2 and stage % 2 == 0
@@ -175,9 +196,11 @@ class Gen:
         e("s_load_dwordx4", s(52, 4), self.KARG, 64)
         e("s_load_dwordx2", s(56, 2), self.KARG, 80)
         e("v_mov_b32", self.TID, v(0))
-        e("v_mov_b32", self.Z1, 0)
-        e("v_mov_b32", self.Z3, 0)
+        for ts in self.ts:
+            e("v_mov_b32", ts.Z1, 0)
+            e("v_mov_b32", ts.Z3, 0)
         e("v_lshlrev_b32", self.GOFF, 3, self.TID)
+        e("v_and_b32", self.LANE, 63, self.TID)
         e("v_readfirstlane_b32", self.WAVE, self.TID)
         e("s_nop", 4)
         e("s_lshr_b32", self.WAVE, self.WAVE, 6)
@@ -214,10 +237,15 @@ class Gen:
         e("s_add_u32", self.TWF.lo(), s(56), sc[3])
         e("s_addc_u32", self.TWF.hi(), s(57), 0)
         self.c("coalesced load of the column {k*S + t}")
-        for k in range(self.RA):
+        # order 0, RA/2, 1, RA/2+1, ...: the first-stage butterflies can start after two loads
+        e("s_add_u32", self.TMP.lo(), self.SRC.lo(), (self.RA // 2) * self.S * 8)
+        e("s_addc_u32", self.TMP.hi(), self.SRC.hi(), 0)
+        for k in range(self.RA // 2):
             e("global_load_dwordx2", self.X[k], self.GOFF, self.SRC)
-            e("s_add_u32", self.SRC.lo(), self.SRC.lo(), self.S * 8)
-            e("s_addc_u32", self.SRC.hi(), self.SRC.hi(), 0)
+            e("global_load_dwordx2", self.X[k + self.RA // 2], self.GOFF, self.TMP)
+            for ptr in (self.SRC, self.TMP):
+                e("s_add_u32", ptr.lo(), ptr.lo(), self.S * 8)
+                e("s_addc_u32", ptr.hi(), ptr.hi(), 0)
         e("s_waitcnt", "lgkmcnt(0)")
         e("s_mov_b64", self.Qm, s(68, 2))
         e("s_mov_b32", self.REDM, s(82))
@@ -261,28 +289,59 @@ class Gen:
                 nsplit = (1 << (c + 1)) * 4 > 32
                 load_stage(c + 1, bufs[(c + 1) % 2], 0 if nsplit else None)
             cur = bufs[c % 2]
+            pend = []
             for j in range(1 << c):
                 if split and j == (1 << c) // 2:
                     # second half of the twiddles goes where the previous stage's lived
+                    self.butterflies(pend)
+                    pend = []
                     load_stage(c, bufs[(c + 1) % 2], 1)
                     e("s_waitcnt", "lgkmcnt(0)")
                     cur = bufs[(c + 1) % 2] - 4 * j
                 tw = tuple(s(cur + 4 * j + i) for i in range(4))
+                blist = []
                 for i in range(1 << b):
                     k0 = (j << (b + 1)) | i
                     k1 = k0 | (1 << b)
-                    if c == 0:
-                        e("s_waitcnt", "vmcnt(%d)" % (RA - 1 - k1))
-                        self.reduce_2q(self.X[k0])       # first-stage U operands: any 64-bit value accepted
-                    self.butterfly(self.X[k0], self.X[k1], tw, self.correct_flag(c))
+                    blist.append((self.X[k0], self.X[k1], tw, self.correct_flag(c)))
+                if c == 0:
+                    # loads were issued in the order 0, RA/2, 1, RA/2+1, ...: pair i needs the first 2i+2
+                    for i in range(0, len(blist), 2):
+                        e("s_waitcnt", "vmcnt(%d)" % max(RA - 2 * (i + 2), 0))
+                        # first-stage U operands: any 64-bit value is accepted
+                        self.zip_emit([(lambda ts, x=blist[i + d][0]: self.ops_reduce_2q(ts, x)) for d in range(2)])
+                        self.butterflies(blist[i:i + 2])
+                else:
+                    pend.extend(blist)
+            if c > 0:
+                self.butterflies(pend)
+
+    # ------------------------------------------------------------------ LDS phase
+    # After pass A the resident half consists of 16 independent sub-transforms of 1024 coefficients
+    # (index bits 9..0).  Wave w owns sub-transform w for ALL remaining stages: 64 lanes x 16
+    # coefficients.  The only workgroup barriers are the ones around the column exchange; between
+    # them the 16 waves run decoupled (LDS operations of one wave execute in order), so the LDS and
+    # twiddle latencies of one wave hide behind the arithmetic of the others.
+    def uniform_twiddle_loads(self, half):
+        """scalar twiddles of the stages over bits 9..7: H = 2^(logn-10) + 16*half + wave"""
+        e, sc = self.e, self.SC
+        buf = self.PB
+        e("s_add_u32", sc[2], self.WAVE, (1 << (self.logn - 10)) + 16 * half)
+        e("s_lshl_b32", sc[3], sc[2], 4)
+        e("s_load_dwordx4", s(buf, 4), self.TW, sc[3])
+        e("s_lshl_b32", sc[3], sc[2], 5)
+        e("s_load_dwordx8", s(buf + 8, 8), self.TW, sc[3])
+        e("s_lshl_b32", sc[3], sc[2], 6)
+        e("s_load_dwordx16", s(buf + 16, 16), self.TW, sc[3])
 
     def lds_write_columns(self, half):
         e = self.e
         a0, a1, a2 = self.A_[0], self.A_[1], self.A_[2]
         self.c("half %d -> LDS image (16 B of padding per 16 coefficients)" % half)
+        self.uniform_twiddle_loads(half)
         e("v_lshrrev_b32", a2, 4, self.TID)
         e("v_lshlrev_b32", a2, 4, a2)
-        e("v_add_u32", a0, self.GOFF, a2)                    # slot(t) * 8
+        e("v_lshl_add_u32", a0, self.TID, 3, a2)              # slot(t) * 8
         e("v_add_u32", a1, 8 * 9216, a0)
         for kk in range(self.RH):
             base, off = (a0, kk * 9216) if kk < 8 else (a1, (kk - 8) * 9216)
@@ -290,161 +349,221 @@ class Gen:
         e("s_waitcnt", "lgkmcnt(0)")
         e("s_barrier")
 
-    def lds_pass_uniform(self, half):
-        """bits 9..7 (R = 3, PLO = 7): twiddles are wave-uniform."""
-        e = self.e
-        a0, a1, a2 = self.A_[0], self.A_[1], self.A_[2]
-        sc = self.SC
-        stage0 = self.logn - 10
-        self.c("LDS pass over bits 9..7")
-        e("v_and_b32", a2, 127, self.TID)
-        e("v_lshrrev_b32", a1, 4, a2)
-        e("v_lshlrev_b32", a1, 4, a1)
-        e("v_lshl_add_u32", a0, a2, 3, a1)
-        e("s_lshr_b32", sc[0], self.WAVE, 1)                 # u_hi of task 0
-        e("s_mul_i32", sc[1], sc[0], 9216)
-        e("v_add_u32", a0, sc[1], a0)
-        e("v_add_u32", a1, 8 * 9216, a0)
-        # twiddles: H = 2^(logn-10) + 16*half + u_hi (+8 for the second task)
-        for g, buf in ((0, self.PB), (1, self.QB)):
-            e("s_add_u32", sc[2], sc[0], (1 << (self.logn - 10)) + 16 * half + 8 * g)
-            e("s_lshl_b32", sc[3], sc[2], 4)
-            e("s_load_dwordx4", s(buf, 4), self.TW, sc[3])
-            e("s_lshl_b32", sc[3], sc[2], 5)
-            e("s_load_dwordx8", s(buf + 8, 8), self.TW, sc[3])
-            e("s_lshl_b32", sc[3], sc[2], 6)
-            e("s_load_dwordx16", s(buf + 16, 16), self.TW, sc[3])
-        Y = [v(2 * k, 2) for k in range(8)]
-        for g, (addr, buf) in enumerate(((a0, self.PB), (a1, self.QB))):
-            for k in range(8):
-                e("ds_read_b64", Y[k], addr, offset=k * 1152)
-            e("s_waitcnt", "lgkmcnt(0)")
-            self.radix8(Y, lambda c, j: tuple(s(buf + (0, 8, 16)[c] + 4 * j + i) for i in range(4)), stage0)
-            for k in range(8):
-                e("ds_write_b64", addr, Y[k], offset=k * 1152)
-        e("s_waitcnt", "lgkmcnt(0)")
-        e("s_barrier")
-
-    def radix8(self, Y, twf, stage0):
+    def radix8(self, Y, twf, stage0, hook=None):
+        """three stages on 8 coefficients; hook(n) runs after the n-th twiddle has been consumed"""
+        n = 0
         for c in range(3):
             b = 2 - c
+            blist, marks = [], []
             for j in range(1 << c):
                 tw = twf(c, j)
                 for i in range(1 << b):
                     k0 = (j << (b + 1)) | i
-                    self.butterfly(Y[k0], Y[k0 | (1 << b)], tw, self.correct_flag(stage0 + c))
+                    blist.append((Y[k0], Y[k0 | (1 << b)], tw, self.correct_flag(stage0 + c)))
+                marks.append(len(blist))
+            self.butterflies(blist)
+            for _ in marks:
+                n += 1
+                if hook:
+                    hook(n)
+
+    # ---- streaming of per-lane twiddles through the small pool of VGPR quads -----------------------------
+    # `stream_begin(requests)` takes the ordered list of (key, issue_fn(slot_reg)); as many as there are free
+    # quads are issued at once, the rest as quads are released.  vector-memory operations complete in issue
+    # order, so "key has landed" == "at most (issued - 1 - position(key)) operations outstanding".
+    def stream_begin(self, requests, base_outstanding=0):
+        self.st_keys = [k for k, _ in requests]
+        self.st_fn = dict(requests)
+        self.st_pending = list(self.st_keys)
+        self.st_slot = {}
+        self.st_issued = 0
+        self.st_other = base_outstanding      # younger foreign operations are not allowed while a stream is live
+        if not hasattr(self, "st_free"):
+            self.st_free = list(range(self.n_tw_slots))
+        self.stream_pump()
+
+    def stream_pump(self):
+        while self.st_pending and self.st_free:
+            k = self.st_pending.pop(0)
+            r = self.st_free.pop(0)
+            self.st_slot[k] = r
+            self.st_fn[k](self.tw_slot(r))
+            self.st_issued += 1
+
+    def stream_wait(self, key, also="") :
+        idx = self.st_keys.index(key)
+        assert key in self.st_slot, "twiddle %r was never issued (pool too small for the access order)" % (key,)
+        self.e("s_waitcnt", ("vmcnt(%d) " % (self.st_issued - 1 - idx) + also).strip())
+        r = self.tw_slot(self.st_slot[key])
+        return tuple(r.sub(i) for i in range(4))
+
+    def stream_release(self, key):
+        self.st_free.append(self.st_slot[key])
+        self.stream_pump()
+
+    def lane_twiddle_requests(self, half, g, tag):
+        """the 7 twiddles of the stages over bits 6..4 for task g, in heap order; H*16 is kept in A_[3]
+        H = 2^(logn-7) + 128*half + 8*wave + (lane >> 4) + 4*g"""
+        e = self.e
+        a3 = self.A_[3]
+
+        def addr(shift):
+            def f():
+                e("v_lshrrev_b32", a3, 4, self.LANE)
+                e("s_lshl_b32", self.SC[5], self.WAVE, 3)
+                e("s_add_u32", self.SC[5], self.SC[5], (1 << (self.logn - 7)) + 128 * half + 4 * g)
+                e("v_add_u32", a3, self.SC[5], a3)
+                e("v_lshlrev_b32", a3, 4 + shift, a3)
+            return f
+
+        reqs = []
+        for c in range(3):
+            for j in range(1 << c):
+                def issue(slot, c=c, j=j):
+                    addr(c)()
+                    e("global_load_dwordx4", slot, a3, self.TW, offset=16 * j)
+                reqs.append(((tag, c, j), issue))
+        return reqs
+
+    def wave_lds_base(self):
+        """SC[6] <- wave * 9216: byte offset of this wave's 1024-coefficient block in the padded image"""
+        self.e("s_mul_i32", self.SC[6], self.WAVE, 9216)
+
+    def lds_pass_uniform(self, half):
+        """bits 9..7 (R = 3): lane l owns the columns l and l + 64 of its wave's block; twiddles wave-uniform."""
+        e = self.e
+        a0, a1 = self.A_[0], self.A_[1]
+        stage0 = self.logn - 10
+        self.c("stages over bits 9..7 (wave-local)")
+        self.wave_lds_base()
+        e("v_lshrrev_b32", a1, 4, self.LANE)
+        e("v_lshlrev_b32", a1, 4, a1)
+        e("v_lshl_add_u32", a0, self.LANE, 3, a1)             # slot(l) * 8
+        e("v_add_u32", a0, self.SC[6], a0)
+        YA = [v(2 * k, 2) for k in range(8)]
+        YB = [v(16 + 2 * k, 2) for k in range(8)]
+        for k in range(8):
+            e("ds_read_b64", YA[k], a0, offset=k * 1152)
+        for k in range(8):
+            e("ds_read_b64", YB[k], a0, offset=k * 1152 + 576)    # column l + 64: 64*8 + 4*16 bytes further
+        twf = lambda c, j: tuple(s(self.PB + (0, 8, 16)[c] + 4 * j + i) for i in range(4))
+        # per-lane twiddles of the next stages start travelling now (no other vector-memory traffic is live)
+        self.stream_begin(self.lane_twiddle_requests(half, 0, "a") + self.lane_twiddle_requests(half, 1, "b"))
+        e("s_waitcnt", "lgkmcnt(8)")
+        self.radix8(YA, twf, stage0)
+        for k in range(8):
+            e("ds_write_b64", a0, YA[k], offset=k * 1152)
+        e("s_waitcnt", "lgkmcnt(8)")                              # task 1's reads (issued before the 8 writes)
+        self.radix8(YB, twf, stage0)
+        for k in range(8):
+            e("ds_write_b64", a0, YB[k], offset=k * 1152 + 576)
 
     def lds_pass_lane(self, half):
-        """bits 6..4 (R = 3, PLO = 4): per-lane twiddles from the heap-ordered table."""
+        """bits 6..4 (R = 3): lane l owns rows (l >> 4) and (l >> 4) + 4, column l & 15; per-lane twiddles."""
         e = self.e
-        a0, a1, a2, a3 = self.A_
+        a0, a2 = self.A_[0], self.A_[2]
         stage0 = self.logn - 7
-        self.c("LDS pass over bits 6..4")
-        e("v_lshrrev_b32", a2, 4, self.TID)                   # u_hi of task 0
+        self.c("stages over bits 6..4 (wave-local)")
+        e("v_lshrrev_b32", a2, 4, self.LANE)
         e("s_movk_i32", self.SC[4], 1152)                    # VOP3 takes no literal on gfx9
         e("v_mul_lo_u32", a0, a2, self.SC[4])
-        e("v_and_b32", a3, 15, self.TID)
-        e("v_lshl_add_u32", a0, a3, 3, a0)
-        e("v_add_u32", a1, 8 * 9216, a0)
-        Y = [v(2 * k, 2) for k in range(8)]
-        for g, addr in enumerate((a0, a1)):
-            # H = 2^(logn-7) + 128*half + u_hi + 64*g ; byte offsets H*16, H*32 + 16j, H*64 + 16j
-            e("v_add_u32", a3, (1 << (self.logn - 7)) + 128 * half + 64 * g, a2)
-            e("v_lshlrev_b32", a3, 4, a3)
-            slots = [self.tw_slot(i) for i in range(7)]
-            e("global_load_dwordx4", slots[0], a3, self.TW)
-            e("v_lshlrev_b32", a3, 1, a3)
-            for j in range(2):
-                e("global_load_dwordx4", slots[1 + j], a3, self.TW, offset=16 * j)
-            e("v_lshlrev_b32", a3, 1, a3)
-            for j in range(4):
-                e("global_load_dwordx4", slots[3 + j], a3, self.TW, offset=16 * j)
-            for k in range(8):
-                e("ds_read_b64", Y[k], addr, offset=k * 144)
-            e("s_waitcnt", "vmcnt(0) lgkmcnt(0)")
-            self.radix8(Y, lambda c, j: tuple(slots[(0, 1, 3)[c] + j].sub(i) for i in range(4)), stage0)
-            for k in range(8):
-                e("ds_write_b64", addr, Y[k], offset=k * 144)
-        e("s_waitcnt", "lgkmcnt(0)")
-        e("s_barrier")
+        e("v_and_b32", a2, 15, self.LANE)
+        e("v_lshl_add_u32", a0, a2, 3, a0)
+        e("v_add_u32", a0, self.SC[6], a0)
+        YA = [v(2 * k, 2) for k in range(8)]
+        YB = [v(16 + 2 * k, 2) for k in range(8)]
+        for k in range(8):
+            e("ds_read_b64", YA[k], a0, offset=k * 144)
+        for k in range(8):
+            e("ds_read_b64", YB[k], a0, offset=k * 144 + 4608)
+        for tag, Y, off, lg in (("a", YA, 0, "lgkmcnt(8)"), ("b", YB, 4608, "lgkmcnt(8)")):
+            first = [True]
 
-    def lds_pass_final(self, half):
-        """bits 3..0 (R = 4, PLO = 0): 16 contiguous coefficients, lane-transposed twiddle table."""
+            def twf(c, j, tag=tag, lg=lg):
+                tw = self.stream_wait((tag, c, j), lg if first[0] else "")
+                first[0] = False
+                return tw
+
+            order = [(tag, c, j) for c in range(3) for j in range(1 << c)]
+            self.radix8(Y, twf, stage0, hook=lambda n, order=order: self.stream_release(order[n - 1]))
+            for k in range(8):
+                e("ds_write_b64", a0, Y[k], offset=k * 144 + off)
+        # the last four stages' twiddles (lane-transposed table) follow in the same stream discipline
+        self.final_prefetch(half)
+
+    def final_prefetch(self, half):
         e = self.e
-        a0, a1, a2 = self.A_[0], self.A_[1], self.A_[2]
-        stage0 = self.logn - 4
-        self.c("LDS pass over bits 3..0")
-        e("s_movk_i32", self.SC[4], 144)
-        e("v_mul_lo_u32", a0, self.TID, self.SC[4])
-        e("v_lshlrev_b32", a2, 4, self.TID)                   # t * 16
-        Y = [v(2 * k, 2) for k in range(16)]
-        for k in range(0, 16, 2):
-            e("ds_read_b128", v(2 * k, 4), a0, offset=8 * k)
-        # running pointer over the 15 slots of the transposed table: slot stride N/16 entries
+        a2 = self.A_[2]
+        e("v_lshlrev_b32", a2, 4, self.TID)                   # block index half*1024 + 64*wave + lane = half*1024 + t
         e("s_add_u32", self.TWFR.lo(), self.TWF.lo(), half * 16384)
         e("s_addc_u32", self.TWFR.hi(), self.TWF.hi(), 0)
-        slot_regs = {}
-        order = [(c, j) for c in range(4) for j in range(1 << c)]
-        free = list(range(self.n_tw_slots))
 
-        def issue(cj):
-            r = free.pop(0)
-            slot_regs[cj] = r
-            e("global_load_dwordx4", self.tw_slot(r), a2, self.TWFR)
+        def issue(slot):
+            e("global_load_dwordx4", slot, a2, self.TWFR)
             e("s_add_u32", self.TWFR.lo(), self.TWFR.lo(), (self.N // 16) * 16)
             e("s_addc_u32", self.TWFR.hi(), self.TWFR.hi(), 0)
 
-        pending = list(order)
-        while pending and free:
-            issue(pending.pop(0))
+        self.stream_begin([(("f", c, j), issue) for c in range(4) for j in range(1 << c)])
+
+    def lds_pass_final(self, half):
+        """bits 3..0 (R = 4): lane l owns the 16 contiguous coefficients of block l; lane-transposed twiddles."""
+        e = self.e
+        a0 = self.A_[0]
+        stage0 = self.logn - 4
+        self.c("stages over bits 3..0 (wave-local)")
+        e("s_movk_i32", self.SC[4], 144)
+        e("v_mul_lo_u32", a0, self.LANE, self.SC[4])
+        e("v_add_u32", a0, self.SC[6], a0)
+        Y = [v(2 * k, 2) for k in range(16)]
+        for k in range(0, 16, 2):
+            e("ds_read_b128", v(2 * k, 4), a0, offset=8 * k)
         e("s_waitcnt", "lgkmcnt(0)")
-        issued = len(order) - len(pending)
-        done = 0
         for c in range(4):
             b = 3 - c
-            for j in range(1 << c):
-                # wait until this twiddle has landed: loads complete in order
-                idx = order.index((c, j))
-                outstanding_allowed = issued - 1 - idx
-                e("s_waitcnt", "vmcnt(%d)" % outstanding_allowed)
-                r = slot_regs[(c, j)]
-                tw = tuple(self.tw_slot(r).sub(i) for i in range(4))
-                for i in range(1 << b):
-                    k0 = (j << (b + 1)) | i
-                    self.butterfly(Y[k0], Y[k0 | (1 << b)], tw, self.correct_flag(stage0 + c))
-                free.append(r)
-                done += 1
-                if pending:
-                    issue(pending.pop(0))
-                    issued += 1
+            # twiddles are consumed two at a time so that butterflies of different twiddles can interleave
+            js = list(range(1 << c))
+            for j0 in range(0, len(js), 2):
+                group = js[j0:j0 + 2]
+                blist = []
+                for j in group:
+                    tw = self.stream_wait(("f", c, j))
+                    for i in range(1 << b):
+                        k0 = (j << (b + 1)) | i
+                        blist.append((Y[k0], Y[k0 | (1 << b)], tw, self.correct_flag(stage0 + c)))
+                self.butterflies(blist)
+                for j in group:
+                    self.stream_release(("f", c, j))
         for k in range(0, 16, 2):
             e("ds_write_b128", a0, v(2 * k, 4), offset=8 * k)
-        e("s_waitcnt", "lgkmcnt(0)")
-        e("s_barrier")
 
     def copy_out(self, half):
+        """wave w stores its 1024 finished coefficients (8 KiB contiguous): canonical reduction + 16-byte stores"""
         e = self.e
         a0, a1, a2 = self.A_[0], self.A_[1], self.A_[2]
-        self.c("copy-out: canonical reduction + coalesced 16-byte stores")
-        e("v_lshrrev_b32", a1, 3, self.TID)
+        self.c("copy-out (wave-local)")
+        e("v_lshrrev_b32", a1, 3, self.LANE)
         e("v_lshlrev_b32", a1, 4, a1)
-        e("v_lshl_add_u32", a0, self.TID, 4, a1)              # slot(2t) * 8
-        e("v_add_u32", a1, 4 * 18432, a0)
-        e("v_lshlrev_b32", a2, 4, self.TID)                   # t * 16
-        n = self.M // (2 * T)
+        e("v_lshl_add_u32", a0, self.LANE, 4, a1)             # slot(2l) * 8
+        e("v_add_u32", a0, self.SC[6], a0)
+        e("v_lshlrev_b32", a2, 4, self.LANE)                  # l * 16
+        # destination of this wave: dst + (half*16 + wave) * 8192
+        e("s_lshl_b32", self.SC[5], self.WAVE, 13)
+        e("s_add_u32", self.TMP.lo(), self.DST.lo(), self.SC[5])
+        e("s_addc_u32", self.TMP.hi(), self.DST.hi(), 0)
+        n = 8
         regs = [v(4 * i, 4) for i in range(n)]
         for i in range(n):
-            base, off = (a0, i * 18432) if i < 4 else (a1, (i - 4) * 18432)
-            e("ds_read_b128", regs[i], base, offset=off)
+            e("ds_read_b128", regs[i], a0, offset=i * 1152)
         for i in range(n):
             r = regs[i]
             e("s_waitcnt", "lgkmcnt(%d)" % (n - 1 - i))
-            self.canon(r.sub(0, 2))
-            self.canon(r.sub(2, 2))
-            e("global_store_dwordx4", a2, r, self.DST)
-            e("s_add_u32", self.DST.lo(), self.DST.lo(), T * 16)
-            e("s_addc_u32", self.DST.hi(), self.DST.hi(), 0)
+            self.zip_emit([(lambda ts, x=r.sub(0, 2): self.ops_canon(ts, x)), (lambda ts, x=r.sub(2, 2): self.ops_canon(ts, x))])
+            e("global_store_dwordx4", a2, r, self.TMP)
+            e("s_add_u32", self.TMP.lo(), self.TMP.lo(), 1024)
+            e("s_addc_u32", self.TMP.hi(), self.TMP.hi(), 0)
         if half + 1 < self.HALVES:
+            e("s_add_u32", self.DST.lo(), self.DST.lo(), self.M * 8)
+            e("s_addc_u32", self.DST.hi(), self.DST.hi(), 0)
             e("s_waitcnt", "lgkmcnt(0)")
             e("s_barrier")
 

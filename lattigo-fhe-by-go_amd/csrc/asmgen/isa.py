@@ -141,6 +141,7 @@ class Machine:
 
     def wv(self, d, val, part=0):
         assert isinstance(d, Reg) and d.kind == "v"
+        assert d.idx + part < 128, "VGPR budget of a 1024-thread workgroup exceeded: v%d" % (d.idx + part)
         self.vgpr[d.idx + part] = val.astype(np.uint32)
         self.vdef[d.idx + part] = True
 
