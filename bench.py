@@ -48,20 +48,24 @@ def dist_env():
     return rank, world, local
 
 
-def timed_region(step, steps, warmup, sync, barrier, all_max):
-    """W untimed warm-ups, then exactly K steps bracketed by barrier + sync; returns max-over-ranks seconds."""
+def timed_region(step, steps, warmup, sync, barrier, all_max, ev_start=None, ev_stop=None):
+    """W untimed warm-ups, then exactly K steps bracketed by barrier + sync; returns (max-over-ranks seconds,
+    this rank's device milliseconds between HIP events recorded on the launch stream around the same K steps)."""
     for _ in range(warmup):
         step()
     sync()
     barrier()
     sync()
     t0 = time.perf_counter()
+    if ev_start:
+        ev_start()
     for _ in range(steps):
         step()
+    dev_ms = ev_stop() if ev_stop else None
     sync()
     dt = time.perf_counter() - t0
     barrier()
-    return all_max(dt)
+    return all_max(dt), dev_ms
 
 
 def cpu_baseline_ntt(N, moduli, target_seconds=12.0):
@@ -119,7 +123,9 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="polynomials per GPU")
     ap.add_argument("--logn", type=int, default=15)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--extras", action="store_true", help="also time InvNTT / MulCoeffsMontgomery / CKKS MulRelin")
+    ap.add_argument("--extras", action="store_true", help="also time InvNTT / MulCoeffsMontgomery")
+    ap.add_argument("--no-ckks", action="store_true", help="skip the CKKS MulRelin leg")
+    ap.add_argument("--ckks-batch", type=int, default=32)
     args = ap.parse_args()
 
     import numpy as np
@@ -171,15 +177,9 @@ def main():
         ctx.NTT(src, dst)
 
     sync = torch.cuda.synchronize
-    # device-side timing of the same K launches with HIP events on the launch stream
-    for _ in range(args.warmup):
-        step()
-    sync()
-    ctx.TimerStart()
-    for _ in range(args.steps):
-        step()
-    kernel_ms = ctx.TimerStop() / args.steps
-    seconds = timed_region(step, args.steps, 0, sync, barrier, all_max)
+    # the K timed launches are bracketed by HIP events on the launch stream as well (device-side duration)
+    seconds, dev_ms = timed_region(step, args.steps, args.warmup, sync, barrier, all_max, ctx.TimerStart, ctx.TimerStop)
+    kernel_ms = dev_ms / args.steps
 
     # parity spot-check inside the bench: first poly against the oracle (checker only)
     bit_exact = None
@@ -192,6 +192,13 @@ def main():
         bit_exact = bool(np.array_equal(got, oc.ntt(base[0])))
         del full
 
+    traffic = None
+    pmc_path = os.path.join(ROOT, "profiles", "r01_final", "pmc_hbm.json")
+    if os.path.exists(pmc_path) and args.logn == 15 and B == 256:
+        try:
+            traffic = json.load(open(pmc_path))["hbm_bytes_per_launch"]   # rocprofv3 --pmc, separate passes (see file)
+        except Exception:
+            traffic = None
     limb_ntts_total = B * world * L
     value = limb_ntts_total * args.steps / seconds
     achieved = ntt_bytes(N, L, my_polys) / (kernel_ms * 1e-3) / 1e9
@@ -213,10 +220,35 @@ def main():
         "poly_ntt_per_s": value / L,
         "bit_exact": bit_exact,
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                     "kernel": "ntt_fwd_kernel<%d>" % args.logn, "kernel_ms": kernel_ms,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "kernel": ("lr_ntt_fwd%d_asm" % args.logn) if args.logn in (14, 15) and not os.environ.get("LR_NO_ASM") else "ntt_fwd_kernel<%d>" % args.logn, "kernel_ms": kernel_ms,
                      "algorithmic_bytes_per_launch": ntt_bytes(N, L, my_polys)},
     }
+
+    if rank == 0 and not args.no_ckks:
+        # second half of BASELINE.json's metric: CKKS MulRelin (ckks/evaluator.go:1016) at DefaultParams[PN15QP880],
+        # device-resident batch of independent ciphertexts, synthetic operands and evaluation key
+        cN, cQm, cPm = params.ckks_moduli("PN15QP880")
+        cB = args.ckks_batch
+        ccQ, ccP = ring.NewContextWithParams(cN, cQm, device=local), ring.NewContextWithParams(cN, cPm, device=local)
+        plan = ring.CkksPlan(ccQ, ccP, cB)
+        clevel = len(cQm) - 1
+        cbeta = -(-len(cQm) // len(cPm))
+        evk = plan.NewSwitchingKey().set(sampling.uniform_poly(cQm + cPm, cN, 2 * cbeta, seed=9))
+        cbase = sampling.uniform_poly(cQm, cN, 2, seed=3)
+        chost = np.concatenate([cbase] * (-(-cB // 2)))[:cB]
+        mkc = lambda: ccQ.NewPoly(cB).set(chost)
+        ct0, ct1, cto = (mkc(), mkc()), (mkc(), mkc()), (ccQ.NewPoly(cB), ccQ.NewPoly(cB))
+        plan.MulRelin(clevel, ct0, ct1, evk, cto)
+        ccQ.Sync()
+        ccQ.TimerStart()
+        for _ in range(3):
+            plan.MulRelin(clevel, ct0, ct1, evk, cto)
+        cms = ccQ.TimerStop() / 3
+        out["ckks_mulrelin"] = {"value": cB / (cms * 1e-3), "unit": "MulRelin/s", "batch": cB, "ms_per_batch": cms,
+                                "params": "PN15QP880 (N=2^15, 18 Q limbs + 3 P limbs, beta=6), level 17",
+                                "algorithmic_GBs": cB * 8 * cN * 360 / (cms * 1e-3) / 1e9}
+        del plan, ct0, ct1, cto, evk
 
     if args.extras and rank == 0:
         extras = {}

@@ -41,7 +41,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
-    seconds = bench.timed_region(step, steps=2, warmup=1, sync=lambda: None, barrier=barrier, all_max=all_max)
+    seconds, _ = bench.timed_region(step, steps=2, warmup=1, sync=lambda: None, barrier=barrier, all_max=all_max)
     gathered = [None] * world
     dist.all_gather_object(gathered, (rank, start, count, results, seconds))
     if rank == 0:
