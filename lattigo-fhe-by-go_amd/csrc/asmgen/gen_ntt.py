@@ -190,7 +190,7 @@ class Gen:
     def prologue(self):
         e, S_ = self.e, self
         logn, N = self.logn, self.N
-        self.c("kernel arguments (NttLaunch, 88 bytes)")
+        self.c("kernel arguments (NttLaunch, 96 bytes; the first 88 are used)")
         e("s_load_dwordx8", s(36, 8), self.KARG, 0)
         e("s_load_dwordx8", s(44, 8), self.KARG, 32)
         e("s_load_dwordx4", s(52, 4), self.KARG, 64)
@@ -597,7 +597,7 @@ def kernel_text(logn, name):
   .amdhsa_kernel {name}
     .amdhsa_group_segment_fixed_size {lds}
     .amdhsa_private_segment_fixed_size 0
-    .amdhsa_kernarg_size 88
+    .amdhsa_kernarg_size 96
     .amdhsa_user_sgpr_count 2
     .amdhsa_user_sgpr_kernarg_segment_ptr 1
     .amdhsa_system_sgpr_workgroup_id_x 1
@@ -620,11 +620,11 @@ def kernel_text(logn, name):
 amdhsa.kernels:
   - .args:
       - .offset: 0
-        .size: 88
+        .size: 96
         .value_kind: by_value
     .group_segment_fixed_size: {lds}
     .kernarg_segment_align: 8
-    .kernarg_segment_size: 88
+    .kernarg_segment_size: 96
     .max_flat_workgroup_size: 1024
     .name: {name}
     .private_segment_fixed_size: 0

@@ -508,8 +508,8 @@ struct Rows {  // a strided view of rows inside a batch buffer
 int run_ntt(lr_context *c, bool inverse, Rows in, Rows out, int mod0, int mod_step, int count, int batch) {
     if (count <= 0 || batch <= 0) return LR_OK;
     const unsigned logn = c->h.logN;
-    if (logn < 1 || logn > 15)
-        return fail(LR_ERR_UNSUPPORTED, "NTT kernels cover 2 <= N <= 2^15 in this build");
+    if (logn < 1 || logn > 16)
+        return fail(LR_ERR_UNSUPPORTED, "NTT kernels cover 2 <= N <= 2^16");
     NttLaunch a;
     a.in = in.base;
     a.out = out.base;
@@ -522,6 +522,8 @@ int run_ntt(lr_context *c, bool inverse, Rows in, Rows out, int mod0, int mod_st
     a.mod0 = mod0;
     a.mod_step = mod_step;
     a.n_items = count;
+    a.sub_log = 0;
+    a.reserved = 0;
     a.batch = batch;
     a.lp = c->d_lp;
     a.tw = inverse ? c->d_inv : c->d_fwd;

@@ -42,7 +42,10 @@ struct NttLaunch {
     const LimbParams *lp;       // [L]
     const Twiddle *tw;          // [L][N] forward or inverse table
     const Twiddle *tw_fin;      // [L][15][N/16] lane-transposed copy of the last four stages (N >= 2^12), or null
+    int sub_log;                // log2(sub-blocks per limb): 0, or 1 when N = 2^16 runs as two 2^15 sub-transforms
+    int reserved;               // (keeps the assembly kernels' argument offsets: fields above are read at fixed offsets)
 };
+static_assert(sizeof(NttLaunch) == 96, "NttLaunch layout is shared with asmgen/gen_ntt.py");
 
 // ---- coefficient-wise launches (lr_ewise.hip) ----
 struct EwiseLaunch {

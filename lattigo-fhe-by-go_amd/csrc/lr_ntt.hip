@@ -110,11 +110,11 @@ LR_D u64 fwd_input(u64 x, const LimbParams &lp) {
 // S0 = global index of the first of these stages (stage s consumes index bit logN-1-s); in
 // MODE 1 the even stages s >= 2 correct.  FENCE keeps the compiler from hoisting every
 // stage's per-lane twiddle loads to the top (register pressure).
-// FIN_STRIDE > 0: twiddles come from the lane-transposed table of the last four stages,
-// entry [slot = 2^c - 1 + j][block] with FIN_STRIDE = N/16 blocks and H = the block index:
+// FIN: twiddles come from the lane-transposed table of the last four stages,
+// entry [slot = 2^c - 1 + j][block] with fin_stride = N/16 blocks and H = the block index:
 // consecutive lanes read consecutive 16-byte entries.
-template <int R, int MODE, int S0, bool FENCE, int GROUP = 0, int FIN_STRIDE = 0, bool LOWREG = false>
-LR_D void fwd_stages(u64 (&x)[1 << R], const Twiddle *__restrict__ tw, u32 H, u64 q, u64 q4) {
+template <int R, int MODE, int S0, bool FENCE, int GROUP = 0, bool FIN = false, bool LOWREG = false>
+LR_D void fwd_stages(u64 (&x)[1 << R], const Twiddle *__restrict__ tw, u32 H, u64 q, u64 q4, int fin_stride = 0) {
 #pragma unroll
     for (int b = R - 1; b >= 0; --b) {
         const int c = R - 1 - b;
@@ -122,7 +122,7 @@ LR_D void fwd_stages(u64 (&x)[1 << R], const Twiddle *__restrict__ tw, u32 H, u6
         const bool correct = (s >= 2) && ((s & 1) == 0);
 #pragma unroll
         for (int j = 0; j < (1 << c); ++j) {
-            const Twiddle w = FIN_STRIDE > 0 ? tw[((1 << c) - 1 + j) * FIN_STRIDE + H] : tw[(H << c) + j];
+            const Twiddle w = FIN ? tw[((1 << c) - 1 + j) * fin_stride + H] : tw[(H << c) + j];
 #pragma unroll
             for (int i = 0; i < (1 << b); ++i) {
                 const int k0 = (j << (b + 1)) | i;
@@ -137,14 +137,14 @@ LR_D void fwd_stages(u64 (&x)[1 << R], const Twiddle *__restrict__ tw, u32 H, u6
     }
 }
 
-template <int R, int FIN_STRIDE = 0, bool LOWREG = false, bool BIGQ = false>
-LR_D void inv_stages(u64 (&x)[1 << R], const Twiddle *__restrict__ tw, u32 H, u64 q, u64 q4) {
+template <int R, bool FIN = false, bool LOWREG = false, bool BIGQ = false>
+LR_D void inv_stages(u64 (&x)[1 << R], const Twiddle *__restrict__ tw, u32 H, u64 q, u64 q4, int fin_stride = 0) {
 #pragma unroll
     for (int b = 0; b < R; ++b) {
         const int c = R - 1 - b;
 #pragma unroll
         for (int j = 0; j < (1 << c); ++j) {
-            const Twiddle w = FIN_STRIDE > 0 ? tw[((1 << c) - 1 + j) * FIN_STRIDE + H] : tw[(H << c) + j];
+            const Twiddle w = FIN ? tw[((1 << c) - 1 + j) * fin_stride + H] : tw[(H << c) + j];
 #pragma unroll
             for (int i = 0; i < (1 << b); ++i) {
                 const int k0 = (j << (b + 1)) | i;
@@ -167,16 +167,25 @@ template <> struct Plan<13> { static constexpr int LOGT = 9,  A = 4, HALVES = 1,
 template <> struct Plan<12> { static constexpr int LOGT = 8,  A = 4, HALVES = 1, P0 = 0, P1 = 4, P2 = 4; };
 
 // one forward LDS pass over bits [PLO, PLO+R) of the M resident coefficients
+// A workgroup may transform a 2^LOGN sub-block of a longer transform (N = 2^16 runs its top stage in a
+// separate kernel): hroot = 2^d + i is the heap position of sub-block i at depth d (1 for a whole limb),
+// fin_stride/fin_block0 locate the sub-block in the lane-transposed table of the full transform.
+struct Sub {
+    u32 hroot;
+    int fin_stride;
+    int fin_block0;
+};
+
 template <int LOGN, int M, int T, int R, int PLO, int MODE, int GROUP = 0, bool LOWREG = false>
 LR_D void fwd_lds_pass(u64 *lds, const Twiddle *__restrict__ tw, const Twiddle *__restrict__ tw_fin, int res_base, int t,
-                       u64 q, u64 q4) {
+                       u64 q, u64 q4, Sub sub) {
     if constexpr (R > 0) {
         constexpr int NT = M >> R;
 #pragma unroll
         for (int u = t; u < NT; u += T) {
             const int u_lo = u & ((1 << PLO) - 1), u_hi = u >> PLO;
             const int base = (u_hi << (PLO + R)) | u_lo;
-            u32 H = (1u << (LOGN - PLO - R)) + (u32)(res_base >> (PLO + R)) + (u32)u_hi;
+            u32 H = (sub.hroot << (LOGN - PLO - R)) + (u32)(res_base >> (PLO + R)) + (u32)u_hi;
             if constexpr (PLO >= 6) H = __builtin_amdgcn_readfirstlane(H);  // wave-uniform: scalar twiddle loads
             u64 y[1 << R];
             // the padded image is linear in k: slot(base + k*2^PLO) = slot(base) + k*(2^PLO + 2^(PLO-3)) for PLO >= 4
@@ -196,9 +205,9 @@ LR_D void fwd_lds_pass(u64 *lds, const Twiddle *__restrict__ tw, const Twiddle *
                 for (int k = 0; k < (1 << R); ++k) y[k] = row[k * KSTRIDE];
             }
             if constexpr (PLO == 0 && R == 4)
-                fwd_stages<R, MODE, LOGN - PLO - R, true, GROUP, (1 << (LOGN - 4)), LOWREG>(y, tw_fin, (u32)((res_base >> 4) + u), q, q4);
+                fwd_stages<R, MODE, LOGN - PLO - R, true, GROUP, true, LOWREG>(y, tw_fin, (u32)(sub.fin_block0 + (res_base >> 4) + u), q, q4, sub.fin_stride);
             else
-                fwd_stages<R, MODE, LOGN - PLO - R, (PLO < 6 && R >= 4), GROUP, 0, LOWREG>(y, tw, H, q, q4);
+                fwd_stages<R, MODE, LOGN - PLO - R, (PLO < 6 && R >= 4), GROUP, false, LOWREG>(y, tw, H, q, q4);
             if constexpr (PLO == 0) {
                 ulonglong2 *p = reinterpret_cast<ulonglong2 *>(row);
 #pragma unroll
@@ -214,14 +223,14 @@ LR_D void fwd_lds_pass(u64 *lds, const Twiddle *__restrict__ tw, const Twiddle *
 
 template <int LOGN, int M, int T, int R, int PLO, bool LOWREG = false, bool BIGQ = false>
 LR_D void inv_lds_pass(u64 *lds, const Twiddle *__restrict__ tw, const Twiddle *__restrict__ tw_fin, int res_base, int t,
-                       u64 q, u64 q4) {
+                       u64 q, u64 q4, Sub sub) {
     if constexpr (R > 0) {
         constexpr int NT = M >> R;
 #pragma unroll
         for (int u = t; u < NT; u += T) {
             const int u_lo = u & ((1 << PLO) - 1), u_hi = u >> PLO;
             const int base = (u_hi << (PLO + R)) | u_lo;
-            u32 H = (1u << (LOGN - PLO - R)) + (u32)(res_base >> (PLO + R)) + (u32)u_hi;
+            u32 H = (sub.hroot << (LOGN - PLO - R)) + (u32)(res_base >> (PLO + R)) + (u32)u_hi;
             if constexpr (PLO >= 6) H = __builtin_amdgcn_readfirstlane(H);
             u64 y[1 << R];
             // the padded image is linear in k: slot(base + k*2^PLO) = slot(base) + k*(2^PLO + 2^(PLO-3)) for PLO >= 4
@@ -241,9 +250,9 @@ LR_D void inv_lds_pass(u64 *lds, const Twiddle *__restrict__ tw, const Twiddle *
                 for (int k = 0; k < (1 << R); ++k) y[k] = row[k * KSTRIDE];
             }
             if constexpr (PLO == 0 && R == 4)
-                inv_stages<R, (1 << (LOGN - 4)), LOWREG, BIGQ>(y, tw_fin, (u32)((res_base >> 4) + u), q, q4);
+                inv_stages<R, true, LOWREG, BIGQ>(y, tw_fin, (u32)(sub.fin_block0 + (res_base >> 4) + u), q, q4, sub.fin_stride);
             else
-                inv_stages<R, 0, LOWREG, BIGQ>(y, tw, H, q, q4);
+                inv_stages<R, false, LOWREG, BIGQ>(y, tw, H, q, q4);
             if constexpr (PLO == 0) {
                 ulonglong2 *p = reinterpret_cast<ulonglong2 *>(row);
 #pragma unroll
@@ -262,18 +271,26 @@ struct Item {
     u64 *dst;
     const Twiddle *tw;
     const Twiddle *tw_fin;
+    Sub sub;
     LimbParams lp;
 };
 
+// n = coefficients per workgroup; the launch carries sub_log = log2(sub-blocks per limb) (0 except N = 2^16)
 LR_D Item locate(const NttLaunch &a, int n) {
-    const int item = blockIdx.x % a.n_items, b = blockIdx.x / a.n_items;
+    const int blocks_per_limb = 1 << a.sub_log;
+    const int wg = blockIdx.x % (a.n_items * blocks_per_limb), b = blockIdx.x / (a.n_items * blocks_per_limb);
+    const int item = wg >> a.sub_log, blk = wg & (blocks_per_limb - 1);
     const int mod = a.mod0 + item * a.mod_step;
+    const long long n_full = (long long)n << a.sub_log;
     Item it;
-    it.src = a.in + (long long)b * a.in_poly_stride + (long long)(a.in_limb0 + item * a.in_limb_step) * n;
-    it.dst = a.out + (long long)b * a.out_poly_stride + (long long)(a.out_limb0 + item * a.out_limb_step) * n;
-    it.tw = a.tw + (long long)mod * n;
-    it.tw_fin = a.tw_fin ? a.tw_fin + (long long)mod * (15 * (n >> 4)) : nullptr;
+    it.src = a.in + (long long)b * a.in_poly_stride + (long long)(a.in_limb0 + item * a.in_limb_step) * n_full + (long long)blk * n;
+    it.dst = a.out + (long long)b * a.out_poly_stride + (long long)(a.out_limb0 + item * a.out_limb_step) * n_full + (long long)blk * n;
+    it.tw = a.tw + (long long)mod * n_full;
+    it.tw_fin = a.tw_fin ? a.tw_fin + (long long)mod * (15 * (n_full >> 4)) : nullptr;
     it.lp = a.lp[mod];
+    it.sub.hroot = (u32)(blocks_per_limb + blk);
+    it.sub.fin_stride = (int)(n_full >> 4);
+    it.sub.fin_block0 = blk * (n >> 4);
     return it;
 }
 
@@ -300,7 +317,7 @@ __global__ __launch_bounds__(1 << Plan<LOGN>::LOGT, 4) void ntt_fwd_kernel(NttLa
     // >= q (ring/ring_scaling.go:19,102), so the U operands are reduced exactly.
 #pragma unroll
     for (int k = 0; k < RA / 2; ++k) x[k] = fwd_input<MODE>(x[k], it.lp);
-    fwd_stages<A, MODE, 0, false, (HALVES > 1 ? 4 : 0), 0, (HALVES > 1)>(x, it.tw, 1u, q, q4);
+    fwd_stages<A, MODE, 0, false, (HALVES > 1 ? 4 : 0), false, (HALVES > 1)>(x, it.tw, it.sub.hroot, q, q4);
 
 #pragma unroll
     for (int half = 0; half < HALVES; ++half) {
@@ -311,9 +328,9 @@ __global__ __launch_bounds__(1 << Plan<LOGN>::LOGT, 4) void ntt_fwd_kernel(NttLa
         }
         __syncthreads();
         const int res_base = half * M;
-        fwd_lds_pass<LOGN, M, T, P::P0, P::P1 + P::P2, MODE, 0, (HALVES > 1)>(lds, it.tw, it.tw_fin, res_base, t, q, q4);
-        fwd_lds_pass<LOGN, M, T, P::P1, P::P2, MODE, 0, (HALVES > 1)>(lds, it.tw, it.tw_fin, res_base, t, q, q4);
-        fwd_lds_pass<LOGN, M, T, P::P2, 0, MODE, (HALVES > 1 ? 4 : 0), (HALVES > 1)>(lds, it.tw, it.tw_fin, res_base, t, q, q4);
+        fwd_lds_pass<LOGN, M, T, P::P0, P::P1 + P::P2, MODE, 0, (HALVES > 1)>(lds, it.tw, it.tw_fin, res_base, t, q, q4, it.sub);
+        fwd_lds_pass<LOGN, M, T, P::P1, P::P2, MODE, 0, (HALVES > 1)>(lds, it.tw, it.tw_fin, res_base, t, q, q4, it.sub);
+        fwd_lds_pass<LOGN, M, T, P::P2, 0, MODE, (HALVES > 1 ? 4 : 0), (HALVES > 1)>(lds, it.tw, it.tw_fin, res_base, t, q, q4, it.sub);
         // copy-out: canonical reduction + coalesced 16-B stores
         ulonglong2 *dst2 = reinterpret_cast<ulonglong2 *>(it.dst + res_base);
         const u64 *const pair = lds + lds_slot(2 * t);
@@ -351,9 +368,9 @@ __global__ __launch_bounds__(1 << Plan<LOGN>::LOGT, 4) void ntt_inv_kernel(NttLa
         for (int i = 0; i < M / (2 * T); ++i)
             *reinterpret_cast<ulonglong2 *>(pair + i * (2 * T + T / 4)) = (src2 + i * T)[t];
         __syncthreads();
-        inv_lds_pass<LOGN, M, T, P::P2, 0, (HALVES > 1), BIGQ>(lds, it.tw, it.tw_fin, res_base, t, q, q4);
-        inv_lds_pass<LOGN, M, T, P::P1, P::P2, (HALVES > 1), BIGQ>(lds, it.tw, it.tw_fin, res_base, t, q, q4);
-        inv_lds_pass<LOGN, M, T, P::P0, P::P1 + P::P2, (HALVES > 1), BIGQ>(lds, it.tw, it.tw_fin, res_base, t, q, q4);
+        inv_lds_pass<LOGN, M, T, P::P2, 0, (HALVES > 1), BIGQ>(lds, it.tw, it.tw_fin, res_base, t, q, q4, it.sub);
+        inv_lds_pass<LOGN, M, T, P::P1, P::P2, (HALVES > 1), BIGQ>(lds, it.tw, it.tw_fin, res_base, t, q, q4, it.sub);
+        inv_lds_pass<LOGN, M, T, P::P0, P::P1 + P::P2, (HALVES > 1), BIGQ>(lds, it.tw, it.tw_fin, res_base, t, q, q4, it.sub);
         {
             const u64 *const col = lds + lds_slot(t);
 #pragma unroll
@@ -361,11 +378,17 @@ __global__ __launch_bounds__(1 << Plan<LOGN>::LOGT, 4) void ntt_inv_kernel(NttLa
         }
         if (half + 1 < HALVES) __syncthreads();
     }
-    inv_stages<A, 0, (HALVES > 1), BIGQ>(x, it.tw, 1u, q, q4);
+    inv_stages<A, false, (HALVES > 1), BIGQ>(x, it.tw, it.sub.hroot, q, q4);
     // MRed(x, nttNInv) of ring/ntt.go:136-138 == x * N^-1 mod q, canonical
+    if (a.sub_log == 0) {
 #pragma unroll
-    for (int k = 0; k < RA; ++k)
-        (it.dst + k * S)[t] = canon_from_4q(mul_shoup_lazy(x[k], it.lp.n_inv, it.lp.n_inv_shoup, q), q);
+        for (int k = 0; k < RA; ++k)
+            (it.dst + k * S)[t] = canon_from_4q(mul_shoup_lazy(x[k], it.lp.n_inv, it.lp.n_inv_shoup, q), q);
+    } else {
+        // sub-block of a longer transform: the last stage and the scaling follow in ntt_top_kernel; values < 4q
+#pragma unroll
+        for (int k = 0; k < RA; ++k) (it.dst + k * S)[t] = x[k];
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -414,6 +437,36 @@ __global__ __launch_bounds__(256) void ntt_small_kernel(NttLaunch a, int logn, i
 }
 
 // ------------------------------------------------------------------------------------------
+// N = 2^16: the stage over index bit 15 as a streaming kernel (two passes over HBM in total).
+//   forward: (x[j], x[j + N/2]) -> butterfly with psi heap entry 1, then the halves are two independent
+//            2^15 transforms (sub-blocks with hroot 2 and 3) handled by ntt_fwd_kernel<15>.
+//   inverse: after the two 2^15 inverse sub-transforms: last Gentleman-Sande stage, scaling by N^-1, canonical.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ntt_top_kernel(NttLaunch a, int logn, int inverse) {
+    const int item = blockIdx.y % a.n_items, b = blockIdx.y / a.n_items;
+    const int mod = a.mod0 + item * a.mod_step;
+    const long long n = 1ll << logn, h = n >> 1;
+    const LimbParams lp = a.lp[mod];
+    const Twiddle w = (a.tw + (long long)mod * n)[1];
+    const u64 q = lp.q, q4 = q << 2;
+    const u64 *src = a.in + (long long)b * a.in_poly_stride + (long long)(a.in_limb0 + item * a.in_limb_step) * n;
+    u64 *dst = a.out + (long long)b * a.out_poly_stride + (long long)(a.out_limb0 + item * a.out_limb_step) * n;
+    for (long long j = (long long)blockIdx.x * 256 + threadIdx.x; j < h; j += (long long)gridDim.x * 256) {
+        u64 U = src[j], V = src[j + h];
+        if (!inverse) {
+            U = bred_add(U, q, lp.bred_hi);
+            fwd_bfly<3>(U, V, w.x, w.y, q, q4, true);                 // X, Y < 8q: the sub-transforms reduce their inputs
+            dst[j] = U;
+            dst[j + h] = V;
+        } else {
+            inv_bfly<false, false>(U, V, w.x, w.y, q, q4);            // inputs < 4q
+            dst[j] = canon_from_4q(mul_shoup_lazy(U, lp.n_inv, lp.n_inv_shoup, q), q);
+            dst[j + h] = canon_from_4q(mul_shoup_lazy(V, lp.n_inv, lp.n_inv_shoup, q), q);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // host launchers
 // ------------------------------------------------------------------------------------------
 template <int LOGN, int MODE>
@@ -428,7 +481,7 @@ static hipError_t launch_fwd(const NttLaunch &a, hipStream_t stream) {
         if (e != hipSuccess) return e;
         configured = true;
     }
-    const dim3 grid((unsigned)(a.n_items * a.batch)), block(1u << P::LOGT);
+    const dim3 grid((unsigned)((a.n_items << a.sub_log) * a.batch)), block(1u << P::LOGT);
     (void)hipGetLastError();  // drop stale (non-sticky) errors of unrelated earlier calls
     hipLaunchKernelGGL(fn, grid, block, lds_bytes, stream, a);
     return hipGetLastError();
@@ -446,7 +499,7 @@ static hipError_t launch_inv(const NttLaunch &a, hipStream_t stream) {
         if (e != hipSuccess) return e;
         configured = true;
     }
-    const dim3 grid((unsigned)(a.n_items * a.batch)), block(1u << P::LOGT);
+    const dim3 grid((unsigned)((a.n_items << a.sub_log) * a.batch)), block(1u << P::LOGT);
     (void)hipGetLastError();
     hipLaunchKernelGGL(fn, grid, block, lds_bytes, stream, a);
     return hipGetLastError();
@@ -472,6 +525,32 @@ hipError_t launch_ntt(const NttLaunch &a, int logn, bool inverse, int mode, hipS
     case 13: return launch_big<13>(a, inverse, mode, stream);
     case 12: return launch_big<12>(a, inverse, mode, stream);
     default: break;
+    }
+    if (logn == 16) {
+        // two kernels: the stage over bit 15 streams through HBM, the rest runs as 2^15 sub-transforms
+        NttLaunch top = a, sub = a;
+        const dim3 tgrid(64, (unsigned)(a.n_items * a.batch)), tblock(256);
+        sub.sub_log = 1;
+        if (!inverse) {
+            (void)hipGetLastError();
+            hipLaunchKernelGGL(ntt_top_kernel, tgrid, tblock, 0, stream, top, 16, 0);
+            hipError_t e = hipGetLastError();
+            if (e != hipSuccess) return e;
+            sub.in = a.out;                      // continue in place on the output rows
+            sub.in_poly_stride = a.out_poly_stride;
+            sub.in_limb0 = a.out_limb0;
+            sub.in_limb_step = a.out_limb_step;
+            return launch_big<15>(sub, false, mode, stream);
+        }
+        hipError_t e = launch_big<15>(sub, true, mode, stream);
+        if (e != hipSuccess) return e;
+        top.in = a.out;
+        top.in_poly_stride = a.out_poly_stride;
+        top.in_limb0 = a.out_limb0;
+        top.in_limb_step = a.out_limb_step;
+        (void)hipGetLastError();
+        hipLaunchKernelGGL(ntt_top_kernel, tgrid, tblock, 0, stream, top, 16, 1);
+        return hipGetLastError();
     }
     if (logn >= 1 && logn <= 11) {
         const dim3 grid((unsigned)(a.n_items * a.batch)), block(256);

@@ -36,7 +36,7 @@ def test_context_tables_match_oracle(gpu_pkg, oracle):
 
 
 @pytest.mark.parametrize("logn,limbs,batch", [(1, 1, 2), (3, 2, 3), (10, 2, 2), (11, 3, 2), (12, 2, 3), (13, 4, 2),
-                                              (14, 8, 2), (15, 16, 2)])
+                                              (14, 8, 2), (15, 16, 2), (16, 3, 2)])
 def test_ntt_vs_oracle(gpu_pkg, oracle, logn, limbs, batch):
     N = 1 << logn
     moduli = list(gpu_pkg.params.Qi60()[-limbs:])
@@ -53,12 +53,12 @@ def test_ntt_vs_oracle(gpu_pkg, oracle, logn, limbs, batch):
     assert np.array_equal(p.get().reshape(batch, limbs, N), x)   # input untouched
 
 
-@pytest.mark.parametrize("logn", [10, 12, 14, 15])
+@pytest.mark.parametrize("logn", [10, 12, 14, 15, 16])
 def test_ntt_accepts_unreduced_and_full_range_input(gpu_pkg, oracle, logn):
     """The reference feeds values >= q into NTT (ring/ring_scaling.go:19,102-105); the result is the
     canonical transform of the input mod q.  Full 64-bit inputs included."""
     N = 1 << logn
-    moduli = [gpu_pkg.params.Qi60()[-1], 1099512938497 if logn <= 15 else 0, gpu_pkg.params.Pi60()[5]]
+    moduli = [gpu_pkg.params.Qi60()[-1], 1099512938497 if logn <= 15 else gpu_pkg.params.ckks_moduli('PN16QP1761')[1][1], gpu_pkg.params.Pi60()[5]]
     ctx = gpu_pkg.ring.NewContextWithParams(N, moduli)
     oc = oracle.Context(N, moduli)
     x = gpu_pkg.sampling.random_u64((1, len(moduli), N), seed=logn)
