@@ -220,6 +220,16 @@ int lr_ckks_mulrelin(lr_ckks_plan *plan, int level, const lr_poly *ct0_c0, const
 /* Rescale, one level (ckks/evaluator.go:933-968 inner loop): DivRoundByLastModulusNTT on both components. */
 int lr_ckks_rescale(lr_ckks_plan *plan, lr_poly *c0, lr_poly *c1);
 
+/* bfv.Evaluator.Mul = tensorAndRescale (bfv/evaluator.go:467,278) for two degree-1 ciphertexts, device-resident
+ * for a whole batch.  lr_bfv_plan owns what bfv.NewEvaluator builds for it: baseconverterQ1Q2 =
+ * NewFastBasisExtender(contextQ, contextQMul), pHalf = (prod QMul) >> 1 and the scratch pools (bfv/evaluator.go:89-112). */
+typedef struct lr_bfv_plan lr_bfv_plan;
+int lr_bfv_plan_create(lr_context *ctxQ, lr_context *ctxQMul, uint64_t t, int max_batch, lr_bfv_plan **out);
+int lr_bfv_plan_destroy(lr_bfv_plan *plan);
+/* operands and results over Q in the coefficient domain, as BFV ciphertexts are; out has degree 2 */
+int lr_bfv_mul(lr_bfv_plan *plan, const lr_poly *ct0_c0, const lr_poly *ct0_c1, const lr_poly *ct1_c0,
+               const lr_poly *ct1_c1, lr_poly *out_c0, lr_poly *out_c1, lr_poly *out_c2);
+
 /* ------------------------------------------------------------------ measurement ------- */
 /* HIP events on the context's stream (bench.py's roofline leg). */
 int lr_timer_start(lr_context *ctx);

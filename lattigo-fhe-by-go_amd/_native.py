@@ -71,6 +71,9 @@ SYMBOLS = {
     "lr_ckks_switch_keys": [vp, i32, vp, vp, vp, vp],
     "lr_ckks_mulrelin": [vp, i32, vp, vp, vp, vp, vp, vp, vp],
     "lr_ckks_rescale": [vp, vp, vp],
+    "lr_bfv_plan_create": [vp, vp, u64, i32, C.POINTER(vp)],
+    "lr_bfv_plan_destroy": [vp],
+    "lr_bfv_mul": [vp, vp, vp, vp, vp, vp, vp, vp],
     "lr_timer_start": [vp],
     "lr_timer_stop": [vp, C.POINTER(C.c_float)],
 }

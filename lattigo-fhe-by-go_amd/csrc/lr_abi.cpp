@@ -1282,6 +1282,143 @@ extern "C" int lr_ckks_rescale(lr_ckks_plan *pl, lr_poly *c0, lr_poly *c1) {
 }
 
 // ------------------------------------------------------------------------------------------
+// bfv.Evaluator.Mul (tensorAndRescale, bfv/evaluator.go:278-464)
+// ------------------------------------------------------------------------------------------
+struct lr_bfv_plan {
+    int device = 0;
+    lr_context *cQ = nullptr, *cM = nullptr;
+    lr_bext *bext = nullptr;
+    u64 t = 0;
+    LimbScalars phalf_q, phalf_m;     // pHalf = (prod QMul) >> 1 reduced modulo each prime
+    int max_batch = 0;
+    Pool aQ[2], aM[2], bQ[2], bM[2], cQ3[3], cM3[3], m00Q, m00M, m01Q, m01M;
+};
+
+namespace {
+// (prod of moduli) >> 1, then reduced modulo every prime of `targets` (little-endian multi-precision)
+void half_product_residues(const std::vector<u64> &moduli, const std::vector<u64> &targets, LimbScalars &out) {
+    std::vector<u64> big(1, 1);
+    for (u64 m : moduli) {
+        u64 carry = 0;
+        for (size_t i = 0; i < big.size(); ++i) {
+            const u128 p = (u128)big[i] * m + carry;
+            big[i] = (u64)p;
+            carry = (u64)(p >> 64);
+        }
+        if (carry) big.push_back(carry);
+    }
+    for (size_t i = 0; i < big.size(); ++i) big[i] = (big[i] >> 1) | (i + 1 < big.size() ? (big[i + 1] << 63) : 0);
+    std::memset(&out, 0, sizeof(out));
+    for (size_t k = 0; k < targets.size(); ++k) {
+        u64 r = 0;
+        for (size_t i = big.size(); i-- > 0;) r = (u64)((((u128)r << 64) | big[i]) % targets[k]);
+        out.v[k] = r;
+    }
+}
+}  // namespace
+
+extern "C" int lr_bfv_plan_create(lr_context *cQ, lr_context *cM, uint64_t t, int max_batch, lr_bfv_plan **out) {
+    if (!cQ || !cM || !out) return fail(LR_ERR_ARG, "null argument");
+    *out = nullptr;
+    if (max_batch < 1) return fail(LR_ERR_ARG, "max_batch must be >= 1");
+    LR_TRY(same_degree(cQ, cM));
+    std::unique_ptr<lr_bfv_plan> p(new lr_bfv_plan());
+    p->cQ = cQ;
+    p->cM = cM;
+    p->device = cQ->device;
+    p->t = t;
+    p->max_batch = max_batch;
+    half_product_residues(cM->h.q, cQ->h.q, p->phalf_q);
+    half_product_residues(cM->h.q, cM->h.q, p->phalf_m);
+    LR_TRY(lr_bext_create(cQ, cM, &p->bext));
+    *out = p.release();
+    return LR_OK;
+}
+
+extern "C" int lr_bfv_plan_destroy(lr_bfv_plan *p) {
+    if (!p) return LR_OK;
+    (void)hipSetDevice(p->device);
+    (void)hipStreamSynchronize(shared_stream(p->device));
+    lr_bext_destroy(p->bext);
+    delete p;
+    return LR_OK;
+}
+
+extern "C" int lr_bfv_mul(lr_bfv_plan *pl, const lr_poly *a0, const lr_poly *a1, const lr_poly *b0, const lr_poly *b1,
+                          lr_poly *o0, lr_poly *o1, lr_poly *o2) {
+    if (!pl || !a0 || !a1 || !b0 || !b1 || !o0 || !o1 || !o2) return fail(LR_ERR_ARG, "null argument");
+    lr_context *cQ = pl->cQ, *cM = pl->cM;
+    const int nQ = cQ->h.L(), nM = cM->h.L(), n = (int)cQ->h.N;
+    const int batch = a0->batch;
+    if (batch > pl->max_batch) return fail(LR_ERR_SHAPE, "batch exceeds the plan's max_batch");
+    for (const lr_poly *p : {a0, a1, b0, b1, (const lr_poly *)o0, (const lr_poly *)o1, (const lr_poly *)o2}) {
+        if (p->N != cQ->h.N || p->limbs < nQ || p->batch != batch) return fail(LR_ERR_SHAPE, "BFV Mul: operands must hold |Q| limbs and share the batch");
+    }
+    LR_HIP(hipSetDevice(cQ->device));
+    const long long sQ = (long long)nQ * n, sM = (long long)nM * n;
+    const lr_poly *A[2] = {a0, a1}, *B[2] = {b0, b1};
+    lr_poly *O[3] = {o0, o1, o2};
+    for (int i = 0; i < 2; ++i) {
+        LR_TRY(pl->aQ[i].ensure(cQ, (size_t)batch * sQ));
+        LR_TRY(pl->aM[i].ensure(cQ, (size_t)batch * sM));
+        LR_TRY(pl->bQ[i].ensure(cQ, (size_t)batch * sQ));
+        LR_TRY(pl->bM[i].ensure(cQ, (size_t)batch * sM));
+    }
+    for (int i = 0; i < 3; ++i) {
+        LR_TRY(pl->cQ3[i].ensure(cQ, (size_t)batch * sQ));
+        LR_TRY(pl->cM3[i].ensure(cQ, (size_t)batch * sM));
+    }
+    LR_TRY(pl->m00Q.ensure(cQ, (size_t)batch * sQ));
+    LR_TRY(pl->m01Q.ensure(cQ, (size_t)batch * sQ));
+    LR_TRY(pl->m00M.ensure(cQ, (size_t)batch * sM));
+    LR_TRY(pl->m01M.ensure(cQ, (size_t)batch * sM));
+    lr_bext *bx = pl->bext;
+    // :298-313  basis extension Q -> QMul, then NTT in both bases
+    for (int i = 0; i < 2; ++i) {
+        for (int side = 0; side < 2; ++side) {
+            const lr_poly *src = side == 0 ? A[i] : B[i];
+            Pool &dQ = side == 0 ? pl->aQ[i] : pl->bQ[i];
+            Pool &dM = side == 0 ? pl->aM[i] : pl->bM[i];
+            LR_TRY(run_ext(cQ, bx->qp, nQ, rows_of(src), batch, segment(dM.d, sM, 0, 0, nM), segment(nullptr, 0, 0, 0, 0)));
+            LR_TRY(run_ntt(cQ, false, rows_of(src), Rows{dQ.d, sQ, 0, 1}, 0, 1, nQ, batch));
+            LR_TRY(run_ntt(cM, false, Rows{dM.d, sM, 0, 1}, Rows{dM.d, sM, 0, 1}, 0, 1, nM, batch));
+        }
+    }
+    // :327-331
+    LR_TRY(run_ewise(cQ, LR_MFORM, nQ, batch, pl->aQ[0].d, sQ, nullptr, 0, pl->m00Q.d, sQ, nullptr));
+    LR_TRY(run_ewise(cM, LR_MFORM, nM, batch, pl->aM[0].d, sM, nullptr, 0, pl->m00M.d, sM, nullptr));
+    LR_TRY(run_ewise(cQ, LR_MFORM, nQ, batch, pl->aQ[1].d, sQ, nullptr, 0, pl->m01Q.d, sQ, nullptr));
+    LR_TRY(run_ewise(cM, LR_MFORM, nM, batch, pl->aM[1].d, sM, nullptr, 0, pl->m01M.d, sM, nullptr));
+    // :354-367 tensor
+    LR_TRY(run_ewise(cQ, LR_MUL_MONT, nQ, batch, pl->m00Q.d, sQ, pl->bQ[0].d, sQ, pl->cQ3[0].d, sQ, nullptr));
+    LR_TRY(run_ewise(cM, LR_MUL_MONT, nM, batch, pl->m00M.d, sM, pl->bM[0].d, sM, pl->cM3[0].d, sM, nullptr));
+    LR_TRY(run_ewise(cQ, LR_MUL_MONT, nQ, batch, pl->m00Q.d, sQ, pl->bQ[1].d, sQ, pl->cQ3[1].d, sQ, nullptr));
+    LR_TRY(run_ewise(cM, LR_MUL_MONT, nM, batch, pl->m00M.d, sM, pl->bM[1].d, sM, pl->cM3[1].d, sM, nullptr));
+    LR_TRY(run_ewise(cQ, LR_MUL_MONT_AND_ADD_NOMOD, nQ, batch, pl->m01Q.d, sQ, pl->bQ[0].d, sQ, pl->cQ3[1].d, sQ, nullptr));
+    LR_TRY(run_ewise(cM, LR_MUL_MONT_AND_ADD_NOMOD, nM, batch, pl->m01M.d, sM, pl->bM[0].d, sM, pl->cM3[1].d, sM, nullptr));
+    LR_TRY(run_ewise(cQ, LR_MUL_MONT, nQ, batch, pl->m01Q.d, sQ, pl->bQ[1].d, sQ, pl->cQ3[2].d, sQ, nullptr));
+    LR_TRY(run_ewise(cM, LR_MUL_MONT, nM, batch, pl->m01M.d, sM, pl->bM[1].d, sM, pl->cM3[2].d, sM, nullptr));
+    // :423-463 back to coefficients, divide by Q (result over QMul), centre, back to Q, times t
+    LimbScalars tsc;
+    for (int i = 0; i < nQ; ++i) tsc.v[i] = mform(bred_add(pl->t, cQ->h.q[i], cQ->h.bred[i].hi), cQ->h.q[i], cQ->h.bred[i].hi, cQ->h.bred[i].lo);
+    const long long poolM_stride = sM;
+    LR_TRY(bx->poolP.ensure(cM, (size_t)batch * poolM_stride));
+    for (int i = 0; i < 3; ++i) {
+        Rows q1{pl->cQ3[i].d, sQ, 0, 1}, q2{pl->cM3[i].d, sM, 0, 1};
+        LR_TRY(run_ntt(cQ, true, q1, q1, 0, 1, nQ, batch));
+        LR_TRY(run_ntt(cM, true, q2, q2, 0, 1, nM, batch));
+        // ModDownSplitedQP(levelQ, levelQMul, c2Q1, c2Q2, c2Q2), ring_basis_extension.go:314
+        LR_TRY(run_ext(cQ, bx->qp, nQ, q1, batch, segment(bx->poolP.d, poolM_stride, 0, 0, nM), segment(nullptr, 0, 0, 0, 0)));
+        LR_TRY(run_submul(cM, nM, batch, pl->cM3[i].d, sM, bx->poolP.d, poolM_stride, (long long)n, pl->cM3[i].d, sM, bx->d_moddown_qp, false, nullptr));
+        LR_TRY(run_ewise(cM, LR_ADD_SCALAR_LIMBS, nM, batch, pl->cM3[i].d, sM, nullptr, 0, pl->cM3[i].d, sM, &pl->phalf_m));   // :457
+        LR_TRY(run_ext(cQ, bx->pq, nM, q2, batch, segment(O[i]->d, O[i]->stride(), 0, 0, nQ), segment(nullptr, 0, 0, 0, 0)));       // :458 ModUpSplitPQ
+        LR_TRY(run_ewise(cQ, LR_SUB_SCALAR_LIMBS, nQ, batch, O[i]->d, O[i]->stride(), nullptr, 0, O[i]->d, O[i]->stride(), &pl->phalf_q));  // :459
+        LR_TRY(run_ewise(cQ, LR_MUL_SCALAR, nQ, batch, O[i]->d, O[i]->stride(), nullptr, 0, O[i]->d, O[i]->stride(), &tsc));         // :462
+    }
+    return LR_OK;
+}
+
+// ------------------------------------------------------------------------------------------
 // measurement
 // ------------------------------------------------------------------------------------------
 extern "C" int lr_timer_start(lr_context *c) {

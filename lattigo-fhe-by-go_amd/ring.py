@@ -420,3 +420,26 @@ class CkksPlan:
 
     def Rescale(self, ct):
         check(lib().lr_ckks_rescale(self.h, ct[0].h, ct[1].h))
+
+
+class BfvPlan:
+    """What bfv.NewEvaluator builds around the ring for Mul (bfv/evaluator.go:89-112) and the tensorAndRescale
+    call sequence (:278-464) for two degree-1 ciphertexts, device-resident."""
+
+    def __init__(self, contextQ, contextQMul, t, max_batch=1):
+        self.contextQ, self.contextQMul, self.t = contextQ, contextQMul, int(t)
+        h = C.c_void_p()
+        check(lib().lr_bfv_plan_create(contextQ.h, contextQMul.h, self.t, max_batch, C.byref(h)))
+        self.h = h
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                lib().lr_bfv_plan_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def Mul(self, ct0, ct1, ctOut):
+        """ct0, ct1: pairs of Poly over Q (coefficient domain); ctOut: triple (degree 2)."""
+        check(lib().lr_bfv_mul(self.h, ct0[0].h, ct0[1].h, ct1[0].h, ct1[1].h, ctOut[0].h, ctOut[1].h, ctOut[2].h))

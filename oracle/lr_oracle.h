@@ -183,6 +183,13 @@ void oc_ckks_switch_keys(oc_ckks_plan *p, int level, const uint64_t *cx, const u
 void oc_ckks_mulrelin(oc_ckks_plan *p, int level, const uint64_t *ct0, const uint64_t *ct1,
                       const uint64_t *evk, uint64_t *out);
 
+/* ---- caller sequence: bfv/evaluator.go:278-464 tensorAndRescale ---- */
+/* degree-1 x degree-1, regular case.  ct0, ct1 = [2][|Q|][N] coefficient domain; out = [3][|Q|][N].
+ * bext = NewFastBasisExtender(contextQ, contextQMul) (bfv/evaluator.go:97); phalf_q / phalf_qm = residues of
+ * pHalf = (prod QMul) >> 1 (:100) modulo the Q and QMul primes; t = plaintext modulus. */
+void oc_bfv_mul(oc_bext *b, uint64_t t, const uint64_t *phalf_q, const uint64_t *phalf_qm,
+                const uint64_t *ct0, const uint64_t *ct1, uint64_t *out);
+
 #ifdef __cplusplus
 }
 #endif

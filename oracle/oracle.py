@@ -117,6 +117,7 @@ def lib():
     sig("oc_ckks_plan_free", None, vp)
     sig("oc_ckks_switch_keys", None, vp, i, vp, vp, vp, vp)
     sig("oc_ckks_mulrelin", None, vp, i, vp, vp, vp, vp)
+    sig("oc_bfv_mul", None, vp, u64, vp, vp, vp, vp, vp)
     _lib = L
     return L
 
@@ -334,6 +335,26 @@ class BasisExtender:
         p1Q, p1P = _arr(p1Q), _arr(p1P)
         out = np.zeros((levelP + 1, self.cQ.N), dtype=np.uint64)
         lib().oc_moddown_split_qp(self.h, levelQ, levelP, _ptr(p1Q), _ptr(p1P), _ptr(out))
+        return out
+
+
+class BfvPlan:
+    """The ring-level call sequence of bfv.Evaluator.Mul (bfv/evaluator.go:278-467)."""
+
+    def __init__(self, ctxQ, ctxQMul, t):
+        self.cQ, self.cM, self.t = ctxQ, ctxQMul, int(t)
+        self.bext = BasisExtender(ctxQ, ctxQMul)            # baseconverterQ1Q2, bfv/evaluator.go:97
+        P = 1
+        for m in ctxQMul.moduli:
+            P *= m
+        self.p_half = P >> 1                                 # :100
+
+    def mul(self, ct0, ct1):
+        ct0, ct1 = _arr(ct0), _arr(ct1)
+        out = np.zeros((3, self.cQ.L, self.cQ.N), dtype=np.uint64)
+        pq = np.array([self.p_half % m for m in self.cQ.moduli], dtype=np.uint64)
+        pm = np.array([self.p_half % m for m in self.cM.moduli], dtype=np.uint64)
+        lib().oc_bfv_mul(self.bext.h, self.t, _ptr(pq), _ptr(pm), _ptr(ct0), _ptr(ct1), _ptr(out))
         return out
 
 

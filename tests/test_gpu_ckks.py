@@ -55,3 +55,24 @@ def test_mulrelin_and_rescale(gpu_pkg, oracle, logn, nq, np_, level):
     for b in range(2):
         for k in range(2):
             assert np.array_equal(out[k].get()[b], oc.rescale_op("oc_div_round_by_last_modulus_ntt", wants[b][k]))
+
+
+@pytest.mark.parametrize("name,logn", [("PN12QP109", 12), ("PN13QP218", 11), ("PN14QP438", 14)])
+def test_bfv_mul(gpu_pkg, oracle, name, logn):
+    """bfv.Evaluator.Mul = tensorAndRescale (bfv/evaluator.go:278-467) on the reference's parameter sets
+    (PN14QP438 = BASELINE config 4: 6 Q primes, 6 61-bit QMul primes, t = 65537); degree-1 x degree-1."""
+    _, Q, P, QMul = gpu_pkg.params.bfv_moduli(name)
+    N, t = 1 << logn, 65537
+    ring = gpu_pkg.ring
+    cQ, cM = ring.NewContextWithParams(N, Q), ring.NewContextWithParams(N, QMul)
+    plan = ring.BfvPlan(cQ, cM, t, 2)
+    oplan = oracle.BfvPlan(oracle.Context(N, Q), oracle.Context(N, QMul), t)
+    mk = lambda s: gpu_pkg.sampling.uniform_poly(Q, N, 2, seed=s)
+    a0, a1, b0, b1 = mk(11), mk(12), mk(13), mk(14)
+    P_ = lambda x: cQ.NewPoly(2).set(x)
+    out = (cQ.NewPoly(2), cQ.NewPoly(2), cQ.NewPoly(2))
+    plan.Mul((P_(a0), P_(a1)), (P_(b0), P_(b1)), out)
+    for b in range(2):
+        want = oplan.mul(np.stack([a0[b], a1[b]]), np.stack([b0[b], b1[b]]))
+        for k in range(3):
+            assert np.array_equal(out[k].get()[b], want[k]), (b, k)
