@@ -157,6 +157,18 @@ typedef enum lr_ewise_op {
 int lr_ewise(lr_context *ctx, int op, int level, const lr_poly *a, const lr_poly *b, lr_poly *out,
              const uint64_t *scalars);
 
+/* ------------------------------------------------------------------ Galois automorphisms */
+/* ring.PermuteNTT (ring/ring_galois.go:55) on limbs 0..level: out[i][j] = in[i][index(j)], index(j) =
+ * bitrev(((gen * (2*bitrev(j)+1) mod 2N) - 1) / 2), computed on the fly.  PermuteNTTWithIndex (:89) with the
+ * table of PermuteNTTIndex(gen, power, N) (:29) is the same call with gen^power mod 2N.  Not in place
+ * ("Careful, not inplace!"): in == out is LR_ERR_ARG. */
+int lr_permute_ntt(lr_context *ctx, int level, const lr_poly *in, uint64_t gen, lr_poly *out);
+/* PermuteNTTIndex (:29): host table of N entries */
+int lr_permute_ntt_index(uint64_t gen, uint64_t power, uint64_t N, uint64_t *index);
+/* Context.Permute (:106), coefficient domain, all limbs of the context: out[j][i*gen mod N] = +-in[j][i]
+ * (a zero coefficient whose sign flips becomes q, as in the reference).  Not in place. */
+int lr_permute(lr_context *ctx, const lr_poly *in, uint64_t gen, lr_poly *out);
+
 /* ------------------------------------------------------------------ basis extension --- */
 /* NewFastBasisExtender(contextQ, contextP), ring/ring_basis_extension.go:57 */
 int lr_bext_create(lr_context *ctxQ, lr_context *ctxP, lr_bext **out);

@@ -1,0 +1,159 @@
+// lattigo_ring.hpp -- C++ host-side mirror of Lattigo's `ring` package over the C ABI (lattigo_ring.h).
+//
+// The reference's host language is Go; no Go toolchain exists in this pipeline, so the host side above the
+// C ABI is C++ (this header) plus a Python ctypes mirror (lattigo-fhe-by-go_amd/ring.py).  Names, argument
+// order and meaning follow the reference (github.com/ldsec/lattigo/ring v1.3.1); where Go panics, these
+// throw ring::Error.  Header-only; link with -llattigo_ring_hip.
+#pragma once
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "lattigo_ring.h"
+
+namespace ring {
+
+struct Error : std::runtime_error {
+    int code;
+    Error(int c, const std::string &m) : std::runtime_error(m), code(c) {}
+};
+
+inline void check(int rc) {
+    if (rc != LR_OK) throw Error(rc, lr_last_error_string());
+}
+
+class Context;
+
+// ring.Poly (ring/ring_object.go:11-13) as a device-resident batch; Coeffs mirrors [][]uint64 on demand
+class Poly {
+  public:
+    Poly(lr_context *ctx, int limbs, int batch = 1) { check(lr_poly_alloc(ctx, limbs, batch, &h_)); }
+    ~Poly() { lr_poly_free(h_); }
+    Poly(const Poly &) = delete;
+    Poly &operator=(const Poly &) = delete;
+    lr_poly *handle() const { return h_; }
+    int GetLenModuli() const {  // ring/ring_object.go:55
+        int l = 0;
+        check(lr_poly_info(h_, nullptr, &l, nullptr, nullptr));
+        return l;
+    }
+    // SetCoefficients / GetCoefficients (ring/ring_object.go:111,129): one slice per limb, like Go's [][]uint64
+    void SetCoefficients(const std::vector<std::vector<uint64_t>> &coeffs, int batch_index = 0) {
+        std::vector<const uint64_t *> ptrs;
+        for (auto &l : coeffs) ptrs.push_back(l.data());
+        check(lr_poly_upload(h_, batch_index, ptrs.data(), (int)ptrs.size()));
+    }
+    std::vector<std::vector<uint64_t>> GetCoefficients(int batch_index = 0) const {
+        uint64_t n = 0;
+        int limbs = 0;
+        check(lr_poly_info(h_, &n, &limbs, nullptr, nullptr));
+        std::vector<std::vector<uint64_t>> out(limbs, std::vector<uint64_t>(n));
+        std::vector<uint64_t *> ptrs;
+        for (auto &l : out) ptrs.push_back(l.data());
+        check(lr_poly_download(h_, batch_index, ptrs.data(), limbs));
+        return out;
+    }
+    void Zero() { check(lr_poly_zero(h_)); }  // ring/ring_object.go:60
+
+  private:
+    lr_poly *h_ = nullptr;
+};
+
+// ring.Context (ring/ring_context.go:18-51)
+class Context {
+  public:
+    // NewContextWithParams (ring/ring_context.go:60); throws where Go returns its error / panics
+    Context(uint64_t N, const std::vector<uint64_t> &Moduli, int device = 0) : N(N), Modulus(Moduli) {
+        check(lr_context_create(N, Moduli.data(), (int)Moduli.size(), device, &h_));
+    }
+    ~Context() { lr_context_destroy(h_); }
+    Context(const Context &) = delete;
+    Context &operator=(const Context &) = delete;
+    lr_context *handle() const { return h_; }
+    const uint64_t N;
+    const std::vector<uint64_t> Modulus;
+
+    Poly *NewPoly(int batch = 1) const { return new Poly(h_, (int)Modulus.size(), batch); }             // :288
+    Poly *NewPolyLvl(uint64_t level, int batch = 1) const { return new Poly(h_, (int)level + 1, batch); } // :300
+
+    void NTT(const Poly *p1, Poly *p2) const { check(lr_ntt(h_, full(), p1->handle(), p2->handle())); }                       // ring/ntt.go:4
+    void NTTLvl(uint64_t level, const Poly *p1, Poly *p2) const { check(lr_ntt(h_, (int)level, p1->handle(), p2->handle())); } // :11
+    void InvNTT(const Poly *p1, Poly *p2) const { check(lr_intt(h_, full(), p1->handle(), p2->handle())); }                    // :18
+    void InvNTTLvl(uint64_t level, const Poly *p1, Poly *p2) const { check(lr_intt(h_, (int)level, p1->handle(), p2->handle())); }
+
+    // ring/ring.go
+    void Add(const Poly *p1, const Poly *p2, Poly *p3) const { ew(LR_ADD, full(), p1, p2, p3); }
+    void AddLvl(uint64_t l, const Poly *p1, const Poly *p2, Poly *p3) const { ew(LR_ADD, (int)l, p1, p2, p3); }
+    void Sub(const Poly *p1, const Poly *p2, Poly *p3) const { ew(LR_SUB, full(), p1, p2, p3); }
+    void Neg(const Poly *p1, Poly *p2) const { ew(LR_NEG, full(), p1, nullptr, p2); }
+    void Reduce(const Poly *p1, Poly *p2) const { ew(LR_REDUCE, full(), p1, nullptr, p2); }
+    void MulCoeffs(const Poly *p1, const Poly *p2, Poly *p3) const { ew(LR_MUL_COEFFS, full(), p1, p2, p3); }
+    void MulCoeffsMontgomery(const Poly *p1, const Poly *p2, Poly *p3) const { ew(LR_MUL_MONT, full(), p1, p2, p3); }
+    void MulCoeffsMontgomeryLvl(uint64_t l, const Poly *p1, const Poly *p2, Poly *p3) const { ew(LR_MUL_MONT, (int)l, p1, p2, p3); }
+    void MulCoeffsMontgomeryAndAdd(const Poly *p1, const Poly *p2, Poly *p3) const { ew(LR_MUL_MONT_AND_ADD, full(), p1, p2, p3); }
+    void MulCoeffsMontgomeryAndAddNoModLvl(uint64_t l, const Poly *p1, const Poly *p2, Poly *p3) const {
+        ew(LR_MUL_MONT_AND_ADD_NOMOD, (int)l, p1, p2, p3);
+    }
+    void MForm(const Poly *p1, Poly *p2) const { ew(LR_MFORM, full(), p1, nullptr, p2); }
+    void MFormLvl(uint64_t l, const Poly *p1, Poly *p2) const { ew(LR_MFORM, (int)l, p1, nullptr, p2); }
+    void InvMForm(const Poly *p1, Poly *p2) const { ew(LR_INV_MFORM, full(), p1, nullptr, p2); }
+    void MulScalar(const Poly *p1, uint64_t scalar, Poly *p2) const { ew(LR_MUL_SCALAR, full(), p1, nullptr, p2, &scalar); }
+    void Copy(const Poly *p0, Poly *p1) const { ew(LR_COPY, full(), p0, nullptr, p1); }
+
+    // ring/ring_scaling.go
+    void DivFloorByLastModulusNTT(Poly *p0) const { check(lr_div_floor_by_last_modulus_ntt(h_, p0->handle())); }
+    void DivFloorByLastModulus(Poly *p0) const { check(lr_div_floor_by_last_modulus(h_, p0->handle())); }
+    void DivRoundByLastModulusNTT(Poly *p0) const { check(lr_div_round_by_last_modulus_ntt(h_, p0->handle())); }
+    void DivRoundByLastModulus(Poly *p0) const { check(lr_div_round_by_last_modulus(h_, p0->handle())); }
+
+    void Sync() const { check(lr_context_sync(h_)); }
+
+  private:
+    int full() const { return (int)Modulus.size() - 1; }
+    void ew(int op, int level, const Poly *a, const Poly *b, Poly *out, const uint64_t *sc = nullptr) const {
+        check(lr_ewise(h_, op, level, a->handle(), b ? b->handle() : nullptr, out->handle(), sc));
+    }
+    lr_context *h_ = nullptr;
+};
+
+// ring.FastBasisExtender (ring/ring_basis_extension.go:9-74)
+class FastBasisExtender {
+  public:
+    FastBasisExtender(const Context *contextQ, const Context *contextP) { check(lr_bext_create(contextQ->handle(), contextP->handle(), &h_)); }
+    ~FastBasisExtender() { lr_bext_destroy(h_); }
+    void ModUpSplitQP(uint64_t level, const Poly *p1, Poly *p2) { check(lr_modup_split_qp(h_, (int)level, p1->handle(), p2->handle())); }
+    void ModUpSplitPQ(uint64_t level, const Poly *p1, Poly *p2) { check(lr_modup_split_pq(h_, (int)level, p1->handle(), p2->handle())); }
+    void ModDownNTTPQ(uint64_t level, Poly *p1, Poly *p2) { check(lr_moddown_ntt_pq(h_, (int)level, p1->handle(), p2->handle())); }
+    void ModDownSplitedNTTPQ(uint64_t level, const Poly *p1Q, Poly *p1P, Poly *p2) {
+        check(lr_moddown_split_ntt_pq(h_, (int)level, p1Q->handle(), p1P->handle(), p2->handle()));
+    }
+    void ModDownPQ(uint64_t level, const Poly *p1, Poly *p2) { check(lr_moddown_pq(h_, (int)level, p1->handle(), p2->handle())); }
+    void ModDownSplitedPQ(uint64_t level, const Poly *p1Q, const Poly *p1P, Poly *p2) {
+        check(lr_moddown_split_pq(h_, (int)level, p1Q->handle(), p1P->handle(), p2->handle()));
+    }
+    void ModDownSplitedQP(uint64_t levelQ, uint64_t levelP, const Poly *p1Q, const Poly *p1P, Poly *p2) {
+        check(lr_moddown_split_qp(h_, (int)levelQ, (int)levelP, p1Q->handle(), p1P->handle(), p2->handle()));
+    }
+
+  private:
+    lr_bext *h_ = nullptr;
+};
+
+// ring.Decomposer (ring/ring_basis_extension.go:398-472)
+class Decomposer {
+  public:
+    Decomposer(const Context *contextQ, const Context *contextP) { check(lr_decomposer_create(contextQ->handle(), contextP->handle(), &h_)); }
+    ~Decomposer() { lr_decomposer_destroy(h_); }
+    void Decompose(uint64_t level, uint64_t crtDecompLevel, const Poly *p0, Poly *p1) {
+        check(lr_decompose(h_, (int)level, (int)crtDecompLevel, p0->handle(), p1->handle()));
+    }
+    void DecomposeAndSplit(uint64_t level, uint64_t crtDecompLevel, const Poly *p0, Poly *p1Q, Poly *p1P) {
+        check(lr_decompose_and_split(h_, (int)level, (int)crtDecompLevel, p0->handle(), p1Q->handle(), p1P->handle()));
+    }
+
+  private:
+    lr_decomposer *h_ = nullptr;
+};
+
+}  // namespace ring

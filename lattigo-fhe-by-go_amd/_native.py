@@ -46,6 +46,9 @@ SYMBOLS = {
     "lr_ntt_host": [vp, i32, C.POINTER(u64p), C.POINTER(u64p)],
     "lr_intt_host": [vp, i32, C.POINTER(u64p), C.POINTER(u64p)],
     "lr_ewise": [vp, i32, i32, vp, vp, vp, u64p],
+    "lr_permute_ntt": [vp, i32, vp, u64, vp],
+    "lr_permute_ntt_index": [u64, u64, u64, u64p],
+    "lr_permute": [vp, vp, u64, vp],
     "lr_bext_create": [vp, vp, C.POINTER(vp)],
     "lr_bext_destroy": [vp],
     "lr_modup_split_qp": [vp, i32, vp, vp],

@@ -677,6 +677,55 @@ extern "C" int lr_ewise(lr_context *c, int op, int level, const lr_poly *a, cons
 }
 
 // ------------------------------------------------------------------------------------------
+// Galois automorphisms (ring/ring_galois.go)
+// ------------------------------------------------------------------------------------------
+static int permute_common(lr_context *c, int level, const lr_poly *in, u64 gen, lr_poly *out, bool ntt_domain) {
+    LR_TRY(check_pair(c, level, in, out));
+    if (in->batch != out->batch) return fail(LR_ERR_SHAPE, "batch mismatch");
+    if (in->d == out->d) return fail(LR_ERR_ARG, "Permute is not in place (ring/ring_galois.go:54)");
+    if (c->h.N < 2 || c->h.logN > 31) return fail(LR_ERR_UNSUPPORTED, "ring degree");
+    LR_HIP(hipSetDevice(c->device));
+    GaloisLaunch L;
+    L.in = in->d;
+    L.out = out->d;
+    L.in_stride = in->stride();
+    L.out_stride = out->stride();
+    L.n = (int)c->h.N;
+    L.logn = (int)c->h.logN;
+    L.ntt_domain = ntt_domain ? 1 : 0;
+    // only gen mod 2N matters in either domain (indices are taken mod 2N resp. mod N with the sign from bit logN)
+    L.gen = gen & ((c->h.N << 1) - 1);
+    L.lp = c->d_lp;
+    LR_HIP(launch_permute(L, level + 1, out->batch, c->stream));
+    return LR_OK;
+}
+
+extern "C" int lr_permute_ntt(lr_context *c, int level, const lr_poly *in, uint64_t gen, lr_poly *out) {
+    if (!c || !in || !out) return fail(LR_ERR_ARG, "null argument");
+    return permute_common(c, level, in, gen, out, true);
+}
+
+extern "C" int lr_permute(lr_context *c, const lr_poly *in, uint64_t gen, lr_poly *out) {
+    if (!c || !in || !out) return fail(LR_ERR_ARG, "null argument");
+    return permute_common(c, c->h.L() - 1, in, gen, out, false);
+}
+
+extern "C" int lr_permute_ntt_index(uint64_t gen, uint64_t power, uint64_t N, uint64_t *index) {
+    if (!index) return fail(LR_ERR_ARG, "null argument");
+    if (N == 0 || (N & (N - 1)) != 0) return fail(LR_ERR_INVALID_DEGREE, "invalid ring degree (must be a power of 2)");
+    const u64 gen_pow = mod_exp(gen, power, 2 * N);
+    unsigned logn = 0;
+    while ((1ull << logn) < N) ++logn;
+    const u64 mask = (N << 1) - 1;
+    for (u64 i = 0; i < N; ++i) {
+        const u64 t1 = 2 * bit_reverse(i, logn) + 1;
+        const u64 t2 = ((gen_pow * t1 & mask) - 1) >> 1;
+        index[i] = bit_reverse(t2, logn);
+    }
+    return LR_OK;
+}
+
+// ------------------------------------------------------------------------------------------
 // basis extension
 // ------------------------------------------------------------------------------------------
 namespace {

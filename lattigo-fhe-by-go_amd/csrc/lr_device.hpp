@@ -83,6 +83,18 @@ struct RowAddLaunch {
     LimbScalars adds; // per output row
 };
 
+// ring/ring_galois.go
+struct GaloisLaunch {
+    const u64 *in;
+    u64 *out;
+    long long in_stride, out_stride;
+    int n, logn;
+    int ntt_domain;    // 1: PermuteNTT gather, 0: Context.Permute scatter with sign
+    u64 gen;           // reduced modulo 2N
+    const LimbParams *lp;
+};
+hipError_t launch_permute(const GaloisLaunch &L, int limbs, int batch, hipStream_t stream);
+
 // ---- basis extension (lr_bext.hip) ----
 struct ExtTables {        // device pointers; modupParams of ring_basis_extension.go:19-37
     int nQ, nP;

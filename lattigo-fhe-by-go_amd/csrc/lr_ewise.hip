@@ -183,4 +183,38 @@ hipError_t launch_rowadd(const RowAddLaunch &L, int rows, int batch, hipStream_t
     return hipGetLastError();
 }
 
+// ---- Galois automorphisms, ring/ring_galois.go ---------------------------------------------
+// NTT domain (:55-101): gather with the index computed on the fly (two bit reversals);
+// coefficient domain (:106-127): scatter with sign.
+__global__ __launch_bounds__(256) void permute_kernel(GaloisLaunch L) {
+    const int limb = blockIdx.y;
+    const long long b = blockIdx.z;
+    const u64 *pin = L.in + b * L.in_stride + (long long)limb * L.n;
+    u64 *pout = L.out + b * L.out_stride + (long long)limb * L.n;
+    const u32 n = (u32)L.n, mask2 = 2 * n - 1;
+    const int logn = L.logn;
+    for (u32 j = blockIdx.x * 256 + threadIdx.x; j < n; j += gridDim.x * 256) {
+        if (L.ntt_domain) {
+            const u32 t1 = 2 * (__brev(j) >> (32 - logn)) + 1;
+            const u32 t2 = ((((u32)L.gen * t1) & mask2) - 1) >> 1;
+            pout[j] = pin[__brev(t2) >> (32 - logn)];
+        } else {
+            const u64 raw = (u64)j * L.gen;
+            const u32 idx = (u32)raw & (n - 1);
+            const u64 x = pin[j], q = L.lp[limb].q;
+            pout[idx] = ((raw >> logn) & 1) ? q - x : x;
+        }
+    }
+}
+
+hipError_t launch_permute(const GaloisLaunch &L, int limbs, int batch, hipStream_t stream) {
+    if (limbs <= 0 || batch <= 0) return hipSuccess;
+    int gx = (L.n + 255) / 256;
+    if (gx > 64) gx = 64;
+    const dim3 grid((unsigned)gx, (unsigned)limbs, (unsigned)batch), block(256);
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(permute_kernel, grid, block, 0, stream, L);
+    return hipGetLastError();
+}
+
 }  // namespace lr

@@ -281,6 +281,13 @@ class Context:
         self.MulCoeffsMontgomery(a, b, p3)
         self.InvNTT(p3, p3)
 
+    # --- Galois automorphisms (ring/ring_galois.go) ------------------------------------------------
+    def Permute(self, polIn, gen, polOut):  # :106
+        check(lib().lr_permute(self.h, polIn.h, int(gen), polOut.h))
+
+    def PermuteNTTLvl(self, level, polIn, gen, polOut):  # package-level PermuteNTT (:55) on limbs 0..level
+        check(lib().lr_permute_ntt(self.h, level, polIn.h, int(gen), polOut.h))
+
     # --- RNS rescale (ring/ring_scaling.go:9-164) ----------------------------------------------
     def DivFloorByLastModulusNTT(self, p0): check(lib().lr_div_floor_by_last_modulus_ntt(self.h, p0.h))
     def DivFloorByLastModulus(self, p0): check(lib().lr_div_floor_by_last_modulus(self.h, p0.h))
@@ -299,6 +306,26 @@ class Context:
         ms = C.c_float()
         check(lib().lr_timer_stop(self.h, C.byref(ms)))
         return ms.value
+
+
+def GenGaloisParams(n, gen):
+    """ring.GenGaloisParams (ring/ring_galois.go:9): powers of gen modulo 2n"""
+    out, mask = [1], (n << 1) - 1
+    for _ in range(1, n >> 1):
+        out.append((out[-1] * gen) & mask)
+    return out
+
+
+def PermuteNTTIndex(gen, power, N):
+    """ring.PermuteNTTIndex (ring/ring_galois.go:29)"""
+    idx = np.empty(N, dtype=np.uint64)
+    check(lib().lr_permute_ntt_index(int(gen), int(power), int(N), idx.ctypes.data_as(nat.u64p)))
+    return idx
+
+
+def PermuteNTT(context, polIn, gen, polOut):
+    """ring.PermuteNTT (ring/ring_galois.go:55): all limbs of polIn"""
+    context.PermuteNTTLvl(polIn.limbs - 1, polIn, gen, polOut)
 
 
 def NewContextWithParams(N, Moduli, device=0):

@@ -1006,3 +1006,47 @@ void oc_bfv_mul(oc_bext *b, u64 t, const u64 *phalf_q, const u64 *phalf_qm, cons
     }
     free(c0Q1); free(c0Q2); free(c1Q1); free(c1Q2); free(c2Q1); free(c2Q2); free(c00Q); free(c00M); free(c01Q); free(c01M);
 }
+
+/* ========================= ring/ring_galois.go ============================ */
+static int log2_u64(u64 n) { int l = 0; while (((u64)1 << l) < n) l++; return l; }
+
+/* PermuteNTTIndex, ring_galois.go:29-50 */
+void oc_permute_ntt_index(u64 gen, u64 power, u64 N, u64 *index) {
+    u64 gen_pow = oc_mod_exp(gen, power, 2 * N);
+    u64 logN = (u64)log2_u64(N), mask = (N << 1) - 1;
+    for (u64 i = 0; i < N; i++) {
+        u64 tmp1 = 2 * oc_bit_reverse64(i, logN) + 1;
+        u64 tmp2 = ((gen_pow * tmp1 & mask) - 1) >> 1;
+        index[i] = oc_bit_reverse64(tmp2, logN);
+    }
+}
+
+/* PermuteNTT, ring_galois.go:55-84 (not in place) */
+void oc_permute_ntt(const u64 *in, u64 gen, u64 *out, int limbs, u64 N) {
+    u64 logN = (u64)log2_u64(N), mask = (N << 1) - 1;
+    for (u64 j = 0; j < N; j++) {
+        u64 tmp1 = 2 * oc_bit_reverse64(j, logN) + 1;
+        u64 tmp2 = ((gen * tmp1 & mask) - 1) >> 1;
+        u64 idx = oc_bit_reverse64(tmp2, logN);
+        for (int i = 0; i < limbs; i++) out[(size_t)i * N + j] = in[(size_t)i * N + idx];
+    }
+}
+
+/* PermuteNTTWithIndex, ring_galois.go:89-101 */
+void oc_permute_ntt_with_index(const u64 *in, const u64 *index, u64 *out, int limbs, u64 N) {
+    for (u64 j = 0; j < N; j++)
+        for (int i = 0; i < limbs; i++) out[(size_t)i * N + j] = in[(size_t)i * N + index[j]];
+}
+
+/* Context.Permute, ring_galois.go:106-127 (coefficient domain; 0 maps to q when the sign flips, as in Go) */
+void oc_permute(const oc_context *c, const u64 *in, u64 gen, u64 *out) {
+    const u64 N = c->N, mask = N - 1;
+    u64 logN = (u64)log2_u64(N);
+    for (u64 i = 0; i < N; i++) {
+        u64 raw = i * gen, index = raw & mask, tmp = (raw >> logN) & 1;
+        for (int j = 0; j < c->L; j++) {
+            u64 qi = c->q[j], x = in[(size_t)j * N + i];
+            out[(size_t)j * N + index] = x * (tmp ^ 1) | (qi - x) * tmp;
+        }
+    }
+}

@@ -183,6 +183,12 @@ void oc_ckks_switch_keys(oc_ckks_plan *p, int level, const uint64_t *cx, const u
 void oc_ckks_mulrelin(oc_ckks_plan *p, int level, const uint64_t *ct0, const uint64_t *ct1,
                       const uint64_t *evk, uint64_t *out);
 
+/* ---- Galois automorphisms: ring/ring_galois.go -------------------------------- */
+void oc_permute_ntt_index(uint64_t gen, uint64_t power, uint64_t N, uint64_t *index);              /* :29  */
+void oc_permute_ntt(const uint64_t *in, uint64_t gen, uint64_t *out, int limbs, uint64_t N);       /* :55  */
+void oc_permute_ntt_with_index(const uint64_t *in, const uint64_t *index, uint64_t *out, int limbs, uint64_t N); /* :89 */
+void oc_permute(const oc_context *c, const uint64_t *in, uint64_t gen, uint64_t *out);             /* :106 */
+
 /* ---- caller sequence: bfv/evaluator.go:278-464 tensorAndRescale ---- */
 /* degree-1 x degree-1, regular case.  ct0, ct1 = [2][|Q|][N] coefficient domain; out = [3][|Q|][N].
  * bext = NewFastBasisExtender(contextQ, contextQMul) (bfv/evaluator.go:97); phalf_q / phalf_qm = residues of

@@ -118,6 +118,10 @@ def lib():
     sig("oc_ckks_switch_keys", None, vp, i, vp, vp, vp, vp)
     sig("oc_ckks_mulrelin", None, vp, i, vp, vp, vp, vp)
     sig("oc_bfv_mul", None, vp, u64, vp, vp, vp, vp, vp)
+    sig("oc_permute_ntt_index", None, u64, u64, u64, vp)
+    sig("oc_permute_ntt", None, vp, u64, vp, i, u64)
+    sig("oc_permute_ntt_with_index", None, vp, vp, vp, i, u64)
+    sig("oc_permute", None, vp, vp, u64, vp)
     _lib = L
     return L
 
@@ -244,6 +248,29 @@ class Context:
         out = np.zeros_like(a) if out is None else _arr(out).copy()
         sc = None if scalars is None else np.ascontiguousarray(scalars, dtype=np.uint64)
         lib().oc_ewise(self.h, OP[op] if isinstance(op, str) else op, level, _ptr(a), _ptr(b), _ptr(out), _ptr(sc))
+        return out
+
+    def permute_ntt(self, p, gen):           # ring.PermuteNTT (ring/ring_galois.go:55)
+        p = _arr(p)
+        out = np.zeros_like(p)
+        lib().oc_permute_ntt(_ptr(p), int(gen), _ptr(out), p.shape[0], self.N)
+        return out
+
+    def permute_ntt_index(self, gen, power):  # ring.PermuteNTTIndex (:29)
+        idx = np.zeros(self.N, dtype=np.uint64)
+        lib().oc_permute_ntt_index(int(gen), int(power), self.N, _ptr(idx))
+        return idx
+
+    def permute_ntt_with_index(self, p, index):   # ring.PermuteNTTWithIndex (:89)
+        p, index = _arr(p), _arr(index)
+        out = np.zeros_like(p)
+        lib().oc_permute_ntt_with_index(_ptr(p), _ptr(index), _ptr(out), p.shape[0], self.N)
+        return out
+
+    def permute(self, p, gen):               # Context.Permute (:106)
+        p = _arr(p)
+        out = np.zeros_like(p)
+        lib().oc_permute(self.h, _ptr(p), int(gen), _ptr(out))
         return out
 
     def rescale_op(self, name, p, nb=None, ntt=False):

@@ -206,3 +206,20 @@ def test_cxx_and_asm_paths_agree(gpu_pkg, oracle, logn, limbs, monkeypatch):
             assert np.array_equal(got[b], want[b]), (no_asm, b)
         ctx.NTT(p, p)      # in place
         assert np.array_equal(p.get(), got)
+
+
+def test_cpp_host_mirror_runs_reference_ntt_test():
+    """tests/cpp/test_ntt_golden.cpp is the C++ twin of ring/ntt_test.go:Test_NTT on include/lattigo_ring.hpp
+    (the C++ host mirror over the C ABI).  Built here with g++ against the in-tree library and executed."""
+    import os
+    import subprocess
+
+    from conftest import GOLDEN_DIR, ROOT
+    exe = os.path.join(ROOT, "tests", "cpp", "test_ntt_golden")
+    src = os.path.join(ROOT, "tests", "cpp", "test_ntt_golden.cpp")
+    libdir = os.path.join(ROOT, "lattigo-fhe-by-go_amd")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I" + os.path.join(ROOT, "include"), src, "-L" + libdir,
+                           "-llattigo_ring_hip", "-Wl,-rpath," + libdir, "-o", exe])
+    out = subprocess.run([exe, GOLDEN_DIR], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "PASS" in out.stdout

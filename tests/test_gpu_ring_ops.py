@@ -225,3 +225,38 @@ def test_rescale_many(gpu_pkg, oracle, ntt, rounding):
     got = p.get()
     for b in range(2):
         assert np.array_equal(got[b], oc.rescale_op("oc_div_%s_by_last_modulus_many" % rounding.lower(), x[b], nb=3, ntt=ntt))
+
+
+@pytest.mark.parametrize("logn", [4, 10, 13])
+def test_galois(gpu_pkg, oracle, logn):
+    """ring/ring_galois.go: PermuteNTT / PermuteNTTIndex / Context.Permute, and the identity the reference's
+    testGaloisShift relies on: NTT(Permute(x)) == PermuteNTT(NTT(x))."""
+    N = 1 << logn
+    moduli = list(gpu_pkg.params.Qi60()[-3:])
+    ring = gpu_pkg.ring
+    ctx = ring.NewContextWithParams(N, moduli)
+    oc = oracle.Context(N, moduli)
+    x = gpu_pkg.sampling.uniform_poly(moduli, N, 2, seed=logn)
+    x[0, 0, 3] = 0                                # a zero whose sign flips becomes q in Context.Permute
+    px, po = ctx.NewPoly(2).set(x), ctx.NewPoly(2)
+    for gen in (5, pow(5, 3, 2 * N), 2 * N - 1):
+        ring.PermuteNTT(ctx, px, gen, po)
+        for b in range(2):
+            assert np.array_equal(po.get()[b], oc.permute_ntt(x[b], gen))
+        ctx.Permute(px, gen, po)
+        for b in range(2):
+            assert np.array_equal(po.get()[b], oc.permute(x[b], gen))
+    assert np.array_equal(ring.PermuteNTTIndex(5, 7, N), oc.permute_ntt_index(5, 7))
+    assert np.array_equal(oc.permute_ntt_with_index(x[0], oc.permute_ntt_index(5, 7)), oc.permute_ntt(x[0], pow(5, 7, 2 * N)))
+    assert ring.GenGaloisParams(N, 5)[:3] == [1, 5, 25 % (2 * N)]
+    # NTT(Permute(x)) == PermuteNTT(NTT(x)) modulo q
+    gen = 5
+    a, bb = ctx.NewPoly(2), ctx.NewPoly(2)
+    ctx.Permute(px, gen, a)
+    ctx.Reduce(a, a)
+    ctx.NTT(a, a)
+    ctx.NTT(px, po)
+    ring.PermuteNTT(ctx, po, gen, bb)
+    assert np.array_equal(a.get(), bb.get())
+    with pytest.raises(ring.LatticeRingError):
+        ring.PermuteNTT(ctx, px, gen, px)          # "Careful, not inplace!"
