@@ -1201,64 +1201,61 @@ int switch_keys_core(lr_ckks_plan *pl, int level, int batch, const u64 *cx, long
     const int beta = (level + 1 + alpha - 1) / alpha;  // :1508
     if (evk->batch < 2 * beta || evk->limbs < nQ + nP) return fail(LR_ERR_SHAPE, "evaluation key: need batch >= 2*beta and |Q|+|P| limbs");
     const long long sQ = (long long)nQ * n, sP = (long long)nP * n;
-    LR_TRY(pl->c2QiQ.ensure(cQ, (size_t)batch * sQ));
+    // every digit's decomposition is kept ([digit][batch][limb][N]) so that the inner product with the key runs
+    // as ONE pass over all digits (keymac_kernel) instead of beta read-modify-write rounds over the accumulators
+    const long long dQ = (long long)batch * sQ, dP = (long long)batch * sP;
+    LR_TRY(pl->c2QiQ.ensure(cQ, (size_t)beta * dQ));
     LR_TRY(pl->c2.ensure(cQ, (size_t)batch * sQ));
-    LR_TRY(pl->c2QiP.ensure(cQ, (size_t)batch * sP));
+    LR_TRY(pl->c2QiP.ensure(cQ, (size_t)beta * dP));
     LR_TRY(pl->pool2P.ensure(cQ, (size_t)batch * sP));
     LR_TRY(pl->pool3P.ensure(cQ, (size_t)batch * sP));
-    hipStream_t st = cQ->stream;
-    // poolQ[i].Zero(), poolP[i].Zero(), :1481-1487
-    const size_t live = (size_t)(level + 1) * n;
-    for (int k = 0; k < 2; ++k) {
-        u64 *pz = k == 0 ? p0 : p1;
-        const long long zs = k == 0 ? p0_stride : p1_stride;
-        if ((size_t)zs == live) {
-            LR_HIP(hipMemsetAsync(pz, 0, (size_t)batch * live * sizeof(u64), st));
-        } else {
-            for (int b = 0; b < batch; ++b) LR_HIP(hipMemsetAsync(pz + b * zs, 0, live * sizeof(u64), st));
-        }
-    }
-    LR_HIP(hipMemsetAsync(pl->pool2P.d, 0, (size_t)batch * sP * sizeof(u64), st));
-    LR_HIP(hipMemsetAsync(pl->pool3P.d, 0, (size_t)batch * sP * sizeof(u64), st));
 
     Rows cxr{const_cast<u64 *>(cx), cx_stride, 0, 1};
     Rows c2r{pl->c2.d, sQ, 0, 1};
     LR_TRY(run_ntt(cQ, true, cxr, c2r, 0, 1, level + 1, batch));  // :1503
-    int reduce = 0;
     for (int i = 0; i < beta; ++i) {
+        u64 *dq = pl->c2QiQ.d + (long long)i * dQ, *dp = pl->c2QiP.d + (long long)i * dP;
         // decomposeAndSplitNTT, :1561-1591
-        LR_TRY(decompose_core(dec, level, i, c2r, batch, pl->c2QiQ.d, sQ, pl->c2QiP.d, sP, true));
+        LR_TRY(decompose_core(dec, level, i, c2r, batch, dq, sQ, dp, sP, true));
         const int d0 = i * alpha;
         int d1 = d0 + dec->xalpha[i];
         if (d1 > level + 1) d1 = level + 1;
         // own-digit limbs are taken from the NTT-domain input (:1579-1584)
-        LR_TRY(run_ewise(cQ, LR_COPY, d1 - d0, batch, cx + (long long)d0 * n, cx_stride, nullptr, 0,
-                         pl->c2QiQ.d + (long long)d0 * n, sQ, nullptr, d0));
-        Rows lo{pl->c2QiQ.d, sQ, 0, 1};
+        LR_TRY(run_ewise(cQ, LR_COPY, d1 - d0, batch, cx + (long long)d0 * n, cx_stride, nullptr, 0, dq + (long long)d0 * n, sQ,
+                         nullptr, d0));
+        Rows lo{dq, sQ, 0, 1};
         LR_TRY(run_ntt(cQ, false, lo, lo, 0, 1, d0, batch));                     // limbs below the digit
-        Rows hi{pl->c2QiQ.d, sQ, d1, 1};
+        Rows hi{dq, sQ, d1, 1};
         LR_TRY(run_ntt(cQ, false, hi, hi, d1, 1, level + 1 - d1, batch));        // limbs above the digit
-        Rows pr{pl->c2QiP.d, sP, 0, 1};
+        Rows pr{dp, sP, 0, 1};
         LR_TRY(run_ntt(cP, false, pr, pr, 0, 1, nP, batch));                     // :1590
-        const u64 *k0 = evk->d + (long long)(2 * i) * evk->stride();
-        const u64 *k1 = evk->d + (long long)(2 * i + 1) * evk->stride();
-        LR_TRY(run_ewise(cQ, LR_MUL_MONT_AND_ADD_NOMOD, level + 1, batch, k0, 0, pl->c2QiQ.d, sQ, p0, p0_stride, nullptr));  // :1515
-        LR_TRY(run_ewise(cQ, LR_MUL_MONT_AND_ADD_NOMOD, level + 1, batch, k1, 0, pl->c2QiQ.d, sQ, p1, p1_stride, nullptr));  // :1516
-        LR_TRY(run_ewise(cP, LR_MUL_MONT_AND_ADD_NOMOD, nP, batch, k0 + (long long)nQ * n, 0, pl->c2QiP.d, sP, pl->pool2P.d, sP, nullptr));  // :1519-1534
-        LR_TRY(run_ewise(cP, LR_MUL_MONT_AND_ADD_NOMOD, nP, batch, k1 + (long long)nQ * n, 0, pl->c2QiP.d, sP, pl->pool3P.d, sP, nullptr));
-        if ((reduce & 7) == 1) {  // :1536-1541
-            LR_TRY(run_ewise(cQ, LR_REDUCE, level + 1, batch, p0, p0_stride, nullptr, 0, p0, p0_stride, nullptr));
-            LR_TRY(run_ewise(cQ, LR_REDUCE, level + 1, batch, p1, p1_stride, nullptr, 0, p1, p1_stride, nullptr));
-            LR_TRY(run_ewise(cP, LR_REDUCE, nP, batch, pl->pool2P.d, sP, nullptr, 0, pl->pool2P.d, sP, nullptr));
-            LR_TRY(run_ewise(cP, LR_REDUCE, nP, batch, pl->pool3P.d, sP, nullptr, 0, pl->pool3P.d, sP, nullptr));
-        }
-        ++reduce;
     }
-    if (((reduce - 1) & 7) != 1) {  // :1547-1552
-        LR_TRY(run_ewise(cQ, LR_REDUCE, level + 1, batch, p0, p0_stride, nullptr, 0, p0, p0_stride, nullptr));
-        LR_TRY(run_ewise(cQ, LR_REDUCE, level + 1, batch, p1, p1_stride, nullptr, 0, p1, p1_stride, nullptr));
-        LR_TRY(run_ewise(cP, LR_REDUCE, nP, batch, pl->pool2P.d, sP, nullptr, 0, pl->pool2P.d, sP, nullptr));
-        LR_TRY(run_ewise(cP, LR_REDUCE, nP, batch, pl->pool3P.d, sP, nullptr, 0, pl->pool3P.d, sP, nullptr));
+    // :1511-1552  sum over the digits of evakey[i][0/1] (*) c2_i, canonical, Q part then P part
+    {
+        KeyMacLaunch K;
+        K.key = evk->d;
+        K.key_poly_stride = evk->stride();
+        K.n = n;
+        K.beta = beta;
+        K.c2 = pl->c2QiQ.d;
+        K.c2_digit_stride = dQ;
+        K.c2_poly_stride = sQ;
+        K.key_limb0 = 0;
+        K.out0 = p0;
+        K.out1 = p1;
+        if (p0_stride != p1_stride) return fail(LR_ERR_SHAPE, "key switch outputs must share their stride");
+        K.out_stride = p0_stride;
+        K.lp = cQ->d_lp;
+        LR_HIP(launch_keymac(K, level + 1, batch, cQ->stream));
+        K.c2 = pl->c2QiP.d;
+        K.c2_digit_stride = dP;
+        K.c2_poly_stride = sP;
+        K.key_limb0 = nQ;
+        K.out0 = pl->pool2P.d;
+        K.out1 = pl->pool3P.d;
+        K.out_stride = sP;
+        K.lp = cP->d_lp;
+        LR_HIP(launch_keymac(K, nP, batch, cQ->stream));
     }
     // ModDownSplitedNTTPQ x2, :1556-1557
     lr_bext *bx = pl->bext;

@@ -83,6 +83,21 @@ struct RowAddLaunch {
     LimbScalars adds; // per output row
 };
 
+// key-switch inner product over all digits (lr_ewise.hip)
+struct KeyMacLaunch {
+    const u64 *c2;                 // [beta][batch][limbs][N], NTT domain
+    long long c2_digit_stride;     // u64 elements between digits
+    long long c2_poly_stride;      // between batch polys
+    const u64 *key;                // SwitchingKey image [2*beta][key limbs][N] (NTT + Montgomery form)
+    long long key_poly_stride;     // between key polys
+    int key_limb0;                 // first key limb of this segment (0 for Q, |Q| for P)
+    u64 *out0, *out1;
+    long long out_stride;
+    int n, beta;
+    const LimbParams *lp;
+};
+hipError_t launch_keymac(const KeyMacLaunch &L, int limbs, int batch, hipStream_t stream);
+
 // ring/ring_galois.go
 struct GaloisLaunch {
     const u64 *in;

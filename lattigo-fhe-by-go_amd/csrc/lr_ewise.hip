@@ -183,6 +183,54 @@ hipError_t launch_rowadd(const RowAddLaunch &L, int rows, int batch, hipStream_t
     return hipGetLastError();
 }
 
+// ---- hybrid key-switch inner product (ckks/evaluator.go:1511-1552) ---------------------------------
+// out0 = sum_i key[i][0] (*) c2[i],  out1 = sum_i key[i][1] (*) c2[i]  over the beta digits, Montgomery products,
+// canonical result.  The reference accumulates digit by digit with MulCoeffsMontgomeryAndAddNoMod and lazy
+// Reduce calls (reduce&7 cadence); the sums are below 8q < 2^64 between reductions either way and the final
+// Reduce makes the result canonical, so one pass over all digits yields the same values while the accumulators
+// never travel through HBM.
+__global__ __launch_bounds__(256) void keymac_kernel(KeyMacLaunch L) {
+    const int limb = blockIdx.y;
+    const long long b = blockIdx.z;
+    const LimbParams lp = L.lp[limb];
+    const long long row = (long long)limb * L.n;
+    const ulonglong2 *pc = reinterpret_cast<const ulonglong2 *>(L.c2 + b * L.c2_poly_stride + row);
+    const ulonglong2 *pk = reinterpret_cast<const ulonglong2 *>(L.key + (long long)(L.key_limb0 + limb) * L.n);
+    ulonglong2 *po0 = reinterpret_cast<ulonglong2 *>(L.out0 + b * L.out_stride + row);
+    ulonglong2 *po1 = reinterpret_cast<ulonglong2 *>(L.out1 + b * L.out_stride + row);
+    const long long cd = L.c2_digit_stride >> 1, kd = L.key_poly_stride >> 1;   // in 16-byte units
+    const int pairs = L.n >> 1;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < pairs; e += gridDim.x * 256) {
+        u64 a0x = 0, a0y = 0, a1x = 0, a1y = 0;
+        for (int i = 0; i < L.beta; ++i) {
+            const ulonglong2 c = pc[e + i * cd];
+            const ulonglong2 k0 = pk[e + (2 * i) * kd], k1 = pk[e + (2 * i + 1) * kd];
+            a0x += mred(k0.x, c.x, lp.q, lp.qinv);
+            a0y += mred(k0.y, c.y, lp.q, lp.qinv);
+            a1x += mred(k1.x, c.x, lp.q, lp.qinv);
+            a1y += mred(k1.y, c.y, lp.q, lp.qinv);
+            if ((i & 7) == 7) {
+                a0x = bred_add(a0x, lp.q, lp.bred_hi);
+                a0y = bred_add(a0y, lp.q, lp.bred_hi);
+                a1x = bred_add(a1x, lp.q, lp.bred_hi);
+                a1y = bred_add(a1y, lp.q, lp.bred_hi);
+            }
+        }
+        po0[e] = make_ulonglong2(bred_add(a0x, lp.q, lp.bred_hi), bred_add(a0y, lp.q, lp.bred_hi));
+        po1[e] = make_ulonglong2(bred_add(a1x, lp.q, lp.bred_hi), bred_add(a1y, lp.q, lp.bred_hi));
+    }
+}
+
+hipError_t launch_keymac(const KeyMacLaunch &L, int limbs, int batch, hipStream_t stream) {
+    if (limbs <= 0 || batch <= 0) return hipSuccess;
+    int gx = ((L.n >> 1) + 255) / 256;
+    if (gx > 64) gx = 64;
+    const dim3 grid((unsigned)gx, (unsigned)limbs, (unsigned)batch), block(256);
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(keymac_kernel, grid, block, 0, stream, L);
+    return hipGetLastError();
+}
+
 // ---- Galois automorphisms, ring/ring_galois.go ---------------------------------------------
 // NTT domain (:55-101): gather with the index computed on the fly (two bit reversals);
 // coefficient domain (:106-127): scatter with sign.
