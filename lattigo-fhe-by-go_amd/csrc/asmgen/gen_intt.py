@@ -1,0 +1,397 @@
+"""Generator of the hand-scheduled inverse NTT kernels for gfx950 (N = 2^14, 2^15; 1024 threads).
+
+Mirror of gen_ntt.py (same LDS image, same twiddle tables, same wave-local LDS phase), Gentleman-Sande
+order: copy-in -> stages over bits 0..3 (lane-transposed table) -> bits 4..6 (per-lane twiddles) ->
+bits 7..9 (wave-uniform twiddles) -> column exchange -> the top stages in registers with SGPR twiddles.
+The last stage is fused with the N^-1 scaling of ring/ntt.go:136-138: its outputs are
+(U+V)*N^-1 and (U-V)*(psi_inv[1]*N^-1), the second constant lives at index 0 of the inverse table.
+
+Lazy ranges (2^57 <= q <= 2^60): a stage over bit b leaves sums ("X type", index bit b clear) below 8q
+and products ("Y type") below 4q.  Both operands of a butterfly have the same type, so only the
+butterflies that add two X-type values need the conditional subtraction of 8q: half of them, known at
+generation time inside a pass and applied unconditionally on the first stage of a pass.
+15 VALU instructions per butterfly without correction, 19 with.  Inputs must be below 4q.
+
+    python gen_intt.py 15 out.s
+    python gen_intt.py 15 --selftest
+"""
+import sys
+
+from gen_ntt import T, Gen, kernel_text_for
+from isa import s, v
+
+
+class GenInv(Gen):
+    def __init__(self, logn):
+        super().__init__(logn)
+        self.Q8 = self.Q4                       # s[18:19] holds 8q here
+        self.NQ2 = s(22, 2)                     # -2q (REDM/REDG are not used by the inverse)
+        self.LP = s(0, 2)                       # LimbParams pointer (kernarg pointer is dead after the prologue)
+        # pass A keeps X[k]; the LDS phase works in v0..v31, so the first half is parked in v32..v63
+        if self.HALVES == 2:
+            self.X = [v(32 + 2 * k, 2) for k in range(16)] + [v(2 * k, 2) for k in range(16)]
+
+    # ------------------------------------------------------------------ arithmetic
+    def ops_modmul_inplace(self, ts, V, tw):
+        """V <- V * w - qhat * q (lazy, [0,4q)) for any 64-bit V"""
+        w0, w1, s0, s1 = tw
+        J = self.JUNK
+        return [
+            ("v_mul_hi_u32", ts.T0, V.hi(), s0),
+            ("v_mul_hi_u32", ts.T2, V.lo(), s1),
+            ("v_mad_u64_u32", ts.Q, J, V.hi(), s1, ts.T01),
+            ("v_mad_u64_u32", ts.C, J, V.lo(), w1, 0),
+            ("v_lshl_add_u64", ts.Q, ts.Q, 0, ts.T23),
+            ("v_mad_u64_u32", ts.C, J, V.hi(), w0, ts.C),
+            ("v_mad_u64_u32", V, J, V.lo(), w0, 0),
+            ("v_mad_u64_u32", V, J, ts.Q.lo(), self.NQ.lo(), V),
+            ("v_mad_u64_u32", ts.C, J, ts.Q.lo(), self.NQ.hi(), ts.C),
+            ("v_mad_u64_u32", ts.C, J, ts.Q.hi(), self.NQ.lo(), ts.C),
+            ("v_add_u32", V.hi(), V.hi(), ts.C.lo()),
+        ]
+
+    def ops_sum_diff(self, ts, U, V):
+        """(U, V) <- (U + V, U + 8q - V)"""
+        return [("v_lshl_add_u64", ts.R, U, 0, self.Q8),
+                ("v_lshl_add_u64", U, U, 0, V),
+                ("v_sub_co_u32", V.lo(), ts.CY, ts.R.lo(), V.lo()),
+                ("v_subb_co_u32", V.hi(), ts.CY, ts.R.hi(), V.hi(), ts.CY)]
+
+    def ops_butterfly(self, ts, U, V, tw, correct):
+        """(U, V) <- (U + V [- 8q], (U + 8q - V) * w)"""
+        ops = self.ops_sum_diff(ts, U, V)
+        mm = self.ops_modmul_inplace(ts, V, tw)
+        if correct:
+            D = ts.R
+            ops += [("v_lshl_add_u64", D, U, 0, self.NQ8),
+                    ("v_cmp_lt_u32", ts.CY, D.hi(), U.hi())]
+            ops += mm[:2]
+            ops += [("v_cndmask_b32", U.lo(), U.lo(), D.lo(), ts.CY),
+                    ("v_cndmask_b32", U.hi(), U.hi(), D.hi(), ts.CY)]
+            ops += mm[2:]
+        else:
+            ops += mm
+        return ops
+
+    def ops_canon4(self, ts, X):
+        """[0,4q) -> [0,q)"""
+        D = ts.R
+        return [("v_lshl_add_u64", D, X, 0, self.NQ2),
+                ("v_cmp_lt_u32", ts.CY, D.hi(), X.hi()),
+                ("v_cndmask_b32", X.lo(), X.lo(), D.lo(), ts.CY),
+                ("v_cndmask_b32", X.hi(), X.hi(), D.hi(), ts.CY),
+                ("v_lshl_add_u64", D, X, 0, self.NQ),
+                ("v_cmp_gt_i32", ts.CY, 0, D.hi()),
+                ("v_cndmask_b32", X.lo(), D.lo(), X.lo(), ts.CY),
+                ("v_cndmask_b32", X.hi(), D.hi(), X.hi(), ts.CY)]
+
+    def ops_last(self, ts, U, V, tw_n, tw_wn):
+        """last stage fused with the scaling: canonical (U+V)*N^-1 and (U-V)*psi_inv[1]*N^-1"""
+        ops = self.ops_sum_diff(ts, U, V)
+        ops += self.ops_modmul_inplace(ts, U, tw_n)
+        ops += self.ops_modmul_inplace(ts, V, tw_wn)
+        # U and V share the temp D and the carry register: sequential, the hazard tracker pads where the
+        # other butterfly in flight does not
+        return ops + self.ops_canon4(ts, U) + self.ops_canon4(ts, V)
+
+    def gs_group(self, Y, R, twf, first_pass, hook=None, last=None):
+        """R Gentleman-Sande stages over the local bits 0..R-1 of 2^R coefficients.
+        twf(c, j): twiddle of heap position (H << c) + j, c = R-1-b."""
+        n = 0
+        for b in range(R):
+            c = R - 1 - b
+            if last is not None and b == R - 1:
+                last()
+                return
+            blist = []
+            for j in range(1 << c):
+                tw = twf(c, j)
+                for i in range(1 << b):
+                    k0 = (j << (b + 1)) | i
+                    if b == 0:
+                        corr = not first_pass
+                    else:
+                        corr = ((k0 >> (b - 1)) & 1) == 0
+                    blist.append((Y[k0], Y[k0 | (1 << b)], tw, corr))
+            self.butterflies(blist)
+            for _ in range(1 << c):
+                n += 1
+                if hook:
+                    hook(n)
+
+    # ------------------------------------------------------------------ sections
+    def prologue_tail(self):
+        e = self.e
+        e("s_waitcnt", "lgkmcnt(0)")
+        e("s_mov_b64", self.Qm, s(68, 2))
+        e("s_sub_u32", self.NQ.lo(), 0, self.Qm.lo())
+        e("s_subb_u32", self.NQ.hi(), 0, self.Qm.hi())
+        e("s_lshl_b64", self.Q8, self.Qm, 3)
+        e("s_sub_u32", self.NQ8.lo(), 0, self.Q8.lo())
+        e("s_subb_u32", self.NQ8.hi(), 0, self.Q8.hi())
+        e("s_lshl_b64", self.NQ2, self.NQ, 1)
+        # LimbParams pointer for the reload before the last stage
+        e("s_lshl_b32", self.SC[3], self.SC[0], 6)
+        e("s_add_u32", self.LP.lo(), s(52), self.SC[3])
+        e("s_addc_u32", self.LP.hi(), s(53), 0)
+
+    def copy_in(self, half):
+        """wave w loads its 1024 contiguous coefficients (8 KiB) with 16-byte loads and lays them into its LDS block"""
+        e = self.e
+        a0, a1, a2 = self.A_[0], self.A_[1], self.A_[2]
+        self.c("half %d: copy-in (wave-local)" % half)
+        self.wave_lds_base()
+        e("v_lshrrev_b32", a1, 3, self.LANE)
+        e("v_lshlrev_b32", a1, 4, a1)
+        e("v_lshl_add_u32", a0, self.LANE, 4, a1)             # slot(2l) * 8
+        e("v_add_u32", a0, self.SC[6], a0)
+        e("v_lshlrev_b32", a2, 4, self.LANE)                  # l * 16
+        e("s_lshl_b32", self.SC[5], self.WAVE, 13)
+        e("s_add_u32", self.TMP.lo(), self.SRC.lo(), self.SC[5])
+        e("s_addc_u32", self.TMP.hi(), self.SRC.hi(), 0)
+        n = 8
+        regs = [v(4 * i, 4) for i in range(n)]
+        for i in range(n):
+            if i == 4:                                        # the immediate offset is 13-bit signed
+                e("s_add_u32", self.TMP.lo(), self.TMP.lo(), 4096)
+                e("s_addc_u32", self.TMP.hi(), self.TMP.hi(), 0)
+            e("global_load_dwordx4", regs[i], a2, self.TMP, offset=(i % 4) * 1024)
+        if half + 1 < self.HALVES:
+            e("s_add_u32", self.SRC.lo(), self.SRC.lo(), self.M * 8)
+            e("s_addc_u32", self.SRC.hi(), self.SRC.hi(), 0)
+        # twiddles of the wave-local stages travel behind the data: bits 0..3 first, then the two bits-4..6 tasks
+        fin = dict(self.final_requests(half))
+        order = [("f", c, j) for c in (3, 2, 1, 0) for j in range(1 << c)]
+        reqs = [(k, fin[k]) for k in order]
+        for g, tag in ((0, "a"), (1, "b")):
+            lane = dict(self.lane_twiddle_requests(half, g, tag))
+            reqs += [((tag, c, j), lane[(tag, c, j)]) for c in (2, 1, 0) for j in range(1 << c)]
+        # final_requests clobbers A_[2] (as l*16 -> t*16); the data loads above have been issued already
+        self.stream_begin(reqs)
+        younger = self.st_issued
+        for i in range(n):
+            e("s_waitcnt", "vmcnt(%d)" % (younger + n - 1 - i))
+            e("ds_write_b128", a0, regs[i], offset=i * 1152)
+
+    def pass_low(self, half):
+        """bits 0..3: lane l owns the 16 contiguous coefficients of block l of its wave"""
+        e = self.e
+        a0 = self.A_[0]
+        self.c("stages over bits 0..3 (wave-local)")
+        e("s_movk_i32", self.SC[4], 144)
+        e("v_mul_lo_u32", a0, self.LANE, self.SC[4])
+        e("v_add_u32", a0, self.SC[6], a0)
+        Y = [v(2 * k, 2) for k in range(16)]
+        for k in range(0, 16, 2):
+            e("ds_read_b128", v(2 * k, 4), a0, offset=8 * k)
+        e("s_waitcnt", "lgkmcnt(0)")
+        for b in range(4):
+            c = 3 - b
+            js = list(range(1 << c))
+            for j0 in range(0, len(js), 2):
+                group = js[j0:j0 + 2]
+                blist = []
+                for j in group:
+                    tw = self.stream_wait(("f", c, j))
+                    for i in range(1 << b):
+                        k0 = (j << (b + 1)) | i
+                        corr = b > 0 and ((k0 >> (b - 1)) & 1) == 0
+                        blist.append((Y[k0], Y[k0 | (1 << b)], tw, corr))
+                self.butterflies(blist)
+                for j in group:
+                    self.stream_release(("f", c, j))
+        for k in range(0, 16, 2):
+            e("ds_write_b128", a0, v(2 * k, 4), offset=8 * k)
+
+    def pass_lane(self, half):
+        """bits 4..6: lane l owns rows (l >> 4) and (l >> 4) + 4, column l & 15"""
+        e = self.e
+        a0, a2 = self.A_[0], self.A_[2]
+        self.c("stages over bits 4..6 (wave-local)")
+        e("v_lshrrev_b32", a2, 4, self.LANE)
+        e("s_movk_i32", self.SC[4], 1152)
+        e("v_mul_lo_u32", a0, a2, self.SC[4])
+        e("v_and_b32", a2, 15, self.LANE)
+        e("v_lshl_add_u32", a0, a2, 3, a0)
+        e("v_add_u32", a0, self.SC[6], a0)
+        YA = [v(2 * k, 2) for k in range(8)]
+        YB = [v(16 + 2 * k, 2) for k in range(8)]
+        for k in range(8):
+            e("ds_read_b64", YA[k], a0, offset=k * 144)
+        for k in range(8):
+            e("ds_read_b64", YB[k], a0, offset=k * 144 + 4608)
+        for tag, Y, off in (("a", YA, 0), ("b", YB, 4608)):
+            first = [True]
+
+            def twf(c, j, tag=tag):
+                tw = self.stream_wait((tag, c, j), "lgkmcnt(8)" if first[0] else "")
+                first[0] = False
+                return tw
+
+            order = [(tag, c, j) for c in (2, 1, 0) for j in range(1 << c)]
+            self.gs_group(Y, 3, twf, False, hook=lambda n, order=order: self.stream_release(order[n - 1]))
+            for k in range(8):
+                e("ds_write_b64", a0, Y[k], offset=k * 144 + off)
+
+    def pass_uniform(self, half):
+        """bits 7..9: lane l owns the columns l and l + 64 of its wave's block; twiddles in SGPRs"""
+        e = self.e
+        a0, a1 = self.A_[0], self.A_[1]
+        self.c("stages over bits 7..9 (wave-local)")
+        e("v_lshrrev_b32", a1, 4, self.LANE)
+        e("v_lshlrev_b32", a1, 4, a1)
+        e("v_lshl_add_u32", a0, self.LANE, 3, a1)             # slot(l) * 8
+        e("v_add_u32", a0, self.SC[6], a0)
+        YA = [v(2 * k, 2) for k in range(8)]
+        YB = [v(16 + 2 * k, 2) for k in range(8)]
+        for k in range(8):
+            e("ds_read_b64", YA[k], a0, offset=k * 1152)
+        for k in range(8):
+            e("ds_read_b64", YB[k], a0, offset=k * 1152 + 576)
+        twf = lambda c, j: tuple(s(self.PB + (0, 8, 16)[c] + 4 * j + i) for i in range(4))
+        e("s_waitcnt", "lgkmcnt(8)")
+        self.gs_group(YA, 3, twf, False)
+        for k in range(8):
+            e("ds_write_b64", a0, YA[k], offset=k * 1152)
+        e("s_waitcnt", "lgkmcnt(8)")
+        self.gs_group(YB, 3, twf, False)
+        for k in range(8):
+            e("ds_write_b64", a0, YB[k], offset=k * 1152 + 576)
+
+    def column_read(self, half):
+        e = self.e
+        a0, a1, a2 = self.A_[0], self.A_[1], self.A_[2]
+        self.c("column exchange: thread t takes the coefficients {kk*1024 + t} of this half")
+        e("s_waitcnt", "lgkmcnt(0)")
+        e("s_barrier")
+        e("v_lshrrev_b32", a2, 4, self.TID)
+        e("v_lshlrev_b32", a2, 4, a2)
+        e("v_lshl_add_u32", a0, self.TID, 3, a2)              # slot(t) * 8
+        e("v_add_u32", a1, 8 * 9216, a0)
+        for kk in range(self.RH):
+            base, off = (a0, kk * 9216) if kk < 8 else (a1, (kk - 8) * 9216)
+            e("ds_read_b64", self.X[half * self.RH + kk], base, offset=off)
+        if half + 1 < self.HALVES:
+            e("s_waitcnt", "lgkmcnt(0)")
+            e("s_barrier")
+
+    # ---- pass A: SGPR twiddles in chunks of 8 (32 dwords), two buffers
+    def chunk_plan(self):
+        plan = []
+        for c in range(self.A - 1, 2, -1):
+            for j0 in range(0, 1 << c, 8):
+                plan.append(("tw", c, j0))
+        plan.append(("low",))           # heap entries 0..7: c = 2, 1 and the fused constant at index 0
+        plan.append(("lp",))
+        return plan
+
+    def chunk_load(self, n):
+        e = self.e
+        item = self.plan[n]
+        buf = (self.QB, self.PB)[n % 2]
+        if item[0] == "tw":
+            _, c, j0 = item
+            off = ((1 << c) + j0) * 16
+            e("s_load_dwordx16", s(buf, 16), self.TW, off)
+            e("s_load_dwordx16", s(buf + 16, 16), self.TW, off + 64)
+        elif item[0] == "low":
+            e("s_load_dwordx16", s(buf, 16), self.TW, 0)
+            e("s_load_dwordx16", s(buf + 16, 16), self.TW, 64)
+        else:
+            e("s_load_dwordx16", s(buf, 16), self.LP, 0)
+        return buf
+
+    def pass_a(self):
+        e = self.e
+        A, RA = self.A, self.RA
+        self.c("top %d stages in registers, wave-uniform twiddles in SGPRs" % A)
+        X = self.X
+        plan = self.plan
+        nchunks = len(plan)
+        # chunks 0 and 1 were requested during the last half's LDS phase
+        for n in range(nchunks):
+            item = plan[n]
+            buf = (self.QB, self.PB)[n % 2]
+            e("s_waitcnt", "lgkmcnt(0)")
+            if item[0] == "tw":
+                _, c, j0 = item
+                b = A - 1 - c
+                blist = []
+                for j in range(j0, j0 + 8):
+                    tw = tuple(s(buf + 4 * (j - j0) + i) for i in range(4))
+                    for i in range(1 << b):
+                        k0 = (j << (b + 1)) | i
+                        corr = True if b == 0 else ((k0 >> (b - 1)) & 1) == 0
+                        blist.append((X[k0], X[k0 | (1 << b)], tw, corr))
+                self.butterflies(blist)
+                if n + 2 < nchunks:
+                    self.chunk_load(n + 2)
+            elif item[0] == "low":
+                for c in (2, 1):
+                    if c > A - 1:
+                        continue
+                    b = A - 1 - c
+                    blist = []
+                    for j in range(1 << c):
+                        tw = tuple(s(buf + 4 * ((1 << c) + j) + i) for i in range(4))
+                        for i in range(1 << b):
+                            k0 = (j << (b + 1)) | i
+                            corr = True if b == 0 else ((k0 >> (b - 1)) & 1) == 0
+                            blist.append((X[k0], X[k0 | (1 << b)], tw, corr))
+                    self.butterflies(blist)
+                self.low_buf = buf
+            else:
+                # LimbParams: n_inv at dwords 10..11, its Shoup companion at 12..13
+                tw_n = (s(buf + 10), s(buf + 11), s(buf + 12), s(buf + 13))
+                tw_wn = tuple(s(self.low_buf + i) for i in range(4))
+                b = A - 1
+                items = []
+                for i in range(1 << b):
+                    items.append(lambda ts, U=X[i], V=X[i | (1 << b)]: self.ops_last(ts, U, V, tw_n, tw_wn))
+                self.zip_emit(items)
+
+    def store_columns(self):
+        e = self.e
+        self.c("coalesced store of the column {k*S + t}")
+        e("v_lshlrev_b32", self.GOFF, 3, self.TID)
+        for k in range(self.RA):
+            e("global_store_dwordx2", self.GOFF, self.X[k], self.DST)
+            e("s_add_u32", self.DST.lo(), self.DST.lo(), self.S * 8)
+            e("s_addc_u32", self.DST.hi(), self.DST.hi(), 0)
+
+    def build(self):
+        self.plan = self.chunk_plan()
+        self.prologue()
+        for half in range(self.HALVES):
+            last = half + 1 == self.HALVES
+            self.uniform_twiddle_loads(half)
+            if last:
+                self.chunk_load(0)
+            self.copy_in(half)
+            self.pass_low(half)
+            self.pass_lane(half)
+            self.pass_uniform(half)
+            if last:
+                self.chunk_load(1)
+            self.column_read(half)
+        self.pass_a()
+        self.store_columns()
+        self.e("s_endpgm")
+        return self.p
+
+
+def selftest(logn):
+    import numpy as np
+
+    from gen_ntt import emulate
+    ok, info = emulate(GenInv(logn), inverse=True)
+    print("inverse logN=%d emulated workgroup: %s; %s" % (logn, "bit-exact vs oracle" if ok else "MISMATCH", info))
+    return ok
+
+
+if __name__ == "__main__":
+    logn = int(sys.argv[1])
+    if len(sys.argv) > 2 and sys.argv[2] == "--selftest":
+        sys.exit(0 if selftest(logn) else 1)
+    text = kernel_text_for(GenInv(logn), "lr_ntt_inv%d_asm" % logn)
+    open(sys.argv[2], "w").write(text)

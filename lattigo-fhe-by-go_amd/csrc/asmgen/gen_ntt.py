@@ -236,6 +236,10 @@ class Gen:
         e("s_mul_i32", sc[3], sc[0], 15 * N)
         e("s_add_u32", self.TWF.lo(), s(56), sc[3])
         e("s_addc_u32", self.TWF.hi(), s(57), 0)
+        self.prologue_tail()
+
+    def prologue_tail(self):
+        e = self.e
         self.c("coalesced load of the column {k*S + t}")
         # order 0, RA/2, 1, RA/2+1, ...: the first-stage butterflies can start after two loads
         e("s_add_u32", self.TMP.lo(), self.SRC.lo(), (self.RA // 2) * self.S * 8)
@@ -491,19 +495,25 @@ class Gen:
         # the last four stages' twiddles (lane-transposed table) follow in the same stream discipline
         self.final_prefetch(half)
 
-    def final_prefetch(self, half):
+    def final_requests(self, half):
+        """the 15 lane-transposed twiddles of the stages over bits 3..0, table row (2^c - 1 + j), in heap order"""
         e = self.e
         a2 = self.A_[2]
-        e("v_lshlrev_b32", a2, 4, self.TID)                   # block index half*1024 + 64*wave + lane = half*1024 + t
-        e("s_add_u32", self.TWFR.lo(), self.TWF.lo(), half * 16384)
-        e("s_addc_u32", self.TWFR.hi(), self.TWF.hi(), 0)
 
-        def issue(slot):
-            e("global_load_dwordx4", slot, a2, self.TWFR)
-            e("s_add_u32", self.TWFR.lo(), self.TWFR.lo(), (self.N // 16) * 16)
-            e("s_addc_u32", self.TWFR.hi(), self.TWFR.hi(), 0)
+        def make(c, j):
+            def issue(slot):
+                e("v_lshlrev_b32", a2, 4, self.TID)           # block index half*1024 + 64*wave + lane = half*1024 + t
+                row = (1 << c) - 1 + j
+                off = half * 16384 + row * (self.N // 16) * 16
+                e("s_add_u32", self.TWFR.lo(), self.TWF.lo(), off)
+                e("s_addc_u32", self.TWFR.hi(), self.TWF.hi(), 0)
+                e("global_load_dwordx4", slot, a2, self.TWFR)
+            return issue
 
-        self.stream_begin([(("f", c, j), issue) for c in range(4) for j in range(1 << c)])
+        return [(("f", c, j), make(c, j)) for c in range(4) for j in range(1 << c)]
+
+    def final_prefetch(self, half):
+        self.stream_begin(self.final_requests(half))
 
     def lds_pass_final(self, half):
         """bits 3..0 (R = 4): lane l owns the 16 contiguous coefficients of block l; lane-transposed twiddles."""
@@ -582,6 +592,10 @@ class Gen:
 
 def kernel_text(logn, name):
     g = Gen(logn)
+    return kernel_text_for(g, name), g, g.p
+
+
+def kernel_text_for(g, name):
     prog = g.build()
     lds_bytes = (16384 + 2048) * 8
     hdr = """  .amdgcn_target "amdgcn-amd-amdhsa--gfx950"
@@ -637,13 +651,14 @@ amdhsa.version: [1, 2]
 ...
   .end_amdgpu_metadata
 """.format(name=name, lds=lds_bytes, vgpr=128, accum=128)
-    return hdr + prog.text() + desc, g, prog
+    return hdr + prog.text() + desc
 
 
 # ------------------------------------------------------------------------------------------
 # self test on the numpy emulator
 # ------------------------------------------------------------------------------------------
-def selftest(logn):
+def emulate(gen, inverse=False):
+    """run one workgroup of the generated program on the numpy emulator; returns (bit-exact?, summary text)"""
     import numpy as np
 
     from isa import Machine
@@ -651,16 +666,24 @@ def selftest(logn):
     import __graft_entry__ as graft
     oracle = graft.load_oracle()
     pkg = graft.load_package()
+    logn = gen.logn
     N = 1 << logn
     q = pkg.params.Qi60()[-3]
     oc = oracle.Context(N, [q])
     x = pkg.sampling.random_u64((N,), seed=5)                 # full 64-bit inputs
     x[:4] = np.uint64(0xFFFFFFFFFFFFFFFF)
-    want = oc.ntt(np.array([[int(val) % q for val in x]], dtype=np.uint64))[0]
+    if inverse:
+        x = (x % np.uint64(4 * q)).astype(np.uint64)          # the inverse accepts [0, 4q)
+        x[:4] = np.uint64(4 * q - 1)
+    canon = np.array([[int(val) % q for val in x]], dtype=np.uint64)
+    want = (oc.intt(canon) if inverse else oc.ntt(canon))[0]
 
     # host-side tables exactly as lr_abi.cpp builds them
-    R64 = 1 << 64
-    psi = [int(oracle.inv_mform(int(w), q)) for w in oc.ntt_psi[0]]
+    table = oc.ntt_psi_inv[0] if inverse else oc.ntt_psi[0]
+    psi = [int(oracle.inv_mform(int(w), q)) for w in table]
+    n_inv = pow(N, -1, q)
+    if inverse:
+        psi[0] = psi[1] * n_inv % q                           # constant of the fused last stage
     tw = np.zeros((N, 2), dtype=np.uint64)
     for i, w in enumerate(psi):
         tw[i, 0] = w
@@ -676,6 +699,8 @@ def selftest(logn):
     red_m = min((1 << (32 + g)) // qh, 0xFFFFFFFF)
     lp = np.zeros(8, dtype=np.uint64)
     lp[0] = q
+    lp[5] = n_inv
+    lp[6] = (n_inv << 64) // q
     lp[7] = red_m | (g << 32)
 
     # flat memory image (byte addresses)
@@ -698,7 +723,6 @@ def selftest(logn):
     karg[8], karg[9], karg[10] = A_LP, A_TW, A_TWF
     place(karg, A_KARG)
 
-    gen = Gen(logn)
     prog = gen.build()
     m = Machine(T, 160 * 1024, mem.size)
     m.mem = mem
@@ -713,11 +737,17 @@ def selftest(logn):
     cnt = prog.count()
     valu = sum(n for op, n in cnt.items() if op.startswith("v_"))
     bf = (1 << gen.A) * logn // 2
-    print("logN=%d emulated workgroup: %s; %d instructions, %d VALU = %.1f per butterfly, s_nop %d" %
-          (logn, "bit-exact vs oracle" if ok else "MISMATCH", len(prog.ins), valu, valu / bf, cnt.get("s_nop", 0)))
+    info = "%d instructions, %d VALU = %.1f per butterfly, s_nop %d" % (len(prog.ins), valu, valu / bf, cnt.get("s_nop", 0))
     if not ok:
         bad = np.nonzero(got != want)[0]
-        print("  mismatches:", bad.size, "first:", bad[:8], [hex(int(got[i])) for i in bad[:3]], [hex(int(want[i])) for i in bad[:3]])
+        info += "\n  mismatches: %d first: %s %s %s" % (bad.size, bad[:8], [hex(int(got[i])) for i in bad[:3]],
+                                                       [hex(int(want[i])) for i in bad[:3]])
+    return ok, info
+
+
+def selftest(logn):
+    ok, info = emulate(Gen(logn))
+    print("logN=%d emulated workgroup: %s; %s" % (logn, "bit-exact vs oracle" if ok else "MISMATCH", info))
     return ok
 
 

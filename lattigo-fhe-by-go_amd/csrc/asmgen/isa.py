@@ -187,6 +187,7 @@ class Machine:
 
     # -- memory helpers (addresses in bytes)
     def _gaddr(self, voff, sbase, offset):
+        assert -4096 <= offset < 4096, "global immediate offset is 13-bit signed"
         base = self.rs64(sbase)[self.lane_wave]
         return base + self.rv(voff).astype(np.uint64) + np.uint64(offset)
 

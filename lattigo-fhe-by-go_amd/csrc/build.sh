@@ -9,17 +9,21 @@ mkdir -p build
 LLVM=${LLVM:-/opt/rocm/lib/llvm/bin}
 for n in 14 15; do
   python3 asmgen/gen_ntt.py $n build/ntt_fwd$n.s
-  $LLVM/clang -x assembler -target amdgcn-amd-amdhsa -mcpu=gfx950 -c build/ntt_fwd$n.s -o build/ntt_fwd$n.o
-  $LLVM/ld.lld -shared build/ntt_fwd$n.o -o build/ntt_fwd$n.hsaco
+  python3 asmgen/gen_intt.py $n build/ntt_inv$n.s
+  for k in fwd inv; do
+    $LLVM/clang -x assembler -target amdgcn-amd-amdhsa -mcpu=gfx950 -c build/ntt_$k$n.s -o build/ntt_$k$n.o
+    $LLVM/ld.lld -shared build/ntt_$k$n.o -o build/ntt_$k$n.hsaco
+  done
 done
 python3 - <<'PY'
 out = []
-for n in (14, 15):
-    data = open("build/ntt_fwd%d.hsaco" % n, "rb").read()
-    out.append('extern "C" const unsigned char lr_hsaco_fwd%d[] __attribute__((aligned(4096))) = {' % n)
-    out.append(",".join(str(b) for b in data))
-    out.append("};")
-    out.append('extern "C" const unsigned long lr_hsaco_fwd%d_size = %d;' % (n, len(data)))
+for k in ("fwd", "inv"):
+    for n in (14, 15):
+        data = open("build/ntt_%s%d.hsaco" % (k, n), "rb").read()
+        out.append('extern "C" const unsigned char lr_hsaco_%s%d[] __attribute__((aligned(4096))) = {' % (k, n))
+        out.append(",".join(str(b) for b in data))
+        out.append("};")
+        out.append('extern "C" const unsigned long lr_hsaco_%s%d_size = %d;' % (k, n, len(data)))
 open("build/lr_asm_blob.cpp", "w").write("\n".join(out) + "\n")
 PY
 pids=()

@@ -271,6 +271,12 @@ extern "C" int lr_context_create(uint64_t N, const uint64_t *moduli, int n_modul
             fwd[(size_t)i * N + j] = make_ulonglong2(wf, shoup_companion(wf, q));
             inv[(size_t)i * N + j] = make_ulonglong2(wi, shoup_companion(wi, q));
         }
+        if (N >= 2) {
+            // heap index 0 is unused by the transform: it carries psi_inv[1] * N^-1, the twiddle of the last
+            // inverse stage fused with the scaling (assembly kernels)
+            const u64 w1n = (u64)(((u128)inv[(size_t)i * N + 1].x * p.n_inv) % q);
+            inv[(size_t)i * N] = make_ulonglong2(w1n, shoup_companion(w1n, q));
+        }
     }
     LR_TRY(to_device(&c->d_lp, lp.data(), lp.size()));
     if (N >= 4096) {
@@ -528,8 +534,8 @@ int run_ntt(lr_context *c, bool inverse, Rows in, Rows out, int mod0, int mod_st
     a.lp = c->d_lp;
     a.tw = inverse ? c->d_inv : c->d_fwd;
     a.tw_fin = inverse ? c->d_inv_fin : c->d_fwd_fin;
-    if (!inverse && (c->ntt_mode & 255) == 1 && c->use_asm && batch <= 65535 && ntt_asm_available((int)logn)) {
-        LR_HIP(launch_ntt_asm(a, (int)logn, c->stream));
+    if ((c->ntt_mode & 255) == 1 && c->use_asm && batch <= 65535 && ntt_asm_available((int)logn)) {
+        LR_HIP(launch_ntt_asm(a, (int)logn, inverse, c->stream));
         return LR_OK;
     }
     LR_HIP(launch_ntt(a, (int)logn, inverse, c->ntt_mode, c->stream));

@@ -1,8 +1,9 @@
 // lr_asm.cpp -- loader/launcher of the hand-scheduled gfx950 assembly kernels (asmgen/gen_ntt.py).
 //
 // The code objects are generated and assembled at build time (build.sh) and embedded in this
-// library (lr_asm_blob.cpp).  They implement exactly the forward NTT of lr_ntt.hip in lazy mode 1
-// (every modulus in [2^57, 2^60]) for N = 2^14 and 2^15; everything else stays on the C++ kernels.
+// library (lr_asm_blob.cpp).  They implement exactly the forward and inverse NTT of lr_ntt.hip in
+// lazy mode 1 (every modulus in [2^57, 2^60]) for N = 2^14 and 2^15; everything else stays on the
+// C++ kernels.
 #include <hip/hip_runtime.h>
 
 #include <map>
@@ -15,14 +16,18 @@ extern const unsigned char lr_hsaco_fwd14[];
 extern const unsigned long lr_hsaco_fwd14_size;
 extern const unsigned char lr_hsaco_fwd15[];
 extern const unsigned long lr_hsaco_fwd15_size;
+extern const unsigned char lr_hsaco_inv14[];
+extern const unsigned long lr_hsaco_inv14_size;
+extern const unsigned char lr_hsaco_inv15[];
+extern const unsigned long lr_hsaco_inv15_size;
 }
 
 namespace lr {
 
 namespace {
 struct AsmKernels {
-    hipModule_t mod14 = nullptr, mod15 = nullptr;
-    hipFunction_t f14 = nullptr, f15 = nullptr;
+    hipModule_t mod[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipFunction_t fn[4] = {nullptr, nullptr, nullptr, nullptr};   // fwd14, fwd15, inv14, inv15
     bool ok = false;
 };
 
@@ -35,13 +40,13 @@ AsmKernels *kernels_for_current_device() {
     auto it = table.find(dev);
     if (it != table.end()) return it->second.ok ? &it->second : nullptr;
     AsmKernels k;
-    if (hipModuleLoadData(&k.mod14, lr_hsaco_fwd14) == hipSuccess &&
-        hipModuleLoadData(&k.mod15, lr_hsaco_fwd15) == hipSuccess &&
-        hipModuleGetFunction(&k.f14, k.mod14, "lr_ntt_fwd14_asm") == hipSuccess &&
-        hipModuleGetFunction(&k.f15, k.mod15, "lr_ntt_fwd15_asm") == hipSuccess)
-        k.ok = true;
-    else
-        (void)hipGetLastError();
+    const void *image[4] = {lr_hsaco_fwd14, lr_hsaco_fwd15, lr_hsaco_inv14, lr_hsaco_inv15};
+    const char *name[4] = {"lr_ntt_fwd14_asm", "lr_ntt_fwd15_asm", "lr_ntt_inv14_asm", "lr_ntt_inv15_asm"};
+    k.ok = true;
+    for (int i = 0; i < 4 && k.ok; ++i)
+        k.ok = hipModuleLoadData(&k.mod[i], image[i]) == hipSuccess &&
+               hipModuleGetFunction(&k.fn[i], k.mod[i], name[i]) == hipSuccess;
+    if (!k.ok) (void)hipGetLastError();
     table[dev] = k;
     return k.ok ? &table[dev] : nullptr;
 }
@@ -49,7 +54,7 @@ AsmKernels *kernels_for_current_device() {
 
 bool ntt_asm_available(int logn) { return (logn == 14 || logn == 15) && kernels_for_current_device() != nullptr; }
 
-hipError_t launch_ntt_asm(const NttLaunch &a, int logn, hipStream_t stream) {
+hipError_t launch_ntt_asm(const NttLaunch &a, int logn, int inverse, hipStream_t stream) {
     AsmKernels *k = kernels_for_current_device();
     if (!k || (logn != 14 && logn != 15)) return hipErrorNotSupported;
     if (a.n_items <= 0 || a.batch <= 0) return hipSuccess;
@@ -60,7 +65,7 @@ hipError_t launch_ntt_asm(const NttLaunch &a, int logn, hipStream_t stream) {
     (void)hipGetLastError();
     // grid: x = limb of the launch, y = polynomial; blocks b and b+8 share an XCD, so the limbs an XCD
     // sees (and whose twiddles live in its L2) are x mod 8 when n_items is a multiple of 8
-    return hipModuleLaunchKernel(logn == 15 ? k->f15 : k->f14, (unsigned)a.n_items, (unsigned)a.batch, 1, 1024, 1, 1, 0, stream,
+    return hipModuleLaunchKernel(k->fn[(inverse ? 2 : 0) + (logn - 14)], (unsigned)a.n_items, (unsigned)a.batch, 1, 1024, 1, 1, 0, stream,
                                  nullptr, extra);
 }
 

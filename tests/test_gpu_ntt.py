@@ -208,6 +208,37 @@ def test_cxx_and_asm_paths_agree(gpu_pkg, oracle, logn, limbs, monkeypatch):
         assert np.array_equal(p.get(), got)
 
 
+@pytest.mark.parametrize("logn,limbs", [(14, 3), (15, 2)])
+def test_cxx_and_asm_inverse_paths_agree(gpu_pkg, oracle, logn, limbs, monkeypatch):
+    """inverse twin of the test above: the assembly InvNTT (last stage fused with the N^-1 scaling) and the C++
+    kernel both equal the oracle, on inputs anywhere in the documented lazy range [0, 4q), out of place and in place"""
+    N = 1 << logn
+    moduli = list(gpu_pkg.params.Qi60()[-limbs:])
+    oc = oracle.Context(N, moduli)
+    x = gpu_pkg.sampling.random_u64((3, limbs, N), seed=78)
+    for i, q in enumerate(moduli):
+        x[:, i] %= np.uint64(4 * q)
+        x[0, i, :3] = np.uint64(4 * q - 1)
+        x[1, i, -3:] = 0
+    want = [oc.intt(np.array([[int(v) % q for v in x[b, i]] for i, q in enumerate(moduli)], dtype=np.uint64)) for b in range(3)]
+    for no_asm in (False, True):
+        if no_asm:
+            monkeypatch.setenv("LR_NO_ASM", "1")
+        else:
+            monkeypatch.delenv("LR_NO_ASM", raising=False)
+        ctx = gpu_pkg.ring.NewContextWithParams(N, moduli)
+        p, r = ctx.NewPoly(3).set(x), ctx.NewPoly(3)
+        ctx.InvNTT(p, r)
+        got = r.get()
+        for b in range(3):
+            assert np.array_equal(got[b], want[b]), (no_asm, b)
+        ctx.InvNTT(p, p)
+        assert np.array_equal(p.get(), got)
+        # round trip through both assembly kernels
+        ctx.NTT(p, p)
+        assert np.array_equal(p.get(), np.stack([[x[b, i] % np.uint64(q) for i, q in enumerate(moduli)] for b in range(3)]))
+
+
 def test_cpp_host_mirror_runs_reference_ntt_test():
     """tests/cpp/test_ntt_golden.cpp is the C++ twin of ring/ntt_test.go:Test_NTT on include/lattigo_ring.hpp
     (the C++ host mirror over the C ABI).  Built here with g++ against the in-tree library and executed."""
