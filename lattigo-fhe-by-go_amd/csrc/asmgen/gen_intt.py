@@ -22,10 +22,14 @@ from isa import s, v
 
 
 class GenInv(Gen):
-    def __init__(self, logn):
-        super().__init__(logn)
-        self.Q8 = self.Q4                       # s[18:19] holds 8q here
-        self.NQ2 = s(22, 2)                     # -2q (REDM/REDG are not used by the inverse)
+    """mode 1: every modulus in (2^33, 2^60], bound B = 8q as described above;
+       mode 0: moduli up to 2^61: B = 4q and every butterfly corrects."""
+
+    def __init__(self, logn, mode=1):
+        assert mode in (0, 1)
+        super().__init__(logn, mode)
+        self.Q8 = self.Q4                       # s[18:19] holds the bound B here
+        self.NQ2 = s(22, 2)                     # -2q (the Barrett constant is not used by the inverse)
         self.LP = s(0, 2)                       # LimbParams pointer (kernarg pointer is dead after the prologue)
         # pass A keeps X[k]; the LDS phase works in v0..v31, so the first half is parked in v32..v63
         if self.HALVES == 2:
@@ -94,6 +98,14 @@ class GenInv(Gen):
         # other butterfly in flight does not
         return ops + self.ops_canon4(ts, U) + self.ops_canon4(ts, V)
 
+    def corr(self, b, k0, first_pass=False):
+        """does the butterfly over local bit b at position k0 subtract the bound from its sum?"""
+        if self.mode == 0:
+            return True
+        if b == 0:
+            return not first_pass           # operand types depend on the lane across a pass boundary
+        return ((k0 >> (b - 1)) & 1) == 0   # sums of two X-type values only
+
     def gs_group(self, Y, R, twf, first_pass, hook=None, last=None):
         """R Gentleman-Sande stages over the local bits 0..R-1 of 2^R coefficients.
         twf(c, j): twiddle of heap position (H << c) + j, c = R-1-b."""
@@ -108,11 +120,7 @@ class GenInv(Gen):
                 tw = twf(c, j)
                 for i in range(1 << b):
                     k0 = (j << (b + 1)) | i
-                    if b == 0:
-                        corr = not first_pass
-                    else:
-                        corr = ((k0 >> (b - 1)) & 1) == 0
-                    blist.append((Y[k0], Y[k0 | (1 << b)], tw, corr))
+                    blist.append((Y[k0], Y[k0 | (1 << b)], tw, self.corr(b, k0, first_pass)))
             self.butterflies(blist)
             for _ in range(1 << c):
                 n += 1
@@ -126,7 +134,7 @@ class GenInv(Gen):
         e("s_mov_b64", self.Qm, s(68, 2))
         e("s_sub_u32", self.NQ.lo(), 0, self.Qm.lo())
         e("s_subb_u32", self.NQ.hi(), 0, self.Qm.hi())
-        e("s_lshl_b64", self.Q8, self.Qm, 3)
+        e("s_lshl_b64", self.Q8, self.Qm, 2 if self.mode == 0 else 3)
         e("s_sub_u32", self.NQ8.lo(), 0, self.Q8.lo())
         e("s_subb_u32", self.NQ8.hi(), 0, self.Q8.hi())
         e("s_lshl_b64", self.NQ2, self.NQ, 1)
@@ -195,8 +203,7 @@ class GenInv(Gen):
                     tw = self.stream_wait(("f", c, j))
                     for i in range(1 << b):
                         k0 = (j << (b + 1)) | i
-                        corr = b > 0 and ((k0 >> (b - 1)) & 1) == 0
-                        blist.append((Y[k0], Y[k0 | (1 << b)], tw, corr))
+                        blist.append((Y[k0], Y[k0 | (1 << b)], tw, self.corr(b, k0, True)))
                 self.butterflies(blist)
                 for j in group:
                     self.stream_release(("f", c, j))
@@ -321,8 +328,7 @@ class GenInv(Gen):
                     tw = tuple(s(buf + 4 * (j - j0) + i) for i in range(4))
                     for i in range(1 << b):
                         k0 = (j << (b + 1)) | i
-                        corr = True if b == 0 else ((k0 >> (b - 1)) & 1) == 0
-                        blist.append((X[k0], X[k0 | (1 << b)], tw, corr))
+                        blist.append((X[k0], X[k0 | (1 << b)], tw, self.corr(b, k0)))
                 self.butterflies(blist)
                 if n + 2 < nchunks:
                     self.chunk_load(n + 2)
@@ -336,8 +342,7 @@ class GenInv(Gen):
                         tw = tuple(s(buf + 4 * ((1 << c) + j) + i) for i in range(4))
                         for i in range(1 << b):
                             k0 = (j << (b + 1)) | i
-                            corr = True if b == 0 else ((k0 >> (b - 1)) & 1) == 0
-                            blist.append((X[k0], X[k0 | (1 << b)], tw, corr))
+                            blist.append((X[k0], X[k0 | (1 << b)], tw, self.corr(b, k0)))
                     self.butterflies(blist)
                 self.low_buf = buf
             else:
@@ -381,17 +386,13 @@ class GenInv(Gen):
 
 
 def selftest(logn):
-    import numpy as np
-
-    from gen_ntt import emulate
-    ok, info = emulate(GenInv(logn), inverse=True)
-    print("inverse logN=%d emulated workgroup: %s; %s" % (logn, "bit-exact vs oracle" if ok else "MISMATCH", info))
-    return ok
+    import gen_ntt
+    return gen_ntt.selftest(logn, inverse=True)
 
 
 if __name__ == "__main__":
     logn = int(sys.argv[1])
     if len(sys.argv) > 2 and sys.argv[2] == "--selftest":
         sys.exit(0 if selftest(logn) else 1)
-    text = kernel_text_for(GenInv(logn), "lr_ntt_inv%d_asm" % logn)
-    open(sys.argv[2], "w").write(text)
+    mode = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+    open(sys.argv[2], "w").write(kernel_text_for(GenInv(logn, mode), "lr_ntt_inv%d_m%d" % (logn, mode)))

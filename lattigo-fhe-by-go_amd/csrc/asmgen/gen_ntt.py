@@ -4,13 +4,14 @@ Same algorithm, data layout and twiddle tables as the C++ kernel `ntt_fwd_kernel
 lr_ntt.hip (pass A in registers -> LDS passes 3+3+4 -> coalesced copy-out, lazy Shoup butterflies
 with correction every second stage); what changes is the instruction stream: registers are
 assigned by hand, the zero halves of the multiply-accumulate addends live in dedicated registers,
-conditional subtractions use the high-word compare, and nothing spills.  15 VALU instructions per
-butterfly without correction, 19 with (the compiler's version: 21-26).
+conditional subtractions use the high-word compare, the butterfly sum rides on the multiply-accumulate
+chain, and nothing spills.  14 VALU instructions per butterfly without correction, 18 with (the
+compiler's version: 21-26).
 
-Valid for contexts whose moduli all satisfy 2^57 <= q <= 2^60 (lazy mode 1 of lr_ntt.hip); the
-host falls back to the C++ kernels otherwise.
+Three variants per degree (Gen.mode) cover every modulus in (2^33, 2^61); the host picks the cheapest one
+the context's largest modulus allows and falls back to the C++ kernels for smaller moduli or degrees.
 
-    python gen_ntt.py 15 out.s        # assembly text
+    python gen_ntt.py 15 out.s [mode] # assembly text
     python gen_ntt.py 15 --selftest   # emulate one workgroup with numpy and compare with a reference NTT
 """
 import sys
@@ -22,8 +23,14 @@ LOGT = 10
 
 
 class Gen:
-    def __init__(self, logn):
-        assert logn in (14, 15)
+    """mode = lazy-correction cadence, all moduli of the launch in (2^33, limit]:
+         1: q <= 2^60, U <- U - 8q (if U >= 8q) before every second stage;
+         2: q <  2^57, no corrections at all (15 stages x 4q of growth stay below 2^64);
+         0: q <  2^61, U <- U - 4q (if U >= 4q) before every stage."""
+
+    def __init__(self, logn, mode=1):
+        assert logn in (14, 15) and mode in (0, 1, 2)
+        self.mode = mode
         self.logn = logn
         self.N = 1 << logn
         self.A = logn - 10            # bits consumed by pass A
@@ -62,8 +69,8 @@ class Gen:
         self.WGX, self.WGY = s(2), s(3)
         self.SRC, self.DST = s(4, 2), s(6, 2)
         self.TW, self.TWF, self.TWFR = s(8, 2), s(10, 2), s(12, 2)
-        self.Qm, self.NQ, self.Q4, self.NQ8 = s(14, 2), s(16, 2), s(18, 2), s(20, 2)
-        self.REDM, self.REDG, self.WAVE = s(22), s(23), s(24)
+        self.Qm, self.NQ, self.Q4, self.NQ8 = s(14, 2), s(16, 2), s(18, 2), s(20, 2)   # NQ8: -8q (mode 1) or -4q (mode 0)
+        self.U0, self.WAVE = s(22), s(24)
         self.SC = [s(25 + i) for i in range(7)]      # s25..s31 scratch
         self.JUNK = s(32, 2)
         self.TMP = s(34, 2)
@@ -124,36 +131,47 @@ class Gen:
         ]
 
     def ops_butterfly(self, ts, U, V, tw, correct):
-        """(U, V) <- (U + V*w, U - V*w + 4q); optional U <- U - 8q if U >= 8q first."""
+        """(U, V) <- (U + r, U + 4q - r), r = V*w - qhat*q in [0,4q); optional U <- U - 8q if U >= 8q first.
+        The product accumulates straight onto U (X = U + r costs nothing) and Y = (2U + 4q) - X; all of it
+        modulo 2^64, exact because the true X and Y are below 2^64."""
+        w0, w1, s0, s1 = tw
+        J = self.JUNK
         ops = []
-        mm = self.ops_modmul(ts, V, tw)
+        hi = [("v_mul_hi_u32", ts.T0, V.hi(), s0),
+              ("v_mul_hi_u32", ts.T2, V.lo(), s1)]
         if correct:
             D = ts.C
             ops += [("v_lshl_add_u64", D, U, 0, self.NQ8),
                     ("v_cmp_lt_u32", ts.CY, D.hi(), U.hi())]
-            ops += mm[:2]                                   # the two mul_hi sit between compare and select
+            ops += hi                                       # the two mul_hi sit between compare and select
             ops += [("v_cndmask_b32", U.lo(), U.lo(), D.lo(), ts.CY),
                     ("v_cndmask_b32", U.hi(), U.hi(), D.hi(), ts.CY)]
-            ops += mm[2:]
         else:
-            ops += mm
-        ops += [("v_lshl_add_u64", V, U, 0, self.Q4),        # Y = U + 4q ...
-                ("v_lshl_add_u64", U, U, 0, ts.R),           # X = U + r
-                ("v_sub_co_u32", V.lo(), ts.CY, V.lo(), ts.R.lo()),
-                ("v_subb_co_u32", V.hi(), ts.CY, V.hi(), ts.R.hi(), ts.CY)]   # ... - r
+            ops += hi
+        ops += [
+            ("v_lshl_add_u64", ts.R, U, 1, self.Q4),        # 2U + 4q
+            ("v_mad_u64_u32", ts.Q, J, V.hi(), s1, ts.T01),
+            ("v_mad_u64_u32", U, J, V.lo(), w0, U),
+            ("v_mad_u64_u32", ts.C, J, V.lo(), w1, 0),
+            ("v_lshl_add_u64", ts.Q, ts.Q, 0, ts.T23),
+            ("v_mad_u64_u32", ts.C, J, V.hi(), w0, ts.C),
+            ("v_mad_u64_u32", U, J, ts.Q.lo(), self.NQ.lo(), U),
+            ("v_mad_u64_u32", ts.C, J, ts.Q.lo(), self.NQ.hi(), ts.C),
+            ("v_mad_u64_u32", ts.C, J, ts.Q.hi(), self.NQ.lo(), ts.C),
+            ("v_add_u32", U.hi(), U.hi(), ts.C.lo()),       # X
+            ("v_sub_co_u32", V.lo(), ts.CY, ts.R.lo(), U.lo()),
+            ("v_subb_co_u32", V.hi(), ts.CY, ts.R.hi(), U.hi(), ts.CY)]   # Y
         return ops
 
     def ops_reduce_2q(self, ts, X):
-        """X <- X - floor~(X/q) * q in [0, 2q) for any 64-bit X (quotient under-estimated by <= 1)."""
-        k = ts.T0
+        """X <- X - floor(X * u0 / 2^64) * q in [0, 2q) for any 64-bit X; u0 = floor(2^64 / q) < 2^32
+        (the quotient of ring.BRedAdd, modular_reduction.go:137-146, which is at most one too small)."""
         return [
-            ("v_mul_hi_u32", k, X.hi(), self.REDM),
-            ("v_lshrrev_b32", k, self.REDG, k),
-            ("v_mad_u64_u32", ts.R, self.JUNK, k, self.Qm.lo(), 0),
-            ("v_mul_lo_u32", ts.T2, k, self.Qm.hi()),
-            ("v_add_u32", ts.R.hi(), ts.R.hi(), ts.T2),
-            ("v_sub_co_u32", X.lo(), ts.CY, X.lo(), ts.R.lo()),
-            ("v_subb_co_u32", X.hi(), ts.CY, X.hi(), ts.R.hi(), ts.CY),
+            ("v_mul_hi_u32", ts.T0, X.lo(), self.U0),
+            ("v_mad_u64_u32", ts.Q, self.JUNK, X.hi(), self.U0, ts.T01),      # Q.hi = floor(X * u0 / 2^64)
+            ("v_mad_u64_u32", X, self.JUNK, ts.Q.hi(), self.NQ.lo(), X),      # X + k * (2^64 - q), low word and carry
+            ("v_mul_lo_u32", ts.T2, ts.Q.hi(), self.NQ.hi()),
+            ("v_add_u32", X.hi(), X.hi(), ts.T2),
         ]
 
     def ops_canon(self, ts, X):
@@ -184,6 +202,10 @@ class Gen:
         self.zip_emit([(lambda ts, x=x: self.ops_butterfly(ts, *x)) for x in blist])
 
     def correct_flag(self, stage):
+        if self.mode == 2:
+            return False
+        if self.mode == 0:
+            return stage >= 1
         return stage >= 2 and stage % 2 == 0
 
     # ------------------------------------------------------------------ kernel sections
@@ -252,12 +274,11 @@ class Gen:
                 e("s_addc_u32", ptr.hi(), ptr.hi(), 0)
         e("s_waitcnt", "lgkmcnt(0)")
         e("s_mov_b64", self.Qm, s(68, 2))
-        e("s_mov_b32", self.REDM, s(82))
-        e("s_mov_b32", self.REDG, s(83))
+        e("s_mov_b32", self.U0, s(72))                # low word of bred_hi = floor(2^64 / q)
         e("s_sub_u32", self.NQ.lo(), 0, self.Qm.lo())
         e("s_subb_u32", self.NQ.hi(), 0, self.Qm.hi())
         e("s_lshl_b64", self.Q4, self.Qm, 2)
-        e("s_lshl_b64", self.TMP, self.Qm, 3)
+        e("s_lshl_b64", self.TMP, self.Qm, 2 if self.mode == 0 else 3)
         e("s_sub_u32", self.NQ8.lo(), 0, self.TMP.lo())
         e("s_subb_u32", self.NQ8.hi(), 0, self.TMP.hi())
 
@@ -657,7 +678,7 @@ amdhsa.version: [1, 2]
 # ------------------------------------------------------------------------------------------
 # self test on the numpy emulator
 # ------------------------------------------------------------------------------------------
-def emulate(gen, inverse=False):
+def emulate(gen, inverse=False, q=None):
     """run one workgroup of the generated program on the numpy emulator; returns (bit-exact?, summary text)"""
     import numpy as np
 
@@ -668,7 +689,7 @@ def emulate(gen, inverse=False):
     pkg = graft.load_package()
     logn = gen.logn
     N = 1 << logn
-    q = pkg.params.Qi60()[-3]
+    q = q or pkg.params.Qi60()[-3]
     oc = oracle.Context(N, [q])
     x = pkg.sampling.random_u64((N,), seed=5)                 # full 64-bit inputs
     x[:4] = np.uint64(0xFFFFFFFFFFFFFFFF)
@@ -699,6 +720,7 @@ def emulate(gen, inverse=False):
     red_m = min((1 << (32 + g)) // qh, 0xFFFFFFFF)
     lp = np.zeros(8, dtype=np.uint64)
     lp[0] = q
+    lp[2] = (1 << 128) // q >> 64
     lp[5] = n_inv
     lp[6] = (n_inv << 64) // q
     lp[7] = red_m | (g << 32)
@@ -745,9 +767,33 @@ def emulate(gen, inverse=False):
     return ok, info
 
 
-def selftest(logn):
-    ok, info = emulate(Gen(logn))
-    print("logN=%d emulated workgroup: %s; %s" % (logn, "bit-exact vs oracle" if ok else "MISMATCH", info))
+def test_moduli(logn, mode):
+    """moduli at both ends of the range the mode accepts"""
+    sys.path.insert(0, __import__("os").path.join(__import__("os").path.dirname(__file__), "..", "..", ".."))
+    import __graft_entry__ as graft
+    params = graft.load_package().params
+    lo = params.GenerateNTTPrimes(34, logn, 1)[0]
+    if mode == 2:
+        return [lo, params.GenerateNTTPrimes(56, logn, 2)[1]]
+    if mode == 1:
+        return [params.Qi60()[-3], params.Qi60()[0], lo]
+    above = [p for p in params.GenerateNTTPrimes(60, logn, 4) if p > (1 << 60)]
+    return [above[-1], lo]
+
+
+def selftest(logn, inverse=False):
+    ok = True
+    for mode in ((0, 1) if inverse else (0, 1, 2)):
+        for q in test_moduli(logn, mode):
+            if inverse:
+                from gen_intt import GenInv
+                gen = GenInv(logn, mode)
+            else:
+                gen = Gen(logn, mode)
+            good, info = emulate(gen, inverse, q)
+            ok = ok and good
+            print("%s logN=%d mode %d q=%d (%d bits): %s; %s" % ("inverse" if inverse else "forward", logn, mode, q, q.bit_length(),
+                                                             "bit-exact vs oracle" if good else "MISMATCH", info), flush=True)
     return ok
 
 
@@ -755,5 +801,5 @@ if __name__ == "__main__":
     logn = int(sys.argv[1])
     if len(sys.argv) > 2 and sys.argv[2] == "--selftest":
         sys.exit(0 if selftest(logn) else 1)
-    text, _, _ = kernel_text(logn, "lr_ntt_fwd%d_asm" % logn)
-    open(sys.argv[2], "w").write(text)
+    mode = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+    open(sys.argv[2], "w").write(kernel_text_for(Gen(logn, mode), "lr_ntt_fwd%d_m%d" % (logn, mode)))

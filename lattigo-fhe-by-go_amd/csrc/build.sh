@@ -7,23 +7,31 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-ma
 mkdir -p build
 # hand-scheduled assembly kernels: generate -> assemble -> embed
 LLVM=${LLVM:-/opt/rocm/lib/llvm/bin}
+# forward: modes 0 (q < 2^61), 1 (q <= 2^60), 2 (q < 2^57); inverse: modes 0 and 1
+gen_one() {  # kind degree mode
+  python3 asmgen/gen_$( [ "$1" = fwd ] && echo ntt || echo intt ).py $2 build/ntt_$1$2_m$3.s $3
+  $LLVM/clang -x assembler -target amdgcn-amd-amdhsa -mcpu=gfx950 -c build/ntt_$1$2_m$3.s -o build/ntt_$1$2_m$3.o
+  $LLVM/ld.lld -shared build/ntt_$1$2_m$3.o -o build/ntt_$1$2_m$3.hsaco
+}
+gpids=()
 for n in 14 15; do
-  python3 asmgen/gen_ntt.py $n build/ntt_fwd$n.s
-  python3 asmgen/gen_intt.py $n build/ntt_inv$n.s
-  for k in fwd inv; do
-    $LLVM/clang -x assembler -target amdgcn-amd-amdhsa -mcpu=gfx950 -c build/ntt_$k$n.s -o build/ntt_$k$n.o
-    $LLVM/ld.lld -shared build/ntt_$k$n.o -o build/ntt_$k$n.hsaco
-  done
+  for m in 0 1 2; do gen_one fwd $n $m & gpids+=($!); done
+  for m in 0 1; do gen_one inv $n $m & gpids+=($!); done
 done
+for p in "${gpids[@]}"; do wait $p; done
 python3 - <<'PY'
-out = []
-for k in ("fwd", "inv"):
-    for n in (14, 15):
-        data = open("build/ntt_%s%d.hsaco" % (k, n), "rb").read()
-        out.append('extern "C" const unsigned char lr_hsaco_%s%d[] __attribute__((aligned(4096))) = {' % (k, n))
-        out.append(",".join(str(b) for b in data))
-        out.append("};")
-        out.append('extern "C" const unsigned long lr_hsaco_%s%d_size = %d;' % (k, n, len(data)))
+out = ['struct lr_asm_blob { const char *name; const unsigned char *data; unsigned long size; };']
+names = [("fwd", n, m) for n in (14, 15) for m in (0, 1, 2)] + [("inv", n, m) for n in (14, 15) for m in (0, 1)]
+for k, n, m in names:
+    data = open("build/ntt_%s%d_m%d.hsaco" % (k, n, m), "rb").read()
+    out.append('static const unsigned char blob_%s%d_m%d[] __attribute__((aligned(4096))) = {' % (k, n, m))
+    out.append(",".join(str(b) for b in data))
+    out.append("};")
+out.append('extern "C" const lr_asm_blob lr_asm_blobs[] = {')
+for k, n, m in names:
+    out.append('  {"lr_ntt_%s%d_m%d", blob_%s%d_m%d, sizeof(blob_%s%d_m%d)},' % (k, n, m, k, n, m, k, n, m))
+out.append("};")
+out.append('extern "C" const int lr_asm_blob_count = %d;' % len(names))
 open("build/lr_asm_blob.cpp", "w").write("\n".join(out) + "\n")
 PY
 pids=()

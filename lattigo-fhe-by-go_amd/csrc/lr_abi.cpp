@@ -88,6 +88,7 @@ struct lr_context {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int ntt_mode = 0;           // lazy-correction cadence allowed by the largest modulus (lr_ntt.hip)
     bool use_asm = true;        // hand-scheduled assembly NTT where it applies (LR_NO_ASM=1 disables)
+    int asm_fwd = -1, asm_inv = -1;   // variant of the assembly kernels all moduli allow, -1 = none
 };
 
 struct lr_poly {
@@ -237,6 +238,15 @@ extern "C" int lr_context_create(uint64_t N, const uint64_t *moduli, int n_modul
         }
         if (qmin >= (1ull << 32)) c->ntt_mode |= 256;
         c->use_asm = std::getenv("LR_NO_ASM") == nullptr;
+        if (qmin > (1ull << 33)) {                    // 32-bit Barrett constant of the assembly kernels
+            c->asm_fwd = qmax < (1ull << 57) ? 2 : qmax <= (1ull << 60) ? 1 : 0;
+            c->asm_inv = qmax <= (1ull << 60) ? 1 : 0;
+            if (const char *force = std::getenv("LR_ASM_VARIANT")) {   // testing aid: a more conservative variant
+                const int f = std::atoi(force);
+                if (f == 0 || (f == 1 && c->asm_fwd >= 1)) c->asm_fwd = f;
+                if (f == 0) c->asm_inv = 0;
+            }
+        }
     }
     LR_HIP(hipSetDevice(device));
     c->stream = shared_stream(device);
@@ -534,8 +544,9 @@ int run_ntt(lr_context *c, bool inverse, Rows in, Rows out, int mod0, int mod_st
     a.lp = c->d_lp;
     a.tw = inverse ? c->d_inv : c->d_fwd;
     a.tw_fin = inverse ? c->d_inv_fin : c->d_fwd_fin;
-    if ((c->ntt_mode & 255) == 1 && c->use_asm && batch <= 65535 && ntt_asm_available((int)logn)) {
-        LR_HIP(launch_ntt_asm(a, (int)logn, inverse, c->stream));
+    const int variant = inverse ? c->asm_inv : c->asm_fwd;
+    if (variant >= 0 && c->use_asm && batch <= 65535 && ntt_asm_available((int)logn)) {
+        LR_HIP(launch_ntt_asm(a, (int)logn, inverse, variant, c->stream));
         return LR_OK;
     }
     LR_HIP(launch_ntt(a, (int)logn, inverse, c->ntt_mode, c->stream));

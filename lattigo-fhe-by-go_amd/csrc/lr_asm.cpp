@@ -1,33 +1,33 @@
 // lr_asm.cpp -- loader/launcher of the hand-scheduled gfx950 assembly kernels (asmgen/gen_ntt.py).
 //
 // The code objects are generated and assembled at build time (build.sh) and embedded in this
-// library (lr_asm_blob.cpp).  They implement exactly the forward and inverse NTT of lr_ntt.hip in
-// lazy mode 1 (every modulus in [2^57, 2^60]) for N = 2^14 and 2^15; everything else stays on the
-// C++ kernels.
+// library (lr_asm_blob.cpp).  They implement exactly the forward and inverse NTT of lr_ntt.hip for
+// N = 2^14 and 2^15 and every modulus in (2^33, 2^61), in three lazy-correction variants; everything
+// else stays on the C++ kernels.
 #include <hip/hip_runtime.h>
 
+#include <cstdio>
 #include <map>
 #include <mutex>
+#include <string>
+#include <vector>
 
 #include "lr_device.hpp"
 
-extern "C" {
-extern const unsigned char lr_hsaco_fwd14[];
-extern const unsigned long lr_hsaco_fwd14_size;
-extern const unsigned char lr_hsaco_fwd15[];
-extern const unsigned long lr_hsaco_fwd15_size;
-extern const unsigned char lr_hsaco_inv14[];
-extern const unsigned long lr_hsaco_inv14_size;
-extern const unsigned char lr_hsaco_inv15[];
-extern const unsigned long lr_hsaco_inv15_size;
-}
+struct lr_asm_blob {
+    const char *name;
+    const unsigned char *data;
+    unsigned long size;
+};
+extern "C" const lr_asm_blob lr_asm_blobs[];
+extern "C" const int lr_asm_blob_count;
 
 namespace lr {
 
 namespace {
 struct AsmKernels {
-    hipModule_t mod[4] = {nullptr, nullptr, nullptr, nullptr};
-    hipFunction_t fn[4] = {nullptr, nullptr, nullptr, nullptr};   // fwd14, fwd15, inv14, inv15
+    std::map<std::string, hipFunction_t> fn;
+    std::vector<hipModule_t> mods;
     bool ok = false;
 };
 
@@ -39,24 +39,33 @@ AsmKernels *kernels_for_current_device() {
     std::lock_guard<std::mutex> lock(mu);
     auto it = table.find(dev);
     if (it != table.end()) return it->second.ok ? &it->second : nullptr;
-    AsmKernels k;
-    const void *image[4] = {lr_hsaco_fwd14, lr_hsaco_fwd15, lr_hsaco_inv14, lr_hsaco_inv15};
-    const char *name[4] = {"lr_ntt_fwd14_asm", "lr_ntt_fwd15_asm", "lr_ntt_inv14_asm", "lr_ntt_inv15_asm"};
+    AsmKernels &k = table[dev];
     k.ok = true;
-    for (int i = 0; i < 4 && k.ok; ++i)
-        k.ok = hipModuleLoadData(&k.mod[i], image[i]) == hipSuccess &&
-               hipModuleGetFunction(&k.fn[i], k.mod[i], name[i]) == hipSuccess;
+    for (int i = 0; i < lr_asm_blob_count && k.ok; ++i) {
+        hipModule_t mod = nullptr;
+        hipFunction_t fn = nullptr;
+        k.ok = hipModuleLoadData(&mod, lr_asm_blobs[i].data) == hipSuccess &&
+               hipModuleGetFunction(&fn, mod, lr_asm_blobs[i].name) == hipSuccess;
+        if (k.ok) {
+            k.mods.push_back(mod);
+            k.fn[lr_asm_blobs[i].name] = fn;
+        }
+    }
     if (!k.ok) (void)hipGetLastError();
-    table[dev] = k;
-    return k.ok ? &table[dev] : nullptr;
+    return k.ok ? &k : nullptr;
 }
 }  // namespace
 
 bool ntt_asm_available(int logn) { return (logn == 14 || logn == 15) && kernels_for_current_device() != nullptr; }
 
-hipError_t launch_ntt_asm(const NttLaunch &a, int logn, int inverse, hipStream_t stream) {
+// variant = lazy-correction mode of asmgen/gen_ntt.py (forward 0, 1, 2) / gen_intt.py (inverse 0, 1)
+hipError_t launch_ntt_asm(const NttLaunch &a, int logn, int inverse, int variant, hipStream_t stream) {
     AsmKernels *k = kernels_for_current_device();
     if (!k || (logn != 14 && logn != 15)) return hipErrorNotSupported;
+    char name[32];
+    std::snprintf(name, sizeof name, "lr_ntt_%s%d_m%d", inverse ? "inv" : "fwd", logn, variant);
+    auto it = k->fn.find(name);
+    if (it == k->fn.end()) return hipErrorNotSupported;
     if (a.n_items <= 0 || a.batch <= 0) return hipSuccess;
     if (a.batch > 65535) return hipErrorInvalidValue;
     NttLaunch args = a;
@@ -65,8 +74,7 @@ hipError_t launch_ntt_asm(const NttLaunch &a, int logn, int inverse, hipStream_t
     (void)hipGetLastError();
     // grid: x = limb of the launch, y = polynomial; blocks b and b+8 share an XCD, so the limbs an XCD
     // sees (and whose twiddles live in its L2) are x mod 8 when n_items is a multiple of 8
-    return hipModuleLaunchKernel(k->fn[(inverse ? 2 : 0) + (logn - 14)], (unsigned)a.n_items, (unsigned)a.batch, 1, 1024, 1, 1, 0, stream,
-                                 nullptr, extra);
+    return hipModuleLaunchKernel(it->second, (unsigned)a.n_items, (unsigned)a.batch, 1, 1024, 1, 1, 0, stream, nullptr, extra);
 }
 
 }  // namespace lr

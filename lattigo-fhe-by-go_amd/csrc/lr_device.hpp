@@ -143,7 +143,7 @@ struct ExtLaunch {
 hipError_t launch_ntt(const NttLaunch &a, int logn, bool inverse, int mode, hipStream_t stream);
 // hand-scheduled assembly forward NTT (lr_asm.cpp); N = 2^14 / 2^15, lazy mode 1 only
 bool ntt_asm_available(int logn);
-hipError_t launch_ntt_asm(const NttLaunch &a, int logn, int inverse, hipStream_t stream);
+hipError_t launch_ntt_asm(const NttLaunch &a, int logn, int inverse, int variant, hipStream_t stream);
 hipError_t launch_ewise(int op, const EwiseLaunch &L, int limbs, int batch, hipStream_t stream);
 hipError_t launch_submul(const SubMulLaunch &L, int limbs, int batch, hipStream_t stream);
 hipError_t launch_rowadd(const RowAddLaunch &L, int rows, int batch, hipStream_t stream);

@@ -184,59 +184,92 @@ def test_full_size_properties_r15(gpu_pkg):
     assert np.array_equal(px.get(), want)
 
 
-@pytest.mark.parametrize("logn,limbs", [(14, 3), (15, 2)])
-def test_cxx_and_asm_paths_agree(gpu_pkg, oracle, logn, limbs, monkeypatch):
-    """N = 2^14 / 2^15 with 60-bit moduli run on the hand-scheduled assembly kernel; LR_NO_ASM=1 selects the
-    C++ kernel.  Both must equal the oracle (full-range inputs)."""
+def _asm_moduli(pkg, kind, logn):
+    """modulus sets that select each variant of the assembly kernels (lr_abi.cpp: asm_fwd / asm_inv)"""
+    P = pkg.params
+    if kind == "qi60":                      # forward variant 1 (q <= 2^60), inverse variant 1
+        return list(P.Qi60()[-2:]) + [P.Qi60()[0]]
+    if kind == "ckks":                      # forward variant 2 (q < 2^57): CKKS-size moduli
+        return [P.GenerateNTTPrimes(50, logn, 1)[0], P.GenerateNTTPrimes(40, logn, 2)[1], P.GenerateNTTPrimes(56, logn, 2)[1]]
+    if kind == "bfv60":                     # GenerateNTTPrimes(60): primes just above 2^60 (bfv QiMul) -> variant 0
+        ps = P.GenerateNTTPrimes(60, logn, 3)
+        assert max(ps) > (1 << 60)
+        return ps
+    if kind == "mixed":                     # 35-bit next to 60-bit: variant 1 covers both
+        return [P.GenerateNTTPrimes(34, logn, 1)[0], P.Qi60()[-1]]
+    raise ValueError(kind)
+
+
+ASM_CASES = [("qi60", None), ("qi60", "0"), ("ckks", None), ("ckks", "1"), ("ckks", "0"), ("bfv60", None), ("mixed", None)]
+
+
+@pytest.mark.parametrize("kind,force", ASM_CASES)
+@pytest.mark.parametrize("logn", [14, 15])
+def test_cxx_and_asm_paths_agree(gpu_pkg, oracle, logn, kind, force, monkeypatch):
+    """N = 2^14 / 2^15 with moduli above 2^33 run on the hand-scheduled assembly kernels (three lazy-correction
+    variants, chosen from the largest modulus; LR_ASM_VARIANT forces a more conservative one); LR_NO_ASM=1 selects
+    the C++ kernel.  All must equal the oracle (full-range inputs)."""
     N = 1 << logn
-    moduli = list(gpu_pkg.params.Qi60()[-limbs:])
+    moduli = _asm_moduli(gpu_pkg, kind, logn)
+    limbs = len(moduli)
     oc = oracle.Context(N, moduli)
-    x = gpu_pkg.sampling.random_u64((3, limbs, N), seed=77)
-    want = [oc.ntt(np.array([[int(v) % q for v in x[b, i]] for i, q in enumerate(moduli)], dtype=np.uint64)) for b in range(3)]
+    x = gpu_pkg.sampling.random_u64((2, limbs, N), seed=77)
+    x[0, :, :5] = np.uint64(0xFFFFFFFFFFFFFFFF)
+    want = [oc.ntt(np.array([[int(v) % q for v in x[b, i]] for i, q in enumerate(moduli)], dtype=np.uint64)) for b in range(2)]
+    if force is not None:
+        monkeypatch.setenv("LR_ASM_VARIANT", force)
+    else:
+        monkeypatch.delenv("LR_ASM_VARIANT", raising=False)
     for no_asm in (False, True):
         if no_asm:
             monkeypatch.setenv("LR_NO_ASM", "1")
         else:
             monkeypatch.delenv("LR_NO_ASM", raising=False)
         ctx = gpu_pkg.ring.NewContextWithParams(N, moduli)
-        p, r = ctx.NewPoly(3).set(x), ctx.NewPoly(3)
+        p, r = ctx.NewPoly(2).set(x), ctx.NewPoly(2)
         ctx.NTT(p, r)
         got = r.get()
-        for b in range(3):
+        for b in range(2):
             assert np.array_equal(got[b], want[b]), (no_asm, b)
         ctx.NTT(p, p)      # in place
         assert np.array_equal(p.get(), got)
 
 
-@pytest.mark.parametrize("logn,limbs", [(14, 3), (15, 2)])
-def test_cxx_and_asm_inverse_paths_agree(gpu_pkg, oracle, logn, limbs, monkeypatch):
+@pytest.mark.parametrize("kind,force", ASM_CASES)
+@pytest.mark.parametrize("logn", [14, 15])
+def test_cxx_and_asm_inverse_paths_agree(gpu_pkg, oracle, logn, kind, force, monkeypatch):
     """inverse twin of the test above: the assembly InvNTT (last stage fused with the N^-1 scaling) and the C++
     kernel both equal the oracle, on inputs anywhere in the documented lazy range [0, 4q), out of place and in place"""
     N = 1 << logn
-    moduli = list(gpu_pkg.params.Qi60()[-limbs:])
+    moduli = _asm_moduli(gpu_pkg, kind, logn)
+    limbs = len(moduli)
     oc = oracle.Context(N, moduli)
-    x = gpu_pkg.sampling.random_u64((3, limbs, N), seed=78)
+    x = gpu_pkg.sampling.random_u64((2, limbs, N), seed=78)
     for i, q in enumerate(moduli):
         x[:, i] %= np.uint64(4 * q)
         x[0, i, :3] = np.uint64(4 * q - 1)
         x[1, i, -3:] = 0
-    want = [oc.intt(np.array([[int(v) % q for v in x[b, i]] for i, q in enumerate(moduli)], dtype=np.uint64)) for b in range(3)]
+    want = [oc.intt(np.array([[int(v) % q for v in x[b, i]] for i, q in enumerate(moduli)], dtype=np.uint64)) for b in range(2)]
+    if force is not None:
+        monkeypatch.setenv("LR_ASM_VARIANT", force)
+    else:
+        monkeypatch.delenv("LR_ASM_VARIANT", raising=False)
     for no_asm in (False, True):
         if no_asm:
             monkeypatch.setenv("LR_NO_ASM", "1")
         else:
             monkeypatch.delenv("LR_NO_ASM", raising=False)
         ctx = gpu_pkg.ring.NewContextWithParams(N, moduli)
-        p, r = ctx.NewPoly(3).set(x), ctx.NewPoly(3)
+        p, r = ctx.NewPoly(2).set(x), ctx.NewPoly(2)
         ctx.InvNTT(p, r)
         got = r.get()
-        for b in range(3):
+        for b in range(2):
             assert np.array_equal(got[b], want[b]), (no_asm, b)
         ctx.InvNTT(p, p)
         assert np.array_equal(p.get(), got)
         # round trip through both assembly kernels
         ctx.NTT(p, p)
-        assert np.array_equal(p.get(), np.stack([[x[b, i] % np.uint64(q) for i, q in enumerate(moduli)] for b in range(3)]))
+        assert np.array_equal(p.get(), np.stack([[x[b, i] % np.uint64(q) for i, q in enumerate(moduli)] for b in range(2)]))
 
 
 def test_cpp_host_mirror_runs_reference_ntt_test():
