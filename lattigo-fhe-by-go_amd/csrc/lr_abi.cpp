@@ -110,6 +110,8 @@ struct DevModup {
     HostModup h;
     u64 *Q = nullptr, *mredQ = nullptr, *qib = nullptr, *P = nullptr, *mredP = nullptr, *bredP_hi = nullptr,
         *qispj = nullptr, *qpj_inv = nullptr;
+    ulonglong2 *qispj_shoup = nullptr;
+    int lazy_terms = 0, exact_terms = 0;
     int init(const std::vector<u64> &Qv, const std::vector<u64> &Pv) {
         h = build_modup(Qv, Pv);
         std::vector<u64> bh(h.P.size());
@@ -122,6 +124,19 @@ struct DevModup {
         LR_TRY(to_device(&bredP_hi, bh.data(), bh.size()));
         LR_TRY(to_device(&qispj, h.qispj_mont.data(), h.qispj_mont.size()));
         LR_TRY(to_device(&qpj_inv, h.qpj_inv.data(), h.qpj_inv.size()));
+        const size_t nQ = h.Q.size(), nP = h.P.size();
+        std::vector<ulonglong2> sh(nQ * nP);
+        u64 pmax = 0;
+        for (size_t j = 0; j < nP; ++j) pmax = h.P[j] > pmax ? h.P[j] : pmax;
+        for (size_t i = 0; i < nQ; ++i)
+            for (size_t j = 0; j < nP; ++j) {
+                const u64 plain = inv_mform(h.qispj_mont[i * nP + j], h.P[j], h.mredP[j]);
+                sh[i * nP + j] = make_ulonglong2(plain, shoup_companion(plain, h.P[j]));
+            }
+        LR_TRY(to_device(&qispj_shoup, sh.data(), sh.size()));
+        const u128 room = ((u128)1 << 64) - pmax;
+        lazy_terms = (int)std::min<u128>(room / ((u128)4 * pmax), 1 << 20);
+        exact_terms = (int)std::min<u128>(room / ((u128)2 * pmax), 1 << 20);
         return LR_OK;
     }
     ExtTables tables() const {
@@ -130,11 +145,15 @@ struct DevModup {
         t.nP = (int)h.P.size();
         t.Q = Q; t.mredQ = mredQ; t.qib_mont = qib; t.P = P; t.mredP = mredP; t.bredP_hi = bredP_hi;
         t.qispj_mont = qispj; t.qpj_inv = qpj_inv;
+        t.qispj_shoup = qispj_shoup;
+        t.lazy_terms = lazy_terms;
+        t.exact_terms = exact_terms;
         return t;
     }
     ~DevModup() {
         for (u64 *p : {Q, mredQ, qib, P, mredP, bredP_hi, qispj, qpj_inv})
             if (p) (void)hipFree(p);
+        if (qispj_shoup) (void)hipFree(qispj_shoup);
     }
 };
 
@@ -186,7 +205,7 @@ struct lr_ckks_plan {
     lr_bext *bext = nullptr;
     lr_decomposer *dec = nullptr;
     int max_batch = 0;
-    Pool c2QiQ, c2QiP, pool2P, pool3P, c2, c00, c01, c0, c1, c2x, q1, q2;
+    Pool c2QiQ, c2QiP, pool2P, pool3P, c2, c0, c1, c2x, q1, q2;
 };
 
 // ------------------------------------------------------------------------------------------
@@ -773,8 +792,10 @@ ExtSegment segment(u64 *out, long long stride, int limb0, int col0, int count) {
 
 int run_submul(lr_context *c, int limbs, int batch, const u64 *a, long long a_stride, const u64 *b, long long b_stride,
                long long b_row_stride, u64 *out, long long out_stride, const u64 *d_consts, bool reduce_b,
-               const LimbScalars *addend) {
+               const LimbScalars *addend, const u64 *plus = nullptr, long long plus_stride = 0) {
     SubMulLaunch L;
+    L.plus = plus;
+    L.plus_stride = plus_stride;
     L.a = a;
     L.b = b;
     L.out = out;
@@ -1209,8 +1230,17 @@ extern "C" int lr_ckks_plan_destroy(lr_ckks_plan *p) {
 namespace {
 
 // switchKeysInPlace, ckks/evaluator.go:1475-1558, on raw buffers: cx/p0/p1 have `q_stride` between batch polys
+// `fin` (optional): the ModDown results go to fin->out0/out1 with fin->plus0/plus1 added (CRed), i.e. the two
+// Context.Add calls that follow the key switch in MulRelin (:1103-1104) ride on the last ModDown pass
+struct KeySwitchEpilogue {
+    u64 *out0, *out1;
+    long long out_stride;
+    const u64 *plus0, *plus1;
+    long long plus_stride;
+};
+
 int switch_keys_core(lr_ckks_plan *pl, int level, int batch, const u64 *cx, long long cx_stride, const lr_poly *evk, u64 *p0,
-                     long long p0_stride, u64 *p1, long long p1_stride) {
+                     long long p0_stride, u64 *p1, long long p1_stride, const KeySwitchEpilogue *fin = nullptr) {
     lr_context *cQ = pl->cQ, *cP = pl->cP;
     lr_decomposer *dec = pl->dec;
     const int nQ = cQ->h.L(), nP = cP->h.L(), n = (int)cQ->h.N;
@@ -1286,7 +1316,11 @@ int switch_keys_core(lr_ckks_plan *pl, int level, int batch, const u64 *cx, long
         LR_TRY(run_ext(cQ, bx->pq, nP, pr, batch, segment(bx->poolQ.d, sQ, 0, 0, level + 1), segment(nullptr, 0, 0, 0, 0)));
         Rows qr{bx->poolQ.d, sQ, 0, 1};
         LR_TRY(run_ntt(cQ, false, qr, qr, 0, 1, level + 1, batch));
-        LR_TRY(run_submul(cQ, level + 1, batch, pq, pqs, bx->poolQ.d, sQ, (long long)n, pq, pqs, bx->d_moddown_pq, false, nullptr));
+        if (fin)
+            LR_TRY(run_submul(cQ, level + 1, batch, pq, pqs, bx->poolQ.d, sQ, (long long)n, k == 0 ? fin->out0 : fin->out1,
+                              fin->out_stride, bx->d_moddown_pq, false, nullptr, k == 0 ? fin->plus0 : fin->plus1, fin->plus_stride));
+        else
+            LR_TRY(run_submul(cQ, level + 1, batch, pq, pqs, bx->poolQ.d, sQ, (long long)n, pq, pqs, bx->d_moddown_pq, false, nullptr));
     }
     return LR_OK;
 }
@@ -1324,17 +1358,22 @@ extern "C" int lr_ckks_mulrelin(lr_ckks_plan *pl, int level, const lr_poly *a0, 
     LR_HIP(hipSetDevice(cQ->device));
     const int n = (int)cQ->h.N, L1 = level + 1;
     const long long s = (long long)L1 * n;
-    for (Pool *p : {&pl->c00, &pl->c01, &pl->c0, &pl->c1, &pl->c2x, &pl->q1, &pl->q2}) LR_TRY(p->ensure(cQ, (size_t)batch * s));
-    // ckks/evaluator.go:1080-1095
-    LR_TRY(run_ewise(cQ, LR_MFORM, L1, batch, a0->d, a0->stride(), nullptr, 0, pl->c00.d, s, nullptr));
-    LR_TRY(run_ewise(cQ, LR_MFORM, L1, batch, a1->d, a1->stride(), nullptr, 0, pl->c01.d, s, nullptr));
-    LR_TRY(run_ewise(cQ, LR_MUL_MONT, L1, batch, pl->c00.d, s, b0->d, b0->stride(), pl->c0.d, s, nullptr));
-    LR_TRY(run_ewise(cQ, LR_MUL_MONT, L1, batch, pl->c00.d, s, b1->d, b1->stride(), pl->c1.d, s, nullptr));
-    LR_TRY(run_ewise(cQ, LR_MUL_MONT_AND_ADD, L1, batch, pl->c01.d, s, b0->d, b0->stride(), pl->c1.d, s, nullptr));
-    LR_TRY(run_ewise(cQ, LR_MUL_MONT, L1, batch, pl->c01.d, s, b1->d, b1->stride(), pl->c2x.d, s, nullptr));
-    LR_TRY(switch_keys_core(pl, level, batch, pl->c2x.d, s, evk, pl->q1.d, s, pl->q2.d, s));          // :1101
-    LR_TRY(run_ewise(cQ, LR_ADD, L1, batch, pl->c0.d, s, pl->q1.d, s, o0->d, o0->stride(), nullptr));  // :1103
-    LR_TRY(run_ewise(cQ, LR_ADD, L1, batch, pl->c1.d, s, pl->q2.d, s, o1->d, o1->stride(), nullptr));  // :1104
+    for (Pool *p : {&pl->c0, &pl->c1, &pl->c2x, &pl->q1, &pl->q2}) LR_TRY(p->ensure(cQ, (size_t)batch * s));
+    // ckks/evaluator.go:1080-1095: MForm x2, MulCoeffsMontgomery x3, MulCoeffsMontgomeryAndAdd, one pass
+    if (o0->stride() != o1->stride()) return fail(LR_ERR_SHAPE, "output polys must share their stride");
+    {
+        TensorLaunch T;
+        T.a0 = a0->d; T.a1 = a1->d; T.b0 = b0->d; T.b1 = b1->d;
+        T.a0_stride = a0->stride(); T.a1_stride = a1->stride(); T.b0_stride = b0->stride(); T.b1_stride = b1->stride();
+        T.c0 = pl->c0.d; T.c1 = pl->c1.d; T.c2 = pl->c2x.d;
+        T.c_stride = s;
+        T.n = n;
+        T.lp = cQ->d_lp;
+        LR_HIP(launch_tensor(T, L1, batch, cQ->stream));
+    }
+    // :1101 key switch of the degree-2 part, :1103-1104 the two additions fused into its last pass
+    KeySwitchEpilogue fin{o0->d, o1->d, o0->stride(), pl->c0.d, pl->c1.d, s};
+    LR_TRY(switch_keys_core(pl, level, batch, pl->c2x.d, s, evk, pl->q1.d, s, pl->q2.d, s, &fin));
     return LR_OK;
 }
 

@@ -48,10 +48,85 @@ __global__ __launch_bounds__(256) void ext_kernel(ExtLaunch L) {
     }
 }
 
+// Same result through Shoup-form constants: every output is the canonical residue of
+// sum_i y_i * (Q/q_i) + qpjInv[v] (mod p_j), which does not depend on how the sum is carried, so the terms are
+// taken lazily ([0,4p) with 9 multiplies, or [0,2p) when the moduli leave less room) and Barrett-reduced only
+// when `chunk` of them have accumulated -- for moduli below 2^57 never before the final BRedAdd.  Two
+// coefficients per thread: 16-byte accesses and two independent dependency chains.
+// EVERY = 0: lazy [0,4p) terms, no intermediate reduction (host guarantees 4p * NIN + p < 2^64);
+// EVERY = 3 / 7: [0,2p) terms, BRedAdd after every 3rd (any p < 2^61) / 7th (p <= 2^60) term.
+template <int NIN, int EVERY, int W>
+__global__ __launch_bounds__(256) void ext_shoup_kernel(ExtLaunch L) {
+    constexpr bool EXACT = EVERY != 0;
+    const int xw = blockIdx.x * 256 + threadIdx.x;
+    if (W * xw >= L.n) return;
+    const long long b = blockIdx.y;
+    const u64 *in = L.in + b * L.in_stride + (long long)L.in_limb0 * L.n + W * xw;
+    u64 y[W][NIN];
+    double vf[W];
+#pragma unroll
+    for (int w = 0; w < W; ++w) vf[w] = 0.0;
+#pragma unroll
+    for (int i = 0; i < NIN; ++i) {
+        const u64 qi = L.t.Q[i];
+        u64 v[W];
+        if (W == 2) {
+            const ulonglong2 t = *reinterpret_cast<const ulonglong2 *>(in + (long long)i * L.n);
+            v[0] = t.x;
+            v[W - 1] = t.y;
+        } else {
+            v[0] = in[(long long)i * L.n];
+        }
+#pragma unroll
+        for (int w = 0; w < W; ++w) {
+            y[w][i] = mred(v[w], L.t.qib_mont[i], qi, L.t.mredQ[i]);
+            vf[w] += (double)y[w][i] / (double)qi;
+        }
+    }
+    u64 vi[W];
+#pragma unroll
+    for (int w = 0; w < W; ++w) vi[w] = (u64)vf[w];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const ExtSegment sg = L.seg[s];
+        u64 *out = sg.out + b * sg.stride + (long long)sg.limb0 * L.n + W * xw;
+        for (int jj = 0; jj < sg.count; ++jj) {
+            const int col = sg.col0 + jj;
+            const u64 pj = L.t.P[col], bh = L.t.bredP_hi[col];
+            u64 acc[W];
+#pragma unroll
+            for (int w = 0; w < W; ++w) acc[w] = 0;
+#pragma unroll
+            for (int i = 0; i < NIN; ++i) {
+                const ulonglong2 c = L.t.qispj_shoup[(long long)i * L.t.nP + col];
+#pragma unroll
+                for (int w = 0; w < W; ++w) {
+                    acc[w] += EXACT ? mul_shoup_exact(y[w][i], c.x, c.y, pj) : mul_shoup_lazy(y[w][i], c.x, c.y, pj);
+                    if (EXACT && (i % (EXACT ? EVERY : 1)) == EVERY - 1 && i + 1 < NIN) acc[w] = bred_add(acc[w], pj, bh);
+                }
+            }
+            const u64 *corr = L.t.qpj_inv + (long long)col * (L.t.nQ + 1);
+#pragma unroll
+            for (int w = 0; w < W; ++w) acc[w] = bred_add(acc[w] + corr[vi[w]], pj, bh);
+            if (W == 2) *reinterpret_cast<ulonglong2 *>(out + (long long)jj * L.n) = make_ulonglong2(acc[0], acc[W - 1]);
+            else out[(long long)jj * L.n] = acc[0];
+        }
+    }
+}
+
 template <int NIN>
 static hipError_t launch_n(const ExtLaunch &L, int batch, hipStream_t stream) {
-    const dim3 grid((unsigned)((L.n + 255) / 256), (unsigned)batch), block(256);
     (void)hipGetLastError();  // drop stale (non-sticky) errors of unrelated earlier calls
+    if ((L.n & 1) == 0 && L.t.exact_terms >= 4) {   // exact_terms >= 4 <=> every p < 2^61
+        // two coefficients per thread while their y_i fit comfortably in registers
+        constexpr int W = NIN <= 20 ? 2 : 1;
+        const dim3 grid((unsigned)((L.n / W + 255) / 256), (unsigned)batch), block(256);
+        if (L.t.lazy_terms >= NIN) hipLaunchKernelGGL((ext_shoup_kernel<NIN, 0, W>), grid, block, 0, stream, L);
+        else if (L.t.exact_terms >= 8) hipLaunchKernelGGL((ext_shoup_kernel<NIN, 7, W>), grid, block, 0, stream, L);
+        else hipLaunchKernelGGL((ext_shoup_kernel<NIN, 3, W>), grid, block, 0, stream, L);
+        return hipGetLastError();
+    }
+    const dim3 grid((unsigned)((L.n + 255) / 256), (unsigned)batch), block(256);
     hipLaunchKernelGGL(ext_kernel<NIN>, grid, block, 0, stream, L);
     return hipGetLastError();
 }

@@ -71,7 +71,20 @@ struct SubMulLaunch {
     const u64 *consts;  // device [limbs], Montgomery form
     int reduce_b;       // 1: b is first reduced with BRedAdd (coefficient-domain rescale, ring_scaling.go:50,146)
     LimbScalars addend; // b + addend[limb] before the reduction (pHalfNegQi); zeros when unused
+    const u64 *plus;    // optional: out = CRed(plus + result) (the Context.Add that follows a ModDown in ckks MulRelin)
+    long long plus_stride;
 };
+
+// degree-2 tensor product of two degree-1 ciphertexts (ckks/evaluator.go:1080-1095) in one pass
+struct TensorLaunch {
+    const u64 *a0, *a1, *b0, *b1;
+    long long a0_stride, a1_stride, b0_stride, b1_stride;
+    u64 *c0, *c1, *c2;
+    long long c_stride;
+    int n;
+    const LimbParams *lp;
+};
+hipError_t launch_tensor(const TensorLaunch &L, int limbs, int batch, hipStream_t stream);
 
 // out_row[r] = in + adds[r] (optionally CRed)
 struct RowAddLaunch {
@@ -121,6 +134,11 @@ struct ExtTables {        // device pointers; modupParams of ring_basis_extensio
     const u64 *bredP_hi;  // [nP]
     const u64 *qispj_mont;// [nQ][nP]
     const u64 *qpj_inv;   // [nP][nQ+1]
+    // the same (Q/q_i) mod p_j out of Montgomery form, with the Shoup companion floor(c * 2^64 / p_j): the
+    // products y_i * c accumulate lazily and are reduced once, to the same canonical residue
+    const ulonglong2 *qispj_shoup;  // [nQ][nP] {c, companion}
+    int lazy_terms;       // how many [0,4p) terms plus one canonical value fit in 64 bits for the largest p
+    int exact_terms;      // the same for [0,2p) terms
 };
 
 struct ExtSegment {       // rows [limb0, limb0+count) of `out` receive table columns [col0, col0+count)

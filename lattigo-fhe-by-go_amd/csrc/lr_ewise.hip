@@ -140,8 +140,64 @@ __global__ __launch_bounds__(256) void submul_kernel(SubMulLaunch L) {
             y.x = bred_add(y.x + add, lp.q, lp.bred_hi);
             y.y = bred_add(y.y + add, lp.q, lp.bred_hi);
         }
-        po[e] = make_ulonglong2(mred(x.x + (lp.q - y.x), c, lp.q, lp.qinv), mred(x.y + (lp.q - y.y), c, lp.q, lp.qinv));
+        ulonglong2 r = make_ulonglong2(mred(x.x + (lp.q - y.x), c, lp.q, lp.qinv), mred(x.y + (lp.q - y.y), c, lp.q, lp.qinv));
+        if (L.plus) {
+            const ulonglong2 p = reinterpret_cast<const ulonglong2 *>(L.plus + b * L.plus_stride + row)[e];
+            r.x = cred(p.x + r.x, lp.q);
+            r.y = cred(p.y + r.y, lp.q);
+        }
+        po[e] = r;
     }
+}
+
+// c0 = MRed(MForm(a0), b0), c1 = MRed(MForm(a0), b1) (+)= MRed(MForm(a1), b0), c2 = MRed(MForm(a1), b1):
+// the six Context calls of ckks/evaluator.go:1080-1095 with the two Montgomery-form temporaries kept in
+// registers (56 B per coefficient instead of 128).
+__global__ __launch_bounds__(256) void tensor_kernel(TensorLaunch L) {
+    const int limb = blockIdx.y;
+    const long long b = blockIdx.z;
+    const LimbParams lp = L.lp[limb];
+    const u64 q = lp.q;
+    const long long row = (long long)limb * L.n;
+    const ulonglong2 *pa0 = reinterpret_cast<const ulonglong2 *>(L.a0 + b * L.a0_stride + row);
+    const ulonglong2 *pa1 = reinterpret_cast<const ulonglong2 *>(L.a1 + b * L.a1_stride + row);
+    const ulonglong2 *pb0 = reinterpret_cast<const ulonglong2 *>(L.b0 + b * L.b0_stride + row);
+    const ulonglong2 *pb1 = reinterpret_cast<const ulonglong2 *>(L.b1 + b * L.b1_stride + row);
+    ulonglong2 *pc0 = reinterpret_cast<ulonglong2 *>(L.c0 + b * L.c_stride + row);
+    ulonglong2 *pc1 = reinterpret_cast<ulonglong2 *>(L.c1 + b * L.c_stride + row);
+    ulonglong2 *pc2 = reinterpret_cast<ulonglong2 *>(L.c2 + b * L.c_stride + row);
+    const int pairs = L.n >> 1;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < pairs; e += gridDim.x * 256) {
+        const ulonglong2 a0 = pa0[e], a1 = pa1[e], b0 = pb0[e], b1 = pb1[e];
+        ulonglong2 c0, c1, c2;
+        {
+            const u64 m0 = mform(a0.x, q, lp.bred_hi, lp.bred_lo), m1 = mform(a1.x, q, lp.bred_hi, lp.bred_lo);
+            c0.x = mred(m0, b0.x, q, lp.qinv);
+            c1.x = cred(mred(m0, b1.x, q, lp.qinv) + mred(m1, b0.x, q, lp.qinv), q);
+            c2.x = mred(m1, b1.x, q, lp.qinv);
+        }
+        {
+            const u64 m0 = mform(a0.y, q, lp.bred_hi, lp.bred_lo), m1 = mform(a1.y, q, lp.bred_hi, lp.bred_lo);
+            c0.y = mred(m0, b0.y, q, lp.qinv);
+            c1.y = cred(mred(m0, b1.y, q, lp.qinv) + mred(m1, b0.y, q, lp.qinv), q);
+            c2.y = mred(m1, b1.y, q, lp.qinv);
+        }
+        pc0[e] = c0;
+        pc1[e] = c1;
+        pc2[e] = c2;
+    }
+}
+
+hipError_t launch_tensor(const TensorLaunch &L, int limbs, int batch, hipStream_t stream) {
+    if (limbs <= 0 || batch <= 0) return hipSuccess;
+    const int pairs = L.n >> 1;
+    int gx = (pairs + 255) / 256;
+    if (gx > 64) gx = 64;
+    if (gx < 1) gx = 1;
+    const dim3 grid((unsigned)gx, (unsigned)limbs, (unsigned)batch), block(256);
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(tensor_kernel, grid, block, 0, stream, L);
+    return hipGetLastError();
 }
 
 hipError_t launch_submul(const SubMulLaunch &L, int limbs, int batch, hipStream_t stream) {
