@@ -66,7 +66,7 @@ class Gen:
         assert self.vgpr_count <= 128
         # ---- SGPR map
         self.KARG = s(0, 2)
-        self.WGX, self.WGY = s(2), s(3)
+        self.WGX, self.WGY, self.WGZ = s(2), s(3), s(4)   # WGZ is consumed before SRC (s[4:5]) is formed
         self.SRC, self.DST = s(4, 2), s(6, 2)
         self.TW, self.TWF, self.TWFR = s(8, 2), s(10, 2), s(12, 2)
         self.Qm, self.NQ, self.Q4, self.NQ8 = s(14, 2), s(16, 2), s(18, 2), s(20, 2)   # NQ8: -8q (mode 1) or -4q (mode 0)
@@ -212,11 +212,12 @@ class Gen:
     def prologue(self):
         e, S_ = self.e, self
         logn, N = self.logn, self.N
-        self.c("kernel arguments (NttLaunch, 96 bytes; the first 88 are used)")
+        self.c("kernel arguments (NttLaunch, 104 bytes)")
         e("s_load_dwordx8", s(36, 8), self.KARG, 0)
         e("s_load_dwordx8", s(44, 8), self.KARG, 32)
         e("s_load_dwordx4", s(52, 4), self.KARG, 64)
         e("s_load_dwordx2", s(56, 2), self.KARG, 80)
+        e("s_load_dwordx4", s(60, 4), self.KARG, 88)      # sub_log (must be 0 here), hole, group, pad
         e("v_mov_b32", self.TID, v(0))
         for ts in self.ts:
             e("v_mov_b32", ts.Z1, 0)
@@ -228,6 +229,14 @@ class Gen:
         e("s_lshr_b32", self.WAVE, self.WAVE, 6)
         e("s_waitcnt", "lgkmcnt(0)")
         sc = self.SC
+        # grid z = group of polys (key-switch digit): poly = z * group + y, and the limbs [z*hole, (z+1)*hole)
+        # of that group are skipped: item = x + (x >= z*hole ? hole : 0).  hole = 0 / z = 0 for plain launches.
+        e("s_mul_i32", sc[0], self.WGZ, s(61))
+        e("s_cmp_ge_u32", self.WGX, sc[0])
+        e("s_cselect_b32", sc[1], s(61), 0)
+        e("s_add_u32", self.WGX, self.WGX, sc[1])
+        e("s_mul_i32", sc[0], self.WGZ, s(62))
+        e("s_add_u32", self.WGY, self.WGY, sc[0])
         e("s_mul_i32", sc[0], self.WGX, s(49))
         e("s_add_u32", sc[0], sc[0], s(48))          # modulus index
         e("s_mul_i32", sc[1], self.WGX, s(45))
@@ -632,12 +641,12 @@ def kernel_text_for(g, name):
   .amdhsa_kernel {name}
     .amdhsa_group_segment_fixed_size {lds}
     .amdhsa_private_segment_fixed_size 0
-    .amdhsa_kernarg_size 96
+    .amdhsa_kernarg_size 104
     .amdhsa_user_sgpr_count 2
     .amdhsa_user_sgpr_kernarg_segment_ptr 1
     .amdhsa_system_sgpr_workgroup_id_x 1
     .amdhsa_system_sgpr_workgroup_id_y 1
-    .amdhsa_system_sgpr_workgroup_id_z 0
+    .amdhsa_system_sgpr_workgroup_id_z 1
     .amdhsa_system_vgpr_workitem_id 0
     .amdhsa_next_free_vgpr {vgpr}
     .amdhsa_next_free_sgpr 100
@@ -655,11 +664,11 @@ def kernel_text_for(g, name):
 amdhsa.kernels:
   - .args:
       - .offset: 0
-        .size: 96
+        .size: 104
         .value_kind: by_value
     .group_segment_fixed_size: {lds}
     .kernarg_segment_align: 8
-    .kernarg_segment_size: 96
+    .kernarg_segment_size: 104
     .max_flat_workgroup_size: 1024
     .name: {name}
     .private_segment_fixed_size: 0
@@ -678,7 +687,8 @@ amdhsa.version: [1, 2]
 # ------------------------------------------------------------------------------------------
 # self test on the numpy emulator
 # ------------------------------------------------------------------------------------------
-def emulate(gen, inverse=False, q=None):
+def emulate(gen, inverse=False, q=None, geom=None):
+    # geom = (x, y, z, hole, group, rows per poly): workgroup ids and the digit-group arguments of NttLaunch
     """run one workgroup of the generated program on the numpy emulator; returns (bit-exact?, summary text)"""
     import numpy as np
 
@@ -730,17 +740,27 @@ def emulate(gen, inverse=False, q=None):
         words = np.ascontiguousarray(arr).view(np.uint32).ravel()
         mem[addr // 4: addr // 4 + words.size] = words
 
-    A_IN, A_OUT, A_LP, A_TW, A_TWF, A_KARG = 0x1000, 0x1000 + 8 * N, 0x100000 * 2, 0x300000, 0x300000 + 16 * N + 0x1000, 0x800
+    gx, gy, gz, hole, group, rows = geom or (0, 0, 0, 0, 0, 1)
+    item = gx + (hole if gx >= gz * hole else 0)
+    where = ((gz * group + gy) * rows + item) * 8 * N          # byte offset of the addressed row
+    span = ((gz * group + gy + 1) * rows + 1) * 8 * N
+    A_KARG, A_IN = 0x800, 0x1000
+    A_OUT = A_IN + span
+    A_LP = A_OUT + span
+    A_TW = A_LP + 0x1000
+    A_TWF = A_TW + 16 * N + 0x1000
     mem = np.zeros((A_TWF + 16 * 15 * blocks + 0x1000) // 4, dtype=np.uint32)
-    place(x, A_IN)
+    place(x, A_IN + where)
     place(lp, A_LP)
     place(tw, A_TW)
     place(twf, A_TWF)
-    karg = np.zeros(11, dtype=np.uint64)
-    karg[0], karg[1], karg[2], karg[3] = A_IN, A_OUT, N, N
+    karg = np.zeros(13, dtype=np.uint64)
+    karg[0], karg[1], karg[2], karg[3] = A_IN, A_OUT, rows * N, rows * N
     karg[4] = 0 | (1 << 32)        # in_limb0, in_limb_step
     karg[5] = 0 | (1 << 32)        # out_limb0, out_limb_step
-    karg[6] = 0 | (1 << 32)        # mod0, mod_step
+    karg[6] = 0 | (0 << 32)        # mod0, mod_step: one modulus serves every row of this harness
+    karg[11] = 0 | (hole << 32)    # sub_log, hole
+    karg[12] = group               # group, pad
     karg[7] = 1 | (1 << 32)        # n_items, batch
     karg[8], karg[9], karg[10] = A_LP, A_TW, A_TWF
     place(karg, A_KARG)
@@ -751,10 +771,10 @@ def emulate(gen, inverse=False, q=None):
     m.vgpr[0] = np.arange(T, dtype=np.uint32)
     m.vdef[0] = True
     m.sgpr[0], m.sgpr[1] = A_KARG, 0
-    m.sgpr[2], m.sgpr[3] = 0, 0
-    m.sdef[0:4] = True
+    m.sgpr[2], m.sgpr[3], m.sgpr[4] = gx, gy, gz
+    m.sdef[0:5] = True
     m.run(prog)
-    got = m.mem[A_OUT // 4: A_OUT // 4 + 2 * N].view(np.uint64)
+    got = m.mem[(A_OUT + where) // 4: (A_OUT + where) // 4 + 2 * N].view(np.uint64)
     ok = np.array_equal(got, want)
     cnt = prog.count()
     valu = sum(n for op, n in cnt.items() if op.startswith("v_"))
@@ -790,7 +810,9 @@ def selftest(logn, inverse=False):
                 gen = GenInv(logn, mode)
             else:
                 gen = Gen(logn, mode)
-            good, info = emulate(gen, inverse, q)
+            # the last modulus of each mode also exercises the digit-group addressing (grid z, skipped limbs)
+            geom = (2, 1, 1, 2, 3, 6) if q == test_moduli(logn, mode)[-1] else None
+            good, info = emulate(gen, inverse, q, geom)
             ok = ok and good
             print("%s logN=%d mode %d q=%d (%d bits): %s; %s" % ("inverse" if inverse else "forward", logn, mode, q, q.bit_length(),
                                                              "bit-exact vs oracle" if good else "MISMATCH", info), flush=True)

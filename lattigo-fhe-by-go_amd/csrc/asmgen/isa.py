@@ -313,6 +313,12 @@ class Machine:
         self.ws(d, (r & 0xFFFFFFFF).astype(np.uint32))
         self.scc = r < 0
 
+    def i_s_cmp_ge_u32(self, a, b):
+        self.scc = self.rs(a) >= self.rs(b)
+
+    def i_s_cselect_b32(self, d, a, b):
+        self.ws(d, np.where(self.scc, self.rs(a), self.rs(b)))
+
     def i_s_mul_i32(self, d, a, b):
         self.ws(d, (self.rs(a).astype(np.uint64) * self.rs(b).astype(np.uint64)) & np.uint64(0xFFFFFFFF))
 

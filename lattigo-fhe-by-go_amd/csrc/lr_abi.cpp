@@ -205,7 +205,7 @@ struct lr_ckks_plan {
     lr_bext *bext = nullptr;
     lr_decomposer *dec = nullptr;
     int max_batch = 0;
-    Pool c2QiQ, c2QiP, pool2P, pool3P, c2, c0, c1, c2x, q1, q2;
+    Pool c2QiQ, c2QiP, poolPP, c2, c0, c1, c2x, q1, q2;
 };
 
 // ------------------------------------------------------------------------------------------
@@ -540,8 +540,11 @@ struct Rows {  // a strided view of rows inside a batch buffer
     int limb0, step;
 };
 
-int run_ntt(lr_context *c, bool inverse, Rows in, Rows out, int mod0, int mod_step, int count, int batch) {
+// hole/group: digit groups of NttLaunch (the polys of group g skip the items [g*hole, (g+1)*hole))
+int run_ntt(lr_context *c, bool inverse, Rows in, Rows out, int mod0, int mod_step, int count, int batch, int hole = 0,
+            int group = 0) {
     if (count <= 0 || batch <= 0) return LR_OK;
+    if (hole > 0 && (group <= 0 || batch % group != 0)) return fail(LR_ERR_ARG, "digit groups must divide the batch");
     const unsigned logn = c->h.logN;
     if (logn < 1 || logn > 16)
         return fail(LR_ERR_UNSUPPORTED, "NTT kernels cover 2 <= N <= 2^16");
@@ -558,13 +561,16 @@ int run_ntt(lr_context *c, bool inverse, Rows in, Rows out, int mod0, int mod_st
     a.mod_step = mod_step;
     a.n_items = count;
     a.sub_log = 0;
-    a.reserved = 0;
+    a.hole = hole;
+    a.group = group;
+    a.pad = 0;
     a.batch = batch;
     a.lp = c->d_lp;
     a.tw = inverse ? c->d_inv : c->d_fwd;
     a.tw_fin = inverse ? c->d_inv_fin : c->d_fwd_fin;
     const int variant = inverse ? c->asm_inv : c->asm_fwd;
-    if (variant >= 0 && c->use_asm && batch <= 65535 && ntt_asm_available((int)logn)) {
+    if (variant >= 0 && c->use_asm && (hole > 0 ? group : batch) <= 65535 && (hole == 0 || batch / group <= 65535) &&
+        ntt_asm_available((int)logn)) {
         LR_HIP(launch_ntt_asm(a, (int)logn, inverse, variant, c->stream));
         return LR_OK;
     }
@@ -1254,12 +1260,13 @@ int switch_keys_core(lr_ckks_plan *pl, int level, int batch, const u64 *cx, long
     LR_TRY(pl->c2QiQ.ensure(cQ, (size_t)beta * dQ));
     LR_TRY(pl->c2.ensure(cQ, (size_t)batch * sQ));
     LR_TRY(pl->c2QiP.ensure(cQ, (size_t)beta * dP));
-    LR_TRY(pl->pool2P.ensure(cQ, (size_t)batch * sP));
-    LR_TRY(pl->pool3P.ensure(cQ, (size_t)batch * sP));
+    LR_TRY(pl->poolPP.ensure(cQ, (size_t)2 * batch * sP));   // P parts of both accumulators, [2][batch][|P|][N]
+    u64 *const pool2P = pl->poolPP.d, *const pool3P = pl->poolPP.d + (long long)batch * sP;
 
     Rows cxr{const_cast<u64 *>(cx), cx_stride, 0, 1};
     Rows c2r{pl->c2.d, sQ, 0, 1};
     LR_TRY(run_ntt(cQ, true, cxr, c2r, 0, 1, level + 1, batch));  // :1503
+    int full = 0;   // leading digits that own exactly alpha limbs at this level: their transforms share one launch
     for (int i = 0; i < beta; ++i) {
         u64 *dq = pl->c2QiQ.d + (long long)i * dQ, *dp = pl->c2QiP.d + (long long)i * dP;
         // decomposeAndSplitNTT, :1561-1591
@@ -1270,12 +1277,26 @@ int switch_keys_core(lr_ckks_plan *pl, int level, int batch, const u64 *cx, long
         // own-digit limbs are taken from the NTT-domain input (:1579-1584)
         LR_TRY(run_ewise(cQ, LR_COPY, d1 - d0, batch, cx + (long long)d0 * n, cx_stride, nullptr, 0, dq + (long long)d0 * n, sQ,
                          nullptr, d0));
+        if (d1 - d0 == alpha && full == i) ++full;
+    }
+    if (full > 0 && level + 1 - alpha > 0) {
+        // limbs outside each digit's own block, all full digits at once (grid z = digit)
+        Rows all{pl->c2QiQ.d, sQ, 0, 1};
+        LR_TRY(run_ntt(cQ, false, all, all, 0, 1, level + 1 - alpha, full * batch, alpha, batch));
+    }
+    for (int i = full; i < beta; ++i) {
+        u64 *dq = pl->c2QiQ.d + (long long)i * dQ;
+        const int d0 = i * alpha;
+        int d1 = d0 + dec->xalpha[i];
+        if (d1 > level + 1) d1 = level + 1;
         Rows lo{dq, sQ, 0, 1};
         LR_TRY(run_ntt(cQ, false, lo, lo, 0, 1, d0, batch));                     // limbs below the digit
         Rows hi{dq, sQ, d1, 1};
         LR_TRY(run_ntt(cQ, false, hi, hi, d1, 1, level + 1 - d1, batch));        // limbs above the digit
-        Rows pr{dp, sP, 0, 1};
-        LR_TRY(run_ntt(cP, false, pr, pr, 0, 1, nP, batch));                     // :1590
+    }
+    {
+        Rows pr{pl->c2QiP.d, sP, 0, 1};                                          // :1590, every digit's P rows
+        LR_TRY(run_ntt(cP, false, pr, pr, 0, 1, nP, beta * batch));
     }
     // :1511-1552  sum over the digits of evakey[i][0/1] (*) c2_i, canonical, Q part then P part
     {
@@ -1298,29 +1319,31 @@ int switch_keys_core(lr_ckks_plan *pl, int level, int batch, const u64 *cx, long
         K.c2_digit_stride = dP;
         K.c2_poly_stride = sP;
         K.key_limb0 = nQ;
-        K.out0 = pl->pool2P.d;
-        K.out1 = pl->pool3P.d;
+        K.out0 = pool2P;
+        K.out1 = pool3P;
         K.out_stride = sP;
         K.lp = cP->d_lp;
         LR_HIP(launch_keymac(K, nP, batch, cQ->stream));
     }
-    // ModDownSplitedNTTPQ x2, :1556-1557
+    // ModDownSplitedNTTPQ x2, :1556-1557; the two calls share every launch up to the final subtract-multiply
     lr_bext *bx = pl->bext;
+    {
+        Rows pr{pool2P, sP, 0, 1};
+        LR_TRY(run_ntt(cP, true, pr, pr, 0, 1, nP, 2 * batch));
+        LR_TRY(bx->poolQ.ensure(cQ, (size_t)2 * batch * sQ));
+        LR_TRY(run_ext(cQ, bx->pq, nP, pr, 2 * batch, segment(bx->poolQ.d, sQ, 0, 0, level + 1), segment(nullptr, 0, 0, 0, 0)));
+        Rows qr{bx->poolQ.d, sQ, 0, 1};
+        LR_TRY(run_ntt(cQ, false, qr, qr, 0, 1, level + 1, 2 * batch));
+    }
     for (int k = 0; k < 2; ++k) {
         u64 *pq = k == 0 ? p0 : p1;
         const long long pqs = k == 0 ? p0_stride : p1_stride;
-        u64 *pp = k == 0 ? pl->pool2P.d : pl->pool3P.d;
-        Rows pr{pp, sP, 0, 1};
-        LR_TRY(run_ntt(cP, true, pr, pr, 0, 1, nP, batch));
-        LR_TRY(bx->poolQ.ensure(cQ, (size_t)batch * sQ));
-        LR_TRY(run_ext(cQ, bx->pq, nP, pr, batch, segment(bx->poolQ.d, sQ, 0, 0, level + 1), segment(nullptr, 0, 0, 0, 0)));
-        Rows qr{bx->poolQ.d, sQ, 0, 1};
-        LR_TRY(run_ntt(cQ, false, qr, qr, 0, 1, level + 1, batch));
+        const u64 *ext = bx->poolQ.d + (long long)k * batch * sQ;
         if (fin)
-            LR_TRY(run_submul(cQ, level + 1, batch, pq, pqs, bx->poolQ.d, sQ, (long long)n, k == 0 ? fin->out0 : fin->out1,
+            LR_TRY(run_submul(cQ, level + 1, batch, pq, pqs, ext, sQ, (long long)n, k == 0 ? fin->out0 : fin->out1,
                               fin->out_stride, bx->d_moddown_pq, false, nullptr, k == 0 ? fin->plus0 : fin->plus1, fin->plus_stride));
         else
-            LR_TRY(run_submul(cQ, level + 1, batch, pq, pqs, bx->poolQ.d, sQ, (long long)n, pq, pqs, bx->d_moddown_pq, false, nullptr));
+            LR_TRY(run_submul(cQ, level + 1, batch, pq, pqs, ext, sQ, (long long)n, pq, pqs, bx->d_moddown_pq, false, nullptr));
     }
     return LR_OK;
 }

@@ -74,7 +74,14 @@ hipError_t launch_ntt_asm(const NttLaunch &a, int logn, int inverse, int variant
     (void)hipGetLastError();
     // grid: x = limb of the launch, y = polynomial; blocks b and b+8 share an XCD, so the limbs an XCD
     // sees (and whose twiddles live in its L2) are x mod 8 when n_items is a multiple of 8
-    return hipModuleLaunchKernel(it->second, (unsigned)a.n_items, (unsigned)a.batch, 1, 1024, 1, 1, 0, stream, nullptr, extra);
+    // z = digit group (NttLaunch::hole / group); plain launches are one group
+    unsigned gy = (unsigned)a.batch, gz = 1;
+    if (a.hole > 0) {
+        if (a.group <= 0 || a.batch % a.group != 0) return hipErrorInvalidValue;
+        gy = (unsigned)a.group;
+        gz = (unsigned)(a.batch / a.group);
+    }
+    return hipModuleLaunchKernel(it->second, (unsigned)a.n_items, gy, gz, 1024, 1, 1, 0, stream, nullptr, extra);
 }
 
 }  // namespace lr

@@ -43,9 +43,13 @@ struct NttLaunch {
     const Twiddle *tw;          // [L][N] forward or inverse table
     const Twiddle *tw_fin;      // [L][15][N/16] lane-transposed copy of the last four stages (N >= 2^12), or null
     int sub_log;                // log2(sub-blocks per limb): 0, or 1 when N = 2^16 runs as two 2^15 sub-transforms
-    int reserved;               // (keeps the assembly kernels' argument offsets: fields above are read at fixed offsets)
+    // digit groups (key switching): batch = groups * group polys; the polys of group g skip the items
+    // [g*hole, (g+1)*hole): item = i + (i >= g*hole ? hole : 0), i < n_items.  hole = 0: plain launch.
+    int hole;
+    int group;
+    int pad;
 };
-static_assert(sizeof(NttLaunch) == 96, "NttLaunch layout is shared with asmgen/gen_ntt.py");
+static_assert(sizeof(NttLaunch) == 104, "NttLaunch layout is shared with asmgen/gen_ntt.py (fields are read at fixed offsets)");
 
 // ---- coefficient-wise launches (lr_ewise.hip) ----
 struct EwiseLaunch {

@@ -279,7 +279,9 @@ struct Item {
 LR_D Item locate(const NttLaunch &a, int n) {
     const int blocks_per_limb = 1 << a.sub_log;
     const int wg = blockIdx.x % (a.n_items * blocks_per_limb), b = blockIdx.x / (a.n_items * blocks_per_limb);
-    const int item = wg >> a.sub_log, blk = wg & (blocks_per_limb - 1);
+    int item = wg >> a.sub_log;
+    const int blk = wg & (blocks_per_limb - 1);
+    if (a.hole > 0 && item >= (b / a.group) * a.hole) item += a.hole;
     const int mod = a.mod0 + item * a.mod_step;
     const long long n_full = (long long)n << a.sub_log;
     Item it;
@@ -443,7 +445,9 @@ __global__ __launch_bounds__(256) void ntt_small_kernel(NttLaunch a, int logn, i
 //   inverse: after the two 2^15 inverse sub-transforms: last Gentleman-Sande stage, scaling by N^-1, canonical.
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void ntt_top_kernel(NttLaunch a, int logn, int inverse) {
-    const int item = blockIdx.y % a.n_items, b = blockIdx.y / a.n_items;
+    int item = blockIdx.y % a.n_items;
+    const int b = blockIdx.y / a.n_items;
+    if (a.hole > 0 && item >= (b / a.group) * a.hole) item += a.hole;
     const int mod = a.mod0 + item * a.mod_step;
     const long long n = 1ll << logn, h = n >> 1;
     const LimbParams lp = a.lp[mod];

@@ -20,8 +20,10 @@ def _ckks(gpu_pkg, oracle, logn, nq, np_, batch, max_batch=None):
     return N, Q, P, cQ, cP, plan, oplan, evk.reshape(beta, 2, nq + np_, N), pevk
 
 
+# the N = 2^14 cases run on the assembly NTT kernels, whose grouped launch transforms every full digit at once
+# (grid z = digit, own limbs skipped); levels 6 and 4 end in a partial digit that takes the per-digit path
 @pytest.mark.parametrize("logn,nq,np_,level", [(10, 6, 2, 5), (10, 6, 2, 4), (10, 6, 2, 2), (11, 7, 3, 6), (10, 18, 3, 17),
-                                               (10, 18, 3, 12)])
+                                               (10, 18, 3, 12), (14, 7, 3, 6), (14, 7, 3, 5), (14, 6, 2, 4), (14, 4, 2, 1)])
 def test_switch_keys(gpu_pkg, oracle, logn, nq, np_, level):
     N, Q, P, cQ, cP, plan, oplan, evk, pevk = _ckks(gpu_pkg, oracle, logn, nq, np_, 2)
     cx = gpu_pkg.sampling.uniform_poly(Q[:level + 1], N, 2, seed=level)

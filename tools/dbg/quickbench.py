@@ -11,8 +11,9 @@ for logn in sizes:
     L = len(moduli)
     B = (1 << 30) // (8 * N * L)      # 1 GiB per buffer
     ctx = ring.NewContextWithParams(N, moduli)
-    base = sampling.uniform_poly(moduli, N, 2, seed=1)
-    host = np.concatenate([base] * (B // 2))
+    nb = int(__import__('os').environ.get('QB_BASE', '2'))
+    base = sampling.uniform_poly(moduli, N, nb, seed=1)
+    host = np.concatenate([base] * (B // nb))
     src, dst = ctx.NewPoly(B).set(host), ctx.NewPoly(B)
     res = {}
     for name, fn in (("ntt", lambda: ctx.NTT(src, dst)), ("intt", lambda: ctx.InvNTT(src, dst))):
