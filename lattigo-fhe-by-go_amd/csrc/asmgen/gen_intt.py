@@ -163,7 +163,7 @@ class GenInv(Gen):
             if i == 4:                                        # the immediate offset is 13-bit signed
                 e("s_add_u32", self.TMP.lo(), self.TMP.lo(), 4096)
                 e("s_addc_u32", self.TMP.hi(), self.TMP.hi(), 0)
-            e("global_load_dwordx4", regs[i], a2, self.TMP, offset=(i % 4) * 1024)
+            e("global_load_dwordx4", regs[i], a2, self.TMP, offset=(i % 4) * 1024, hint="nt")
         if half + 1 < self.HALVES:
             e("s_add_u32", self.SRC.lo(), self.SRC.lo(), self.M * 8)
             e("s_addc_u32", self.SRC.hi(), self.SRC.hi(), 0)
@@ -360,7 +360,7 @@ class GenInv(Gen):
         self.c("coalesced store of the column {k*S + t}")
         e("v_lshlrev_b32", self.GOFF, 3, self.TID)
         for k in range(self.RA):
-            e("global_store_dwordx2", self.GOFF, self.X[k], self.DST)
+            e("global_store_dwordx2", self.GOFF, self.X[k], self.DST, hint="nt")
             e("s_add_u32", self.DST.lo(), self.DST.lo(), self.S * 8)
             e("s_addc_u32", self.DST.hi(), self.DST.hi(), 0)
 

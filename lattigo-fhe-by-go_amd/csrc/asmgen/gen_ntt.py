@@ -276,8 +276,8 @@ class Gen:
         e("s_add_u32", self.TMP.lo(), self.SRC.lo(), (self.RA // 2) * self.S * 8)
         e("s_addc_u32", self.TMP.hi(), self.SRC.hi(), 0)
         for k in range(self.RA // 2):
-            e("global_load_dwordx2", self.X[k], self.GOFF, self.SRC)
-            e("global_load_dwordx2", self.X[k + self.RA // 2], self.GOFF, self.TMP)
+            e("global_load_dwordx2", self.X[k], self.GOFF, self.SRC, hint="nt")
+            e("global_load_dwordx2", self.X[k + self.RA // 2], self.GOFF, self.TMP, hint="nt")
             for ptr in (self.SRC, self.TMP):
                 e("s_add_u32", ptr.lo(), ptr.lo(), self.S * 8)
                 e("s_addc_u32", ptr.hi(), ptr.hi(), 0)
@@ -598,7 +598,7 @@ class Gen:
             r = regs[i]
             e("s_waitcnt", "lgkmcnt(%d)" % (n - 1 - i))
             self.zip_emit([(lambda ts, x=r.sub(0, 2): self.ops_canon(ts, x)), (lambda ts, x=r.sub(2, 2): self.ops_canon(ts, x))])
-            e("global_store_dwordx4", a2, r, self.TMP)
+            e("global_store_dwordx4", a2, r, self.TMP, hint="nt")
             e("s_add_u32", self.TMP.lo(), self.TMP.lo(), 1024)
             e("s_addc_u32", self.TMP.hi(), self.TMP.hi(), 0)
         if half + 1 < self.HALVES:

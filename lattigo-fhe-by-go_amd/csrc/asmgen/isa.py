@@ -384,15 +384,16 @@ class Machine:
         for k in range(n):
             self.wv(d, self.mem[idx + k], k)
 
-    def i_global_load_dwordx2(self, d, voff, sbase, offset=0):
+    # `hint` (nt / sc0 / sc1 cache policy bits) does not change what is loaded or stored
+    def i_global_load_dwordx2(self, d, voff, sbase, offset=0, hint=""):
         assert d.n == 2
         self._gload(d, voff, sbase, 2, offset)
 
-    def i_global_load_dwordx4(self, d, voff, sbase, offset=0):
+    def i_global_load_dwordx4(self, d, voff, sbase, offset=0, hint=""):
         assert d.n == 4
         self._gload(d, voff, sbase, 4, offset)
 
-    def i_global_store_dwordx4(self, voff, data, sbase, offset=0):
+    def i_global_store_dwordx4(self, voff, data, sbase, offset=0, hint=""):
         assert data.n == 4
         addr = self._gaddr(voff, sbase, offset)
         assert np.all(addr % 16 == 0)
@@ -400,7 +401,7 @@ class Machine:
         for k in range(4):
             self.mem[idx + k] = self.rv(data, k)
 
-    def i_global_store_dwordx2(self, voff, data, sbase, offset=0):
+    def i_global_store_dwordx2(self, voff, data, sbase, offset=0, hint=""):
         assert data.n == 2
         addr = self._gaddr(voff, sbase, offset)
         idx = (addr // 4).astype(np.int64)

@@ -1,0 +1,193 @@
+"""Instruction-level throughput probes for the assembly NTT kernels: each variant is a register-only loop of one
+instruction pattern, 1024 threads per workgroup, one workgroup per CU.  Reports cycles per wave-instruction per SIMD.
+    python gen.py outdir        # writes <variant>.s ; assemble + link like csrc/build.sh
+"""
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "..", "..", "lattigo-fhe-by-go_amd", "csrc", "asmgen"))
+from gen_ntt import Gen, kernel_text_for  # noqa: E402
+from gen_intt import GenInv  # noqa: E402
+from isa import VCC, s, v  # noqa: E402
+
+ITER = 256
+
+
+class Probe(Gen):
+    def __init__(self, variant):
+        super().__init__(15, 1)
+        self.variant = variant
+        self.persistent = False
+
+    def body(self):
+        e, X = self.e, self.X
+        tw = tuple(s(36 + i) for i in range(4))
+        var = self.variant
+        if var.startswith("cfg_"):
+            # cfg_<ts0 carry>_<twiddle base>[_c]: interleaved butterflies with the given SGPR placement
+            parts = var.split("_")
+            c0, twb = parts[1], int(parts[2])
+            self.ts[0].CY = VCC if c0 == "vcc" else s(int(c0), 2)
+            tw = tuple(s(twb + i) for i in range(4))
+            for i in range(4):
+                pass
+            corr = len(parts) > 3
+            self.butterflies([(X[i], X[i + 16], tw, corr) for i in range(16)])
+            return 16 * (18 if corr else 14)
+        if var in ("bfly_nc", "bfly_c"):
+            self.butterflies([(X[i], X[i + 16], tw, var == "bfly_c") for i in range(16)])
+            return 16 * (14 if var == "bfly_nc" else 18)
+        if var == "bfly_nc_2sgpr":    # both temp sets carry through SGPR pairs
+            self.ts[0].CY = s(98, 2)
+            self.butterflies([(X[i], X[i + 16], tw, False) for i in range(16)])
+            return 16 * 14
+        if var == "bfly_c_seq":
+            for i in range(16):
+                for op in self.ops_butterfly(self.ts[0], X[i], X[i + 16], tw, True):
+                    e(*op)
+            return 16 * 18
+        if var == "bfly_nc_seq":      # no interleaving of two butterflies
+            for i in range(16):
+                for op in self.ops_butterfly(self.ts[0], X[i], X[i + 16], tw, False):
+                    e(*op)
+            return 16 * 14
+        if var == "inv_c":
+            gi = self.inv
+            self.zip_emit([(lambda ts, U=X[i], V=X[i + 16]: gi.ops_butterfly(ts, U, V, tw, True)) for i in range(16)])
+            return 16 * 19
+        n = 128
+        for i in range(n):
+            d = X[i % 32]
+            a = X[(i + 7) % 32]
+            if var == "mad_vsv":
+                e("v_mad_u64_u32", d, self.JUNK, a.lo(), s(36), d)
+            elif var == "mad_vvv":
+                e("v_mad_u64_u32", d, self.JUNK, a.lo(), a.hi(), d)
+            elif var == "mad_vs0":
+                e("v_mad_u64_u32", d, self.JUNK, a.lo(), s(36), 0)
+            elif var == "mulhi_vs":
+                e("v_mul_hi_u32", d.lo(), a.hi(), s(36))
+            elif var == "mulhi_vv":
+                e("v_mul_hi_u32", d.lo(), a.hi(), a.lo())
+            elif var == "mullo_vv":
+                e("v_mul_lo_u32", d.lo(), a.hi(), a.lo())
+            elif var == "lshl_add":
+                e("v_lshl_add_u64", d, a, 0, s(36, 2))
+            elif var == "lshl_add_vvv":
+                e("v_lshl_add_u64", d, a, 0, d)
+            elif var == "add_u32":
+                e("v_add_u32", d.lo(), a.lo(), d.hi())
+            elif var == "cndmask_vcc":
+                e("v_cndmask_b32", d.lo(), a.lo(), a.hi(), VCC)
+            elif var == "cndmask_sgpr":
+                e("v_cndmask_b32", d.lo(), a.lo(), a.hi(), s(100, 2))
+            elif var == "sub_co_pair":
+                if i % 2 == 0:
+                    e("v_sub_co_u32", d.lo(), VCC, a.lo(), d.lo())
+                else:
+                    e("v_subb_co_u32", d.hi(), VCC, a.hi(), d.hi(), VCC)
+            elif var == "cmp":
+                e("v_cmp_lt_u32", VCC if i % 2 else s(100, 2), a.hi(), d.hi())
+            elif var == "mad_sdst_vcc":
+                e("v_mad_u64_u32", d, VCC, a.lo(), s(36), d)
+            elif var == "mad_sdst_alt":
+                e("v_mad_u64_u32", d, s(40 + 2 * (i % 4), 2), a.lo(), s(36), d)
+            elif var == "subb_sgpr":
+                if i % 2 == 0:
+                    e("v_sub_co_u32", d.lo(), s(100, 2), a.lo(), d.lo())
+                else:
+                    e("v_subb_co_u32", d.hi(), s(100, 2), a.hi(), d.hi(), s(100, 2))
+            elif var == "cmp_vcc":
+                e("v_cmp_lt_u32", VCC, a.hi(), d.hi())
+            elif var == "cmp_sgpr":
+                e("v_cmp_lt_u32", s(100, 2), a.hi(), d.hi())
+            elif var == "cndmask_vcc2":
+                if i == 0:
+                    e("v_cmp_lt_u32", VCC, a.hi(), d.hi())
+                    e("s_nop", 4)
+                e("v_cndmask_b32", d.lo(), a.lo(), a.hi(), VCC)
+            elif var == "cndmask_e64_vcc":
+                e("v_cndmask_b32_e64", d.lo(), a.lo(), a.hi(), VCC)
+            elif var == "mad_add_mix":
+                if i % 2 == 0:
+                    e("v_mad_u64_u32", d, self.JUNK, a.lo(), s(36), d)
+                else:
+                    e("v_add_u32", d.lo(), a.lo(), d.hi())
+            elif var == "mulhi_add_mix":
+                if i % 2 == 0:
+                    e("v_mul_hi_u32", d.lo(), a.hi(), s(36))
+                else:
+                    e("v_add_u32", d.lo(), a.lo(), d.hi())
+            elif var == "xor_b32":
+                e("v_xor_b32", d.lo(), a.lo(), d.hi())
+            elif var == "and_or":
+                e("v_and_or_b32", d.lo(), a.lo(), a.hi(), d.lo())
+            elif var == "add3":
+                e("v_add3_u32", d.lo(), a.lo(), a.hi(), d.lo())
+            elif var == "lshl_add_u32":
+                e("v_lshl_add_u32", d.lo(), a.lo(), 3, d.lo())
+            elif var == "mov":
+                e("v_mov_b32", d.lo(), a.hi())
+            elif var == "fma_f64":
+                e("v_fma_f64", d, a, a, d)
+            elif var == "fma_f32":
+                e("v_fma_f32", d.lo(), a.lo(), a.hi(), d.lo())
+            else:
+                raise ValueError(var)
+        return n
+
+    def build(self):
+        e = self.e
+        self.inv = GenInv(15, 1)
+        self.inv.p, self.inv.e = self.p, self.e
+        e("s_load_dwordx2", self.DST, self.KARG, 16)
+        e("s_load_dwordx4", s(36, 4), self.KARG, 0)
+        e("v_mov_b32", self.TID, v(0))
+        for ts in self.ts:
+            e("v_mov_b32", ts.Z1, 0)
+            e("v_mov_b32", ts.Z3, 0)
+        for k in range(32):
+            e("v_lshlrev_b32", self.X[k].lo(), k % 7, self.TID)
+            e("v_add_u32", self.X[k].hi(), 12345 + k, self.TID)
+        e("s_waitcnt", "lgkmcnt(0)")
+        e("s_mov_b64", self.NQ, s(36, 2))
+        e("s_mov_b64", self.Q4, s(38, 2))
+        e("s_mov_b64", self.NQ8, s(36, 2))
+        e("s_mov_b64", self.NQ2 if hasattr(self, "NQ2") else self.Qm, s(38, 2))
+        e("s_mov_b64", VCC, 0)
+        e("s_mov_b64", s(100, 2), 0)
+        for b in (40, 64, 68, 92, 96):
+            e("s_mov_b64", s(b, 2), s(36, 2))
+            e("s_mov_b64", s(b + 2, 2), s(38, 2))
+        e("s_movk_i32", self.REM, ITER)
+        self.p.label("L_top")
+        self.count = self.body()
+        e("s_sub_u32", self.REM, self.REM, 1)
+        e("s_cmp_eq_u32", self.REM, 0)
+        e("s_cbranch_scc0", "L_top")
+        # keep the result alive
+        e("v_lshlrev_b32", self.GOFF, 3, self.TID)
+        for k in range(1, 32):
+            e("v_xor_b32", self.X[0].lo(), self.X[0].lo(), self.X[k].lo())
+            e("v_xor_b32", self.X[0].hi(), self.X[0].hi(), self.X[k].hi())
+        e("global_store_dwordx2", self.GOFF, self.X[0], self.DST)
+        e("s_endpgm")
+        return self.p
+
+
+VARIANTS = ["cfg_98_36", "cfg_32_36", "cfg_2_36", "cfg_32_68", "cfg_vcc_68", "cfg_98_92", "cfg_98_40", "cfg_34_64", "cfg_2_36_c", "cfg_98_36_c", "cfg_32_36_c"]
+_OLD = ["bfly_nc", "bfly_c", "bfly_nc_seq", "bfly_c_seq", "bfly_nc_2sgpr", "inv_c", "mad_sdst_vcc", "mad_sdst_alt", "subb_sgpr", "cmp_vcc", "cmp_sgpr",
+            "cndmask_vcc2", "cndmask_e64_vcc", "mad_add_mix", "mulhi_add_mix", "xor_b32", "and_or", "add3", "lshl_add_u32", "mov", "mad_vsv", "mad_vvv", "mad_vs0", "mulhi_vs", "mulhi_vv", "mullo_vv",
+            "lshl_add", "lshl_add_vvv", "add_u32", "cndmask_vcc", "cndmask_sgpr", "sub_co_pair", "cmp", "fma_f64", "fma_f32"]
+
+if __name__ == "__main__":
+    out = sys.argv[1]
+    os.makedirs(out, exist_ok=True)
+    meta = []
+    for var in VARIANTS:
+        g = Probe(var)
+        text = kernel_text_for(g, "probe_" + var)
+        open(os.path.join(out, var + ".s"), "w").write(text)
+        meta.append("%s %d" % (var, g.count * ITER))
+    open(os.path.join(out, "variants.txt"), "w").write("\n".join(meta) + "\n")

@@ -1,0 +1,43 @@
+// Loads the probe code objects produced by gen.py and reports cycles per wave-instruction per SIMD.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <fstream>
+#include <iterator>
+#include <string>
+#include <vector>
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
+int main(int argc, char **argv) {
+    const std::string dir = argc > 1 ? argv[1] : ".";
+    std::ifstream list(dir + "/variants.txt");
+    std::string name; long long count;
+    void *out; CK(hipMalloc(&out, 1 << 20));
+    int clk_khz = 0; CK(hipDeviceGetAttribute(&clk_khz, hipDeviceAttributeClockRate, 0));
+    int cus = 0; CK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0));
+    printf("device clock %d kHz, %d CUs\n", clk_khz, cus);
+    while (list >> name >> count) {
+        std::ifstream f(dir + "/" + name + ".hsaco", std::ios::binary);
+        std::vector<char> img((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+        hipModule_t mod; hipFunction_t fn;
+        CK(hipModuleLoadData(&mod, img.data()));
+        CK(hipModuleGetFunction(&fn, mod, ("probe_" + name).c_str()));
+        struct { unsigned long long a, b; void *out; char pad[80]; } args = {0x0123456789ABCDEFull, 0x0FEDCBA987654321ull, out, {0}};
+        size_t size = 104;
+        void *extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
+        hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+        const int rounds = 4;
+        for (int rep = 0; rep < 3; ++rep) {
+            CK(hipEventRecord(e0, 0));
+            CK(hipModuleLaunchKernel(fn, cus * rounds, 1, 1, 1024, 1, 1, 0, 0, nullptr, extra));
+            CK(hipEventRecord(e1, 0));
+            CK(hipEventSynchronize(e1));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+            if (rep == 2) {
+                // per SIMD: rounds workgroups x 4 waves x count instructions
+                const double instr = (double)rounds * 4 * count;
+                printf("%-14s %8.3f ms  %6.2f cycles/instr at %d MHz (nominal)\n", name.c_str(), ms, ms * 1e-3 * clk_khz * 1e3 / instr, clk_khz / 1000);
+            }
+        }
+        CK(hipModuleUnload(mod));
+    }
+    return 0;
+}

@@ -1,0 +1,17 @@
+"""One launch pattern for counter collection: forward NTT R15 (batch 256), a few launches."""
+import sys
+sys.path.insert(0, '/root/repo')
+import numpy as np
+import __graft_entry__ as g
+pkg = g.load_package()
+ring, params, sampling = pkg.ring, pkg.params, pkg.sampling
+logn = int(sys.argv[1]) if len(sys.argv) > 1 else 15
+N, moduli = params.DefaultParamsQi(logn)
+L = len(moduli)
+B = (1 << 30) // (8 * N * L)
+ctx = ring.NewContextWithParams(N, moduli)
+base = sampling.uniform_poly(moduli, N, 2, seed=1)
+src, dst = ctx.NewPoly(B).set(np.concatenate([base] * (B // 2))), ctx.NewPoly(B)
+for _ in range(5):
+    ctx.NTT(src, dst)
+ctx.Sync()
