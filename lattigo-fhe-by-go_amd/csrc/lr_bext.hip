@@ -71,11 +71,11 @@ __global__ __launch_bounds__(256) void ext_shoup_kernel(ExtLaunch L) {
         const u64 qi = L.t.Q[i];
         u64 v[W];
         if (W == 2) {
-            const ulonglong2 t = *reinterpret_cast<const ulonglong2 *>(in + (long long)i * L.n);
+            const ulonglong2 t = ld_stream(reinterpret_cast<const ulonglong2 *>(in + (long long)i * L.n));
             v[0] = t.x;
             v[W - 1] = t.y;
         } else {
-            v[0] = in[(long long)i * L.n];
+            v[0] = ld_stream(in + (long long)i * L.n);
         }
 #pragma unroll
         for (int w = 0; w < W; ++w) {
@@ -108,8 +108,8 @@ __global__ __launch_bounds__(256) void ext_shoup_kernel(ExtLaunch L) {
             const u64 *corr = L.t.qpj_inv + (long long)col * (L.t.nQ + 1);
 #pragma unroll
             for (int w = 0; w < W; ++w) acc[w] = bred_add(acc[w] + corr[vi[w]], pj, bh);
-            if (W == 2) *reinterpret_cast<ulonglong2 *>(out + (long long)jj * L.n) = make_ulonglong2(acc[0], acc[W - 1]);
-            else out[(long long)jj * L.n] = acc[0];
+            if (W == 2) st_stream(reinterpret_cast<ulonglong2 *>(out + (long long)jj * L.n), make_ulonglong2(acc[0], acc[W - 1]));
+            else st_stream(out + (long long)jj * L.n, acc[0]);
         }
     }
 }

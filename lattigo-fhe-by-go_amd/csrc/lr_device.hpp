@@ -160,6 +160,24 @@ struct ExtLaunch {
     ExtSegment seg[2];
 };
 
+#if defined(__HIPCC__)
+// streaming access to poly data (each element is read or written once per launch): the `nt` cache policy keeps
+// it from displacing the twiddle / key tables in L2 and the Infinity Cache
+typedef unsigned long long lr_u64x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ ulonglong2 ld_stream(const ulonglong2 *p) {
+    const lr_u64x2 v = __builtin_nontemporal_load(reinterpret_cast<const lr_u64x2 *>(p));
+    return make_ulonglong2(v.x, v.y);
+}
+__device__ __forceinline__ unsigned long ld_stream(const unsigned long *p) { return __builtin_nontemporal_load(p); }
+__device__ __forceinline__ void st_stream(unsigned long *p, unsigned long v) { __builtin_nontemporal_store(v, p); }
+__device__ __forceinline__ void st_stream(ulonglong2 *p, ulonglong2 v) {
+    lr_u64x2 t;
+    t.x = v.x;
+    t.y = v.y;
+    __builtin_nontemporal_store(t, reinterpret_cast<lr_u64x2 *>(p));
+}
+#endif
+
 // host launchers (defined next to their kernels)
 // mode: lazy-correction cadence of the forward butterflies (lr_ntt.hip): 0 = q < 2^61, 1 = q <= 2^60, 2 = q < 2^57
 hipError_t launch_ntt(const NttLaunch &a, int logn, bool inverse, int mode, hipStream_t stream);

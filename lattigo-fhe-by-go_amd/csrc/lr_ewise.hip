@@ -62,11 +62,11 @@ __global__ __launch_bounds__(256) void ewise_kernel(EwiseLaunch L) {
     ulonglong2 *po = reinterpret_cast<ulonglong2 *>(L.out + b * L.out_stride + row);
     const int pairs = L.n >> 1;
     for (int e = blockIdx.x * 256 + threadIdx.x; e < pairs; e += gridDim.x * 256) {
-        const ulonglong2 x = pa[e];
+        const ulonglong2 x = ld_stream(pa + e);
         ulonglong2 y = make_ulonglong2(0, 0), z = make_ulonglong2(0, 0);
-        if constexpr (reads_b(OP)) y = pb[e];
-        if constexpr (reads_out(OP)) z = po[e];
-        po[e] = make_ulonglong2(apply<OP>(x.x, y.x, z.x, lp, s), apply<OP>(x.y, y.y, z.y, lp, s));
+        if constexpr (reads_b(OP)) y = ld_stream(pb + e);
+        if constexpr (reads_out(OP)) z = ld_stream(po + e);
+        st_stream(po + e, make_ulonglong2(apply<OP>(x.x, y.x, z.x, lp, s), apply<OP>(x.y, y.y, z.y, lp, s)));
     }
 }
 
@@ -134,19 +134,19 @@ __global__ __launch_bounds__(256) void submul_kernel(SubMulLaunch L) {
     ulonglong2 *po = reinterpret_cast<ulonglong2 *>(L.out + b * L.out_stride + row);
     const int pairs = L.n >> 1;
     for (int e = blockIdx.x * 256 + threadIdx.x; e < pairs; e += gridDim.x * 256) {
-        const ulonglong2 x = pa[e];
-        ulonglong2 y = pb[e];
+        const ulonglong2 x = ld_stream(pa + e);
+        ulonglong2 y = ld_stream(pb + e);
         if (L.reduce_b) {
             y.x = bred_add(y.x + add, lp.q, lp.bred_hi);
             y.y = bred_add(y.y + add, lp.q, lp.bred_hi);
         }
         ulonglong2 r = make_ulonglong2(mred(x.x + (lp.q - y.x), c, lp.q, lp.qinv), mred(x.y + (lp.q - y.y), c, lp.q, lp.qinv));
         if (L.plus) {
-            const ulonglong2 p = reinterpret_cast<const ulonglong2 *>(L.plus + b * L.plus_stride + row)[e];
+            const ulonglong2 p = ld_stream(reinterpret_cast<const ulonglong2 *>(L.plus + b * L.plus_stride + row) + e);
             r.x = cred(p.x + r.x, lp.q);
             r.y = cred(p.y + r.y, lp.q);
         }
-        po[e] = r;
+        st_stream(po + e, r);
     }
 }
 
@@ -168,7 +168,7 @@ __global__ __launch_bounds__(256) void tensor_kernel(TensorLaunch L) {
     ulonglong2 *pc2 = reinterpret_cast<ulonglong2 *>(L.c2 + b * L.c_stride + row);
     const int pairs = L.n >> 1;
     for (int e = blockIdx.x * 256 + threadIdx.x; e < pairs; e += gridDim.x * 256) {
-        const ulonglong2 a0 = pa0[e], a1 = pa1[e], b0 = pb0[e], b1 = pb1[e];
+        const ulonglong2 a0 = ld_stream(pa0 + e), a1 = ld_stream(pa1 + e), b0 = ld_stream(pb0 + e), b1 = ld_stream(pb1 + e);
         ulonglong2 c0, c1, c2;
         {
             const u64 m0 = mform(a0.x, q, lp.bred_hi, lp.bred_lo), m1 = mform(a1.x, q, lp.bred_hi, lp.bred_lo);
@@ -182,9 +182,9 @@ __global__ __launch_bounds__(256) void tensor_kernel(TensorLaunch L) {
             c1.y = cred(mred(m0, b1.y, q, lp.qinv) + mred(m1, b0.y, q, lp.qinv), q);
             c2.y = mred(m1, b1.y, q, lp.qinv);
         }
-        pc0[e] = c0;
-        pc1[e] = c1;
-        pc2[e] = c2;
+        st_stream(pc0 + e, c0);
+        st_stream(pc1 + e, c1);
+        st_stream(pc2 + e, c2);
     }
 }
 
@@ -259,7 +259,7 @@ __global__ __launch_bounds__(256) void keymac_kernel(KeyMacLaunch L) {
     for (int e = blockIdx.x * 256 + threadIdx.x; e < pairs; e += gridDim.x * 256) {
         u64 a0x = 0, a0y = 0, a1x = 0, a1y = 0;
         for (int i = 0; i < L.beta; ++i) {
-            const ulonglong2 c = pc[e + i * cd];
+            const ulonglong2 c = ld_stream(pc + e + i * cd);
             const ulonglong2 k0 = pk[e + (2 * i) * kd], k1 = pk[e + (2 * i + 1) * kd];
             a0x += mred(k0.x, c.x, lp.q, lp.qinv);
             a0y += mred(k0.y, c.y, lp.q, lp.qinv);
@@ -272,8 +272,8 @@ __global__ __launch_bounds__(256) void keymac_kernel(KeyMacLaunch L) {
                 a1y = bred_add(a1y, lp.q, lp.bred_hi);
             }
         }
-        po0[e] = make_ulonglong2(bred_add(a0x, lp.q, lp.bred_hi), bred_add(a0y, lp.q, lp.bred_hi));
-        po1[e] = make_ulonglong2(bred_add(a1x, lp.q, lp.bred_hi), bred_add(a1y, lp.q, lp.bred_hi));
+        st_stream(po0 + e, make_ulonglong2(bred_add(a0x, lp.q, lp.bred_hi), bred_add(a0y, lp.q, lp.bred_hi)));
+        st_stream(po1 + e, make_ulonglong2(bred_add(a1x, lp.q, lp.bred_hi), bred_add(a1y, lp.q, lp.bred_hi)));
     }
 }
 

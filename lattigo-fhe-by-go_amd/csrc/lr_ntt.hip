@@ -314,7 +314,7 @@ __global__ __launch_bounds__(1 << Plan<LOGN>::LOGT, 4) void ntt_fwd_kernel(NttLa
 
     u64 x[RA];
 #pragma unroll
-    for (int k = 0; k < RA; ++k) x[k] = (it.src + k * S)[t];   // uniform row base (SGPR) + one lane offset
+    for (int k = 0; k < RA; ++k) x[k] = ld_stream(it.src + k * S + t);   // uniform row base (SGPR) + one lane offset
     // The first stage needs U < 8q; V may be any 64-bit value.  The reference accepts inputs
     // >= q (ring/ring_scaling.go:19,102), so the U operands are reduced exactly.
 #pragma unroll
@@ -339,7 +339,7 @@ __global__ __launch_bounds__(1 << Plan<LOGN>::LOGT, 4) void ntt_fwd_kernel(NttLa
 #pragma unroll
         for (int i = 0; i < M / (2 * T); ++i) {   // element pair e = t + i*T; slot(2e) = slot(2t) + i*(2T + 2T/8)
             const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(pair + i * (2 * T + T / 4));
-            (dst2 + i * T)[t] = make_ulonglong2(fwd_canon<MODE>(v.x, it.lp), fwd_canon<MODE>(v.y, it.lp));
+            st_stream(dst2 + i * T + t, make_ulonglong2(fwd_canon<MODE>(v.x, it.lp), fwd_canon<MODE>(v.y, it.lp)));
         }
         if (half + 1 < HALVES) __syncthreads();
     }
@@ -368,7 +368,7 @@ __global__ __launch_bounds__(1 << Plan<LOGN>::LOGT, 4) void ntt_inv_kernel(NttLa
         u64 *const pair = lds + lds_slot(2 * t);
 #pragma unroll
         for (int i = 0; i < M / (2 * T); ++i)
-            *reinterpret_cast<ulonglong2 *>(pair + i * (2 * T + T / 4)) = (src2 + i * T)[t];
+            *reinterpret_cast<ulonglong2 *>(pair + i * (2 * T + T / 4)) = ld_stream(src2 + i * T + t);
         __syncthreads();
         inv_lds_pass<LOGN, M, T, P::P2, 0, (HALVES > 1), BIGQ>(lds, it.tw, it.tw_fin, res_base, t, q, q4, it.sub);
         inv_lds_pass<LOGN, M, T, P::P1, P::P2, (HALVES > 1), BIGQ>(lds, it.tw, it.tw_fin, res_base, t, q, q4, it.sub);
@@ -385,7 +385,7 @@ __global__ __launch_bounds__(1 << Plan<LOGN>::LOGT, 4) void ntt_inv_kernel(NttLa
     if (a.sub_log == 0) {
 #pragma unroll
         for (int k = 0; k < RA; ++k)
-            (it.dst + k * S)[t] = canon_from_4q(mul_shoup_lazy(x[k], it.lp.n_inv, it.lp.n_inv_shoup, q), q);
+            st_stream(it.dst + k * S + t, canon_from_4q(mul_shoup_lazy(x[k], it.lp.n_inv, it.lp.n_inv_shoup, q), q));
     } else {
         // sub-block of a longer transform: the last stage and the scaling follow in ntt_top_kernel; values < 4q
 #pragma unroll
@@ -456,7 +456,7 @@ __global__ __launch_bounds__(256) void ntt_top_kernel(NttLaunch a, int logn, int
     const u64 *src = a.in + (long long)b * a.in_poly_stride + (long long)(a.in_limb0 + item * a.in_limb_step) * n;
     u64 *dst = a.out + (long long)b * a.out_poly_stride + (long long)(a.out_limb0 + item * a.out_limb_step) * n;
     for (long long j = (long long)blockIdx.x * 256 + threadIdx.x; j < h; j += (long long)gridDim.x * 256) {
-        u64 U = src[j], V = src[j + h];
+        u64 U = ld_stream(src + j), V = ld_stream(src + j + h);
         if (!inverse) {
             U = bred_add(U, q, lp.bred_hi);
             fwd_bfly<3>(U, V, w.x, w.y, q, q4, true);                 // X, Y < 8q: the sub-transforms reduce their inputs
@@ -464,8 +464,8 @@ __global__ __launch_bounds__(256) void ntt_top_kernel(NttLaunch a, int logn, int
             dst[j + h] = V;
         } else {
             inv_bfly<false, false>(U, V, w.x, w.y, q, q4);            // inputs < 4q
-            dst[j] = canon_from_4q(mul_shoup_lazy(U, lp.n_inv, lp.n_inv_shoup, q), q);
-            dst[j + h] = canon_from_4q(mul_shoup_lazy(V, lp.n_inv, lp.n_inv_shoup, q), q);
+            st_stream(dst + j, canon_from_4q(mul_shoup_lazy(U, lp.n_inv, lp.n_inv_shoup, q), q));
+            st_stream(dst + j + h, canon_from_4q(mul_shoup_lazy(V, lp.n_inv, lp.n_inv_shoup, q), q));
         }
     }
 }
