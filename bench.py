@@ -259,6 +259,28 @@ def main():
                                 "algorithmic_GBs": cB * 8 * cN * 360 / (cms * 1e-3) / 1e9}
         del plan, ct0, ct1, cto, evk
 
+    if rank == 0 and not args.no_ckks:
+        # BASELINE.json config 4: BFV DefaultParams[PN14QP438] Evaluator.Mul (tensorAndRescale, bfv/evaluator.go:278),
+        # degree-1 x degree-1 -> degree-2, coefficient-domain operands, device-resident batch
+        bN, bQ, _, bQMul = params.bfv_moduli("PN14QP438")
+        bB = args.ckks_batch
+        bcQ, bcM = ring.NewContextWithParams(bN, bQ, device=local), ring.NewContextWithParams(bN, bQMul, device=local)
+        bplan = ring.BfvPlan(bcQ, bcM, 65537, bB)
+        bbase = sampling.uniform_poly(bQ, bN, 2, seed=5)
+        bhost = np.concatenate([bbase] * (-(-bB // 2)))[:bB]
+        mkb = lambda: bcQ.NewPoly(bB).set(bhost)
+        b0, b1, bo = (mkb(), mkb()), (mkb(), mkb()), (bcQ.NewPoly(bB), bcQ.NewPoly(bB), bcQ.NewPoly(bB))
+        for _ in range(3):
+            bplan.Mul(b0, b1, bo)
+        bcQ.Sync()
+        bcQ.TimerStart()
+        for _ in range(10):
+            bplan.Mul(b0, b1, bo)
+        bms = bcQ.TimerStop() / 10
+        out["bfv_mul"] = {"value": bB / (bms * 1e-3), "unit": "Mul/s", "batch": bB, "ms_per_batch": bms,
+                          "params": "PN14QP438 (N=2^14, 6 Q limbs, 6 QMul limbs, t=65537)"}
+        del bplan, b0, b1, bo
+
     if not args.no_extras and rank == 0:
         # the other kernels BASELINE.json's north_star asks throughput for, same ring, same resident batch
         extras = {}
