@@ -1274,9 +1274,7 @@ int switch_keys_core(lr_ckks_plan *pl, int level, int batch, const u64 *cx, long
         const int d0 = i * alpha;
         int d1 = d0 + dec->xalpha[i];
         if (d1 > level + 1) d1 = level + 1;
-        // own-digit limbs are taken from the NTT-domain input (:1579-1584)
-        LR_TRY(run_ewise(cQ, LR_COPY, d1 - d0, batch, cx + (long long)d0 * n, cx_stride, nullptr, 0, dq + (long long)d0 * n, sQ,
-                         nullptr, d0));
+        // own-digit limbs are taken from the NTT-domain input (:1579-1584): the inner product reads them in place
         if (d1 - d0 == alpha && full == i) ++full;
     }
     if (full > 0 && level + 1 - alpha > 0) {
@@ -1314,6 +1312,9 @@ int switch_keys_core(lr_ckks_plan *pl, int level, int batch, const u64 *cx, long
         if (p0_stride != p1_stride) return fail(LR_ERR_SHAPE, "key switch outputs must share their stride");
         K.out_stride = p0_stride;
         K.lp = cQ->d_lp;
+        K.own = cx;
+        K.own_stride = cx_stride;
+        K.alpha = alpha;
         LR_HIP(launch_keymac(K, level + 1, batch, cQ->stream));
         K.c2 = pl->c2QiP.d;
         K.c2_digit_stride = dP;
@@ -1323,6 +1324,9 @@ int switch_keys_core(lr_ckks_plan *pl, int level, int batch, const u64 *cx, long
         K.out1 = pool3P;
         K.out_stride = sP;
         K.lp = cP->d_lp;
+        K.own = nullptr;
+        K.own_stride = 0;
+        K.alpha = 0;
         LR_HIP(launch_keymac(K, nP, batch, cQ->stream));
     }
     // ModDownSplitedNTTPQ x2, :1556-1557; the two calls share every launch up to the final subtract-multiply

@@ -112,6 +112,11 @@ struct KeyMacLaunch {
     long long out_stride;
     int n, beta;
     const LimbParams *lp;
+    // limbs [i*alpha, (i+1)*alpha) of digit i are the NTT-domain input itself (ckks/evaluator.go:1579-1584):
+    // read from `own` (poly stride own_stride) instead of a copy inside c2; alpha = 0 disables
+    const u64 *own;
+    long long own_stride;
+    int alpha;
 };
 hipError_t launch_keymac(const KeyMacLaunch &L, int limbs, int batch, hipStream_t stream);
 

@@ -255,11 +255,13 @@ __global__ __launch_bounds__(256) void keymac_kernel(KeyMacLaunch L) {
     ulonglong2 *po0 = reinterpret_cast<ulonglong2 *>(L.out0 + b * L.out_stride + row);
     ulonglong2 *po1 = reinterpret_cast<ulonglong2 *>(L.out1 + b * L.out_stride + row);
     const long long cd = L.c2_digit_stride >> 1, kd = L.key_poly_stride >> 1;   // in 16-byte units
+    const ulonglong2 *pown = L.alpha > 0 ? reinterpret_cast<const ulonglong2 *>(L.own + b * L.own_stride + row) : nullptr;
+    const int own_digit = L.alpha > 0 ? limb / L.alpha : -1;
     const int pairs = L.n >> 1;
     for (int e = blockIdx.x * 256 + threadIdx.x; e < pairs; e += gridDim.x * 256) {
         u64 a0x = 0, a0y = 0, a1x = 0, a1y = 0;
         for (int i = 0; i < L.beta; ++i) {
-            const ulonglong2 c = ld_stream(pc + e + i * cd);
+            const ulonglong2 c = ld_stream(i == own_digit ? pown + e : pc + e + i * cd);
             const ulonglong2 k0 = pk[e + (2 * i) * kd], k1 = pk[e + (2 * i + 1) * kd];
             a0x += mred(k0.x, c.x, lp.q, lp.qinv);
             a0y += mred(k0.y, c.y, lp.q, lp.qinv);
