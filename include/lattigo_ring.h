@@ -231,6 +231,17 @@ int lr_ckks_mulrelin(lr_ckks_plan *plan, int level, const lr_poly *ct0_c0, const
                      lr_poly *out_c0, lr_poly *out_c1);
 /* Rescale, one level (ckks/evaluator.go:933-968 inner loop): DivRoundByLastModulusNTT on both components. */
 int lr_ckks_rescale(lr_ckks_plan *plan, lr_poly *c0, lr_poly *c1);
+/* permuteNTT (ckks/evaluator.go:1448-1468), the body of RotateColumns with a specific rotation key (:1222) and of
+ * Conjugate (:1446): both components are permuted by the Galois element `gen` (what ring.PermuteNTTIndex turns
+ * into RotationKeys.permuteNTTLeftIndex[k] / permuteNTTConjugateIndex), the second is key-switched with `rotkey`
+ * (a SwitchingKey image as for lr_ckks_switch_keys).  out may alias the input. */
+int lr_ckks_rotate(lr_ckks_plan *plan, int level, const lr_poly *c0, const lr_poly *c1, uint64_t gen,
+                   const lr_poly *rotkey, lr_poly *out_c0, lr_poly *out_c1);
+/* RotateHoisted + switchKeyHoisted (ckks/evaluator.go:1252-1391): n_rot rotations of one ciphertext share the
+ * digit decomposition of its second component.  gens[r], rotkeys[r] -> (outs_c0[r], outs_c1[r]); not in place. */
+int lr_ckks_rotate_hoisted(lr_ckks_plan *plan, int level, const lr_poly *c0, const lr_poly *c1, int n_rot,
+                           const uint64_t *gens, const lr_poly *const *rotkeys, lr_poly *const *outs_c0,
+                           lr_poly *const *outs_c1);
 
 /* bfv.Evaluator.Mul = tensorAndRescale (bfv/evaluator.go:467,278) for two degree-1 ciphertexts, device-resident
  * for a whole batch.  lr_bfv_plan owns what bfv.NewEvaluator builds for it: baseconverterQ1Q2 =

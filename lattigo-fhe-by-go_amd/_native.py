@@ -74,6 +74,8 @@ SYMBOLS = {
     "lr_ckks_switch_keys": [vp, i32, vp, vp, vp, vp],
     "lr_ckks_mulrelin": [vp, i32, vp, vp, vp, vp, vp, vp, vp],
     "lr_ckks_rescale": [vp, vp, vp],
+    "lr_ckks_rotate": [vp, i32, vp, vp, u64, vp, vp, vp],
+    "lr_ckks_rotate_hoisted": [vp, i32, vp, vp, i32, u64p, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)],
     "lr_bfv_plan_create": [vp, vp, u64, i32, C.POINTER(vp)],
     "lr_bfv_plan_destroy": [vp],
     "lr_bfv_mul": [vp, vp, vp, vp, vp, vp, vp, vp],

@@ -205,7 +205,7 @@ struct lr_ckks_plan {
     lr_bext *bext = nullptr;
     lr_decomposer *dec = nullptr;
     int max_batch = 0;
-    Pool c2QiQ, c2QiP, poolPP, c2, c0, c1, c2x, q1, q2;
+    Pool c2QiQ, c2QiP, poolPP, c2, c0, c1, c2x, q1, q2, permQ, permP;
 };
 
 // ------------------------------------------------------------------------------------------
@@ -1245,24 +1245,37 @@ struct KeySwitchEpilogue {
     long long plus_stride;
 };
 
-int switch_keys_core(lr_ckks_plan *pl, int level, int batch, const u64 *cx, long long cx_stride, const lr_poly *evk, u64 *p0,
-                     long long p0_stride, u64 *p1, long long p1_stride, const KeySwitchEpilogue *fin = nullptr) {
+int run_permute_ntt(lr_context *c, int limbs, int batch, const u64 *in, long long in_stride, u64 *out, long long out_stride,
+                    u64 gen) {
+    GaloisLaunch L;
+    L.in = in;
+    L.out = out;
+    L.in_stride = in_stride;
+    L.out_stride = out_stride;
+    L.n = (int)c->h.N;
+    L.logn = (int)c->h.logN;
+    L.ntt_domain = 1;
+    L.gen = gen & ((c->h.N << 1) - 1);
+    L.lp = c->d_lp;
+    LR_HIP(launch_permute(L, limbs, batch, c->stream));
+    return LR_OK;
+}
+
+// Digit decomposition of switchKeysInPlace / RotateHoisted (ckks/evaluator.go:1503-1510, 1258-1272, 1561-1591):
+// pl->c2QiQ = [beta][batch][|Q|][N], pl->c2QiP = [beta][batch][|P|][N], both in the NTT domain.  The limbs a digit
+// owns are the NTT-domain input itself; they are copied into the digit only when `copy_own` (the hoisted path
+// permutes whole digits), otherwise the inner product reads them in place.
+int ks_decompose(lr_ckks_plan *pl, int level, int batch, const u64 *cx, long long cx_stride, bool copy_own) {
     lr_context *cQ = pl->cQ, *cP = pl->cP;
     lr_decomposer *dec = pl->dec;
     const int nQ = cQ->h.L(), nP = cP->h.L(), n = (int)cQ->h.N;
     const int alpha = dec->alpha;
     const int beta = (level + 1 + alpha - 1) / alpha;  // :1508
-    if (evk->batch < 2 * beta || evk->limbs < nQ + nP) return fail(LR_ERR_SHAPE, "evaluation key: need batch >= 2*beta and |Q|+|P| limbs");
     const long long sQ = (long long)nQ * n, sP = (long long)nP * n;
-    // every digit's decomposition is kept ([digit][batch][limb][N]) so that the inner product with the key runs
-    // as ONE pass over all digits (keymac_kernel) instead of beta read-modify-write rounds over the accumulators
     const long long dQ = (long long)batch * sQ, dP = (long long)batch * sP;
     LR_TRY(pl->c2QiQ.ensure(cQ, (size_t)beta * dQ));
     LR_TRY(pl->c2.ensure(cQ, (size_t)batch * sQ));
     LR_TRY(pl->c2QiP.ensure(cQ, (size_t)beta * dP));
-    LR_TRY(pl->poolPP.ensure(cQ, (size_t)2 * batch * sP));   // P parts of both accumulators, [2][batch][|P|][N]
-    u64 *const pool2P = pl->poolPP.d, *const pool3P = pl->poolPP.d + (long long)batch * sP;
-
     Rows cxr{const_cast<u64 *>(cx), cx_stride, 0, 1};
     Rows c2r{pl->c2.d, sQ, 0, 1};
     LR_TRY(run_ntt(cQ, true, cxr, c2r, 0, 1, level + 1, batch));  // :1503
@@ -1274,7 +1287,9 @@ int switch_keys_core(lr_ckks_plan *pl, int level, int batch, const u64 *cx, long
         const int d0 = i * alpha;
         int d1 = d0 + dec->xalpha[i];
         if (d1 > level + 1) d1 = level + 1;
-        // own-digit limbs are taken from the NTT-domain input (:1579-1584): the inner product reads them in place
+        if (copy_own)   // :1579-1584
+            LR_TRY(run_ewise(cQ, LR_COPY, d1 - d0, batch, cx + (long long)d0 * n, cx_stride, nullptr, 0, dq + (long long)d0 * n,
+                             sQ, nullptr, d0));
         if (d1 - d0 == alpha && full == i) ++full;
     }
     if (full > 0 && level + 1 - alpha > 0) {
@@ -1296,14 +1311,31 @@ int switch_keys_core(lr_ckks_plan *pl, int level, int batch, const u64 *cx, long
         Rows pr{pl->c2QiP.d, sP, 0, 1};                                          // :1590, every digit's P rows
         LR_TRY(run_ntt(cP, false, pr, pr, 0, 1, nP, beta * batch));
     }
-    // :1511-1552  sum over the digits of evakey[i][0/1] (*) c2_i, canonical, Q part then P part
+    return LR_OK;
+}
+
+// Inner product of the digits with a switching key and the two ModDownSplitedNTTPQ (:1511-1557 / :1339-1387).
+// digQ/digP: [beta][batch][|Q| resp. |P|][N]; own/own_stride: where the digits' own limbs live when they were not
+// copied (nullptr: inside digQ).
+int ks_accumulate(lr_ckks_plan *pl, int level, int batch, const u64 *digQ, const u64 *digP, const u64 *own, long long own_stride,
+                  const lr_poly *evk, u64 *p0, long long p0_stride, u64 *p1, long long p1_stride, const KeySwitchEpilogue *fin) {
+    lr_context *cQ = pl->cQ, *cP = pl->cP;
+    const int nQ = cQ->h.L(), nP = cP->h.L(), n = (int)cQ->h.N;
+    const int alpha = pl->dec->alpha;
+    const int beta = (level + 1 + alpha - 1) / alpha;
+    if (evk->batch < 2 * beta || evk->limbs < nQ + nP) return fail(LR_ERR_SHAPE, "evaluation key: need batch >= 2*beta and |Q|+|P| limbs");
+    const long long sQ = (long long)nQ * n, sP = (long long)nP * n;
+    const long long dQ = (long long)batch * sQ, dP = (long long)batch * sP;
+    LR_TRY(pl->poolPP.ensure(cQ, (size_t)2 * batch * sP));   // P parts of both accumulators, [2][batch][|P|][N]
+    u64 *const pool2P = pl->poolPP.d, *const pool3P = pl->poolPP.d + (long long)batch * sP;
+    // sum over the digits of evakey[i][0/1] (*) c2_i, canonical, Q part then P part
     {
         KeyMacLaunch K;
         K.key = evk->d;
         K.key_poly_stride = evk->stride();
         K.n = n;
         K.beta = beta;
-        K.c2 = pl->c2QiQ.d;
+        K.c2 = digQ;
         K.c2_digit_stride = dQ;
         K.c2_poly_stride = sQ;
         K.key_limb0 = 0;
@@ -1312,11 +1344,11 @@ int switch_keys_core(lr_ckks_plan *pl, int level, int batch, const u64 *cx, long
         if (p0_stride != p1_stride) return fail(LR_ERR_SHAPE, "key switch outputs must share their stride");
         K.out_stride = p0_stride;
         K.lp = cQ->d_lp;
-        K.own = cx;
-        K.own_stride = cx_stride;
-        K.alpha = alpha;
+        K.own = own;
+        K.own_stride = own_stride;
+        K.alpha = own ? alpha : 0;
         LR_HIP(launch_keymac(K, level + 1, batch, cQ->stream));
-        K.c2 = pl->c2QiP.d;
+        K.c2 = digP;
         K.c2_digit_stride = dP;
         K.c2_poly_stride = sP;
         K.key_limb0 = nQ;
@@ -1329,7 +1361,7 @@ int switch_keys_core(lr_ckks_plan *pl, int level, int batch, const u64 *cx, long
         K.alpha = 0;
         LR_HIP(launch_keymac(K, nP, batch, cQ->stream));
     }
-    // ModDownSplitedNTTPQ x2, :1556-1557; the two calls share every launch up to the final subtract-multiply
+    // ModDownSplitedNTTPQ x2; the two calls share every launch up to the final subtract-multiply
     lr_bext *bx = pl->bext;
     {
         Rows pr{pool2P, sP, 0, 1};
@@ -1352,6 +1384,13 @@ int switch_keys_core(lr_ckks_plan *pl, int level, int batch, const u64 *cx, long
     return LR_OK;
 }
 
+// switchKeysInPlace, ckks/evaluator.go:1475-1558, on raw buffers: cx/p0/p1 have `q_stride` between batch polys
+int switch_keys_core(lr_ckks_plan *pl, int level, int batch, const u64 *cx, long long cx_stride, const lr_poly *evk, u64 *p0,
+                     long long p0_stride, u64 *p1, long long p1_stride, const KeySwitchEpilogue *fin = nullptr) {
+    LR_TRY(ks_decompose(pl, level, batch, cx, cx_stride, false));
+    return ks_accumulate(pl, level, batch, pl->c2QiQ.d, pl->c2QiP.d, cx, cx_stride, evk, p0, p0_stride, p1, p1_stride, fin);
+}
+
 int check_ct(const lr_ckks_plan *pl, int level, const lr_poly *p, int batch) {
     if (!p) return fail(LR_ERR_ARG, "null poly");
     if (p->N != pl->cQ->h.N) return fail(LR_ERR_SHAPE, "ring degree mismatch");
@@ -1372,6 +1411,68 @@ extern "C" int lr_ckks_switch_keys(lr_ckks_plan *pl, int level, const lr_poly *c
     LR_TRY(check_ct(pl, level, p1, batch));
     LR_HIP(hipSetDevice(pl->cQ->device));
     return switch_keys_core(pl, level, batch, cx->d, cx->stride(), evk, p0->d, p0->stride(), p1->d, p1->stride());
+}
+
+// permuteNTT (ckks/evaluator.go:1448-1468): RotateColumns with a specific rotation key / Conjugate.
+// gen = the Galois element (ring.PermuteNTTIndex's `gen^power`); the two trailing Context calls (:1466-1467)
+// ride on the last ModDown pass.
+extern "C" int lr_ckks_rotate(lr_ckks_plan *pl, int level, const lr_poly *c0, const lr_poly *c1, uint64_t gen, const lr_poly *rotkey,
+                              lr_poly *o0, lr_poly *o1) {
+    if (!pl || !c0 || !c1 || !rotkey || !o0 || !o1) return fail(LR_ERR_ARG, "null argument");
+    if (level < 0 || level + 1 > pl->cQ->h.L()) return fail(LR_ERR_SHAPE, "level out of range");
+    const int batch = c0->batch;
+    if (batch > pl->max_batch) return fail(LR_ERR_SHAPE, "batch exceeds the plan's max_batch");
+    for (const lr_poly *p : {c0, c1, (const lr_poly *)o0, (const lr_poly *)o1}) LR_TRY(check_ct(pl, level, p, batch));
+    if (o0->stride() != o1->stride()) return fail(LR_ERR_SHAPE, "output polys must share their stride");
+    lr_context *cQ = pl->cQ;
+    LR_HIP(hipSetDevice(cQ->device));
+    const int n = (int)cQ->h.N, L1 = level + 1;
+    const long long s = (long long)L1 * n;
+    for (Pool *p : {&pl->c0, &pl->c2x, &pl->q1, &pl->q2}) LR_TRY(p->ensure(cQ, (size_t)batch * s));
+    LR_TRY(run_permute_ntt(cQ, L1, batch, c0->d, c0->stride(), pl->c0.d, s, gen));    // :1458
+    LR_TRY(run_permute_ntt(cQ, L1, batch, c1->d, c1->stride(), pl->c2x.d, s, gen));   // :1459
+    KeySwitchEpilogue fin{o0->d, o1->d, o0->stride(), pl->c0.d, nullptr, s};
+    return switch_keys_core(pl, level, batch, pl->c2x.d, s, rotkey, pl->q1.d, s, pl->q2.d, s, &fin);   // :1464-1467
+}
+
+// RotateHoisted + switchKeyHoisted (ckks/evaluator.go:1252-1391): n_rot rotations of one ciphertext share the
+// digit decomposition; per rotation the digits are permuted, multiplied into the rotation key and brought down.
+extern "C" int lr_ckks_rotate_hoisted(lr_ckks_plan *pl, int level, const lr_poly *c0, const lr_poly *c1, int n_rot,
+                                      const uint64_t *gens, const lr_poly *const *rotkeys, lr_poly *const *outs0,
+                                      lr_poly *const *outs1) {
+    if (!pl || !c0 || !c1 || !gens || !rotkeys || !outs0 || !outs1) return fail(LR_ERR_ARG, "null argument");
+    if (n_rot < 0) return fail(LR_ERR_ARG, "negative rotation count");
+    if (level < 0 || level + 1 > pl->cQ->h.L()) return fail(LR_ERR_SHAPE, "level out of range");
+    const int batch = c0->batch;
+    if (batch > pl->max_batch) return fail(LR_ERR_SHAPE, "batch exceeds the plan's max_batch");
+    LR_TRY(check_ct(pl, level, c0, batch));
+    LR_TRY(check_ct(pl, level, c1, batch));
+    lr_context *cQ = pl->cQ, *cP = pl->cP;
+    LR_HIP(hipSetDevice(cQ->device));
+    const int nQ = cQ->h.L(), nP = cP->h.L(), n = (int)cQ->h.N, L1 = level + 1;
+    const int alpha = pl->dec->alpha;
+    const int beta = (L1 + alpha - 1) / alpha;
+    const long long s = (long long)L1 * n, sQ = (long long)nQ * n, sP = (long long)nP * n;
+    for (int r = 0; r < n_rot; ++r) {
+        if (!rotkeys[r] || !outs0[r] || !outs1[r]) return fail(LR_ERR_ARG, "null argument");
+        LR_TRY(check_ct(pl, level, outs0[r], batch));
+        LR_TRY(check_ct(pl, level, outs1[r], batch));
+        if (outs0[r]->stride() != outs1[r]->stride()) return fail(LR_ERR_SHAPE, "output polys must share their stride");
+        if (outs0[r]->d == c0->d || outs1[r]->d == c0->d || outs0[r]->d == c1->d || outs1[r]->d == c1->d)
+            return fail(LR_ERR_ARG, "hoisted rotations are not in place");
+    }
+    LR_TRY(ks_decompose(pl, level, batch, c1->d, c1->stride(), true));                         // :1258-1272
+    for (Pool *p : {&pl->c0, &pl->q1, &pl->q2}) LR_TRY(p->ensure(cQ, (size_t)batch * s));
+    LR_TRY(pl->permQ.ensure(cQ, (size_t)beta * batch * sQ));
+    LR_TRY(pl->permP.ensure(cQ, (size_t)beta * batch * sP));
+    for (int r = 0; r < n_rot; ++r) {
+        LR_TRY(run_permute_ntt(cQ, L1, batch, c0->d, c0->stride(), pl->c0.d, s, gens[r]));     // :1314-1318
+        LR_TRY(run_permute_ntt(cQ, L1, beta * batch, pl->c2QiQ.d, sQ, pl->permQ.d, sQ, gens[r]));   // :1346, all digits
+        LR_TRY(run_permute_ntt(cP, nP, beta * batch, pl->c2QiP.d, sP, pl->permP.d, sP, gens[r]));   // :1347
+        KeySwitchEpilogue fin{outs0[r]->d, outs1[r]->d, outs0[r]->stride(), pl->c0.d, nullptr, s};   // :1389-1390
+        LR_TRY(ks_accumulate(pl, level, batch, pl->permQ.d, pl->permP.d, nullptr, 0, rotkeys[r], pl->q1.d, s, pl->q2.d, s, &fin));
+    }
+    return LR_OK;
 }
 
 extern "C" int lr_ckks_mulrelin(lr_ckks_plan *pl, int level, const lr_poly *a0, const lr_poly *a1, const lr_poly *b0,

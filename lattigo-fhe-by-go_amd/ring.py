@@ -448,6 +448,20 @@ class CkksPlan:
     def Rescale(self, ct):
         check(lib().lr_ckks_rescale(self.h, ct[0].h, ct[1].h))
 
+    def PermuteNTT(self, level, ct0, gen, rotkey, ctOut):
+        """evaluator.permuteNTT (ckks/evaluator.go:1448): RotateColumns with the key of that rotation, or Conjugate.
+        gen: the Galois element whose PermuteNTTIndex the reference stores next to the key."""
+        check(lib().lr_ckks_rotate(self.h, level, ct0[0].h, ct0[1].h, int(gen), rotkey.h, ctOut[0].h, ctOut[1].h))
+
+    def RotateHoisted(self, level, ct0, gens, rotkeys, ctOuts):
+        """evaluator.RotateHoisted (ckks/evaluator.go:1252): ctOuts[r] = rotation of ct0 by the Galois element gens[r]."""
+        n = len(gens)
+        g = (C.c_uint64 * n)(*[int(x) for x in gens])
+        keys = (C.c_void_p * n)(*[k.h.value for k in rotkeys])
+        o0 = (C.c_void_p * n)(*[o[0].h.value for o in ctOuts])
+        o1 = (C.c_void_p * n)(*[o[1].h.value for o in ctOuts])
+        check(lib().lr_ckks_rotate_hoisted(self.h, level, ct0[0].h, ct0[1].h, n, g, keys, o0, o1))
+
 
 class BfvPlan:
     """What bfv.NewEvaluator builds around the ring for Mul (bfv/evaluator.go:89-112) and the tensorAndRescale

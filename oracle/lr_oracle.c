@@ -1050,3 +1050,85 @@ void oc_permute(const oc_context *c, const u64 *in, u64 gen, u64 *out) {
         }
     }
 }
+
+
+/* ---- ckks rotations -------------------------------------------------------------------- */
+/* evaluator.permuteNTT, ckks/evaluator.go:1448-1468 (ct0 != ctOut branch) */
+void oc_ckks_permute_ntt(oc_ckks_plan *p, int level, const u64 *ct, u64 gen, const u64 *evk, u64 *out) {
+    const oc_context *cQ = p->cQ;
+    const u64 N = cQ->N;
+    const size_t s = (size_t)(level + 1) * N;
+    u64 *el0 = (u64 *)calloc(s, 8), *el1 = (u64 *)calloc(s, 8), *p0 = (u64 *)calloc(s, 8), *p1 = (u64 *)calloc(s, 8);
+    oc_permute_ntt(ct, gen, el0, level + 1, N);                                    /* :1458 */
+    oc_permute_ntt(ct + s, gen, el1, level + 1, N);                                /* :1459 */
+    oc_ckks_switch_keys(p, level, el1, evk, p0, p1);                               /* :1464 */
+    oc_ewise(cQ, OC_ADD, level, el0, p0, out, NULL);                               /* :1466 */
+    memcpy(out + s, p1, s * 8);                                                    /* :1467 CopyLvl */
+    free(el0); free(el1); free(p0); free(p1);
+}
+
+/* RotateHoisted (:1252-1289) with switchKeyHoisted (:1292-1391) per rotation */
+void oc_ckks_rotate_hoisted(oc_ckks_plan *p, int level, const u64 *ct, int n_rot, const u64 *gens,
+                            const u64 *const *evks, u64 *out) {
+    const oc_context *cQ = p->cQ, *cP = p->cP;
+    const u64 N = cQ->N;
+    const int nQ = cQ->L, nP = cP->L, nQP = nQ + nP;
+    const size_t s = (size_t)(level + 1) * N, szQ = (size_t)nQ * N, szP = (size_t)nP * N;
+    const int alpha = p->alpha;
+    const int beta = (level + 1 + alpha - 1) / alpha;                              /* :1263 */
+    const u64 *c2ntt = ct + s;
+    u64 *c2inv = (u64 *)calloc(szQ, 8);
+    oc_intt_lvl(cQ, level, c2ntt, c2inv);                                          /* :1260 */
+    u64 *decQ = (u64 *)calloc(szQ * beta, 8), *decP = (u64 *)calloc(szP * beta, 8);
+    for (int i = 0; i < beta; i++)                                                 /* :1268-1272 */
+        decompose_and_split_ntt(p, level, i, c2ntt, c2inv, decQ + szQ * i, decP + szP * i);
+    u64 *permQ = (u64 *)calloc(szQ, 8), *permP = (u64 *)calloc(szP, 8);
+    u64 *pool2Q = (u64 *)calloc(szQ, 8), *pool3Q = (u64 *)calloc(szQ, 8);
+    u64 *pool2P = (u64 *)calloc(szP, 8), *pool3P = (u64 *)calloc(szP, 8);
+    for (int r = 0; r < n_rot; r++) {
+        const u64 gen = gens[r];
+        const u64 *evk = evks[r];
+        u64 *o0 = out + (size_t)r * 2 * s, *o1 = o0 + s;
+        oc_permute_ntt(ct, gen, o0, level + 1, N);                                 /* :1314-1315 */
+        memset(pool2Q, 0, szQ * 8); memset(pool3Q, 0, szQ * 8);                    /* :1320-1326 */
+        memset(pool2P, 0, szP * 8); memset(pool3P, 0, szP * 8);
+        int reduce = 0;
+        for (int i = 0; i < beta; i++) {
+            oc_permute_ntt(decQ + szQ * i, gen, permQ, level + 1, N);              /* :1346 */
+            oc_permute_ntt(decP + szP * i, gen, permP, nP, N);                     /* :1347 */
+            const u64 *k0 = evk + ((size_t)i * 2 + 0) * nQP * N;
+            const u64 *k1 = evk + ((size_t)i * 2 + 1) * nQP * N;
+            oc_ewise(cQ, OC_MUL_MONT_AND_ADD_NOMOD, level, k0, permQ, pool2Q, NULL);   /* :1349 */
+            oc_ewise(cQ, OC_MUL_MONT_AND_ADD_NOMOD, level, k1, permQ, pool3Q, NULL);   /* :1350 */
+            for (int j = 0, ki = nQ; j < nP; j++, ki++) {                            /* :1353-1367 */
+                u64 pj = cP->q[j], qinv = cP->mred[j];
+                const u64 *key0 = k0 + (size_t)ki * N, *key1 = k1 + (size_t)ki * N;
+                const u64 *c2 = permP + (size_t)j * N;
+                u64 *p2 = pool2P + (size_t)j * N, *p3 = pool3P + (size_t)j * N;
+                for (u64 y = 0; y < N; y++) {
+                    p2[y] += oc_mred(key0[y], c2[y], pj, qinv);
+                    p3[y] += oc_mred(key1[y], c2[y], pj, qinv);
+                }
+            }
+            if ((reduce & 7) == 1) {                                                 /* :1369-1374 */
+                oc_ewise(cQ, OC_REDUCE, level, pool2Q, NULL, pool2Q, NULL);
+                oc_ewise(cQ, OC_REDUCE, level, pool3Q, NULL, pool3Q, NULL);
+                oc_ewise(cP, OC_REDUCE, nP - 1, pool2P, NULL, pool2P, NULL);
+                oc_ewise(cP, OC_REDUCE, nP - 1, pool3P, NULL, pool3P, NULL);
+            }
+            reduce++;
+        }
+        if (((reduce - 1) & 7) != 1) {                                               /* :1379-1384 */
+            oc_ewise(cQ, OC_REDUCE, level, pool2Q, NULL, pool2Q, NULL);
+            oc_ewise(cQ, OC_REDUCE, level, pool3Q, NULL, pool3Q, NULL);
+            oc_ewise(cP, OC_REDUCE, nP - 1, pool2P, NULL, pool2P, NULL);
+            oc_ewise(cP, OC_REDUCE, nP - 1, pool3P, NULL, pool3P, NULL);
+        }
+        oc_moddown_split_ntt_pq(p->bext, level, pool2Q, pool2P, pool2Q);             /* :1388 */
+        oc_moddown_split_ntt_pq(p->bext, level, pool3Q, pool3P, pool3Q);             /* :1389 */
+        oc_ewise(cQ, OC_ADD, level, o0, pool2Q, o0, NULL);                           /* :1391 */
+        memcpy(o1, pool3Q, s * 8);                                                   /* :1392 */
+    }
+    free(c2inv); free(decQ); free(decP); free(permQ); free(permP);
+    free(pool2Q); free(pool3Q); free(pool2P); free(pool3P);
+}

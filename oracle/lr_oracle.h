@@ -183,6 +183,13 @@ void oc_ckks_switch_keys(oc_ckks_plan *p, int level, const uint64_t *cx, const u
 void oc_ckks_mulrelin(oc_ckks_plan *p, int level, const uint64_t *ct0, const uint64_t *ct1,
                       const uint64_t *evk, uint64_t *out);
 
+/* permuteNTT (ckks/evaluator.go:1448-1468): ct, out = [2][level+1][N]; gen = Galois element; evk as above. */
+void oc_ckks_permute_ntt(oc_ckks_plan *p, int level, const uint64_t *ct, uint64_t gen, const uint64_t *evk,
+                         uint64_t *out);
+/* RotateHoisted + switchKeyHoisted (:1252-1391): out = [n_rot][2][level+1][N]. */
+void oc_ckks_rotate_hoisted(oc_ckks_plan *p, int level, const uint64_t *ct, int n_rot, const uint64_t *gens,
+                            const uint64_t *const *evks, uint64_t *out);
+
 /* ---- Galois automorphisms: ring/ring_galois.go -------------------------------- */
 void oc_permute_ntt_index(uint64_t gen, uint64_t power, uint64_t N, uint64_t *index);              /* :29  */
 void oc_permute_ntt(const uint64_t *in, uint64_t gen, uint64_t *out, int limbs, uint64_t N);       /* :55  */

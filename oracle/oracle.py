@@ -117,6 +117,8 @@ def lib():
     sig("oc_ckks_plan_free", None, vp)
     sig("oc_ckks_switch_keys", None, vp, i, vp, vp, vp, vp)
     sig("oc_ckks_mulrelin", None, vp, i, vp, vp, vp, vp)
+    sig("oc_ckks_permute_ntt", None, vp, i, vp, u64, vp, vp)
+    sig("oc_ckks_rotate_hoisted", None, vp, i, vp, i, vp, vp, vp)
     sig("oc_bfv_mul", None, vp, u64, vp, vp, vp, vp, vp)
     sig("oc_permute_ntt_index", None, u64, u64, u64, vp)
     sig("oc_permute_ntt", None, vp, u64, vp, i, u64)
@@ -435,6 +437,22 @@ class CkksPlan:
         p1 = np.zeros_like(p0)
         lib().oc_ckks_switch_keys(self.h, level, _ptr(cx), _ptr(evk), _ptr(p0), _ptr(p1))
         return p0, p1
+
+    def permute_ntt(self, level, ct, gen, evk):
+        ct, evk = _arr(ct), _arr(evk)
+        out = np.zeros((2, level + 1, self.cQ.N), dtype=np.uint64)
+        lib().oc_ckks_permute_ntt(self.h, level, _ptr(ct), C.c_uint64(int(gen)), _ptr(evk), _ptr(out))
+        return out
+
+    def rotate_hoisted(self, level, ct, gens, evks):
+        ct = _arr(ct)
+        evks = [_arr(e) for e in evks]
+        n = len(gens)
+        out = np.zeros((n, 2, level + 1, self.cQ.N), dtype=np.uint64)
+        g = (C.c_uint64 * n)(*[int(x) for x in gens])
+        ptrs = (C.c_void_p * n)(*[e.ctypes.data for e in evks])
+        lib().oc_ckks_rotate_hoisted(self.h, level, _ptr(ct), n, g, ptrs, _ptr(out))
+        return out
 
     def mulrelin(self, level, ct0, ct1, evk):
         ct0, ct1, evk = _arr(ct0), _arr(ct1), _arr(evk)

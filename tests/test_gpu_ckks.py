@@ -78,3 +78,55 @@ def test_bfv_mul(gpu_pkg, oracle, name, logn):
         want = oplan.mul(np.stack([a0[b], a1[b]]), np.stack([b0[b], b1[b]]))
         for k in range(3):
             assert np.array_equal(out[k].get()[b], want[k]), (b, k)
+
+
+def _galois(gpu_pkg, N, k):
+    """Galois element of a left rotation by k: 5^k mod 2N (ckks/keygen.go:281-286 GenRot... -> ring.PermuteNTTIndex(GaloisGen, k, N))"""
+    return pow(5, k, 2 * N)
+
+
+@pytest.mark.parametrize("logn,nq,np_,level,k", [(10, 6, 2, 5, 1), (11, 7, 3, 6, 5), (10, 6, 2, 3, 17), (14, 6, 2, 5, 3), (12, 18, 3, 17, 2)])
+def test_rotate_columns(gpu_pkg, oracle, logn, nq, np_, level, k):
+    """evaluator.permuteNTT (ckks/evaluator.go:1448) = RotateColumns with the key of that rotation: both components
+    permuted, the second key-switched, against the oracle's restatement; also in place and the conjugation element"""
+    N, Q, P, cQ, cP, plan, oplan, evk, pevk = _ckks(gpu_pkg, oracle, logn, nq, np_, 2)
+    mk = lambda s: gpu_pkg.sampling.uniform_poly(Q[:level + 1], N, 2, seed=s)
+    a0, a1 = mk(31), mk(32)
+    P_ = lambda x: cQ.NewPolyLvl(level, 2).set(x)
+    for gen in (_galois(gpu_pkg, N, k), 2 * N - 1):
+        ct = (P_(a0), P_(a1))
+        out = (cQ.NewPolyLvl(level, 2), cQ.NewPolyLvl(level, 2))
+        plan.PermuteNTT(level, ct, gen, pevk, out)
+        for b in range(2):
+            want = oplan.permute_ntt(level, np.stack([a0[b], a1[b]]), gen, evk)
+            assert np.array_equal(out[0].get()[b], want[0]), (gen, b)
+            assert np.array_equal(out[1].get()[b], want[1]), (gen, b)
+        got = (out[0].get(), out[1].get())
+        plan.PermuteNTT(level, ct, gen, pevk, ct)       # ctOut == ct0
+        assert np.array_equal(ct[0].get(), got[0]) and np.array_equal(ct[1].get(), got[1])
+
+
+@pytest.mark.parametrize("logn,nq,np_,level", [(10, 6, 2, 5), (11, 7, 3, 6), (10, 6, 2, 2), (14, 6, 2, 4)])
+def test_rotate_hoisted(gpu_pkg, oracle, logn, nq, np_, level):
+    """RotateHoisted (ckks/evaluator.go:1252): several rotations share one digit decomposition; every output equals
+    the oracle's restatement of switchKeyHoisted.  (Hoisted and plain rotations are not bit-identical: permuting the
+    extended digits differs from extending the permuted digit by multiples of the digit modulus, which the reference
+    only compares after decryption.)"""
+    N, Q, P, cQ, cP, plan, oplan, evk0, pevk0 = _ckks(gpu_pkg, oracle, logn, nq, np_, 2)
+    beta = -(-nq // np_)
+    rots = [1, 3, 4]
+    gens = [_galois(gpu_pkg, N, k) for k in rots]
+    evks = [gpu_pkg.sampling.uniform_poly(Q + P, N, 2 * beta, seed=200 + k) for k in rots]
+    pevks = [plan.NewSwitchingKey().set(e) for e in evks]
+    mk = lambda s: gpu_pkg.sampling.uniform_poly(Q[:level + 1], N, 2, seed=s)
+    a0, a1 = mk(41), mk(42)
+    ct = (cQ.NewPolyLvl(level, 2).set(a0), cQ.NewPolyLvl(level, 2).set(a1))
+    outs = [(cQ.NewPolyLvl(level, 2), cQ.NewPolyLvl(level, 2)) for _ in rots]
+    plan.RotateHoisted(level, ct, gens, pevks, outs)
+    for b in range(2):
+        want = oplan.rotate_hoisted(level, np.stack([a0[b], a1[b]]), gens, [e.reshape(beta, 2, nq + np_, N) for e in evks])
+        for r in range(len(rots)):
+            assert np.array_equal(outs[r][0].get()[b], want[r][0]), (r, b)
+            assert np.array_equal(outs[r][1].get()[b], want[r][1]), (r, b)
+    # the first component does not go through the key switch: plain and hoisted agree on everything but the noise term
+    assert not np.array_equal(outs[0][0].get(), outs[1][0].get())
