@@ -97,6 +97,12 @@ int lr_poly_info(const lr_poly *p, uint64_t *N, int *limbs, int *batch, void **d
  * passed through cgo as a whole; the shim passes `limbs` pinned *uint64).  Synchronises. */
 int lr_poly_upload(lr_poly *p, int batch_index, const uint64_t *const *limb_ptrs, int limbs);
 int lr_poly_download(const lr_poly *p, int batch_index, uint64_t *const *limb_ptrs, int limbs);
+/* Poly.MarshalBinary / UnmarshalBinary image of ONE poly (ring/ring_object.go:159-176,222-229,252-270): byte 0 = log2 N,
+ * byte 1 = number of moduli, then limb-major big-endian uint64 (WriteCoeffsTo :146, DecodeCoeffs :197).  The bytes
+ * cross PCIe as they are and are swapped on the device, so serialized ciphertexts and keys go disk -> HBM without
+ * a host pass.  An encoding with fewer moduli than the poly fills its first rows.  Synchronises. */
+int lr_poly_unmarshal(lr_poly *p, int batch_index, const uint8_t *data, size_t len);
+int lr_poly_marshal(const lr_poly *p, int batch_index, uint8_t *data, size_t capacity, size_t *written);
 /* dense host image [batch][limbs][N].  Synchronises. */
 int lr_poly_upload_dense(lr_poly *p, const uint64_t *host, size_t count);
 int lr_poly_download_dense(const lr_poly *p, uint64_t *host, size_t count);

@@ -519,6 +519,52 @@ static int dense_copy(const lr_poly *p, u64 *host, const u64 *host_src, size_t c
     return LR_OK;
 }
 
+// Poly.MarshalBinary / UnmarshalBinary image (ring/ring_object.go:159-176,222-229,252-270): byte 0 = log2 N, byte 1 = number
+// of moduli, then limb-major big-endian words.  The payload goes host <-> device as it is; the byte swap runs on
+// the device.
+extern "C" int lr_poly_unmarshal(lr_poly *p, int batch_index, const uint8_t *data, size_t len) {
+    if (!p || !data) return fail(LR_ERR_ARG, "null argument");
+    if (batch_index < 0 || batch_index >= p->batch) return fail(LR_ERR_SHAPE, "batch index out of range");
+    if (len < 2) return fail(LR_ERR_ARG, "error : invalid polynomial encoding");
+    const unsigned logn = data[0];
+    const int limbs = data[1];
+    if (logn > 63 || ((u64)1 << logn) != p->N) return fail(LR_ERR_SHAPE, "encoded degree differs from the poly's");
+    if (limbs > p->limbs) return fail(LR_ERR_SHAPE, "encoding has more moduli than the poly");
+    const size_t words = (size_t)limbs * p->N;
+    if (len - 2 != words * 8) return fail(LR_ERR_ARG, "error : invalid polynomial encoding");   // :262-264
+    LR_HIP(hipSetDevice(p->device));
+    u64 *stage = nullptr;
+    LR_HIP(hipMalloc((void **)&stage, words * 8 + 8));
+    hipError_t e = hipMemcpyAsync(stage, data + 2, words * 8, hipMemcpyHostToDevice, p->stream);
+    if (e == hipSuccess) e = launch_bswap(stage, p->d + (long long)batch_index * p->stride(), words, p->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(p->stream);
+    (void)hipFree(stage);
+    LR_HIP(e);
+    return LR_OK;
+}
+
+extern "C" int lr_poly_marshal(const lr_poly *p, int batch_index, uint8_t *data, size_t capacity, size_t *written) {
+    if (!p || !data) return fail(LR_ERR_ARG, "null argument");
+    if (batch_index < 0 || batch_index >= p->batch) return fail(LR_ERR_SHAPE, "batch index out of range");
+    if (p->limbs > 255) return fail(LR_ERR_UNSUPPORTED, "the encoding holds the number of moduli in one byte");
+    const size_t words = (size_t)p->limbs * p->N;
+    if (capacity < words * 8 + 2) return fail(LR_ERR_ARG, "Data array is too small to write ring.Poly");   // :164-167
+    unsigned logn = 0;
+    while (((u64)1 << logn) < p->N) ++logn;
+    data[0] = (uint8_t)logn;                                                                              // :168
+    data[1] = (uint8_t)p->limbs;                                                                          // :169
+    LR_HIP(hipSetDevice(p->device));
+    u64 *stage = nullptr;
+    LR_HIP(hipMalloc((void **)&stage, words * 8 + 8));
+    hipError_t e = launch_bswap(p->d + (long long)batch_index * p->stride(), stage, words, p->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(data + 2, stage, words * 8, hipMemcpyDeviceToHost, p->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(p->stream);
+    (void)hipFree(stage);
+    LR_HIP(e);
+    if (written) *written = words * 8 + 2;
+    return LR_OK;
+}
+
 extern "C" int lr_poly_upload_dense(lr_poly *p, const uint64_t *host, size_t count) {
     if (!p || !host) return fail(LR_ERR_ARG, "null argument");
     return dense_copy(p, nullptr, host, count);

@@ -120,6 +120,9 @@ struct KeyMacLaunch {
 };
 hipError_t launch_keymac(const KeyMacLaunch &L, int limbs, int batch, hipStream_t stream);
 
+// Poly.MarshalBinary payload (ring/ring_object.go:146-156,197-207): big-endian words <-> device rows
+hipError_t launch_bswap(const u64 *in, u64 *out, size_t words, hipStream_t stream);
+
 // ring/ring_galois.go
 struct GaloisLaunch {
     const u64 *in;

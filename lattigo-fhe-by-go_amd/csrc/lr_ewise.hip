@@ -188,6 +188,20 @@ __global__ __launch_bounds__(256) void tensor_kernel(TensorLaunch L) {
     }
 }
 
+__global__ __launch_bounds__(256) void bswap_kernel(const u64 *in, u64 *out, size_t words) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < words; i += (size_t)gridDim.x * 256)
+        out[i] = __builtin_bswap64(in[i]);
+}
+
+hipError_t launch_bswap(const u64 *in, u64 *out, size_t words, hipStream_t stream) {
+    if (words == 0) return hipSuccess;
+    size_t blocks = (words + 255) / 256;
+    if (blocks > 65535) blocks = 65535;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(bswap_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, in, out, words);
+    return hipGetLastError();
+}
+
 hipError_t launch_tensor(const TensorLaunch &L, int limbs, int batch, hipStream_t stream) {
     if (limbs <= 0 || batch <= 0) return hipSuccess;
     const int pairs = L.n >> 1;

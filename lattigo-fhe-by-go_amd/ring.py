@@ -90,6 +90,19 @@ class Poly:
         check(lib().lr_poly_download_dense(self.h, out.ctypes.data_as(C.c_void_p), out.size))
         return out[0] if self.batch == 1 else out
 
+    def UnmarshalBinary(self, data, batch_index=0):
+        """Poly.UnmarshalBinary (ring/ring_object.go:252): the big-endian image goes to the device as it is."""
+        data = bytes(data)
+        check(lib().lr_poly_unmarshal(self.h, batch_index, data, len(data)))
+        return self
+
+    def MarshalBinary(self, batch_index=0):
+        """Poly.MarshalBinary (ring/ring_object.go:222)."""
+        buf = (C.c_uint8 * (2 + 8 * self.limbs * self.N))()
+        n = C.c_size_t(0)
+        check(lib().lr_poly_marshal(self.h, batch_index, buf, len(buf), C.byref(n)))
+        return bytes(buf[:n.value])
+
     def set_limb_slices(self, batch_index, limb_arrays):
         """Go boundary form: one independent array per limb (``[][]uint64``)."""
         arrs = [np.ascontiguousarray(x, dtype=np.uint64) for x in limb_arrays]

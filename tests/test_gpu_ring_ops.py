@@ -260,3 +260,25 @@ def test_galois(gpu_pkg, oracle, logn):
     assert np.array_equal(a.get(), bb.get())
     with pytest.raises(ring.LatticeRingError):
         ring.PermuteNTT(ctx, px, gen, px)          # "Careful, not inplace!"
+
+
+def test_marshal_binary_round_trip(gpu_pkg):
+    """Poly.MarshalBinary / UnmarshalBinary (ring/ring_object.go:222,252): log2 N, number of moduli, limb-major
+    big-endian words -- checked against an independent numpy encoding, both directions, plus the reference's
+    length check"""
+    N, moduli = 1 << 10, list(gpu_pkg.params.Qi60()[-3:])
+    ctx = gpu_pkg.ring.NewContextWithParams(N, moduli)
+    x = gpu_pkg.sampling.uniform_poly(moduli, N, 2, seed=13)
+    p = ctx.NewPoly(2).set(x)
+    for b in range(2):
+        want = bytes([10, 3]) + x[b].astype(">u8").tobytes()
+        assert p.MarshalBinary(b) == want
+    q = ctx.NewPoly(2)
+    q.UnmarshalBinary(bytes([10, 3]) + x[1].astype(">u8").tobytes(), 0)
+    q.UnmarshalBinary(bytes([10, 2]) + x[0][:2].astype(">u8").tobytes(), 1)     # fewer moduli: first rows only
+    got = q.get()
+    assert np.array_equal(got[0], x[1]) and np.array_equal(got[1][:2], x[0][:2])
+    with pytest.raises(gpu_pkg._native.LatticeRingError):
+        q.UnmarshalBinary(bytes([10, 3]) + x[1].astype(">u8").tobytes()[:-8], 0)
+    with pytest.raises(gpu_pkg._native.LatticeRingError):
+        q.UnmarshalBinary(bytes([11, 3]) + x[1].astype(">u8").tobytes(), 0)
