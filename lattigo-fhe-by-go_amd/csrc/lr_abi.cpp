@@ -609,7 +609,7 @@ int run_ntt(lr_context *c, bool inverse, Rows in, Rows out, int mod0, int mod_st
     a.sub_log = 0;
     a.hole = hole;
     a.group = group;
-    a.pad = 0;
+    a.fuse_top = 0;
     a.batch = batch;
     a.lp = c->d_lp;
     a.tw = inverse ? c->d_inv : c->d_fwd;

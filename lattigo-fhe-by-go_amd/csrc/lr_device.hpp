@@ -47,7 +47,8 @@ struct NttLaunch {
     // [g*hole, (g+1)*hole): item = i + (i >= g*hole ? hole : 0), i < n_items.  hole = 0: plain launch.
     int hole;
     int group;
-    int pad;
+    int fuse_top;               // sub_log = 1, forward, out of place: the sub-transforms compute the stage over bit 15 while
+                                // loading (each reads both halves of the limb), no separate streaming pass
 };
 static_assert(sizeof(NttLaunch) == 104, "NttLaunch layout is shared with asmgen/gen_ntt.py (fields are read at fixed offsets)");
 

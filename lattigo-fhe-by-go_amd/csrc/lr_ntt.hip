@@ -313,8 +313,22 @@ __global__ __launch_bounds__(1 << Plan<LOGN>::LOGT, 4) void ntt_fwd_kernel(NttLa
     const int t = threadIdx.x;
 
     u64 x[RA];
+    if (LOGN == 15 && a.sub_log == 1 && a.fuse_top) {
+        // N = 2^16, out of place: sub-block 0 continues with X = U + V*psi[1], sub-block 1 with Y = U - V*psi[1] of the
+        // stage over bit 15 (U from the low half of the limb, V from the high half); both blocks read both halves
+        const int blk = (int)it.sub.hroot - 2;
+        const u64 *lo = it.src - (long long)blk * N, *hi = lo + N;
+        const Twiddle w1 = it.tw[1];
 #pragma unroll
-    for (int k = 0; k < RA; ++k) x[k] = ld_stream(it.src + k * S + t);   // uniform row base (SGPR) + one lane offset
+        for (int k = 0; k < RA; ++k) {
+            const u64 U = bred_add(ld_stream(lo + k * S + t), q, it.lp.bred_hi);
+            const u64 r = mul_shoup_lazy(ld_stream(hi + k * S + t), w1.x, w1.y, q);   // [0,4q) for any 64-bit V
+            x[k] = blk ? U + q4 - r : U + r;                                             // < 5q
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < RA; ++k) x[k] = ld_stream(it.src + k * S + t);   // uniform row base (SGPR) + one lane offset
+    }
     // The first stage needs U < 8q; V may be any 64-bit value.  The reference accepts inputs
     // >= q (ring/ring_scaling.go:19,102), so the U operands are reduced exactly.
 #pragma unroll
@@ -536,6 +550,18 @@ hipError_t launch_ntt(const NttLaunch &a, int logn, bool inverse, int mode, hipS
         const dim3 tgrid(64, (unsigned)(a.n_items * a.batch)), tblock(256);
         sub.sub_log = 1;
         if (!inverse) {
+            // out of place (no byte of the input rows is an output row): one pass, the sub-transforms do the top stage
+            const long long n_full = 1ll << 16;
+            const long long last = (long long)(a.n_items - 1 + (a.hole > 0 ? a.hole : 0));
+            const u64 *in_lo = a.in + (long long)a.in_limb0 * n_full;
+            const u64 *in_hi = a.in + (long long)(a.batch - 1) * a.in_poly_stride + ((long long)a.in_limb0 + last * a.in_limb_step + 1) * n_full;
+            const u64 *out_lo = a.out + (long long)a.out_limb0 * n_full;
+            const u64 *out_hi = a.out + (long long)(a.batch - 1) * a.out_poly_stride + ((long long)a.out_limb0 + last * a.out_limb_step + 1) * n_full;
+            const bool positive = a.in_poly_stride >= 0 && a.out_poly_stride >= 0 && a.in_limb_step >= 0 && a.out_limb_step >= 0;
+            if (positive && (in_hi <= out_lo || out_hi <= in_lo)) {
+                sub.fuse_top = 1;
+                return launch_big<15>(sub, false, mode, stream);
+            }
             (void)hipGetLastError();
             hipLaunchKernelGGL(ntt_top_kernel, tgrid, tblock, 0, stream, top, 16, 0);
             hipError_t e = hipGetLastError();

@@ -8,7 +8,7 @@ pytestmark = pytest.mark.gpu
 
 def _ckks(gpu_pkg, oracle, logn, nq, np_, batch, max_batch=None):
     N = 1 << logn
-    _, Qf, Pf = gpu_pkg.params.ckks_moduli("PN15QP880")
+    _, Qf, Pf = gpu_pkg.params.ckks_moduli("PN16QP1761" if logn == 16 else "PN15QP880")   # NTT-friendly up to 2^logN
     Q, P = Qf[:nq], Pf[:np_]
     ring = gpu_pkg.ring
     cQ, cP = ring.NewContextWithParams(N, Q), ring.NewContextWithParams(N, P)
@@ -36,7 +36,8 @@ def test_switch_keys(gpu_pkg, oracle, logn, nq, np_, level):
         assert np.array_equal(p1.get()[b], w1)
 
 
-@pytest.mark.parametrize("logn,nq,np_,level", [(10, 6, 2, 5), (12, 18, 3, 17), (11, 18, 3, 9)])
+# (16, 5, 2, 4): BASELINE config 5's degree (N = 2^16: two-pass NTT) on a short modulus chain
+@pytest.mark.parametrize("logn,nq,np_,level", [(10, 6, 2, 5), (12, 18, 3, 17), (11, 18, 3, 9), (15, 5, 2, 4), (16, 5, 2, 4)])
 def test_mulrelin_and_rescale(gpu_pkg, oracle, logn, nq, np_, level):
     N, Q, P, cQ, cP, plan, oplan, evk, pevk = _ckks(gpu_pkg, oracle, logn, nq, np_, 2)
     mk = lambda s: gpu_pkg.sampling.uniform_poly(Q[:level + 1], N, 2, seed=s)
