@@ -25,15 +25,18 @@ class GenInv(Gen):
     """mode 1: every modulus in (2^33, 2^60], bound B = 8q as described above;
        mode 0: moduli up to 2^61: B = 4q and every butterfly corrects."""
 
-    def __init__(self, logn, mode=1):
+    def __init__(self, logn, mode=1, threads=1024):
         assert mode in (0, 1)
-        super().__init__(logn, mode)
+        super().__init__(logn, mode, threads)
         self.Q8 = self.Q4                       # s[18:19] holds the bound B here
         self.NQ2 = s(22, 2)                     # -2q (the Barrett constant is not used by the inverse)
         self.LP = s(0, 2)                       # LimbParams pointer (kernarg pointer is dead after the prologue)
         # pass A keeps X[k]; the LDS phase works in v0..v31, so the first half is parked in v32..v63
         if self.HALVES == 2:
-            self.X = [v(32 + 2 * k, 2) for k in range(16)] + [v(2 * k, 2) for k in range(16)]
+            for c in range(self.C):
+                for k in range(self.RA):
+                    h, r = divmod(k, self.SPH)
+                    self.X[c * self.RA + k] = v(32 * (1 - h) + 2 * (c * self.SPH + r), 2)
 
     # ------------------------------------------------------------------ arithmetic
     def ops_modmul_inplace(self, ts, V, tw):
@@ -274,10 +277,14 @@ class GenInv(Gen):
         e("v_lshrrev_b32", a2, 4, self.TID)
         e("v_lshlrev_b32", a2, 4, a2)
         e("v_lshl_add_u32", a0, self.TID, 3, a2)              # slot(t) * 8
-        e("v_add_u32", a1, 8 * 9216, a0)
-        for kk in range(self.RH):
-            base, off = (a0, kk * 9216) if kk < 8 else (a1, (kk - 8) * 9216)
-            e("ds_read_b64", self.X[half * self.RH + kk], base, offset=off)
+        e("v_add_u32", a1, 8 * 9216 if self.C == 1 else 4608, a0)
+        for c in range(self.C):
+            for kk in range(self.SPH):
+                if self.C == 1:
+                    base, off = (a0, kk * 9216) if kk < 8 else (a1, (kk - 8) * 9216)
+                else:
+                    base, off = (a0 if c == 0 else a1), kk * 9216
+                e("ds_read_b64", self.X[c * self.RA + self.SPH * half + kk], base, offset=off)
         if half + 1 < self.HALVES:
             e("s_waitcnt", "lgkmcnt(0)")
             e("s_barrier")
@@ -328,7 +335,8 @@ class GenInv(Gen):
                     tw = tuple(s(buf + 4 * (j - j0) + i) for i in range(4))
                     for i in range(1 << b):
                         k0 = (j << (b + 1)) | i
-                        blist.append((X[k0], X[k0 | (1 << b)], tw, self.corr(b, k0)))
+                        for col in range(self.C):
+                            blist.append((X[col * RA + k0], X[col * RA + (k0 | (1 << b))], tw, self.corr(b, k0)))
                 self.butterflies(blist)
                 if n + 2 < nchunks:
                     self.chunk_load(n + 2)
@@ -342,7 +350,8 @@ class GenInv(Gen):
                         tw = tuple(s(buf + 4 * ((1 << c) + j) + i) for i in range(4))
                         for i in range(1 << b):
                             k0 = (j << (b + 1)) | i
-                            blist.append((X[k0], X[k0 | (1 << b)], tw, self.corr(b, k0)))
+                            for col in range(self.C):
+                                blist.append((X[col * RA + k0], X[col * RA + (k0 | (1 << b))], tw, self.corr(b, k0)))
                     self.butterflies(blist)
                 self.low_buf = buf
             else:
@@ -352,15 +361,19 @@ class GenInv(Gen):
                 b = A - 1
                 items = []
                 for i in range(1 << b):
-                    items.append(lambda ts, U=X[i], V=X[i | (1 << b)]: self.ops_last(ts, U, V, tw_n, tw_wn))
+                    for col in range(self.C):
+                        items.append(lambda ts, U=X[col * RA + i], V=X[col * RA + (i | (1 << b))]: self.ops_last(ts, U, V, tw_n, tw_wn))
                 self.zip_emit(items)
 
     def store_columns(self):
         e = self.e
-        self.c("coalesced store of the column {k*S + t}")
+        self.c("coalesced store of the columns {k*S + t + c*T}")
         e("v_lshlrev_b32", self.GOFF, 3, self.TID)
+        if self.C == 2:
+            e("v_add_u32", self.A_[2], self.T * 8, self.GOFF)
         for k in range(self.RA):
-            e("global_store_dwordx2", self.GOFF, self.X[k], self.DST, hint="nt")
+            for col in range(self.C):
+                e("global_store_dwordx2", self.GOFF if col == 0 else self.A_[2], self.X[col * self.RA + k], self.DST, hint="nt")
             e("s_add_u32", self.DST.lo(), self.DST.lo(), self.S * 8)
             e("s_addc_u32", self.DST.hi(), self.DST.hi(), 0)
 
@@ -385,14 +398,16 @@ class GenInv(Gen):
         return self.p
 
 
-def selftest(logn):
+def selftest(logn, threads=1024):
     import gen_ntt
-    return gen_ntt.selftest(logn, inverse=True)
+    return gen_ntt.selftest(logn, inverse=True, threads=threads)
 
 
 if __name__ == "__main__":
     logn = int(sys.argv[1])
     if len(sys.argv) > 2 and sys.argv[2] == "--selftest":
-        sys.exit(0 if selftest(logn) else 1)
+        sys.exit(0 if selftest(logn, int(sys.argv[3]) if len(sys.argv) > 3 else 1024) else 1)
     mode = int(sys.argv[3]) if len(sys.argv) > 3 else 1
-    open(sys.argv[2], "w").write(kernel_text_for(GenInv(logn, mode), "lr_ntt_inv%d_m%d" % (logn, mode)))
+    threads = int(sys.argv[4]) if len(sys.argv) > 4 else 1024
+    name = "lr_ntt_inv%d%s_m%d" % (logn, "x" if threads == 512 else "", mode)
+    open(sys.argv[2], "w").write(kernel_text_for(GenInv(logn, mode, threads), name))

@@ -28,23 +28,33 @@ class Gen:
          2: q <  2^57, no corrections at all (15 stages x 4q of growth stay below 2^64);
          0: q <  2^61, U <- U - 4q (if U >= 4q) before every stage."""
 
-    def __init__(self, logn, mode=1):
-        assert logn in (14, 15) and mode in (0, 1, 2)
+    def __init__(self, logn, mode=1, threads=1024):
+        assert logn in (14, 15) and mode in (0, 1, 2) and threads in (512, 1024)
         self.mode = mode
         self.logn = logn
         self.N = 1 << logn
+        self.T = threads              # 1024, or 512 for N = 2^14: half the LDS and registers, two workgroups per CU
+        self.WAVES = threads // 64
         self.A = logn - 10            # bits consumed by pass A
-        self.RA = 1 << self.A         # coefficients per thread
-        self.S = self.N >> self.A     # = T
-        self.HALVES = self.RA // 16
-        self.M = self.N // self.HALVES
+        self.RA = 1 << self.A         # rows k of a column {k*S + t}
+        self.S = self.N >> self.A     # row length = 1024 = size of the sub-transforms the LDS phase works on
+        self.C = self.S // self.T     # columns per thread (t and t + T)
+        self.NX = self.C * self.RA    # coefficients per thread
+        self.HALVES = self.NX // 16
+        self.SPH = self.RA // self.HALVES   # sub-transforms resident in LDS at a time: one per wave
+        self.M = self.SPH * self.S    # coefficients of one LDS image
         self.RH = 16
-        assert self.S == T and self.M == 16384
+        assert self.S == 1024 and self.SPH == self.WAVES and self.NX in (16, 32)
         self.p = Program()
         self.pos = 0                  # issue position for the carry hazard tracker
         self.carry_pos = {}
-        # ---- VGPR map
-        self.X = [v(2 * k, 2) for k in range(self.RA)]
+        # ---- VGPR map.  X[c*RA + k] = coefficient k*S + t + c*T; the values of LDS image h (rows SPH*h .. SPH*h+SPH-1
+        # of every column) sit in v[32h .. 32h+31]
+        self.X = [None] * self.NX
+        for c in range(self.C):
+            for k in range(self.RA):
+                h, r = divmod(k, self.SPH)
+                self.X[c * self.RA + k] = v(32 * h + 2 * (c * self.SPH + r), 2)
         base = 64
 
         class TS:
@@ -271,13 +281,17 @@ class Gen:
 
     def prologue_tail(self):
         e = self.e
-        self.c("coalesced load of the column {k*S + t}")
-        # order 0, RA/2, 1, RA/2+1, ...: the first-stage butterflies can start after two loads
+        self.c("coalesced load of the columns {k*S + t + c*T}")
+        # order 0, RA/2, 1, RA/2+1, ... (per column): the first-stage butterflies can start after two loads
         e("s_add_u32", self.TMP.lo(), self.SRC.lo(), (self.RA // 2) * self.S * 8)
         e("s_addc_u32", self.TMP.hi(), self.SRC.hi(), 0)
+        if self.C == 2:
+            e("v_add_u32", self.A_[2], self.T * 8, self.GOFF)
         for k in range(self.RA // 2):
-            e("global_load_dwordx2", self.X[k], self.GOFF, self.SRC, hint="nt")
-            e("global_load_dwordx2", self.X[k + self.RA // 2], self.GOFF, self.TMP, hint="nt")
+            for c in range(self.C):
+                off = self.GOFF if c == 0 else self.A_[2]
+                e("global_load_dwordx2", self.X[c * self.RA + k], off, self.SRC, hint="nt")
+                e("global_load_dwordx2", self.X[c * self.RA + k + self.RA // 2], off, self.TMP, hint="nt")
             for ptr in (self.SRC, self.TMP):
                 e("s_add_u32", ptr.lo(), ptr.lo(), self.S * 8)
                 e("s_addc_u32", ptr.hi(), ptr.hi(), 0)
@@ -337,11 +351,12 @@ class Gen:
                 for i in range(1 << b):
                     k0 = (j << (b + 1)) | i
                     k1 = k0 | (1 << b)
-                    blist.append((self.X[k0], self.X[k1], tw, self.correct_flag(c)))
+                    for col in range(self.C):
+                        blist.append((self.X[col * RA + k0], self.X[col * RA + k1], tw, self.correct_flag(c)))
                 if c == 0:
-                    # loads were issued in the order 0, RA/2, 1, RA/2+1, ...: pair i needs the first 2i+2
+                    # loads were issued in the order of this list: pair i needs the first 2i+2
                     for i in range(0, len(blist), 2):
-                        e("s_waitcnt", "vmcnt(%d)" % max(RA - 2 * (i + 2), 0))
+                        e("s_waitcnt", "vmcnt(%d)" % max(self.NX - 2 * (i + 2), 0))
                         # first-stage U operands: any 64-bit value is accepted
                         self.zip_emit([(lambda ts, x=blist[i + d][0]: self.ops_reduce_2q(ts, x)) for d in range(2)])
                         self.butterflies(blist[i:i + 2])
@@ -357,10 +372,10 @@ class Gen:
     # them the 16 waves run decoupled (LDS operations of one wave execute in order), so the LDS and
     # twiddle latencies of one wave hide behind the arithmetic of the others.
     def uniform_twiddle_loads(self, half):
-        """scalar twiddles of the stages over bits 9..7: H = 2^(logn-10) + 16*half + wave"""
+        """scalar twiddles of the stages over bits 9..7: H = 2^(logn-10) + SPH*half + wave"""
         e, sc = self.e, self.SC
         buf = self.PB
-        e("s_add_u32", sc[2], self.WAVE, (1 << (self.logn - 10)) + 16 * half)
+        e("s_add_u32", sc[2], self.WAVE, (1 << (self.logn - 10)) + self.SPH * half)
         e("s_lshl_b32", sc[3], sc[2], 4)
         e("s_load_dwordx4", s(buf, 4), self.TW, sc[3])
         e("s_lshl_b32", sc[3], sc[2], 5)
@@ -376,10 +391,15 @@ class Gen:
         e("v_lshrrev_b32", a2, 4, self.TID)
         e("v_lshlrev_b32", a2, 4, a2)
         e("v_lshl_add_u32", a0, self.TID, 3, a2)              # slot(t) * 8
-        e("v_add_u32", a1, 8 * 9216, a0)
-        for kk in range(self.RH):
-            base, off = (a0, kk * 9216) if kk < 8 else (a1, (kk - 8) * 9216)
-            e("ds_write_b64", base, self.X[half * self.RH + kk], offset=off)
+        # row kk of column c goes to block kk at slot(t + c*T) = slot(t) + 576*c
+        e("v_add_u32", a1, 8 * 9216 if self.C == 1 else 4608, a0)
+        for c in range(self.C):
+            for kk in range(self.SPH):
+                if self.C == 1:
+                    base, off = (a0, kk * 9216) if kk < 8 else (a1, (kk - 8) * 9216)
+                else:
+                    base, off = (a0 if c == 0 else a1), kk * 9216
+                e("ds_write_b64", base, self.X[c * self.RA + self.SPH * half + kk], offset=off)
         e("s_waitcnt", "lgkmcnt(0)")
         e("s_barrier")
 
@@ -437,7 +457,7 @@ class Gen:
 
     def lane_twiddle_requests(self, half, g, tag):
         """the 7 twiddles of the stages over bits 6..4 for task g, in heap order; H*16 is kept in A_[3]
-        H = 2^(logn-7) + 128*half + 8*wave + (lane >> 4) + 4*g"""
+        H = 2^(logn-7) + 8*(SPH*half + wave) + (lane >> 4) + 4*g"""
         e = self.e
         a3 = self.A_[3]
 
@@ -445,7 +465,7 @@ class Gen:
             def f():
                 e("v_lshrrev_b32", a3, 4, self.LANE)
                 e("s_lshl_b32", self.SC[5], self.WAVE, 3)
-                e("s_add_u32", self.SC[5], self.SC[5], (1 << (self.logn - 7)) + 128 * half + 4 * g)
+                e("s_add_u32", self.SC[5], self.SC[5], (1 << (self.logn - 7)) + 8 * self.SPH * half + 4 * g)
                 e("v_add_u32", a3, self.SC[5], a3)
                 e("v_lshlrev_b32", a3, 4 + shift, a3)
             return f
@@ -534,7 +554,7 @@ class Gen:
             def issue(slot):
                 e("v_lshlrev_b32", a2, 4, self.TID)           # block index half*1024 + 64*wave + lane = half*1024 + t
                 row = (1 << c) - 1 + j
-                off = half * 16384 + row * (self.N // 16) * 16
+                off = half * self.SPH * 1024 + row * (self.N // 16) * 16      # block index SPH*64*half + t, 16 B each
                 e("s_add_u32", self.TWFR.lo(), self.TWF.lo(), off)
                 e("s_addc_u32", self.TWFR.hi(), self.TWF.hi(), 0)
                 e("global_load_dwordx4", slot, a2, self.TWFR)
@@ -627,7 +647,7 @@ def kernel_text(logn, name):
 
 def kernel_text_for(g, name):
     prog = g.build()
-    lds_bytes = (16384 + 2048) * 8
+    lds_bytes = g.SPH * 9216
     hdr = """  .amdgcn_target "amdgcn-amd-amdhsa--gfx950"
   .text
   .globl {name}
@@ -669,7 +689,7 @@ amdhsa.kernels:
     .group_segment_fixed_size: {lds}
     .kernarg_segment_align: 8
     .kernarg_segment_size: 104
-    .max_flat_workgroup_size: 1024
+    .max_flat_workgroup_size: {threads}
     .name: {name}
     .private_segment_fixed_size: 0
     .sgpr_count: 106
@@ -680,7 +700,7 @@ amdhsa.target: amdgcn-amd-amdhsa--gfx950
 amdhsa.version: [1, 2]
 ...
   .end_amdgpu_metadata
-""".format(name=name, lds=lds_bytes, vgpr=128, accum=128)
+""".format(name=name, lds=lds_bytes, vgpr=128, accum=128, threads=g.T)
     return hdr + prog.text() + desc
 
 
@@ -766,9 +786,9 @@ def emulate(gen, inverse=False, q=None, geom=None):
     place(karg, A_KARG)
 
     prog = gen.build()
-    m = Machine(T, 160 * 1024, mem.size)
+    m = Machine(gen.T, 160 * 1024, mem.size)
     m.mem = mem
-    m.vgpr[0] = np.arange(T, dtype=np.uint32)
+    m.vgpr[0] = np.arange(gen.T, dtype=np.uint32)
     m.vdef[0] = True
     m.sgpr[0], m.sgpr[1] = A_KARG, 0
     m.sgpr[2], m.sgpr[3], m.sgpr[4] = gx, gy, gz
@@ -801,20 +821,20 @@ def test_moduli(logn, mode):
     return [above[-1], lo]
 
 
-def selftest(logn, inverse=False):
+def selftest(logn, inverse=False, threads=1024):
     ok = True
     for mode in ((0, 1) if inverse else (0, 1, 2)):
         for q in test_moduli(logn, mode):
             if inverse:
                 from gen_intt import GenInv
-                gen = GenInv(logn, mode)
+                gen = GenInv(logn, mode, threads)
             else:
-                gen = Gen(logn, mode)
+                gen = Gen(logn, mode, threads)
             # the last modulus of each mode also exercises the digit-group addressing (grid z, skipped limbs)
             geom = (2, 1, 1, 2, 3, 6) if q == test_moduli(logn, mode)[-1] else None
             good, info = emulate(gen, inverse, q, geom)
             ok = ok and good
-            print("%s logN=%d mode %d q=%d (%d bits): %s; %s" % ("inverse" if inverse else "forward", logn, mode, q, q.bit_length(),
+            print("%s logN=%d T=%d mode %d q=%d (%d bits): %s; %s" % ("inverse" if inverse else "forward", logn, threads, mode, q, q.bit_length(),
                                                              "bit-exact vs oracle" if good else "MISMATCH", info), flush=True)
     return ok
 
@@ -822,6 +842,9 @@ def selftest(logn, inverse=False):
 if __name__ == "__main__":
     logn = int(sys.argv[1])
     if len(sys.argv) > 2 and sys.argv[2] == "--selftest":
-        sys.exit(0 if selftest(logn) else 1)
+        threads = int(sys.argv[3]) if len(sys.argv) > 3 else 1024
+        sys.exit(0 if selftest(logn, threads=threads) else 1)
     mode = int(sys.argv[3]) if len(sys.argv) > 3 else 1
-    open(sys.argv[2], "w").write(kernel_text_for(Gen(logn, mode), "lr_ntt_fwd%d_m%d" % (logn, mode)))
+    threads = int(sys.argv[4]) if len(sys.argv) > 4 else 1024
+    name = "lr_ntt_fwd%d%s_m%d" % (logn, "x" if threads == 512 else "", mode)     # x: two workgroups per CU
+    open(sys.argv[2], "w").write(kernel_text_for(Gen(logn, mode, threads), name))

@@ -8,28 +8,32 @@ mkdir -p build
 # hand-scheduled assembly kernels: generate -> assemble -> embed
 LLVM=${LLVM:-/opt/rocm/lib/llvm/bin}
 # forward: modes 0 (q < 2^61), 1 (q <= 2^60), 2 (q < 2^57); inverse: modes 0 and 1
-gen_one() {  # kind degree mode
-  python3 asmgen/gen_$( [ "$1" = fwd ] && echo ntt || echo intt ).py $2 build/ntt_$1$2_m$3.s $3
-  $LLVM/clang -x assembler -target amdgcn-amd-amdhsa -mcpu=gfx950 -c build/ntt_$1$2_m$3.s -o build/ntt_$1$2_m$3.o
-  $LLVM/ld.lld -shared build/ntt_$1$2_m$3.o -o build/ntt_$1$2_m$3.hsaco
+gen_one() {  # kind degree mode [threads]; 512 threads = the two-workgroups-per-CU plan ("x" kernels, N = 2^14)
+  local tag=$2; [ "${4:-1024}" = 512 ] && tag=${2}x
+  python3 asmgen/gen_$( [ "$1" = fwd ] && echo ntt || echo intt ).py $2 build/ntt_$1${tag}_m$3.s $3 ${4:-1024}
+  $LLVM/clang -x assembler -target amdgcn-amd-amdhsa -mcpu=gfx950 -c build/ntt_$1${tag}_m$3.s -o build/ntt_$1${tag}_m$3.o
+  $LLVM/ld.lld -shared build/ntt_$1${tag}_m$3.o -o build/ntt_$1${tag}_m$3.hsaco
 }
 gpids=()
 for n in 14 15; do
   for m in 0 1 2; do gen_one fwd $n $m & gpids+=($!); done
   for m in 0 1; do gen_one inv $n $m & gpids+=($!); done
 done
+for m in 0 1 2; do gen_one fwd 14 $m 512 & gpids+=($!); done
+for m in 0 1; do gen_one inv 14 $m 512 & gpids+=($!); done
 for p in "${gpids[@]}"; do wait $p; done
 python3 - <<'PY'
 out = ['struct lr_asm_blob { const char *name; const unsigned char *data; unsigned long size; };']
 names = [("fwd", n, m) for n in (14, 15) for m in (0, 1, 2)] + [("inv", n, m) for n in (14, 15) for m in (0, 1)]
+names += [("fwd", "14x", m) for m in (0, 1, 2)] + [("inv", "14x", m) for m in (0, 1)]
 for k, n, m in names:
-    data = open("build/ntt_%s%d_m%d.hsaco" % (k, n, m), "rb").read()
-    out.append('static const unsigned char blob_%s%d_m%d[] __attribute__((aligned(4096))) = {' % (k, n, m))
+    data = open("build/ntt_%s%s_m%d.hsaco" % (k, n, m), "rb").read()
+    out.append('static const unsigned char blob_%s%s_m%d[] __attribute__((aligned(4096))) = {' % (k, n, m))
     out.append(",".join(str(b) for b in data))
     out.append("};")
 out.append('extern "C" const lr_asm_blob lr_asm_blobs[] = {')
 for k, n, m in names:
-    out.append('  {"lr_ntt_%s%d_m%d", blob_%s%d_m%d, sizeof(blob_%s%d_m%d)},' % (k, n, m, k, n, m, k, n, m))
+    out.append('  {"lr_ntt_%s%s_m%d", blob_%s%s_m%d, sizeof(blob_%s%s_m%d)},' % (k, n, m, k, n, m, k, n, m))
 out.append("};")
 out.append('extern "C" const int lr_asm_blob_count = %d;' % len(names))
 open("build/lr_asm_blob.cpp", "w").write("\n".join(out) + "\n")

@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <map>
 #include <mutex>
 #include <string>
@@ -62,8 +63,12 @@ bool ntt_asm_available(int logn) { return (logn == 14 || logn == 15) && kernels_
 hipError_t launch_ntt_asm(const NttLaunch &a, int logn, int inverse, int variant, hipStream_t stream) {
     AsmKernels *k = kernels_for_current_device();
     if (!k || (logn != 14 && logn != 15)) return hipErrorNotSupported;
+    // N = 2^14 has a 512-thread plan (two columns per thread, half the LDS image): two workgroups share a CU and one
+    // covers the other's load and store phases.  LR_ASM_14_1024=1 selects the 1024-thread kernels (testing aid).
+    const bool wide14 = std::getenv("LR_ASM_14_1024") != nullptr;
+    const bool x = logn == 14 && !wide14;
     char name[32];
-    std::snprintf(name, sizeof name, "lr_ntt_%s%d_m%d", inverse ? "inv" : "fwd", logn, variant);
+    std::snprintf(name, sizeof name, "lr_ntt_%s%d%s_m%d", inverse ? "inv" : "fwd", logn, x ? "x" : "", variant);
     auto it = k->fn.find(name);
     if (it == k->fn.end()) return hipErrorNotSupported;
     if (a.n_items <= 0 || a.batch <= 0) return hipSuccess;
@@ -81,7 +86,7 @@ hipError_t launch_ntt_asm(const NttLaunch &a, int logn, int inverse, int variant
         gy = (unsigned)a.group;
         gz = (unsigned)(a.batch / a.group);
     }
-    return hipModuleLaunchKernel(it->second, (unsigned)a.n_items, gy, gz, 1024, 1, 1, 0, stream, nullptr, extra);
+    return hipModuleLaunchKernel(it->second, (unsigned)a.n_items, gy, gz, x ? 512 : 1024, 1, 1, 0, stream, nullptr, extra);
 }
 
 }  // namespace lr

@@ -272,6 +272,33 @@ def test_cxx_and_asm_inverse_paths_agree(gpu_pkg, oracle, logn, kind, force, mon
         assert np.array_equal(p.get(), np.stack([[x[b, i] % np.uint64(q) for i, q in enumerate(moduli)] for b in range(2)]))
 
 
+@pytest.mark.parametrize("kind", ["qi60", "ckks", "bfv60"])
+def test_asm_2p14_both_plans(gpu_pkg, oracle, kind, monkeypatch):
+    """N = 2^14 has two assembly plans: 512 threads / two columns per thread / two workgroups per CU (default) and
+    1024 threads / one workgroup per CU (LR_ASM_14_1024=1); both directions of both plans equal the oracle"""
+    logn, N = 14, 1 << 14
+    moduli = _asm_moduli(gpu_pkg, kind, logn)
+    oc = oracle.Context(N, moduli)
+    x = gpu_pkg.sampling.random_u64((3, len(moduli), N), seed=123)
+    y = x.copy()
+    for i, q in enumerate(moduli):
+        y[:, i] %= np.uint64(4 * q)
+    red = lambda a, b: np.array([[int(v) % q for v in a[b, i]] for i, q in enumerate(moduli)], dtype=np.uint64)
+    for wide in (False, True):
+        if wide:
+            monkeypatch.setenv("LR_ASM_14_1024", "1")
+        else:
+            monkeypatch.delenv("LR_ASM_14_1024", raising=False)
+        ctx = gpu_pkg.ring.NewContextWithParams(N, moduli)
+        p, r = ctx.NewPoly(3).set(x), ctx.NewPoly(3)
+        ctx.NTT(p, r)
+        pi, ri = ctx.NewPoly(3).set(y), ctx.NewPoly(3)
+        ctx.InvNTT(pi, ri)
+        for b in range(3):
+            assert np.array_equal(r.get()[b], oc.ntt(red(x, b))), (wide, b)
+            assert np.array_equal(ri.get()[b], oc.intt(red(y, b))), (wide, b)
+
+
 def test_cpp_host_mirror_runs_reference_ntt_test():
     """tests/cpp/test_ntt_golden.cpp is the C++ twin of ring/ntt_test.go:Test_NTT on include/lattigo_ring.hpp
     (the C++ host mirror over the C ABI).  Built here with g++ against the in-tree library and executed."""
