@@ -29,7 +29,7 @@ class Gen:
          0: q <  2^61, U <- U - 4q (if U >= 4q) before every stage."""
 
     def __init__(self, logn, mode=1, threads=1024):
-        assert logn in (14, 15) and mode in (0, 1, 2) and threads in (512, 1024)
+        assert logn in (13, 14, 15) and mode in (0, 1, 2) and threads in (512, 1024)
         self.mode = mode
         self.logn = logn
         self.N = 1 << logn

@@ -19,13 +19,15 @@ for n in 14 15; do
   for m in 0 1 2; do gen_one fwd $n $m & gpids+=($!); done
   for m in 0 1; do gen_one inv $n $m & gpids+=($!); done
 done
-for m in 0 1 2; do gen_one fwd 14 $m 512 & gpids+=($!); done
-for m in 0 1; do gen_one inv 14 $m 512 & gpids+=($!); done
+for n in 13 14; do
+  for m in 0 1 2; do gen_one fwd $n $m 512 & gpids+=($!); done
+  for m in 0 1; do gen_one inv $n $m 512 & gpids+=($!); done
+done
 for p in "${gpids[@]}"; do wait $p; done
 python3 - <<'PY'
 out = ['struct lr_asm_blob { const char *name; const unsigned char *data; unsigned long size; };']
 names = [("fwd", n, m) for n in (14, 15) for m in (0, 1, 2)] + [("inv", n, m) for n in (14, 15) for m in (0, 1)]
-names += [("fwd", "14x", m) for m in (0, 1, 2)] + [("inv", "14x", m) for m in (0, 1)]
+names += [("fwd", n, m) for n in ("13x", "14x") for m in (0, 1, 2)] + [("inv", n, m) for n in ("13x", "14x") for m in (0, 1)]
 for k, n, m in names:
     data = open("build/ntt_%s%s_m%d.hsaco" % (k, n, m), "rb").read()
     out.append('static const unsigned char blob_%s%s_m%d[] __attribute__((aligned(4096))) = {' % (k, n, m))

@@ -57,16 +57,16 @@ AsmKernels *kernels_for_current_device() {
 }
 }  // namespace
 
-bool ntt_asm_available(int logn) { return (logn == 14 || logn == 15) && kernels_for_current_device() != nullptr; }
+bool ntt_asm_available(int logn) { return logn >= 13 && logn <= 15 && kernels_for_current_device() != nullptr; }
 
 // variant = lazy-correction mode of asmgen/gen_ntt.py (forward 0, 1, 2) / gen_intt.py (inverse 0, 1)
 hipError_t launch_ntt_asm(const NttLaunch &a, int logn, int inverse, int variant, hipStream_t stream) {
     AsmKernels *k = kernels_for_current_device();
-    if (!k || (logn != 14 && logn != 15)) return hipErrorNotSupported;
-    // N = 2^14 has a 512-thread plan (two columns per thread, half the LDS image): two workgroups share a CU and one
+    if (!k || logn < 13 || logn > 15) return hipErrorNotSupported;
+    // N = 2^13 and 2^14 have a 512-thread plan (two columns per thread, 72 KiB LDS image): two workgroups share a CU and one
     // covers the other's load and store phases.  LR_ASM_14_1024=1 selects the 1024-thread kernels (testing aid).
     const bool wide14 = std::getenv("LR_ASM_14_1024") != nullptr;
-    const bool x = logn == 14 && !wide14;
+    const bool x = logn == 13 || (logn == 14 && !wide14);
     char name[32];
     std::snprintf(name, sizeof name, "lr_ntt_%s%d%s_m%d", inverse ? "inv" : "fwd", logn, x ? "x" : "", variant);
     auto it = k->fn.find(name);
