@@ -25,9 +25,9 @@ class GenInv(Gen):
     """mode 1: every modulus in (2^33, 2^60], bound B = 8q as described above;
        mode 0: moduli up to 2^61: B = 4q and every butterfly corrects."""
 
-    def __init__(self, logn, mode=1, threads=1024):
+    def __init__(self, logn, mode=1, threads=1024, sub=False):
         assert mode in (0, 1)
-        super().__init__(logn, mode, threads)
+        super().__init__(logn, mode, threads, sub)
         self.Q8 = self.Q4                       # s[18:19] holds the bound B here
         self.NQ2 = s(22, 2)                     # -2q (the Barrett constant is not used by the inverse)
         self.LP = s(0, 2)                       # LimbParams pointer (kernarg pointer is dead after the prologue)
@@ -141,10 +141,17 @@ class GenInv(Gen):
         e("s_sub_u32", self.NQ8.lo(), 0, self.Q8.lo())
         e("s_subb_u32", self.NQ8.hi(), 0, self.Q8.hi())
         e("s_lshl_b64", self.NQ2, self.NQ, 1)
-        # LimbParams pointer for the reload before the last stage
-        e("s_lshl_b32", self.SC[3], self.SC[0], 6)
-        e("s_add_u32", self.LP.lo(), s(52), self.SC[3])
-        e("s_addc_u32", self.LP.hi(), s(53), 0)
+        if not self.sub:
+            # LimbParams pointer for the reload before the last stage
+            e("s_lshl_b32", self.SC[3], self.SC[0], 6)
+            e("s_add_u32", self.LP.lo(), s(52), self.SC[3])
+            e("s_addc_u32", self.LP.hi(), s(53), 0)
+
+    def sub_source(self, blk_bytes):
+        """inverse: this block's half of the limb"""
+        e = self.e
+        e("s_add_u32", self.SRC.lo(), self.SRC.lo(), blk_bytes)
+        e("s_addc_u32", self.SRC.hi(), self.SRC.hi(), 0)
 
     def copy_in(self, half):
         """wave w loads its 1024 contiguous coefficients (8 KiB) with 16-byte loads and lays them into its LDS block"""
@@ -296,7 +303,8 @@ class GenInv(Gen):
             for j0 in range(0, 1 << c, 8):
                 plan.append(("tw", c, j0))
         plan.append(("low",))           # heap entries 0..7: c = 2, 1 and the fused constant at index 0
-        plan.append(("lp",))
+        if not self.sub:
+            plan.append(("lp",))        # N^-1 for the fused last stage (a sub-block leaves that to ntt_top_kernel)
         return plan
 
     def chunk_load(self, n):
@@ -306,8 +314,14 @@ class GenInv(Gen):
         if item[0] == "tw":
             _, c, j0 = item
             off = ((1 << c) + j0) * 16
-            e("s_load_dwordx16", s(buf, 16), self.TW, off)
-            e("s_load_dwordx16", s(buf + 16, 16), self.TW, off + 64)
+            table = self.stage_table(c)
+            e("s_load_dwordx16", s(buf, 16), table, off)
+            e("s_load_dwordx16", s(buf + 16, 16), table, off + 64)
+        elif item[0] == "low" and self.sub:
+            # under heap root 2 + blk: stage c = 2 -> 4 entries at buf, c = 1 -> 2 entries at buf+16, c = 0 -> buf+24
+            e("s_load_dwordx16", s(buf, 16), self.stage_table(2), 4 * 16)
+            e("s_load_dwordx8", s(buf + 16, 8), self.stage_table(1), 2 * 16)
+            e("s_load_dwordx4", s(buf + 24, 4), self.stage_table(0), 1 * 16)
         elif item[0] == "low":
             e("s_load_dwordx16", s(buf, 16), self.TW, 0)
             e("s_load_dwordx16", s(buf + 16, 16), self.TW, 64)
@@ -341,13 +355,16 @@ class GenInv(Gen):
                 if n + 2 < nchunks:
                     self.chunk_load(n + 2)
             elif item[0] == "low":
-                for c in (2, 1):
+                for c in ((2, 1, 0) if self.sub else (2, 1)):
                     if c > A - 1:
                         continue
                     b = A - 1 - c
                     blist = []
                     for j in range(1 << c):
-                        tw = tuple(s(buf + 4 * ((1 << c) + j) + i) for i in range(4))
+                        if self.sub:
+                            tw = tuple(s(buf + (0, 16, 24)[2 - c] + 4 * j + i) for i in range(4))
+                        else:
+                            tw = tuple(s(buf + 4 * ((1 << c) + j) + i) for i in range(4))
                         for i in range(1 << b):
                             k0 = (j << (b + 1)) | i
                             for col in range(self.C):
@@ -406,8 +423,14 @@ def selftest(logn, threads=1024):
 if __name__ == "__main__":
     logn = int(sys.argv[1])
     if len(sys.argv) > 2 and sys.argv[2] == "--selftest":
+        if logn == 16:
+            import gen_ntt
+            sys.exit(0 if gen_ntt.selftest_sub(inverse=True) else 1)
         sys.exit(0 if selftest(logn, int(sys.argv[3]) if len(sys.argv) > 3 else 1024) else 1)
     mode = int(sys.argv[3]) if len(sys.argv) > 3 else 1
     threads = int(sys.argv[4]) if len(sys.argv) > 4 else 1024
+    if logn == 16:
+        open(sys.argv[2], "w").write(kernel_text_for(GenInv(15, mode, 1024, sub=True), "lr_ntt_inv16s_m%d" % mode))
+        sys.exit(0)
     name = "lr_ntt_inv%d%s_m%d" % (logn, "x" if threads == 512 else "", mode)
     open(sys.argv[2], "w").write(kernel_text_for(GenInv(logn, mode, threads), name))

@@ -28,8 +28,16 @@ class Gen:
          2: q <  2^57, no corrections at all (15 stages x 4q of growth stay below 2^64);
          0: q <  2^61, U <- U - 4q (if U >= 4q) before every stage."""
 
-    def __init__(self, logn, mode=1, threads=1024):
+    def __init__(self, logn, mode=1, threads=1024, sub=False, fused=True):
         assert logn in (13, 14, 15) and mode in (0, 1, 2) and threads in (512, 1024)
+        assert not sub or (logn == 15 and threads == 1024)
+        self.fused = fused            # forward sub-block kernels: compute the top stage while loading (out of place only)
+        # sub: the kernel transforms one 2^15 half ("sub-block" blk = workgroup x & 1) of an N = 2^16 limb; twiddles come
+        # from the 2^16 tables under heap root 2 + blk.  Forward: the stage over bit 15 is computed while loading
+        # (X = U + V*psi[1] for blk 0, Y = U - V*psi[1] for blk 1, both blocks read both halves).  Inverse: the
+        # outputs stay lazy; ntt_top_kernel finishes with the last stage and the scaling.
+        self.sub = sub
+        self.NFULL = (2 if sub else 1) << logn
         self.mode = mode
         self.logn = logn
         self.N = 1 << logn
@@ -81,6 +89,8 @@ class Gen:
         self.TW, self.TWF, self.TWFR = s(8, 2), s(10, 2), s(12, 2)
         self.Qm, self.NQ, self.Q4, self.NQ8 = s(14, 2), s(16, 2), s(18, 2), s(20, 2)   # NQ8: -8q (mode 1) or -4q (mode 0)
         self.U0, self.WAVE = s(22), s(24)
+        self.BLK1, self.HI = s(0), s(2, 2)            # sub-block kernels: 1 + blk; high half of the limb (loads only)
+        self.TWS = s(2, 2)                            # ... and afterwards the per-stage table base
         self.SC = [s(25 + i) for i in range(7)]      # s25..s31 scratch
         self.JUNK = s(32, 2)
         self.TMP = s(34, 2)
@@ -239,6 +249,10 @@ class Gen:
         e("s_lshr_b32", self.WAVE, self.WAVE, 6)
         e("s_waitcnt", "lgkmcnt(0)")
         sc = self.SC
+        if self.sub:
+            e("s_and_b32", self.BLK1, self.WGX, 1)
+            e("s_add_u32", self.BLK1, self.BLK1, 1)      # 1 + blk: heap root 2 + blk = 1 + BLK1
+            e("s_lshr_b32", self.WGX, self.WGX, 1)
         # grid z = group of polys (key-switch digit): poly = z * group + y, and the limbs [z*hole, (z+1)*hole)
         # of that group are skipped: item = x + (x >= z*hole ? hole : 0).  hole = 0 / z = 0 for plain launches.
         e("s_mul_i32", sc[0], self.WGZ, s(61))
@@ -259,7 +273,7 @@ class Gen:
             e("s_mul_hi_u32", self.TMP.hi(), self.WGY, stride_lo)
             e("s_mul_i32", sc[3], self.WGY, stride_hi)
             e("s_add_u32", self.TMP.hi(), self.TMP.hi(), sc[3])
-            e("s_lshl_b32", sc[3], row, logn)
+            e("s_lshl_b32", sc[3], row, logn + (1 if self.sub else 0))
             e("s_add_u32", self.TMP.lo(), self.TMP.lo(), sc[3])
             e("s_addc_u32", self.TMP.hi(), self.TMP.hi(), 0)
             e("s_lshl_b64", self.TMP, self.TMP, 3)
@@ -271,16 +285,110 @@ class Gen:
         e("s_addc_u32", self.TMP.hi(), s(53), 0)
         e("s_load_dwordx16", s(68, 16), self.TMP, 0)
         # twiddle table bases
-        e("s_mul_i32", sc[3], sc[0], N * 16)
+        e("s_mul_i32", sc[3], sc[0], self.NFULL * 16)
         e("s_add_u32", self.TW.lo(), s(54), sc[3])
         e("s_addc_u32", self.TW.hi(), s(55), 0)
-        e("s_mul_i32", sc[3], sc[0], 15 * N)
+        e("s_mul_i32", sc[3], sc[0], 15 * self.NFULL)
         e("s_add_u32", self.TWF.lo(), s(56), sc[3])
         e("s_addc_u32", self.TWF.hi(), s(57), 0)
+        if self.sub:
+            # this block's half of the limb and of the lane-transposed rows
+            e("s_sub_u32", sc[3], self.BLK1, 1)
+            e("s_lshl_b32", sc[3], sc[3], logn)                    # blk * N
+            e("s_add_u32", self.TWF.lo(), self.TWF.lo(), sc[3])   # blk * (N/16) entries of 16 bytes
+            e("s_addc_u32", self.TWF.hi(), self.TWF.hi(), 0)
+            e("s_lshl_b32", sc[3], sc[3], 3)
+            e("s_add_u32", self.DST.lo(), self.DST.lo(), sc[3])
+            e("s_addc_u32", self.DST.hi(), self.DST.hi(), 0)
+            self.sub_source(sc[3])
         self.prologue_tail()
+
+    def sub_source(self, blk_bytes):
+        """forward: SRC stays at the low half, HI = the high half (fused top stage reads both); without the fusion
+        the block reads its own half, which ntt_top_kernel has prepared"""
+        e = self.e
+        if not self.fused:
+            e("s_add_u32", self.SRC.lo(), self.SRC.lo(), blk_bytes)
+            e("s_addc_u32", self.SRC.hi(), self.SRC.hi(), 0)
+            return
+        e("s_add_u32", self.HI.lo(), self.SRC.lo(), self.N * 8)
+        e("s_addc_u32", self.HI.hi(), self.SRC.hi(), 0)
+
+    def stage_table(self, c):
+        """SGPR pair addressing the twiddles of pass-A stage c: under heap root 2 + blk the index (1 << c) + j of a whole
+        transform becomes ((2 + blk) << c) + j"""
+        if not self.sub:
+            return self.TW
+        e = self.e
+        e("s_lshl_b32", self.SC[3], self.BLK1, c + 4)
+        e("s_add_u32", self.TWS.lo(), self.TW.lo(), self.SC[3])
+        e("s_addc_u32", self.TWS.hi(), self.TW.hi(), 0)
+        return self.TWS
+
+    def ops_mulacc(self, ts, U, V, tw):
+        """U <- U + (V*w - qhat*q), the product in [0,4q) for any 64-bit V"""
+        w0, w1, s0, s1 = tw
+        J = self.JUNK
+        return [("v_mul_hi_u32", ts.T0, V.hi(), s0),
+                ("v_mul_hi_u32", ts.T2, V.lo(), s1),
+                ("v_mad_u64_u32", ts.Q, J, V.hi(), s1, ts.T01),
+                ("v_mad_u64_u32", U, J, V.lo(), w0, U),
+                ("v_mad_u64_u32", ts.C, J, V.lo(), w1, 0),
+                ("v_lshl_add_u64", ts.Q, ts.Q, 0, ts.T23),
+                ("v_mad_u64_u32", ts.C, J, V.hi(), w0, ts.C),
+                ("v_mad_u64_u32", U, J, ts.Q.lo(), self.NQ.lo(), U),
+                ("v_mad_u64_u32", ts.C, J, ts.Q.lo(), self.NQ.hi(), ts.C),
+                ("v_mad_u64_u32", ts.C, J, ts.Q.hi(), self.NQ.lo(), ts.C),
+                ("v_add_u32", U.hi(), U.hi(), ts.C.lo())]
+
+    def fused_top(self):
+        """N = 2^16, forward: X[k] <- U_k + V_k * w with U from the low half of the limb, V from the high half and
+        w = psi[1] (sub-block 0) or q - psi[1] (sub-block 1; kept at index 0 of the forward table)."""
+        e = self.e
+        W1 = tuple(s(96 + i) for i in range(4))
+        e("s_sub_u32", self.SC[3], 2, self.BLK1)
+        e("s_lshl_b32", self.SC[3], self.SC[3], 4)
+        e("s_load_dwordx4", s(96, 4), self.TW, self.SC[3])
+        e("s_mov_b64", self.TMP, self.SRC)
+        for k in range(self.RA):
+            e("global_load_dwordx2", self.X[k], self.GOFF, self.TMP, hint="nt")
+            e("s_add_u32", self.TMP.lo(), self.TMP.lo(), self.S * 8)
+            e("s_addc_u32", self.TMP.hi(), self.TMP.hi(), 0)
+        V = [v(self.tw_base + 2 * i, 2) for i in range(16)]     # the twiddle pool is idle until the LDS phase
+
+        def v_loads():
+            for i in range(16):
+                e("global_load_dwordx2", V[i], self.GOFF, self.HI, hint="nt")
+                e("s_add_u32", self.HI.lo(), self.HI.lo(), self.S * 8)
+                e("s_addc_u32", self.HI.hi(), self.HI.hi(), 0)
+
+        v_loads()
+        self.constants()
+        for chunk in range(2):
+            for i in range(0, 16, 2):
+                e("s_waitcnt", "vmcnt(%d)" % (14 - i))
+                self.zip_emit([(lambda ts, U=self.X[16 * chunk + i + d], Vr=V[i + d]:
+                                self.ops_reduce_2q(ts, U) + self.ops_mulacc(ts, U, Vr, W1)) for d in range(2)])
+            if chunk == 0:
+                v_loads()
+
+    def constants(self):
+        e = self.e
+        e("s_waitcnt", "lgkmcnt(0)")
+        e("s_mov_b64", self.Qm, s(68, 2))
+        e("s_mov_b32", self.U0, s(72))                # low word of bred_hi = floor(2^64 / q)
+        e("s_sub_u32", self.NQ.lo(), 0, self.Qm.lo())
+        e("s_subb_u32", self.NQ.hi(), 0, self.Qm.hi())
+        e("s_lshl_b64", self.Q4, self.Qm, 2)
+        e("s_lshl_b64", self.TMP, self.Qm, 2 if self.mode == 0 else 3)
+        e("s_sub_u32", self.NQ8.lo(), 0, self.TMP.lo())
+        e("s_subb_u32", self.NQ8.hi(), 0, self.TMP.hi())
 
     def prologue_tail(self):
         e = self.e
+        if self.sub and self.fused:
+            self.fused_top()
+            return
         self.c("coalesced load of the columns {k*S + t + c*T}")
         # order 0, RA/2, 1, RA/2+1, ... (per column): the first-stage butterflies can start after two loads
         e("s_add_u32", self.TMP.lo(), self.SRC.lo(), (self.RA // 2) * self.S * 8)
@@ -295,15 +403,7 @@ class Gen:
             for ptr in (self.SRC, self.TMP):
                 e("s_add_u32", ptr.lo(), ptr.lo(), self.S * 8)
                 e("s_addc_u32", ptr.hi(), ptr.hi(), 0)
-        e("s_waitcnt", "lgkmcnt(0)")
-        e("s_mov_b64", self.Qm, s(68, 2))
-        e("s_mov_b32", self.U0, s(72))                # low word of bred_hi = floor(2^64 / q)
-        e("s_sub_u32", self.NQ.lo(), 0, self.Qm.lo())
-        e("s_subb_u32", self.NQ.hi(), 0, self.Qm.hi())
-        e("s_lshl_b64", self.Q4, self.Qm, 2)
-        e("s_lshl_b64", self.TMP, self.Qm, 2 if self.mode == 0 else 3)
-        e("s_sub_u32", self.NQ8.lo(), 0, self.TMP.lo())
-        e("s_subb_u32", self.NQ8.hi(), 0, self.TMP.hi())
+        self.constants()
 
     def pass_a(self):
         e = self.e
@@ -317,9 +417,10 @@ class Gen:
                 count = ntw // 2
                 first += half * count
             off, dw, dst = first * 16, count * 4, buf
+            table = self.stage_table(c)
             while dw > 0:
                 n = 16 if dw >= 16 else dw
-                e({4: "s_load_dwordx4", 8: "s_load_dwordx8", 16: "s_load_dwordx16"}[n], s(dst, n), self.TW, off)
+                e({4: "s_load_dwordx4", 8: "s_load_dwordx8", 16: "s_load_dwordx16"}[n], s(dst, n), table, off)
                 off += n * 4
                 dst += n
                 dw -= n
@@ -376,6 +477,9 @@ class Gen:
         e, sc = self.e, self.SC
         buf = self.PB
         e("s_add_u32", sc[2], self.WAVE, (1 << (self.logn - 10)) + self.SPH * half)
+        if self.sub:
+            e("s_lshl_b32", sc[3], self.BLK1, self.logn - 10)
+            e("s_add_u32", sc[2], sc[2], sc[3])
         e("s_lshl_b32", sc[3], sc[2], 4)
         e("s_load_dwordx4", s(buf, 4), self.TW, sc[3])
         e("s_lshl_b32", sc[3], sc[2], 5)
@@ -466,6 +570,9 @@ class Gen:
                 e("v_lshrrev_b32", a3, 4, self.LANE)
                 e("s_lshl_b32", self.SC[5], self.WAVE, 3)
                 e("s_add_u32", self.SC[5], self.SC[5], (1 << (self.logn - 7)) + 8 * self.SPH * half + 4 * g)
+                if self.sub:
+                    e("s_lshl_b32", self.SC[4], self.BLK1, self.logn - 7)
+                    e("s_add_u32", self.SC[5], self.SC[5], self.SC[4])
                 e("v_add_u32", a3, self.SC[5], a3)
                 e("v_lshlrev_b32", a3, 4 + shift, a3)
             return f
@@ -554,7 +661,7 @@ class Gen:
             def issue(slot):
                 e("v_lshlrev_b32", a2, 4, self.TID)           # block index half*1024 + 64*wave + lane = half*1024 + t
                 row = (1 << c) - 1 + j
-                off = half * self.SPH * 1024 + row * (self.N // 16) * 16      # block index SPH*64*half + t, 16 B each
+                off = half * self.SPH * 1024 + row * (self.NFULL // 16) * 16  # block index SPH*64*half + t, 16 B each
                 e("s_add_u32", self.TWFR.lo(), self.TWF.lo(), off)
                 e("s_addc_u32", self.TWFR.hi(), self.TWF.hi(), 0)
                 e("global_load_dwordx4", slot, a2, self.TWFR)
@@ -821,6 +928,100 @@ def test_moduli(logn, mode):
     return [above[-1], lo]
 
 
+def emulate_sub(make_gen, inverse, q, pretop=False):
+    """N = 2^16 through the two sub-block workgroups of one limb; returns (bit-exact?, summary)"""
+    import numpy as np
+
+    from isa import Machine
+    sys.path.insert(0, __import__("os").path.join(__import__("os").path.dirname(__file__), "..", "..", ".."))
+    import __graft_entry__ as graft
+    oracle = graft.load_oracle()
+    pkg = graft.load_package()
+    N, NF = 1 << 15, 1 << 16
+    oc = oracle.Context(NF, [q])
+    x = pkg.sampling.random_u64((NF,), seed=9)
+    x[:4] = np.uint64(0xFFFFFFFFFFFFFFFF)
+    if inverse:
+        x = (x % np.uint64(4 * q)).astype(np.uint64)
+    canon = np.array([[int(val) % q for val in x]], dtype=np.uint64)
+    want = (oc.intt(canon) if inverse else oc.ntt(canon))[0]
+    table = oc.ntt_psi_inv[0] if inverse else oc.ntt_psi[0]
+    psi = [int(oracle.inv_mform(int(w), q)) for w in table]
+    n_inv = pow(NF, -1, q)
+    psi[0] = psi[1] * n_inv % q if inverse else q - psi[1]     # lr_abi.cpp fills the unused heap entry 0 like this
+    tw = np.zeros((NF, 2), dtype=np.uint64)
+    for i, w in enumerate(psi):
+        tw[i, 0] = w
+        tw[i, 1] = (w << 64) // q
+    blocks = NF // 16
+    twf = np.zeros((15, blocks, 2), dtype=np.uint64)
+    for cc in range(4):
+        for j in range(1 << cc):
+            for bk in range(blocks):
+                twf[(1 << cc) - 1 + j, bk] = tw[((blocks + bk) << cc) + j]
+    lp = np.zeros(8, dtype=np.uint64)
+    lp[0] = q
+    lp[2] = (1 << 128) // q >> 64
+    lp[5] = n_inv
+    lp[6] = (n_inv << 64) // q
+    A_KARG, A_IN = 0x800, 0x1000
+    A_OUT = A_IN + 8 * NF + 0x1000
+    A_LP = A_OUT + 8 * NF + 0x1000
+    A_TW = A_LP + 0x1000
+    A_TWF = A_TW + 16 * NF + 0x1000
+    mem = np.zeros((A_TWF + 16 * 15 * blocks + 0x1000) // 4, dtype=np.uint32)
+
+    def place(arr, addr):
+        words = np.ascontiguousarray(arr).view(np.uint32).ravel()
+        mem[addr // 4: addr // 4 + words.size] = words
+
+    if pretop:
+        # what ntt_top_kernel leaves for the plain forward sub-blocks: X = U + V*psi[1], Y = U - V*psi[1] (lazy, < 8q)
+        xs = [int(a) % q for a in x]
+        w = psi[1]
+        x = np.array([(xs[j] + xs[j + N] * w) % q + q for j in range(N)] + [(xs[j] - xs[j + N] * w) % q + 3 * q for j in range(N)],
+                     dtype=np.uint64)
+    place(x, A_IN)
+    place(lp, A_LP)
+    place(tw, A_TW)
+    place(twf, A_TWF)
+    karg = np.zeros(13, dtype=np.uint64)
+    karg[0], karg[1], karg[2], karg[3] = A_IN, A_OUT, NF, NF
+    karg[4] = 0 | (1 << 32)
+    karg[5] = 0 | (1 << 32)
+    karg[6] = 0
+    karg[7] = 1 | (1 << 32)
+    karg[8], karg[9], karg[10] = A_LP, A_TW, A_TWF
+    karg[11] = 1                   # sub_log = 1, hole = 0
+    karg[12] = 1                   # group
+    place(karg, A_KARG)
+    info = ""
+    for blk in range(2):
+        gen = make_gen()
+        prog = gen.build()
+        m = Machine(gen.T, 160 * 1024, mem.size)
+        m.mem = mem
+        m.vgpr[0] = np.arange(gen.T, dtype=np.uint32)
+        m.vdef[0] = True
+        m.sgpr[0], m.sgpr[1] = A_KARG, 0
+        m.sgpr[2], m.sgpr[3], m.sgpr[4] = blk, 0, 0
+        m.sdef[0:5] = True
+        m.run(prog)
+        mem = m.mem
+        cnt = prog.count()
+        info = "%d instructions, %d VALU" % (len(prog.ins), sum(n for op, n in cnt.items() if op.startswith("v_")))
+    got = mem[A_OUT // 4: A_OUT // 4 + 2 * NF].view(np.uint64).copy()
+    if inverse:
+        # what ntt_top_kernel does next: last Gentleman-Sande stage and the scaling
+        U = [int(a) for a in got[:N]]
+        V = [int(a) for a in got[N:]]
+        assert max(max(U), max(V)) < 8 * q
+        w1n = psi[0]
+        got = np.array([(u + v) * n_inv % q for u, v in zip(U, V)] + [(u - v) * w1n % q for u, v in zip(U, V)], dtype=np.uint64)
+    ok = bool(np.array_equal(got, want))
+    return ok, info
+
+
 def selftest(logn, inverse=False, threads=1024):
     ok = True
     for mode in ((0, 1) if inverse else (0, 1, 2)):
@@ -839,12 +1040,40 @@ def selftest(logn, inverse=False, threads=1024):
     return ok
 
 
+def selftest_sub(inverse=False):
+    """the sub-block kernels of N = 2^16"""
+    ok = True
+    for mode in ((0, 1) if inverse else (0, 1, 2)):
+        q = test_moduli(16, mode)[0]
+        if inverse:
+            from gen_intt import GenInv
+            make = lambda: GenInv(15, mode, 1024, sub=True)
+        else:
+            make = lambda: Gen(15, mode, 1024, sub=True)
+        good, info = emulate_sub(make, inverse, q)
+        if not inverse:
+            # the plain variant continues from the output of the separate top-stage pass
+            good2, _ = emulate_sub(lambda: Gen(15, mode, 1024, sub=True, fused=False), inverse, q, pretop=True)
+            good = good and good2
+        ok = ok and good
+        print("%s N=2^16 sub-blocks mode %d q=%d (%d bits): %s; %s" % ("inverse" if inverse else "forward", mode, q, q.bit_length(),
+                                                                    "bit-exact vs oracle" if good else "MISMATCH", info), flush=True)
+    return ok
+
+
 if __name__ == "__main__":
     logn = int(sys.argv[1])
     if len(sys.argv) > 2 and sys.argv[2] == "--selftest":
+        if logn == 16:
+            sys.exit(0 if selftest_sub() else 1)
         threads = int(sys.argv[3]) if len(sys.argv) > 3 else 1024
         sys.exit(0 if selftest(logn, threads=threads) else 1)
     mode = int(sys.argv[3]) if len(sys.argv) > 3 else 1
     threads = int(sys.argv[4]) if len(sys.argv) > 4 else 1024
+    if logn == 16:      # the 2^15 sub-block kernels of N = 2^16: "s" with the fused top stage, "p" plain
+        fused = not (len(sys.argv) > 5 and sys.argv[5] == "plain")
+        open(sys.argv[2], "w").write(kernel_text_for(Gen(15, mode, 1024, sub=True, fused=fused),
+                                                     "lr_ntt_fwd16%s_m%d" % ("s" if fused else "p", mode)))
+        sys.exit(0)
     name = "lr_ntt_fwd%d%s_m%d" % (logn, "x" if threads == 512 else "", mode)     # x: two workgroups per CU
     open(sys.argv[2], "w").write(kernel_text_for(Gen(logn, mode, threads), name))

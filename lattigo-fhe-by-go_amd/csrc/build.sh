@@ -23,11 +23,19 @@ for n in 13 14; do
   for m in 0 1 2; do gen_one fwd $n $m 512 & gpids+=($!); done
   for m in 0 1; do gen_one inv $n $m 512 & gpids+=($!); done
 done
+# N = 2^16: 2^15 sub-block kernels (forward with the top stage fused into the loads = s, plain = p; inverse = s)
+gen_sub() {  # kind tag mode [plain]
+  python3 asmgen/gen_$( [ "$1" = fwd ] && echo ntt || echo intt ).py 16 build/ntt_$1$2_m$3.s $3 1024 $4
+  $LLVM/clang -x assembler -target amdgcn-amd-amdhsa -mcpu=gfx950 -c build/ntt_$1$2_m$3.s -o build/ntt_$1$2_m$3.o
+  $LLVM/ld.lld -shared build/ntt_$1$2_m$3.o -o build/ntt_$1$2_m$3.hsaco
+}
+for m in 0 1 2; do gen_sub fwd 16s $m & gpids+=($!); gen_sub fwd 16p $m plain & gpids+=($!); done
+for m in 0 1; do gen_sub inv 16s $m & gpids+=($!); done
 for p in "${gpids[@]}"; do wait $p; done
 python3 - <<'PY'
 out = ['struct lr_asm_blob { const char *name; const unsigned char *data; unsigned long size; };']
 names = [("fwd", n, m) for n in (14, 15) for m in (0, 1, 2)] + [("inv", n, m) for n in (14, 15) for m in (0, 1)]
-names += [("fwd", n, m) for n in ("13x", "14x") for m in (0, 1, 2)] + [("inv", n, m) for n in ("13x", "14x") for m in (0, 1)]
+names += [("fwd", n, m) for n in ("13x", "14x", "16s", "16p") for m in (0, 1, 2)] + [("inv", n, m) for n in ("13x", "14x", "16s") for m in (0, 1)]
 for k, n, m in names:
     data = open("build/ntt_%s%s_m%d.hsaco" % (k, n, m), "rb").read()
     out.append('static const unsigned char blob_%s%s_m%d[] __attribute__((aligned(4096))) = {' % (k, n, m))

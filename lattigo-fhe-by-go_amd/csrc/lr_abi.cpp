@@ -301,8 +301,11 @@ extern "C" int lr_context_create(uint64_t N, const uint64_t *moduli, int n_modul
             inv[(size_t)i * N + j] = make_ulonglong2(wi, shoup_companion(wi, q));
         }
         if (N >= 2) {
-            // heap index 0 is unused by the transform: it carries psi_inv[1] * N^-1, the twiddle of the last
-            // inverse stage fused with the scaling (assembly kernels)
+            // heap index 0 is unused by the transform.  Forward: q - psi[1], the twiddle that turns the X-form butterfly
+            // into the Y output of the N = 2^16 top stage (assembly sub-block 1).  Inverse: psi_inv[1] * N^-1, the
+            // twiddle of the last inverse stage fused with the scaling.
+            const u64 nw1 = q - fwd[(size_t)i * N + 1].x;
+            fwd[(size_t)i * N] = make_ulonglong2(nw1, shoup_companion(nw1, q));
             const u64 w1n = (u64)(((u128)inv[(size_t)i * N + 1].x * p.n_inv) % q);
             inv[(size_t)i * N] = make_ulonglong2(w1n, shoup_companion(w1n, q));
         }
@@ -615,7 +618,33 @@ int run_ntt(lr_context *c, bool inverse, Rows in, Rows out, int mod0, int mod_st
     a.tw = inverse ? c->d_inv : c->d_fwd;
     a.tw_fin = inverse ? c->d_inv_fin : c->d_fwd_fin;
     const int variant = inverse ? c->asm_inv : c->asm_fwd;
-    if (variant >= 0 && c->use_asm && (hole > 0 ? group : batch) <= 65535 && (hole == 0 || batch / group <= 65535) &&
+    if (logn == 16 && variant >= 0 && c->use_asm && (hole > 0 ? group : batch) <= 65535 && (hole == 0 || batch / group <= 65535) &&
+        ntt_asm_available(16)) {
+        // two 2^15 sub-blocks per limb on the assembly kernels + the streaming stage over bit 15
+        if (!inverse) {
+            if (ntt_rows_disjoint(a, 16)) {
+                LR_HIP(launch_ntt_asm16(a, 0, 's', variant, c->stream));     // top stage fused into the loads
+                return LR_OK;
+            }
+            LR_HIP(launch_ntt_top(a, 0, c->stream));
+            NttLaunch sub = a;
+            sub.in = a.out;                      // continue in place on the output rows
+            sub.in_poly_stride = a.out_poly_stride;
+            sub.in_limb0 = a.out_limb0;
+            sub.in_limb_step = a.out_limb_step;
+            LR_HIP(launch_ntt_asm16(sub, 0, 'p', variant, c->stream));
+            return LR_OK;
+        }
+        LR_HIP(launch_ntt_asm16(a, 1, 's', variant, c->stream));
+        NttLaunch top = a;
+        top.in = a.out;
+        top.in_poly_stride = a.out_poly_stride;
+        top.in_limb0 = a.out_limb0;
+        top.in_limb_step = a.out_limb_step;
+        LR_HIP(launch_ntt_top(top, 1, c->stream));
+        return LR_OK;
+    }
+    if (logn != 16 && variant >= 0 && c->use_asm && (hole > 0 ? group : batch) <= 65535 && (hole == 0 || batch / group <= 65535) &&
         ntt_asm_available((int)logn)) {
         LR_HIP(launch_ntt_asm(a, (int)logn, inverse, variant, c->stream));
         return LR_OK;

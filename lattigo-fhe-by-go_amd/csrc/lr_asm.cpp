@@ -57,7 +57,7 @@ AsmKernels *kernels_for_current_device() {
 }
 }  // namespace
 
-bool ntt_asm_available(int logn) { return logn >= 13 && logn <= 15 && kernels_for_current_device() != nullptr; }
+bool ntt_asm_available(int logn) { return logn >= 13 && logn <= 16 && kernels_for_current_device() != nullptr; }
 
 // variant = lazy-correction mode of asmgen/gen_ntt.py (forward 0, 1, 2) / gen_intt.py (inverse 0, 1)
 hipError_t launch_ntt_asm(const NttLaunch &a, int logn, int inverse, int variant, hipStream_t stream) {
@@ -87,6 +87,32 @@ hipError_t launch_ntt_asm(const NttLaunch &a, int logn, int inverse, int variant
         gz = (unsigned)(a.batch / a.group);
     }
     return hipModuleLaunchKernel(it->second, (unsigned)a.n_items, gy, gz, x ? 512 : 1024, 1, 1, 0, stream, nullptr, extra);
+}
+
+// N = 2^16 runs as two 2^15 sub-blocks per limb (grid x = 2 * n_items).  kind: 's' = forward with the stage over
+// bit 15 fused into the loads (out of place only) / inverse sub-blocks (lazy outputs, ntt_top_kernel follows),
+// 'p' = forward sub-blocks after a separate ntt_top_kernel pass (in place allowed).
+hipError_t launch_ntt_asm16(const NttLaunch &a, int inverse, char kind, int variant, hipStream_t stream) {
+    AsmKernels *k = kernels_for_current_device();
+    if (!k) return hipErrorNotSupported;
+    char name[32];
+    std::snprintf(name, sizeof name, "lr_ntt_%s16%c_m%d", inverse ? "inv" : "fwd", kind, variant);
+    auto it = k->fn.find(name);
+    if (it == k->fn.end()) return hipErrorNotSupported;
+    if (a.n_items <= 0 || a.batch <= 0) return hipSuccess;
+    NttLaunch args = a;
+    args.sub_log = 1;
+    size_t size = sizeof(NttLaunch);
+    void *extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
+    (void)hipGetLastError();
+    unsigned gy = (unsigned)a.batch, gz = 1;
+    if (a.hole > 0) {
+        if (a.group <= 0 || a.batch % a.group != 0) return hipErrorInvalidValue;
+        gy = (unsigned)a.group;
+        gz = (unsigned)(a.batch / a.group);
+    }
+    if (gy > 65535u || gz > 65535u) return hipErrorInvalidValue;
+    return hipModuleLaunchKernel(it->second, 2u * (unsigned)a.n_items, gy, gz, 1024, 1, 1, 0, stream, nullptr, extra);
 }
 
 }  // namespace lr

@@ -193,6 +193,10 @@ hipError_t launch_ntt(const NttLaunch &a, int logn, bool inverse, int mode, hipS
 // hand-scheduled assembly forward NTT (lr_asm.cpp); N = 2^14 / 2^15, lazy mode 1 only
 bool ntt_asm_available(int logn);
 hipError_t launch_ntt_asm(const NttLaunch &a, int logn, int inverse, int variant, hipStream_t stream);
+hipError_t launch_ntt_asm16(const NttLaunch &a, int inverse, char kind, int variant, hipStream_t stream);
+// N = 2^16 helpers (lr_ntt.hip): the streaming stage over bit 15, and whether no input row of a launch is an output row
+hipError_t launch_ntt_top(const NttLaunch &a, int inverse, hipStream_t stream);
+bool ntt_rows_disjoint(const NttLaunch &a, int logn);
 hipError_t launch_ewise(int op, const EwiseLaunch &L, int limbs, int batch, hipStream_t stream);
 hipError_t launch_submul(const SubMulLaunch &L, int limbs, int batch, hipStream_t stream);
 hipError_t launch_rowadd(const RowAddLaunch &L, int rows, int batch, hipStream_t stream);

@@ -465,8 +465,10 @@ __global__ __launch_bounds__(256) void ntt_top_kernel(NttLaunch a, int logn, int
     const int mod = a.mod0 + item * a.mod_step;
     const long long n = 1ll << logn, h = n >> 1;
     const LimbParams lp = a.lp[mod];
-    const Twiddle w = (a.tw + (long long)mod * n)[1];
+    const Twiddle w = (a.tw + (long long)mod * n)[inverse ? 0 : 1];   // inverse: entry 0 = psi_inv[1] * N^-1
     const u64 q = lp.q, q4 = q << 2;
+    // the inverse sub-transforms leave values below 8q (q <= 2^60) or below 4q (larger moduli)
+    const u64 bound = (q >> 60) ? q4 : q4 << 1;
     const u64 *src = a.in + (long long)b * a.in_poly_stride + (long long)(a.in_limb0 + item * a.in_limb_step) * n;
     u64 *dst = a.out + (long long)b * a.out_poly_stride + (long long)(a.out_limb0 + item * a.out_limb_step) * n;
     for (long long j = (long long)blockIdx.x * 256 + threadIdx.x; j < h; j += (long long)gridDim.x * 256) {
@@ -477,9 +479,9 @@ __global__ __launch_bounds__(256) void ntt_top_kernel(NttLaunch a, int logn, int
             dst[j] = U;
             dst[j + h] = V;
         } else {
-            inv_bfly<false, false>(U, V, w.x, w.y, q, q4);            // inputs < 4q
-            st_stream(dst + j, canon_from_4q(mul_shoup_lazy(U, lp.n_inv, lp.n_inv_shoup, q), q));
-            st_stream(dst + j + h, canon_from_4q(mul_shoup_lazy(V, lp.n_inv, lp.n_inv_shoup, q), q));
+            const u64 s = U + V, t = U + bound - V;                   // any 64-bit value is a valid multiplicand
+            st_stream(dst + j, canon_from_4q(mul_shoup_lazy(s, lp.n_inv, lp.n_inv_shoup, q), q));
+            st_stream(dst + j + h, canon_from_4q(mul_shoup_lazy(t, w.x, w.y, q), q));
         }
     }
 }
@@ -535,6 +537,25 @@ static hipError_t launch_big(const NttLaunch &a, bool inverse, int mode, hipStre
     }
 }
 
+hipError_t launch_ntt_top(const NttLaunch &a, int inverse, hipStream_t stream) {
+    if (a.n_items <= 0 || a.batch <= 0) return hipSuccess;
+    const dim3 tgrid(64, (unsigned)(a.n_items * a.batch)), tblock(256);
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(ntt_top_kernel, tgrid, tblock, 0, stream, a, 16, inverse);
+    return hipGetLastError();
+}
+
+bool ntt_rows_disjoint(const NttLaunch &a, int logn) {
+    const long long n_full = 1ll << logn;
+    const long long last = (long long)(a.n_items - 1 + (a.hole > 0 ? a.hole : 0));
+    const u64 *in_lo = a.in + (long long)a.in_limb0 * n_full;
+    const u64 *in_hi = a.in + (long long)(a.batch - 1) * a.in_poly_stride + ((long long)a.in_limb0 + last * a.in_limb_step + 1) * n_full;
+    const u64 *out_lo = a.out + (long long)a.out_limb0 * n_full;
+    const u64 *out_hi = a.out + (long long)(a.batch - 1) * a.out_poly_stride + ((long long)a.out_limb0 + last * a.out_limb_step + 1) * n_full;
+    const bool positive = a.in_poly_stride >= 0 && a.out_poly_stride >= 0 && a.in_limb_step >= 0 && a.out_limb_step >= 0;
+    return positive && (in_hi <= out_lo || out_hi <= in_lo);
+}
+
 hipError_t launch_ntt(const NttLaunch &a, int logn, bool inverse, int mode, hipStream_t stream) {
     if (a.n_items <= 0 || a.batch <= 0) return hipSuccess;
     switch (logn) {
@@ -551,14 +572,7 @@ hipError_t launch_ntt(const NttLaunch &a, int logn, bool inverse, int mode, hipS
         sub.sub_log = 1;
         if (!inverse) {
             // out of place (no byte of the input rows is an output row): one pass, the sub-transforms do the top stage
-            const long long n_full = 1ll << 16;
-            const long long last = (long long)(a.n_items - 1 + (a.hole > 0 ? a.hole : 0));
-            const u64 *in_lo = a.in + (long long)a.in_limb0 * n_full;
-            const u64 *in_hi = a.in + (long long)(a.batch - 1) * a.in_poly_stride + ((long long)a.in_limb0 + last * a.in_limb_step + 1) * n_full;
-            const u64 *out_lo = a.out + (long long)a.out_limb0 * n_full;
-            const u64 *out_hi = a.out + (long long)(a.batch - 1) * a.out_poly_stride + ((long long)a.out_limb0 + last * a.out_limb_step + 1) * n_full;
-            const bool positive = a.in_poly_stride >= 0 && a.out_poly_stride >= 0 && a.in_limb_step >= 0 && a.out_limb_step >= 0;
-            if (positive && (in_hi <= out_lo || out_hi <= in_lo)) {
+            if (ntt_rows_disjoint(a, 16)) {
                 sub.fuse_top = 1;
                 return launch_big<15>(sub, false, mode, stream);
             }
