@@ -32,7 +32,7 @@ for logn in (12, 13, 14, 15, 16):
     N, Q = params.DefaultParamsQi(logn)
     _, P = params.DefaultParamsPi(logn)
     L = len(Q)
-    B = max(2, (1 << 29) // (8 * N * L))          # 512 MiB per buffer
+    B = max(2, (1 << 30) // (8 * N * L))          # 1 GiB per buffer (R15: 256 polys, the batch bench.py uses)
     cQ, cP = ring.NewContextWithParams(N, Q), ring.NewContextWithParams(N, P)
     base = sampling.uniform_poly(Q, N, 2, seed=logn)
     host = np.concatenate([base] * (B // 2))
