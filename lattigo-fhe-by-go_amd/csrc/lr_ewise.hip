@@ -259,9 +259,14 @@ hipError_t launch_rowadd(const RowAddLaunch &L, int rows, int batch, hipStream_t
 // Reduce calls (reduce&7 cadence); the sums are below 8q < 2^64 between reductions either way and the final
 // Reduce makes the result canonical, so one pass over all digits yields the same values while the accumulators
 // never travel through HBM.
+// BETA > 0: the digit count is known at compile time, so all of a coefficient pair's digit and key loads are issued
+// before the first multiply (memory-level parallelism instead of one load round trip per digit); BETA = 0: generic.
+template <int BETA>
 __global__ __launch_bounds__(256) void keymac_kernel(KeyMacLaunch L) {
+    // x = poly of the batch (fastest): the workgroups that run together share one tile of the key, which therefore
+    // stays in L2 instead of being re-read from the Infinity Cache once per poly
     const int limb = blockIdx.y;
-    const long long b = blockIdx.z;
+    const long long b = blockIdx.x;
     const LimbParams lp = L.lp[limb];
     const long long row = (long long)limb * L.n;
     const ulonglong2 *pc = reinterpret_cast<const ulonglong2 *>(L.c2 + b * L.c2_poly_stride + row);
@@ -272,20 +277,44 @@ __global__ __launch_bounds__(256) void keymac_kernel(KeyMacLaunch L) {
     const ulonglong2 *pown = L.alpha > 0 ? reinterpret_cast<const ulonglong2 *>(L.own + b * L.own_stride + row) : nullptr;
     const int own_digit = L.alpha > 0 ? limb / L.alpha : -1;
     const int pairs = L.n >> 1;
-    for (int e = blockIdx.x * 256 + threadIdx.x; e < pairs; e += gridDim.x * 256) {
+    const int beta = BETA > 0 ? BETA : L.beta;
+    for (int e = blockIdx.z * 256 + threadIdx.x; e < pairs; e += gridDim.z * 256) {
         u64 a0x = 0, a0y = 0, a1x = 0, a1y = 0;
-        for (int i = 0; i < L.beta; ++i) {
-            const ulonglong2 c = ld_stream(i == own_digit ? pown + e : pc + e + i * cd);
-            const ulonglong2 k0 = pk[e + (2 * i) * kd], k1 = pk[e + (2 * i + 1) * kd];
-            a0x += mred(k0.x, c.x, lp.q, lp.qinv);
-            a0y += mred(k0.y, c.y, lp.q, lp.qinv);
-            a1x += mred(k1.x, c.x, lp.q, lp.qinv);
-            a1y += mred(k1.y, c.y, lp.q, lp.qinv);
-            if ((i & 7) == 7) {
-                a0x = bred_add(a0x, lp.q, lp.bred_hi);
-                a0y = bred_add(a0y, lp.q, lp.bred_hi);
-                a1x = bred_add(a1x, lp.q, lp.bred_hi);
-                a1y = bred_add(a1y, lp.q, lp.bred_hi);
+        if constexpr (BETA > 0) {
+            ulonglong2 c[BETA], k0[BETA], k1[BETA];
+#pragma unroll
+            for (int i = 0; i < BETA; ++i) {
+                c[i] = ld_stream(i == own_digit ? pown + e : pc + e + i * cd);
+                k0[i] = pk[e + (2 * i) * kd];
+                k1[i] = pk[e + (2 * i + 1) * kd];
+            }
+#pragma unroll
+            for (int i = 0; i < BETA; ++i) {
+                a0x += mred(k0[i].x, c[i].x, lp.q, lp.qinv);
+                a0y += mred(k0[i].y, c[i].y, lp.q, lp.qinv);
+                a1x += mred(k1[i].x, c[i].x, lp.q, lp.qinv);
+                a1y += mred(k1[i].y, c[i].y, lp.q, lp.qinv);
+                if ((i & 7) == 7) {
+                    a0x = bred_add(a0x, lp.q, lp.bred_hi);
+                    a0y = bred_add(a0y, lp.q, lp.bred_hi);
+                    a1x = bred_add(a1x, lp.q, lp.bred_hi);
+                    a1y = bred_add(a1y, lp.q, lp.bred_hi);
+                }
+            }
+        } else {
+            for (int i = 0; i < beta; ++i) {
+                const ulonglong2 c = ld_stream(i == own_digit ? pown + e : pc + e + i * cd);
+                const ulonglong2 k0 = pk[e + (2 * i) * kd], k1 = pk[e + (2 * i + 1) * kd];
+                a0x += mred(k0.x, c.x, lp.q, lp.qinv);
+                a0y += mred(k0.y, c.y, lp.q, lp.qinv);
+                a1x += mred(k1.x, c.x, lp.q, lp.qinv);
+                a1y += mred(k1.y, c.y, lp.q, lp.qinv);
+                if ((i & 7) == 7) {
+                    a0x = bred_add(a0x, lp.q, lp.bred_hi);
+                    a0y = bred_add(a0y, lp.q, lp.bred_hi);
+                    a1x = bred_add(a1x, lp.q, lp.bred_hi);
+                    a1y = bred_add(a1y, lp.q, lp.bred_hi);
+                }
             }
         }
         st_stream(po0 + e, make_ulonglong2(bred_add(a0x, lp.q, lp.bred_hi), bred_add(a0y, lp.q, lp.bred_hi)));
@@ -297,9 +326,15 @@ hipError_t launch_keymac(const KeyMacLaunch &L, int limbs, int batch, hipStream_
     if (limbs <= 0 || batch <= 0) return hipSuccess;
     int gx = ((L.n >> 1) + 255) / 256;
     if (gx > 64) gx = 64;
-    const dim3 grid((unsigned)gx, (unsigned)limbs, (unsigned)batch), block(256);
+    const dim3 grid((unsigned)batch, (unsigned)limbs, (unsigned)gx), block(256);
     (void)hipGetLastError();
-    hipLaunchKernelGGL(keymac_kernel, grid, block, 0, stream, L);
+    switch (L.beta) {
+#define LR_KM(B) \
+    case B: hipLaunchKernelGGL(keymac_kernel<B>, grid, block, 0, stream, L); break;
+        LR_KM(1) LR_KM(2) LR_KM(3) LR_KM(4) LR_KM(5) LR_KM(6) LR_KM(7) LR_KM(8) LR_KM(9) LR_KM(10)
+#undef LR_KM
+    default: hipLaunchKernelGGL(keymac_kernel<0>, grid, block, 0, stream, L); break;
+    }
     return hipGetLastError();
 }
 
