@@ -287,10 +287,7 @@ class GenInv(Gen):
         e("v_add_u32", a1, 8 * 9216 if self.C == 1 else 4608, a0)
         for c in range(self.C):
             for kk in range(self.SPH):
-                if self.C == 1:
-                    base, off = (a0, kk * 9216) if kk < 8 else (a1, (kk - 8) * 9216)
-                else:
-                    base, off = (a0 if c == 0 else a1), kk * 9216
+                base, off = self.lds_col(c, kk, a0, a1)
                 e("ds_read_b64", self.X[c * self.RA + self.SPH * half + kk], base, offset=off)
         if half + 1 < self.HALVES:
             e("s_waitcnt", "lgkmcnt(0)")
@@ -386,11 +383,12 @@ class GenInv(Gen):
         e = self.e
         self.c("coalesced store of the columns {k*S + t + c*T}")
         e("v_lshlrev_b32", self.GOFF, 3, self.TID)
-        if self.C == 2:
-            e("v_add_u32", self.A_[2], self.T * 8, self.GOFF)
+        if self.C > 1:
+            e("v_add_u32", self.A_[2], 4096, self.GOFF)
         for k in range(self.RA):
             for col in range(self.C):
-                e("global_store_dwordx2", self.GOFF if col == 0 else self.A_[2], self.X[col * self.RA + k], self.DST, hint="nt")
+                off, imm = self.col_addr(col)
+                e("global_store_dwordx2", off, self.X[col * self.RA + k], self.DST, offset=imm, hint="nt")
             e("s_add_u32", self.DST.lo(), self.DST.lo(), self.S * 8)
             e("s_addc_u32", self.DST.hi(), self.DST.hi(), 0)
 
@@ -432,5 +430,5 @@ if __name__ == "__main__":
     if logn == 16:
         open(sys.argv[2], "w").write(kernel_text_for(GenInv(15, mode, 1024, sub=True), "lr_ntt_inv16s_m%d" % mode))
         sys.exit(0)
-    name = "lr_ntt_inv%d%s_m%d" % (logn, "x" if threads == 512 else "", mode)
+    name = "lr_ntt_inv%d%s_m%d" % (logn, "x" if threads < 1024 else "", mode)
     open(sys.argv[2], "w").write(kernel_text_for(GenInv(logn, mode, threads), name))

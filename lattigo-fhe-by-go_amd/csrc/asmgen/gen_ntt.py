@@ -29,7 +29,7 @@ class Gen:
          0: q <  2^61, U <- U - 4q (if U >= 4q) before every stage."""
 
     def __init__(self, logn, mode=1, threads=1024, sub=False, fused=True):
-        assert logn in (13, 14, 15) and mode in (0, 1, 2) and threads in (512, 1024)
+        assert logn in (12, 13, 14, 15) and mode in (0, 1, 2) and threads in (256, 512, 1024)
         assert not sub or (logn == 15 and threads == 1024)
         self.fused = fused            # forward sub-block kernels: compute the top stage while loading (out of place only)
         # sub: the kernel transforms one 2^15 half ("sub-block" blk = workgroup x & 1) of an N = 2^16 limb; twiddles come
@@ -41,7 +41,7 @@ class Gen:
         self.mode = mode
         self.logn = logn
         self.N = 1 << logn
-        self.T = threads              # 1024, or 512 for N = 2^14: half the LDS and registers, two workgroups per CU
+        self.T = threads              # 1024; 512 (N = 2^13, 2^14) / 256 (N = 2^12): smaller LDS image, several workgroups per CU
         self.WAVES = threads // 64
         self.A = logn - 10            # bits consumed by pass A
         self.RA = 1 << self.A         # rows k of a column {k*S + t}
@@ -125,6 +125,19 @@ class Gen:
 
     def c(self, text):
         self.p.comment(text)
+
+    def col_addr(self, c):
+        """(offset VGPR, immediate) addressing column t + c*T of a row: GOFF = t*8, A_[2] = GOFF + 4096"""
+        off = c * self.T * 8
+        return (self.GOFF if off < 4096 else self.A_[2]), off % 4096
+
+    def lds_col(self, c, kk, a0, a1):
+        """(base VGPR, immediate) of row kk, column t + c*T in the LDS image: block kk at slot(t + c*T) = slot(t) + 9T/8 * c.
+        a1 = a0 + 8 blocks (one column per thread) or a0 + 4608 (several)"""
+        if self.C == 1:
+            return (a0, kk * 9216) if kk < 8 else (a1, (kk - 8) * 9216)
+        off = kk * 9216 + c * self.T * 9
+        return (a0, off) if off < 65536 else (a1, off - 4608)
 
     def tw_slot(self, i):
         return v(self.tw_base + 4 * i, 4)
@@ -393,13 +406,13 @@ class Gen:
         # order 0, RA/2, 1, RA/2+1, ... (per column): the first-stage butterflies can start after two loads
         e("s_add_u32", self.TMP.lo(), self.SRC.lo(), (self.RA // 2) * self.S * 8)
         e("s_addc_u32", self.TMP.hi(), self.SRC.hi(), 0)
-        if self.C == 2:
-            e("v_add_u32", self.A_[2], self.T * 8, self.GOFF)
+        if self.C > 1:
+            e("v_add_u32", self.A_[2], 4096, self.GOFF)
         for k in range(self.RA // 2):
             for c in range(self.C):
-                off = self.GOFF if c == 0 else self.A_[2]
-                e("global_load_dwordx2", self.X[c * self.RA + k], off, self.SRC, hint="nt")
-                e("global_load_dwordx2", self.X[c * self.RA + k + self.RA // 2], off, self.TMP, hint="nt")
+                off, imm = self.col_addr(c)
+                e("global_load_dwordx2", self.X[c * self.RA + k], off, self.SRC, offset=imm, hint="nt")
+                e("global_load_dwordx2", self.X[c * self.RA + k + self.RA // 2], off, self.TMP, offset=imm, hint="nt")
             for ptr in (self.SRC, self.TMP):
                 e("s_add_u32", ptr.lo(), ptr.lo(), self.S * 8)
                 e("s_addc_u32", ptr.hi(), ptr.hi(), 0)
@@ -499,10 +512,7 @@ class Gen:
         e("v_add_u32", a1, 8 * 9216 if self.C == 1 else 4608, a0)
         for c in range(self.C):
             for kk in range(self.SPH):
-                if self.C == 1:
-                    base, off = (a0, kk * 9216) if kk < 8 else (a1, (kk - 8) * 9216)
-                else:
-                    base, off = (a0 if c == 0 else a1), kk * 9216
+                base, off = self.lds_col(c, kk, a0, a1)
                 e("ds_write_b64", base, self.X[c * self.RA + self.SPH * half + kk], offset=off)
         e("s_waitcnt", "lgkmcnt(0)")
         e("s_barrier")
@@ -1075,5 +1085,5 @@ if __name__ == "__main__":
         open(sys.argv[2], "w").write(kernel_text_for(Gen(15, mode, 1024, sub=True, fused=fused),
                                                      "lr_ntt_fwd16%s_m%d" % ("s" if fused else "p", mode)))
         sys.exit(0)
-    name = "lr_ntt_fwd%d%s_m%d" % (logn, "x" if threads == 512 else "", mode)     # x: two workgroups per CU
+    name = "lr_ntt_fwd%d%s_m%d" % (logn, "x" if threads < 1024 else "", mode)     # x: several workgroups per CU
     open(sys.argv[2], "w").write(kernel_text_for(Gen(logn, mode, threads), name))

@@ -8,8 +8,8 @@ mkdir -p build
 # hand-scheduled assembly kernels: generate -> assemble -> embed
 LLVM=${LLVM:-/opt/rocm/lib/llvm/bin}
 # forward: modes 0 (q < 2^61), 1 (q <= 2^60), 2 (q < 2^57); inverse: modes 0 and 1
-gen_one() {  # kind degree mode [threads]; 512 threads = the two-workgroups-per-CU plan ("x" kernels, N = 2^14)
-  local tag=$2; [ "${4:-1024}" = 512 ] && tag=${2}x
+gen_one() {  # kind degree mode [threads]; fewer than 1024 threads = the several-workgroups-per-CU plans ("x" kernels)
+  local tag=$2; [ "${4:-1024}" != 1024 ] && tag=${2}x
   python3 asmgen/gen_$( [ "$1" = fwd ] && echo ntt || echo intt ).py $2 build/ntt_$1${tag}_m$3.s $3 ${4:-1024}
   $LLVM/clang -x assembler -target amdgcn-amd-amdhsa -mcpu=gfx950 -c build/ntt_$1${tag}_m$3.s -o build/ntt_$1${tag}_m$3.o
   $LLVM/ld.lld -shared build/ntt_$1${tag}_m$3.o -o build/ntt_$1${tag}_m$3.hsaco
@@ -23,6 +23,8 @@ for n in 13 14; do
   for m in 0 1 2; do gen_one fwd $n $m 512 & gpids+=($!); done
   for m in 0 1; do gen_one inv $n $m 512 & gpids+=($!); done
 done
+for m in 0 1 2; do gen_one fwd 12 $m 256 & gpids+=($!); done
+for m in 0 1; do gen_one inv 12 $m 256 & gpids+=($!); done
 # N = 2^16: 2^15 sub-block kernels (forward with the top stage fused into the loads = s, plain = p; inverse = s)
 gen_sub() {  # kind tag mode [plain]
   python3 asmgen/gen_$( [ "$1" = fwd ] && echo ntt || echo intt ).py 16 build/ntt_$1$2_m$3.s $3 1024 $4
@@ -35,7 +37,7 @@ for p in "${gpids[@]}"; do wait $p; done
 python3 - <<'PY'
 out = ['struct lr_asm_blob { const char *name; const unsigned char *data; unsigned long size; };']
 names = [("fwd", n, m) for n in (14, 15) for m in (0, 1, 2)] + [("inv", n, m) for n in (14, 15) for m in (0, 1)]
-names += [("fwd", n, m) for n in ("13x", "14x", "16s", "16p") for m in (0, 1, 2)] + [("inv", n, m) for n in ("13x", "14x", "16s") for m in (0, 1)]
+names += [("fwd", n, m) for n in ("12x", "13x", "14x", "16s", "16p") for m in (0, 1, 2)] + [("inv", n, m) for n in ("12x", "13x", "14x", "16s") for m in (0, 1)]
 for k, n, m in names:
     data = open("build/ntt_%s%s_m%d.hsaco" % (k, n, m), "rb").read()
     out.append('static const unsigned char blob_%s%s_m%d[] __attribute__((aligned(4096))) = {' % (k, n, m))

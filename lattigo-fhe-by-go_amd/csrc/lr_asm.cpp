@@ -57,16 +57,17 @@ AsmKernels *kernels_for_current_device() {
 }
 }  // namespace
 
-bool ntt_asm_available(int logn) { return logn >= 13 && logn <= 16 && kernels_for_current_device() != nullptr; }
+bool ntt_asm_available(int logn) { return logn >= 12 && logn <= 16 && kernels_for_current_device() != nullptr; }
 
 // variant = lazy-correction mode of asmgen/gen_ntt.py (forward 0, 1, 2) / gen_intt.py (inverse 0, 1)
 hipError_t launch_ntt_asm(const NttLaunch &a, int logn, int inverse, int variant, hipStream_t stream) {
     AsmKernels *k = kernels_for_current_device();
-    if (!k || logn < 13 || logn > 15) return hipErrorNotSupported;
-    // N = 2^13 and 2^14 have a 512-thread plan (two columns per thread, 72 KiB LDS image): two workgroups share a CU and one
+    if (!k || logn < 12 || logn > 15) return hipErrorNotSupported;
+    // N = 2^12 (256 threads, four columns per thread, 36 KiB LDS image) and N = 2^13, 2^14 (512 threads, two columns,
+    // 72 KiB) run several workgroups per CU: one
     // covers the other's load and store phases.  LR_ASM_14_1024=1 selects the 1024-thread kernels (testing aid).
     const bool wide14 = std::getenv("LR_ASM_14_1024") != nullptr;
-    const bool x = logn == 13 || (logn == 14 && !wide14);
+    const bool x = logn <= 13 || (logn == 14 && !wide14);
     char name[32];
     std::snprintf(name, sizeof name, "lr_ntt_%s%d%s_m%d", inverse ? "inv" : "fwd", logn, x ? "x" : "", variant);
     auto it = k->fn.find(name);
@@ -86,7 +87,7 @@ hipError_t launch_ntt_asm(const NttLaunch &a, int logn, int inverse, int variant
         gy = (unsigned)a.group;
         gz = (unsigned)(a.batch / a.group);
     }
-    return hipModuleLaunchKernel(it->second, (unsigned)a.n_items, gy, gz, x ? 512 : 1024, 1, 1, 0, stream, nullptr, extra);
+    return hipModuleLaunchKernel(it->second, (unsigned)a.n_items, gy, gz, !x ? 1024 : logn == 12 ? 256 : 512, 1, 1, 0, stream, nullptr, extra);
 }
 
 // N = 2^16 runs as two 2^15 sub-blocks per limb (grid x = 2 * n_items).  kind: 's' = forward with the stage over

@@ -204,7 +204,7 @@ ASM_CASES = [("qi60", None), ("qi60", "0"), ("ckks", None), ("ckks", "1"), ("ckk
 
 
 @pytest.mark.parametrize("kind,force", ASM_CASES)
-@pytest.mark.parametrize("logn", [13, 14, 15, 16])
+@pytest.mark.parametrize("logn", [12, 13, 14, 15, 16])
 def test_cxx_and_asm_paths_agree(gpu_pkg, oracle, logn, kind, force, monkeypatch):
     """N = 2^14 / 2^15 with moduli above 2^33 run on the hand-scheduled assembly kernels (three lazy-correction
     variants, chosen from the largest modulus; LR_ASM_VARIANT forces a more conservative one); LR_NO_ASM=1 selects
@@ -236,7 +236,7 @@ def test_cxx_and_asm_paths_agree(gpu_pkg, oracle, logn, kind, force, monkeypatch
 
 
 @pytest.mark.parametrize("kind,force", ASM_CASES)
-@pytest.mark.parametrize("logn", [13, 14, 15, 16])
+@pytest.mark.parametrize("logn", [12, 13, 14, 15, 16])
 def test_cxx_and_asm_inverse_paths_agree(gpu_pkg, oracle, logn, kind, force, monkeypatch):
     """inverse twin of the test above: the assembly InvNTT (last stage fused with the N^-1 scaling) and the C++
     kernel both equal the oracle, on inputs anywhere in the documented lazy range [0, 4q), out of place and in place"""
