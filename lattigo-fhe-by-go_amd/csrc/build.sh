@@ -19,12 +19,9 @@ for n in 14 15; do
   for m in 0 1 2; do gen_one fwd $n $m & gpids+=($!); done
   for m in 0 1; do gen_one inv $n $m & gpids+=($!); done
 done
-for n in 13 14; do
-  for m in 0 1 2; do gen_one fwd $n $m 512 & gpids+=($!); done
-  for m in 0 1; do gen_one inv $n $m 512 & gpids+=($!); done
-done
-for m in 0 1 2; do gen_one fwd 12 $m 256 & gpids+=($!); done
-for m in 0 1; do gen_one inv 12 $m 256 & gpids+=($!); done
+# measured best plan per degree and direction: 2^14: 512 threads; 2^13: 256 forward / 512 inverse; 2^12: 256
+for m in 0 1 2; do gen_one fwd 14 $m 512 & gpids+=($!); gen_one fwd 13 $m 256 & gpids+=($!); gen_one fwd 12 $m 256 & gpids+=($!); done
+for m in 0 1; do gen_one inv 14 $m 512 & gpids+=($!); gen_one inv 13 $m 512 & gpids+=($!); gen_one inv 12 $m 256 & gpids+=($!); done
 # N = 2^16: 2^15 sub-block kernels (forward with the top stage fused into the loads = s, plain = p; inverse = s)
 gen_sub() {  # kind tag mode [plain]
   python3 asmgen/gen_$( [ "$1" = fwd ] && echo ntt || echo intt ).py 16 build/ntt_$1$2_m$3.s $3 1024 $4

@@ -87,7 +87,7 @@ hipError_t launch_ntt_asm(const NttLaunch &a, int logn, int inverse, int variant
         gy = (unsigned)a.group;
         gz = (unsigned)(a.batch / a.group);
     }
-    return hipModuleLaunchKernel(it->second, (unsigned)a.n_items, gy, gz, !x ? 1024 : logn == 12 ? 256 : 512, 1, 1, 0, stream, nullptr, extra);
+    return hipModuleLaunchKernel(it->second, (unsigned)a.n_items, gy, gz, !x ? 1024 : (logn == 12 || (logn == 13 && !inverse)) ? 256 : 512, 1, 1, 0, stream, nullptr, extra);
 }
 
 // N = 2^16 runs as two 2^15 sub-blocks per limb (grid x = 2 * n_items).  kind: 's' = forward with the stage over
