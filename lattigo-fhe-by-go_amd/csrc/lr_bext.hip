@@ -92,13 +92,13 @@ __global__ __launch_bounds__(256) void ext_shoup_kernel(ExtLaunch L) {
         u64 *out = sg.out + b * sg.stride + (long long)sg.limb0 * L.n + W * xw;
         for (int jj = 0; jj < sg.count; ++jj) {
             const int col = sg.col0 + jj;
-            const u64 pj = L.t.P[col], bh = L.t.bredP_hi[col];
+            const u64 pj = ld_const(L.t.P + col), bh = ld_const(L.t.bredP_hi + col);
             u64 acc[W];
 #pragma unroll
             for (int w = 0; w < W; ++w) acc[w] = 0;
 #pragma unroll
             for (int i = 0; i < NIN; ++i) {
-                const ulonglong2 c = L.t.qispj_shoup[(long long)i * L.t.nP + col];
+                const ulonglong2 c = ld_const(L.t.qispj_shoup + (long long)i * L.t.nP + col);
 #pragma unroll
                 for (int w = 0; w < W; ++w) {
                     acc[w] += EXACT ? mul_shoup_exact(y[w][i], c.x, c.y, pj) : mul_shoup_lazy(y[w][i], c.x, c.y, pj);

@@ -170,6 +170,16 @@ struct ExtLaunch {
 };
 
 #if defined(__HIPCC__)
+// Tables that no kernel writes, read at wave-uniform addresses: through the constant address space, so that the
+// compiler keeps using scalar loads after the kernel has started storing (it cannot prove that the stores do not
+// alias a plain global pointer and falls back to one vector load round trip per use).
+typedef const unsigned long __attribute__((address_space(4))) lr_const_u64;
+__device__ __forceinline__ unsigned long ld_const(const unsigned long *p) { return *(lr_const_u64 *)(unsigned long)p; }
+__device__ __forceinline__ ulonglong2 ld_const(const ulonglong2 *p) {
+    lr_const_u64 *q = (lr_const_u64 *)(unsigned long)p;
+    return make_ulonglong2(q[0], q[1]);
+}
+
 // streaming access to poly data (each element is read or written once per launch): the `nt` cache policy keeps
 // it from displacing the twiddle / key tables in L2 and the Infinity Cache
 typedef unsigned long long lr_u64x2 __attribute__((ext_vector_type(2)));
