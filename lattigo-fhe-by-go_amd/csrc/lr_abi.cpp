@@ -135,7 +135,7 @@ struct DevModup {
             }
         LR_TRY(to_device(&qispj_shoup, sh.data(), sh.size()));
         const u128 room = ((u128)1 << 64) - pmax;
-        lazy_terms = (int)std::min<u128>(room / ((u128)4 * pmax), 1 << 20);
+        lazy_terms = (int)std::min<u128>(room / ((u128)5 * pmax), 1 << 20);   // 4p per term + p per unit of the correction v <= terms
         exact_terms = (int)std::min<u128>(room / ((u128)2 * pmax), 1 << 20);
         return LR_OK;
     }

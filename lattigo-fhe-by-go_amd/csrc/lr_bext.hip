@@ -106,8 +106,16 @@ __global__ __launch_bounds__(256) void ext_shoup_kernel(ExtLaunch L) {
                 }
             }
             const u64 *corr = L.t.qpj_inv + (long long)col * (L.t.nQ + 1);
+            if (EXACT) {
 #pragma unroll
-            for (int w = 0; w < W; ++w) acc[w] = bred_add(acc[w] + corr[vi[w]], pj, bh);
+                for (int w = 0; w < W; ++w) acc[w] = bred_add(acc[w] + corr[vi[w]], pj, bh);
+            } else {
+                // qpjInv[j][v] = v * qpjInv[j][1] mod p_j (ring_basis_extension.go:134-138): the product instead of a
+                // per-lane table look-up; the host admits this path only if NIN lazy terms plus NIN * p fit in 64 bits
+                const u64 nq = ld_const(corr + 1);
+#pragma unroll
+                for (int w = 0; w < W; ++w) acc[w] = bred_add(acc[w] + vi[w] * nq, pj, bh);
+            }
             if (W == 2) st_stream(reinterpret_cast<ulonglong2 *>(out + (long long)jj * L.n), make_ulonglong2(acc[0], acc[W - 1]));
             else st_stream(out + (long long)jj * L.n, acc[0]);
         }

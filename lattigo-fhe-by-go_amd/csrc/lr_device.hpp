@@ -150,7 +150,7 @@ struct ExtTables {        // device pointers; modupParams of ring_basis_extensio
     // the same (Q/q_i) mod p_j out of Montgomery form, with the Shoup companion floor(c * 2^64 / p_j): the
     // products y_i * c accumulate lazily and are reduced once, to the same canonical residue
     const ulonglong2 *qispj_shoup;  // [nQ][nP] {c, companion}
-    int lazy_terms;       // how many [0,4p) terms plus one canonical value fit in 64 bits for the largest p
+    int lazy_terms;       // how many [0,4p) terms, each with one p of the correction v * qpjInv[1], fit in 64 bits
     int exact_terms;      // the same for [0,2p) terms
 };
 
