@@ -873,10 +873,13 @@ ExtSegment segment(u64 *out, long long stride, int limb0, int col0, int count) {
 
 int run_submul(lr_context *c, int limbs, int batch, const u64 *a, long long a_stride, const u64 *b, long long b_stride,
                long long b_row_stride, u64 *out, long long out_stride, const u64 *d_consts, bool reduce_b,
-               const LimbScalars *addend, const u64 *plus = nullptr, long long plus_stride = 0) {
+               const LimbScalars *addend, const u64 *plus = nullptr, long long plus_stride = 0, const LimbScalars *post = nullptr) {
     SubMulLaunch L;
     L.plus = plus;
     L.plus_stride = plus_stride;
+    L.has_post = post ? 1 : 0;
+    if (post) L.post = *post;
+    else std::memset(&L.post, 0, sizeof(L.post));
     L.a = a;
     L.b = b;
     L.out = out;
@@ -1596,7 +1599,7 @@ struct lr_bfv_plan {
     u64 t = 0;
     LimbScalars phalf_q, phalf_m;     // pHalf = (prod QMul) >> 1 reduced modulo each prime
     int max_batch = 0;
-    Pool aQ[2], aM[2], bQ[2], bM[2], cQ3[3], cM3[3], m00Q, m00M, m01Q, m01M;
+    Pool aQ[2], aM[2], bQ[2], bM[2], cQ3[3], cM3[3];
 };
 
 namespace {
@@ -1673,10 +1676,6 @@ extern "C" int lr_bfv_mul(lr_bfv_plan *pl, const lr_poly *a0, const lr_poly *a1,
         LR_TRY(pl->cQ3[i].ensure(cQ, (size_t)batch * sQ));
         LR_TRY(pl->cM3[i].ensure(cQ, (size_t)batch * sM));
     }
-    LR_TRY(pl->m00Q.ensure(cQ, (size_t)batch * sQ));
-    LR_TRY(pl->m01Q.ensure(cQ, (size_t)batch * sQ));
-    LR_TRY(pl->m00M.ensure(cQ, (size_t)batch * sM));
-    LR_TRY(pl->m01M.ensure(cQ, (size_t)batch * sM));
     lr_bext *bx = pl->bext;
     // :298-313  basis extension Q -> QMul, then NTT in both bases
     for (int i = 0; i < 2; ++i) {
@@ -1689,20 +1688,25 @@ extern "C" int lr_bfv_mul(lr_bfv_plan *pl, const lr_poly *a0, const lr_poly *a1,
             LR_TRY(run_ntt(cM, false, Rows{dM.d, sM, 0, 1}, Rows{dM.d, sM, 0, 1}, 0, 1, nM, batch));
         }
     }
-    // :327-331
-    LR_TRY(run_ewise(cQ, LR_MFORM, nQ, batch, pl->aQ[0].d, sQ, nullptr, 0, pl->m00Q.d, sQ, nullptr));
-    LR_TRY(run_ewise(cM, LR_MFORM, nM, batch, pl->aM[0].d, sM, nullptr, 0, pl->m00M.d, sM, nullptr));
-    LR_TRY(run_ewise(cQ, LR_MFORM, nQ, batch, pl->aQ[1].d, sQ, nullptr, 0, pl->m01Q.d, sQ, nullptr));
-    LR_TRY(run_ewise(cM, LR_MFORM, nM, batch, pl->aM[1].d, sM, nullptr, 0, pl->m01M.d, sM, nullptr));
-    // :354-367 tensor
-    LR_TRY(run_ewise(cQ, LR_MUL_MONT, nQ, batch, pl->m00Q.d, sQ, pl->bQ[0].d, sQ, pl->cQ3[0].d, sQ, nullptr));
-    LR_TRY(run_ewise(cM, LR_MUL_MONT, nM, batch, pl->m00M.d, sM, pl->bM[0].d, sM, pl->cM3[0].d, sM, nullptr));
-    LR_TRY(run_ewise(cQ, LR_MUL_MONT, nQ, batch, pl->m00Q.d, sQ, pl->bQ[1].d, sQ, pl->cQ3[1].d, sQ, nullptr));
-    LR_TRY(run_ewise(cM, LR_MUL_MONT, nM, batch, pl->m00M.d, sM, pl->bM[1].d, sM, pl->cM3[1].d, sM, nullptr));
-    LR_TRY(run_ewise(cQ, LR_MUL_MONT_AND_ADD_NOMOD, nQ, batch, pl->m01Q.d, sQ, pl->bQ[0].d, sQ, pl->cQ3[1].d, sQ, nullptr));
-    LR_TRY(run_ewise(cM, LR_MUL_MONT_AND_ADD_NOMOD, nM, batch, pl->m01M.d, sM, pl->bM[0].d, sM, pl->cM3[1].d, sM, nullptr));
-    LR_TRY(run_ewise(cQ, LR_MUL_MONT, nQ, batch, pl->m01Q.d, sQ, pl->bQ[1].d, sQ, pl->cQ3[2].d, sQ, nullptr));
-    LR_TRY(run_ewise(cM, LR_MUL_MONT, nM, batch, pl->m01M.d, sM, pl->bM[1].d, sM, pl->cM3[2].d, sM, nullptr));
+    // :327-367 MForm x2 and the four products per base, one pass each (the middle component comes out reduced where
+    // the reference leaves it in [0,2q): the InvNTT that follows is canonical either way)
+    for (int base = 0; base < 2; ++base) {
+        lr_context *cx = base == 0 ? cQ : cM;
+        const long long sx = base == 0 ? sQ : sM;
+        TensorLaunch T;
+        T.a0 = base == 0 ? pl->aQ[0].d : pl->aM[0].d;
+        T.a1 = base == 0 ? pl->aQ[1].d : pl->aM[1].d;
+        T.b0 = base == 0 ? pl->bQ[0].d : pl->bM[0].d;
+        T.b1 = base == 0 ? pl->bQ[1].d : pl->bM[1].d;
+        T.a0_stride = T.a1_stride = T.b0_stride = T.b1_stride = sx;
+        T.c0 = base == 0 ? pl->cQ3[0].d : pl->cM3[0].d;
+        T.c1 = base == 0 ? pl->cQ3[1].d : pl->cM3[1].d;
+        T.c2 = base == 0 ? pl->cQ3[2].d : pl->cM3[2].d;
+        T.c_stride = sx;
+        T.n = n;
+        T.lp = cx->d_lp;
+        LR_HIP(launch_tensor(T, base == 0 ? nQ : nM, batch, cx->stream));
+    }
     // :423-463 back to coefficients, divide by Q (result over QMul), centre, back to Q, times t
     LimbScalars tsc;
     for (int i = 0; i < nQ; ++i) tsc.v[i] = mform(bred_add(pl->t, cQ->h.q[i], cQ->h.bred[i].hi), cQ->h.q[i], cQ->h.bred[i].hi, cQ->h.bred[i].lo);
@@ -1714,11 +1718,21 @@ extern "C" int lr_bfv_mul(lr_bfv_plan *pl, const lr_poly *a0, const lr_poly *a1,
         LR_TRY(run_ntt(cM, true, q2, q2, 0, 1, nM, batch));
         // ModDownSplitedQP(levelQ, levelQMul, c2Q1, c2Q2, c2Q2), ring_basis_extension.go:314
         LR_TRY(run_ext(cQ, bx->qp, nQ, q1, batch, segment(bx->poolP.d, poolM_stride, 0, 0, nM), segment(nullptr, 0, 0, 0, 0)));
-        LR_TRY(run_submul(cM, nM, batch, pl->cM3[i].d, sM, bx->poolP.d, poolM_stride, (long long)n, pl->cM3[i].d, sM, bx->d_moddown_qp, false, nullptr));
-        LR_TRY(run_ewise(cM, LR_ADD_SCALAR_LIMBS, nM, batch, pl->cM3[i].d, sM, nullptr, 0, pl->cM3[i].d, sM, &pl->phalf_m));   // :457
+        // the subtract-multiply of the ModDown with the AddScalarBigint(pHalf) of :457 as its epilogue
+        LR_TRY(run_submul(cM, nM, batch, pl->cM3[i].d, sM, bx->poolP.d, poolM_stride, (long long)n, pl->cM3[i].d, sM, bx->d_moddown_qp, false, nullptr,
+                          nullptr, 0, &pl->phalf_m));
         LR_TRY(run_ext(cQ, bx->pq, nM, q2, batch, segment(O[i]->d, O[i]->stride(), 0, 0, nQ), segment(nullptr, 0, 0, 0, 0)));       // :458 ModUpSplitPQ
-        LR_TRY(run_ewise(cQ, LR_SUB_SCALAR_LIMBS, nQ, batch, O[i]->d, O[i]->stride(), nullptr, 0, O[i]->d, O[i]->stride(), &pl->phalf_q));  // :459
-        LR_TRY(run_ewise(cQ, LR_MUL_SCALAR, nQ, batch, O[i]->d, O[i]->stride(), nullptr, 0, O[i]->d, O[i]->stride(), &tsc));         // :462
+        {
+            ScalarPairLaunch S;                                                                                                     // :459 + :462
+            S.in = O[i]->d;
+            S.out = O[i]->d;
+            S.in_stride = S.out_stride = O[i]->stride();
+            S.n = n;
+            S.lp = cQ->d_lp;
+            S.sub = pl->phalf_q;
+            S.mul = tsc;
+            LR_HIP(launch_scalar_pair(S, nQ, batch, cQ->stream));
+        }
     }
     return LR_OK;
 }

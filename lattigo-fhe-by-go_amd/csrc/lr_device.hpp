@@ -78,7 +78,20 @@ struct SubMulLaunch {
     LimbScalars addend; // b + addend[limb] before the reduction (pHalfNegQi); zeros when unused
     const u64 *plus;    // optional: out = CRed(plus + result) (the Context.Add that follows a ModDown in ckks MulRelin)
     long long plus_stride;
+    int has_post;       // 1: out = CRed(result + post[limb]) (the AddScalarBigint that follows ModDownSplitedQP in bfv Mul)
+    LimbScalars post;
 };
+
+// out = MRed(CRed(x + (q - sub[limb])), mul[limb]): SubScalarBigint then MulScalar (bfv/evaluator.go:459,462) in one pass
+struct ScalarPairLaunch {
+    const u64 *in;
+    u64 *out;
+    long long in_stride, out_stride;
+    int n;
+    const LimbParams *lp;
+    LimbScalars sub, mul;
+};
+hipError_t launch_scalar_pair(const ScalarPairLaunch &L, int limbs, int batch, hipStream_t stream);
 
 // degree-2 tensor product of two degree-1 ciphertexts (ckks/evaluator.go:1080-1095) in one pass
 struct TensorLaunch {

@@ -146,6 +146,11 @@ __global__ __launch_bounds__(256) void submul_kernel(SubMulLaunch L) {
             r.x = cred(p.x + r.x, lp.q);
             r.y = cred(p.y + r.y, lp.q);
         }
+        if (L.has_post) {
+            const u64 s = L.post.v[limb];
+            r.x = cred(r.x + s, lp.q);
+            r.y = cred(r.y + s, lp.q);
+        }
         st_stream(po + e, r);
     }
 }
@@ -199,6 +204,33 @@ hipError_t launch_bswap(const u64 *in, u64 *out, size_t words, hipStream_t strea
     if (blocks > 65535) blocks = 65535;
     (void)hipGetLastError();
     hipLaunchKernelGGL(bswap_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, in, out, words);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void scalar_pair_kernel(ScalarPairLaunch L) {
+    const int limb = blockIdx.y;
+    const long long b = blockIdx.z;
+    const LimbParams lp = L.lp[limb];
+    const u64 q = lp.q, s1 = L.sub.v[limb], s2 = L.mul.v[limb];
+    const long long row = (long long)limb * L.n;
+    const ulonglong2 *pi = reinterpret_cast<const ulonglong2 *>(L.in + b * L.in_stride + row);
+    ulonglong2 *po = reinterpret_cast<ulonglong2 *>(L.out + b * L.out_stride + row);
+    const int pairs = L.n >> 1;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < pairs; e += gridDim.x * 256) {
+        const ulonglong2 x = ld_stream(pi + e);
+        st_stream(po + e, make_ulonglong2(mred(cred(x.x + (q - s1), q), s2, q, lp.qinv), mred(cred(x.y + (q - s1), q), s2, q, lp.qinv)));
+    }
+}
+
+hipError_t launch_scalar_pair(const ScalarPairLaunch &L, int limbs, int batch, hipStream_t stream) {
+    if (limbs <= 0 || batch <= 0) return hipSuccess;
+    const int pairs = L.n >> 1;
+    int gx = (pairs + 255) / 256;
+    if (gx > 64) gx = 64;
+    if (gx < 1) gx = 1;
+    const dim3 grid((unsigned)gx, (unsigned)limbs, (unsigned)batch), block(256);
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(scalar_pair_kernel, grid, block, 0, stream, L);
     return hipGetLastError();
 }
 
