@@ -55,6 +55,20 @@ class Poly {
         return out;
     }
     void Zero() { check(lr_poly_zero(h_)); }  // ring/ring_object.go:60
+    // MarshalBinary / UnmarshalBinary (ring/ring_object.go:222,252): log2 N, moduli count, big-endian limb-major words
+    std::vector<uint8_t> MarshalBinary(int batch_index = 0) const {
+        uint64_t n = 0;
+        int limbs = 0;
+        check(lr_poly_info(h_, &n, &limbs, nullptr, nullptr));
+        std::vector<uint8_t> data(2 + (size_t)limbs * n * 8);
+        size_t written = 0;
+        check(lr_poly_marshal(h_, batch_index, data.data(), data.size(), &written));
+        data.resize(written);
+        return data;
+    }
+    void UnmarshalBinary(const std::vector<uint8_t> &data, int batch_index = 0) {
+        check(lr_poly_unmarshal(h_, batch_index, data.data(), data.size()));
+    }
 
   private:
     lr_poly *h_ = nullptr;
@@ -106,6 +120,10 @@ class Context {
     void DivFloorByLastModulus(Poly *p0) const { check(lr_div_floor_by_last_modulus(h_, p0->handle())); }
     void DivRoundByLastModulusNTT(Poly *p0) const { check(lr_div_round_by_last_modulus_ntt(h_, p0->handle())); }
     void DivRoundByLastModulus(Poly *p0) const { check(lr_div_round_by_last_modulus(h_, p0->handle())); }
+
+    // ring/ring_galois.go
+    void PermuteNTT(const Poly *polIn, uint64_t gen, Poly *polOut) const { check(lr_permute_ntt(h_, full(), polIn->handle(), gen, polOut->handle())); }   // :55
+    void Permute(const Poly *polIn, uint64_t gen, Poly *polOut) const { check(lr_permute(h_, polIn->handle(), gen, polOut->handle())); }                  // :106
 
     void Sync() const { check(lr_context_sync(h_)); }
 
