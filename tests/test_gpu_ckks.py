@@ -37,7 +37,9 @@ def test_switch_keys(gpu_pkg, oracle, logn, nq, np_, level):
 
 
 # (16, 5, 2, 4): BASELINE config 5's degree (N = 2^16: two-pass NTT) on a short modulus chain
-@pytest.mark.parametrize("logn,nq,np_,level", [(10, 6, 2, 5), (12, 18, 3, 17), (11, 18, 3, 9), (15, 5, 2, 4), (16, 5, 2, 4)])
+# (15, 18, 3, 17) is BASELINE config 3 at full size: DefaultParams[PN15QP880], level 17
+@pytest.mark.parametrize("logn,nq,np_,level", [(10, 6, 2, 5), (12, 18, 3, 17), (11, 18, 3, 9), (15, 5, 2, 4), (16, 5, 2, 4),
+                                               (15, 18, 3, 17)])
 def test_mulrelin_and_rescale(gpu_pkg, oracle, logn, nq, np_, level):
     N, Q, P, cQ, cP, plan, oplan, evk, pevk = _ckks(gpu_pkg, oracle, logn, nq, np_, 2)
     mk = lambda s: gpu_pkg.sampling.uniform_poly(Q[:level + 1], N, 2, seed=s)
