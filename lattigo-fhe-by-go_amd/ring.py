@@ -466,6 +466,20 @@ class CkksPlan:
         gen: the Galois element whose PermuteNTTIndex the reference stores next to the key."""
         check(lib().lr_ckks_rotate(self.h, level, ct0[0].h, ct0[1].h, int(gen), rotkey.h, ctOut[0].h, ctOut[1].h))
 
+    def RotateColumnsPow2(self, level, ct0, k, pow2_keys, ctOut):
+        """evaluator.rotateColumnsPow2 (ckks/evaluator.go:1408-1430): rotation by k as the chain of the power-of-two
+        rotations in its binary expansion.  pow2_keys: {2^i: (Galois element, SwitchingKey image)}."""
+        if ctOut[0] is not ct0[0]:
+            self.contextQ.CopyLvl(level, ct0[0], ctOut[0])     # :1417-1418
+            self.contextQ.CopyLvl(level, ct0[1], ctOut[1])
+        idx = 1
+        while k > 0:
+            if k & 1:
+                gen, key = pow2_keys[idx]
+                self.PermuteNTT(level, ctOut, gen, key, ctOut)  # :1424
+            idx <<= 1
+            k >>= 1
+
     def RotateHoisted(self, level, ct0, gens, rotkeys, ctOuts):
         """evaluator.RotateHoisted (ckks/evaluator.go:1252): ctOuts[r] = rotation of ct0 by the Galois element gens[r]."""
         n = len(gens)

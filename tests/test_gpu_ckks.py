@@ -133,3 +133,26 @@ def test_rotate_hoisted(gpu_pkg, oracle, logn, nq, np_, level):
             assert np.array_equal(outs[r][1].get()[b], want[r][1]), (r, b)
     # the first component does not go through the key switch: plain and hoisted agree on everything but the noise term
     assert not np.array_equal(outs[0][0].get(), outs[1][0].get())
+
+
+def test_rotate_columns_pow2_chain(gpu_pkg, oracle):
+    """rotateColumnsPow2 (ckks/evaluator.go:1408): rotation by k = 5 as the chain of the rotations by 1 and 4, each a
+    permuteNTT with its own key; equals the oracle's permute_ntt applied in the same order"""
+    logn, nq, np_, level = 11, 6, 2, 5
+    N, Q, P, cQ, cP, plan, oplan, evk, pevk = _ckks(gpu_pkg, oracle, logn, nq, np_, 2)
+    beta = -(-nq // np_)
+    keys, okeys = {}, {}
+    for i in (1, 2, 4):
+        e = gpu_pkg.sampling.uniform_poly(Q + P, N, 2 * beta, seed=300 + i)
+        keys[i] = (_galois(gpu_pkg, N, i), plan.NewSwitchingKey().set(e))
+        okeys[i] = e.reshape(beta, 2, nq + np_, N)
+    mk = lambda s: gpu_pkg.sampling.uniform_poly(Q[:level + 1], N, 2, seed=s)
+    a0, a1 = mk(51), mk(52)
+    ct = (cQ.NewPolyLvl(level, 2).set(a0), cQ.NewPolyLvl(level, 2).set(a1))
+    out = (cQ.NewPolyLvl(level, 2), cQ.NewPolyLvl(level, 2))
+    plan.RotateColumnsPow2(level, ct, 5, keys, out)
+    for b in range(2):
+        want = np.stack([a0[b], a1[b]])
+        for i in (1, 4):
+            want = oplan.permute_ntt(level, want, keys[i][0], okeys[i])
+        assert np.array_equal(out[0].get()[b], want[0]) and np.array_equal(out[1].get()[b], want[1])
