@@ -141,7 +141,8 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
     torch.cuda.set_device(local)
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("LR_BENCH_FORCE_DIST") == "1"   # the latter: rehearse the RCCL path on one GPU
+    if use_dist:
         import torch.distributed as dist
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
         tok = torch.zeros(1, device="cuda")
@@ -318,7 +319,7 @@ def main():
         out["cpu_baseline"] = cpu_baseline_ntt(N, moduli)
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()
