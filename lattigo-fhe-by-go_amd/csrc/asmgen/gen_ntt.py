@@ -145,24 +145,6 @@ class Gen:
     # ------------------------------------------------------------------ arithmetic macros
     # Each macro returns a list of instructions for one temp set; `zip_emit` interleaves the lists of two
     # independent items so that consecutive instructions of a wave rarely depend on each other.
-    def ops_modmul(self, ts, V, tw):
-        """ts.R <- V * w - qhat * q (lazy, [0,4q)); tw = (w0, w1, s0, s1) registers (SGPR or VGPR)."""
-        w0, w1, s0, s1 = tw
-        J = self.JUNK
-        return [
-            ("v_mul_hi_u32", ts.T0, V.hi(), s0),
-            ("v_mul_hi_u32", ts.T2, V.lo(), s1),
-            ("v_mad_u64_u32", ts.Q, J, V.hi(), s1, ts.T01),
-            ("v_mad_u64_u32", ts.R, J, V.lo(), w0, 0),
-            ("v_mad_u64_u32", ts.C, J, V.lo(), w1, 0),
-            ("v_lshl_add_u64", ts.Q, ts.Q, 0, ts.T23),
-            ("v_mad_u64_u32", ts.C, J, V.hi(), w0, ts.C),
-            ("v_mad_u64_u32", ts.R, J, ts.Q.lo(), self.NQ.lo(), ts.R),
-            ("v_mad_u64_u32", ts.C, J, ts.Q.lo(), self.NQ.hi(), ts.C),
-            ("v_mad_u64_u32", ts.C, J, ts.Q.hi(), self.NQ.lo(), ts.C),
-            ("v_add_u32", ts.R.hi(), ts.R.hi(), ts.C.lo()),
-        ]
-
     def ops_butterfly(self, ts, U, V, tw, correct):
         """(U, V) <- (U + r, U + 4q - r), r = V*w - qhat*q in [0,4q); optional U <- U - 8q if U >= 8q first.
         The product accumulates straight onto U (X = U + r costs nothing) and Y = (2U + 4q) - X; all of it
