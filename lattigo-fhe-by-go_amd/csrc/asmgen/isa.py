@@ -1,7 +1,7 @@
 """A tiny gfx950 instruction IR with two back ends: assembly text and a numpy SIMT emulator.
 
-The hand-scheduled NTT kernels (gen_ntt.py) are straight-line programs (no branches), so one
-workgroup can be emulated with every VGPR as a numpy vector over the workgroup's threads and
+The hand-scheduled NTT kernels (gen_ntt.py) are straight-line programs apart from one
+workgroup-uniform loop over the polys a workgroup processes, so one workgroup can be emulated with every VGPR as a numpy vector over the workgroup's threads and
 every SGPR as a vector over its waves.  The emulator covers exactly the instruction subset the
 generator emits and checks the structural rules the assembler will not (even alignment of 64-bit
 VGPR operands, one constant-bus operand per VALU instruction, no read of an unwritten register).
@@ -64,12 +64,19 @@ class Program:
     def comment(self, text):
         self.ins.append(("#", (text,), {}))
 
+    def label(self, name):
+        """branch target"""
+        self.ins.append(("@", (name,), {}))
+
     # ---- text back end ------------------------------------------------------------------
     def text(self):
         out = []
         for op, args, mods in self.ins:
             if op == "#":
                 out.append("  ; " + args[0])
+                continue
+            if op == "@":
+                out.append(args[0] + ":")
                 continue
             line = "  " + op
             if args:
@@ -192,10 +199,22 @@ class Machine:
         return base + self.rv(voff).astype(np.uint64) + np.uint64(offset)
 
     def run(self, prog):
+        """branches must be workgroup-uniform (the kernels only loop on launch-wide counters)"""
+        labels = {args[0]: k for k, (op, args, _) in enumerate(prog.ins) if op == "@"}
+        pc = 0
         with np.errstate(over="ignore"):
-            for op, args, mods in prog.ins:
-                if op == "#":
+            while pc < len(prog.ins):
+                op, args, mods = prog.ins[pc]
+                pc += 1
+                if op in ("#", "@"):
                     continue
+                if op in ("s_branch", "s_cbranch_scc0", "s_cbranch_scc1"):
+                    assert np.all(self.scc == self.scc[0]), "divergent branch"
+                    if op == "s_branch" or bool(self.scc[0]) == (op == "s_cbranch_scc1"):
+                        pc = labels[args[0]]
+                    continue
+                if op == "s_endpgm":
+                    break
                 getattr(self, "i_" + op)(*args, **mods)
 
     # -- VALU
@@ -312,6 +331,14 @@ class Machine:
         r = self.rs(a).astype(np.int64) - self.rs(b).astype(np.int64) - self.scc.astype(np.int64)
         self.ws(d, (r & 0xFFFFFFFF).astype(np.uint32))
         self.scc = r < 0
+
+    def i_s_cmp_eq_u32(self, a, b):
+        self.scc = self.rs(a) == self.rs(b)
+
+    def i_s_min_u32(self, d, a, b):
+        x, y = self.rs(a), self.rs(b)
+        self.ws(d, np.minimum(x, y))
+        self.scc = x <= y
 
     def i_s_cmp_ge_u32(self, a, b):
         self.scc = self.rs(a) >= self.rs(b)

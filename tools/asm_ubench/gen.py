@@ -18,7 +18,7 @@ class Probe(Gen):
     def __init__(self, variant):
         super().__init__(15, 1)
         self.variant = variant
-        self.persistent = False
+        self.REM = s(23)
 
     def body(self):
         e, X = self.e, self.X
@@ -137,8 +137,60 @@ class Probe(Gen):
                 raise ValueError(var)
         return n
 
+    def build_mem(self):
+        """burst = what one wave of the NTT kernel does at its start: 32 x dwordx2 (or 16 x dwordx4, 8 x dwordx4 twice...)
+        covering its share of a 256 KiB limb, then s_waitcnt vmcnt(0); one workgroup per CU, ITER items per workgroup"""
+        e = self.e
+        var = self.variant
+        e("s_load_dwordx2", self.DST, self.KARG, 16)
+        e("s_load_dwordx2", self.SRC, self.KARG, 24)
+        e("v_mov_b32", self.TID, v(0))
+        e("v_and_b32", self.LANE, 63, self.TID)
+        e("v_readfirstlane_b32", self.WAVE, self.TID)
+        e("s_nop", 4)
+        e("s_lshr_b32", self.WAVE, self.WAVE, 6)
+        e("s_waitcnt", "lgkmcnt(0)")
+        # item base: (workgroup id * ITER) * 256 KiB, wrapped into a 1 GiB buffer by the host-side size choice
+        e("s_and_b32", self.SC[0], self.WGX, 255)
+        e("s_lshl_b32", self.SC[0], self.SC[0], 24)            # 64 items of 256 KiB per workgroup slot, 4 GiB in all
+        e("s_add_u32", self.SRC.lo(), self.SRC.lo(), self.SC[0])
+        e("s_addc_u32", self.SRC.hi(), self.SRC.hi(), 0)
+        wide = "x4" in var
+        if wide:
+            e("v_lshlrev_b32", self.GOFF, 4, self.TID)          # t*16: rows of 16 KiB
+        else:
+            e("v_lshlrev_b32", self.GOFF, 3, self.TID)          # t*8: rows of 8 KiB
+        e("s_movk_i32", self.REM, 64)
+        self.p.label("L_top")
+        e("s_mov_b64", self.TMP, self.SRC)
+        n = 16 if wide else 32
+        for k in range(n):
+            if wide:
+                e("global_load_dwordx4", v(4 * (k % 16), 4), self.GOFF, self.TMP, hint="nt")
+            else:
+                e("global_load_dwordx2", self.X[k], self.GOFF, self.TMP, hint="nt")
+            e("s_add_u32", self.TMP.lo(), self.TMP.lo(), 16384 if wide else 8192)
+            e("s_addc_u32", self.TMP.hi(), self.TMP.hi(), 0)
+        e("s_waitcnt", "vmcnt(0)")
+        if "work" in var:
+            # stand-in for the compute phase: ~30 us of dependent VALU per item
+            for i in range(2000):
+                e("v_mad_u64_u32", self.X[i % 32], self.JUNK, self.X[(i + 7) % 32].lo(), s(36), self.X[i % 32])
+        e("s_add_u32", self.SRC.lo(), self.SRC.lo(), 262144)
+        e("s_addc_u32", self.SRC.hi(), self.SRC.hi(), 0)
+        e("s_sub_u32", self.REM, self.REM, 1)
+        e("s_cmp_eq_u32", self.REM, 0)
+        e("s_cbranch_scc0", "L_top")
+        e("v_lshlrev_b32", self.GOFF, 3, self.TID)
+        e("global_store_dwordx2", self.GOFF, self.X[0], self.DST)
+        e("s_endpgm")
+        self.count = 64
+        return self.p
+
     def build(self):
         e = self.e
+        if self.variant.startswith("mem_"):
+            return self.build_mem()
         self.inv = GenInv(15, 1)
         self.inv.p, self.inv.e = self.p, self.e
         e("s_load_dwordx2", self.DST, self.KARG, 16)
@@ -176,7 +228,8 @@ class Probe(Gen):
         return self.p
 
 
-VARIANTS = ["cfg_98_36", "cfg_32_36", "cfg_2_36", "cfg_32_68", "cfg_vcc_68", "cfg_98_92", "cfg_98_40", "cfg_34_64", "cfg_2_36_c", "cfg_98_36_c", "cfg_32_36_c"]
+VARIANTS = ["mem_x2", "mem_x4", "mem_x2_work", "mem_x4_work"]
+_OLD2 = ["cfg_98_36", "cfg_32_36", "cfg_2_36", "cfg_32_68", "cfg_vcc_68", "cfg_98_92", "cfg_98_40", "cfg_34_64", "cfg_2_36_c", "cfg_98_36_c", "cfg_32_36_c"]
 _OLD = ["bfly_nc", "bfly_c", "bfly_nc_seq", "bfly_c_seq", "bfly_nc_2sgpr", "inv_c", "mad_sdst_vcc", "mad_sdst_alt", "subb_sgpr", "cmp_vcc", "cmp_sgpr",
             "cndmask_vcc2", "cndmask_e64_vcc", "mad_add_mix", "mulhi_add_mix", "xor_b32", "and_or", "add3", "lshl_add_u32", "mov", "mad_vsv", "mad_vvv", "mad_vs0", "mulhi_vs", "mulhi_vv", "mullo_vv",
             "lshl_add", "lshl_add_vvv", "add_u32", "cndmask_vcc", "cndmask_sgpr", "sub_co_pair", "cmp", "fma_f64", "fma_f32"]

@@ -11,6 +11,7 @@ int main(int argc, char **argv) {
     std::ifstream list(dir + "/variants.txt");
     std::string name; long long count;
     void *out; CK(hipMalloc(&out, 1 << 20));
+    void *big; CK(hipMalloc(&big, (size_t)5 << 30)); CK(hipMemset(big, 1, (size_t)5 << 30));
     int clk_khz = 0; CK(hipDeviceGetAttribute(&clk_khz, hipDeviceAttributeClockRate, 0));
     int cus = 0; CK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0));
     printf("device clock %d kHz, %d CUs\n", clk_khz, cus);
@@ -20,7 +21,7 @@ int main(int argc, char **argv) {
         hipModule_t mod; hipFunction_t fn;
         CK(hipModuleLoadData(&mod, img.data()));
         CK(hipModuleGetFunction(&fn, mod, ("probe_" + name).c_str()));
-        struct { unsigned long long a, b; void *out; char pad[80]; } args = {0x0123456789ABCDEFull, 0x0FEDCBA987654321ull, out, {0}};
+        struct { unsigned long long a, b; void *out; void *in; char pad[72]; } args = {0x0123456789ABCDEFull, 0x0FEDCBA987654321ull, out, big, {0}};
         size_t size = 104;
         void *extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
         hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -31,7 +32,12 @@ int main(int argc, char **argv) {
             CK(hipEventRecord(e1, 0));
             CK(hipEventSynchronize(e1));
             float ms; CK(hipEventElapsedTime(&ms, e0, e1));
-            if (rep == 2) {
+            if (rep == 2 && name.rfind("mem_", 0) == 0) {
+                // every workgroup reads 64 items of 256 KiB
+                const double bytes = (double)cus * rounds * 64 * 262144;
+                printf("%-14s %8.3f ms  %7.1f GB/s aggregate, %6.2f us per 256 KiB item per CU\n", name.c_str(), ms, bytes / (ms * 1e-3) / 1e9,
+                       ms * 1e3 / (rounds * 64));
+            } else if (rep == 2) {
                 // per SIMD: rounds workgroups x 4 waves x count instructions
                 const double instr = (double)rounds * 4 * count;
                 printf("%-14s %8.3f ms  %6.2f cycles/instr at %d MHz (nominal)\n", name.c_str(), ms, ms * 1e-3 * clk_khz * 1e3 / instr, clk_khz / 1000);
