@@ -1,0 +1,117 @@
+package ring
+
+// #include <stdlib.h>
+// #include "lattigo_ring.h"
+import "C"
+
+import (
+	"runtime"
+	"unsafe"
+)
+
+// CkksPlan owns what ckks.NewEvaluator builds around the ring (ckks/evaluator.go:63-112: base converter,
+// decomposer, scratch pools) on the device, and runs the evaluator's ring call sequences as one cgo call each.
+// An evaluator built on this shim replaces the bodies of MulRelin / Rescale / RotateColumns / RotateHoisted by
+// these calls; everything else (scale bookkeeping, level checks, panics) stays Go.
+type CkksPlan struct {
+	contextQ, contextP *Context
+	h                  *C.lr_ckks_plan
+}
+
+func NewCkksPlan(contextQ, contextP *Context, maxBatch int) *CkksPlan {
+	p := &CkksPlan{contextQ: contextQ, contextP: contextP}
+	check(C.lr_ckks_plan_create(contextQ.h, contextP.h, C.int(maxBatch), &p.h))
+	runtime.SetFinalizer(p, func(p *CkksPlan) { C.lr_ckks_plan_destroy(p.h) })
+	return p
+}
+
+// SwitchingKeyImage lays SwitchingKey.evakey ([beta][2]*ring.Poly over QP, ckks/keygen.go:68-70) out as one device
+// polynomial with batch = 2*beta, which is what the key-switching entry points take.
+func (p *CkksPlan) SwitchingKeyImage(evakey [][2]*Poly) *Poly {
+	limbs := len(evakey[0][0].Coeffs)
+	img := &Poly{resident: true}
+	check(C.lr_poly_alloc(p.contextQ.h, C.int(limbs), C.int(2*len(evakey)), &img.d)) // limbs beyond |Q| follow contextP: see lr_ckks_switch_keys
+	for i := range evakey {
+		for k := 0; k < 2; k++ {
+			var pin runtime.Pinner
+			src := evakey[i][k]
+			ptrs, free := src.limbPtrs(&pin)
+			check(C.lr_poly_upload(img.d, C.int(2*i+k), ptrs, C.int(limbs)))
+			free()
+			pin.Unpin()
+		}
+	}
+	runtime.SetFinalizer(img, func(q *Poly) { C.lr_poly_free(q.d) })
+	return img
+}
+
+// SwitchKeysInPlace = evaluator.switchKeysInPlace (ckks/evaluator.go:1475).
+func (p *CkksPlan) SwitchKeysInPlace(level uint64, cx, evakey, p0, p1 *Poly) {
+	in(cx)
+	check(C.lr_ckks_switch_keys(p.h, C.int(level), cx.d, evakey.d, p0.d, p1.d))
+	out(p0, p1)
+}
+
+// MulRelin = the degree-1 x degree-1 branch of evaluator.MulRelin with an evaluation key (ckks/evaluator.go:1016-1133).
+func (p *CkksPlan) MulRelin(level uint64, ct0, ct1 [2]*Poly, evakey *Poly, ctOut [2]*Poly) {
+	in(ct0[0], ct0[1], ct1[0], ct1[1])
+	check(C.lr_ckks_mulrelin(p.h, C.int(level), ct0[0].d, ct0[1].d, ct1[0].d, ct1[1].d, evakey.d, ctOut[0].d, ctOut[1].d))
+	out(ctOut[0], ctOut[1])
+}
+
+// Rescale = one iteration of evaluator.Rescale's loop (ckks/evaluator.go:958-960) on both components.
+func (p *CkksPlan) Rescale(ct [2]*Poly) {
+	in(ct[0], ct[1])
+	check(C.lr_ckks_rescale(p.h, ct[0].d, ct[1].d))
+	for _, q := range ct {
+		q.Coeffs = q.Coeffs[:len(q.Coeffs)-1]
+	}
+	out(ct[0], ct[1])
+}
+
+// PermuteNTT = evaluator.permuteNTT (ckks/evaluator.go:1448): RotateColumns with the key of that rotation, Conjugate.
+func (p *CkksPlan) PermuteNTT(level uint64, ct0 [2]*Poly, galEl uint64, rotkey *Poly, ctOut [2]*Poly) {
+	in(ct0[0], ct0[1])
+	check(C.lr_ckks_rotate(p.h, C.int(level), ct0[0].d, ct0[1].d, C.uint64_t(galEl), rotkey.d, ctOut[0].d, ctOut[1].d))
+	out(ctOut[0], ctOut[1])
+}
+
+// RotateHoisted = evaluator.RotateHoisted (ckks/evaluator.go:1252) for the rotations galEls[r] with keys rotkeys[r].
+func (p *CkksPlan) RotateHoisted(level uint64, ct0 [2]*Poly, galEls []uint64, rotkeys []*Poly, ctOuts [][2]*Poly) {
+	in(ct0[0], ct0[1])
+	n := len(galEls)
+	sz := C.size_t(n) * C.size_t(unsafe.Sizeof(uintptr(0)))
+	keys := (**C.lr_poly)(C.malloc(sz))
+	o0 := (**C.lr_poly)(C.malloc(sz))
+	o1 := (**C.lr_poly)(C.malloc(sz))
+	defer C.free(unsafe.Pointer(keys))
+	defer C.free(unsafe.Pointer(o0))
+	defer C.free(unsafe.Pointer(o1))
+	ks, a0, a1 := unsafe.Slice(keys, n), unsafe.Slice(o0, n), unsafe.Slice(o1, n)
+	for r := 0; r < n; r++ {
+		ks[r], a0[r], a1[r] = rotkeys[r].d, ctOuts[r][0].d, ctOuts[r][1].d
+	}
+	check(C.lr_ckks_rotate_hoisted(p.h, C.int(level), ct0[0].d, ct0[1].d, C.int(n), (*C.uint64_t)(unsafe.Pointer(&galEls[0])), keys, o0, o1))
+	for r := 0; r < n; r++ {
+		out(ctOuts[r][0], ctOuts[r][1])
+	}
+}
+
+// BfvPlan: what bfv.NewEvaluator builds for Mul (bfv/evaluator.go:89-112) and tensorAndRescale (:278-464).
+type BfvPlan struct {
+	h *C.lr_bfv_plan
+}
+
+func NewBfvPlan(contextQ, contextQMul *Context, t uint64, maxBatch int) *BfvPlan {
+	p := &BfvPlan{}
+	check(C.lr_bfv_plan_create(contextQ.h, contextQMul.h, C.uint64_t(t), C.int(maxBatch), &p.h))
+	runtime.SetFinalizer(p, func(p *BfvPlan) { C.lr_bfv_plan_destroy(p.h) })
+	return p
+}
+
+// Mul = evaluator.Mul for two degree-1 ciphertexts (bfv/evaluator.go:467 -> tensorAndRescale).
+func (p *BfvPlan) Mul(ct0, ct1 [2]*Poly, ctOut [3]*Poly) {
+	in(ct0[0], ct0[1], ct1[0], ct1[1])
+	check(C.lr_bfv_mul(p.h, ct0[0].d, ct0[1].d, ct1[0].d, ct1[1].d, ctOut[0].d, ctOut[1].d, ctOut[2].d))
+	out(ctOut[0], ctOut[1], ctOut[2])
+}
