@@ -1,0 +1,122 @@
+"""End-to-end algebra on top of the bit parity: a CKKS relinearisation key built the way the reference builds it
+(ckks/keygen.go:newSwitchingKey -- for digit i: (-a_i*s + e_i + P*s^2 on the limbs of digit i, a_i) over Q||P, NTT +
+Montgomery form) must make MulRelin's output decrypt to the product of the two plaintexts up to a small noise.  This
+checks the meaning of the pipeline (key layout, digit decomposition, ModDown by P), not just its agreement with the
+oracle's restatement of the same call sequence.  Python integers are the arbiter; the oracle only supplies NTTs."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _small(N, bound, seed):
+    rng = np.random.default_rng(seed)
+    return rng.integers(-bound, bound + 1, size=N)
+
+
+def _residues(v, moduli):
+    return np.array([[int(x) % q for x in v] for q in moduli], dtype=np.uint64)
+
+
+def _mulmod(a, b, moduli):
+    return np.array([[int(x) * int(y) % q for x, y in zip(a[i], b[i])] for i, q in enumerate(moduli)], dtype=np.uint64)
+
+
+def _addmod(a, b, moduli):
+    return np.array([[(int(x) + int(y)) % q for x, y in zip(a[i], b[i])] for i, q in enumerate(moduli)], dtype=np.uint64)
+
+
+def _negmod(a, moduli):
+    return np.array([[(q - int(x)) % q for x in a[i]] for i, q in enumerate(moduli)], dtype=np.uint64)
+
+
+def _mont(a, moduli):
+    return np.array([[(int(x) << 64) % q for x in a[i]] for i, q in enumerate(moduli)], dtype=np.uint64)
+
+
+@pytest.mark.parametrize("logn,nq,np_", [(10, 3, 1), (11, 4, 2)])
+def test_mulrelin_decrypts_to_the_product(gpu_pkg, oracle, logn, nq, np_):
+    N = 1 << logn
+    _, Qf, Pf = gpu_pkg.params.ckks_moduli("PN15QP880")
+    Q, P = Qf[:nq], Pf[:np_]
+    QP = Q + P
+    level = nq - 1
+    alpha, beta = np_, -(-nq // np_)
+    ocQP, ocQ = oracle.Context(N, QP), oracle.Context(N, Q)
+    Pprod = 1
+    for p in P:
+        Pprod *= p
+
+    s = _small(N, 1, 1)                                            # ternary secret
+    s_ntt = ocQP.ntt(_residues(s, QP))
+    s2_ntt = _mulmod(s_ntt, s_ntt, QP)
+
+    # relinearisation key: evakey[i] = (-a_i*s + e_i + P*s^2 [limbs of digit i only], a_i), ckks/keygen.go:238-270
+    evk = np.zeros((beta, 2, nq + np_, N), dtype=np.uint64)
+    for i in range(beta):
+        a_i = gpu_pkg.sampling.uniform_poly(QP, N, 1, seed=700 + i)[0]
+        e_i = ocQP.ntt(_residues(_small(N, 6, 710 + i), QP))
+        k0 = _addmod(_negmod(_mulmod(a_i, s_ntt, QP), QP), e_i, QP)
+        for j in range(alpha):
+            idx = i * alpha + j
+            if idx >= nq:
+                break
+            q = QP[idx]
+            k0[idx] = np.array([(int(x) + (Pprod % q) * int(y)) % q for x, y in zip(k0[idx], s2_ntt[idx])], dtype=np.uint64)
+        evk[i, 0], evk[i, 1] = _mont(k0, QP), _mont(a_i, QP)
+
+    # two ciphertexts (b, a) with b = -a*s + m + e over Q, NTT domain
+    def encrypt(seed):
+        a = gpu_pkg.sampling.uniform_poly(Q, N, 1, seed=seed)[0]
+        me = _small(N, 1 << 12, seed + 1) + _small(N, 6, seed + 2)     # message + error, what decryption returns
+        me_ntt = ocQ.ntt(_residues(me, Q))
+        b = _addmod(_negmod(_mulmod(a, s_ntt[:nq], Q), Q), me_ntt, Q)
+        return (b, a), me
+
+    (b0, a0), m0 = encrypt(800)
+    (b1, a1), m1 = encrypt(810)
+
+    ring = gpu_pkg.ring
+    cQ, cP = ring.NewContextWithParams(N, Q), ring.NewContextWithParams(N, P)
+    plan = ring.CkksPlan(cQ, cP, 1)
+    pevk = plan.NewSwitchingKey().set(evk.reshape(2 * beta, nq + np_, N))
+    P_ = lambda x: cQ.NewPolyLvl(level, 1).set(x[None])
+    out = (cQ.NewPolyLvl(level, 1), cQ.NewPolyLvl(level, 1))
+    plan.MulRelin(level, (P_(b0), P_(a0)), (P_(b1), P_(a1)), pevk, out)
+    d0, d1 = out[0].get().reshape(nq, N), out[1].get().reshape(nq, N)
+
+    # decrypt: d0 + d1*s, back to coefficients, centred; must equal the negacyclic product m0*m1 up to the
+    # relinearisation noise (digits * e_i / P plus rounding), the same small integer vector in every limb
+    dec = ocQ.intt(_addmod(d0, _mulmod(d1, s_ntt[:nq], Q), Q))
+    prod = np.zeros(N, dtype=object)
+    m0o, m1o = [int(x) for x in m0], [int(x) for x in m1]
+    for i in range(N):
+        if m0o[i] == 0:
+            continue
+        for j in range(N):
+            k = i + j
+            if k < N:
+                prod[k] += m0o[i] * m1o[j]
+            else:
+                prod[k - N] -= m0o[i] * m1o[j]
+    noise = None
+    for i, q in enumerate(Q):
+        centred = np.array([((int(x) - int(p)) % q + q // 2) % q - q // 2 for x, p in zip(dec[i], prod)], dtype=object)
+        assert max(abs(int(v)) for v in centred) < 1 << 20, (i, max(abs(int(v)) for v in centred))
+        if noise is None:
+            noise = centred
+        else:
+            assert all(int(u) == int(v) for u, v in zip(noise, centred))   # one integer polynomial, consistently in all limbs
+
+    # control: the same key with the P*s^2 term of digit 0 left out must NOT decrypt (the check above is not vacuous)
+    bad = evk.copy()
+    a_0 = np.array([[int(x) * pow(1 << 64, -1, q) % q for x in bad[0, 1, i]] for i, q in enumerate(QP)], dtype=np.uint64)
+    e_0 = ocQP.ntt(_residues(_small(N, 6, 710), QP))
+    bad[0, 0] = _mont(_addmod(_negmod(_mulmod(a_0, s_ntt, QP), QP), e_0, QP), QP)
+    pbad = plan.NewSwitchingKey().set(bad.reshape(2 * beta, nq + np_, N))
+    plan.MulRelin(level, (P_(b0), P_(a0)), (P_(b1), P_(a1)), pbad, out)
+    d0, d1 = out[0].get().reshape(nq, N), out[1].get().reshape(nq, N)
+    dec = ocQ.intt(_addmod(d0, _mulmod(d1, s_ntt[:nq], Q), Q))
+    q = Q[0]
+    worst = max(abs(((int(x) - int(p)) % q + q // 2) % q - q // 2) for x, p in zip(dec[0], prod))
+    assert worst > 1 << 30
