@@ -120,3 +120,50 @@ def test_mulrelin_decrypts_to_the_product(gpu_pkg, oracle, logn, nq, np_):
     q = Q[0]
     worst = max(abs(((int(x) - int(p)) % q + q // 2) % q - q // 2) for x, p in zip(dec[0], prod))
     assert worst > 1 << 30
+
+
+def test_bfv_mul_decrypts_to_the_product(gpu_pkg, oracle):
+    """bfv tensorAndRescale (bfv/evaluator.go:278): for ciphertexts (b, a), b = -a*s + floor(Q/t)*m + e, the degree-2
+    output (c0, c1, c2) satisfies round(t/Q * (c0 + c1*s + c2*s^2)) = m0*m1 mod (X^N + 1, t).  Python integers decide."""
+    name, t = "PN12QP109", 65537
+    N, Q, _, QMul = gpu_pkg.params.bfv_moduli(name)
+    ocQ = oracle.Context(N, Q)
+    Qprod = 1
+    for q in Q:
+        Qprod *= q
+    delta = Qprod // t
+    s = _small(N, 1, 11)
+    s_ntt = ocQ.ntt(_residues(s, Q))
+
+    def encrypt(seed):
+        a = gpu_pkg.sampling.uniform_poly(Q, N, 1, seed=seed)[0]               # coefficient domain
+        m = np.random.default_rng(seed + 1).integers(0, t, size=N)
+        e = _small(N, 6, seed + 2)
+        as_ = ocQ.intt(_mulmod(ocQ.ntt(a), s_ntt, Q))
+        body = _residues([delta * int(x) + int(y) for x, y in zip(m, e)], Q)
+        return (_addmod(_negmod(as_, Q), body, Q), a), m
+
+    (b0, a0), m0 = encrypt(900)
+    (b1, a1), m1 = encrypt(910)
+    ring = gpu_pkg.ring
+    cQ, cM = ring.NewContextWithParams(N, Q), ring.NewContextWithParams(N, QMul)
+    plan = ring.BfvPlan(cQ, cM, t, 1)
+    P_ = lambda x: cQ.NewPoly(1).set(x[None])
+    out = (cQ.NewPoly(1), cQ.NewPoly(1), cQ.NewPoly(1))
+    plan.Mul((P_(b0), P_(a0)), (P_(b1), P_(a1)), out)
+    c = [o.get().reshape(len(Q), N) for o in out]
+
+    s2_ntt = _mulmod(s_ntt, s_ntt, Q)
+    acc = ocQ.ntt(c[0])
+    acc = _addmod(acc, _mulmod(ocQ.ntt(c[1]), s_ntt, Q), Q)
+    acc = _addmod(acc, _mulmod(ocQ.ntt(c[2]), s2_ntt, Q), Q)
+    v = ocQ.intt(acc)
+    # CRT lift to [0, Q), scale by t/Q with rounding, reduce mod t
+    crt = [(Qprod // q) * pow(Qprod // q, -1, q) for q in Q]
+    full = np.convolve(m0.astype(object), m1.astype(object))
+    want = [(int(full[k]) - (int(full[k + N]) if k + N < len(full) else 0)) % t for k in range(N)]
+    got = []
+    for k in range(N):
+        x = sum(int(v[i][k]) * crt[i] for i in range(len(Q))) % Qprod
+        got.append(((t * x + Qprod // 2) // Qprod) % t)
+    assert got == want
