@@ -167,3 +167,62 @@ def test_bfv_mul_decrypts_to_the_product(gpu_pkg, oracle):
         x = sum(int(v[i][k]) * crt[i] for i in range(len(Q))) % Qprod
         got.append(((t * x + Qprod // 2) // Qprod) % t)
     assert got == want
+
+
+@pytest.mark.parametrize("hoisted", [False, True])
+def test_rotation_decrypts_to_the_permuted_plaintext(gpu_pkg, oracle, hoisted):
+    """RotateColumns / RotateHoisted: with a switching key from s(X^g) to s (ckks/keygen.go: -a_i*s + e_i + P*s(X^g) on
+    the limbs of digit i), the rotated ciphertext decrypts under s to the plaintext with X -> X^g applied, up to the
+    key-switching noise.  The automorphism on plaintexts is Context.Permute in the coefficient domain."""
+    logn, nq, np_ = 10, 4, 2
+    N = 1 << logn
+    _, Qf, Pf = gpu_pkg.params.ckks_moduli("PN15QP880")
+    Q, P = Qf[:nq], Pf[:np_]
+    QP = Q + P
+    level = nq - 1
+    alpha, beta = np_, -(-nq // np_)
+    ocQP, ocQ = oracle.Context(N, QP), oracle.Context(N, Q)
+    Pprod = P[0] * P[1]
+    s = _small(N, 1, 21)
+    s_ntt = ocQP.ntt(_residues(s, QP))
+    gens = [pow(5, k, 2 * N) for k in (1, 7)] if hoisted else [pow(5, 3, 2 * N)]
+
+    def rotation_key(g, seed):
+        sg_ntt = ocQP.permute_ntt(s_ntt, g)                                   # s(X^g)
+        key = np.zeros((beta, 2, nq + np_, N), dtype=np.uint64)
+        for i in range(beta):
+            a_i = gpu_pkg.sampling.uniform_poly(QP, N, 1, seed=seed + i)[0]
+            e_i = ocQP.ntt(_residues(_small(N, 6, seed + 10 + i), QP))
+            k0 = _addmod(_negmod(_mulmod(a_i, s_ntt, QP), QP), e_i, QP)
+            for j in range(alpha):
+                idx = i * alpha + j
+                if idx >= nq:
+                    break
+                q = QP[idx]
+                k0[idx] = np.array([(int(x) + (Pprod % q) * int(y)) % q for x, y in zip(k0[idx], sg_ntt[idx])], dtype=np.uint64)
+            key[i, 0], key[i, 1] = _mont(k0, QP), _mont(a_i, QP)
+        return key
+
+    a = gpu_pkg.sampling.uniform_poly(Q, N, 1, seed=950)[0]
+    me = _small(N, 1 << 20, 951) + _small(N, 6, 952)
+    me_res = _residues(me, Q)
+    b = _addmod(_negmod(_mulmod(a, s_ntt[:nq], Q), Q), ocQ.ntt(me_res), Q)
+
+    ring = gpu_pkg.ring
+    cQ, cP = ring.NewContextWithParams(N, Q), ring.NewContextWithParams(N, P)
+    plan = ring.CkksPlan(cQ, cP, 1)
+    keys = [plan.NewSwitchingKey().set(rotation_key(g, 960 + 40 * n).reshape(2 * beta, nq + np_, N)) for n, g in enumerate(gens)]
+    P_ = lambda x: cQ.NewPolyLvl(level, 1).set(x[None])
+    ct = (P_(b), P_(a))
+    outs = [(cQ.NewPolyLvl(level, 1), cQ.NewPolyLvl(level, 1)) for _ in gens]
+    if hoisted:
+        plan.RotateHoisted(level, ct, gens, keys, outs)
+    else:
+        plan.PermuteNTT(level, ct, gens[0], keys[0], outs[0])
+    for g, o in zip(gens, outs):
+        d0, d1 = o[0].get().reshape(nq, N), o[1].get().reshape(nq, N)
+        dec = ocQ.intt(_addmod(d0, _mulmod(d1, s_ntt[:nq], Q), Q))
+        want = ocQ.permute(me_res, g)                                          # m(X^g) mod q_i, coefficient domain
+        for i, q in enumerate(Q):
+            worst = max(abs(((int(x) - int(w)) % q + q // 2) % q - q // 2) for x, w in zip(dec[i], want[i]))
+            assert worst < 1 << 16, (g, i, worst)
