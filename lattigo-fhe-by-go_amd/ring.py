@@ -461,6 +461,38 @@ class CkksPlan:
     def Rescale(self, ct):
         check(lib().lr_ckks_rescale(self.h, ct[0].h, ct[1].h))
 
+    def EncryptPk(self, contextQP, baseconverter, level, u, pk, e, plaintext, ctOut):
+        """pkEncryptor.encrypt, the branch through the special primes (ckks/encryptor.go:207-243), after the sampling:
+        u = SampleTernaryMontgomeryNTT over QP, e = the two Gaussian samples as residues over QP (coefficient domain,
+        what SampleAndAdd adds, ring/gaussianSampler.go:254-274), pk = (pk0, pk1) over QP, plaintext over Q (NTT).
+        Compositions of entry points of the ring: MulCoeffsMontgomery x2, InvNTT x2, Add x2, ModDownPQ x2, NTT x2, Add."""
+        cQ = self.contextQ
+        p0, p1 = contextQP.NewPoly(u.batch), contextQP.NewPoly(u.batch)
+        contextQP.MulCoeffsMontgomery(u, pk[0], p0)                     # :213
+        contextQP.MulCoeffsMontgomery(u, pk[1], p1)                     # :215
+        contextQP.InvNTT(p0, p0)                                        # :218
+        contextQP.InvNTT(p1, p1)
+        contextQP.Add(p0, e[0], p0)                                     # :222 SampleAndAdd
+        contextQP.Add(p1, e[1], p1)
+        baseconverter.ModDownPQ(level, p0, ctOut[0])                    # :227
+        baseconverter.ModDownPQ(level, p1, ctOut[1])
+        cQ.NTTLvl(level, ctOut[0], ctOut[0])                            # :233
+        cQ.NTTLvl(level, ctOut[1], ctOut[1])
+        cQ.AddLvl(level, ctOut[0], plaintext, ctOut[0])                 # :238
+
+    def Decrypt(self, level, ct, sk, ptOut):
+        """decryptor.Decrypt (ckks/decryptor.go:53-78): Horner evaluation at the secret key (Montgomery NTT form)."""
+        cQ = self.contextQ
+        degree = len(ct) - 1
+        cQ.CopyLvl(level, ct[degree], ptOut)
+        for i in range(degree, 0, -1):
+            cQ.MulCoeffsMontgomeryLvl(level, ptOut, sk, ptOut)
+            cQ.AddLvl(level, ptOut, ct[i - 1], ptOut)
+            if i & 7 == 7:
+                cQ.ReduceLvl(level, ptOut, ptOut)
+        if degree & 7 != 7:
+            cQ.ReduceLvl(level, ptOut, ptOut)
+
     def PermuteNTT(self, level, ct0, gen, rotkey, ctOut):
         """evaluator.permuteNTT (ckks/evaluator.go:1448): RotateColumns with the key of that rotation, or Conjugate.
         gen: the Galois element whose PermuteNTTIndex the reference stores next to the key."""

@@ -226,3 +226,74 @@ def test_rotation_decrypts_to_the_permuted_plaintext(gpu_pkg, oracle, hoisted):
         for i, q in enumerate(Q):
             worst = max(abs(((int(x) - int(w)) % q + q // 2) % q - q // 2) for x, w in zip(dec[i], want[i]))
             assert worst < 1 << 16, (g, i, worst)
+
+
+def test_encrypt_mulrelin_decrypt_chain(gpu_pkg, oracle):
+    """The encrypt and decrypt tails of SURVEY 8(f)-2 as compositions of the ring's entry points: public-key encryption
+    through the special primes (ckks/encryptor.go:207-243: MulCoeffsMontgomery, InvNTT over QP, ModDownPQ, NTT, Add),
+    MulRelin, Horner decryption (ckks/decryptor.go:53-78).  decrypt(encrypt(m)) = m + small noise, and
+    decrypt(MulRelin(encrypt(m0), encrypt(m1))) = m0*m1 + small noise, judged with Python integers."""
+    logn, nq, np_ = 10, 4, 2
+    N = 1 << logn
+    _, Qf, Pf = gpu_pkg.params.ckks_moduli("PN15QP880")
+    Q, P = Qf[:nq], Pf[:np_]
+    QP = Q + P
+    level = nq - 1
+    alpha, beta = np_, -(-nq // np_)
+    ocQP, ocQ = oracle.Context(N, QP), oracle.Context(N, Q)
+    Pprod = P[0] * P[1]
+    ring = gpu_pkg.ring
+    cQ, cP, cQP = ring.NewContextWithParams(N, Q), ring.NewContextWithParams(N, P), ring.NewContextWithParams(N, QP)
+    plan = ring.CkksPlan(cQ, cP, 1)
+    bc = ring.NewFastBasisExtender(cQ, cP)
+
+    s = _small(N, 1, 31)
+    s_ntt = ocQP.ntt(_residues(s, QP))
+    s2_ntt = _mulmod(s_ntt, s_ntt, QP)
+    # public key (-a*s + e, a) over QP, relinearisation key as in the first test; all in NTT + Montgomery form
+    a_pk = gpu_pkg.sampling.uniform_poly(QP, N, 1, seed=1000)[0]
+    pk0 = _addmod(_negmod(_mulmod(a_pk, s_ntt, QP), QP), ocQP.ntt(_residues(_small(N, 6, 1001), QP)), QP)
+    ppk = (cQP.NewPoly(1).set(_mont(pk0, QP)[None]), cQP.NewPoly(1).set(_mont(a_pk, QP)[None]))
+    evk = np.zeros((beta, 2, nq + np_, N), dtype=np.uint64)
+    for i in range(beta):
+        a_i = gpu_pkg.sampling.uniform_poly(QP, N, 1, seed=1010 + i)[0]
+        k0 = _addmod(_negmod(_mulmod(a_i, s_ntt, QP), QP), ocQP.ntt(_residues(_small(N, 6, 1020 + i), QP)), QP)
+        for j in range(alpha):
+            idx = i * alpha + j
+            if idx < nq:
+                q = QP[idx]
+                k0[idx] = np.array([(int(x) + (Pprod % q) * int(y)) % q for x, y in zip(k0[idx], s2_ntt[idx])], dtype=np.uint64)
+        evk[i, 0], evk[i, 1] = _mont(k0, QP), _mont(a_i, QP)
+    pevk = plan.NewSwitchingKey().set(evk.reshape(2 * beta, nq + np_, N))
+    psk = cQ.NewPoly(1).set(_mont(s_ntt[:nq], Q)[None])
+
+    def encrypt(m, seed):
+        u = ocQP.ntt(_residues(_small(N, 1, seed), QP))
+        pu = cQP.NewPoly(1).set(_mont(u, QP)[None])
+        e = [cQP.NewPoly(1).set(_residues(_small(N, 6, seed + 1 + k), QP)[None]) for k in range(2)]
+        pt = cQ.NewPolyLvl(level, 1).set(ocQ.ntt(_residues(m, Q))[None])
+        ct = (cQ.NewPolyLvl(level, 1), cQ.NewPolyLvl(level, 1))
+        plan.EncryptPk(cQP, bc, level, pu, ppk, e, pt, ct)
+        return ct
+
+    def decrypt(ct):
+        pt = cQ.NewPolyLvl(level, 1)
+        plan.Decrypt(level, ct, psk, pt)
+        return ocQ.intt(pt.get().reshape(nq, N))
+
+    def centred_error(dec, want):
+        worst = 0
+        for i, q in enumerate(Q):
+            worst = max(worst, max(abs(((int(x) - int(w)) % q + q // 2) % q - q // 2) for x, w in zip(dec[i], want)))
+        return worst
+
+    m0, m1 = _small(N, 1 << 12, 1100), _small(N, 1 << 12, 1101)
+    ct0, ct1 = encrypt(m0, 1110), encrypt(m1, 1120)
+    assert centred_error(decrypt(ct0), m0) < 1 << 12          # fresh noise: u*e_pk + e0 + e1*s, rounded by P
+    out = (cQ.NewPolyLvl(level, 1), cQ.NewPolyLvl(level, 1))
+    plan.MulRelin(level, ct0, ct1, pevk, out)
+    full = np.convolve(m0.astype(object), m1.astype(object))
+    prod = [int(full[k]) - (int(full[k + N]) if k + N < len(full) else 0) for k in range(N)]
+    # noise of the product ~ m * fresh noise * N: far below the moduli, far above zero
+    assert centred_error(decrypt(out), prod) < 1 << 34
+    assert centred_error(decrypt(out), [0] * N) > 1 << 20
