@@ -123,6 +123,13 @@ func (c *Context) MulByPow2(p1 *Poly, pow2 uint64, p2 *Poly) {
 	c.ew(C.LR_MUL_BY_POW2, c.top(), p1, nil, p2, []uint64{pow2})
 }
 
+// MultByMonomial (ring/ring.go:663); p1 and p2 must differ here (the reference goes through a temporary).
+func (c *Context) MultByMonomial(p1 *Poly, monomialDeg uint64, p2 *Poly) {
+	in(p1)
+	check(C.lr_mult_by_monomial(c.h, p1.d, C.uint64_t(monomialDeg), p2.d))
+	out(p2)
+}
+
 // Copy / CopyLvl (ring/ring_object.go:85,98).
 func (c *Context) Copy(p0, p1 *Poly)                  { c.ew(C.LR_COPY, c.top(), p0, nil, p1, nil) }
 func (c *Context) CopyLvl(level uint64, p0, p1 *Poly) { c.ew(C.LR_COPY, level, p0, nil, p1, nil) }

@@ -174,6 +174,9 @@ int lr_permute_ntt_index(uint64_t gen, uint64_t power, uint64_t N, uint64_t *ind
 /* Context.Permute (:106), coefficient domain, all limbs of the context: out[j][i*gen mod N] = +-in[j][i]
  * (a zero coefficient whose sign flips becomes q, as in the reference).  Not in place. */
 int lr_permute(lr_context *ctx, const lr_poly *in, uint64_t gen, lr_poly *out);
+/* Context.MultByMonomial (ring/ring.go:663): out = in * X^monomial_deg in Z_q[X]/(X^N+1), coefficient domain, all limbs.
+ * Negated coefficients are q - x without reduction, as in the reference (a zero coefficient becomes q).  in != out. */
+int lr_mult_by_monomial(lr_context *ctx, const lr_poly *in, uint64_t monomial_deg, lr_poly *out);
 
 /* ------------------------------------------------------------------ basis extension --- */
 /* NewFastBasisExtender(contextQ, contextP), ring/ring_basis_extension.go:57 */

@@ -51,6 +51,7 @@ SYMBOLS = {
     "lr_permute_ntt": [vp, i32, vp, u64, vp],
     "lr_permute_ntt_index": [u64, u64, u64, u64p],
     "lr_permute": [vp, vp, u64, vp],
+    "lr_mult_by_monomial": [vp, vp, u64, vp],
     "lr_bext_create": [vp, vp, C.POINTER(vp)],
     "lr_bext_destroy": [vp],
     "lr_modup_split_qp": [vp, i32, vp, vp],

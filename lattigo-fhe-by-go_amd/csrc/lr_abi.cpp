@@ -827,6 +827,27 @@ extern "C" int lr_permute(lr_context *c, const lr_poly *in, uint64_t gen, lr_pol
     return permute_common(c, c->h.L() - 1, in, gen, out, false);
 }
 
+extern "C" int lr_mult_by_monomial(lr_context *c, const lr_poly *in, uint64_t monomial_deg, lr_poly *out) {
+    if (!c || !in || !out) return fail(LR_ERR_ARG, "null argument");
+    const int level = c->h.L() - 1;
+    LR_TRY(check_pair(c, level, in, out));
+    if (in->batch != out->batch) return fail(LR_ERR_SHAPE, "batch mismatch");
+    if (in->d == out->d) return fail(LR_ERR_ARG, "MultByMonomial needs distinct input and output here (the reference copies through a temporary)");
+    LR_HIP(hipSetDevice(c->device));
+    GaloisLaunch L;
+    L.in = in->d;
+    L.out = out->d;
+    L.in_stride = in->stride();
+    L.out_stride = out->stride();
+    L.n = (int)c->h.N;
+    L.logn = (int)c->h.logN;
+    L.ntt_domain = 0;
+    L.gen = monomial_deg % (c->h.N << 1);      // ring/ring.go:667
+    L.lp = c->d_lp;
+    LR_HIP(launch_monomial(L, level + 1, out->batch, c->stream));
+    return LR_OK;
+}
+
 extern "C" int lr_permute_ntt_index(uint64_t gen, uint64_t power, uint64_t N, uint64_t *index) {
     if (!index) return fail(LR_ERR_ARG, "null argument");
     if (N == 0 || (N & (N - 1)) != 0) return fail(LR_ERR_INVALID_DEGREE, "invalid ring degree (must be a power of 2)");

@@ -148,6 +148,9 @@ struct GaloisLaunch {
     const LimbParams *lp;
 };
 hipError_t launch_permute(const GaloisLaunch &L, int limbs, int batch, hipStream_t stream);
+// Context.MultByMonomial (ring/ring.go:663): out = in * X^shift in Z_q[X]/(X^N+1), shift already reduced modulo 2N;
+// like the reference, negated coefficients are q - x without reduction (0 becomes q).  Not in place.
+hipError_t launch_monomial(const GaloisLaunch &L, int limbs, int batch, hipStream_t stream);
 
 // ---- basis extension (lr_bext.hip) ----
 struct ExtTables {        // device pointers; modupParams of ring_basis_extension.go:19-37

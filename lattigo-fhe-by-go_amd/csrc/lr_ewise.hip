@@ -234,6 +234,38 @@ hipError_t launch_scalar_pair(const ScalarPairLaunch &L, int limbs, int batch, h
     return hipGetLastError();
 }
 
+// GaloisLaunch::gen carries the shift (mod 2N)
+__global__ __launch_bounds__(256) void monomial_kernel(GaloisLaunch L) {
+    const int limb = blockIdx.y;
+    const long long b = blockIdx.z;
+    const u64 q = L.lp[limb].q;
+    const u64 *pi = L.in + b * L.in_stride + (long long)limb * L.n;
+    u64 *po = L.out + b * L.out_stride + (long long)limb * L.n;
+    const int n = L.n;
+    const bool flip = L.gen >= (u64)n;           // X^N = -1: the whole polynomial changes sign first (:700-707)
+    const int shift = (int)(L.gen % (u64)n);
+    for (int j = blockIdx.x * 256 + threadIdx.x; j < n; j += gridDim.x * 256) {
+        if (L.gen == 0) {
+            po[j] = pi[j];                         // :669-678
+            continue;
+        }
+        const int src = j < shift ? n - shift + j : j - shift;
+        u64 v = pi[src];
+        if (flip) v = q - v;                       // tmpx
+        po[j] = j < shift ? q - v : v;             // :712-723
+    }
+}
+
+hipError_t launch_monomial(const GaloisLaunch &L, int limbs, int batch, hipStream_t stream) {
+    if (limbs <= 0 || batch <= 0) return hipSuccess;
+    int gx = (L.n + 255) / 256;
+    if (gx > 64) gx = 64;
+    const dim3 grid((unsigned)gx, (unsigned)limbs, (unsigned)batch), block(256);
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(monomial_kernel, grid, block, 0, stream, L);
+    return hipGetLastError();
+}
+
 hipError_t launch_tensor(const TensorLaunch &L, int limbs, int batch, hipStream_t stream) {
     if (limbs <= 0 || batch <= 0) return hipSuccess;
     const int pairs = L.n >> 1;

@@ -298,6 +298,9 @@ class Context:
     def Permute(self, polIn, gen, polOut):  # :106
         check(lib().lr_permute(self.h, polIn.h, int(gen), polOut.h))
 
+    def MultByMonomial(self, p1, monomialDeg, p2):  # ring/ring.go:663
+        check(lib().lr_mult_by_monomial(self.h, p1.h, int(monomialDeg), p2.h))
+
     def PermuteNTTLvl(self, level, polIn, gen, polOut):  # package-level PermuteNTT (:55) on limbs 0..level
         check(lib().lr_permute_ntt(self.h, level, polIn.h, int(gen), polOut.h))
 

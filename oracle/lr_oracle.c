@@ -1132,3 +1132,28 @@ void oc_ckks_rotate_hoisted(oc_ckks_plan *p, int level, const u64 *ct, int n_rot
     free(c2inv); free(decQ); free(decP); free(permQ); free(permP);
     free(pool2Q); free(pool3Q); free(pool2P); free(pool3P);
 }
+
+
+/* Context.MultByMonomial, ring/ring.go:663-727 (through the temporary tmpx, so p1 may equal p2) */
+void oc_mult_by_monomial(const oc_context *c, const u64 *p1, u64 monomial_deg, u64 *p2) {
+    const u64 N = c->N;
+    u64 shift = monomial_deg % (N << 1);                              /* :667 */
+    if (shift == 0) {
+        for (int i = 0; i < c->L; i++)
+            for (u64 j = 0; j < N; j++) p2[(size_t)i * N + j] = p1[(size_t)i * N + j];   /* :669-678 */
+        return;
+    }
+    u64 *tmpx = (u64 *)malloc(sizeof(u64) * (size_t)c->L * N);
+    for (int i = 0; i < c->L; i++) {
+        const u64 qi = c->q[i];
+        for (u64 j = 0; j < N; j++)
+            tmpx[(size_t)i * N + j] = shift < N ? p1[(size_t)i * N + j] : qi - p1[(size_t)i * N + j];   /* :684-707 */
+    }
+    shift %= N;                                                       /* :710 */
+    for (int i = 0; i < c->L; i++) {
+        const u64 qi = c->q[i];
+        for (u64 j = 0; j < shift; j++) p2[(size_t)i * N + j] = qi - tmpx[(size_t)i * N + N - shift + j];   /* :712-717 */
+        for (u64 j = shift; j < N; j++) p2[(size_t)i * N + j] = tmpx[(size_t)i * N + j - shift];            /* :719-726 */
+    }
+    free(tmpx);
+}

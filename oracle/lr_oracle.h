@@ -190,6 +190,8 @@ void oc_ckks_permute_ntt(oc_ckks_plan *p, int level, const uint64_t *ct, uint64_
 void oc_ckks_rotate_hoisted(oc_ckks_plan *p, int level, const uint64_t *ct, int n_rot, const uint64_t *gens,
                             const uint64_t *const *evks, uint64_t *out);
 
+void oc_mult_by_monomial(const oc_context *c, const uint64_t *p1, uint64_t monomial_deg, uint64_t *p2);   /* ring/ring.go:663 */
+
 /* ---- Galois automorphisms: ring/ring_galois.go -------------------------------- */
 void oc_permute_ntt_index(uint64_t gen, uint64_t power, uint64_t N, uint64_t *index);              /* :29  */
 void oc_permute_ntt(const uint64_t *in, uint64_t gen, uint64_t *out, int limbs, uint64_t N);       /* :55  */

@@ -124,6 +124,7 @@ def lib():
     sig("oc_permute_ntt", None, vp, u64, vp, i, u64)
     sig("oc_permute_ntt_with_index", None, vp, vp, vp, i, u64)
     sig("oc_permute", None, vp, vp, u64, vp)
+    sig("oc_mult_by_monomial", None, vp, vp, u64, vp)
     _lib = L
     return L
 
@@ -273,6 +274,12 @@ class Context:
         p = _arr(p)
         out = np.zeros_like(p)
         lib().oc_permute(self.h, _ptr(p), int(gen), _ptr(out))
+        return out
+
+    def mult_by_monomial(self, p, deg):      # Context.MultByMonomial (ring/ring.go:663)
+        p = _arr(p)
+        out = np.zeros_like(p)
+        lib().oc_mult_by_monomial(self.h, _ptr(p), int(deg), _ptr(out))
         return out
 
     def rescale_op(self, name, p, nb=None, ntt=False):

@@ -282,3 +282,18 @@ def test_marshal_binary_round_trip(gpu_pkg):
         q.UnmarshalBinary(bytes([10, 3]) + x[1].astype(">u8").tobytes()[:-8], 0)
     with pytest.raises(gpu_pkg._native.LatticeRingError):
         q.UnmarshalBinary(bytes([11, 3]) + x[1].astype(">u8").tobytes(), 0)
+
+
+@pytest.mark.parametrize("deg", [0, 1, 5, 63, 64, 65, 127, 128 + 7, 1000003])
+def test_mult_by_monomial(gpu_pkg, oracle, deg):
+    """Context.MultByMonomial (ring/ring.go:663): negacyclic shift; negated coefficients are q - x unreduced, so a zero
+    coefficient comes out as q exactly as in the reference"""
+    N, moduli = 64, list(gpu_pkg.params.Qi60()[-2:])
+    ctx, oc = gpu_pkg.ring.NewContextWithParams(N, moduli), oracle.Context(N, moduli)
+    x = gpu_pkg.sampling.uniform_poly(moduli, N, 2, seed=17)
+    x[0, :, 3] = 0
+    x[1, :, N - 1] = 0
+    p, r = ctx.NewPoly(2).set(x), ctx.NewPoly(2)
+    ctx.MultByMonomial(p, deg, r)
+    for b in range(2):
+        assert np.array_equal(r.get()[b], oc.mult_by_monomial(x[b], deg)), (deg, b)
