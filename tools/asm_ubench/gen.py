@@ -47,6 +47,30 @@ class Probe(Gen):
                 for op in self.ops_butterfly(self.ts[0], X[i], X[i + 16], tw, True):
                     e(*op)
             return 16 * 18
+        if var == "fp64_bfly":
+            # the butterfly an FP64 path would use for moduli <= 50 bits: error-free product (mul + fma), quotient by
+            # multiplication with 1/q and round-to-nearest, exact remainder by fma, then X = U + r, Y = U - r
+            n = 0
+            for rep in range(2):
+                for i in range(0, 16, 2):
+                    for d in range(2):          # two butterflies interleaved by hand
+                        pass
+                    A = [(X[i + d], X[i + d + 16], self.ts[d]) for d in range(2)]
+                    seq = lambda U, V, ts: [
+                        ("v_mul_f64", ts.Q, V, s(36, 2)),
+                        ("v_fma_f64", ts.R, V, s(36, 2), "-" + repr(ts.Q)),
+                        ("v_mul_f64", ts.C, ts.Q, s(38, 2)),
+                        ("v_rndne_f64", ts.C, ts.C),
+                        ("v_fma_f64", ts.Q, "-" + repr(ts.C), s(40, 2), ts.Q),
+                        ("v_add_f64", ts.Q, ts.Q, ts.R),
+                        ("v_add_f64", V, U, "-" + repr(ts.Q)),
+                        ("v_add_f64", U, U, ts.Q)]
+                    a, b = seq(*A[0]), seq(*A[1])
+                    for k in range(len(a)):
+                        e(*a[k])
+                        e(*b[k])
+                    n += 16
+            return n
         if var == "bfly_nc_seq":      # no interleaving of two butterflies
             for i in range(16):
                 for op in self.ops_butterfly(self.ts[0], X[i], X[i + 16], tw, False):
@@ -228,7 +252,7 @@ class Probe(Gen):
         return self.p
 
 
-VARIANTS = ["mem_x2", "mem_x4", "mem_x2_work", "mem_x4_work"]
+VARIANTS = ["bfly_nc", "fp64_bfly", "bfly_nc", "fp64_bfly"]
 _OLD2 = ["cfg_98_36", "cfg_32_36", "cfg_2_36", "cfg_32_68", "cfg_vcc_68", "cfg_98_92", "cfg_98_40", "cfg_34_64", "cfg_2_36_c", "cfg_98_36_c", "cfg_32_36_c"]
 _OLD = ["bfly_nc", "bfly_c", "bfly_nc_seq", "bfly_c_seq", "bfly_nc_2sgpr", "inv_c", "mad_sdst_vcc", "mad_sdst_alt", "subb_sgpr", "cmp_vcc", "cmp_sgpr",
             "cndmask_vcc2", "cndmask_e64_vcc", "mad_add_mix", "mulhi_add_mix", "xor_b32", "and_or", "add3", "lshl_add_u32", "mov", "mad_vsv", "mad_vvv", "mad_vs0", "mulhi_vs", "mulhi_vv", "mullo_vv",
