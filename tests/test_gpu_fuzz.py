@@ -1,0 +1,109 @@
+"""Seeded differential fuzzing of the C ABI against the oracle: random degrees, limb counts, levels, batches and
+operations, including the shapes the structured tests do not enumerate (level 0, batch 1, odd limb counts, the small
+degrees that run on the whole-limb kernel, moduli of mixed sizes, the key-switch pipeline at random levels)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _moduli(pkg, rng, logn, count):
+    """a random mix of modulus sizes that are NTT-friendly for this degree"""
+    pool = list(pkg.params.Qi60()[-8:]) + list(pkg.params.Pi60()[-4:])
+    pool += pkg.params.GenerateNTTPrimes(40, logn, 3) + pkg.params.GenerateNTTPrimes(50, logn, 2) + pkg.params.GenerateNTTPrimes(34, logn, 1)
+    pool = sorted(set(pool))
+    idx = rng.choice(len(pool), size=count, replace=False)
+    return [pool[i] for i in idx]
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_ntt_and_elementwise_fuzz(gpu_pkg, oracle, seed):
+    rng = np.random.default_rng(1000 + seed)
+    logn = int(rng.integers(1, 15))
+    N = 1 << logn
+    limbs = int(rng.integers(1, 7))
+    batch = int(rng.integers(1, 5))
+    level = int(rng.integers(0, limbs))
+    moduli = _moduli(gpu_pkg, rng, max(logn, 4), limbs)
+    ctx, oc = gpu_pkg.ring.NewContextWithParams(N, moduli), oracle.Context(N, moduli)
+    x = gpu_pkg.sampling.random_u64((batch, limbs, N), seed=seed)             # full-range inputs
+    y = gpu_pkg.sampling.uniform_poly(moduli, N, batch, seed=seed + 1).reshape(batch, limbs, N)
+    px, py, pr = ctx.NewPoly(batch).set(x), ctx.NewPoly(batch).set(y), ctx.NewPoly(batch)
+    red = lambda a, b: np.array([[int(v) % q for v in a[b, i]] for i, q in enumerate(moduli)], dtype=np.uint64)
+
+    ctx.NTTLvl(level, px, pr)
+    got = pr.get().reshape(batch, limbs, N)
+    for b in range(batch):
+        assert np.array_equal(got[b, :level + 1], oc.ntt(red(x, b))[:level + 1]), ("ntt", logn, limbs, level, b)
+    ctx.InvNTTLvl(level, py, pr)
+    got = pr.get().reshape(batch, limbs, N)
+    for b in range(batch):
+        assert np.array_equal(got[b, :level + 1], oc.intt(y[b])[:level + 1]), ("intt", logn, limbs, level, b)
+
+    ops = ["ADD", "SUB", "MUL_MONT", "MUL_COEFFS", "MUL_MONT_AND_ADD", "MUL_MONT_AND_SUB_NOMOD", "MUL_COEFFS_AND_ADD_NOMOD"]
+    op = ops[int(rng.integers(0, len(ops)))]
+    z = gpu_pkg.sampling.uniform_poly(moduli, N, batch, seed=seed + 2).reshape(batch, limbs, N)
+    pz = ctx.NewPoly(batch).set(z)
+    pr.set(y)                                                                  # accumulate variants read the output
+    ctx._ew(op, level, pz, py, pr)
+    got = pr.get().reshape(batch, limbs, N)
+    for b in range(batch):
+        want = oc.ewise(op, z[b], y[b], y[b].copy(), level=level)
+        assert np.array_equal(got[b, :level + 1], want[:level + 1]), (op, logn, limbs, level, b)
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_basis_extension_and_rescale_fuzz(gpu_pkg, oracle, seed):
+    rng = np.random.default_rng(2000 + seed)
+    logn = int(rng.integers(3, 13))
+    N = 1 << logn
+    nq, np_ = int(rng.integers(1, 9)), int(rng.integers(1, 5))
+    batch = int(rng.integers(1, 4))
+    mods = _moduli(gpu_pkg, rng, max(logn, 4), nq + np_)
+    Q, P = mods[:nq], mods[nq:]
+    ring = gpu_pkg.ring
+    cQ, cP = ring.NewContextWithParams(N, Q), ring.NewContextWithParams(N, P)
+    be = ring.NewFastBasisExtender(cQ, cP)
+    ocQ, ocP = oracle.Context(N, Q), oracle.Context(N, P)
+    obe = oracle.BasisExtender(ocQ, ocP)
+    level = int(rng.integers(0, nq))
+    x = gpu_pkg.sampling.uniform_poly(Q, N, batch, seed=seed).reshape(batch, nq, N)
+    px, pp = cQ.NewPoly(batch).set(x), cP.NewPoly(batch)
+    be.ModUpSplitQP(level, px, pp)
+    got = pp.get().reshape(batch, np_, N)
+    for b in range(batch):
+        assert np.array_equal(got[b], obe.modup_split_qp(level, x[b])), ("modup", nq, np_, level, b)
+    if nq >= 2:
+        ctx_level = nq - 1
+        pr = cQ.NewPoly(batch).set(x)
+        cQ.DivRoundByLastModulusNTT(pr)
+        got = pr.get().reshape(batch, ctx_level, N)
+        for b in range(batch):
+            assert np.array_equal(got[b], ocQ.rescale_op("oc_div_round_by_last_modulus_ntt", x[b])), ("rescale", nq, b)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_key_switch_fuzz(gpu_pkg, oracle, seed):
+    rng = np.random.default_rng(3000 + seed)
+    logn = int(rng.integers(4, 13))
+    N = 1 << logn
+    nq, np_ = int(rng.integers(2, 10)), int(rng.integers(1, 4))
+    _, Qf, Pf = gpu_pkg.params.ckks_moduli("PN15QP880")
+    Q, P = Qf[:nq], Pf[:np_]
+    batch = int(rng.integers(1, 4))
+    level = int(rng.integers(0, nq))
+    ring = gpu_pkg.ring
+    cQ, cP = ring.NewContextWithParams(N, Q), ring.NewContextWithParams(N, P)
+    plan = ring.CkksPlan(cQ, cP, batch)
+    oplan = oracle.CkksPlan(oracle.Context(N, Q), oracle.Context(N, P))
+    beta = -(-nq // np_)
+    evk = gpu_pkg.sampling.uniform_poly(Q + P, N, 2 * beta, seed=seed + 5)
+    pevk = plan.NewSwitchingKey().set(evk)
+    cx = gpu_pkg.sampling.uniform_poly(Q[:level + 1], N, batch, seed=seed).reshape(batch, level + 1, N)
+    pcx = cQ.NewPolyLvl(level, batch).set(cx)
+    p0, p1 = cQ.NewPolyLvl(level, batch), cQ.NewPolyLvl(level, batch)
+    plan.SwitchKeysInPlace(level, pcx, pevk, p0, p1)
+    g0, g1 = p0.get().reshape(batch, level + 1, N), p1.get().reshape(batch, level + 1, N)
+    for b in range(batch):
+        w0, w1 = oplan.switch_keys(level, cx[b], evk.reshape(beta, 2, nq + np_, N))
+        assert np.array_equal(g0[b], w0) and np.array_equal(g1[b], w1), (logn, nq, np_, level, b)
