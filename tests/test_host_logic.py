@@ -38,3 +38,19 @@ def test_shard_units_partitions_the_batch():
 def test_algorithmic_bytes():
     # limb-NTT = 16*N bytes; R15 poly-NTT = 8 MiB
     assert bench.ntt_bytes(1 << 15, 16) == 8 << 20
+
+
+def test_precompute_under_sanitizers(tmp_path):
+    """the host-side table generation (constants, primitive roots with the reference's factorisation quirks, psi tables,
+    basis-extension tables) compiled with AddressSanitizer + UndefinedBehaviorSanitizer and run on the CPU"""
+    import os
+    import subprocess
+
+    from conftest import ROOT
+    src = os.path.join(ROOT, "tests", "cpp", "host_precompute_sanitize.cpp")
+    csrc = os.path.join(ROOT, "lattigo-fhe-by-go_amd", "csrc")
+    exe = str(tmp_path / "host_san")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-I" + csrc,
+                           "-I" + os.path.join(ROOT, "include"), src, os.path.join(csrc, "lr_precompute.cpp"), "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.startswith("ok "), out.stdout + out.stderr
