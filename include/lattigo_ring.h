@@ -51,6 +51,7 @@ typedef struct lr_context lr_context;       /* ring.Context           ring/ring_
 typedef struct lr_poly lr_poly;             /* batch of ring.Poly     ring/ring_object.go:11-13             */
 typedef struct lr_bext lr_bext;             /* ring.FastBasisExtender ring/ring_basis_extension.go:9-18     */
 typedef struct lr_decomposer lr_decomposer; /* ring.Decomposer        ring/ring_basis_extension.go:398-407  */
+typedef struct lr_simple_scaler lr_simple_scaler; /* ring.SimpleScaler  ring/ring_scaling.go:168-181           */
 typedef struct lr_ckks_plan lr_ckks_plan;   /* scratch pools + tables of ckks.evaluator, ckks/evaluator.go:63-97 */
 
 const char *lr_last_error_string(void);     /* thread-local, never NULL */
@@ -177,6 +178,20 @@ int lr_permute(lr_context *ctx, const lr_poly *in, uint64_t gen, lr_poly *out);
 /* Context.MultByMonomial (ring/ring.go:663): out = in * X^monomial_deg in Z_q[X]/(X^N+1), coefficient domain, all limbs.
  * Negated coefficients are q - x without reduction, as in the reference (a zero coefficient becomes q).  in != out. */
 int lr_mult_by_monomial(lr_context *ctx, const lr_poly *in, uint64_t monomial_deg, lr_poly *out);
+
+/* ------------------------------------------------------------------ SimpleScaler --- */
+/* NewSimpleScaler(t, context) (ring/ring_scaling.go:186): per modulus qi the integer part wi and the double-double
+ * fractional part ti of ((Q/qi)^-1 mod qi) * t / qi, computed with the operation sequence of ring/float128.go.
+ * t a power of two selects the masked reduction (:201-211), otherwise Montgomery / Barrett modulo t (:214-243).
+ * t == 0 is LR_ERR_ARG (the reference divides by zero). */
+int lr_simple_scaler_create(lr_context *ctx, uint64_t t, lr_simple_scaler **out);
+int lr_simple_scaler_destroy(lr_simple_scaler *s);
+/* host copies of wi[count] and ti[count][2] (hi, lo), count = number of moduli */
+int lr_simple_scaler_tables(const lr_simple_scaler *s, uint64_t *wi, double *ti, int count);
+/* SimpleScaler.Scale (:275): p2[j][i] = round(t/Q * p1[.][i]) mod t for every limb j of p2 (p2 may belong to another
+ * context of the same degree, e.g. bfv's contextT; bfv/encoder.go:142).  p1 holds all moduli of the scaler's context,
+ * coefficient domain.  p1 == p2 is allowed. */
+int lr_simple_scale(lr_simple_scaler *s, const lr_poly *p1, lr_poly *p2);
 
 /* ------------------------------------------------------------------ basis extension --- */
 /* NewFastBasisExtender(contextQ, contextP), ring/ring_basis_extension.go:57 */

@@ -174,4 +174,17 @@ class Decomposer {
     lr_decomposer *h_ = nullptr;
 };
 
+// ring.SimpleScaler, ring/ring_scaling.go:168-300
+class SimpleScaler {
+  public:
+    SimpleScaler(uint64_t t, const Context *context) { check(lr_simple_scaler_create(context->handle(), t, &h_)); }   // NewSimpleScaler :186
+    ~SimpleScaler() { lr_simple_scaler_destroy(h_); }
+    SimpleScaler(const SimpleScaler &) = delete;
+    SimpleScaler &operator=(const SimpleScaler &) = delete;
+    void Scale(const Poly *p1, Poly *p2) { check(lr_simple_scale(h_, p1->handle(), p2->handle())); }                 // :275
+
+  private:
+    lr_simple_scaler *h_ = nullptr;
+};
+
 }  // namespace ring

@@ -52,6 +52,10 @@ SYMBOLS = {
     "lr_permute_ntt_index": [u64, u64, u64, u64p],
     "lr_permute": [vp, vp, u64, vp],
     "lr_mult_by_monomial": [vp, vp, u64, vp],
+    "lr_simple_scaler_create": [vp, u64, C.POINTER(vp)],
+    "lr_simple_scaler_destroy": [vp],
+    "lr_simple_scaler_tables": [vp, u64p, C.POINTER(C.c_double), i32],
+    "lr_simple_scale": [vp, vp, vp],
     "lr_bext_create": [vp, vp, C.POINTER(vp)],
     "lr_bext_destroy": [vp],
     "lr_modup_split_qp": [vp, i32, vp, vp],

@@ -199,6 +199,18 @@ struct lr_decomposer {
     std::vector<std::vector<std::unique_ptr<DevModup>>> modup;  // [beta][xalpha-1]
 };
 
+struct lr_simple_scaler {
+    int device = 0;
+    lr_context *ctx = nullptr;
+    HostSimpleScaler h;
+    u64 *d_wi = nullptr;
+    double *d_ti = nullptr;
+    ~lr_simple_scaler() {
+        if (d_wi) (void)hipFree(d_wi);
+        if (d_ti) (void)hipFree(d_ti);
+    }
+};
+
 struct lr_ckks_plan {
     int device = 0;
     lr_context *cQ = nullptr, *cP = nullptr;
@@ -1070,6 +1082,75 @@ extern "C" int lr_moddown_split_qp(lr_bext *b, int levelQ, int levelP, const lr_
 // ------------------------------------------------------------------------------------------
 // Decomposer
 // ------------------------------------------------------------------------------------------
+// ------------------------------------------------------------------------------------------
+// SimpleScaler (ring/ring_scaling.go:166-300)
+// ------------------------------------------------------------------------------------------
+extern "C" int lr_simple_scaler_create(lr_context *c, uint64_t t, lr_simple_scaler **out) {
+    if (!out) return fail(LR_ERR_ARG, "out is null");
+    *out = nullptr;
+    if (!c) return fail(LR_ERR_ARG, "null context");
+    std::unique_ptr<lr_simple_scaler> s(new (std::nothrow) lr_simple_scaler);
+    if (!s) return fail(LR_ERR_ARG, "out of host memory");
+    if (!build_simple_scaler(t, c->h.q, s->h)) return fail(LR_ERR_ARG, "t must be non-zero (BRedParams divides by it, ring/modular_reduction.go:97)");
+    s->device = c->device;
+    s->ctx = c;
+    LR_HIP(hipSetDevice(c->device));
+    std::vector<double> ti(2 * s->h.ti.size());
+    for (size_t i = 0; i < s->h.ti.size(); ++i) {
+        ti[2 * i] = s->h.ti[i].hi;
+        ti[2 * i + 1] = s->h.ti[i].lo;
+    }
+    LR_TRY(to_device(&s->d_wi, s->h.wi.data(), s->h.wi.size()));
+    LR_TRY(to_device(&s->d_ti, ti.data(), ti.size()));
+    *out = s.release();
+    return LR_OK;
+}
+
+extern "C" int lr_simple_scaler_destroy(lr_simple_scaler *s) {
+    if (!s) return LR_OK;
+    (void)hipSetDevice(s->device);
+    (void)hipStreamSynchronize(shared_stream(s->device));
+    delete s;
+    return LR_OK;
+}
+
+extern "C" int lr_simple_scaler_tables(const lr_simple_scaler *s, uint64_t *wi, double *ti, int count) {
+    if (!s || !wi || !ti) return fail(LR_ERR_ARG, "null argument");
+    if (count != (int)s->h.wi.size()) return fail(LR_ERR_SHAPE, "table size mismatch");
+    for (int i = 0; i < count; ++i) {
+        wi[i] = s->h.wi[i];
+        ti[2 * i] = s->h.ti[i].hi;
+        ti[2 * i + 1] = s->h.ti[i].lo;
+    }
+    return LR_OK;
+}
+
+extern "C" int lr_simple_scale(lr_simple_scaler *s, const lr_poly *p1, lr_poly *p2) {
+    if (!s || !p1 || !p2) return fail(LR_ERR_ARG, "null argument");
+    lr_context *c = s->ctx;
+    if (p1->N != c->h.N || p2->N != c->h.N) return fail(LR_ERR_SHAPE, "ring degree mismatch");
+    if (p1->limbs < c->h.L()) return fail(LR_ERR_SHAPE, "p1 must hold every modulus of the scaler's context (index out of range in the reference)");
+    if (p1->device != c->device || p2->device != c->device) return fail(LR_ERR_ARG, "poly lives on another device");
+    if (p1->batch != p2->batch) return fail(LR_ERR_SHAPE, "batch mismatch");
+    LR_HIP(hipSetDevice(c->device));
+    ScaleLaunch L;
+    L.in = p1->d;
+    L.out = p2->d;
+    L.in_stride = p1->stride();
+    L.out_stride = p2->stride();
+    L.wi = s->d_wi;
+    L.ti = s->d_ti;
+    L.t = s->h.t;
+    L.add_param = s->h.add_param;
+    L.mul_param = s->h.mul_param;
+    L.pow2 = s->h.pow2 ? 1 : 0;
+    L.limbs_in = c->h.L();
+    L.limbs_out = p2->limbs;
+    L.n = (int)c->h.N;
+    LR_HIP(launch_simple_scale(L, p1->batch, c->stream));
+    return LR_OK;
+}
+
 extern "C" int lr_decomposer_create(lr_context *cQ, lr_context *cP, lr_decomposer **out) {
     if (!cQ || !cP || !out) return fail(LR_ERR_ARG, "null argument");
     *out = nullptr;

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include "lr_arith.hpp"
+#include "lr_float128.hpp"
 
 namespace lr {
 
@@ -151,6 +152,19 @@ hipError_t launch_permute(const GaloisLaunch &L, int limbs, int batch, hipStream
 // Context.MultByMonomial (ring/ring.go:663): out = in * X^shift in Z_q[X]/(X^N+1), shift already reduced modulo 2N;
 // like the reference, negated coefficients are q - x without reduction (0 becomes q).  Not in place.
 hipError_t launch_monomial(const GaloisLaunch &L, int limbs, int batch, hipStream_t stream);
+
+// SimpleScaler.Scale (ring/ring_scaling.go:275-300): one thread per coefficient reconstructs round(t/Q * x) mod t from all
+// limbs of the input (integer parts in Z_t, fractional parts in double-double) and writes it to every limb of the output
+struct ScaleLaunch {
+    const u64 *in;
+    u64 *out;
+    long long in_stride, out_stride;   // between batch polys, in words
+    const u64 *wi;                     // [limbs_in]
+    const double *ti;                  // [limbs_in][2] (hi, lo)
+    u64 t, add_param, mul_param;
+    int pow2, limbs_in, limbs_out, n;
+};
+hipError_t launch_simple_scale(const ScaleLaunch &L, int batch, hipStream_t stream);
 
 // ---- basis extension (lr_bext.hip) ----
 struct ExtTables {        // device pointers; modupParams of ring_basis_extension.go:19-37

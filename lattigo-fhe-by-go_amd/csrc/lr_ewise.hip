@@ -266,6 +266,51 @@ hipError_t launch_monomial(const GaloisLaunch &L, int limbs, int batch, hipStrea
     return hipGetLastError();
 }
 
+// ring_scaling.go:275-300.  `a` accumulates without reduction and wraps modulo 2^64 exactly like the reference's uint64.
+__global__ __launch_bounds__(256) void simple_scale_kernel(ScaleLaunch L) {
+    const long long b = blockIdx.y;
+    const u64 *pi = L.in + b * L.in_stride;
+    u64 *po = L.out + b * L.out_stride;
+    const int n = L.n;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        u64 a = 0;
+        F128 f{0.0, 0.0};
+        for (int j = 0; j < L.limbs_in; ++j) {
+            const u64 x = ld_stream(pi + (long long)j * n + i);
+            const u64 w = ld_const(L.wi + j);
+            if (L.pow2) {
+                a += (x * w) & L.add_param;                                // :205
+            } else {
+                u64 hi, lo;
+                mul_wide64(w, x, hi, lo);                                  // :219-229
+                u64 r = hi - mul_hi64(lo * L.mul_param, L.t) + L.t;
+                if (r >= L.t) r -= L.t;
+                a += r;
+            }
+            const F128 tj{L.ti[2 * j], L.ti[2 * j + 1]};
+            f = f128_add(f, f128_mul(tj, f128_set_uint64(x)));            // :290
+        }
+        a += f128_to_uint64(f);                                            // :293
+        if (L.pow2) {
+            a &= L.mul_param;                                              // :209
+        } else {
+            a = a - mul_hi64(a, L.add_param) * L.t;                        // :233-241
+            if (a >= L.t) a -= L.t;
+        }
+        for (int j = 0; j < L.limbs_out; ++j) st_stream(po + (long long)j * n + i, a);
+    }
+}
+
+hipError_t launch_simple_scale(const ScaleLaunch &L, int batch, hipStream_t stream) {
+    if (batch <= 0 || L.limbs_out <= 0) return hipSuccess;
+    int gx = (L.n + 255) / 256;
+    if (gx > 1024) gx = 1024;
+    const dim3 grid((unsigned)gx, (unsigned)batch), block(256);
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(simple_scale_kernel, grid, block, 0, stream, L);
+    return hipGetLastError();
+}
+
 hipError_t launch_tensor(const TensorLaunch &L, int limbs, int batch, hipStream_t stream) {
     if (limbs <= 0 || batch <= 0) return hipSuccess;
     const int pairs = L.n >> 1;

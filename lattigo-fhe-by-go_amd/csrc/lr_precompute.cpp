@@ -301,4 +301,33 @@ std::vector<u64> build_moddown(const HostContext &over, const HostContext &divis
     return r;
 }
 
+bool build_simple_scaler(u64 t, const std::vector<u64> &moduli, HostSimpleScaler &out) {
+    if (t == 0) return false;
+    out.t = t;
+    out.pow2 = (t & (t - 1)) == 0;                                   // ring_scaling.go:201
+    BarrettConst bt{0, 0};
+    if (out.pow2) {
+        out.add_param = out.mul_param = t - 1;
+    } else {
+        bt = barrett_const(t);
+        out.add_param = bt.hi;                                       // :216
+        out.mul_param = montgomery_const(t);                         // :217
+    }
+    const int L = (int)moduli.size();
+    out.wi.assign(L, 0);
+    out.ti.assign(L, F128{0.0, 0.0});
+    for (int i = 0; i < L; ++i) {
+        const u64 qi = moduli[i];
+        u64 bar = inverse_mod_prime(product_mod(moduli, i, qi), qi);  // QiBarre, :250-253
+        F128 tmp = f128_div(f128_set_uint53(t), f128_set_uint64(qi));  // :255
+        tmp = f128_mul(tmp, f128_set_uint64(bar));                     // :257
+        u64 w = f128_to_uint53(tmp);                                   // :260
+        if (!out.pow2) w = mform(w, t, bt.hi, bt.lo);                  // :263-265
+        out.wi[i] = w;
+        bar = mulmod(bar, t % qi, qi);                                 // :267-268
+        out.ti[i] = f128_div(f128_set_uint64(bar), f128_set_uint64(qi));   // :270
+    }
+    return true;
+}
+
 }  // namespace lr

@@ -9,6 +9,7 @@
 #include <vector>
 
 #include "lr_arith.hpp"
+#include "lr_float128.hpp"
 
 namespace lr {
 
@@ -51,5 +52,17 @@ HostModup build_modup(const std::vector<u64> &Q, const std::vector<u64> &P);
 // genModDownParams(contextP, contextQ), ring_basis_extension.go:39: for each modulus m of `over`,
 // MForm((prod of `divisor` moduli)^-1 mod m)
 std::vector<u64> build_moddown(const HostContext &over, const HostContext &divisor);
+
+// NewSimpleScaler(t, context), ring/ring_scaling.go:186-268
+struct HostSimpleScaler {
+    u64 t = 0;
+    bool pow2 = false;              // t is a power of two: products are masked, otherwise Montgomery-reduced modulo t
+    u64 add_param = 0;              // t-1 (mask) or BRedParams(t)[0]
+    u64 mul_param = 0;              // t-1 (mask) or MRedParams(t)
+    std::vector<u64> wi;            // floor(QiBarre * t / qi), in Montgomery form modulo t unless pow2
+    std::vector<F128> ti;           // ((QiBarre * t) mod qi) / qi as a double-double
+};
+// returns false when t == 0 (the reference divides by zero in BRedParams)
+bool build_simple_scaler(u64 t, const std::vector<u64> &moduli, HostSimpleScaler &out);
 
 }  // namespace lr

@@ -429,6 +429,40 @@ def NewDecomposer(contextQ, contextP):
     return Decomposer(contextQ, contextP)
 
 
+class SimpleScaler:
+    """ring.SimpleScaler (ring/ring_scaling.go:168-300): reconstruct a polynomial of `context`, scale it by t/Q and
+    return it modulo t."""
+
+    def __init__(self, t, context):
+        self.t, self.context = int(t), context
+        h = C.c_void_p()
+        check(lib().lr_simple_scaler_create(context.h, self.t, C.byref(h)))
+        self.h = h
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                lib().lr_simple_scaler_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def tables(self):
+        """(wi[L], ti[L][2]) as computed on the host by NewSimpleScaler"""
+        n = len(self.context.Modulus)
+        wi = np.zeros(n, dtype=np.uint64)
+        ti = np.zeros((n, 2), dtype=np.float64)
+        check(lib().lr_simple_scaler_tables(self.h, wi.ctypes.data_as(C.POINTER(C.c_uint64)), ti.ctypes.data_as(C.POINTER(C.c_double)), n))
+        return wi, ti
+
+    def Scale(self, p1, p2):  # :275
+        check(lib().lr_simple_scale(self.h, p1.h, p2.h))
+
+
+def NewSimpleScaler(t, context):  # ring/ring_scaling.go:186
+    return SimpleScaler(t, context)
+
+
 class CkksPlan:
     """What ckks.NewEvaluator builds around the ring (ckks/evaluator.go:81-112) plus the
     MulRelin / switchKeysInPlace / Rescale call sequences (:1016, :1475, :933), device-resident."""

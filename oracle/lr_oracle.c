@@ -10,6 +10,7 @@
  * fused; Go never fuses it because it has no multiply -- SURVEY A.5).
  */
 #include "lr_oracle.h"
+#include <math.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -1156,4 +1157,149 @@ void oc_mult_by_monomial(const oc_context *c, const u64 *p1, u64 monomial_deg, u
         for (u64 j = shift; j < N; j++) p2[(size_t)i * N + j] = tmpx[(size_t)i * N + j - shift];            /* :719-726 */
     }
     free(tmpx);
+}
+
+
+/* ------------------------------------------------------------------------------------------------
+ * Float128 (ring/float128.go): double-double arithmetic, operation for operation.  Compiled with -ffp-contract=off.
+ * ---------------------------------------------------------------------------------------------- */
+void oc_f128_set_uint53(u64 i, double r[2]) { r[0] = (double)i; r[1] = 0.0; }                     /* :32 */
+void oc_f128_set_uint64(u64 i, double r[2]) { r[0] = (double)(i >> 12); r[1] = (double)(i & 0xfff) / 4096.0; }   /* :43 */
+u64 oc_f128_to_uint53(const double f[2]) { return (u64)f[0]; }
+u64 oc_f128_to_uint64(const double f[2]) {
+    /* uint64(f[0]*4096) + uint64(math.Round((f[0]*4096 - float64(that)) + f[1]*4096)); a negative rounded value wraps like
+     * Go's amd64 conversion (through int64) */
+    const double s = f[0] * 4096.0;
+    const u64 t = (u64)s;
+    const double r = round((s - (double)t) + f[1] * 4096.0);
+    return t + (u64)(int64_t)r;
+}
+static void f_two_sum(double a, double b, double *s, double *err) {
+    *s = a + b;
+    const double bb = *s - a;
+    *err = (a - (*s - bb)) + (b - bb);
+}
+static void f_quick_two_sum(double a, double b, double *s, double *err) {
+    *s = a + b;
+    *err = b - (*s - a);
+}
+static void f_two_diff(double a, double b, double *s, double *err) {
+    *s = a - b;
+    const double bb = *s - a;
+    *err = (a - (*s - bb)) - (b + bb);
+}
+static void f_split(double a, double *hi, double *lo) {
+    const double temp = 134217729.0 * a;
+    *hi = temp - (temp - a);
+    *lo = a - *hi;
+}
+static void f_two_prod(double a, double b, double *p, double *err) {
+    double ah, al, bh, bl;
+    *p = a * b;
+    f_split(a, &ah, &al);
+    f_split(b, &bh, &bl);
+    *err = ((ah * bh - *p) + ah * bl + al * bh) + al * bl;
+}
+void oc_f128_add(const double a[2], const double b[2], double f[2]) {
+    double s1, s2, t1, t2;
+    f_two_sum(a[0], b[0], &s1, &s2);
+    f_two_sum(a[1], b[1], &t1, &t2);
+    s2 += t1;
+    f_quick_two_sum(s1, s2, &s1, &s2);
+    s2 += t2;
+    f_quick_two_sum(s1, s2, &f[0], &f[1]);
+}
+void oc_f128_mul(const double a[2], const double b[2], double f[2]) {
+    double p1, p2;
+    f_two_prod(a[0], b[0], &p1, &p2);
+    p2 += a[0] * b[1] + a[1] * b[0];
+    f_quick_two_sum(p1, p2, &f[0], &f[1]);
+}
+void oc_f128_div(const double a[2], const double b[2], double f[2]) {
+    double p1, p2, p3, p4, v1, v2;
+    const double q1 = a[0] / b[0];
+    f_two_prod(q1, b[0], &p1, &p2);
+    p2 += q1 * b[1];
+    const double t0 = p1 + p2;
+    const double t1 = p2 - (t0 - p1);
+    f_two_diff(a[0], t0, &p3, &p4);
+    f_two_diff(a[1], t1, &v1, &v2);
+    p4 += v1;
+    f_quick_two_sum(p3, p4, &p3, &p4);
+    p4 += v2;
+    const double r = (p3 + p4) / b[0];
+    const double hi = q1 + r;
+    f[1] = r - (hi - q1);
+    f[0] = hi;
+}
+
+/* NewSimpleScaler, ring/ring_scaling.go:186-271.  wi[L], ti[L][2]; params[0] = reducealgoAddParam, params[1] =
+ * reducealgoMulParam.  QiStar mod qi is the product of the other moduli; its inverse by Fermat (prime moduli). */
+void oc_simple_scaler_new(const oc_context *c, u64 t, u64 *wi, double *ti, u64 params[2]) {
+    const int pow2 = (t & (t - 1)) == 0 && t != 0;                     /* :201 */
+    u64 ut[2] = {0, 0};
+    if (pow2) {
+        params[0] = params[1] = t - 1;                                 /* :203-204 */
+    } else {
+        oc_bred_params(t, ut);
+        params[0] = ut[0];                                             /* :216 */
+        params[1] = oc_mred_params(t);                                 /* :217 */
+    }
+    for (int i = 0; i < c->L; i++) {
+        const u64 qi = c->q[i];
+        u64 star = 1;
+        for (int k = 0; k < c->L; k++)
+            if (k != i) star = (u64)(((unsigned __int128)star * (c->q[k] % qi)) % qi);
+        u64 bar = oc_mod_exp(star, qi - 2, qi);                        /* :252-253 */
+        double a[2], b[2], tmp[2];
+        oc_f128_set_uint53(t, a);
+        oc_f128_set_uint64(qi, b);
+        oc_f128_div(a, b, tmp);                                        /* :255 */
+        oc_f128_set_uint64(bar, b);
+        oc_f128_mul(tmp, b, a);                                        /* :257 */
+        wi[i] = oc_f128_to_uint53(a);                                  /* :260 */
+        if ((t & (t - 1)) != 0 && t != 0) wi[i] = oc_mform(wi[i], t, ut);   /* :263-265 */
+        bar = (u64)(((unsigned __int128)bar * t) % qi);                /* :267-268 */
+        oc_f128_set_uint64(bar, a);
+        oc_f128_set_uint64(qi, b);
+        oc_f128_div(a, b, &ti[2 * i]);                                 /* :270 */
+    }
+}
+
+/* SimpleScaler.Scale, ring/ring_scaling.go:275-300: p1 [L][N] -> p2 [L2][N] */
+void oc_simple_scale(const oc_context *c, u64 t, const u64 *wi, const double *ti, const u64 params[2], const u64 *p1,
+                     u64 *p2, int L2) {
+    const int pow2 = (t & (t - 1)) == 0 && t != 0;
+    for (u64 i = 0; i < c->N; i++) {
+        u64 a = 0;
+        double b[2] = {0.0, 0.0};
+        for (int j = 0; j < c->L; j++) {
+            const u64 x = p1[(size_t)j * c->N + i];
+            if (pow2) {
+                a += (wi[j] * x) & params[0];                          /* :205 */
+            } else {
+                const unsigned __int128 m = (unsigned __int128)wi[j] * x;   /* :219-229 */
+                const u64 R = (u64)m * params[1];
+                const u64 H = (u64)(((unsigned __int128)R * t) >> 64);
+                u64 r = (u64)(m >> 64) - H + t;
+                if (r >= t) r -= t;
+                a += r;
+            }
+            double fx[2], pr[2], nb[2];
+            oc_f128_set_uint64(x, fx);
+            oc_f128_mul(&ti[2 * j], fx, pr);
+            oc_f128_add(b, pr, nb);                                    /* :290 */
+            b[0] = nb[0];
+            b[1] = nb[1];
+        }
+        a += oc_f128_to_uint64(b);                                     /* :293 */
+        if (pow2) {
+            a &= params[1];                                            /* :209 */
+        } else {
+            const u64 s0 = (u64)(((unsigned __int128)a * params[0]) >> 64);   /* :233-241 */
+            a = a - s0 * t;
+            if (a >= t) a -= t;
+        }
+        for (int j = 0; j < L2; j++) p2[(size_t)j * c->N + i] = a;      /* :296-298 */
+    }
 }

@@ -205,6 +205,18 @@ void oc_permute(const oc_context *c, const uint64_t *in, uint64_t gen, uint64_t 
 void oc_bfv_mul(oc_bext *b, uint64_t t, const uint64_t *phalf_q, const uint64_t *phalf_qm,
                 const uint64_t *ct0, const uint64_t *ct1, uint64_t *out);
 
+/* ---- Float128 (ring/float128.go) and SimpleScaler (ring/ring_scaling.go:166-300) ---- */
+void     oc_f128_set_uint53(uint64_t i, double r[2]);
+void     oc_f128_set_uint64(uint64_t i, double r[2]);
+uint64_t oc_f128_to_uint53(const double f[2]);
+uint64_t oc_f128_to_uint64(const double f[2]);
+void     oc_f128_add(const double a[2], const double b[2], double f[2]);
+void     oc_f128_mul(const double a[2], const double b[2], double f[2]);
+void     oc_f128_div(const double a[2], const double b[2], double f[2]);
+void oc_simple_scaler_new(const oc_context *c, uint64_t t, uint64_t *wi, double *ti, uint64_t params[2]);
+void oc_simple_scale(const oc_context *c, uint64_t t, const uint64_t *wi, const double *ti, const uint64_t params[2],
+                     const uint64_t *p1, uint64_t *p2, int L2);
+
 #ifdef __cplusplus
 }
 #endif

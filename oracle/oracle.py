@@ -125,6 +125,16 @@ def lib():
     sig("oc_permute_ntt_with_index", None, vp, vp, vp, i, u64)
     sig("oc_permute", None, vp, vp, u64, vp)
     sig("oc_mult_by_monomial", None, vp, vp, u64, vp)
+    dp = C.POINTER(C.c_double)
+    sig("oc_f128_set_uint53", None, u64, dp)
+    sig("oc_f128_set_uint64", None, u64, dp)
+    sig("oc_f128_to_uint53", u64, dp)
+    sig("oc_f128_to_uint64", u64, dp)
+    sig("oc_f128_add", None, dp, dp, dp)
+    sig("oc_f128_mul", None, dp, dp, dp)
+    sig("oc_f128_div", None, dp, dp, dp)
+    sig("oc_simple_scaler_new", None, vp, u64, u64p, dp, u64p)
+    sig("oc_simple_scale", None, vp, u64, u64p, dp, u64p, vp, vp, i)
     _lib = L
     return L
 
@@ -312,6 +322,56 @@ class ModupParams:
             lib().oc_modup_params_free(C.cast(self.p, C.c_void_p))
         except Exception:
             pass
+
+
+class Float128:
+    """ring.Float128 (ring/float128.go): a pair of float64"""
+
+    def __init__(self, hi=0.0, lo=0.0):
+        self.v = (C.c_double * 2)(hi, lo)
+
+    @staticmethod
+    def SetUint53(i):
+        f = Float128()
+        lib().oc_f128_set_uint53(int(i), f.v)
+        return f
+
+    @staticmethod
+    def SetUint64(i):
+        f = Float128()
+        lib().oc_f128_set_uint64(int(i), f.v)
+        return f
+
+    def _bin(self, name, other):
+        f = Float128()
+        getattr(lib(), name)(self.v, other.v, f.v)
+        return f
+
+    def Add(self, o): return self._bin("oc_f128_add", o)
+    def Mul(self, o): return self._bin("oc_f128_mul", o)
+    def Div(self, o): return self._bin("oc_f128_div", o)
+    def ToUint64(self): return int(lib().oc_f128_to_uint64(self.v))
+    def ToUint53(self): return int(lib().oc_f128_to_uint53(self.v))
+    def pair(self): return (float(self.v[0]), float(self.v[1]))
+
+
+class SimpleScaler:
+    """ring.SimpleScaler (ring/ring_scaling.go:168-300)"""
+
+    def __init__(self, t, ctx):
+        self.t, self.ctx = int(t), ctx
+        self.wi = np.zeros(ctx.L, dtype=np.uint64)
+        self.ti = np.zeros((ctx.L, 2), dtype=np.float64)
+        self.params = np.zeros(2, dtype=np.uint64)
+        lib().oc_simple_scaler_new(ctx.h, self.t, self.wi.ctypes.data_as(u64p), self.ti.ctypes.data_as(C.POINTER(C.c_double)),
+                                   self.params.ctypes.data_as(u64p))
+
+    def scale(self, p1, limbs_out=1):
+        p1 = _arr(p1)
+        out = np.zeros((limbs_out, self.ctx.N), dtype=np.uint64)
+        lib().oc_simple_scale(self.ctx.h, self.t, self.wi.ctypes.data_as(u64p), self.ti.ctypes.data_as(C.POINTER(C.c_double)),
+                              self.params.ctypes.data_as(u64p), _ptr(p1), _ptr(out), limbs_out)
+        return out
 
 
 class BasisExtender:

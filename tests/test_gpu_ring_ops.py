@@ -297,3 +297,100 @@ def test_mult_by_monomial(gpu_pkg, oracle, deg):
     ctx.MultByMonomial(p, deg, r)
     for b in range(2):
         assert np.array_equal(r.get()[b], oc.mult_by_monomial(x[b], deg)), (deg, b)
+
+
+# ---- SimpleScaler (ring/ring_scaling.go:166-300) -----------------------------------------------------------------------
+@pytest.mark.parametrize("t", [65537, 1 << 16, 786433, 2, (1 << 40) + 15])
+@pytest.mark.parametrize("logn,limbs", [(4, 1), (10, 3), (13, 4)])
+def test_simple_scaler_against_oracle(gpu_pkg, oracle, t, logn, limbs):
+    """NewSimpleScaler tables (host, double-double) and Scale (device, double-double + Z_t arithmetic), bit for bit: full-range
+    residues, both reduction flavours (t a power of two or not), output into a one-limb context T as bfv/encoder.go:142 does"""
+    N = 1 << logn
+    moduli = (list(gpu_pkg.params.Qi60()[-2:]) + gpu_pkg.params.GenerateNTTPrimes(40, max(logn, 4), 1) + gpu_pkg.params.GenerateNTTPrimes(50, max(logn, 4), 1))[:limbs]
+    ring = gpu_pkg.ring
+    ctx, oc = ring.NewContextWithParams(N, moduli), oracle.Context(N, moduli)
+    s, os_ = ring.NewSimpleScaler(t, ctx), oracle.SimpleScaler(t, oc)
+    wi, ti = s.tables()
+    assert np.array_equal(wi, os_.wi)
+    assert ti.tobytes() == os_.ti.tobytes()
+    batch = 3
+    x = gpu_pkg.sampling.uniform_poly(moduli, N, batch, seed=t % 97 + logn).reshape(batch, limbs, N)
+    x[0, :, 0] = 0
+    for i, q in enumerate(moduli):
+        x[1, i, 1] = q - 1
+    p1 = ctx.NewPoly(batch).set(x)
+    tprime = gpu_pkg.params.GenerateNTTPrimes(30, max(logn, 4), 1)
+    ctxT = ring.NewContextWithParams(N, tprime)
+    p2 = ctxT.NewPoly(batch)
+    s.Scale(p1, p2)
+    got = p2.get().reshape(batch, 1, N)
+    for b in range(batch):
+        assert np.array_equal(got[b], os_.scale(x[b], 1)), (t, logn, b)
+    # into a poly of the same context: every limb receives the value (:296-298); in place as well
+    p3 = ctx.NewPoly(batch)
+    s.Scale(p1, p3)
+    got3 = p3.get().reshape(batch, limbs, N)
+    s.Scale(p1, p1)
+    got1 = p1.get().reshape(batch, limbs, N)
+    for b in range(batch):
+        want = os_.scale(x[b], limbs)
+        assert np.array_equal(got3[b], want) and np.array_equal(got1[b], want)
+
+
+def test_simple_scaler_decodes_bfv_plaintext(gpu_pkg, oracle):
+    """bfv/encoder.go:142 semantics at the full PN14QP438 size: Delta*m + noise -> m"""
+    from fractions import Fraction
+    N, Q, _, _ = gpu_pkg.params.bfv_moduli("PN14QP438")
+    Q, t = list(Q), 65537
+    ctx = gpu_pkg.ring.NewContextWithParams(N, Q)
+    s = gpu_pkg.ring.NewSimpleScaler(t, ctx)
+    rng = np.random.default_rng(9)
+    m = rng.integers(0, t, N)
+    bigQ = 1
+    for q in Q:
+        bigQ *= q
+    delta = bigQ // t
+    noise = rng.integers(-(1 << 20), 1 << 20, N)
+    x = np.array([[(delta * int(v) + int(e)) % q for v, e in zip(m, noise)] for q in Q], dtype=np.uint64)
+    p1, p2 = ctx.NewPoly(1).set(x[None]), ctx.NewPoly(1)
+    s.Scale(p1, p2)
+    got = p2.get().reshape(len(Q), N)
+    assert np.array_equal(got[0], m.astype(np.uint64)) and np.array_equal(got[-1], got[0])
+
+
+def test_simple_scaler_errors(gpu_pkg):
+    ring = gpu_pkg.ring
+    moduli = list(gpu_pkg.params.Qi60()[-2:])
+    ctx = ring.NewContextWithParams(16, moduli)
+    with pytest.raises(gpu_pkg.ring.LatticeRingError):
+        ring.NewSimpleScaler(0, ctx)                          # the reference divides by zero in BRedParams
+    s = ring.NewSimpleScaler(65537, ctx)
+    other = ring.NewContextWithParams(32, moduli)
+    with pytest.raises(gpu_pkg.ring.LatticeRingError):
+        s.Scale(ctx.NewPoly(1), other.NewPoly(1))             # degree mismatch
+    with pytest.raises(gpu_pkg.ring.LatticeRingError):
+        s.Scale(ctx.NewPoly(2), ctx.NewPoly(1))               # batch mismatch
+    with pytest.raises(gpu_pkg.ring.LatticeRingError):
+        s.Scale(ctx.NewPolyLvl(0, 1), ctx.NewPoly(1))         # p1 misses a modulus
+
+
+@pytest.mark.parametrize("logn", [12, 13, 14])
+def test_simple_scaling_reference_property(gpu_pkg, logn):
+    """twin of ring/ring_test.go:587-624 on the device path: T = 0x3ee0001, DefaultParamsQi[logN], in place, every
+    coefficient against round(T*x/Q) mod T computed with big integers"""
+    from fractions import Fraction
+    t, (N, moduli) = 0x3ee0001, gpu_pkg.params.DefaultParamsQi(logn)
+    moduli = list(moduli)
+    rng = np.random.default_rng(100 + logn)
+    ctx = gpu_pkg.ring.NewContextWithParams(N, moduli)
+    s = gpu_pkg.ring.NewSimpleScaler(t, ctx)
+    Q = 1
+    for q in moduli:
+        Q *= q
+    raw = rng.bytes(96 * N)
+    xs = [int.from_bytes(raw[96 * i:96 * i + 96], "little") % Q for i in range(N)]
+    p = ctx.NewPoly(1).set(np.array([[x % q for x in xs] for q in moduli], dtype=np.uint64)[None])
+    s.Scale(p, p)
+    got = p.get().reshape(len(moduli), N)[0]
+    want = np.array([int(Fraction(2 * t * x + Q, 2 * Q)) % t for x in xs], dtype=np.uint64)
+    assert np.array_equal(got, want)
