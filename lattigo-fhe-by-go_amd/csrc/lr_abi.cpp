@@ -111,7 +111,7 @@ struct DevModup {
     u64 *Q = nullptr, *mredQ = nullptr, *qib = nullptr, *P = nullptr, *mredP = nullptr, *bredP_hi = nullptr,
         *qispj = nullptr, *qpj_inv = nullptr;
     ulonglong2 *qispj_shoup = nullptr;
-    int lazy_terms = 0, exact_terms = 0;
+    int lazy_terms = 0, exact_terms = 0, word_barrett = 0;
     int init(const std::vector<u64> &Qv, const std::vector<u64> &Pv) {
         h = build_modup(Qv, Pv);
         std::vector<u64> bh(h.P.size());
@@ -137,6 +137,8 @@ struct DevModup {
         const u128 room = ((u128)1 << 64) - pmax;
         lazy_terms = (int)std::min<u128>(room / ((u128)5 * pmax), 1 << 20);   // 4p per term + p per unit of the correction v <= terms
         exact_terms = (int)std::min<u128>(room / ((u128)2 * pmax), 1 << 20);
+        word_barrett = 1;
+        for (size_t j = 0; j < nP; ++j) word_barrett &= (h.P[j] >> 32) != 0 && h.P[j] != ((u64)1 << 32) ? 1 : 0;
         return LR_OK;
     }
     ExtTables tables() const {
@@ -148,6 +150,7 @@ struct DevModup {
         t.qispj_shoup = qispj_shoup;
         t.lazy_terms = lazy_terms;
         t.exact_terms = exact_terms;
+        t.word_barrett = word_barrett;
         return t;
     }
     ~DevModup() {

@@ -122,6 +122,132 @@ __global__ __launch_bounds__(256) void ext_shoup_kernel(ExtLaunch L) {
     }
 }
 
+// The lazy case once more, with the quotient taken once per output instead of once per term:
+//   sum_i (y_i*c_ij - qhat_i*p_j) + v*qpjInv[j][1]  ==  sum_i y_i*c_ij  -  (sum_i qhat_i)*p_j  +  v*qpjInv[j][1]   (mod 2^64)
+// and the left side is below 2^64 (the host admits the lazy path only then), so the value -- and with it the canonical
+// residue bred_add returns -- is the one ext_shoup_kernel<NIN, 0, W> computes.  The low 64 bits of every product are
+// gathered in two multiply-accumulate chains (`lo`: the 2^0 column with its carries; `hi`: the 2^32 column, of which only
+// the low word is kept), the quotient estimates in a third and a fourth: 7 VALU instructions per term instead of about 28.
+// The quotient sum falls short of sum_i floor(y_i*c_ij / p_j) by fewer than 3*NIN + NIN/8 + 2, so the value stays below
+// (4*NIN + NIN/8 + 2) * p_j <= 5*NIN*p_j for NIN >= 2, the room the host checks (ExtTables::lazy_terms).
+// multiply-accumulate steps spelled out, so that every one is a single v_mad_u64_u32 whatever part of the result is used
+// later (left to itself the compiler narrows the `hi` chain to v_mul_lo_u32 + v_add3_u32 and widens the quotient sums to
+// add / add-with-carry pairs): c = wave-uniform table word (SGPR), y = per-lane word
+__device__ __forceinline__ u64 mad_word(u32 c, u32 y, u64 acc) {
+    u64 d, carry;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(d), "=s"(carry) : "s"(c), "v"(y), "v"(acc));
+    return d;
+}
+__device__ __forceinline__ u64 mad_word_vv(u32 a, u32 y, u64 acc) {
+    u64 d, carry;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(d), "=s"(carry) : "v"(a), "v"(y), "v"(acc));
+    return d;
+}
+// acc + floor(c * y / 2^32): v_mul_hi_u32, then x * 1 + acc
+__device__ __forceinline__ u64 mad_hi_word(u32 c, u32 y, u64 acc) {
+    const u32 h = __umulhi(c, y);
+    u64 d, carry;
+    asm("v_mad_u64_u32 %0, %1, %2, 1, %3" : "=v"(d), "=s"(carry) : "v"(h), "v"(acc));
+    return d;
+}
+
+// x - c if that does not borrow, else x (the borrow of the subtraction is the select mask: 4 instructions)
+__device__ __forceinline__ u64 csub_borrow(u64 x, u64 c) {
+    u64 t;
+    const bool borrow = __builtin_usubl_overflow(x, c, &t);
+    return borrow ? x : t;
+}
+
+// canonical residue of x modulo p for p > 2^32 and floor(x / p) < 2^32, with a one-word quotient estimate: u = floor(2^64 / p)
+// fits a word, qe = floor((x >> 32) * u / 2^32) is below floor(x / p) by at most 3 (the dropped low word of x is worth less than
+// one p, u is short of 2^64 / p by less than one, the floor by one more), so x - qe * p lies in [0, 4p)
+__device__ __forceinline__ u64 bred_word(u64 x, u64 p, u64 p2, u32 u) {
+    const u32 qe = __umulhi((u32)(x >> 32), u);
+    const u64 r = x - (u64)qe * p;
+    return csub_borrow(csub_borrow(r, p2), p);
+}
+
+template <int NIN, int W>
+__global__ __launch_bounds__(256) void ext_sum_kernel(ExtLaunch L) {
+    const int xw = blockIdx.x * 256 + threadIdx.x;
+    if (W * xw >= L.n) return;
+    const long long b = blockIdx.y;
+    const u64 *in = L.in + b * L.in_stride + (long long)L.in_limb0 * L.n + W * xw;
+    u32 y0[W][NIN], y1[W][NIN];
+    double vf[W];
+#pragma unroll
+    for (int w = 0; w < W; ++w) vf[w] = 0.0;
+#pragma unroll
+    for (int i = 0; i < NIN; ++i) {
+        const u64 qi = L.t.Q[i];
+        u64 v[W];
+        if (W == 2) {
+            const ulonglong2 t = ld_stream(reinterpret_cast<const ulonglong2 *>(in + (long long)i * L.n));
+            v[0] = t.x;
+            v[W - 1] = t.y;
+        } else {
+            v[0] = ld_stream(in + (long long)i * L.n);
+        }
+#pragma unroll
+        for (int w = 0; w < W; ++w) {
+            const u64 y = mred(v[w], L.t.qib_mont[i], qi, L.t.mredQ[i]);
+            vf[w] += (double)y / (double)qi;
+            y0[w][i] = (u32)y;
+            y1[w][i] = (u32)(y >> 32);
+        }
+    }
+    u32 vi[W];
+#pragma unroll
+    for (int w = 0; w < W; ++w) vi[w] = (u32)(u64)vf[w];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const ExtSegment sg = L.seg[s];
+        u64 *out = sg.out + b * sg.stride + (long long)sg.limb0 * L.n + W * xw;
+        for (int jj = 0; jj < sg.count; ++jj) {
+            const int col = sg.col0 + jj;
+            const u64 pj = ld_const(L.t.P + col), bh = ld_const(L.t.bredP_hi + col);
+            const u64 nq = ld_const(L.t.qpj_inv + (long long)col * (L.t.nQ + 1) + 1);
+            u64 lo[W], hi[W], qs[W], xs[W];
+#pragma unroll
+            for (int w = 0; w < W; ++w) lo[w] = hi[w] = qs[w] = xs[w] = 0;
+#pragma unroll
+            for (int i = 0; i < NIN; ++i) {
+                const ulonglong2 c = ld_const(L.t.qispj_shoup + (long long)i * L.t.nP + col);
+                const u32 w0 = (u32)c.x, w1 = (u32)(c.x >> 32), s0 = (u32)c.y, s1 = (u32)(c.y >> 32);
+#pragma unroll
+                for (int w = 0; w < W; ++w) {
+                    lo[w] = mad_word(w0, y0[w][i], lo[w]);
+                    hi[w] = mad_word(w1, y0[w][i], hi[w]);
+                    hi[w] = mad_word(w0, y1[w][i], hi[w]);
+                    qs[w] = mad_word(s1, y1[w][i], qs[w]);
+                    // y1 < 2^29 (every q_i < 2^61): eight of these products fit one 64-bit sum, whose high word joins the quotient
+                    xs[w] = mad_word(s0, y1[w][i], xs[w]);
+                    if ((i & 7) == 7 || i == NIN - 1) {
+                        qs[w] += xs[w] >> 32;
+                        xs[w] = 0;
+                    }
+                    qs[w] = mad_hi_word(s1, y0[w][i], qs[w]);
+                }
+            }
+            const u64 np = 0 - pj;
+            const u32 n0 = (u32)np, n1 = (u32)(np >> 32), c0 = (u32)nq, c1 = (u32)(nq >> 32);
+            u64 r[W];
+#pragma unroll
+            for (int w = 0; w < W; ++w) {
+                const u32 h0 = (u32)qs[w], h1 = (u32)(qs[w] >> 32);
+                lo[w] = mad_word(n0, h0, lo[w]);
+                hi[w] = mad_word(n1, h0, hi[w]);
+                hi[w] = mad_word(n0, h1, hi[w]);
+                lo[w] = mad_word(c0, vi[w], lo[w]);
+                hi[w] = mad_word(c1, vi[w], hi[w]);
+                r[w] = bred_word(lo[w] + (hi[w] << 32), pj, pj << 1, (u32)bh);
+            }
+            if (W == 2) st_stream(reinterpret_cast<ulonglong2 *>(out + (long long)jj * L.n), make_ulonglong2(r[0], r[W - 1]));
+            else st_stream(out + (long long)jj * L.n, r[0]);
+        }
+    }
+}
+
 template <int NIN>
 static hipError_t launch_n(const ExtLaunch &L, int batch, hipStream_t stream) {
     (void)hipGetLastError();  // drop stale (non-sticky) errors of unrelated earlier calls
@@ -129,7 +255,8 @@ static hipError_t launch_n(const ExtLaunch &L, int batch, hipStream_t stream) {
         // two coefficients per thread while their y_i fit comfortably in registers
         constexpr int W = NIN <= 20 ? 2 : 1;
         const dim3 grid((unsigned)((L.n / W + 255) / 256), (unsigned)batch), block(256);
-        if (L.t.lazy_terms >= NIN) hipLaunchKernelGGL((ext_shoup_kernel<NIN, 0, W>), grid, block, 0, stream, L);
+        if (L.t.lazy_terms >= (NIN < 2 ? 2 : NIN) && L.t.word_barrett) hipLaunchKernelGGL((ext_sum_kernel<NIN, W>), grid, block, 0, stream, L);
+        else if (L.t.lazy_terms >= NIN) hipLaunchKernelGGL((ext_shoup_kernel<NIN, 0, W>), grid, block, 0, stream, L);
         else if (L.t.exact_terms >= 8) hipLaunchKernelGGL((ext_shoup_kernel<NIN, 7, W>), grid, block, 0, stream, L);
         else hipLaunchKernelGGL((ext_shoup_kernel<NIN, 3, W>), grid, block, 0, stream, L);
         return hipGetLastError();
