@@ -17,17 +17,28 @@ generation time inside a pass and applied unconditionally on the first stage of 
 """
 import sys
 
-from gen_ntt import T, Gen, kernel_text_for
-from isa import s, v
+from gen_ntt import T, Dual, Gen, kernel_text_for
+from isa import Neg, s, v
 
 
 class GenInv(Gen):
     """mode 1: every modulus in (2^33, 2^60], bound B = 8q as described above;
        mode 0: moduli up to 2^61: B = 4q and every butterfly corrects."""
 
-    def __init__(self, logn, mode=1, threads=1024, sub=False):
+    def __init__(self, logn, mode=1, threads=1024, sub=False, fp=False, dual=False):
         assert mode in (0, 1)
-        super().__init__(logn, mode, threads, sub)
+        super().__init__(logn, mode, threads, sub, fp=fp, dual=dual)
+        # FP64 body: inputs below 2^52 (the contract is < 4q, q < 2^46).  A Gentleman-Sande stage doubles the bound of its
+        # sums; products come back within q.  With B the bound in units of q (4 on entry), a stage needs B <= 16 (|U - V| <=
+        # 2^51 keeps the quotient estimate within one); the sums of the stage that would leave B = 32 are reduced to q/2.
+        self.fp_reduce = set()
+        bound = 4
+        for g in range(logn):
+            bound *= 2
+            if bound > 16:
+                self.fp_reduce.add(g)
+                bound = 1
+        self.stage_base = 0
         self.Q8 = self.Q4                       # s[18:19] holds the bound B here
         self.NQ2 = s(22, 2)                     # -2q (the Barrett constant is not used by the inverse)
         self.LP = s(0, 2)                       # LimbParams pointer (kernarg pointer is dead after the prologue)
@@ -64,8 +75,25 @@ class GenInv(Gen):
                 ("v_sub_co_u32", V.lo(), ts.CY, ts.R.lo(), V.lo()),
                 ("v_subb_co_u32", V.hi(), ts.CY, ts.R.hi(), V.hi(), ts.CY)]
 
+    def ops_butterfly_gs_fp(self, ts, U, V, tw, reduce):
+        ops = [("v_add_f64", ts.T23, U, Neg(V)),
+               ("v_add_f64", U, U, V)]
+        ops += self.ops_modmul_fp(ts, ts.T23, tw, dst=V)
+        if reduce:
+            ops += [("v_mul_f64", ts.T01, U, self.QINV),
+                    ("v_rndne_f64", ts.T01, ts.T01),
+                    ("v_fma_f64", U, Neg(ts.T01), self.QD, U)]
+        return ops
+
+    def ops_ingest_small(self, ts, X):
+        """an integer below 2^52 -> the same value as a double: 2^52 + x has x as its mantissa"""
+        return [("v_or_b32", X.hi(), 0x43300000, X.hi()),
+                ("v_add_f64", X, X, Neg(self.MAGIC))]
+
     def ops_butterfly(self, ts, U, V, tw, correct):
         """(U, V) <- (U + V [- 8q], (U + 8q - V) * w)"""
+        if self.fp:
+            return self.ops_butterfly_gs_fp(ts, U, V, tw, correct)
         ops = self.ops_sum_diff(ts, U, V)
         mm = self.ops_modmul_inplace(ts, V, tw)
         if correct:
@@ -94,6 +122,10 @@ class GenInv(Gen):
 
     def ops_last(self, ts, U, V, tw_n, tw_wn):
         """last stage fused with the scaling: canonical (U+V)*N^-1 and (U-V)*psi_inv[1]*N^-1"""
+        if self.fp:
+            return ([("v_add_f64", ts.T23, U, Neg(V)), ("v_add_f64", U, U, V)]
+                    + self.ops_modmul_fp(ts, U, tw_n, dst=U) + self.ops_modmul_fp(ts, ts.T23, tw_wn, dst=V)
+                    + self.ops_canon_fp(ts, U) + self.ops_canon_fp(ts, V))
         ops = self.ops_sum_diff(ts, U, V)
         ops += self.ops_modmul_inplace(ts, U, tw_n)
         ops += self.ops_modmul_inplace(ts, V, tw_wn)
@@ -103,6 +135,8 @@ class GenInv(Gen):
 
     def corr(self, b, k0, first_pass=False):
         """does the butterfly over local bit b at position k0 subtract the bound from its sum?"""
+        if self.fp:
+            return (self.stage_base + b) in self.fp_reduce
         if self.mode == 0:
             return True
         if b == 0:
@@ -133,6 +167,20 @@ class GenInv(Gen):
     # ------------------------------------------------------------------ sections
     def prologue_tail(self):
         e = self.e
+        if self.dual:
+            self.mark = len(self.p.ins)
+        if self.fp:
+            e("s_waitcnt", "lgkmcnt(0)")
+            e("s_cmp_eq_u32", self.FPL.sub(1), 0)
+            e("s_cbranch_scc1", "INT_BODY")
+            for ptr, d in ((self.TW, self.DTW), (self.TWF, self.DTWF)):
+                e("s_add_u32", ptr.lo(), ptr.lo(), d.lo())
+                e("s_addc_u32", ptr.hi(), ptr.hi(), d.hi())
+            for i, dst in enumerate((self.QD, self.QINV, self.NINV, self.NINVQ)):
+                e("s_mov_b64", dst, self.FPL.sub(2 * i, 2))
+            e("s_mov_b32", self.MAGIC.lo(), 0)
+            e("s_mov_b32", self.MAGIC.hi(), 0x43300000)
+            return
         e("s_waitcnt", "lgkmcnt(0)")
         e("s_mov_b64", self.Qm, s(68, 2))
         e("s_sub_u32", self.NQ.lo(), 0, self.Qm.lo())
@@ -203,6 +251,9 @@ class GenInv(Gen):
         for k in range(0, 16, 2):
             e("ds_read_b128", v(2 * k, 4), a0, offset=8 * k)
         e("s_waitcnt", "lgkmcnt(0)")
+        self.stage_base = 0
+        if self.fp:
+            self.zip_emit([(lambda ts, x=y: self.ops_ingest_small(ts, x)) for y in Y])
         for b in range(4):
             c = 3 - b
             js = list(range(1 << c))
@@ -237,6 +288,7 @@ class GenInv(Gen):
             e("ds_read_b64", YA[k], a0, offset=k * 144)
         for k in range(8):
             e("ds_read_b64", YB[k], a0, offset=k * 144 + 4608)
+        self.stage_base = 4
         for tag, Y, off in (("a", YA, 0), ("b", YB, 4608)):
             first = [True]
 
@@ -267,6 +319,7 @@ class GenInv(Gen):
             e("ds_read_b64", YB[k], a0, offset=k * 1152 + 576)
         twf = lambda c, j: tuple(s(self.PB + (0, 8, 16)[c] + 4 * j + i) for i in range(4))
         e("s_waitcnt", "lgkmcnt(8)")
+        self.stage_base = 7
         self.gs_group(YA, 3, twf, False)
         for k in range(8):
             e("ds_write_b64", a0, YA[k], offset=k * 1152)
@@ -333,6 +386,7 @@ class GenInv(Gen):
         X = self.X
         plan = self.plan
         nchunks = len(plan)
+        self.stage_base = 10
         # chunks 0 and 1 were requested during the last half's LDS phase
         for n in range(nchunks):
             item = plan[n]
@@ -371,6 +425,8 @@ class GenInv(Gen):
             else:
                 # LimbParams: n_inv at dwords 10..11, its Shoup companion at 12..13
                 tw_n = (s(buf + 10), s(buf + 11), s(buf + 12), s(buf + 13))
+                if self.fp:
+                    tw_n = (self.NINV.lo(), self.NINV.hi(), self.NINVQ.lo(), self.NINVQ.hi())
                 tw_wn = tuple(s(self.low_buf + i) for i in range(4))
                 b = A - 1
                 items = []
@@ -385,6 +441,9 @@ class GenInv(Gen):
         e("v_lshlrev_b32", self.GOFF, 3, self.TID)
         if self.C > 1:
             e("v_add_u32", self.A_[2], 4096, self.GOFF)
+        if self.fp and self.sub:
+            # ntt_top_kernel continues on integers: canonical residues
+            self.zip_emit([(lambda ts, x=x: self.ops_canon_fp(ts, x)) for x in self.X])
         for k in range(self.RA):
             for col in range(self.C):
                 off, imm = self.col_addr(col)
@@ -427,8 +486,14 @@ if __name__ == "__main__":
         sys.exit(0 if selftest(logn, int(sys.argv[3]) if len(sys.argv) > 3 else 1024) else 1)
     mode = int(sys.argv[3]) if len(sys.argv) > 3 else 1
     threads = int(sys.argv[4]) if len(sys.argv) > 4 else 1024
+    # mode 3: FP64 body for the limbs below 2^46, the integer body of mode 1 for the others
+    def make(logn_, threads_, **kw):
+        if mode == 3:
+            return Dual(lambda fp: GenInv(logn_, 1, threads_, fp=fp, dual=True, **kw))
+        return GenInv(logn_, mode, threads_, **kw)
+
     if logn == 16:
-        open(sys.argv[2], "w").write(kernel_text_for(GenInv(15, mode, 1024, sub=True), "lr_ntt_inv16s_m%d" % mode))
+        open(sys.argv[2], "w").write(kernel_text_for(make(15, 1024, sub=True), "lr_ntt_inv16s_m%d" % mode))
         sys.exit(0)
     name = "lr_ntt_inv%d%s_m%d" % (logn, "x" if threads < 1024 else "", mode)
-    open(sys.argv[2], "w").write(kernel_text_for(GenInv(logn, mode, threads), name))
+    open(sys.argv[2], "w").write(kernel_text_for(make(logn, threads), name))

@@ -16,7 +16,7 @@ the context's largest modulus allows and falls back to the C++ kernels for small
 """
 import sys
 
-from isa import VCC, Program, s, v
+from isa import VCC, Neg, Program, Reg, s, v
 
 T = 1024
 LOGT = 10
@@ -28,8 +28,14 @@ class Gen:
          2: q <  2^57, no corrections at all (15 stages x 4q of growth stay below 2^64);
          0: q <  2^61, U <- U - 4q (if U >= 4q) before every stage."""
 
-    def __init__(self, logn, mode=1, threads=1024, sub=False, fused=True):
+    def __init__(self, logn, mode=1, threads=1024, sub=False, fused=True, fp=False, dual=False):
         assert logn in (12, 13, 14, 15) and mode in (0, 1, 2) and threads in (256, 512, 1024)
+        # dual: the kernel carries two bodies behind one prologue (class Dual): `fp` = the FP64 body for moduli below 2^46
+        # (error-free products by v_mul_f64 / v_fma_f64, quotients by v_rndne_f64, no lazy corrections: 8 instructions per
+        # butterfly), otherwise the integer body of `mode`; the workgroup picks by its limb's entry in NttLaunch::fp_lp
+        assert not fp or dual
+        self.fp, self.dual = fp, dual
+        self.mark = None
         assert not sub or (logn == 15 and threads == 1024)
         self.fused = fused            # forward sub-block kernels: compute the top stage while loading (out of place only)
         # sub: the kernel transforms one 2^15 half ("sub-block" blk = workgroup x & 1) of an N = 2^16 limb; twiddles come
@@ -95,6 +101,14 @@ class Gen:
         self.JUNK = s(32, 2)
         self.TMP = s(34, 2)
         self.PB, self.QB = 36, 68                     # two 32-dword twiddle buffers
+        # dual kernels: table deltas (FP table - integer table, bytes), FP constants of the limb
+        # (loaded into s[84:95], inside the second twiddle buffer; the FP body moves what it keeps into the registers
+        # that hold the integer body's constants)
+        self.DTW, self.DTWF = s(84, 2), s(86, 2)
+        self.FPL = s(88, 8)                           # FpLimb: q, 1/q, N^-1 mod q, N^-1 / q as doubles (lr_device.hpp)
+        self.QD, self.QINV = s(14, 2), s(16, 2)
+        self.MAGIC = s(18, 2)                         # 2^52
+        self.NINV, self.NINVQ = s(20, 2), s(22, 2)
 
     # ------------------------------------------------------------------ emission helpers
     def e(self, op, *args, **mods):
@@ -145,10 +159,59 @@ class Gen:
     # ------------------------------------------------------------------ arithmetic macros
     # Each macro returns a list of instructions for one temp set; `zip_emit` interleaves the lists of two
     # independent items so that consecutive instructions of a wave rarely depend on each other.
+    @staticmethod
+    def pair(r):
+        assert r.idx % 2 == 0
+        return Reg(r.kind, r.idx, 2)
+
+    # ---- FP64 body.  Values are integer-valued doubles, |x| < 2^50 throughout (q < 2^46: a product term is at most
+    # 0.67q in magnitude, 16 stages add at most 11q to the 2^32 + q/2 the ingest leaves), so every sum is exact; a
+    # twiddle is the pair (w, RN(w/q)) of doubles.  r = V*w - rint(V * (w/q)) * q: h = RN(V*w), l = V*w - h (exact, fma),
+    # h - b*q is an integer below 2^51 in magnitude (exact, fma), r = (h - b*q) + l.
+    def ops_modmul_fp(self, ts, V, tw, dst=None):
+        """dst (default ts.Q) <- V*w mod q, centred (|.| <= q for |V| <= 2^51, <= 0.67q for |V| < 2^50); dst may be V"""
+        W, WQ = self.pair(tw[0]), self.pair(tw[2])
+        return [("v_mul_f64", ts.Q, V, W),
+                ("v_mul_f64", ts.R, V, WQ),
+                ("v_fma_f64", ts.C, V, W, Neg(ts.Q)),
+                ("v_rndne_f64", ts.R, ts.R),
+                ("v_fma_f64", ts.Q, Neg(ts.R), self.QD, ts.Q),
+                ("v_add_f64", dst or ts.Q, ts.Q, ts.C)]
+
+    def ops_butterfly_fp(self, ts, U, V, tw):
+        return self.ops_modmul_fp(ts, V, tw) + [("v_add_f64", V, U, Neg(ts.Q)),
+                                                ("v_add_f64", U, U, ts.Q)]
+
+    def ops_ingest(self, ts, X):
+        """any 64-bit integer -> an integer-valued double congruent to it, |.| <= q/2 + 2^32:
+        hi * 2^32 is reduced with the quotient trick (exact: a multiple of 2^32 below 2^64), the low word is added"""
+        return [("v_cvt_f64_u32", ts.Q, X.hi()),
+                ("v_cvt_f64_u32", ts.C, X.lo()),
+                ("v_ldexp_f64", ts.Q, ts.Q, 32),
+                ("v_mul_f64", ts.R, ts.Q, self.QINV),
+                ("v_rndne_f64", ts.R, ts.R),
+                ("v_fma_f64", ts.Q, Neg(ts.R), self.QD, ts.Q),
+                ("v_add_f64", X, ts.Q, ts.C)]
+
+    def ops_canon_fp(self, ts, X):
+        """integer-valued double -> canonical residue as a 64-bit integer: centred remainder, + q if negative, then the
+        mantissa of 2^52 + y is y"""
+        return [("v_mul_f64", ts.R, X, self.QINV),
+                ("v_rndne_f64", ts.R, ts.R),
+                ("v_fma_f64", X, Neg(ts.R), self.QD, X),
+                ("v_ashrrev_i32", ts.T0, 31, X.hi()),
+                ("v_and_b32", ts.C.lo(), self.QD.lo(), ts.T0),
+                ("v_and_b32", ts.C.hi(), self.QD.hi(), ts.T0),
+                ("v_add_f64", X, X, ts.C),
+                ("v_add_f64", X, X, self.MAGIC),
+                ("v_and_b32", X.hi(), 0xFFFFF, X.hi())]
+
     def ops_butterfly(self, ts, U, V, tw, correct):
         """(U, V) <- (U + r, U + 4q - r), r = V*w - qhat*q in [0,4q); optional U <- U - 8q if U >= 8q first.
         The product accumulates straight onto U (X = U + r costs nothing) and Y = (2U + 4q) - X; all of it
         modulo 2^64, exact because the true X and Y are below 2^64."""
+        if self.fp:
+            return self.ops_butterfly_fp(ts, U, V, tw)
         w0, w1, s0, s1 = tw
         J = self.JUNK
         ops = []
@@ -191,6 +254,8 @@ class Gen:
 
     def ops_canon(self, ts, X):
         """X in [0, 16q) -> canonical [0, q)."""
+        if self.fp:
+            return self.ops_canon_fp(ts, X)
         D = ts.C
         return self.ops_reduce_2q(ts, X) + [
             ("v_lshl_add_u64", D, X, 0, self.NQ),
@@ -227,12 +292,15 @@ class Gen:
     def prologue(self):
         e, S_ = self.e, self
         logn, N = self.logn, self.N
-        self.c("kernel arguments (NttLaunch, 104 bytes)")
+        self.c("kernel arguments (NttLaunch, 128 bytes)")
         e("s_load_dwordx8", s(36, 8), self.KARG, 0)
         e("s_load_dwordx8", s(44, 8), self.KARG, 32)
         e("s_load_dwordx4", s(52, 4), self.KARG, 64)
         e("s_load_dwordx2", s(56, 2), self.KARG, 80)
         e("s_load_dwordx4", s(60, 4), self.KARG, 88)      # sub_log (must be 0 here), hole, group, pad
+        if self.dual:
+            e("s_load_dwordx4", s(84, 4), self.KARG, 104)     # fp_tw_delta, fp_fin_delta
+            e("s_load_dwordx2", s(92, 2), self.KARG, 120)     # fp_lp
         e("v_mov_b32", self.TID, v(0))
         for ts in self.ts:
             e("v_mov_b32", ts.Z1, 0)
@@ -279,6 +347,13 @@ class Gen:
         e("s_add_u32", self.TMP.lo(), s(52), sc[3])
         e("s_addc_u32", self.TMP.hi(), s(53), 0)
         e("s_load_dwordx16", s(68, 16), self.TMP, 0)
+        if self.dual:
+            # FpLimb (32 bytes) of this modulus: q = 0.0 marks a limb the FP body does not take
+            e("s_lshl_b32", sc[3], sc[0], 5)
+            e("s_add_u32", self.TMP.lo(), s(92), sc[3])
+            e("s_addc_u32", self.TMP.hi(), s(93), 0)
+            e("s_load_dwordx4", s(88, 4), self.TMP, 0)
+            e("s_load_dwordx4", s(92, 4), self.TMP, 16)
         # twiddle table bases
         e("s_mul_i32", sc[3], sc[0], self.NFULL * 16)
         e("s_add_u32", self.TW.lo(), s(54), sc[3])
@@ -322,6 +397,8 @@ class Gen:
 
     def ops_mulacc(self, ts, U, V, tw):
         """U <- U + (V*w - qhat*q), the product in [0,4q) for any 64-bit V"""
+        if self.fp:
+            return self.ops_modmul_fp(ts, V, tw) + [("v_add_f64", U, U, ts.Q)]
         w0, w1, s0, s1 = tw
         J = self.JUNK
         return [("v_mul_hi_u32", ts.T0, V.hi(), s0),
@@ -359,16 +436,37 @@ class Gen:
 
         v_loads()
         self.constants()
+        if self.fp:
+            e("s_load_dwordx4", s(96, 4), self.TW, self.SC[3])     # the same entry of the FP table
+            e("s_waitcnt", "lgkmcnt(0)")
         for chunk in range(2):
             for i in range(0, 16, 2):
                 e("s_waitcnt", "vmcnt(%d)" % (14 - i))
-                self.zip_emit([(lambda ts, U=self.X[16 * chunk + i + d], Vr=V[i + d]:
-                                self.ops_reduce_2q(ts, U) + self.ops_mulacc(ts, U, Vr, W1)) for d in range(2)])
+                if self.fp:
+                    self.zip_emit([(lambda ts, U=self.X[16 * chunk + i + d], Vr=V[i + d]:
+                                    self.ops_ingest(ts, U) + self.ops_ingest(ts, Vr) + self.ops_mulacc(ts, U, Vr, W1)) for d in range(2)])
+                else:
+                    self.zip_emit([(lambda ts, U=self.X[16 * chunk + i + d], Vr=V[i + d]:
+                                    self.ops_reduce_2q(ts, U) + self.ops_mulacc(ts, U, Vr, W1)) for d in range(2)])
             if chunk == 0:
                 v_loads()
 
     def constants(self):
         e = self.e
+        if self.dual:
+            self.mark = len(self.p.ins)               # everything before this point is common to the two bodies
+        if self.fp:
+            e("s_waitcnt", "lgkmcnt(0)")
+            e("s_cmp_eq_u32", self.FPL.sub(1), 0)
+            e("s_cbranch_scc1", "INT_BODY")
+            for i, dst in enumerate((self.QD, self.QINV, self.NINV, self.NINVQ)):
+                e("s_mov_b64", dst, self.FPL.sub(2 * i, 2))
+            for ptr, d in ((self.TW, self.DTW), (self.TWF, self.DTWF)):
+                e("s_add_u32", ptr.lo(), ptr.lo(), d.lo())
+                e("s_addc_u32", ptr.hi(), ptr.hi(), d.hi())
+            e("s_mov_b32", self.MAGIC.lo(), 0)
+            e("s_mov_b32", self.MAGIC.hi(), 0x43300000)
+            return
         e("s_waitcnt", "lgkmcnt(0)")
         e("s_mov_b64", self.Qm, s(68, 2))
         e("s_mov_b32", self.U0, s(72))                # low word of bred_hi = floor(2^64 / q)
@@ -454,7 +552,11 @@ class Gen:
                     for i in range(0, len(blist), 2):
                         e("s_waitcnt", "vmcnt(%d)" % max(self.NX - 2 * (i + 2), 0))
                         # first-stage U operands: any 64-bit value is accepted
-                        self.zip_emit([(lambda ts, x=blist[i + d][0]: self.ops_reduce_2q(ts, x)) for d in range(2)])
+                        if self.fp:
+                            if not (self.sub and self.fused):     # (the fused top stage has converted its operands)
+                                self.zip_emit([(lambda ts, x=blist[i + d][k]: self.ops_ingest(ts, x)) for d in range(2) for k in range(2)])
+                        else:
+                            self.zip_emit([(lambda ts, x=blist[i + d][0]: self.ops_reduce_2q(ts, x)) for d in range(2)])
                         self.butterflies(blist[i:i + 2])
                 else:
                     pend.extend(blist)
@@ -739,6 +841,28 @@ class Gen:
         return self.p
 
 
+class Dual:
+    """two bodies behind one prologue: FP64 for limbs whose FpLimb entry is set, the integer body otherwise"""
+
+    def __init__(self, make):
+        self.gf, self.gi = make(True), make(False)
+        for k in ("logn", "T", "SPH", "A", "N", "sub"):
+            setattr(self, k, getattr(self.gf, k))
+        self.p = None
+
+    def build(self):
+        pf, pi = self.gf.build(), self.gi.build()
+        mf, mi = self.gf.mark, self.gi.mark
+        assert mf is not None and mf == mi and repr(pf.ins[:mf]) == repr(pi.ins[:mi]), "the two bodies must share their prologue"
+        assert not any(op == "@" for op, _, _ in pf.ins + pi.ins)
+        p = Program()
+        p.ins = list(pf.ins)
+        p.label("INT_BODY")
+        p.ins += pi.ins[mi:]
+        self.p = p
+        return p
+
+
 def kernel_text(logn, name):
     g = Gen(logn)
     return kernel_text_for(g, name), g, g.p
@@ -760,7 +884,7 @@ def kernel_text_for(g, name):
   .amdhsa_kernel {name}
     .amdhsa_group_segment_fixed_size {lds}
     .amdhsa_private_segment_fixed_size 0
-    .amdhsa_kernarg_size 104
+    .amdhsa_kernarg_size 128
     .amdhsa_user_sgpr_count 2
     .amdhsa_user_sgpr_kernarg_segment_ptr 1
     .amdhsa_system_sgpr_workgroup_id_x 1
@@ -783,11 +907,11 @@ def kernel_text_for(g, name):
 amdhsa.kernels:
   - .args:
       - .offset: 0
-        .size: 104
+        .size: 128
         .value_kind: by_value
     .group_segment_fixed_size: {lds}
     .kernarg_segment_align: 8
-    .kernarg_segment_size: 104
+    .kernarg_segment_size: 128
     .max_flat_workgroup_size: {threads}
     .name: {name}
     .private_segment_fixed_size: 0
@@ -868,12 +992,17 @@ def emulate(gen, inverse=False, q=None, geom=None):
     A_LP = A_OUT + span
     A_TW = A_LP + 0x1000
     A_TWF = A_TW + 16 * N + 0x1000
-    mem = np.zeros((A_TWF + 16 * 15 * blocks + 0x1000) // 4, dtype=np.uint32)
+    A_FTW = A_TWF + 16 * 15 * blocks + 0x1000
+    A_FTWF = A_FTW + 16 * N + 0x1000
+    A_FLP = A_FTWF + 16 * 15 * blocks + 0x1000
+    mem = np.zeros((A_FLP + 0x1000) // 4, dtype=np.uint32)
     place(x, A_IN + where)
     place(lp, A_LP)
     place(tw, A_TW)
     place(twf, A_TWF)
-    karg = np.zeros(13, dtype=np.uint64)
+    fp_tables(np, q, n_inv, tw, twf, lambda a, b, c: (place(a, A_FTW), place(b, A_FTWF), place(c, A_FLP)))
+    karg = np.zeros(16, dtype=np.uint64)
+    karg[13], karg[14], karg[15] = A_FTW - A_TW, A_FTWF - A_TWF, A_FLP
     karg[0], karg[1], karg[2], karg[3] = A_IN, A_OUT, rows * N, rows * N
     karg[4] = 0 | (1 << 32)        # in_limb0, in_limb_step
     karg[5] = 0 | (1 << 32)        # out_limb0, out_limb_step
@@ -899,11 +1028,35 @@ def emulate(gen, inverse=False, q=None, geom=None):
     valu = sum(n for op, n in cnt.items() if op.startswith("v_"))
     bf = (1 << gen.A) * logn // 2
     info = "%d instructions, %d VALU = %.1f per butterfly, s_nop %d" % (len(prog.ins), valu, valu / bf, cnt.get("s_nop", 0))
+    if getattr(gen, "gf", None) is not None:
+        ran = sum(n for op, n in m.executed.items() if op.startswith("v_"))
+        info = "%s body, %d VALU executed = %.1f per butterfly" % ("FP64" if m.executed.get("v_fma_f64") else "integer", ran, ran / bf)
+        ok = ok and bool(m.executed.get("v_fma_f64")) == (q < FP_LIMIT)
     if not ok:
         bad = np.nonzero(got != want)[0]
         info += "\n  mismatches: %d first: %s %s %s" % (bad.size, bad[:8], [hex(int(got[i])) for i in bad[:3]],
                                                        [hex(int(want[i])) for i in bad[:3]])
     return ok, info
+
+
+FP_LIMIT = 1 << 46
+
+
+def fp_tables(np, q, n_inv, tw, twf, put):
+    """what lr_abi.cpp builds for the FP body: every (w, floor(w 2^64 / q)) becomes the pair of doubles (w, RN(w / q));
+    FpLimb = {q, RN(1/q), N^-1 mod q, RN(N^-1 / q)}, all zero for a modulus the FP body does not take"""
+    def conv(t):
+        w = t[..., 0].astype(np.float64)
+        out = np.zeros(t.shape, dtype=np.float64)
+        out[..., 0] = w
+        out[..., 1] = w / np.float64(q)
+        return out
+    flp = np.zeros(4, dtype=np.float64)
+    if q < FP_LIMIT:
+        flp[:] = [q, np.float64(1.0) / np.float64(q), n_inv, np.float64(n_inv) / np.float64(q)]
+        put(conv(tw), conv(twf), flp)
+    else:
+        put(np.zeros(tw.shape), np.zeros(twf.shape), flp)
 
 
 def test_moduli(logn, mode):
@@ -961,7 +1114,10 @@ def emulate_sub(make_gen, inverse, q, pretop=False):
     A_LP = A_OUT + 8 * NF + 0x1000
     A_TW = A_LP + 0x1000
     A_TWF = A_TW + 16 * NF + 0x1000
-    mem = np.zeros((A_TWF + 16 * 15 * blocks + 0x1000) // 4, dtype=np.uint32)
+    A_FTW = A_TWF + 16 * 15 * blocks + 0x1000
+    A_FTWF = A_FTW + 16 * NF + 0x1000
+    A_FLP = A_FTWF + 16 * 15 * blocks + 0x1000
+    mem = np.zeros((A_FLP + 0x1000) // 4, dtype=np.uint32)
 
     def place(arr, addr):
         words = np.ascontiguousarray(arr).view(np.uint32).ravel()
@@ -977,7 +1133,9 @@ def emulate_sub(make_gen, inverse, q, pretop=False):
     place(lp, A_LP)
     place(tw, A_TW)
     place(twf, A_TWF)
-    karg = np.zeros(13, dtype=np.uint64)
+    fp_tables(np, q, n_inv, tw, twf, lambda a, b, c: (place(a, A_FTW), place(b, A_FTWF), place(c, A_FLP)))
+    karg = np.zeros(16, dtype=np.uint64)
+    karg[13], karg[14], karg[15] = A_FTW - A_TW, A_FTWF - A_TWF, A_FLP
     karg[0], karg[1], karg[2], karg[3] = A_IN, A_OUT, NF, NF
     karg[4] = 0 | (1 << 32)
     karg[5] = 0 | (1 << 32)
@@ -1062,10 +1220,16 @@ if __name__ == "__main__":
         sys.exit(0 if selftest(logn, threads=threads) else 1)
     mode = int(sys.argv[3]) if len(sys.argv) > 3 else 1
     threads = int(sys.argv[4]) if len(sys.argv) > 4 else 1024
+    # mode 3: FP64 body for the limbs below 2^46, the integer body of mode 2 for the others (every modulus below 2^57)
+    def make(logn_, threads_, **kw):
+        if mode == 3:
+            return Dual(lambda fp: Gen(logn_, 2, threads_, fp=fp, dual=True, **kw))
+        return Gen(logn_, mode, threads_, **kw)
+
     if logn == 16:      # the 2^15 sub-block kernels of N = 2^16: "s" with the fused top stage, "p" plain
         fused = not (len(sys.argv) > 5 and sys.argv[5] == "plain")
-        open(sys.argv[2], "w").write(kernel_text_for(Gen(15, mode, 1024, sub=True, fused=fused),
+        open(sys.argv[2], "w").write(kernel_text_for(make(15, 1024, sub=True, fused=fused),
                                                      "lr_ntt_fwd16%s_m%d" % ("s" if fused else "p", mode)))
         sys.exit(0)
     name = "lr_ntt_fwd%d%s_m%d" % (logn, "x" if threads < 1024 else "", mode)     # x: several workgroups per CU
-    open(sys.argv[2], "w").write(kernel_text_for(Gen(logn, mode, threads), name))
+    open(sys.argv[2], "w").write(kernel_text_for(make(logn, threads), name))

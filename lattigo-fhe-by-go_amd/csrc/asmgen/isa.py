@@ -54,6 +54,18 @@ def s(i, n=1):
 VCC = Reg("vcc", 0, 2)
 
 
+class Neg:
+    """floating-point source operand with the VOP3 negate modifier"""
+    __slots__ = ("r",)
+
+    def __init__(self, r):
+        assert isinstance(r, Reg) and r.n == 2
+        self.r = r
+
+    def __repr__(self):
+        return "-" + repr(self.r)
+
+
 class Program:
     def __init__(self):
         self.ins = []
@@ -98,7 +110,7 @@ class Program:
 
 
 def _fmt(a):
-    if isinstance(a, Reg):
+    if isinstance(a, (Reg, Neg)):
         return repr(a)
     if isinstance(a, int):
         return str(a) if -16 <= a <= 64 else hex(a & 0xFFFFFFFF)
@@ -174,6 +186,8 @@ class Machine:
     def _const_bus(self, args):
         n = set()
         for a in args:
+            if isinstance(a, Neg):
+                a = a.r
             if isinstance(a, Reg) and a.kind == "s":
                 n.add(a.idx)
             elif isinstance(a, int) and not (-16 <= a <= 64):
@@ -201,6 +215,7 @@ class Machine:
     def run(self, prog):
         """branches must be workgroup-uniform (the kernels only loop on launch-wide counters)"""
         labels = {args[0]: k for k, (op, args, _) in enumerate(prog.ins) if op == "@"}
+        self.executed = {}
         pc = 0
         with np.errstate(over="ignore"):
             while pc < len(prog.ins):
@@ -215,6 +230,7 @@ class Machine:
                     continue
                 if op == "s_endpgm":
                     break
+                self.executed[op] = self.executed.get(op, 0) + 1
                 getattr(self, "i_" + op)(*args, **mods)
 
     # -- VALU
@@ -296,6 +312,54 @@ class Machine:
 
     def i_v_readfirstlane_b32(self, d, a):
         self.ws(d, self.rv(a).reshape(self.W, WAVE)[:, 0])
+
+    # -- FP64 (IEEE round-to-nearest-even; fma evaluated exactly with rationals, then rounded once)
+    def rf64(self, a):
+        if isinstance(a, Neg):
+            return -self.rf64(a.r)
+        if isinstance(a, Reg):
+            return self.rv64(a).view(np.float64)
+        return np.full(self.T, float(a), dtype=np.float64)   # inline constants 0, 0.5, 1.0, 2.0, 4.0 and small integers
+
+    def wf64(self, d, val):
+        self.wv64(d, np.ascontiguousarray(val, dtype=np.float64).view(np.uint64))
+
+    def i_v_mul_f64(self, d, a, b):
+        self._const_bus((a, b))
+        self.wf64(d, self.rf64(a) * self.rf64(b))
+
+    def i_v_add_f64(self, d, a, b):
+        self._const_bus((a, b))
+        self.wf64(d, self.rf64(a) + self.rf64(b))
+
+    def i_v_fma_f64(self, d, a, b, c):
+        from fractions import Fraction
+        self._const_bus((a, b, c))
+        x, y, z = self.rf64(a), self.rf64(b), self.rf64(c)
+        assert np.all(np.isfinite(x)) and np.all(np.isfinite(y)) and np.all(np.isfinite(z))
+        out = np.empty(self.T, dtype=np.float64)
+        xi, yi, zi = x.astype(object), y.astype(object), z.astype(object)
+        for k in range(self.T):
+            fx, fy, fz = xi[k], yi[k], zi[k]
+            if fx == int(fx) and fy == int(fy) and fz == int(fz):
+                out[k] = float(int(fx) * int(fy) + int(fz))      # int -> float conversion rounds to nearest even
+            else:
+                out[k] = float(Fraction(fx) * Fraction(fy) + Fraction(fz))
+        self.wf64(d, out)
+
+    def i_v_rndne_f64(self, d, a):
+        self.wf64(d, np.rint(self.rf64(a)))
+
+    def i_v_cvt_f64_u32(self, d, a):
+        self.wf64(d, self.rv(a).astype(np.float64))
+
+    def i_v_ldexp_f64(self, d, a, e):
+        assert isinstance(e, int)
+        self.wf64(d, np.ldexp(self.rf64(a), e))
+
+    def i_v_ashrrev_i32(self, d, sh, a):
+        self._const_bus((sh, a))
+        self.wv(d, (self.rv(a).astype(np.int32) >> (self.rv(sh) & np.uint32(31)).astype(np.int32)).astype(np.uint32))
 
     # -- SALU
     def i_s_mov_b32(self, d, a):

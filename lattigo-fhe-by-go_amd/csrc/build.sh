@@ -30,11 +30,19 @@ gen_sub() {  # kind tag mode [plain]
 }
 for m in 0 1 2; do gen_sub fwd 16s $m & gpids+=($!); gen_sub fwd 16p $m plain & gpids+=($!); done
 for m in 0 1; do gen_sub inv 16s $m & gpids+=($!); done
+# dual kernels (mode 3): FP64 body for the limbs below 2^46, integer mode-2 body for the others
+gen_one fwd 14 3 & gpids+=($!); gen_one fwd 15 3 & gpids+=($!)
+gen_one fwd 14 3 512 & gpids+=($!); gen_one fwd 13 3 256 & gpids+=($!); gen_one fwd 12 3 256 & gpids+=($!)
+gen_sub fwd 16s 3 & gpids+=($!); gen_sub fwd 16p 3 plain & gpids+=($!)
+gen_one inv 14 3 & gpids+=($!); gen_one inv 15 3 & gpids+=($!)
+gen_one inv 14 3 512 & gpids+=($!); gen_one inv 13 3 512 & gpids+=($!); gen_one inv 12 3 256 & gpids+=($!)
+gen_sub inv 16s 3 & gpids+=($!)
 for p in "${gpids[@]}"; do wait $p; done
 python3 - <<'PY'
 out = ['struct lr_asm_blob { const char *name; const unsigned char *data; unsigned long size; };']
 names = [("fwd", n, m) for n in (14, 15) for m in (0, 1, 2)] + [("inv", n, m) for n in (14, 15) for m in (0, 1)]
 names += [("fwd", n, m) for n in ("12x", "13x", "14x", "16s", "16p") for m in (0, 1, 2)] + [("inv", n, m) for n in ("12x", "13x", "14x", "16s") for m in (0, 1)]
+names += [("fwd", n, 3) for n in (14, 15, "12x", "13x", "14x", "16s", "16p")] + [("inv", n, 3) for n in (14, 15, "12x", "13x", "14x", "16s")]
 for k, n, m in names:
     data = open("build/ntt_%s%s_m%d.hsaco" % (k, n, m), "rb").read()
     out.append('static const unsigned char blob_%s%s_m%d[] __attribute__((aligned(4096))) = {' % (k, n, m))

@@ -89,6 +89,9 @@ struct lr_context {
     int ntt_mode = 0;           // lazy-correction cadence allowed by the largest modulus (lr_ntt.hip)
     bool use_asm = true;        // hand-scheduled assembly NTT where it applies (LR_NO_ASM=1 disables)
     int asm_fwd = -1, asm_inv = -1;   // variant of the assembly kernels all moduli allow, -1 = none
+    // variant 3 = dual kernels: FP64 body for the limbs below 2^46, integer body (mode 2) for the others
+    Twiddle *d_fwd_fp = nullptr, *d_inv_fp = nullptr, *d_fwd_fin_fp = nullptr, *d_inv_fin_fp = nullptr;
+    FpLimb *d_fp_lp = nullptr;
 };
 
 struct lr_poly {
@@ -281,6 +284,12 @@ extern "C" int lr_context_create(uint64_t N, const uint64_t *moduli, int n_modul
                 if (f == 0) c->asm_inv = 0;
             }
         }
+        // the FP64 body takes any modulus below 2^46; the integer body next to it needs the others in (2^33, 2^57)
+        if (qmin < kFpLimit && qmax < (1ull << 57) && std::getenv("LR_NO_FP") == nullptr && std::getenv("LR_ASM_VARIANT") == nullptr) {
+            bool ok = true;
+            for (u64 q : c->h.q) ok = ok && (q < kFpLimit || q > (1ull << 33));
+            if (ok) c->asm_fwd = c->asm_inv = 3;
+        }
     }
     LR_HIP(hipSetDevice(device));
     c->stream = shared_stream(device);
@@ -326,6 +335,23 @@ extern "C" int lr_context_create(uint64_t N, const uint64_t *moduli, int n_modul
         }
     }
     LR_TRY(to_device(&c->d_lp, lp.data(), lp.size()));
+    const bool fp_tables = c->asm_fwd == 3 || c->asm_inv == 3;
+    // FP64 body: the same table with every (w, floor(w 2^64 / q)) replaced by the doubles (w, RN(w / q)); zero for the other limbs
+    auto to_fp = [&](std::vector<Twiddle> &t, size_t per_limb) {
+        for (int i = 0; i < L; ++i) {
+            const u64 q = c->h.q[i];
+            for (size_t j = 0; j < per_limb; ++j) {
+                Twiddle &e = t[(size_t)i * per_limb + j];
+                if (q < kFpLimit) {
+                    const double w = (double)e.x, wq = w / (double)q;
+                    std::memcpy(&e.x, &w, 8);
+                    std::memcpy(&e.y, &wq, 8);
+                } else {
+                    e = make_ulonglong2(0, 0);
+                }
+            }
+        }
+    };
     if (N >= 4096) {
         const size_t blocks = N >> 4;
         std::vector<Twiddle> ffin((size_t)L * 15 * blocks), ifin((size_t)L * 15 * blocks);
@@ -340,9 +366,27 @@ extern "C" int lr_context_create(uint64_t N, const uint64_t *moduli, int n_modul
                     }
         LR_TRY(to_device(&c->d_fwd_fin, ffin.data(), ffin.size()));
         LR_TRY(to_device(&c->d_inv_fin, ifin.data(), ifin.size()));
+        if (fp_tables) {
+            to_fp(ffin, 15 * blocks);
+            to_fp(ifin, 15 * blocks);
+            LR_TRY(to_device(&c->d_fwd_fin_fp, ffin.data(), ffin.size()));
+            LR_TRY(to_device(&c->d_inv_fin_fp, ifin.data(), ifin.size()));
+        }
     }
     LR_TRY(to_device(&c->d_fwd, fwd.data(), fwd.size()));
     LR_TRY(to_device(&c->d_inv, inv.data(), inv.size()));
+    if (fp_tables) {
+        std::vector<FpLimb> fl(L);
+        for (int i = 0; i < L; ++i) {
+            const u64 q = c->h.q[i];
+            fl[i] = q < kFpLimit ? FpLimb{(double)q, 1.0 / (double)q, (double)lp[i].n_inv, (double)lp[i].n_inv / (double)q} : FpLimb{0.0, 0.0, 0.0, 0.0};
+        }
+        LR_TRY(to_device(&c->d_fp_lp, fl.data(), fl.size()));
+        to_fp(fwd, N);
+        to_fp(inv, N);
+        LR_TRY(to_device(&c->d_fwd_fp, fwd.data(), fwd.size()));
+        LR_TRY(to_device(&c->d_inv_fp, inv.data(), inv.size()));
+    }
     LR_TRY(to_device(&c->d_rescale, c->h.rescale.data(), c->h.rescale.size()));
     *out = c.release();
     return LR_OK;
@@ -352,7 +396,8 @@ extern "C" int lr_context_destroy(lr_context *c) {
     if (!c) return LR_OK;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(shared_stream(c->device));
-    for (void *p : {(void *)c->d_lp, (void *)c->d_fwd, (void *)c->d_inv, (void *)c->d_fwd_fin, (void *)c->d_inv_fin, (void *)c->d_rescale, (void *)c->scratch})
+    for (void *p : {(void *)c->d_lp, (void *)c->d_fwd, (void *)c->d_inv, (void *)c->d_fwd_fin, (void *)c->d_inv_fin, (void *)c->d_rescale, (void *)c->scratch,
+                    (void *)c->d_fwd_fp, (void *)c->d_inv_fp, (void *)c->d_fwd_fin_fp, (void *)c->d_inv_fin_fp, (void *)c->d_fp_lp})
         if (p) (void)hipFree(p);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -633,6 +678,13 @@ int run_ntt(lr_context *c, bool inverse, Rows in, Rows out, int mod0, int mod_st
     a.tw = inverse ? c->d_inv : c->d_fwd;
     a.tw_fin = inverse ? c->d_inv_fin : c->d_fwd_fin;
     const int variant = inverse ? c->asm_inv : c->asm_fwd;
+    a.fp_tw_delta = a.fp_fin_delta = 0;
+    a.fp_lp = nullptr;
+    if (variant == 3) {
+        a.fp_tw_delta = (const char *)(inverse ? c->d_inv_fp : c->d_fwd_fp) - (const char *)a.tw;
+        a.fp_fin_delta = (const char *)(inverse ? c->d_inv_fin_fp : c->d_fwd_fin_fp) - (const char *)a.tw_fin;
+        a.fp_lp = c->d_fp_lp;
+    }
     if (logn == 16 && variant >= 0 && c->use_asm && (hole > 0 ? group : batch) <= 65535 && (hole == 0 || batch / group <= 65535) &&
         ntt_asm_available(16)) {
         // two 2^15 sub-blocks per limb on the assembly kernels + the streaming stage over bit 15

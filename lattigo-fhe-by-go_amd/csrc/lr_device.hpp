@@ -29,6 +29,13 @@ struct LimbScalars { u64 v[kMaxLimbs]; };
 // a twiddle factor in the kernels' internal form: x = psi power (plain domain), y = floor(x*2^64/q)
 typedef ulonglong2 Twiddle;
 
+constexpr u64 kFpLimit = 1ull << 46;
+// per-limb constants of the FP64 butterflies (moduli below 2^46); q = 0.0: the limb stays on the integer body
+struct FpLimb {
+    double q, q_inv;            // q and RN(1/q)
+    double n_inv, n_inv_q;      // N^-1 mod q and RN(n_inv / q): the scaling of the inverse transform
+};
+
 // Addressing of one NTT launch.  Work item (b, i): batch element b, i-th limb of the launch.
 struct NttLaunch {
     const u64 *in;
@@ -50,8 +57,12 @@ struct NttLaunch {
     int group;
     int fuse_top;               // sub_log = 1, forward, out of place: the sub-transforms compute the stage over bit 15 while
                                 // loading (each reads both halves of the limb), no separate streaming pass
+    // dual assembly kernels ("m3"): a limb whose fp_lp entry is set runs on the FP64 body, with twiddles (w, RN(w/q)) as
+    // doubles in tables laid out exactly like tw / tw_fin, found at tw + fp_tw_delta / tw_fin + fp_fin_delta (bytes)
+    long long fp_tw_delta, fp_fin_delta;
+    const FpLimb *fp_lp;        // [L], or null for every other kernel
 };
-static_assert(sizeof(NttLaunch) == 104, "NttLaunch layout is shared with asmgen/gen_ntt.py (fields are read at fixed offsets)");
+static_assert(sizeof(NttLaunch) == 128, "NttLaunch layout is shared with asmgen/gen_ntt.py (fields are read at fixed offsets)");
 
 // ---- coefficient-wise launches (lr_ewise.hip) ----
 struct EwiseLaunch {

@@ -8,6 +8,9 @@ ring, params, sampling = pkg.ring, pkg.params, pkg.sampling
 sizes = [int(a) for a in sys.argv[1:]] or [12, 13, 14, 15]
 for logn in sizes:
     N, moduli = params.DefaultParamsQi(logn)
+    bits = int(__import__('os').environ.get('QB_BITS', '0'))      # QB_BITS=40: moduli of that size instead (FP64 body below 2^46)
+    if bits:
+        moduli = params.GenerateNTTPrimes(bits, logn, len(moduli))
     L = len(moduli)
     B = (1 << 30) // (8 * N * L)      # 1 GiB per buffer
     ctx = ring.NewContextWithParams(N, moduli)
