@@ -65,6 +65,9 @@ const char *lr_build_info(void);
  * (incl. primitiveRoot's search order, ring/utils.go:182) and uploads them to `device`. */
 int lr_context_create(uint64_t N, const uint64_t *moduli, int n_moduli, int device, lr_context **out);
 int lr_context_destroy(lr_context *ctx);
+/* diagnostics: the assembly NTT variant the context's moduli select (forward, inverse): 0..2 = integer lazy-correction modes,
+ * 3 = dual kernels (FP64 butterflies for the limbs below 2^46, integer body for the others), -1 = C++ kernels only */
+int lr_context_ntt_variants(const lr_context *ctx, int *forward, int *inverse);
 /* use an externally owned hipStream_t (e.g. torch's current stream); NULL = the context's own */
 int lr_context_set_stream(lr_context *ctx, void *hip_stream);
 int lr_context_sync(lr_context *ctx);       /* hipStreamSynchronize on the context's stream */

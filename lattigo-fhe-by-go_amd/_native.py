@@ -25,6 +25,7 @@ SYMBOLS = {
     "lr_build_info": [],
     "lr_context_create": [u64, u64p, i32, i32, C.POINTER(vp)],
     "lr_context_destroy": [vp],
+    "lr_context_ntt_variants": [vp, C.POINTER(i32), C.POINTER(i32)],
     "lr_context_set_stream": [vp, vp],
     "lr_context_sync": [vp],
     "lr_context_info": [vp, u64p, C.POINTER(i32), C.POINTER(i32)],

@@ -180,6 +180,7 @@ class GenInv(Gen):
                 e("s_mov_b64", dst, self.FPL.sub(2 * i, 2))
             e("s_mov_b32", self.MAGIC.lo(), 0)
             e("s_mov_b32", self.MAGIC.hi(), 0x43300000)
+            e("v_mul_f64", self.BIAS, self.QINV, 0.5)
             return
         e("s_waitcnt", "lgkmcnt(0)")
         e("s_mov_b64", self.Qm, s(68, 2))

@@ -109,6 +109,8 @@ class Gen:
         self.QD, self.QINV = s(14, 2), s(16, 2)
         self.MAGIC = s(18, 2)                         # 2^52
         self.NINV, self.NINVQ = s(20, 2), s(22, 2)
+        self.BIAS = v(126, 2)                         # 1/(2q), per lane (a second scalar operand is not allowed)
+        assert self.vgpr_count <= 126
 
     # ------------------------------------------------------------------ emission helpers
     def e(self, op, *args, **mods):
@@ -194,15 +196,13 @@ class Gen:
                 ("v_add_f64", X, ts.Q, ts.C)]
 
     def ops_canon_fp(self, ts, X):
-        """integer-valued double -> canonical residue as a 64-bit integer: centred remainder, + q if negative, then the
-        mantissa of 2^52 + y is y"""
-        return [("v_mul_f64", ts.R, X, self.QINV),
-                ("v_rndne_f64", ts.R, ts.R),
+        """integer-valued double, |x| < 2^50 -> canonical residue as a 64-bit integer.  floor((x + 1/2) / q) is the exact
+        quotient: x/q is an integer or at least 1/q > 2^-46 away from one, the computed (x + 1/2) * RN(1/q) is off by less
+        than 1/(2q) (q < 2^46, |x/q| below 2^12 + 12), so the bias of 1/(2q) keeps it on the right side of every integer.
+        Then y = x - k*q is in [0, q) exactly and the mantissa of 2^52 + y is y."""
+        return [("v_fma_f64", ts.R, X, self.QINV, self.BIAS),
+                ("v_floor_f64", ts.R, ts.R),
                 ("v_fma_f64", X, Neg(ts.R), self.QD, X),
-                ("v_ashrrev_i32", ts.T0, 31, X.hi()),
-                ("v_and_b32", ts.C.lo(), self.QD.lo(), ts.T0),
-                ("v_and_b32", ts.C.hi(), self.QD.hi(), ts.T0),
-                ("v_add_f64", X, X, ts.C),
                 ("v_add_f64", X, X, self.MAGIC),
                 ("v_and_b32", X.hi(), 0xFFFFF, X.hi())]
 
@@ -466,6 +466,7 @@ class Gen:
                 e("s_addc_u32", ptr.hi(), ptr.hi(), d.hi())
             e("s_mov_b32", self.MAGIC.lo(), 0)
             e("s_mov_b32", self.MAGIC.hi(), 0x43300000)
+            e("v_mul_f64", self.BIAS, self.QINV, 0.5)
             return
         e("s_waitcnt", "lgkmcnt(0)")
         e("s_mov_b64", self.Qm, s(68, 2))
@@ -1073,6 +1074,19 @@ def test_moduli(logn, mode):
     return [above[-1], lo]
 
 
+def fp_test_moduli(logn):
+    """dual kernels: the largest NTT prime below 2^46 (the FP body's range bounds at their tightest), a 30-bit one (below what the
+    integer bodies accept) and one just above 2^46 (integer body of the same kernel)"""
+    sys.path.insert(0, __import__("os").path.join(__import__("os").path.dirname(__file__), "..", "..", ".."))
+    import __graft_entry__ as graft
+    params = graft.load_package().params
+    step = 2 << logn
+    p = FP_LIMIT - step + 1
+    while not params.is_prime(p):
+        p -= step
+    return [p, params.GenerateNTTPrimes(30, logn, 1)[0], params.GenerateNTTPrimes(46, logn, 1)[0]]
+
+
 def emulate_sub(make_gen, inverse, q, pretop=False):
     """N = 2^16 through the two sub-block workgroups of one limb; returns (bit-exact?, summary)"""
     import numpy as np
@@ -1187,6 +1201,17 @@ def selftest(logn, inverse=False, threads=1024):
             ok = ok and good
             print("%s logN=%d T=%d mode %d q=%d (%d bits): %s; %s" % ("inverse" if inverse else "forward", logn, threads, mode, q, q.bit_length(),
                                                              "bit-exact vs oracle" if good else "MISMATCH", info), flush=True)
+    for q in fp_test_moduli(logn):
+        if inverse:
+            from gen_intt import GenInv
+            gen = Dual(lambda fp: GenInv(logn, 1, threads, fp=fp, dual=True))
+        else:
+            gen = Dual(lambda fp: Gen(logn, 2, threads, fp=fp, dual=True))
+        geom = (2, 1, 1, 2, 3, 6) if q == fp_test_moduli(logn)[0] else None
+        good, info = emulate(gen, inverse, q, geom)
+        ok = ok and good
+        print("%s logN=%d T=%d dual q=%d (%d bits): %s; %s" % ("inverse" if inverse else "forward", logn, threads, q, q.bit_length(),
+                                                        "bit-exact vs oracle" if good else "MISMATCH", info), flush=True)
     return ok
 
 
@@ -1208,6 +1233,17 @@ def selftest_sub(inverse=False):
         ok = ok and good
         print("%s N=2^16 sub-blocks mode %d q=%d (%d bits): %s; %s" % ("inverse" if inverse else "forward", mode, q, q.bit_length(),
                                                                     "bit-exact vs oracle" if good else "MISMATCH", info), flush=True)
+    for q in fp_test_moduli(16)[:2]:
+        if inverse:
+            from gen_intt import GenInv
+            good, info = emulate_sub(lambda: Dual(lambda fp: GenInv(15, 1, 1024, sub=True, fp=fp, dual=True)), True, q)
+        else:
+            good, info = emulate_sub(lambda: Dual(lambda fp: Gen(15, 2, 1024, sub=True, fp=fp, dual=True)), False, q)
+            good2, _ = emulate_sub(lambda: Dual(lambda fp: Gen(15, 2, 1024, sub=True, fused=False, fp=fp, dual=True)), False, q, pretop=True)
+            good = good and good2
+        ok = ok and good
+        print("%s N=2^16 sub-blocks dual q=%d (%d bits): %s; %s" % ("inverse" if inverse else "forward", q, q.bit_length(),
+                                                             "bit-exact vs oracle" if good else "MISMATCH", info), flush=True)
     return ok
 
 

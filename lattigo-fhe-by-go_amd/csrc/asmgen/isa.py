@@ -112,6 +112,9 @@ class Program:
 def _fmt(a):
     if isinstance(a, (Reg, Neg)):
         return repr(a)
+    if isinstance(a, float):
+        assert a in (0.5, 1.0, 2.0, 4.0)          # inline floating-point constants
+        return repr(a)
     if isinstance(a, int):
         return str(a) if -16 <= a <= 64 else hex(a & 0xFFFFFFFF)
     return str(a)
@@ -346,6 +349,9 @@ class Machine:
             else:
                 out[k] = float(Fraction(fx) * Fraction(fy) + Fraction(fz))
         self.wf64(d, out)
+
+    def i_v_floor_f64(self, d, a):
+        self.wf64(d, np.floor(self.rf64(a)))
 
     def i_v_rndne_f64(self, d, a):
         self.wf64(d, np.rint(self.rf64(a)))

@@ -392,6 +392,13 @@ extern "C" int lr_context_create(uint64_t N, const uint64_t *moduli, int n_modul
     return LR_OK;
 }
 
+extern "C" int lr_context_ntt_variants(const lr_context *c, int *forward, int *inverse) {
+    if (!c || !forward || !inverse) return fail(LR_ERR_ARG, "null argument");
+    *forward = c->use_asm ? c->asm_fwd : -1;
+    *inverse = c->use_asm ? c->asm_inv : -1;
+    return LR_OK;
+}
+
 extern "C" int lr_context_destroy(lr_context *c) {
     if (!c) return LR_OK;
     (void)hipSetDevice(c->device);

@@ -298,6 +298,12 @@ class Context:
     def Permute(self, polIn, gen, polOut):  # :106
         check(lib().lr_permute(self.h, polIn.h, int(gen), polOut.h))
 
+    def ntt_variants(self):
+        """(forward, inverse) assembly variants this context selects (diagnostics)"""
+        f, i = C.c_int(), C.c_int()
+        check(lib().lr_context_ntt_variants(self.h, C.byref(f), C.byref(i)))
+        return f.value, i.value
+
     def MultByMonomial(self, p1, monomialDeg, p2):  # ring/ring.go:663
         check(lib().lr_mult_by_monomial(self.h, p1.h, int(monomialDeg), p2.h))
 

@@ -197,10 +197,19 @@ def _asm_moduli(pkg, kind, logn):
         return ps
     if kind == "mixed":                     # 35-bit next to 60-bit: variant 1 covers both
         return [P.GenerateNTTPrimes(34, logn, 1)[0], P.Qi60()[-1]]
+    if kind == "fp":                        # dual kernels, every limb on the FP64 body: 30 bits (below what the integer bodies
+        step = 2 << logn                    # take), 40 bits, and the largest NTT prime below 2^46 (tightest range bounds)
+        p = (1 << 46) - step + 1
+        while not P.is_prime(p):
+            p -= step
+        return [P.GenerateNTTPrimes(30, logn, 1)[0], P.GenerateNTTPrimes(40, logn, 1)[0], p]
+    if kind == "fpedge":                    # dual kernels: both sides of the 2^46 boundary in one launch
+        return [P.GenerateNTTPrimes(46, logn, 1)[0], _asm_moduli(pkg, "fp", logn)[2], P.GenerateNTTPrimes(45, logn, 1)[0]]
     raise ValueError(kind)
 
 
-ASM_CASES = [("qi60", None), ("qi60", "0"), ("ckks", None), ("ckks", "1"), ("ckks", "0"), ("bfv60", None), ("mixed", None)]
+ASM_CASES = [("qi60", None), ("qi60", "0"), ("ckks", None), ("ckks", "1"), ("ckks", "0"), ("bfv60", None), ("mixed", None),
+             ("fp", None), ("fpedge", None)]
 
 
 @pytest.mark.parametrize("kind,force", ASM_CASES)
@@ -272,7 +281,7 @@ def test_cxx_and_asm_inverse_paths_agree(gpu_pkg, oracle, logn, kind, force, mon
         assert np.array_equal(p.get(), np.stack([[x[b, i] % np.uint64(q) for i, q in enumerate(moduli)] for b in range(2)]))
 
 
-@pytest.mark.parametrize("kind", ["qi60", "ckks", "bfv60"])
+@pytest.mark.parametrize("kind", ["qi60", "ckks", "bfv60", "fp"])
 def test_asm_2p14_both_plans(gpu_pkg, oracle, kind, monkeypatch):
     """N = 2^14 has two assembly plans: 512 threads / two columns per thread / two workgroups per CU (default) and
     1024 threads / one workgroup per CU (LR_ASM_14_1024=1); both directions of both plans equal the oracle"""
@@ -314,3 +323,21 @@ def test_cpp_host_mirror_runs_reference_ntt_test():
     out = subprocess.run([exe, GOLDEN_DIR], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "PASS" in out.stdout
+
+
+def test_fp64_bodies_are_selected(gpu_pkg, monkeypatch):
+    """contexts whose moduli allow it run on the dual kernels (variant 3: FP64 butterflies for the limbs below 2^46); LR_NO_FP=1 and
+    a modulus of 57 bits or more keep the integer variants"""
+    P, ring = gpu_pkg.params, gpu_pkg.ring
+    monkeypatch.delenv("LR_ASM_VARIANT", raising=False)
+    monkeypatch.delenv("LR_NO_ASM", raising=False)
+    monkeypatch.delenv("LR_NO_FP", raising=False)
+    N, Q, Pm = P.ckks_moduli("PN15QP880")
+    assert ring.NewContextWithParams(N, Q).ntt_variants() == (3, 3)
+    assert ring.NewContextWithParams(N, Pm).ntt_variants() == (2, 1)        # 50-bit moduli only: nothing for the FP body
+    assert ring.NewContextWithParams(1 << 13, P.ckks_moduli("PN13QP218")[1]).ntt_variants() == (3, 3)   # 30-bit moduli
+    N, moduli = P.DefaultParamsQi(15)
+    assert ring.NewContextWithParams(N, moduli).ntt_variants() == (1, 1)
+    monkeypatch.setenv("LR_NO_FP", "1")
+    N, Q, _ = P.ckks_moduli("PN15QP880")
+    assert ring.NewContextWithParams(N, Q).ntt_variants() == (2, 1)
