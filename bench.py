@@ -315,6 +315,21 @@ def main():
                                         "note": "%d -> %d limbs, %d modular multiplies per coefficient (compute-bound)" %
                                                 (L, len(pmod), L + L * len(pmod))}
             del outP, bext
+        if 12 <= args.logn <= 15:
+            # the same transform on CKKS-size moduli (DefaultParams[PN15QP880]'s first limbs at N = 2^15: one of 50 bits, the rest
+            # 40): limbs below 2^46 run on the FP64 body of the dual kernels, the others on the integer body beside it
+            cq = list(params.ckks_moduli("PN15QP880")[1][:L]) if args.logn == 15 else params.GenerateNTTPrimes(40, args.logn, L)
+            ctxC = ring.NewContextWithParams(N, cq, device=local)
+            cb = sampling.uniform_poly(cq, N, min(my_polys, 2), seed=11)
+            csrc = ctxC.NewPoly(my_polys).set(np.concatenate([cb] * (-(-my_polys // cb.shape[0])))[:my_polys])
+            cdst = ctxC.NewPoly(my_polys)
+            for name, fn in (("ntt", lambda: ctxC.NTT(csrc, cdst)), ("intt", lambda: ctxC.InvNTT(csrc, cdst))):
+                ms = timed(fn)
+                extras[name + "_ckks_moduli"] = {"limb_ntt_per_s": my_polys * L / (ms * 1e-3), "ms": ms,
+                                                 "frac_hbm": ntt_bytes(N, L, my_polys) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                                 "moduli_bits": [int(q).bit_length() for q in cq],
+                                                 "asm_variants": list(ctxC.ntt_variants())}
+            del csrc, cdst, ctxC
         out["extras"] = extras
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -54,4 +54,23 @@ for logn in (12, 13, 14, 15, 16):
     rows.append(r)
     print(json.dumps(r), flush=True)
     del a, b, c, pp, be, cQ, cP
-json.dump({"device": "MI355X", "peak_GBs": PEAK, "rows": rows}, open(sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/sweep.json", "w"), indent=1)
+# the same transforms on the CKKS default moduli (ckks/params.go:36-87: 30..55-bit limbs): limbs below 2^46 run on the FP64
+# bodies of the dual kernels
+ckks_rows = []
+for name in ("PN12QP109", "PN13QP218", "PN14QP438", "PN15QP880", "PN16QP1761"):
+    N, Q, _ = params.ckks_moduli(name)
+    L = len(Q)
+    B = max(2, (1 << 30) // (8 * N * L))
+    cQ = ring.NewContextWithParams(N, Q)
+    base = sampling.uniform_poly(Q, N, 2, seed=L)
+    a, c = cQ.NewPoly(B).set(np.concatenate([base] * (B // 2))), cQ.NewPoly(B)
+    r = {"params": name, "logN": N.bit_length() - 1, "limbs": L, "batch": B, "moduli_bits": [int(q).bit_length() for q in Q],
+         "asm_variants": list(cQ.ntt_variants())}
+    for op, fn in (("ntt", lambda: cQ.NTT(a, c)), ("intt", lambda: cQ.InvNTT(a, c))):
+        ms = timeit(cQ, fn)
+        gbs = 16 * N * L * B / (ms * 1e-3) / 1e9
+        r[op] = {"ms": round(ms, 4), "limb_ntt_per_s": round(B * L / (ms * 1e-3)), "GBs": round(gbs), "frac_hbm": round(gbs / PEAK, 4)}
+    ckks_rows.append(r)
+    print(json.dumps(r), flush=True)
+    del a, c, cQ
+json.dump({"device": "MI355X", "peak_GBs": PEAK, "rows": rows, "ckks_moduli_rows": ckks_rows}, open(sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/sweep.json", "w"), indent=1)
