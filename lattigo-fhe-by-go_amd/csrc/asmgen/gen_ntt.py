@@ -90,7 +90,14 @@ class Gen:
         assert self.vgpr_count <= 128
         # ---- SGPR map
         self.KARG = s(0, 2)
-        self.WGX, self.WGY, self.WGZ = s(2), s(3), s(4)   # WGZ is consumed before SRC (s[4:5]) is formed
+        # launch grid (WGX = limb of the launch, WGY = polynomial of the digit group, WGZ = digit group).  The dispatcher deals
+        # consecutive workgroups out to the eight XCDs in turn.  Limb fastest (x = limb): XCD j only sees the limbs j mod 8,
+        # whose twiddles stay in its L2 -- best when all limbs cost the same and n_items <= 16.  Polynomial fastest (x = poly):
+        # every XCD works on the same limb at any time and sees every modulus -- needed by the dual kernels (a launch that
+        # mixes FP64 and integer limbs otherwise waits for the XCD that holds the integer ones) and better for N = 2^16
+        # (64 sub-block ids: four limbs' tables per XCD do not fit its L2)
+        self.swap_grid = bool(dual or sub)
+        self.WGX, self.WGY, self.WGZ = (s(3), s(2), s(4)) if self.swap_grid else (s(2), s(3), s(4))   # WGZ is consumed before SRC (s[4:5]) is formed
         self.SRC, self.DST = s(4, 2), s(6, 2)
         self.TW, self.TWF, self.TWFR = s(8, 2), s(10, 2), s(12, 2)
         self.Qm, self.NQ, self.Q4, self.NQ8 = s(14, 2), s(16, 2), s(18, 2), s(20, 2)   # NQ8: -8q (mode 1) or -4q (mode 0)
@@ -847,7 +854,7 @@ class Dual:
 
     def __init__(self, make):
         self.gf, self.gi = make(True), make(False)
-        for k in ("logn", "T", "SPH", "A", "N", "sub"):
+        for k in ("logn", "T", "SPH", "A", "N", "sub", "WGX", "WGY"):
             setattr(self, k, getattr(self.gf, k))
         self.p = None
 
@@ -1020,7 +1027,7 @@ def emulate(gen, inverse=False, q=None, geom=None):
     m.vgpr[0] = np.arange(gen.T, dtype=np.uint32)
     m.vdef[0] = True
     m.sgpr[0], m.sgpr[1] = A_KARG, 0
-    m.sgpr[2], m.sgpr[3], m.sgpr[4] = gx, gy, gz
+    m.sgpr[gen.WGX.idx], m.sgpr[gen.WGY.idx], m.sgpr[4] = gx, gy, gz
     m.sdef[0:5] = True
     m.run(prog)
     got = m.mem[(A_OUT + where) // 4: (A_OUT + where) // 4 + 2 * N].view(np.uint64)
@@ -1168,7 +1175,7 @@ def emulate_sub(make_gen, inverse, q, pretop=False):
         m.vgpr[0] = np.arange(gen.T, dtype=np.uint32)
         m.vdef[0] = True
         m.sgpr[0], m.sgpr[1] = A_KARG, 0
-        m.sgpr[2], m.sgpr[3], m.sgpr[4] = blk, 0, 0
+        m.sgpr[gen.WGX.idx], m.sgpr[gen.WGY.idx], m.sgpr[4] = blk, 0, 0
         m.sdef[0:5] = True
         m.run(prog)
         mem = m.mem

@@ -78,16 +78,19 @@ hipError_t launch_ntt_asm(const NttLaunch &a, int logn, int inverse, int variant
     size_t size = sizeof(NttLaunch);
     void *extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
     (void)hipGetLastError();
-    // grid: x = limb of the launch, y = polynomial; blocks b and b+8 share an XCD, so the limbs an XCD
-    // sees (and whose twiddles live in its L2) are x mod 8 when n_items is a multiple of 8
-    // z = digit group (NttLaunch::hole / group); plain launches are one group
+    // grid: limb of the launch, polynomial, z = digit group (NttLaunch::hole / group; plain launches are one group).
+    // Consecutive workgroups go to the eight XCDs in turn.  Integer variants: x = limb, so XCD j only sees the limbs j mod 8
+    // and keeps their twiddles in its L2.  Dual kernels (variant 3): x = polynomial, every XCD sees every modulus -- a launch
+    // that mixes the cheaper FP64 limbs with integer ones otherwise waits for the XCD holding the latter (gen_ntt.py: swap_grid)
     unsigned gy = (unsigned)a.batch, gz = 1;
     if (a.hole > 0) {
         if (a.group <= 0 || a.batch % a.group != 0) return hipErrorInvalidValue;
         gy = (unsigned)a.group;
         gz = (unsigned)(a.batch / a.group);
     }
-    return hipModuleLaunchKernel(it->second, (unsigned)a.n_items, gy, gz, !x ? 1024 : (logn == 12 || (logn == 13 && !inverse)) ? 256 : 512, 1, 1, 0, stream, nullptr, extra);
+    const unsigned threads = !x ? 1024 : (logn == 12 || (logn == 13 && !inverse)) ? 256 : 512;
+    if (variant == 3) return hipModuleLaunchKernel(it->second, gy, (unsigned)a.n_items, gz, threads, 1, 1, 0, stream, nullptr, extra);
+    return hipModuleLaunchKernel(it->second, (unsigned)a.n_items, gy, gz, threads, 1, 1, 0, stream, nullptr, extra);
 }
 
 // N = 2^16 runs as two 2^15 sub-blocks per limb (grid x = 2 * n_items).  kind: 's' = forward with the stage over
@@ -112,8 +115,8 @@ hipError_t launch_ntt_asm16(const NttLaunch &a, int inverse, char kind, int vari
         gy = (unsigned)a.group;
         gz = (unsigned)(a.batch / a.group);
     }
-    if (gy > 65535u || gz > 65535u) return hipErrorInvalidValue;
-    return hipModuleLaunchKernel(it->second, 2u * (unsigned)a.n_items, gy, gz, 1024, 1, 1, 0, stream, nullptr, extra);
+    if (gz > 65535u) return hipErrorInvalidValue;
+    return hipModuleLaunchKernel(it->second, gy, 2u * (unsigned)a.n_items, gz, 1024, 1, 1, 0, stream, nullptr, extra);
 }
 
 }  // namespace lr

@@ -11,6 +11,8 @@ for logn in sizes:
     bits = int(__import__('os').environ.get('QB_BITS', '0'))      # QB_BITS=40: moduli of that size instead (FP64 body below 2^46)
     if bits:
         moduli = params.GenerateNTTPrimes(bits, logn, len(moduli))
+    if __import__('os').environ.get('QB_CKKS') and logn == 15:       # PN15QP880's first limbs: one of 51 bits, the rest 41
+        moduli = list(params.ckks_moduli("PN15QP880")[1][:len(moduli)])
     L = len(moduli)
     B = (1 << 30) // (8 * N * L)      # 1 GiB per buffer
     ctx = ring.NewContextWithParams(N, moduli)

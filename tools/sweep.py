@@ -60,7 +60,7 @@ ckks_rows = []
 for name in ("PN12QP109", "PN13QP218", "PN14QP438", "PN15QP880", "PN16QP1761"):
     N, Q, _ = params.ckks_moduli(name)
     L = len(Q)
-    B = max(2, (1 << 30) // (8 * N * L))
+    B = max(2, (1 << 30) // (8 * N * L)) & ~1
     cQ = ring.NewContextWithParams(N, Q)
     base = sampling.uniform_poly(Q, N, 2, seed=L)
     a, c = cQ.NewPoly(B).set(np.concatenate([base] * (B // 2))), cQ.NewPoly(B)
