@@ -8,6 +8,8 @@ ring, params, sampling = pkg.ring, pkg.params, pkg.sampling
 logn = int(sys.argv[1]) if len(sys.argv) > 1 else 15
 N, moduli = params.DefaultParamsQi(logn)
 L = len(moduli)
+if len(sys.argv) > 2:                      # pmc_run.py 15 40: moduli of that many bits (below 2^46: the FP64 body)
+    moduli = params.GenerateNTTPrimes(int(sys.argv[2]), logn, L)
 B = (1 << 30) // (8 * N * L)
 ctx = ring.NewContextWithParams(N, moduli)
 base = sampling.uniform_poly(moduli, N, 2, seed=1)
