@@ -108,3 +108,48 @@ def test_key_switch_fuzz(gpu_pkg, oracle, seed):
     for b in range(batch):
         w0, w1 = oplan.switch_keys(level, cx[b], evk.reshape(beta, 2, nq + np_, N))
         assert np.array_equal(g0[b], w0) and np.array_equal(g1[b], w1), (logn, nq, np_, level, b)
+
+
+def _ckks_size_moduli(pkg, rng, logn, count):
+    """moduli between 30 and 56 bits: contexts that select the dual assembly kernels (FP64 body below 2^46 next to the integer one)"""
+    pool = []
+    for bits in (30, 34, 40, 45, 46, 50, 56):
+        pool += pkg.params.GenerateNTTPrimes(bits, logn, 2)
+    pool = sorted(set(pool))
+    idx = rng.choice(len(pool), size=count, replace=False)
+    return [pool[i] for i in idx]
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_dual_kernel_fuzz(gpu_pkg, oracle, seed):
+    """random mixes of FP64-class and integer-class moduli at the degrees of the assembly kernels: NTT of full-range inputs, InvNTT of
+    inputs anywhere in [0, 4q), at random levels and batches, in place and out of place"""
+    rng = np.random.default_rng(4000 + seed)
+    logn = 12 + seed % 5
+    N = 1 << logn
+    limbs = int(rng.integers(1, 8))
+    batch = int(rng.integers(1, 4))
+    level = int(rng.integers(0, limbs))
+    moduli = _ckks_size_moduli(gpu_pkg, rng, logn, limbs)
+    ctx, oc = gpu_pkg.ring.NewContextWithParams(N, moduli), oracle.Context(N, moduli)
+    x = gpu_pkg.sampling.random_u64((batch, limbs, N), seed=seed)
+    x[0, :, :3] = np.uint64(0xFFFFFFFFFFFFFFFF)
+    y = x.copy()
+    for i, q in enumerate(moduli):
+        y[:, i] %= np.uint64(4 * q)
+        y[0, i, :2] = np.uint64(4 * q - 1)
+    red = lambda a, b: np.array([[int(v) % q for v in a[b, i]] for i, q in enumerate(moduli)], dtype=np.uint64)
+    px, py, pr = ctx.NewPoly(batch).set(x), ctx.NewPoly(batch).set(y), ctx.NewPoly(batch)
+    ctx.NTTLvl(level, px, pr)
+    got = pr.get().reshape(batch, limbs, N)
+    for b in range(batch):
+        assert np.array_equal(got[b, :level + 1], oc.ntt(red(x, b))[:level + 1]), ("ntt", logn, moduli, level, b)
+    ctx.InvNTTLvl(level, py, pr)
+    got = pr.get().reshape(batch, limbs, N)
+    for b in range(batch):
+        assert np.array_equal(got[b, :level + 1], oc.intt(red(y, b))[:level + 1]), ("intt", logn, moduli, level, b)
+    ctx.NTTLvl(level, px, px)
+    ctx.InvNTTLvl(level, px, px)                     # in place, round trip
+    got = px.get().reshape(batch, limbs, N)
+    for b in range(batch):
+        assert np.array_equal(got[b, :level + 1], red(x, b)[:level + 1]), ("round trip", logn, moduli, level, b)
