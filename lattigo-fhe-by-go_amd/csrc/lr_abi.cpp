@@ -85,6 +85,10 @@ struct lr_context {
     u64 *d_rescale = nullptr;   // [L][L]
     u64 *scratch = nullptr;     // rescale temporaries, grown on demand
     size_t scratch_words = 0;
+    // DivRoundByLastModulusNTT: per level, -(pHalfNegQi[i] * NTT_i(1 + X + ... + X^(N-1))) * rescaleParams[i] for i < level,
+    // [level][N], built on first use (rescale_round_table)
+    std::map<int, u64 *> rescale_round_plus;
+    std::mutex rescale_mu;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int ntt_mode = 0;           // lazy-correction cadence allowed by the largest modulus (lr_ntt.hip)
     bool use_asm = true;        // hand-scheduled assembly NTT where it applies (LR_NO_ASM=1 disables)
@@ -406,6 +410,8 @@ extern "C" int lr_context_destroy(lr_context *c) {
     for (void *p : {(void *)c->d_lp, (void *)c->d_fwd, (void *)c->d_inv, (void *)c->d_fwd_fin, (void *)c->d_inv_fin, (void *)c->d_rescale, (void *)c->scratch,
                     (void *)c->d_fwd_fp, (void *)c->d_inv_fp, (void *)c->d_fwd_fin_fp, (void *)c->d_inv_fin_fp, (void *)c->d_fp_lp})
         if (p) (void)hipFree(p);
+    for (auto &kv : c->rescale_round_plus)
+        if (kv.second) (void)hipFree(kv.second);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     delete c;
@@ -1364,9 +1370,50 @@ int rescale_coeff_domain(lr_context *c, lr_poly *p0, bool round) {
     return LR_OK;
 }
 
+// The rounding variant transforms (t + pHalfNegQi[i]) under modulus i, t = the centred last limb (:101-105).  The transform is
+// linear and the addend is the same in every coefficient: NTT_i(t + a_i * ones) = NTT_i(t) + a_i * NTT_i(ones), so the
+// polynomial is transformed as it is (one source row for all limbs, like the floor variant) and the constant vector joins
+// the subtract-multiply as its `plus` operand, already multiplied by -rescaleParams[i]: the same canonical residue without the
+// pass that writes `level` shifted copies of the row.  The table depends on the level only and is built once.
+int rescale_round_table(lr_context *c, int level, const u64 **out) {
+    std::lock_guard<std::mutex> lock(c->rescale_mu);
+    auto it = c->rescale_round_plus.find(level);
+    if (it != c->rescale_round_plus.end()) {
+        *out = it->second;
+        return LR_OK;
+    }
+    const int n = (int)c->h.N;
+    const long long words = (long long)level * n;
+    u64 *table = nullptr;
+    LR_HIP(hipMalloc((void **)&table, (size_t)words * sizeof(u64)));
+    c->rescale_round_plus[level] = table;
+    LR_TRY(ensure_scratch(c, (size_t)words));
+    LR_HIP(hipMemsetAsync(table, 0, (size_t)words * sizeof(u64), c->stream));
+    const u64 pj = c->h.q[level], phalf = (pj - 1) >> 1;
+    RowAddLaunch M;
+    M.in = table;                       // a row of zeros
+    M.in_stride = 0;
+    M.out = c->scratch;
+    M.out_stride = words;
+    M.n = n;
+    M.q = 0;
+    std::memset(&M.adds, 0, sizeof(M.adds));
+    for (int i = 0; i < level; ++i) M.adds.v[i] = c->h.q[i] - bred_add(phalf, c->h.q[i], c->h.bred[i].hi);   // pHalfNegQi
+    LR_HIP(launch_rowadd(M, level, 1, c->stream));
+    Rows tmp{c->scratch, words, 0, 1};
+    LR_TRY(run_ntt(c, false, tmp, tmp, 0, 1, level, 1));
+    // table = MRed(0 + (q - NTT(a_i * ones)), rescaleParams[i])
+    LR_TRY(run_submul(c, level, 1, table, words, c->scratch, words, (long long)n, table, words,
+                      c->d_rescale + (size_t)(level - 1) * c->h.L(), false, nullptr));
+    *out = table;
+    return LR_OK;
+}
+
 int rescale_ntt_domain(lr_context *c, lr_poly *p0, bool round) {
     const int level = p0->limbs - 1, n = (int)c->h.N, batch = p0->batch;
     const long long tmp_stride = (long long)level * n;
+    const u64 *plus = nullptr;
+    if (round && std::getenv("LR_RESCALE_UNFUSED") == nullptr) LR_TRY(rescale_round_table(c, level, &plus));
     LR_TRY(ensure_scratch(c, (size_t)batch * tmp_stride));
     Rows last{p0->d, p0->stride(), level, 0};
     LR_TRY(run_ntt(c, true, last, last, level, 0, 1, batch));  // :15 / :80
@@ -1382,6 +1429,11 @@ int rescale_ntt_domain(lr_context *c, lr_poly *p0, bool round) {
         std::memset(&L.adds, 0, sizeof(L.adds));
         L.adds.v[0] = phalf;
         LR_HIP(launch_rowadd(L, 1, batch, c->stream));            // :87-89
+    }
+    if (round && plus) {
+        LR_TRY(run_ntt(c, false, last, tmp, 0, 1, level, batch));  // NTT_i(t); the shift by pHalfNegQi[i] rides in `plus`
+    } else if (round) {
+        const u64 pj = c->h.q[level], phalf = (pj - 1) >> 1;
         RowAddLaunch M;
         M.in = p0->d + (long long)level * n;
         M.in_stride = p0->stride();
@@ -1397,7 +1449,7 @@ int rescale_ntt_domain(lr_context *c, lr_poly *p0, bool round) {
         LR_TRY(run_ntt(c, false, last, tmp, 0, 1, level, batch));  // :19: NTT of the last limb under modulus i
     }
     LR_TRY(run_submul(c, level, batch, p0->d, p0->stride(), c->scratch, tmp_stride, (long long)n, p0->d, p0->stride(),
-                      c->d_rescale + (size_t)(level - 1) * c->h.L(), false, nullptr));
+                      c->d_rescale + (size_t)(level - 1) * c->h.L(), false, nullptr, plus, 0));
     p0->limbs = level;
     return LR_OK;
 }

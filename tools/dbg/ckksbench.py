@@ -26,6 +26,9 @@ for rep in range(3):
     best = min(best, cQ.TimerStop() / 3)
 print(name, "N=%d |Q|=%d |P|=%d batch=%d: MulRelin %.3f ms/batch = %.1f mul/s; algorithmic %.1f GB/s" % (
     N, len(Q), len(P), B, best, B / (best * 1e-3), B * 8 * N * 360 / (best * 1e-3) / 1e9))
+warm = (mk(), mk())
+plan.Rescale(warm)            # first use at a level builds its constant table
+cQ.Sync()
 cQ.TimerStart()
 plan.Rescale(out)
 print("Rescale (both components): %.3f ms/batch" % cQ.TimerStop())
