@@ -118,7 +118,7 @@ struct DevModup {
     u64 *Q = nullptr, *mredQ = nullptr, *qib = nullptr, *P = nullptr, *mredP = nullptr, *bredP_hi = nullptr,
         *qispj = nullptr, *qpj_inv = nullptr;
     ulonglong2 *qispj_shoup = nullptr;
-    int lazy_terms = 0, exact_terms = 0, word_barrett = 0;
+    int lazy_terms = 0, exact_terms = 0, word_barrett = 0, wide_ok = 0;
     int init(const std::vector<u64> &Qv, const std::vector<u64> &Pv) {
         h = build_modup(Qv, Pv);
         std::vector<u64> bh(h.P.size());
@@ -145,6 +145,12 @@ struct DevModup {
         lazy_terms = (int)std::min<u128>(room / ((u128)5 * pmax), 1 << 20);   // 4p per term + p per unit of the correction v <= terms
         exact_terms = (int)std::min<u128>(room / ((u128)2 * pmax), 1 << 20);
         word_barrett = 1;
+        {
+            u64 qmax = 0;
+            for (size_t i = 0; i < nQ; ++i) qmax = h.Q[i] > qmax ? h.Q[i] : qmax;
+            // a group's sum of y_i * c_ij (y_i < q_i) over n terms is below n * qmax * p_j, which must stay below p_j * 2^64
+            wide_ok = std::getenv("LR_EXT_NARROW") ? 0 : (int)std::min<u128>((((u128)1 << 64) - 1) / qmax, 1 << 20);
+        }
         for (size_t j = 0; j < nP; ++j) word_barrett &= (h.P[j] >> 32) != 0 && h.P[j] != ((u64)1 << 32) ? 1 : 0;
         return LR_OK;
     }
@@ -158,6 +164,7 @@ struct DevModup {
         t.lazy_terms = lazy_terms;
         t.exact_terms = exact_terms;
         t.word_barrett = word_barrett;
+        t.wide_ok = wide_ok;
         return t;
     }
     ~DevModup() {

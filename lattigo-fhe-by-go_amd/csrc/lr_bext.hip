@@ -248,6 +248,99 @@ __global__ __launch_bounds__(256) void ext_sum_kernel(ExtLaunch L) {
     }
 }
 
+// Moduli that leave no room for lazy terms (60-bit QMul / P): the products are summed exactly in 128 bits and reduced ONCE,
+// by a Montgomery reduction -- sum_i MRed(y_i, qispj_mont[i][j]) and MRed-of-the-sum are the same residue modulo p_j, and the
+// reduction's precondition (sum < p_j * 2^64) holds because NIN * max q_i < 2^64 (ExtTables::wide_ok, checked by the host).
+// With y = y1 * 2^32 + y0 and c = c1 * 2^32 + c0 (y1, c1 < 2^29: every modulus is below 2^61) the sum is gathered by columns:
+//   lo  += y0 * c0            one v_mad_u64_u32 whose carry-out is counted (+1 instruction),
+//   mid += y0 * c1 + y1 * c0  two v_mad_u64_u32 (each product < 2^61; folded into lo / hi every four terms),
+//   hi  += y1 * c1            one v_mad_u64_u32 (each product < 2^58).
+// About 6 VALU instructions per term instead of the ~23 of an exact Shoup product with its share of the Barrett steps.
+__device__ __forceinline__ void mad_carry(u32 c, u32 y, u64 &acc, u32 &carries) {
+    asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc" : "+v"(acc), "+v"(carries) : "s"(c), "v"(y) : "vcc");
+}
+
+// G = terms per Montgomery reduction (G * max q_i < 2^64); NIN > G: the partial residues (each below p_j) are added up.
+template <int NIN, int W, int G>
+__global__ __launch_bounds__(256) void ext_wide_kernel(ExtLaunch L) {
+    const int xw = blockIdx.x * 256 + threadIdx.x;
+    if (W * xw >= L.n) return;
+    const long long b = blockIdx.y;
+    const u64 *in = L.in + b * L.in_stride + (long long)L.in_limb0 * L.n + W * xw;
+    u32 y0[W][NIN], y1[W][NIN];
+    double vf[W];
+#pragma unroll
+    for (int w = 0; w < W; ++w) vf[w] = 0.0;
+#pragma unroll
+    for (int i = 0; i < NIN; ++i) {
+        const u64 qi = L.t.Q[i];
+        u64 v[W];
+        if (W == 2) {
+            const ulonglong2 t = ld_stream(reinterpret_cast<const ulonglong2 *>(in + (long long)i * L.n));
+            v[0] = t.x;
+            v[W - 1] = t.y;
+        } else {
+            v[0] = ld_stream(in + (long long)i * L.n);
+        }
+#pragma unroll
+        for (int w = 0; w < W; ++w) {
+            const u64 y = mred(v[w], L.t.qib_mont[i], qi, L.t.mredQ[i]);
+            vf[w] += (double)y / (double)qi;
+            y0[w][i] = (u32)y;
+            y1[w][i] = (u32)(y >> 32);
+        }
+    }
+    u32 vi[W];
+#pragma unroll
+    for (int w = 0; w < W; ++w) vi[w] = (u32)(u64)vf[w];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const ExtSegment sg = L.seg[s];
+        u64 *out = sg.out + b * sg.stride + (long long)sg.limb0 * L.n + W * xw;
+        for (int jj = 0; jj < sg.count; ++jj) {
+            const int col = sg.col0 + jj;
+            const u64 pj = ld_const(L.t.P + col), pinv = ld_const(L.t.mredP + col);
+            const u64 *corr = L.t.qpj_inv + (long long)col * (L.t.nQ + 1);
+            u64 lo[W], mid[W], hi[W], r[W];
+            u32 cy[W];
+#pragma unroll
+            for (int w = 0; w < W; ++w) {
+                lo[w] = mid[w] = hi[w] = 0;
+                cy[w] = 0;
+                r[w] = corr[vi[w]];                                           // qpjInv[j][v], canonical
+            }
+#pragma unroll
+            for (int i = 0; i < NIN; ++i) {
+                const u64 c = ld_const(L.t.qispj_mont + (long long)i * L.t.nP + col);
+                const u32 c0 = (u32)c, c1 = (u32)(c >> 32);
+                const bool group_end = i == NIN - 1 || i % G == G - 1;
+#pragma unroll
+                for (int w = 0; w < W; ++w) {
+                    mad_carry(c0, y0[w][i], lo[w], cy[w]);
+                    mid[w] = mad_word(c1, y0[w][i], mid[w]);
+                    mid[w] = mad_word(c0, y1[w][i], mid[w]);
+                    hi[w] = mad_word(c1, y1[w][i], hi[w]);
+                    if ((i & 3) == 3 || group_end) {
+                        const u64 low_part = mid[w] << 32;
+                        lo[w] += low_part;
+                        hi[w] += (mid[w] >> 32) + (lo[w] < low_part ? 1 : 0);
+                        mid[w] = 0;
+                    }
+                    if (group_end) {
+                        const u64 th = hi[w] + cy[w];                         // the group's sum is th * 2^64 + lo, th < p_j
+                        const u64 H = mul_hi64(lo[w] * pinv, pj);             // MRed on the 128-bit sum (modular_reduction.go:70)
+                        r[w] = cred(r[w] + cred(th - H + pj, pj), pj);
+                        lo[w] = hi[w] = 0;
+                        cy[w] = 0;
+                    }
+                }
+            }
+            if (W == 2) st_stream(reinterpret_cast<ulonglong2 *>(out + (long long)jj * L.n), make_ulonglong2(r[0], r[W - 1]));
+            else st_stream(out + (long long)jj * L.n, r[0]);
+        }
+    }
+}
+
 template <int NIN>
 static hipError_t launch_n(const ExtLaunch &L, int batch, hipStream_t stream) {
     (void)hipGetLastError();  // drop stale (non-sticky) errors of unrelated earlier calls
@@ -257,6 +350,9 @@ static hipError_t launch_n(const ExtLaunch &L, int batch, hipStream_t stream) {
         const dim3 grid((unsigned)((L.n / W + 255) / 256), (unsigned)batch), block(256);
         if (L.t.lazy_terms >= (NIN < 2 ? 2 : NIN) && L.t.word_barrett) hipLaunchKernelGGL((ext_sum_kernel<NIN, W>), grid, block, 0, stream, L);
         else if (L.t.lazy_terms >= NIN) hipLaunchKernelGGL((ext_shoup_kernel<NIN, 0, W>), grid, block, 0, stream, L);
+        else if (L.t.wide_ok >= NIN) hipLaunchKernelGGL((ext_wide_kernel<NIN, W, NIN>), grid, block, 0, stream, L);
+        else if (L.t.wide_ok >= 16 && NIN > 16) hipLaunchKernelGGL((ext_wide_kernel<NIN, W, (NIN > 16 ? 16 : NIN)>), grid, block, 0, stream, L);
+        else if (L.t.wide_ok >= 8 && NIN > 8) hipLaunchKernelGGL((ext_wide_kernel<NIN, W, (NIN > 8 ? 8 : NIN)>), grid, block, 0, stream, L);
         else if (L.t.exact_terms >= 8) hipLaunchKernelGGL((ext_shoup_kernel<NIN, 7, W>), grid, block, 0, stream, L);
         else hipLaunchKernelGGL((ext_shoup_kernel<NIN, 3, W>), grid, block, 0, stream, L);
         return hipGetLastError();

@@ -194,6 +194,7 @@ struct ExtTables {        // device pointers; modupParams of ring_basis_extensio
     int lazy_terms;       // how many [0,4p) terms, each with one p of the correction v * qpjInv[1], fit in 64 bits
     int exact_terms;      // the same for [0,2p) terms
     int word_barrett;     // every p_j > 2^32: floor(2^64 / p_j) fits one word (ext_sum_kernel's final reduction)
+    int wide_ok;          // how many input terms keep n * max q_i below 2^64 (ext_wide_kernel: one Montgomery reduction per group)
 };
 
 struct ExtSegment {       // rows [limb0, limb0+count) of `out` receive table columns [col0, col0+count)
