@@ -126,6 +126,35 @@ def test_modup(gpu_pkg, oracle, nq, np_, logn):
         assert np.array_equal(pp.get()[0], obe.modup_split_qp(nq - 2, x[0]))
 
 
+@pytest.mark.parametrize("nq,np_,logn,above", [(17, 5, 6, False), (21, 2, 6, False), (32, 4, 8, False), (33, 2, 6, False), (40, 3, 5, False),
+                                                (9, 4, 7, True), (20, 3, 6, True)])
+def test_modup_long_sums(gpu_pkg, oracle, nq, np_, logn, above):
+    """the 128-bit column sums of ext_wide_kernel at every group structure: one group (n * q < 2^64), groups of 16 (60-bit inputs,
+    more than 16 limbs; one coefficient per thread beyond 20 limbs), groups of 8 (inputs just above 2^60: bfv's QMul primes)"""
+    N = 1 << logn
+    P_ = gpu_pkg.params
+    if above:
+        mods = P_.GenerateNTTPrimes(60, max(logn, 4), nq + np_)
+        assert min(mods) > (1 << 60)
+        Q, P = mods[:nq], mods[nq:]
+    else:
+        Q, P = list(P_.Qi60()[-nq:]), list(P_.Pi60()[-np_:])
+    ring = gpu_pkg.ring
+    cQ, cP = ring.NewContextWithParams(N, Q), ring.NewContextWithParams(N, P)
+    be = ring.NewFastBasisExtender(cQ, cP)
+    obe = oracle.BasisExtender(oracle.Context(N, Q), oracle.Context(N, P))
+    x = gpu_pkg.sampling.uniform_poly(Q, N, 2, seed=nq)
+    for i, q in enumerate(Q):
+        x[0, i, 0] = q - 1                      # the largest residues in every limb at once: the sums at their maximum
+        x[1, i, 1] = 0
+    px, pp = cQ.NewPoly(2).set(x), cP.NewPoly(2)
+    for level in (nq - 1, nq // 2):
+        be.ModUpSplitQP(level, px, pp)
+        got = pp.get()
+        for b in range(2):
+            assert np.array_equal(got[b], obe.modup_split_qp(level, x[b])), (level, b)
+
+
 @pytest.mark.parametrize("nq,np_,level", [(4, 2, 3), (4, 2, 1), (18, 3, 17)])
 def test_moddown_variants(gpu_pkg, oracle, nq, np_, level):
     N = 1 << 11
