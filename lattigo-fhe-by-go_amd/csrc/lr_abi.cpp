@@ -235,6 +235,7 @@ struct lr_ckks_plan {
     lr_decomposer *dec = nullptr;
     int max_batch = 0;
     Pool c2QiQ, c2QiP, poolPP, c2, c0, c1, c2x, q1, q2, permQ, permP;
+    Pool stageQ, stageP;   // N = 2^16: the extensions land here and the transforms go out of place (fused top stage, see ks_decompose)
 };
 
 // ------------------------------------------------------------------------------------------
@@ -1577,14 +1578,23 @@ int ks_decompose(lr_ckks_plan *pl, int level, int batch, const u64 *cx, long lon
     LR_TRY(pl->c2QiQ.ensure(cQ, (size_t)beta * dQ));
     LR_TRY(pl->c2.ensure(cQ, (size_t)batch * sQ));
     LR_TRY(pl->c2QiP.ensure(cQ, (size_t)beta * dP));
+    // N = 2^16: a forward transform whose input and output rows are disjoint computes its top stage while loading (one
+    // launch); in place it needs a separate streaming pass first.  The extensions therefore land in staging buffers of the
+    // same shape and the transforms write the pools the consumers read.
+    const bool staged = cQ->h.logN == 16 && cQ->use_asm && cQ->asm_fwd >= 0 && std::getenv("LR_NO_STAGING") == nullptr;
+    if (staged) {
+        LR_TRY(pl->stageQ.ensure(cQ, (size_t)beta * dQ));
+        LR_TRY(pl->stageP.ensure(cQ, (size_t)beta * dP));
+    }
+    u64 *const srcQ = staged ? pl->stageQ.d : pl->c2QiQ.d, *const srcP = staged ? pl->stageP.d : pl->c2QiP.d;
     Rows cxr{const_cast<u64 *>(cx), cx_stride, 0, 1};
     Rows c2r{pl->c2.d, sQ, 0, 1};
     LR_TRY(run_ntt(cQ, true, cxr, c2r, 0, 1, level + 1, batch));  // :1503
     int full = 0;   // leading digits that own exactly alpha limbs at this level: their transforms share one launch
     for (int i = 0; i < beta; ++i) {
-        u64 *dq = pl->c2QiQ.d + (long long)i * dQ, *dp = pl->c2QiP.d + (long long)i * dP;
+        u64 *dq = pl->c2QiQ.d + (long long)i * dQ;
         // decomposeAndSplitNTT, :1561-1591
-        LR_TRY(decompose_core(dec, level, i, c2r, batch, dq, sQ, dp, sP, true));
+        LR_TRY(decompose_core(dec, level, i, c2r, batch, srcQ + (long long)i * dQ, sQ, srcP + (long long)i * dP, sP, true));
         const int d0 = i * alpha;
         int d1 = d0 + dec->xalpha[i];
         if (d1 > level + 1) d1 = level + 1;
@@ -1595,22 +1605,22 @@ int ks_decompose(lr_ckks_plan *pl, int level, int batch, const u64 *cx, long lon
     }
     if (full > 0 && level + 1 - alpha > 0) {
         // limbs outside each digit's own block, all full digits at once (grid z = digit)
-        Rows all{pl->c2QiQ.d, sQ, 0, 1};
-        LR_TRY(run_ntt(cQ, false, all, all, 0, 1, level + 1 - alpha, full * batch, alpha, batch));
+        Rows in{srcQ, sQ, 0, 1}, all{pl->c2QiQ.d, sQ, 0, 1};
+        LR_TRY(run_ntt(cQ, false, in, all, 0, 1, level + 1 - alpha, full * batch, alpha, batch));
     }
     for (int i = full; i < beta; ++i) {
-        u64 *dq = pl->c2QiQ.d + (long long)i * dQ;
+        u64 *dq = pl->c2QiQ.d + (long long)i * dQ, *sq = srcQ + (long long)i * dQ;
         const int d0 = i * alpha;
         int d1 = d0 + dec->xalpha[i];
         if (d1 > level + 1) d1 = level + 1;
-        Rows lo{dq, sQ, 0, 1};
-        LR_TRY(run_ntt(cQ, false, lo, lo, 0, 1, d0, batch));                     // limbs below the digit
-        Rows hi{dq, sQ, d1, 1};
-        LR_TRY(run_ntt(cQ, false, hi, hi, d1, 1, level + 1 - d1, batch));        // limbs above the digit
+        Rows lo{dq, sQ, 0, 1}, lo_in{sq, sQ, 0, 1};
+        LR_TRY(run_ntt(cQ, false, lo_in, lo, 0, 1, d0, batch));                  // limbs below the digit
+        Rows hi{dq, sQ, d1, 1}, hi_in{sq, sQ, d1, 1};
+        LR_TRY(run_ntt(cQ, false, hi_in, hi, d1, 1, level + 1 - d1, batch));     // limbs above the digit
     }
     {
-        Rows pr{pl->c2QiP.d, sP, 0, 1};                                          // :1590, every digit's P rows
-        LR_TRY(run_ntt(cP, false, pr, pr, 0, 1, nP, beta * batch));
+        Rows pr{pl->c2QiP.d, sP, 0, 1}, pr_in{srcP, sP, 0, 1};                   // :1590, every digit's P rows
+        LR_TRY(run_ntt(cP, false, pr_in, pr, 0, 1, nP, beta * batch));
     }
     return LR_OK;
 }
@@ -1668,9 +1678,14 @@ int ks_accumulate(lr_ckks_plan *pl, int level, int batch, const u64 *digQ, const
         Rows pr{pool2P, sP, 0, 1};
         LR_TRY(run_ntt(cP, true, pr, pr, 0, 1, nP, 2 * batch));
         LR_TRY(bx->poolQ.ensure(cQ, (size_t)2 * batch * sQ));
-        LR_TRY(run_ext(cQ, bx->pq, nP, pr, 2 * batch, segment(bx->poolQ.d, sQ, 0, 0, level + 1), segment(nullptr, 0, 0, 0, 0)));
-        Rows qr{bx->poolQ.d, sQ, 0, 1};
-        LR_TRY(run_ntt(cQ, false, qr, qr, 0, 1, level + 1, 2 * batch));
+        u64 *ext_out = bx->poolQ.d;
+        if (cQ->h.logN == 16 && cQ->use_asm && cQ->asm_fwd >= 0 && std::getenv("LR_NO_STAGING") == nullptr) {
+            LR_TRY(pl->stageQ.ensure(cQ, (size_t)2 * batch * sQ));     // (the digits' staging area is free again)
+            ext_out = pl->stageQ.d;
+        }
+        LR_TRY(run_ext(cQ, bx->pq, nP, pr, 2 * batch, segment(ext_out, sQ, 0, 0, level + 1), segment(nullptr, 0, 0, 0, 0)));
+        Rows qr{bx->poolQ.d, sQ, 0, 1}, qr_in{ext_out, sQ, 0, 1};
+        LR_TRY(run_ntt(cQ, false, qr_in, qr, 0, 1, level + 1, 2 * batch));
     }
     for (int k = 0; k < 2; ++k) {
         u64 *pq = k == 0 ? p0 : p1;
