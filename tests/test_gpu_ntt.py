@@ -341,3 +341,31 @@ def test_fp64_bodies_are_selected(gpu_pkg, monkeypatch):
     monkeypatch.setenv("LR_NO_FP", "1")
     N, Q, _ = P.ckks_moduli("PN15QP880")
     assert ring.NewContextWithParams(N, Q).ntt_variants() == (2, 1)
+
+
+@pytest.mark.parametrize("scheme,name", [("ckks", n) for n in ("PN12QP109", "PN13QP218", "PN14QP438", "PN15QP880", "PN16QP1761")]
+                         + [("bfv", n) for n in ("PN12QP109", "PN13QP218", "PN14QP438", "PN15QP880")])
+def test_default_parameter_sets_full_size(gpu_pkg, oracle, scheme, name):
+    """every default parameter set of ckks/params.go:36-87 and bfv/params.go:47-88 at its full degree, all limbs of Q and P (and
+    QMul) in one context each: NTT of full-range input and InvNTT against the oracle (whatever kernel variant the moduli select)"""
+    P = gpu_pkg.params
+    if scheme == "ckks":
+        N, Q, Pm = P.ckks_moduli(name)
+        groups = [list(Q) + list(Pm)]
+    else:
+        N, Q, Pm, QMul = P.bfv_moduli(name)
+        groups = [list(Q) + list(Pm), list(QMul)]
+    for moduli in groups:
+        limbs = len(moduli)
+        ctx, oc = gpu_pkg.ring.NewContextWithParams(N, moduli), oracle.Context(N, moduli)
+        x = gpu_pkg.sampling.random_u64((1, limbs, N), seed=limbs)
+        red = np.array([[int(v) % q for v in x[0, i]] for i, q in enumerate(moduli)], dtype=np.uint64)
+        p, r = ctx.NewPoly(1).set(x), ctx.NewPoly(1)
+        ctx.NTT(p, r)
+        assert np.array_equal(r.get().reshape(1, limbs, N)[0], oc.ntt(red)), (name, ctx.ntt_variants())
+        ctx.InvNTT(r, r)
+        assert np.array_equal(r.get().reshape(1, limbs, N)[0], red), (name, ctx.ntt_variants())
+        y = np.stack([[x[0, i] % np.uint64(4 * q) for i, q in enumerate(moduli)]])
+        p.set(y)
+        ctx.InvNTT(p, r)
+        assert np.array_equal(r.get().reshape(1, limbs, N)[0], oc.intt(np.array([[int(v) % q for v in y[0, i]] for i, q in enumerate(moduli)], dtype=np.uint64)))
