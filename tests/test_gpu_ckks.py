@@ -156,3 +156,9 @@ def test_rotate_columns_pow2_chain(gpu_pkg, oracle):
         for i in (1, 4):
             want = oplan.permute_ntt(level, want, keys[i][0], okeys[i])
         assert np.array_equal(out[0].get()[b], want[0]) and np.array_equal(out[1].get()[b], want[1])
+
+
+def test_mulrelin_2p16_without_staging(gpu_pkg, oracle, monkeypatch):
+    """N = 2^16 with in-place forward transforms (separate top-stage pass) instead of the staged, fused ones"""
+    monkeypatch.setenv("LR_NO_STAGING", "1")
+    test_mulrelin_and_rescale(gpu_pkg, oracle, 16, 5, 2, 4)

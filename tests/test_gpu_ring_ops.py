@@ -423,3 +423,21 @@ def test_simple_scaling_reference_property(gpu_pkg, logn):
     got = p.get().reshape(len(moduli), N)[0]
     want = np.array([int(Fraction(2 * t * x + Q, 2 * Q)) % t for x in xs], dtype=np.uint64)
     assert np.array_equal(got, want)
+
+
+# ---- the alternative paths behind the environment switches of INTEGRATION.md section 7 stay verified ---------------------------
+@pytest.mark.parametrize("nq,np_,logn", [(16, 16, 12), (3, 18, 10), (18, 3, 11)])
+def test_modup_per_term_fallback(gpu_pkg, oracle, nq, np_, logn, monkeypatch):
+    monkeypatch.setenv("LR_EXT_NARROW", "1")
+    test_modup(gpu_pkg, oracle, nq, np_, logn)
+
+
+@pytest.mark.parametrize("logn", [10, 12, 13])
+def test_rescale_round_unfused_agrees(gpu_pkg, oracle, logn, monkeypatch):
+    """the rounding rescale with the constant folded into the subtract-multiply (default) and with the explicit shifted copies"""
+    for unfused in (False, True):
+        if unfused:
+            monkeypatch.setenv("LR_RESCALE_UNFUSED", "1")
+        else:
+            monkeypatch.delenv("LR_RESCALE_UNFUSED", raising=False)
+        test_rescale(gpu_pkg, oracle, "DivRoundByLastModulusNTT", logn)
