@@ -28,13 +28,17 @@ class Gen:
          2: q <  2^57, no corrections at all (15 stages x 4q of growth stay below 2^64);
          0: q <  2^61, U <- U - 4q (if U >= 4q) before every stage."""
 
-    def __init__(self, logn, mode=1, threads=1024, sub=False, fused=True, fp=False, dual=False):
+    def __init__(self, logn, mode=1, threads=1024, sub=False, fused=True, fp=False, dual=False, epi=False):
         assert logn in (12, 13, 14, 15) and mode in (0, 1, 2) and threads in (256, 512, 1024)
         # dual: the kernel carries two bodies behind one prologue (class Dual): `fp` = the FP64 body for moduli below 2^46
         # (error-free products by v_mul_f64 / v_fma_f64, quotients by v_rndne_f64, no lazy corrections: 8 instructions per
         # butterfly), otherwise the integer body of `mode`; the workgroup picks by its limb's entry in NttLaunch::fp_lp
         assert not fp or dual
-        self.fp, self.dual = fp, dual
+        # epi: the FP64 body ends in out = (x - NTT(in)) * c + plus (mod q) instead of out = NTT(in): the subtract-multiply of
+        # ModDownSplitedNTTPQ (ring_basis_extension.go:237-239) with the addition that follows it in MulRelin
+        # (ckks/evaluator.go:1103-1104), x / plus addressed like the output rows (NttLaunch::epi_*).  Launched on FP64 limbs only.
+        assert not epi or (dual and not sub)
+        self.fp, self.dual, self.epi = fp, dual, epi
         self.mark = None
         assert not sub or (logn == 15 and threads == 1024)
         self.fused = fused            # forward sub-block kernels: compute the top stage while loading (out of place only)
@@ -299,7 +303,7 @@ class Gen:
     def prologue(self):
         e, S_ = self.e, self
         logn, N = self.logn, self.N
-        self.c("kernel arguments (NttLaunch, 128 bytes)")
+        self.c("kernel arguments (NttLaunch, 168 bytes)")
         e("s_load_dwordx8", s(36, 8), self.KARG, 0)
         e("s_load_dwordx8", s(44, 8), self.KARG, 32)
         e("s_load_dwordx4", s(52, 4), self.KARG, 64)
@@ -821,20 +825,103 @@ class Gen:
         e("s_addc_u32", self.TMP.hi(), self.DST.hi(), 0)
         n = 8
         regs = [v(4 * i, 4) for i in range(n)]
-        for i in range(n):
-            e("ds_read_b128", regs[i], a0, offset=i * 1152)
-        for i in range(n):
-            r = regs[i]
-            e("s_waitcnt", "lgkmcnt(%d)" % (n - 1 - i))
-            self.zip_emit([(lambda ts, x=r.sub(0, 2): self.ops_canon(ts, x)), (lambda ts, x=r.sub(2, 2): self.ops_canon(ts, x))])
-            e("global_store_dwordx4", a2, r, self.TMP, hint="nt")
-            e("s_add_u32", self.TMP.lo(), self.TMP.lo(), 1024)
-            e("s_addc_u32", self.TMP.hi(), self.TMP.hi(), 0)
+        if self.fp and self.epi:
+            self.copy_out_epilogue(half, regs, a0, a2)
+        else:
+            for i in range(n):
+                e("ds_read_b128", regs[i], a0, offset=i * 1152)
+            for i in range(n):
+                r = regs[i]
+                e("s_waitcnt", "lgkmcnt(%d)" % (n - 1 - i))
+                self.zip_emit([(lambda ts, x=r.sub(0, 2): self.ops_canon(ts, x)), (lambda ts, x=r.sub(2, 2): self.ops_canon(ts, x))])
+                e("global_store_dwordx4", a2, r, self.TMP, hint="nt")
+                e("s_add_u32", self.TMP.lo(), self.TMP.lo(), 1024)
+                e("s_addc_u32", self.TMP.hi(), self.TMP.hi(), 0)
         if half + 1 < self.HALVES:
             e("s_add_u32", self.DST.lo(), self.DST.lo(), self.M * 8)
             e("s_addc_u32", self.DST.hi(), self.DST.hi(), 0)
             e("s_waitcnt", "lgkmcnt(0)")
             e("s_barrier")
+
+    def ops_epilogue(self, ts, Y, X, P, EC):
+        """Y (the transform's value, a lazy double) <- canonical ((x - Y) * c + plus) mod q; X, P: canonical 64-bit integers"""
+        ops = []
+        for R in (X, P):
+            ops += [("v_or_b32", R.hi(), 0x43300000, R.hi()),
+                    ("v_add_f64", R, R, Neg(self.MAGIC))]
+        ops += [("v_add_f64", Y, X, Neg(Y))]
+        ops += self.ops_modmul_fp(ts, Y, EC, dst=Y)
+        ops += [("v_add_f64", Y, Y, P)]
+        return ops + self.ops_canon_fp(ts, Y)
+
+    def copy_out_epilogue(self, half, regs, a0, a2):
+        """copy-out with the subtract-multiply-add epilogue: x and plus live at the output's offsets inside their own rows"""
+        e = self.e
+        sc = self.SC
+        K = 36                                       # the uniform-twiddle buffer is idle here: scratch SGPRs
+        e("s_load_dwordx8", s(K, 8), self.KARG, 128)          # epi_x, epi_x_stride, epi_plus, epi_plus_stride
+        e("s_load_dwordx2", s(K + 8, 2), self.KARG, 160)      # epi_consts
+        e("s_load_dwordx4", s(K + 12, 4), self.KARG, 40)      # out_limb0, out_limb_step, mod0, mod_step
+        e("s_waitcnt", "lgkmcnt(0)")
+        e("s_mul_i32", sc[0], self.WGX, s(K + 13))
+        e("s_add_u32", sc[0], sc[0], s(K + 12))               # output row
+        e("s_mul_i32", sc[1], self.WGX, s(K + 15))
+        e("s_add_u32", sc[1], sc[1], s(K + 14))               # modulus index
+        rows = []
+        for base, stride, dst in ((s(K, 2), s(K + 2, 2), s(K + 20, 2)), (s(K + 4, 2), s(K + 6, 2), s(K + 22, 2))):
+            e("s_mul_i32", self.TMP.lo(), self.WGY, stride.lo())
+            e("s_mul_hi_u32", self.TMP.hi(), self.WGY, stride.lo())
+            e("s_mul_i32", sc[3], self.WGY, stride.hi())
+            e("s_add_u32", self.TMP.hi(), self.TMP.hi(), sc[3])
+            e("s_lshl_b32", sc[3], sc[0], self.logn)
+            e("s_add_u32", self.TMP.lo(), self.TMP.lo(), sc[3])
+            e("s_addc_u32", self.TMP.hi(), self.TMP.hi(), 0)
+            e("s_lshl_b64", self.TMP, self.TMP, 3)
+            e("s_add_u32", dst.lo(), base.lo(), self.TMP.lo())
+            e("s_addc_u32", dst.hi(), base.hi(), self.TMP.hi())
+            # this wave's 8 KiB: (half * SPH + wave) * 8192 bytes into the row
+            e("s_lshl_b32", sc[3], self.WAVE, 13)
+            e("s_add_u32", sc[3], sc[3], half * self.SPH * 8192)
+            e("s_add_u32", dst.lo(), dst.lo(), sc[3])
+            e("s_addc_u32", dst.hi(), dst.hi(), 0)
+            rows.append(dst)
+        XR, PR = rows
+        e("s_lshl_b32", sc[3], sc[1], 4)
+        e("s_add_u32", self.TMP.lo(), s(K + 8), sc[3])
+        e("s_addc_u32", self.TMP.hi(), s(K + 9), 0)
+        e("s_load_dwordx4", s(K + 24, 4), self.TMP, 0)         # EpiLimb: c, c / q as doubles
+        e("s_waitcnt", "lgkmcnt(0)")                           # (scalar loads return out of order: no counting across them)
+        EC = tuple(s(K + 24 + i) for i in range(4))
+        # restore the store pointer (TMP was scratch): dst + wave * 8192
+        e("s_lshl_b32", sc[5], self.WAVE, 13)
+        e("s_add_u32", self.TMP.lo(), self.DST.lo(), sc[5])
+        e("s_addc_u32", self.TMP.hi(), self.DST.hi(), 0)
+        n = 8
+        for i in range(n):
+            e("ds_read_b128", regs[i], a0, offset=i * 1152)
+        XQ = [v(self.tw_base + 8 * i, 4) for i in range(4)]
+        PQ = [v(self.tw_base + 8 * i + 4, 4) for i in range(4)]
+        for batch in range(2):
+            for i in range(4):
+                k = 4 * batch + i
+                e("global_load_dwordx4", XQ[i], a2, XR, offset=(k % 4) * 1024, hint="nt")
+                e("global_load_dwordx4", PQ[i], a2, PR, offset=(k % 4) * 1024, hint="nt")
+            for ptr in (XR, PR):
+                e("s_add_u32", ptr.lo(), ptr.lo(), 4096)
+                e("s_addc_u32", ptr.hi(), ptr.hi(), 0)
+            for i in range(4):
+                k = 4 * batch + i
+                r = regs[k]
+                # loads return in order: at most the 2*(3-i) younger loads of this batch may still be out (stores issued
+                # in between can only make the wait longer)
+                e("s_waitcnt", "vmcnt(%d) lgkmcnt(%d)" % (2 * (3 - i), n - 1 - k))
+                self.zip_emit([(lambda ts, y=r.sub(0, 2), x=XQ[i].sub(0, 2), pp=PQ[i].sub(0, 2): self.ops_epilogue(ts, y, x, pp, EC)),
+                               (lambda ts, y=r.sub(2, 2), x=XQ[i].sub(2, 2), pp=PQ[i].sub(2, 2): self.ops_epilogue(ts, y, x, pp, EC))])
+            for i in range(4):
+                k = 4 * batch + i
+                e("global_store_dwordx4", a2, regs[k], self.TMP, hint="nt")
+                e("s_add_u32", self.TMP.lo(), self.TMP.lo(), 1024)
+                e("s_addc_u32", self.TMP.hi(), self.TMP.hi(), 0)
 
     def build(self):
         self.prologue()
@@ -854,7 +941,7 @@ class Dual:
 
     def __init__(self, make):
         self.gf, self.gi = make(True), make(False)
-        for k in ("logn", "T", "SPH", "A", "N", "sub", "WGX", "WGY"):
+        for k in ("logn", "T", "SPH", "A", "N", "sub", "WGX", "WGY", "epi"):
             setattr(self, k, getattr(self.gf, k))
         self.p = None
 
@@ -892,7 +979,7 @@ def kernel_text_for(g, name):
   .amdhsa_kernel {name}
     .amdhsa_group_segment_fixed_size {lds}
     .amdhsa_private_segment_fixed_size 0
-    .amdhsa_kernarg_size 128
+    .amdhsa_kernarg_size 168
     .amdhsa_user_sgpr_count 2
     .amdhsa_user_sgpr_kernarg_segment_ptr 1
     .amdhsa_system_sgpr_workgroup_id_x 1
@@ -915,11 +1002,11 @@ def kernel_text_for(g, name):
 amdhsa.kernels:
   - .args:
       - .offset: 0
-        .size: 128
+        .size: 168
         .value_kind: by_value
     .group_segment_fixed_size: {lds}
     .kernarg_segment_align: 8
-    .kernarg_segment_size: 128
+    .kernarg_segment_size: 168
     .max_flat_workgroup_size: {threads}
     .name: {name}
     .private_segment_fixed_size: 0
@@ -1009,8 +1096,22 @@ def emulate(gen, inverse=False, q=None, geom=None):
     place(tw, A_TW)
     place(twf, A_TWF)
     fp_tables(np, q, n_inv, tw, twf, lambda a, b, c: (place(a, A_FTW), place(b, A_FTWF), place(c, A_FLP)))
-    karg = np.zeros(16, dtype=np.uint64)
+    karg = np.zeros(21, dtype=np.uint64)
     karg[13], karg[14], karg[15] = A_FTW - A_TW, A_FTWF - A_TWF, A_FLP
+    if getattr(gen, "epi", False) and q < FP_LIMIT:
+        # x and plus: canonical polys laid out like the output; c: a random constant in (w, w / q) form
+        rng = np.random.default_rng(7)
+        xe = (rng.integers(0, 1 << 62, N, dtype=np.uint64) % np.uint64(q)).astype(np.uint64)
+        pe = (rng.integers(0, 1 << 62, N, dtype=np.uint64) % np.uint64(q)).astype(np.uint64)
+        xe[:3], pe[:3] = [0, q - 1, q - 1], [q - 1, 0, q - 1]
+        ce = int(rng.integers(1, q))
+        A_X, A_P, A_EC = mem.size * 4, mem.size * 4 + span, mem.size * 4 + 2 * span
+        mem = np.concatenate([mem, np.zeros((2 * span + 0x1000) // 4, dtype=np.uint32)])
+        place(xe, A_X + where)
+        place(pe, A_P + where)
+        place(np.array([ce, np.float64(ce) / np.float64(q)], dtype=np.float64), A_EC)      # modulus index 0
+        karg[16], karg[17], karg[18], karg[19], karg[20] = A_X, rows * N, A_P, rows * N, A_EC
+        want = np.array([((int(a) - int(b)) * ce + int(c)) % q for a, b, c in zip(xe, want, pe)], dtype=np.uint64)
     karg[0], karg[1], karg[2], karg[3] = A_IN, A_OUT, rows * N, rows * N
     karg[4] = 0 | (1 << 32)        # in_limb0, in_limb_step
     karg[5] = 0 | (1 << 32)        # out_limb0, out_limb_step
@@ -1219,6 +1320,14 @@ def selftest(logn, inverse=False, threads=1024):
         ok = ok and good
         print("%s logN=%d T=%d dual q=%d (%d bits): %s; %s" % ("inverse" if inverse else "forward", logn, threads, q, q.bit_length(),
                                                         "bit-exact vs oracle" if good else "MISMATCH", info), flush=True)
+    if not inverse:
+        # the epilogue kernels: out = (x - NTT(in)) * c + plus on the FP64 body, plain and with the digit-group addressing
+        for q in fp_test_moduli(logn)[:2]:
+            for geom in (None, (2, 1, 1, 2, 3, 6)):
+                good, info = emulate(Dual(lambda fp: Gen(logn, 2, threads, fp=fp, dual=True, epi=True)), False, q, geom)
+                ok = ok and good
+                print("forward logN=%d T=%d epilogue q=%d (%d bits): %s; %s" % (logn, threads, q, q.bit_length(),
+                                                                          "bit-exact vs oracle" if good else "MISMATCH", info), flush=True)
     return ok
 
 
@@ -1267,6 +1376,8 @@ if __name__ == "__main__":
     def make(logn_, threads_, **kw):
         if mode == 3:
             return Dual(lambda fp: Gen(logn_, 2, threads_, fp=fp, dual=True, **kw))
+        if mode == 4:   # mode 3 whose FP64 body ends in the subtract-multiply-add epilogue
+            return Dual(lambda fp: Gen(logn_, 2, threads_, fp=fp, dual=True, epi=True, **kw))
         return Gen(logn_, mode, threads_, **kw)
 
     if logn == 16:      # the 2^15 sub-block kernels of N = 2^16: "s" with the fused top stage, "p" plain

@@ -37,12 +37,16 @@ gen_sub fwd 16s 3 & gpids+=($!); gen_sub fwd 16p 3 plain & gpids+=($!)
 gen_one inv 14 3 & gpids+=($!); gen_one inv 15 3 & gpids+=($!)
 gen_one inv 14 3 512 & gpids+=($!); gen_one inv 13 3 512 & gpids+=($!); gen_one inv 12 3 256 & gpids+=($!)
 gen_sub inv 16s 3 & gpids+=($!)
+# mode 4: the dual forward kernels with the subtract-multiply-add epilogue on the FP64 body (ModDown inside the key switch)
+gen_one fwd 14 4 & gpids+=($!); gen_one fwd 15 4 & gpids+=($!)
+gen_one fwd 14 4 512 & gpids+=($!); gen_one fwd 13 4 256 & gpids+=($!); gen_one fwd 12 4 256 & gpids+=($!)
 for p in "${gpids[@]}"; do wait $p; done
 python3 - <<'PY'
 out = ['struct lr_asm_blob { const char *name; const unsigned char *data; unsigned long size; };']
 names = [("fwd", n, m) for n in (14, 15) for m in (0, 1, 2)] + [("inv", n, m) for n in (14, 15) for m in (0, 1)]
 names += [("fwd", n, m) for n in ("12x", "13x", "14x", "16s", "16p") for m in (0, 1, 2)] + [("inv", n, m) for n in ("12x", "13x", "14x", "16s") for m in (0, 1)]
 names += [("fwd", n, 3) for n in (14, 15, "12x", "13x", "14x", "16s", "16p")] + [("inv", n, 3) for n in (14, 15, "12x", "13x", "14x", "16s")]
+names += [("fwd", n, 4) for n in (14, 15, "12x", "13x", "14x")]
 for k, n, m in names:
     data = open("build/ntt_%s%s_m%d.hsaco" % (k, n, m), "rb").read()
     out.append('static const unsigned char blob_%s%s_m%d[] __attribute__((aligned(4096))) = {' % (k, n, m))

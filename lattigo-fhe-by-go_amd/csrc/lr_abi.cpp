@@ -201,8 +201,12 @@ struct lr_bext {
     DevModup qp, pq;
     std::vector<u64> moddown_pq, moddown_qp;  // host copies (Montgomery form)
     u64 *d_moddown_pq = nullptr, *d_moddown_qp = nullptr;
+    // the ModDown P->Q constants once more for the epilogue of the FP64 forward kernels: plain value c = MRed(moddown_pq[i], 1)
+    // and RN(c / q_i) as doubles (zero for the limbs of 2^46 and more, which stay on the separate subtract-multiply)
+    EpiLimb *d_moddown_pq_epi = nullptr;
     Pool poolQ, poolP;
     ~lr_bext() {
+        if (d_moddown_pq_epi) (void)hipFree(d_moddown_pq_epi);
         if (d_moddown_pq) (void)hipFree(d_moddown_pq);
         if (d_moddown_qp) (void)hipFree(d_moddown_qp);
     }
@@ -235,6 +239,7 @@ struct lr_ckks_plan {
     lr_decomposer *dec = nullptr;
     int max_batch = 0;
     Pool c2QiQ, c2QiP, poolPP, c2, c0, c1, c2x, q1, q2, permQ, permP;
+    Pool zerosQ;           // one poly of zeros over Q: the `plus` operand of the NTT epilogue where a caller has none
     Pool stageQ, stageP;   // N = 2^16: the extensions land here and the transforms go out of place (fused top stage, see ks_decompose)
 };
 
@@ -671,8 +676,23 @@ struct Rows {  // a strided view of rows inside a batch buffer
 };
 
 // hole/group: digit groups of NttLaunch (the polys of group g skip the items [g*hole, (g+1)*hole))
+// epilogue of the forward FP64 kernels (NttLaunch::epi_*); every limb of the launch must be below 2^46 (ntt_epilogue_ok)
+struct NttEpilogue {
+    const u64 *x;
+    long long x_stride;
+    const u64 *plus;
+    long long plus_stride;
+    const EpiLimb *consts;
+};
+
+bool ntt_epilogue_ok(const lr_context *c) {
+    const unsigned logn = c->h.logN;
+    return c->use_asm && c->asm_fwd == 3 && logn >= 12 && logn <= 15 && ntt_asm_available((int)logn) &&
+           std::getenv("LR_NO_EPILOGUE") == nullptr;
+}
+
 int run_ntt(lr_context *c, bool inverse, Rows in, Rows out, int mod0, int mod_step, int count, int batch, int hole = 0,
-            int group = 0) {
+            int group = 0, const NttEpilogue *epi = nullptr) {
     if (count <= 0 || batch <= 0) return LR_OK;
     if (hole > 0 && (group <= 0 || batch % group != 0)) return fail(LR_ERR_ARG, "digit groups must divide the batch");
     const unsigned logn = c->h.logN;
@@ -701,6 +721,9 @@ int run_ntt(lr_context *c, bool inverse, Rows in, Rows out, int mod0, int mod_st
     const int variant = inverse ? c->asm_inv : c->asm_fwd;
     a.fp_tw_delta = a.fp_fin_delta = 0;
     a.fp_lp = nullptr;
+    a.epi_x = a.epi_plus = nullptr;
+    a.epi_x_stride = a.epi_plus_stride = 0;
+    a.epi_consts = nullptr;
     if (variant == 3) {
         a.fp_tw_delta = (const char *)(inverse ? c->d_inv_fp : c->d_fwd_fp) - (const char *)a.tw;
         a.fp_fin_delta = (const char *)(inverse ? c->d_inv_fin_fp : c->d_fwd_fin_fp) - (const char *)a.tw_fin;
@@ -730,6 +753,16 @@ int run_ntt(lr_context *c, bool inverse, Rows in, Rows out, int mod0, int mod_st
         top.in_limb0 = a.out_limb0;
         top.in_limb_step = a.out_limb_step;
         LR_HIP(launch_ntt_top(top, 1, c->stream));
+        return LR_OK;
+    }
+    if (epi) {
+        if (inverse || hole > 0 || !ntt_epilogue_ok(c)) return fail(LR_ERR_ARG, "NTT epilogue: not available for this launch");
+        a.epi_x = epi->x;
+        a.epi_x_stride = epi->x_stride;
+        a.epi_plus = epi->plus;
+        a.epi_plus_stride = epi->plus_stride;
+        a.epi_consts = epi->consts;
+        LR_HIP(launch_ntt_asm(a, (int)logn, 0, 4, c->stream));
         return LR_OK;
     }
     if (logn != 16 && variant >= 0 && c->use_asm && (hole > 0 ? group : batch) <= 65535 && (hole == 0 || batch / group <= 65535) &&
@@ -982,7 +1015,10 @@ ExtSegment segment(u64 *out, long long stride, int limb0, int col0, int count) {
 
 int run_submul(lr_context *c, int limbs, int batch, const u64 *a, long long a_stride, const u64 *b, long long b_stride,
                long long b_row_stride, u64 *out, long long out_stride, const u64 *d_consts, bool reduce_b,
-               const LimbScalars *addend, const u64 *plus = nullptr, long long plus_stride = 0, const LimbScalars *post = nullptr) {
+               const LimbScalars *addend, const u64 *plus = nullptr, long long plus_stride = 0, const LimbScalars *post = nullptr,
+               int limb0 = 0) {
+    // limb0 > 0: the launch covers the limbs limb0 .. limb0 + limbs - 1; the row pointers (a, b, out, plus) and d_consts are
+    // passed already advanced to that limb, the modulus table is advanced here (addend / post are not supported then)
     SubMulLaunch L;
     L.plus = plus;
     L.plus_stride = plus_stride;
@@ -997,7 +1033,7 @@ int run_submul(lr_context *c, int limbs, int batch, const u64 *a, long long a_st
     L.out_stride = out_stride;
     L.b_row_stride = b_row_stride;
     L.n = (int)c->h.N;
-    L.lp = c->d_lp;
+    L.lp = c->d_lp + limb0;
     L.consts = d_consts;
     L.reduce_b = reduce_b ? 1 : 0;
     if (addend) L.addend = *addend;
@@ -1029,6 +1065,14 @@ extern "C" int lr_bext_create(lr_context *cQ, lr_context *cP, lr_bext **out) {
     b->moddown_qp = build_moddown(cP->h, cQ->h);  // :67
     LR_TRY(to_device(&b->d_moddown_pq, b->moddown_pq.data(), b->moddown_pq.size()));
     LR_TRY(to_device(&b->d_moddown_qp, b->moddown_qp.data(), b->moddown_qp.size()));
+    {
+        std::vector<EpiLimb> ec(cQ->h.L());
+        for (int i = 0; i < cQ->h.L(); ++i) {
+            const u64 q = cQ->h.q[i], cc = inv_mform(b->moddown_pq[i], q, cQ->h.mred[i]);
+            ec[i] = q < kFpLimit ? EpiLimb{(double)cc, (double)cc / (double)q} : EpiLimb{0.0, 0.0};
+        }
+        LR_TRY(to_device(&b->d_moddown_pq_epi, ec.data(), ec.size()));
+    }
     *out = b.release();
     return LR_OK;
 }
@@ -1685,6 +1729,45 @@ int ks_accumulate(lr_ckks_plan *pl, int level, int batch, const u64 *digQ, const
         }
         LR_TRY(run_ext(cQ, bx->pq, nP, pr, 2 * batch, segment(ext_out, sQ, 0, 0, level + 1), segment(nullptr, 0, 0, 0, 0)));
         Rows qr{bx->poolQ.d, sQ, 0, 1}, qr_in{ext_out, sQ, 0, 1};
+        if (fin && ntt_epilogue_ok(cQ)) {
+            // the subtract-multiply and the addition of MulRelin / the rotations inside the forward transform's copy-out, for
+            // every run of limbs below 2^46 (FP64 body); the other limbs keep the separate pass
+            const long long n64 = (long long)n;
+            const bool need_zeros = !fin->plus0 || !fin->plus1;
+            if (need_zeros && pl->zerosQ.words < (size_t)sQ) {
+                LR_TRY(pl->zerosQ.ensure(cQ, (size_t)sQ));
+                LR_HIP(hipMemsetAsync(pl->zerosQ.d, 0, (size_t)sQ * sizeof(u64), cQ->stream));
+            }
+            int l0 = 0;
+            while (l0 <= level) {
+                const bool fpc = cQ->h.q[l0] < kFpLimit;
+                int l1 = l0 + 1;
+                while (l1 <= level && (cQ->h.q[l1] < kFpLimit) == fpc) ++l1;
+                if (fpc) {
+                    for (int k = 0; k < 2; ++k) {
+                        Rows src{ext_out + (long long)k * batch * sQ, sQ, l0, 1};
+                        Rows dst{k == 0 ? fin->out0 : fin->out1, fin->out_stride, l0, 1};
+                        const u64 *plus = k == 0 ? fin->plus0 : fin->plus1;
+                        const NttEpilogue ep{k == 0 ? p0 : p1, k == 0 ? p0_stride : p1_stride, plus ? plus : pl->zerosQ.d,
+                                             plus ? fin->plus_stride : 0, bx->d_moddown_pq_epi};
+                        LR_TRY(run_ntt(cQ, false, src, dst, l0, 1, l1 - l0, batch, 0, 0, &ep));
+                    }
+                } else {
+                    Rows src{ext_out, sQ, l0, 1}, dst{bx->poolQ.d, sQ, l0, 1};
+                    LR_TRY(run_ntt(cQ, false, src, dst, l0, 1, l1 - l0, 2 * batch));
+                    for (int k = 0; k < 2; ++k) {
+                        const u64 *pq = (k == 0 ? p0 : p1) + l0 * n64;
+                        const u64 *ext = bx->poolQ.d + (long long)k * batch * sQ + l0 * n64;
+                        const u64 *plus = k == 0 ? fin->plus0 : fin->plus1;
+                        LR_TRY(run_submul(cQ, l1 - l0, batch, pq, k == 0 ? p0_stride : p1_stride, ext, sQ, n64,
+                                          (k == 0 ? fin->out0 : fin->out1) + l0 * n64, fin->out_stride, bx->d_moddown_pq + l0, false,
+                                          nullptr, plus ? plus + l0 * n64 : nullptr, fin->plus_stride, nullptr, l0));
+                    }
+                }
+                l0 = l1;
+            }
+            return LR_OK;
+        }
         LR_TRY(run_ntt(cQ, false, qr_in, qr, 0, 1, level + 1, 2 * batch));
     }
     for (int k = 0; k < 2; ++k) {

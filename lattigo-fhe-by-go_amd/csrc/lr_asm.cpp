@@ -89,7 +89,7 @@ hipError_t launch_ntt_asm(const NttLaunch &a, int logn, int inverse, int variant
         gz = (unsigned)(a.batch / a.group);
     }
     const unsigned threads = !x ? 1024 : (logn == 12 || (logn == 13 && !inverse)) ? 256 : 512;
-    if (variant == 3) return hipModuleLaunchKernel(it->second, gy, (unsigned)a.n_items, gz, threads, 1, 1, 0, stream, nullptr, extra);
+    if (variant >= 3) return hipModuleLaunchKernel(it->second, gy, (unsigned)a.n_items, gz, threads, 1, 1, 0, stream, nullptr, extra);
     return hipModuleLaunchKernel(it->second, (unsigned)a.n_items, gy, gz, threads, 1, 1, 0, stream, nullptr, extra);
 }
 

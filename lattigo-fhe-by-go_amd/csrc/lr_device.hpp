@@ -36,6 +36,8 @@ struct FpLimb {
     double n_inv, n_inv_q;      // N^-1 mod q and RN(n_inv / q): the scaling of the inverse transform
 };
 
+struct EpiLimb { double c, c_over_q; };
+
 // Addressing of one NTT launch.  Work item (b, i): batch element b, i-th limb of the launch.
 struct NttLaunch {
     const u64 *in;
@@ -61,8 +63,15 @@ struct NttLaunch {
     // doubles in tables laid out exactly like tw / tw_fin, found at tw + fp_tw_delta / tw_fin + fp_fin_delta (bytes)
     long long fp_tw_delta, fp_fin_delta;
     const FpLimb *fp_lp;        // [L], or null for every other kernel
+    // epilogue kernels ("m4", forward, FP64 limbs only): out = (x - NTT(in)) * c + plus (mod q), x and plus laid out like the
+    // output rows (row = out_limb0 + i * out_limb_step) with their own strides between polys
+    const u64 *epi_x;
+    long long epi_x_stride;
+    const u64 *epi_plus;
+    long long epi_plus_stride;
+    const EpiLimb *epi_consts;  // [L]: c and RN(c / q) as doubles, indexed like lp
 };
-static_assert(sizeof(NttLaunch) == 128, "NttLaunch layout is shared with asmgen/gen_ntt.py (fields are read at fixed offsets)");
+static_assert(sizeof(NttLaunch) == 168, "NttLaunch layout is shared with asmgen/gen_ntt.py (fields are read at fixed offsets)");
 
 // ---- coefficient-wise launches (lr_ewise.hip) ----
 struct EwiseLaunch {
