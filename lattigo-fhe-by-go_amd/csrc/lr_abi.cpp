@@ -88,6 +88,7 @@ struct lr_context {
     // DivRoundByLastModulusNTT: per level, -(pHalfNegQi[i] * NTT_i(1 + X + ... + X^(N-1))) * rescaleParams[i] for i < level,
     // [level][N], built on first use (rescale_round_table)
     std::map<int, u64 *> rescale_round_plus;
+    std::map<int, EpiLimb *> rescale_epi;       // per level: rescaleParams as (c, c / q) doubles for the NTT epilogue
     std::mutex rescale_mu;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int ntt_mode = 0;           // lazy-correction cadence allowed by the largest modulus (lr_ntt.hip)
@@ -424,6 +425,8 @@ extern "C" int lr_context_destroy(lr_context *c) {
                     (void *)c->d_fwd_fp, (void *)c->d_inv_fp, (void *)c->d_fwd_fin_fp, (void *)c->d_inv_fin_fp, (void *)c->d_fp_lp})
         if (p) (void)hipFree(p);
     for (auto &kv : c->rescale_round_plus)
+        if (kv.second) (void)hipFree(kv.second);
+    for (auto &kv : c->rescale_epi)
         if (kv.second) (void)hipFree(kv.second);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -1457,6 +1460,16 @@ int rescale_round_table(lr_context *c, int level, const u64 **out) {
     // table = MRed(0 + (q - NTT(a_i * ones)), rescaleParams[i])
     LR_TRY(run_submul(c, level, 1, table, words, c->scratch, words, (long long)n, table, words,
                       c->d_rescale + (size_t)(level - 1) * c->h.L(), false, nullptr));
+    {
+        std::vector<EpiLimb> ec(c->h.L());
+        for (int i = 0; i < level; ++i) {
+            const u64 q = c->h.q[i], cc = inv_mform(c->h.rescale[(size_t)(level - 1) * c->h.L() + i], q, c->h.mred[i]);
+            ec[i] = q < kFpLimit ? EpiLimb{(double)cc, (double)cc / (double)q} : EpiLimb{0.0, 0.0};
+        }
+        EpiLimb *d = nullptr;
+        LR_TRY(to_device(&d, ec.data(), ec.size()));
+        c->rescale_epi[level] = d;
+    }
     *out = table;
     return LR_OK;
 }
@@ -1481,6 +1494,31 @@ int rescale_ntt_domain(lr_context *c, lr_poly *p0, bool round) {
         std::memset(&L.adds, 0, sizeof(L.adds));
         L.adds.v[0] = phalf;
         LR_HIP(launch_rowadd(L, 1, batch, c->stream));            // :87-89
+    }
+    if (round && plus && ntt_epilogue_ok(c)) {
+        // (x - NTT_i(t)) * rescaleParams[i] + plus inside the forward transform's copy-out for the runs of limbs below 2^46
+        const EpiLimb *ec = c->rescale_epi[level];
+        const long long n64 = (long long)n;
+        int l0 = 0;
+        while (l0 < level) {
+            const bool fpc = c->h.q[l0] < kFpLimit;
+            int l1 = l0 + 1;
+            while (l1 < level && (c->h.q[l1] < kFpLimit) == fpc) ++l1;
+            if (fpc) {
+                const NttEpilogue ep{p0->d, p0->stride(), plus, 0, ec};
+                Rows dst{p0->d, p0->stride(), l0, 1};
+                LR_TRY(run_ntt(c, false, last, dst, l0, 1, l1 - l0, batch, 0, 0, &ep));
+            } else {
+                Rows dst{c->scratch, tmp_stride, l0, 1};
+                LR_TRY(run_ntt(c, false, last, dst, l0, 1, l1 - l0, batch));
+                LR_TRY(run_submul(c, l1 - l0, batch, p0->d + l0 * n64, p0->stride(), c->scratch + l0 * n64, tmp_stride, n64,
+                                  p0->d + l0 * n64, p0->stride(), c->d_rescale + (size_t)(level - 1) * c->h.L() + l0, false, nullptr,
+                                  plus + l0 * n64, 0, nullptr, l0));
+            }
+            l0 = l1;
+        }
+        p0->limbs = level;
+        return LR_OK;
     }
     if (round && plus) {
         LR_TRY(run_ntt(c, false, last, tmp, 0, 1, level, batch));  // NTT_i(t); the shift by pHalfNegQi[i] rides in `plus`

@@ -162,3 +162,10 @@ def test_mulrelin_2p16_without_staging(gpu_pkg, oracle, monkeypatch):
     """N = 2^16 with in-place forward transforms (separate top-stage pass) instead of the staged, fused ones"""
     monkeypatch.setenv("LR_NO_STAGING", "1")
     test_mulrelin_and_rescale(gpu_pkg, oracle, 16, 5, 2, 4)
+
+
+@pytest.mark.parametrize("logn,nq,np_,level", [(12, 18, 3, 17), (15, 5, 2, 4)])
+def test_mulrelin_and_rescale_without_epilogue(gpu_pkg, oracle, logn, nq, np_, level, monkeypatch):
+    """ModDown and the rounding rescale with the separate subtract-multiply pass instead of the forward kernels' epilogue"""
+    monkeypatch.setenv("LR_NO_EPILOGUE", "1")
+    test_mulrelin_and_rescale(gpu_pkg, oracle, logn, nq, np_, level)
