@@ -1767,11 +1767,16 @@ int ks_accumulate(lr_ckks_plan *pl, int level, int batch, const u64 *digQ, const
         }
         LR_TRY(run_ext(cQ, bx->pq, nP, pr, 2 * batch, segment(ext_out, sQ, 0, 0, level + 1), segment(nullptr, 0, 0, 0, 0)));
         Rows qr{bx->poolQ.d, sQ, 0, 1}, qr_in{ext_out, sQ, 0, 1};
-        if (fin && ntt_epilogue_ok(cQ)) {
+        if (ntt_epilogue_ok(cQ)) {
             // the subtract-multiply and the addition of MulRelin / the rotations inside the forward transform's copy-out, for
             // every run of limbs below 2^46 (FP64 body); the other limbs keep the separate pass
             const long long n64 = (long long)n;
-            const bool need_zeros = !fin->plus0 || !fin->plus1;
+            // without `fin` (plain SwitchKeysInPlace) the results replace p0 / p1 and nothing is added
+            u64 *const outs[2] = {fin ? fin->out0 : p0, fin ? fin->out1 : p1};
+            const long long out_strides[2] = {fin ? fin->out_stride : p0_stride, fin ? fin->out_stride : p1_stride};
+            const u64 *const pluses[2] = {fin ? fin->plus0 : nullptr, fin ? fin->plus1 : nullptr};
+            const long long plus_stride = fin ? fin->plus_stride : 0;
+            const bool need_zeros = !pluses[0] || !pluses[1];
             if (need_zeros && pl->zerosQ.words < (size_t)sQ) {
                 LR_TRY(pl->zerosQ.ensure(cQ, (size_t)sQ));
                 LR_HIP(hipMemsetAsync(pl->zerosQ.d, 0, (size_t)sQ * sizeof(u64), cQ->stream));
@@ -1784,10 +1789,10 @@ int ks_accumulate(lr_ckks_plan *pl, int level, int batch, const u64 *digQ, const
                 if (fpc) {
                     for (int k = 0; k < 2; ++k) {
                         Rows src{ext_out + (long long)k * batch * sQ, sQ, l0, 1};
-                        Rows dst{k == 0 ? fin->out0 : fin->out1, fin->out_stride, l0, 1};
-                        const u64 *plus = k == 0 ? fin->plus0 : fin->plus1;
+                        Rows dst{outs[k], out_strides[k], l0, 1};
+                        const u64 *plus = pluses[k];
                         const NttEpilogue ep{k == 0 ? p0 : p1, k == 0 ? p0_stride : p1_stride, plus ? plus : pl->zerosQ.d,
-                                             plus ? fin->plus_stride : 0, bx->d_moddown_pq_epi};
+                                             plus ? plus_stride : 0, bx->d_moddown_pq_epi};
                         LR_TRY(run_ntt(cQ, false, src, dst, l0, 1, l1 - l0, batch, 0, 0, &ep));
                     }
                 } else {
@@ -1796,10 +1801,10 @@ int ks_accumulate(lr_ckks_plan *pl, int level, int batch, const u64 *digQ, const
                     for (int k = 0; k < 2; ++k) {
                         const u64 *pq = (k == 0 ? p0 : p1) + l0 * n64;
                         const u64 *ext = bx->poolQ.d + (long long)k * batch * sQ + l0 * n64;
-                        const u64 *plus = k == 0 ? fin->plus0 : fin->plus1;
+                        const u64 *plus = pluses[k];
                         LR_TRY(run_submul(cQ, l1 - l0, batch, pq, k == 0 ? p0_stride : p1_stride, ext, sQ, n64,
-                                          (k == 0 ? fin->out0 : fin->out1) + l0 * n64, fin->out_stride, bx->d_moddown_pq + l0, false,
-                                          nullptr, plus ? plus + l0 * n64 : nullptr, fin->plus_stride, nullptr, l0));
+                                          outs[k] + l0 * n64, out_strides[k], bx->d_moddown_pq + l0, false,
+                                          nullptr, plus ? plus + l0 * n64 : nullptr, plus_stride, nullptr, l0));
                     }
                 }
                 l0 = l1;
