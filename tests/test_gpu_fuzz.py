@@ -153,3 +153,41 @@ def test_dual_kernel_fuzz(gpu_pkg, oracle, seed):
     got = px.get().reshape(batch, limbs, N)
     for b in range(batch):
         assert np.array_equal(got[b, :level + 1], red(x, b)[:level + 1]), ("round trip", logn, moduli, level, b)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_mulrelin_rescale_fuzz(gpu_pkg, oracle, seed):
+    """MulRelin followed by Rescale at random levels, limb counts and batches on the CKKS default moduli (dual kernels, epilogue
+    kernels where the limbs allow, staging at N = 2^16) against the oracle's restatement of the same ring calls"""
+    rng = np.random.default_rng(5000 + seed)
+    logn = 12 + seed % 5
+    N = 1 << logn
+    _, Qf, Pf = gpu_pkg.params.ckks_moduli("PN16QP1761" if logn == 16 else "PN15QP880")
+    nq, np_ = int(rng.integers(3, 9)), int(rng.integers(1, 4))
+    Q, P = Qf[:nq], Pf[:np_]
+    level = int(rng.integers(1, nq))
+    batch = int(rng.integers(1, 4))
+    ring = gpu_pkg.ring
+    cQ, cP = ring.NewContextWithParams(N, Q), ring.NewContextWithParams(N, P)
+    plan = ring.CkksPlan(cQ, cP, batch)
+    oplan = oracle.CkksPlan(oracle.Context(N, Q), oracle.Context(N, P))
+    beta = -(-nq // np_)
+    evk = gpu_pkg.sampling.uniform_poly(Q + P, N, 2 * beta, seed=seed + 70)
+    pevk = plan.NewSwitchingKey().set(evk)
+    mk = lambda s: gpu_pkg.sampling.uniform_poly(Q[:level + 1], N, batch, seed=s).reshape(batch, level + 1, N)
+    a0, a1, b0, b1 = mk(1), mk(2), mk(3), mk(4)
+    P_ = lambda x: cQ.NewPolyLvl(level, batch).set(x)
+    out = (cQ.NewPolyLvl(level, batch), cQ.NewPolyLvl(level, batch))
+    plan.MulRelin(level, (P_(a0), P_(a1)), (P_(b0), P_(b1)), pevk, out)
+    g0, g1 = out[0].get().reshape(batch, level + 1, N), out[1].get().reshape(batch, level + 1, N)
+    wants = []
+    for b in range(batch):
+        want = oplan.mulrelin(level, np.stack([a0[b], a1[b]]), np.stack([b0[b], b1[b]]), evk.reshape(beta, 2, nq + np_, N))
+        wants.append(want)
+        assert np.array_equal(g0[b], want[0]) and np.array_equal(g1[b], want[1]), ("mulrelin", logn, nq, np_, level, b)
+    plan.Rescale(out)
+    oc = oracle.Context(N, Q[:level + 1])
+    r0, r1 = out[0].get().reshape(batch, level, N), out[1].get().reshape(batch, level, N)
+    for b in range(batch):
+        for k, got in ((0, r0), (1, r1)):
+            assert np.array_equal(got[b], oc.rescale_op("oc_div_round_by_last_modulus_ntt", wants[b][k])), ("rescale", logn, level, b, k)
