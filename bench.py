@@ -125,7 +125,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the InvNTT / MulCoeffsMontgomery / ModUp timings")
     ap.add_argument("--no-ckks", action="store_true", help="skip the CKKS MulRelin leg")
-    ap.add_argument("--ckks-batch", type=int, default=64)
+    ap.add_argument("--ckks-batch", type=int, default=128)
     args = ap.parse_args()
 
     import numpy as np
