@@ -8,7 +8,9 @@ pytestmark = pytest.mark.gpu
 
 def _ckks(gpu_pkg, oracle, logn, nq, np_, batch, max_batch=None):
     N = 1 << logn
-    _, Qf, Pf = gpu_pkg.params.ckks_moduli("PN16QP1761" if logn == 16 else "PN15QP880")   # NTT-friendly up to 2^logN
+    # NTT-friendly up to 2^logN; PN15QP880 has three special primes, PN16QP1761 four
+    _, Qf, Pf = gpu_pkg.params.ckks_moduli("PN16QP1761" if logn == 16 or np_ > 3 else "PN15QP880")
+    assert len(Qf) >= nq and len(Pf) >= np_
     Q, P = Qf[:nq], Pf[:np_]
     ring = gpu_pkg.ring
     cQ, cP = ring.NewContextWithParams(N, Q), ring.NewContextWithParams(N, P)
@@ -23,7 +25,11 @@ def _ckks(gpu_pkg, oracle, logn, nq, np_, batch, max_batch=None):
 # the N = 2^14 cases run on the assembly NTT kernels, whose grouped launch transforms every full digit at once
 # (grid z = digit, own limbs skipped); levels 6 and 4 end in a partial digit that takes the per-digit path
 @pytest.mark.parametrize("logn,nq,np_,level", [(10, 6, 2, 5), (10, 6, 2, 4), (10, 6, 2, 2), (11, 7, 3, 6), (10, 18, 3, 17),
-                                               (10, 18, 3, 12), (14, 7, 3, 6), (14, 7, 3, 5), (14, 6, 2, 4), (14, 4, 2, 1)])
+                                               (10, 18, 3, 12), (14, 7, 3, 6), (14, 7, 3, 5), (14, 6, 2, 4), (14, 4, 2, 1),
+                                               # alpha = 4 digits (DefaultParams[PN16QP1761]'s shape) at a small degree, full and partial last digit
+                                               (10, 10, 4, 9), (10, 10, 4, 5), (13, 9, 4, 8),
+                                               # BASELINE config 5 at full size: PN16QP1761, 34 Q + 4 P limbs, beta = 9 (ckks/params.go:78-86)
+                                               (16, 34, 4, 33), (16, 34, 4, 20)])
 def test_switch_keys(gpu_pkg, oracle, logn, nq, np_, level):
     N, Q, P, cQ, cP, plan, oplan, evk, pevk = _ckks(gpu_pkg, oracle, logn, nq, np_, 2)
     cx = gpu_pkg.sampling.uniform_poly(Q[:level + 1], N, 2, seed=level)
@@ -38,8 +44,10 @@ def test_switch_keys(gpu_pkg, oracle, logn, nq, np_, level):
 
 # (16, 5, 2, 4): BASELINE config 5's degree (N = 2^16: two-pass NTT) on a short modulus chain
 # (15, 18, 3, 17) is BASELINE config 3 at full size: DefaultParams[PN15QP880], level 17
+# (16, 34, 4, 33) is BASELINE config 5's per-GPU workload at full size: DefaultParams[PN16QP1761] (ckks/params.go:78-86), level 33;
+# level 20 ends in a partial digit (21 limbs = 5 digits of 4 + 1 limb) and takes the trivial-copy branch of the decomposer
 @pytest.mark.parametrize("logn,nq,np_,level", [(10, 6, 2, 5), (12, 18, 3, 17), (11, 18, 3, 9), (15, 5, 2, 4), (16, 5, 2, 4),
-                                               (15, 18, 3, 17)])
+                                               (15, 18, 3, 17), (12, 10, 4, 9), (16, 34, 4, 33), (16, 34, 4, 20), (16, 34, 4, 22)])
 def test_mulrelin_and_rescale(gpu_pkg, oracle, logn, nq, np_, level):
     N, Q, P, cQ, cP, plan, oplan, evk, pevk = _ckks(gpu_pkg, oracle, logn, nq, np_, 2)
     mk = lambda s: gpu_pkg.sampling.uniform_poly(Q[:level + 1], N, 2, seed=s)

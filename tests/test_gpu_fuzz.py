@@ -88,8 +88,8 @@ def test_key_switch_fuzz(gpu_pkg, oracle, seed):
     # seeds 8..15: the degrees of the assembly kernels (grouped launches over the digits, skipped own limbs, 2^16 sub-blocks)
     logn = int(rng.integers(4, 13)) if seed < 8 else 13 + (seed % 4)
     N = 1 << logn
-    nq, np_ = int(rng.integers(2, 10)), int(rng.integers(1, 4))
-    _, Qf, Pf = gpu_pkg.params.ckks_moduli("PN16QP1761" if logn == 16 else "PN15QP880")
+    nq, np_ = int(rng.integers(2, 10)), int(rng.integers(1, 5))
+    _, Qf, Pf = gpu_pkg.params.ckks_moduli("PN16QP1761" if logn == 16 or np_ > 3 else "PN15QP880")
     Q, P = Qf[:nq], Pf[:np_]
     batch = int(rng.integers(1, 4))
     level = int(rng.integers(0, nq))
@@ -162,8 +162,8 @@ def test_mulrelin_rescale_fuzz(gpu_pkg, oracle, seed):
     rng = np.random.default_rng(5000 + seed)
     logn = 12 + seed % 5
     N = 1 << logn
-    _, Qf, Pf = gpu_pkg.params.ckks_moduli("PN16QP1761" if logn == 16 else "PN15QP880")
-    nq, np_ = int(rng.integers(3, 9)), int(rng.integers(1, 4))
+    nq, np_ = int(rng.integers(3, 9)), int(rng.integers(1, 5))
+    _, Qf, Pf = gpu_pkg.params.ckks_moduli("PN16QP1761" if logn == 16 or np_ > 3 else "PN15QP880")
     Q, P = Qf[:nq], Pf[:np_]
     level = int(rng.integers(1, nq))
     batch = int(rng.integers(1, 4))

@@ -441,3 +441,84 @@ def test_rescale_round_unfused_agrees(gpu_pkg, oracle, logn, monkeypatch):
         else:
             monkeypatch.delenv("LR_RESCALE_UNFUSED", raising=False)
         test_rescale(gpu_pkg, oracle, "DivRoundByLastModulusNTT", logn)
+
+
+# ---- the HBM-bound family at the BASELINE shapes (config 2: N = 2^14, 8 limbs; the benched ring R15: N = 2^15, 16 limbs) ----------
+# The kernels put the limb on blockIdx.y and the batch on blockIdx.z with 16 B per lane: a shape-dependent indexing error would not
+# show at N = 2^12 x 3 limbs x batch 2.  Every coefficient of every poly against the oracle.
+REAL_SHAPES = [(14, 8, 3), (15, 16, 3)]
+
+
+@pytest.mark.parametrize("logn,limbs,batch", REAL_SHAPES)
+@pytest.mark.parametrize("op", ["MUL_MONT", "MUL_MONT_AND_ADD_NOMOD", "MUL_MONT_AND_ADD", "MUL_COEFFS", "ADD", "SUB"])
+def test_three_operand_ops_at_baseline_shapes(gpu_pkg, oracle, logn, limbs, batch, op):
+    N, moduli = gpu_pkg.params.DefaultParamsQi(logn)
+    moduli = list(moduli)
+    assert len(moduli) == limbs
+    ctx, oc = gpu_pkg.ring.NewContextWithParams(N, moduli), oracle.Context(N, moduli)
+    mk = lambda s: gpu_pkg.sampling.uniform_poly(moduli, N, batch, seed=900 + s).reshape(batch, limbs, N)
+    a, b, c = mk(1), mk(2), mk(3)
+    pa, pb, pc = ctx.NewPoly(batch).set(a), ctx.NewPoly(batch).set(b), ctx.NewPoly(batch).set(c)
+    level = limbs - 1 if op != "MUL_MONT_AND_ADD_NOMOD" else limbs - 2      # the ...Lvl form on a lower level: top limb untouched
+    ctx._ew(op, level, pa, pb, pc)
+    got = pc.get().reshape(batch, limbs, N)
+    for i in range(batch):
+        want = oc.ewise(op, a[i], b[i], out=c[i], level=level)
+        assert np.array_equal(got[i, :level + 1], want[:level + 1]), (op, i)
+        assert np.array_equal(got[i, level + 1:], c[i, level + 1:]), (op, i)
+
+
+@pytest.mark.parametrize("logn,limbs,batch", REAL_SHAPES)
+def test_two_operand_ops_at_baseline_shapes(gpu_pkg, oracle, logn, limbs, batch):
+    N, moduli = gpu_pkg.params.DefaultParamsQi(logn)
+    moduli = list(moduli)
+    ctx, oc = gpu_pkg.ring.NewContextWithParams(N, moduli), oracle.Context(N, moduli)
+    a = gpu_pkg.sampling.uniform_poly(moduli, N, batch, seed=77).reshape(batch, limbs, N)
+    pa, pc = ctx.NewPoly(batch).set(a), ctx.NewPoly(batch)
+    for op in ("MFORM", "INV_MFORM", "NEG"):
+        ctx._ew(op, limbs - 1, pa, None, pc)
+        got = pc.get().reshape(batch, limbs, N)
+        for i in range(batch):
+            assert np.array_equal(got[i], oc.ewise(op, a[i])), (op, i)
+    ctx.MulScalar(pa, 0x123456789ABCDEF1, pc)
+    got = pc.get().reshape(batch, limbs, N)
+    for i in range(batch):
+        assert np.array_equal(got[i], oc.ewise("MUL_SCALAR", a[i], scalars=[0x123456789ABCDEF1])), i
+
+
+@pytest.mark.parametrize("logn,limbs,batch", REAL_SHAPES)
+def test_modup_split_qp_at_baseline_shapes(gpu_pkg, oracle, logn, limbs, batch):
+    """ModUpSplitQP 8 -> 8 at N = 2^14 (config 2's ring) and 16 -> 16 at N = 2^15 (the benched extension), every coefficient"""
+    N, Q = gpu_pkg.params.DefaultParamsQi(logn)
+    _, P = gpu_pkg.params.DefaultParamsPi(logn)
+    Q, P = list(Q), list(P)
+    ring = gpu_pkg.ring
+    cQ, cP = ring.NewContextWithParams(N, Q), ring.NewContextWithParams(N, P)
+    be = ring.NewFastBasisExtender(cQ, cP)
+    obe = oracle.BasisExtender(oracle.Context(N, Q), oracle.Context(N, P))
+    x = gpu_pkg.sampling.uniform_poly(Q, N, batch, seed=55).reshape(batch, limbs, N)
+    px, pp = cQ.NewPoly(batch).set(x), cP.NewPoly(batch)
+    be.ModUpSplitQP(limbs - 1, px, pp)
+    got = pp.get().reshape(batch, len(P), N)
+    for b in range(batch):
+        assert np.array_equal(got[b], obe.modup_split_qp(limbs - 1, x[b])), b
+    be.ModUpSplitPQ(len(P) - 1, pp, px)
+    got = px.get().reshape(batch, limbs, N)
+    for b in range(batch):
+        assert np.array_equal(got[b], obe.modup_split_pq(len(P) - 1, obe.modup_split_qp(limbs - 1, x[b]))), b
+
+
+@pytest.mark.parametrize("logn,limbs,batch", REAL_SHAPES)
+@pytest.mark.parametrize("name", ["DivFloorByLastModulusNTT", "DivRoundByLastModulusNTT", "DivRoundByLastModulus"])
+def test_rescale_at_baseline_shapes(gpu_pkg, oracle, logn, limbs, batch, name):
+    N, moduli = gpu_pkg.params.DefaultParamsQi(logn)
+    moduli = list(moduli)
+    ctx, oc = gpu_pkg.ring.NewContextWithParams(N, moduli), oracle.Context(N, moduli)
+    x = gpu_pkg.sampling.uniform_poly(moduli, N, batch, seed=31).reshape(batch, limbs, N)
+    p = ctx.NewPoly(batch).set(x)
+    getattr(ctx, name)(p)
+    oname = {"DivFloorByLastModulusNTT": "oc_div_floor_by_last_modulus_ntt", "DivRoundByLastModulusNTT": "oc_div_round_by_last_modulus_ntt",
+             "DivRoundByLastModulus": "oc_div_round_by_last_modulus"}[name]
+    got = p.get().reshape(batch, limbs - 1, N)
+    for b in range(batch):
+        assert np.array_equal(got[b], oc.rescale_op(oname, x[b])), (name, b)
