@@ -1,19 +1,27 @@
 #!/usr/bin/env python3
-"""Headline benchmark: batched forward NTT on the reference's benchmark ring R15.
+"""Headline benchmark: batched forward NTT on the reference's benchmark ring R15, plus the CKKS / BFV caller sequences.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--workload ntt|ckks16]
 
-Workload (BASELINE.json metric "NTT/s ... at N=2^15, L=16"): ring.DefaultParamsQi[15]
+Workload "ntt" (default; BASELINE.json metric "NTT/s ... at N=2^15, L=16"): ring.DefaultParamsQi[15]
 (ring/params.go:14: N = 2^15, 16 x 60-bit limbs), a batch of B uniform polynomials resident in HBM
 (synthetic, splitmix64 -- the reference's BenchmarkRing uses NewUniformPoly, ring_benchmark_test.go:160).
 One step = Context.NTT (ring/ntt.go:4) over the whole batch = ONE kernel launch of B*16 limb-NTTs.
 Units are independent polynomials, so N GPUs shard the batch with no data-path collective
-(weak scaling: B polys per GPU); the only collectives are the timing barrier and a max over ranks.
+(weak scaling: B polys per GPU); the collectives of that leg are the timing barrier and a max over ranks.
 
-Prints one JSON line (rank 0).  `value` = limb-NTTs per second over all GPUs; `roofline.achieved` =
-algorithmic bytes (16*N per limb-NTT) / kernel time measured with HIP events on the
-launch stream.  `cpu_baseline` times the CPU oracle (C restatement of the Go algorithm; Go itself is
-not installable here) on the host cores, rank 0 at N=1 only.
+Workload "ckks16" (BASELINE.json config 5): independent CKKS MulRelin at DefaultParams[PN16QP1761] (N = 2^16, 34 Q + 4 P
+limbs, ckks/params.go:78-86), --config5-units ciphertext products per GPU (128 = config 5's share of one GPU of eight), each rank
+on its contiguous block, then ONE gather of the results to rank 0 (torch.distributed.gather on the nccl backend = RCCL
+send/recv over xGMI; lattigo-fhe-by-go_amd/sharding.py).  One step = the whole block + the gather; compute-only and
+compute+gather times are reported separately.  The default run carries this leg as the `config5` object.
+
+Prints one JSON line (rank 0).  `value` = units per second over all GPUs; `roofline.achieved` = algorithmic bytes
+ / device time measured with HIP events on the launch stream inside this run; `roofline.kernel` is the
+kernel the library reports it dispatched.  `roofline.traffic` is null here: PMC counters need their own rocprofv3 passes
+(tools/collect_profiles.sh writes them to profiles/, named in `traffic_profile`).  `cpu_baseline` objects time the CPU oracle
+(C restatement of the Go algorithm, rebuilt -O2 -march=native on this machine; Go itself is not installable here) on the
+host cores, rank 0 at N=1 only, on bounded samples.
 """
 import argparse
 import json
@@ -29,7 +37,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.
 
 
 def shard_units(total, rank, world):
-    """Contiguous block partition of `total` independent units: (start, count) for `rank`."""
+    """Contiguous block partition of `total` independent units: (start, count) for `rank` (package: sharding.shard_units)."""
     base, extra = divmod(total, world)
     count = base + (1 if rank < extra else 0)
     start = rank * base + min(rank, extra)
@@ -39,6 +47,13 @@ def shard_units(total, rank, world):
 def ntt_bytes(N, limbs, polys=1):
     """Algorithmic HBM bytes of `polys` poly-NTTs: read 8N + write 8N per limb."""
     return 16 * N * limbs * polys
+
+
+def mulrelin_bytes(N, nq, np_, products=1):
+    """Algorithmic HBM bytes of CKKS MulRelin at full level: two input ciphertexts 2*2*nq limbs, the
+    evaluation key beta*2*(nq+np) limbs, the output ciphertext 2*nq limbs; PN15QP880: 8N*360 per product."""
+    beta = -(-nq // np_)
+    return 8 * N * (4 * nq + beta * 2 * (nq + np_) + 2 * nq) * products
 
 
 def dist_env():
@@ -68,50 +83,48 @@ def timed_region(step, steps, warmup, sync, barrier, all_max, ev_start=None, ev_
     return all_max(dt), dev_ms
 
 
-def cpu_baseline_ntt(N, moduli, target_seconds=12.0):
-    """Times the CPU oracle's Context.NTT (serial over limbs, as ring/ntt.go:4-8) with one thread per host
-    core, each on its own polynomials (the reference's goroutine-per-evaluator model,
-    examples/dbfv/psi/psi.go:219-233), on a bounded sample."""
-    import concurrent.futures as cf
+# ------------------------------------------------------------------------------------------------------------------------
+# CPU baseline: the oracle (kind "port") on the host cores of this machine
+# ------------------------------------------------------------------------------------------------------------------------
+def host_cores():
+    try:
+        return max(1, len(os.sched_getaffinity(0)))
+    except Exception:
+        return max(1, os.cpu_count() or 1)
 
-    import numpy as np
+
+def cpu_baseline(make_worker, units_per_call, unit, what, target_seconds):
+    """make_worker(i) -> a no-argument callable doing ONE call of the reference's method on thread i's own operands
+    (FastBasisExtender and the evaluators own scratch: one object per thread, like one per goroutine,
+    examples/dbfv/psi/psi.go:219-233).  Times one call on one thread, then T threads x k calls."""
+    import concurrent.futures as cf
 
     import __graft_entry__ as graft
     oracle = graft.load_oracle()
-    pkg = graft.load_package()
-    oc = oracle.Context(N, moduli)
-    cores = max(1, min(os.cpu_count() or 1, 32))
-    x = pkg.sampling.uniform_poly(moduli, N, 1, seed=1)[0]
-    bufs = [(x.copy(), np.empty_like(x)) for _ in range(cores)]
-    lib = oracle.lib()
-    level = len(moduli) - 1
-
-    def one(i):
-        a, b = bufs[i]
-        lib.oc_ntt_lvl(oc.h, level, a.ctypes.data, b.ctypes.data)
-
+    cores = host_cores()
+    workers = [make_worker(i) for i in range(cores)]
     t0 = time.perf_counter()
-    one(0)
+    workers[0]()
     t_one = time.perf_counter() - t0
-    per_thread = max(1, int(target_seconds / max(t_one, 1e-6)))
-    per_thread = min(per_thread, 8192)
+    per_thread = max(1, min(8192, int(target_seconds / max(t_one, 1e-6))))
 
     def work(i):
         for _ in range(per_thread):
-            one(i)
+            workers[i]()
 
     with cf.ThreadPoolExecutor(max_workers=cores) as ex:
         t0 = time.perf_counter()
         list(ex.map(work, range(cores)))
         dt = time.perf_counter() - t0
-    polys = cores * per_thread
+    calls = cores * per_thread
     return {
-        "value": polys * len(moduli) / dt,
-        "unit": "limb-NTT/s",
+        "value": calls * units_per_call / dt,
+        "unit": unit,
         "cores": cores,
         "kind": "port",
-        "sample": "%d poly-NTTs (N=2^%d, %d limbs) = %d limb-NTTs, %d threads x %d polys, %.1f s; 1-thread poly-NTT %.2f ms"
-                  % (polys, N.bit_length() - 1, len(moduli), polys * len(moduli), cores, per_thread, dt, t_one * 1e3),
+        "one_thread_value": units_per_call / t_one,
+        "march_native": bool(oracle.native_loaded),
+        "sample": "%s: %d threads x %d calls, %.1f s; one call on one thread %.2f ms" % (what, cores, per_thread, dt, t_one * 1e3),
     }
 
 
@@ -120,12 +133,16 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--batch", type=int, default=256, help="polynomials per GPU")
+    ap.add_argument("--workload", choices=["ntt", "ckks16"], default="ntt")
+    ap.add_argument("--batch", type=int, default=256, help="polynomials per GPU (workload ntt)")
     ap.add_argument("--logn", type=int, default=15)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the InvNTT / MulCoeffsMontgomery / ModUp timings")
-    ap.add_argument("--no-ckks", action="store_true", help="skip the CKKS MulRelin leg")
+    ap.add_argument("--no-ckks", action="store_true", help="skip the CKKS MulRelin / BFV Mul legs")
+    ap.add_argument("--no-config5", action="store_true", help="skip the PN16QP1761 sharded MulRelin + gather leg")
     ap.add_argument("--ckks-batch", type=int, default=128)
+    ap.add_argument("--config5-units", type=int, default=128, help="PN16QP1761 ciphertext products per GPU")
+    ap.add_argument("--config5-chunk", type=int, default=32, help="products per lr_ckks_mulrelin call")
     args = ap.parse_args()
 
     import numpy as np
@@ -144,6 +161,8 @@ def main():
     use_dist = world > 1 or os.environ.get("LR_BENCH_FORCE_DIST") == "1"   # the latter: rehearse the RCCL path on one GPU
     if use_dist:
         import torch.distributed as dist
+        if "MASTER_ADDR" not in os.environ:
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=os.environ.get("MASTER_PORT", "29533"), RANK="0", WORLD_SIZE="1")
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
         tok = torch.zeros(1, device="cuda")
 
@@ -162,12 +181,135 @@ def main():
         def all_max(v):
             return v
 
-    ring, params, sampling = pkg.ring, pkg.params, pkg.sampling
+    ring, params, sampling, sharding = pkg.ring, pkg.params, pkg.sampling, pkg.sharding
+    sync = torch.cuda.synchronize
+    oracle = graft.load_oracle() if rank == 0 else None
+    want_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline
+    if want_cpu:
+        oracle.use_native()
+
+    def warm_clock(step, ctx):
+        # the device clock needs some tens of milliseconds of load to leave its idle state (the first launches after
+        # start-up run ~12 % slower); bring it up during set-up so that short --steps/--warmup runs measure steady state
+        t_up = time.perf_counter()
+        while time.perf_counter() - t_up < 0.25:
+            for _ in range(20):
+                step()
+            ctx.Sync()
+
+    # --------------------------------------------------------------------------------------------------------------------
+    # config 5: PN16QP1761 MulRelin on this rank's block of independent ciphertext products, then the gather to rank 0
+    # --------------------------------------------------------------------------------------------------------------------
+    def config5_leg(steps, warmup):
+        cN, cQm, cPm = params.ckks_moduli("PN16QP1761")
+        nq, np_ = len(cQm), len(cPm)
+        level, beta = nq - 1, -(-nq // np_)
+        per_gpu = args.config5_units
+        total = per_gpu * world
+        start, count = sharding.shard_units(total, rank, world)
+        chunk = min(args.config5_chunk, count)
+        cQ, cP = ring.NewContextWithParams(cN, cQm, device=local), ring.NewContextWithParams(cN, cPm, device=local)
+        # every launch of this leg goes on torch's current stream, so the collective is ordered after the products
+        # without a host synchronisation in between
+        stream = torch.cuda.current_stream().cuda_stream
+        cQ.SetStream(stream)
+        cP.SetStream(stream)
+        plan = ring.CkksPlan(cQ, cP, chunk)
+        evk_h = sampling.uniform_poly(cQm + cPm, cN, 2 * beta, seed=9)       # replicated on every rank
+        evk = plan.NewSwitchingKey().set(evk_h)
+        # unit g of the global batch has its own seeded operands; a few distinct ones tiled over the block (generation cost)
+        distinct = min(count, 4)
+        base = [sampling.uniform_poly(cQm, cN, 4, seed=0xC5 * 1000 + ((start + j) % 64)).reshape(4, nq, cN) for j in range(distinct)]
+        host = np.stack([base[j % distinct] for j in range(count)])           # [count, 4 (a0 a1 b0 b1), nq, N]
+        dev_in = torch.from_numpy(host.view(np.int64)).to("cuda")             # resident before timing
+        dev_out = torch.empty((count, 2, nq, cN), dtype=torch.int64, device="cuda")
+        del host
+        esz = 8
+
+        def comp(t, u0, nb, k):
+            # component k of units u0..u0+nb as an lr_poly over the tensor's memory: poly stride = t.shape[1] * nq limbs
+            return ring.Poly.wrap_strided(cQ, t.data_ptr() + ((u0 * t.shape[1] + k) * nq * cN) * esz, nq, nb, t.shape[1] * nq)
+
+        calls = []
+        for u0 in range(0, count, chunk):
+            nb = min(chunk, count - u0)
+            calls.append(((comp(dev_in, u0, nb, 0), comp(dev_in, u0, nb, 1)), (comp(dev_in, u0, nb, 2), comp(dev_in, u0, nb, 3)),
+                          (comp(dev_out, u0, nb, 0), comp(dev_out, u0, nb, 1))))
+
+        def compute():
+            for ct0, ct1, out in calls:
+                plan.MulRelin(level, ct0, ct1, evk, out)
+
+        gathered = [None]
+
+        def step():
+            compute()
+            gathered[0] = sharding.gather_blocks(dev_out, total, rank, world, dst=0) if use_dist else dev_out
+
+        warm_clock(compute, cQ)
+        seconds, dev_ms = timed_region(step, steps, warmup, sync, barrier, all_max, cQ.TimerStart, cQ.TimerStop)
+        # compute only, same block, no collective
+        comp_seconds, comp_ms = timed_region(compute, steps, 1, sync, barrier, all_max, cQ.TimerStart, cQ.TimerStop)
+        res = {
+            "value": total * steps / seconds, "unit": "MulRelin/s", "params": "PN16QP1761 (N=2^16, %d Q + %d P limbs, beta=%d), level %d" % (nq, np_, beta, level),
+            "units_total": total, "units_per_gpu": per_gpu, "chunk": chunk, "n_gpus": world,
+            "ms_per_step_compute_and_gather": seconds / steps * 1e3, "ms_per_step_compute_only": comp_seconds / steps * 1e3,
+            "compute_only_value": total * steps / comp_seconds,
+            "gather": ("torch.distributed.gather(nccl=RCCL) of %d x %.1f MiB to rank 0" % (total, 2 * nq * cN * 8 / 2**20)) if use_dist else "none (single process)",
+            "gather_bytes_to_root": (total - count) * 2 * nq * cN * 8 if use_dist else 0,
+            "roofline": {"bound": "hbm", "achieved": mulrelin_bytes(cN, nq, np_, count) / (comp_ms / steps * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "traffic": None, "pipeline_ms": comp_ms / steps,
+                         "algorithmic_bytes_per_product": mulrelin_bytes(cN, nq, np_)},
+        }
+        res["roofline"]["frac"] = res["roofline"]["achieved"] / HBM_PEAK_GBS
+        if rank == 0:
+            # placement + parity: global unit 0 (this rank's) and, when gathered, the first unit of the last rank's block
+            oplan = oracle.CkksPlan(oracle.Context(cN, cQm), oracle.Context(cN, cPm))
+            full = gathered[0] if gathered[0] is not None else dev_out
+            checks = {0}
+            if use_dist and world > 1:
+                checks.add(sharding.shard_units(total, world - 1, world)[0])
+            ok = True
+            for g in sorted(checks):
+                owner = sharding.unit_owner(g, total, world)
+                s_owner, c_owner = sharding.shard_units(total, owner, world)
+                d_owner = min(c_owner, 4)
+                opnd = sampling.uniform_poly(cQm, cN, 4, seed=0xC5 * 1000 + ((s_owner + (g - s_owner) % d_owner) % 64)).reshape(4, nq, cN)
+                want = oplan.mulrelin(level, opnd[0:2], opnd[2:4], evk_h.reshape(beta, 2, nq + np_, cN))
+                got = full[g].cpu().numpy().view(np.uint64)
+                ok = ok and bool(np.array_equal(got, want))
+            res["bit_exact"] = ok
+            res["checked_units"] = sorted(checks)
+        return res
+
+    if args.workload == "ckks16":
+        c5 = config5_leg(max(1, min(args.steps, 10)), max(1, min(args.warmup, 2)))
+        if rank == 0:
+            steps = max(1, min(args.steps, 10))
+            out = {"metric": "CKKS homomorphic-mul/s at N=2^16 (MulRelin, DefaultParams[PN16QP1761]), sharded batch + gather to rank 0",
+                   "value": c5["value"], "unit": "MulRelin/s", "n_gpus": world, "steps": steps, "warmup": max(1, min(args.warmup, 2)),
+                   "ms_per_step": c5["ms_per_step_compute_and_gather"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                   "dtype": "u64", "data": "synthetic",
+                   "config": {"workload": "BASELINE config 5: %d independent CKKS MulRelin per GPU at PN16QP1761, contiguous blocks, RCCL gather" % args.config5_units,
+                              "units_per_gpu": args.config5_units},
+                   "roofline": c5.pop("roofline"), "config5": c5}
+            print(json.dumps(out), flush=True)
+        if use_dist:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    # --------------------------------------------------------------------------------------------------------------------
+    # headline: forward NTT on R15
+    # --------------------------------------------------------------------------------------------------------------------
     N, moduli = params.DefaultParamsQi(args.logn)
     L = len(moduli)
     B = args.batch
     _, my_polys = shard_units(B * world, rank, world)   # weak scaling: B per GPU
     ctx = ring.NewContextWithParams(N, moduli, device=local)
+    fwd_variant, inv_variant = ctx.ntt_variants()
+    if 12 <= args.logn <= 16 and fwd_variant < 0 and not os.environ.get("LR_NO_ASM"):
+        raise SystemExit("bench.py: the context did not select an assembly NTT kernel (variant -1); refusing to report the C++ fallback as the headline")
     # synthetic operands: a few distinct polys tiled over the batch (generation cost), resident before timing
     base = sampling.uniform_poly(moduli, N, min(my_polys, 8), seed=0x4C415454 ^ rank)
     host = np.concatenate([base] * (-(-my_polys // base.shape[0])))[:my_polys]
@@ -177,37 +319,22 @@ def main():
     def step():
         ctx.NTT(src, dst)
 
-    # the device clock needs some tens of milliseconds of load to leave its idle state (the first launches after
-    # start-up run ~12 % slower); bring it up during set-up so that short --steps/--warmup runs measure steady state
-    t_up = time.perf_counter()
-    while time.perf_counter() - t_up < 0.25:
-        for _ in range(20):
-            step()
-        ctx.Sync()
-
-    sync = torch.cuda.synchronize
+    warm_clock(step, ctx)
     # the K timed launches are bracketed by HIP events on the launch stream as well (device-side duration)
     seconds, dev_ms = timed_region(step, args.steps, args.warmup, sync, barrier, all_max, ctx.TimerStart, ctx.TimerStop)
     kernel_ms = dev_ms / args.steps
+    kernel_name = ctx.last_ntt_kernel()
 
-    # parity spot-check inside the bench: first poly against the oracle (checker only)
+    # parity spot-check inside the bench: first and last poly against the oracle (checker only)
     bit_exact = None
+    oc = None
     if rank == 0:
-        oracle = graft.load_oracle()
         oc = oracle.Context(N, moduli)
-        got = np.empty((L, N), dtype=np.uint64)
         full = dst.get().reshape(my_polys, L, N)
-        got[:] = full[0]
-        bit_exact = bool(np.array_equal(got, oc.ntt(base[0])))
+        bit_exact = bool(np.array_equal(full[0], oc.ntt(base[0])) and
+                         np.array_equal(full[my_polys - 1], oc.ntt(base[(my_polys - 1) % base.shape[0]])))
         del full
 
-    traffic = None
-    pmc_path = os.path.join(ROOT, "profiles", "r01_final", "pmc_hbm.json")
-    if os.path.exists(pmc_path) and args.logn == 15 and B == 256:
-        try:
-            traffic = json.load(open(pmc_path))["hbm_bytes_per_launch"]   # rocprofv3 --pmc, separate passes (see file)
-        except Exception:
-            traffic = None
     limb_ntts_total = B * world * L
     value = limb_ntts_total * args.steps / seconds
     achieved = ntt_bytes(N, L, my_polys) / (kernel_ms * 1e-3) / 1e9
@@ -229,111 +356,166 @@ def main():
         "poly_ntt_per_s": value / L,
         "bit_exact": bit_exact,
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "kernel": ("lr_ntt_fwd%d%s_m1" % (args.logn, "" if args.logn == 15 else "x" if args.logn < 16 else "s")) if 12 <= args.logn <= 16 and not os.environ.get("LR_NO_ASM") else "ntt_fwd_kernel<%d>" % args.logn, "kernel_ms": kernel_ms,
+                     "frac": achieved / HBM_PEAK_GBS,
+                     # PMC counters cannot be read inside this run (rocprofv3 --pmc needs its own passes): null here, the
+                     # collected figure for this kernel and shape lives in the file below (tools/collect_profiles.sh)
+                     "traffic": None, "traffic_profile": "profiles/r02/pmc_hbm.json",
+                     "kernel": kernel_name, "asm_variant": fwd_variant, "kernel_ms": kernel_ms,
                      "algorithmic_bytes_per_launch": ntt_bytes(N, L, my_polys),
                      # the north star says "HBM-read roofline"; `achieved` counts read + write, this is the read half
                      "achieved_read_only": achieved / 2},
     }
+
+    def timed_on(c, fn, reps):
+        for _ in range(3):
+            fn()
+        c.Sync()
+        c.TimerStart()
+        for _ in range(reps):
+            fn()
+        return c.TimerStop() / reps
 
     if rank == 0 and not args.no_ckks:
         # second half of BASELINE.json's metric: CKKS MulRelin (ckks/evaluator.go:1016) at DefaultParams[PN15QP880],
         # device-resident batch of independent ciphertexts, synthetic operands and evaluation key
         cN, cQm, cPm = params.ckks_moduli("PN15QP880")
         cB = args.ckks_batch
+        nq, np_ = len(cQm), len(cPm)
         ccQ, ccP = ring.NewContextWithParams(cN, cQm, device=local), ring.NewContextWithParams(cN, cPm, device=local)
         plan = ring.CkksPlan(ccQ, ccP, cB)
-        clevel = len(cQm) - 1
-        cbeta = -(-len(cQm) // len(cPm))
-        evk = plan.NewSwitchingKey().set(sampling.uniform_poly(cQm + cPm, cN, 2 * cbeta, seed=9))
-        cbase = sampling.uniform_poly(cQm, cN, 2, seed=3)
-        chost = np.concatenate([cbase] * (-(-cB // 2)))[:cB]
-        mkc = lambda: ccQ.NewPoly(cB).set(chost)
-        ct0, ct1, cto = (mkc(), mkc()), (mkc(), mkc()), (ccQ.NewPoly(cB), ccQ.NewPoly(cB))
-        for _ in range(3):
-            plan.MulRelin(clevel, ct0, ct1, evk, cto)
-        ccQ.Sync()
-        ccQ.TimerStart()
-        for _ in range(10):
-            plan.MulRelin(clevel, ct0, ct1, evk, cto)
-        cms = ccQ.TimerStop() / 10
+        clevel = nq - 1
+        cbeta = -(-nq // np_)
+        evk_h = sampling.uniform_poly(cQm + cPm, cN, 2 * cbeta, seed=9)
+        evk = plan.NewSwitchingKey().set(evk_h)
+        cbase = [sampling.uniform_poly(cQm, cN, 2, seed=3 + k) for k in range(4)]          # a0, a1, b0, b1 for two distinct products
+        tile = lambda x: np.concatenate([x] * (-(-cB // 2)))[:cB]
+        ct0 = (ccQ.NewPoly(cB).set(tile(cbase[0])), ccQ.NewPoly(cB).set(tile(cbase[1])))
+        ct1 = (ccQ.NewPoly(cB).set(tile(cbase[2])), ccQ.NewPoly(cB).set(tile(cbase[3])))
+        cto = (ccQ.NewPoly(cB), ccQ.NewPoly(cB))
+        cms = timed_on(ccQ, lambda: plan.MulRelin(clevel, ct0, ct1, evk, cto), 10)
+        oplan = oracle.CkksPlan(oracle.Context(cN, cQm), oracle.Context(cN, cPm))
+        idx = cB - 1
+        want = oplan.mulrelin(clevel, np.stack([cbase[0][idx % 2], cbase[1][idx % 2]]), np.stack([cbase[2][idx % 2], cbase[3][idx % 2]]),
+                              evk_h.reshape(cbeta, 2, nq + np_, cN))
+        got0, got1 = cto[0].get().reshape(cB, nq, cN)[idx], cto[1].get().reshape(cB, nq, cN)[idx]
+        alg = mulrelin_bytes(cN, nq, np_, cB) / (cms * 1e-3) / 1e9
         out["ckks_mulrelin"] = {"value": cB / (cms * 1e-3), "unit": "MulRelin/s", "batch": cB, "ms_per_batch": cms,
                                 "params": "PN15QP880 (N=2^15, 18 Q limbs + 3 P limbs, beta=6), level 17",
-                                "algorithmic_GBs": cB * 8 * cN * 360 / (cms * 1e-3) / 1e9}
+                                "bit_exact": bool(np.array_equal(got0, want[0]) and np.array_equal(got1, want[1])),
+                                "roofline": {"bound": "hbm", "achieved": alg, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / HBM_PEAK_GBS,
+                                             "traffic": None, "traffic_profile": "profiles/r02/mulrelin_pmc_hbm.json",
+                                             "kernel": "pipeline of launches; per-kernel split in profiles/r02/mulrelin_kernel_stats.csv",
+                                             "pipeline_ms": cms, "algorithmic_bytes_per_product": mulrelin_bytes(cN, nq, np_)}}
+        if want_cpu:
+            def mk_mulrelin(i):
+                op = oracle.CkksPlan(oracle.Context(cN, cQm), oracle.Context(cN, cPm))
+                a, b, k = np.stack([cbase[0][0], cbase[1][0]]), np.stack([cbase[2][0], cbase[3][0]]), evk_h.reshape(cbeta, 2, nq + np_, cN)
+                return lambda: op.mulrelin(clevel, a, b, k)
+            out["ckks_mulrelin"]["cpu_baseline"] = cpu_baseline(mk_mulrelin, 1, "MulRelin/s", "oracle MulRelin PN15QP880 level 17", 2.0)
         del plan, ct0, ct1, cto, evk
 
-    if rank == 0 and not args.no_ckks:
         # BASELINE.json config 4: BFV DefaultParams[PN14QP438] Evaluator.Mul (tensorAndRescale, bfv/evaluator.go:278),
         # degree-1 x degree-1 -> degree-2, coefficient-domain operands, device-resident batch
         bN, bQ, _, bQMul = params.bfv_moduli("PN14QP438")
         bB = args.ckks_batch
         bcQ, bcM = ring.NewContextWithParams(bN, bQ, device=local), ring.NewContextWithParams(bN, bQMul, device=local)
         bplan = ring.BfvPlan(bcQ, bcM, 65537, bB)
-        bbase = sampling.uniform_poly(bQ, bN, 2, seed=5)
-        bhost = np.concatenate([bbase] * (-(-bB // 2)))[:bB]
-        mkb = lambda: bcQ.NewPoly(bB).set(bhost)
-        b0, b1, bo = (mkb(), mkb()), (mkb(), mkb()), (bcQ.NewPoly(bB), bcQ.NewPoly(bB), bcQ.NewPoly(bB))
-        for _ in range(3):
-            bplan.Mul(b0, b1, bo)
-        bcQ.Sync()
-        bcQ.TimerStart()
-        for _ in range(10):
-            bplan.Mul(b0, b1, bo)
-        bms = bcQ.TimerStop() / 10
+        bbase = [sampling.uniform_poly(bQ, bN, 2, seed=5 + k) for k in range(4)]
+        btile = lambda x: np.concatenate([x] * (-(-bB // 2)))[:bB]
+        b0 = (bcQ.NewPoly(bB).set(btile(bbase[0])), bcQ.NewPoly(bB).set(btile(bbase[1])))
+        b1 = (bcQ.NewPoly(bB).set(btile(bbase[2])), bcQ.NewPoly(bB).set(btile(bbase[3])))
+        bo = (bcQ.NewPoly(bB), bcQ.NewPoly(bB), bcQ.NewPoly(bB))
+        bms = timed_on(bcQ, lambda: bplan.Mul(b0, b1, bo), 10)
+        obplan = oracle.BfvPlan(oracle.Context(bN, bQ), oracle.Context(bN, bQMul), 65537)
+        bidx = bB - 1
+        bwant = obplan.mul(np.stack([bbase[0][bidx % 2], bbase[1][bidx % 2]]), np.stack([bbase[2][bidx % 2], bbase[3][bidx % 2]]))
+        bok = all(np.array_equal(bo[k].get().reshape(bB, len(bQ), bN)[bidx], bwant[k]) for k in range(3))
         out["bfv_mul"] = {"value": bB / (bms * 1e-3), "unit": "Mul/s", "batch": bB, "ms_per_batch": bms,
-                          "params": "PN14QP438 (N=2^14, 6 Q limbs, 6 QMul limbs, t=65537)"}
+                          "params": "PN14QP438 (N=2^14, 6 Q limbs, 6 QMul limbs, t=65537)", "bit_exact": bool(bok)}
+        if want_cpu:
+            def mk_bfv(i):
+                op = oracle.BfvPlan(oracle.Context(bN, bQ), oracle.Context(bN, bQMul), 65537)
+                a, b = np.stack([bbase[0][0], bbase[1][0]]), np.stack([bbase[2][0], bbase[3][0]])
+                return lambda: op.mul(a, b)
+            out["bfv_mul"]["cpu_baseline"] = cpu_baseline(mk_bfv, 1, "Mul/s", "oracle bfv Mul PN14QP438", 2.0)
         del bplan, b0, b1, bo
 
     if not args.no_extras and rank == 0:
-        # the other kernels BASELINE.json's north_star asks throughput for, same ring, same resident batch
+        # the other kernels BASELINE.json's north_star asks throughput for, same ring, same resident batch; after timing,
+        # the last poly of every output is compared with the oracle
         extras = {}
         reps = max(10, min(args.steps, 50))
-
-        def timed(fn):
-            for _ in range(3):
-                fn()
-            ctx.Sync()
-            ctx.TimerStart()
-            for _ in range(reps):
-                fn()
-            return ctx.TimerStop() / reps
+        last = my_polys - 1
+        x_last = base[last % base.shape[0]]
+        timed = lambda fn: timed_on(ctx, fn, reps)
 
         ms = timed(lambda: ctx.InvNTT(src, dst))
-        extras["intt"] = {"limb_ntt_per_s": my_polys * L / (ms * 1e-3), "ms": ms,
-                          "frac_hbm": ntt_bytes(N, L, my_polys) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        extras["intt"] = {"limb_ntt_per_s": my_polys * L / (ms * 1e-3), "ms": ms, "kernel": ctx.last_ntt_kernel(),
+                          "frac_hbm": ntt_bytes(N, L, my_polys) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                          "bit_exact": bool(np.array_equal(dst.get().reshape(my_polys, L, N)[last], oc.intt(x_last)))}
+        ctx.Copy(src, dst)
         ms = timed(lambda: ctx.MulCoeffsMontgomery(src, dst, dst))
+        # dst <- MRed(src, dst) applied (3 + reps) times to dst = src: replay the chain on the oracle for the checked poly
+        chain = x_last.copy()
+        for _ in range(3 + reps):
+            chain = oc.ewise("MUL_MONT", x_last, chain)
         extras["mulcoeffs_montgomery"] = {"poly_per_s": my_polys / (ms * 1e-3), "ms": ms,
-                                          "frac_hbm": 24 * N * L * my_polys / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                                          "frac_hbm": 24 * N * L * my_polys / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                          "bit_exact": bool(np.array_equal(dst.get().reshape(my_polys, L, N)[last], chain))}
+        if want_cpu:
+            def mk_mul(i):
+                a, b, o = x_last.copy(), x_last.copy(), np.empty_like(x_last)
+                lib = oracle.lib()
+                return lambda: lib.oc_ewise(oc.h, oracle.OP["MUL_MONT"], L - 1, a.ctypes.data, b.ctypes.data, o.ctypes.data, None)
+            extras["mulcoeffs_montgomery"]["cpu_baseline"] = cpu_baseline(mk_mul, 1, "poly/s", "oracle MulCoeffsMontgomery R15", 1.0)
         _, pmod = params.DefaultParamsPi(args.logn)
         ctxP = ring.NewContextWithParams(N, pmod, device=local)
         bext = ring.NewFastBasisExtender(ctx, ctxP)
-        if True:
-            outP = ctxP.NewPoly(my_polys)
-            ms = timed(lambda: bext.ModUpSplitQP(L - 1, src, outP))
-            extras["modup_split_qp"] = {"poly_per_s": my_polys / (ms * 1e-3), "ms": ms,
-                                        "frac_hbm": 8 * N * (L + len(pmod)) * my_polys / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                        "note": "%d -> %d limbs, %d modular multiplies per coefficient (compute-bound)" %
-                                                (L, len(pmod), L + L * len(pmod))}
-            del outP, bext
+        outP = ctxP.NewPoly(my_polys)
+        ms = timed(lambda: bext.ModUpSplitQP(L - 1, src, outP))
+        obe = oracle.BasisExtender(oc, oracle.Context(N, pmod))
+        extras["modup_split_qp"] = {"poly_per_s": my_polys / (ms * 1e-3), "ms": ms,
+                                    "frac_hbm": 8 * N * (L + len(pmod)) * my_polys / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                    "note": "%d -> %d limbs, %d modular multiplies per coefficient (compute-bound)" %
+                                            (L, len(pmod), L + L * len(pmod)),
+                                    "bit_exact": bool(np.array_equal(outP.get().reshape(my_polys, len(pmod), N)[last], obe.modup_split_qp(L - 1, x_last)))}
+        if want_cpu:
+            def mk_modup(i):
+                be = oracle.BasisExtender(oracle.Context(N, moduli), oracle.Context(N, pmod))
+                return lambda: be.modup_split_qp(L - 1, x_last)
+            extras["modup_split_qp"]["cpu_baseline"] = cpu_baseline(mk_modup, 1, "poly/s", "oracle ModUpSplitQP R15 16->16", 2.0)
+        del outP, bext
         if 12 <= args.logn <= 15:
             # the same transform on CKKS-size moduli (DefaultParams[PN15QP880]'s first limbs at N = 2^15: one of 50 bits, the rest
             # 40): limbs below 2^46 run on the FP64 body of the dual kernels, the others on the integer body beside it
             cq = list(params.ckks_moduli("PN15QP880")[1][:L]) if args.logn == 15 else params.GenerateNTTPrimes(40, args.logn, L)
             ctxC = ring.NewContextWithParams(N, cq, device=local)
+            occ = oracle.Context(N, cq)
             cb = sampling.uniform_poly(cq, N, min(my_polys, 2), seed=11)
             csrc = ctxC.NewPoly(my_polys).set(np.concatenate([cb] * (-(-my_polys // cb.shape[0])))[:my_polys])
             cdst = ctxC.NewPoly(my_polys)
-            for name, fn in (("ntt", lambda: ctxC.NTT(csrc, cdst)), ("intt", lambda: ctxC.InvNTT(csrc, cdst))):
-                ms = timed(fn)
+            for name, fn, ofn in (("ntt", lambda: ctxC.NTT(csrc, cdst), occ.ntt), ("intt", lambda: ctxC.InvNTT(csrc, cdst), occ.intt)):
+                ms = timed_on(ctxC, fn, reps)
                 extras[name + "_ckks_moduli"] = {"limb_ntt_per_s": my_polys * L / (ms * 1e-3), "ms": ms,
                                                  "frac_hbm": ntt_bytes(N, L, my_polys) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                                  "moduli_bits": [int(q).bit_length() for q in cq],
-                                                 "asm_variants": list(ctxC.ntt_variants())}
+                                                 "asm_variants": list(ctxC.ntt_variants()), "kernel": ctxC.last_ntt_kernel(),
+                                                 "bit_exact": bool(np.array_equal(cdst.get().reshape(my_polys, L, N)[last], ofn(cb[last % cb.shape[0]])))}
             del csrc, cdst, ctxC
         out["extras"] = extras
 
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline_ntt(N, moduli)
+    del src, dst
+    if not args.no_config5 and not args.no_ckks:
+        c5 = config5_leg(3, 1)
+        if rank == 0:
+            out["config5"] = c5
+
+    if want_cpu:
+        def mk_ntt(i):
+            a, b = base[0].copy(), np.empty_like(base[0])
+            lib = oracle.lib()
+            return lambda: lib.oc_ntt_lvl(oc.h, L - 1, a.ctypes.data, b.ctypes.data)
+        out["cpu_baseline"] = cpu_baseline(mk_ntt, L, "limb-NTT/s", "oracle Context.NTT on R15 (N=2^%d, %d limbs), one poly per call" % (args.logn, L), 8.0)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if use_dist:

@@ -24,8 +24,13 @@
  *  - "level" has the reference's meaning: limbs 0..level are touched, the rest ignored
  *    (ring/ntt.go:11, ring/ring.go:20).  Passing more limbs than a poly owns is
  *    LR_ERR_SHAPE (Go would panic with an index error).
- *  - in == out aliasing is legal wherever the reference allows it (everywhere).
+ *  - in == out aliasing is legal wherever the reference allows it (everywhere; the Galois permutations are "not in place" in the
+ *    reference as well, ring/ring_galois.go:54, and return LR_ERR_ARG).
  *  - results are bit-identical to the reference on the same inputs.
+ *  - threads: an lr_context is immutable after creation and may be shared by threads, each with its own polys / extender /
+ *    decomposer / plan (the reference's goroutine-per-evaluator model); its temporaries are leased per call.  Every other handle
+ *    is single-threaded, like the reference's FastBasisExtender and evaluators (their scratch polys, ring_basis_extension.go:16-17).
+ *  - the LR_* environment switches of INTEGRATION.md section 7 are read once per handle, at its creation.
  */
 #ifndef LATTIGO_RING_H
 #define LATTIGO_RING_H
@@ -44,7 +49,9 @@ typedef enum lr_status {
     LR_ERR_SHAPE = 3,          /* limb/batch/N mismatch (Go: index-out-of-range panic)                       */
     LR_ERR_ARG = 4,            /* null handle, bad enum, unsupported parameter                               */
     LR_ERR_HIP = 5,            /* HIP runtime failure; see lr_last_error_string()                            */
-    LR_ERR_UNSUPPORTED = 6     /* size outside what the kernels are built for                                */
+    LR_ERR_UNSUPPORTED = 6,    /* size outside what the kernels are built for                                */
+    LR_ERR_NOMEM = 7,          /* host allocation failed (std::bad_alloc caught at the boundary)                */
+    LR_ERR_INTERNAL = 8        /* any other C++ exception caught at the boundary; see lr_last_error_string()    */
 } lr_status;
 
 typedef struct lr_context lr_context;       /* ring.Context           ring/ring_context.go:18-51            */
@@ -68,8 +75,14 @@ int lr_context_destroy(lr_context *ctx);
 /* diagnostics: the assembly NTT variant the context's moduli select (forward, inverse): 0..2 = integer lazy-correction modes,
  * 3 = dual kernels (FP64 butterflies for the limbs below 2^46, integer body for the others), -1 = C++ kernels only */
 int lr_context_ntt_variants(const lr_context *ctx, int *forward, int *inverse);
-/* use an externally owned hipStream_t (e.g. torch's current stream); NULL = the context's own */
+/* use an externally owned hipStream_t (e.g. torch's current stream); NULL = the device's shared stream.  A stream belongs to a
+ * CONTEXT; polys, extenders, decomposers and plans run on the stream their contexts have at call time.  Handles built over two
+ * contexts (lr_bext, lr_ckks_plan, lr_bfv_plan) interleave launches of both: set the same stream on both contexts, or the
+ * pipeline entry points return LR_ERR_ARG.  Change streams only between calls (after lr_context_sync). */
 int lr_context_set_stream(lr_context *ctx, void *hip_stream);
+/* diagnostics: name of the kernel the last NTT / InvNTT launch of this context dispatched, e.g. "lr_ntt_fwd15_m1" (assembly
+ * code object) or "ntt_fwd_kernel<15>" (C++ kernel); bench.py reports it next to the roofline figures */
+int lr_context_last_ntt_kernel(const lr_context *ctx, char *buf, size_t capacity);
 int lr_context_sync(lr_context *ctx);       /* hipStreamSynchronize on the context's stream */
 int lr_context_info(const lr_context *ctx, uint64_t *N, int *n_moduli, int *device);
 
@@ -179,7 +192,8 @@ int lr_permute_ntt_index(uint64_t gen, uint64_t power, uint64_t N, uint64_t *ind
  * (a zero coefficient whose sign flips becomes q, as in the reference).  Not in place. */
 int lr_permute(lr_context *ctx, const lr_poly *in, uint64_t gen, lr_poly *out);
 /* Context.MultByMonomial (ring/ring.go:663): out = in * X^monomial_deg in Z_q[X]/(X^N+1), coefficient domain, all limbs.
- * Negated coefficients are q - x without reduction, as in the reference (a zero coefficient becomes q).  in != out. */
+ * Negated coefficients are q - x without reduction, as in the reference (a zero coefficient becomes q).  in == out is allowed
+ * (staged through a temporary, as the reference's tmpx, :682). */
 int lr_mult_by_monomial(lr_context *ctx, const lr_poly *in, uint64_t monomial_deg, lr_poly *out);
 
 /* ------------------------------------------------------------------ SimpleScaler --- */
@@ -248,7 +262,7 @@ int lr_ckks_plan_destroy(lr_ckks_plan *plan);
 /* switchKeysInPlace (ckks/evaluator.go:1475): cx over Q[0..level], NTT domain;
  * evk = SwitchingKey.evakey as one poly, batch = beta*2, limbs = |Q|+|P|
  * (ckks/keygen.go:68-70: evakey[i][0], evakey[i][1] in NTT + Montgomery form);
- * p0, p1 over Q[0..level] receive the two key-switched components. */
+ * p0, p1 over Q[0..level] receive the two key-switched components (any strides; neither may alias cx). */
 int lr_ckks_switch_keys(lr_ckks_plan *plan, int level, const lr_poly *cx, const lr_poly *evk,
                         lr_poly *p0, lr_poly *p1);
 /* MulRelin (ckks/evaluator.go:1016), ciphertext x ciphertext, with evaluation key.
@@ -256,6 +270,25 @@ int lr_ckks_switch_keys(lr_ckks_plan *plan, int level, const lr_poly *cx, const 
 int lr_ckks_mulrelin(lr_ckks_plan *plan, int level, const lr_poly *ct0_c0, const lr_poly *ct0_c1,
                      const lr_poly *ct1_c0, const lr_poly *ct1_c1, const lr_poly *evk,
                      lr_poly *out_c0, lr_poly *out_c1);
+/* MulRelin with evakey == nil (ckks/evaluator.go:1038-1111): the degree-2 result (out_c0, out_c1, out_c2), no key switch.
+ * Outputs may alias the inputs (ctOut == ct0 / ct1: the reference goes through its pools and copies, :1105-1111); ct0 == ct1 is
+ * the squaring branch (:1083-1088), whose result equals the regular branch's on the same operands. */
+int lr_ckks_mul_norelin(lr_ckks_plan *plan, int level, const lr_poly *ct0_c0, const lr_poly *ct0_c1,
+                        const lr_poly *ct1_c0, const lr_poly *ct1_c1, lr_poly *out_c0, lr_poly *out_c1, lr_poly *out_c2);
+/* MulRelin, plaintext x ciphertext branch (ckks/evaluator.go:1113-1131): out_ck = MRed(MForm(pt), ct_ck).  pt: the plaintext's
+ * value (NTT domain), batch 1 (broadcast) or the ciphertexts' batch. */
+int lr_ckks_mul_plain(lr_ckks_plan *plan, int level, const lr_poly *pt, const lr_poly *ct_c0, const lr_poly *ct_c1,
+                      lr_poly *out_c0, lr_poly *out_c1);
+/* pkEncryptor.encrypt, the branch through the special primes, after the sampling (ckks/encryptor.go:205-234):
+ * ct = ModDownPQ(InvNTT(u * pk_k) + e_k) -> NTT, + pt on component 0.  u (SampleTernaryMontgomeryNTT, :206), pk0 / pk1 and
+ * e0 / e1 (the residues gaussianSampler.SampleAndAdd adds, coefficient domain, values in [0, q]) hold |Q|+|P| limbs in contextQP's
+ * order; pk may have batch 1.  pt over Q[0..level], NTT domain.  Sampling stays on the host (out of scope).
+ * The reference's Context.NTT at :229 walks every modulus of contextQ (a Go index panic for level < |Q|-1); here limbs 0..level. */
+int lr_ckks_encrypt_pk(lr_ckks_plan *plan, int level, const lr_poly *u, const lr_poly *pk0, const lr_poly *pk1,
+                       const lr_poly *e0, const lr_poly *e1, const lr_poly *pt, lr_poly *out_c0, lr_poly *out_c1);
+/* decryptor.Decrypt (ckks/decryptor.go:53-78): Horner evaluation of ct[0..degree] at the secret key (NTT + Montgomery form,
+ * batch 1 or the ciphertexts' batch) with the reference's lazy-reduction cadence; pt_out over Q[0..level]. */
+int lr_ckks_decrypt(lr_ckks_plan *plan, int level, const lr_poly *const *ct, int degree, const lr_poly *sk, lr_poly *pt_out);
 /* Rescale, one level (ckks/evaluator.go:933-968 inner loop): DivRoundByLastModulusNTT on both components. */
 int lr_ckks_rescale(lr_ckks_plan *plan, lr_poly *c0, lr_poly *c1);
 /* permuteNTT (ckks/evaluator.go:1448-1468), the body of RotateColumns with a specific rotation key (:1222) and of

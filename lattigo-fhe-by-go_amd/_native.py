@@ -16,7 +16,7 @@ vp = C.c_void_p
 i32 = C.c_int
 
 STATUS = {0: "LR_OK", 1: "LR_ERR_INVALID_DEGREE", 2: "LR_ERR_NOT_NTT_FRIENDLY", 3: "LR_ERR_SHAPE",
-          4: "LR_ERR_ARG", 5: "LR_ERR_HIP", 6: "LR_ERR_UNSUPPORTED"}
+          4: "LR_ERR_ARG", 5: "LR_ERR_HIP", 6: "LR_ERR_UNSUPPORTED", 7: "LR_ERR_NOMEM", 8: "LR_ERR_INTERNAL"}
 
 # every symbol declared in include/lattigo_ring.h: name -> argtypes
 SYMBOLS = {
@@ -82,6 +82,11 @@ SYMBOLS = {
     "lr_ckks_switch_keys": [vp, i32, vp, vp, vp, vp],
     "lr_ckks_mulrelin": [vp, i32, vp, vp, vp, vp, vp, vp, vp],
     "lr_ckks_rescale": [vp, vp, vp],
+    "lr_ckks_mul_norelin": [vp, i32, vp, vp, vp, vp, vp, vp, vp],
+    "lr_ckks_mul_plain": [vp, i32, vp, vp, vp, vp, vp],
+    "lr_ckks_encrypt_pk": [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp],
+    "lr_ckks_decrypt": [vp, i32, C.POINTER(vp), i32, vp, vp],
+    "lr_context_last_ntt_kernel": [vp, C.c_char_p, C.c_size_t],
     "lr_ckks_rotate": [vp, i32, vp, vp, u64, vp, vp, vp],
     "lr_ckks_rotate_hoisted": [vp, i32, vp, vp, i32, u64p, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)],
     "lr_bfv_plan_create": [vp, vp, u64, i32, C.POINTER(vp)],

@@ -6,8 +6,11 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -41,6 +44,24 @@ int fail(int code, const std::string &msg) {
         if (rc_ != LR_OK) return rc_; \
     } while (0)
 
+// Every extern "C" body runs inside guarded(): the host side uses std::vector / std::map / std::string / new, and no
+// exception may cross the C boundary into a Go / Python / C caller (include/lattigo_ring.h, conventions).
+template <class F>
+int guarded(F &&body) noexcept {
+    try {
+        return body();
+    } catch (const std::bad_alloc &) {
+        try { g_error = "out of host memory"; } catch (...) {}
+        return LR_ERR_NOMEM;
+    } catch (const std::exception &e) {
+        try { g_error = std::string("internal error: ") + e.what(); } catch (...) {}
+        return LR_ERR_INTERNAL;
+    } catch (...) {
+        try { g_error = "internal error (unknown exception)"; } catch (...) {}
+        return LR_ERR_INTERNAL;
+    }
+}
+
 template <class T>
 int to_device(T **dst, const T *src, size_t count) {
     *dst = nullptr;
@@ -68,7 +89,80 @@ hipStream_t shared_stream(int device) {
     return s;
 }
 
+// Device scratch of a context, leased per call: a context may be shared by threads that each own their plans / extenders
+// (the reference's goroutine-per-evaluator model, examples/dbfv/psi/psi.go:221; ring.Context allocates its temporaries per
+// call).  Two calls in flight therefore never share a buffer; a buffer returns to the free list when its call has
+// enqueued its last kernel, and the next lease's work follows on the same stream.
+struct ScratchPool {
+    struct Buf { u64 *d; size_t words; };
+    std::mutex mu;
+    std::vector<Buf> free_list;
+    int acquire(size_t words, Buf *out) {
+        out->d = nullptr;
+        out->words = 0;
+        if (words == 0) return LR_OK;
+        {
+            std::lock_guard<std::mutex> lock(mu);
+            size_t best = free_list.size();
+            for (size_t i = 0; i < free_list.size(); ++i)
+                if (free_list[i].words >= words && (best == free_list.size() || free_list[i].words < free_list[best].words)) best = i;
+            if (best != free_list.size()) {
+                *out = free_list[best];
+                free_list.erase(free_list.begin() + (long)best);
+                return LR_OK;
+            }
+            // nothing fits: drop the largest idle buffer (hipFree waits for the device) so repeated growth does not pile up
+            if (!free_list.empty()) {
+                size_t big = 0;
+                for (size_t i = 1; i < free_list.size(); ++i)
+                    if (free_list[i].words > free_list[big].words) big = i;
+                (void)hipFree(free_list[big].d);
+                free_list.erase(free_list.begin() + (long)big);
+            }
+        }
+        LR_HIP(hipMalloc((void **)&out->d, words * sizeof(u64)));
+        out->words = words;
+        return LR_OK;
+    }
+    void release(Buf b) {
+        if (!b.d) return;
+        std::lock_guard<std::mutex> lock(mu);
+        free_list.push_back(b);
+    }
+    ~ScratchPool() {
+        for (Buf &b : free_list) (void)hipFree(b.d);
+    }
+};
+
+struct ScratchLease {
+    ScratchPool *pool = nullptr;
+    ScratchPool::Buf buf{nullptr, 0};
+    int take(ScratchPool *p, size_t words) {
+        pool = p;
+        return p->acquire(words, &buf);
+    }
+    u64 *d() const { return buf.d; }
+    ~ScratchLease() {
+        if (pool) pool->release(buf);
+    }
+};
+
 }  // namespace
+
+lr::Options lr::Options::from_env() {
+    Options o;
+    o.no_asm = std::getenv("LR_NO_ASM") != nullptr;
+    o.no_fp = std::getenv("LR_NO_FP") != nullptr;
+    o.no_epilogue = std::getenv("LR_NO_EPILOGUE") != nullptr;
+    o.rescale_unfused = std::getenv("LR_RESCALE_UNFUSED") != nullptr;
+    o.no_staging = std::getenv("LR_NO_STAGING") != nullptr;
+    o.ext_narrow = std::getenv("LR_EXT_NARROW") != nullptr;
+    o.asm14_1024 = std::getenv("LR_ASM_14_1024") != nullptr;
+    o.no_ingest = std::getenv("LR_NO_INGEST") != nullptr;
+    if (const char *v = std::getenv("LR_NTT_MODE")) o.ntt_mode = std::atoi(v);
+    if (const char *v = std::getenv("LR_ASM_VARIANT")) o.asm_variant = std::atoi(v);
+    return o;
+}
 
 // ------------------------------------------------------------------------------------------
 // handles
@@ -83,12 +177,13 @@ struct lr_context {
     Twiddle *d_fwd_fin = nullptr;  // lane-transposed tables of the last four stages, [L][15][N/16]
     Twiddle *d_inv_fin = nullptr;
     u64 *d_rescale = nullptr;   // [L][L]
-    u64 *scratch = nullptr;     // rescale temporaries, grown on demand
-    size_t scratch_words = 0;
+    Options opt;                // environment switches, read once at creation
+    ScratchPool scratch;        // rescale / staging temporaries, leased per call (thread-safe)
+    char last_ntt_kernel[32] = "";   // name of the kernel the last NTT launch of this context dispatched (diagnostics, bench.py)
     // DivRoundByLastModulusNTT: per level, -(pHalfNegQi[i] * NTT_i(1 + X + ... + X^(N-1))) * rescaleParams[i] for i < level,
     // [level][N], built on first use (rescale_round_table)
-    std::map<int, u64 *> rescale_round_plus;
-    std::map<int, EpiLimb *> rescale_epi;       // per level: rescaleParams as (c, c / q) doubles for the NTT epilogue
+    struct RoundTable { u64 *plus; EpiLimb *epi; };
+    std::map<int, RoundTable> rescale_round;    // per level; epi = rescaleParams as (c, c / q) doubles for the NTT epilogue
     std::mutex rescale_mu;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int ntt_mode = 0;           // lazy-correction cadence allowed by the largest modulus (lr_ntt.hip)
@@ -100,10 +195,9 @@ struct lr_context {
 };
 
 struct lr_poly {
-    lr_context *ctx = nullptr;     // creator; only dereferenced while the caller holds it (operations), never on free
+    lr_context *ctx = nullptr;     // creator; only dereferenced while the caller holds it (operations: its stream at call time), never on free
     int device = 0;
     u64 N = 0;
-    hipStream_t stream = nullptr;  // the creator's stream at allocation time
     u64 *d = nullptr;
     bool owned = false;
     int limbs = 0;        // logical limb count (rescale shrinks it)
@@ -120,7 +214,7 @@ struct DevModup {
         *qispj = nullptr, *qpj_inv = nullptr;
     ulonglong2 *qispj_shoup = nullptr;
     int lazy_terms = 0, exact_terms = 0, word_barrett = 0, wide_ok = 0;
-    int init(const std::vector<u64> &Qv, const std::vector<u64> &Pv) {
+    int init(const std::vector<u64> &Qv, const std::vector<u64> &Pv, bool ext_narrow) {
         h = build_modup(Qv, Pv);
         std::vector<u64> bh(h.P.size());
         for (size_t j = 0; j < bh.size(); ++j) bh[j] = h.bredP[j].hi;
@@ -150,7 +244,7 @@ struct DevModup {
             u64 qmax = 0;
             for (size_t i = 0; i < nQ; ++i) qmax = h.Q[i] > qmax ? h.Q[i] : qmax;
             // a group's sum of y_i * c_ij (y_i < q_i) over n terms is below n * qmax * p_j, which must stay below p_j * 2^64
-            wide_ok = std::getenv("LR_EXT_NARROW") ? 0 : (int)std::min<u128>((((u128)1 << 64) - 1) / qmax, 1 << 20);
+            wide_ok = ext_narrow ? 0 : (int)std::min<u128>((((u128)1 << 64) - 1) / qmax, 1 << 20);
         }
         for (size_t j = 0; j < nP; ++j) word_barrett &= (h.P[j] >> 32) != 0 && h.P[j] != ((u64)1 << 32) ? 1 : 0;
         return LR_OK;
@@ -239,7 +333,9 @@ struct lr_ckks_plan {
     lr_bext *bext = nullptr;
     lr_decomposer *dec = nullptr;
     int max_batch = 0;
+    Options opt;           // environment switches, read once at plan creation
     Pool c2QiQ, c2QiP, poolPP, c2, c0, c1, c2x, q1, q2, permQ, permP;
+    Pool encQ, encP;       // pk-encryption temporaries over Q||P (lr_ckks_encrypt_pk)
     Pool zerosQ;           // one poly of zeros over Q: the `plus` operand of the NTT epilogue where a caller has none
     Pool stageQ, stageP;   // N = 2^16: the extensions land here and the transforms go out of place (fused top stage, see ks_decompose)
 };
@@ -252,6 +348,7 @@ extern "C" const char *lr_last_error_string(void) { return g_error.c_str(); }
 extern "C" const char *lr_build_info(void) { return "lattigo_ring 0.1 gfx950 hip"; }
 
 extern "C" int lr_device_count(int *count) {
+    return guarded([&]() -> int {
     if (!count) return fail(LR_ERR_ARG, "count is null");
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
@@ -261,12 +358,14 @@ extern "C" int lr_device_count(int *count) {
     }
     *count = n;
     return LR_OK;
+    });
 }
 
 // ------------------------------------------------------------------------------------------
 // Context
 // ------------------------------------------------------------------------------------------
 extern "C" int lr_context_create(uint64_t N, const uint64_t *moduli, int n_moduli, int device, lr_context **out) {
+    return guarded([&]() -> int {
     if (!out) return fail(LR_ERR_ARG, "out is null");
     *out = nullptr;
     if (!moduli || n_moduli <= 0 || n_moduli > kMaxLimbs) return fail(LR_ERR_ARG, "bad modulus list (1..64 moduli)");
@@ -278,6 +377,7 @@ extern "C" int lr_context_create(uint64_t N, const uint64_t *moduli, int n_modul
     for (u64 q : c->h.q)
         if (q >> 61) return fail(LR_ERR_UNSUPPORTED, "modulus must be below 2^61 (the reference's lazy NTT has the same limit)");
     c->device = device;
+    c->opt = Options::from_env();
     {
         u64 qmax = 0, qmin = ~(u64)0;
         for (u64 q : c->h.q) {
@@ -287,23 +387,23 @@ extern "C" int lr_context_create(uint64_t N, const uint64_t *moduli, int n_modul
         if (qmax < (1ull << 57)) c->ntt_mode = 2;
         else if (qmin >= (1ull << 57)) c->ntt_mode = qmax <= (1ull << 60) ? 1 : 0;
         else c->ntt_mode = 3;                         // mixed sizes: generic path
-        if (const char *force = std::getenv("LR_NTT_MODE")) {
-            const int f = std::atoi(force);           // testing aid: 0 and 3 are always valid where 1 is
+        if (c->opt.ntt_mode >= 0) {
+            const int f = c->opt.ntt_mode;            // testing aid: 0 and 3 are always valid where 1 is
             if ((f == 0 && c->ntt_mode == 1) || f == 3) c->ntt_mode = f;
         }
         if (qmin >= (1ull << 32)) c->ntt_mode |= 256;
-        c->use_asm = std::getenv("LR_NO_ASM") == nullptr;
+        c->use_asm = !c->opt.no_asm;
         if (qmin > (1ull << 33)) {                    // 32-bit Barrett constant of the assembly kernels
             c->asm_fwd = qmax < (1ull << 57) ? 2 : qmax <= (1ull << 60) ? 1 : 0;
             c->asm_inv = qmax <= (1ull << 60) ? 1 : 0;
-            if (const char *force = std::getenv("LR_ASM_VARIANT")) {   // testing aid: a more conservative variant
-                const int f = std::atoi(force);
+            if (c->opt.asm_variant >= 0) {   // testing aid: a more conservative variant
+                const int f = c->opt.asm_variant;
                 if (f == 0 || (f == 1 && c->asm_fwd >= 1)) c->asm_fwd = f;
                 if (f == 0) c->asm_inv = 0;
             }
         }
         // the FP64 body takes any modulus below 2^46; the integer body next to it needs the others in (2^33, 2^57)
-        if (qmin < kFpLimit && qmax < (1ull << 57) && std::getenv("LR_NO_FP") == nullptr && std::getenv("LR_ASM_VARIANT") == nullptr) {
+        if (qmin < kFpLimit && qmax < (1ull << 57) && !c->opt.no_fp && c->opt.asm_variant < 0) {
             bool ok = true;
             for (u64 q : c->h.q) ok = ok && (q < kFpLimit || q > (1ull << 33));
             if (ok) c->asm_fwd = c->asm_inv = 3;
@@ -408,54 +508,66 @@ extern "C" int lr_context_create(uint64_t N, const uint64_t *moduli, int n_modul
     LR_TRY(to_device(&c->d_rescale, c->h.rescale.data(), c->h.rescale.size()));
     *out = c.release();
     return LR_OK;
+    });
 }
 
 extern "C" int lr_context_ntt_variants(const lr_context *c, int *forward, int *inverse) {
+    return guarded([&]() -> int {
     if (!c || !forward || !inverse) return fail(LR_ERR_ARG, "null argument");
     *forward = c->use_asm ? c->asm_fwd : -1;
     *inverse = c->use_asm ? c->asm_inv : -1;
     return LR_OK;
+    });
 }
 
 extern "C" int lr_context_destroy(lr_context *c) {
+    return guarded([&]() -> int {
     if (!c) return LR_OK;
     (void)hipSetDevice(c->device);
-    (void)hipStreamSynchronize(shared_stream(c->device));
-    for (void *p : {(void *)c->d_lp, (void *)c->d_fwd, (void *)c->d_inv, (void *)c->d_fwd_fin, (void *)c->d_inv_fin, (void *)c->d_rescale, (void *)c->scratch,
+    (void)hipDeviceSynchronize();   // whatever stream the handle last ran on (its own, the shared one, a caller's)
+    for (void *p : {(void *)c->d_lp, (void *)c->d_fwd, (void *)c->d_inv, (void *)c->d_fwd_fin, (void *)c->d_inv_fin, (void *)c->d_rescale,
                     (void *)c->d_fwd_fp, (void *)c->d_inv_fp, (void *)c->d_fwd_fin_fp, (void *)c->d_inv_fin_fp, (void *)c->d_fp_lp})
         if (p) (void)hipFree(p);
-    for (auto &kv : c->rescale_round_plus)
-        if (kv.second) (void)hipFree(kv.second);
-    for (auto &kv : c->rescale_epi)
-        if (kv.second) (void)hipFree(kv.second);
+    for (auto &kv : c->rescale_round) {
+        if (kv.second.plus) (void)hipFree(kv.second.plus);
+        if (kv.second.epi) (void)hipFree(kv.second.epi);
+    }
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     delete c;
     return LR_OK;
+    });
 }
 
 extern "C" int lr_context_set_stream(lr_context *c, void *hip_stream) {
+    return guarded([&]() -> int {
     if (!c) return fail(LR_ERR_ARG, "null context");
     c->stream = hip_stream ? (hipStream_t)hip_stream : shared_stream(c->device);
     return LR_OK;
+    });
 }
 
 extern "C" int lr_context_sync(lr_context *c) {
+    return guarded([&]() -> int {
     if (!c) return fail(LR_ERR_ARG, "null context");
     LR_HIP(hipSetDevice(c->device));
     LR_HIP(hipStreamSynchronize(c->stream));
     return LR_OK;
+    });
 }
 
 extern "C" int lr_context_info(const lr_context *c, uint64_t *N, int *n_moduli, int *device) {
+    return guarded([&]() -> int {
     if (!c) return fail(LR_ERR_ARG, "null context");
     if (N) *N = c->h.N;
     if (n_moduli) *n_moduli = c->h.L();
     if (device) *device = c->device;
     return LR_OK;
+    });
 }
 
 extern "C" int lr_context_get_table(const lr_context *c, int which, uint64_t *dst, size_t dst_count) {
+    return guarded([&]() -> int {
     if (!c || !dst) return fail(LR_ERR_ARG, "null argument");
     const HostContext &h = c->h;
     const size_t L = (size_t)h.L();
@@ -484,12 +596,14 @@ extern "C" int lr_context_get_table(const lr_context *c, int which, uint64_t *ds
     if (dst_count != src->size()) return fail(LR_ERR_SHAPE, "table size mismatch");
     std::memcpy(dst, src->data(), src->size() * sizeof(u64));
     return LR_OK;
+    });
 }
 
 // ------------------------------------------------------------------------------------------
 // Poly
 // ------------------------------------------------------------------------------------------
 extern "C" int lr_poly_alloc(lr_context *c, int limbs, int batch, lr_poly **out) {
+    return guarded([&]() -> int {
     if (!c || !out) return fail(LR_ERR_ARG, "null argument");
     *out = nullptr;
     if (limbs <= 0 || limbs > kMaxLimbs || batch <= 0) return fail(LR_ERR_SHAPE, "limbs must be 1..64 and batch >= 1");
@@ -498,7 +612,6 @@ extern "C" int lr_poly_alloc(lr_context *c, int limbs, int batch, lr_poly **out)
     p->ctx = c;
     p->device = c->device;
     p->N = c->h.N;
-    p->stream = c->stream;
     p->limbs = p->alloc_limbs = limbs;
     p->batch = batch;
     p->owned = true;
@@ -507,9 +620,11 @@ extern "C" int lr_poly_alloc(lr_context *c, int limbs, int batch, lr_poly **out)
     LR_HIP(hipMemsetAsync(p->d, 0, bytes, c->stream));
     *out = p.release();
     return LR_OK;
+    });
 }
 
 extern "C" int lr_poly_wrap(lr_context *c, void *device_ptr, int limbs, int batch, lr_poly **out) {
+    return guarded([&]() -> int {
     if (!c || !out || !device_ptr) return fail(LR_ERR_ARG, "null argument");
     *out = nullptr;
     if (limbs <= 0 || limbs > kMaxLimbs || batch <= 0) return fail(LR_ERR_SHAPE, "limbs must be 1..64 and batch >= 1");
@@ -518,51 +633,60 @@ extern "C" int lr_poly_wrap(lr_context *c, void *device_ptr, int limbs, int batc
     p->ctx = c;
     p->device = c->device;
     p->N = c->h.N;
-    p->stream = c->stream;
     p->d = (u64 *)device_ptr;
     p->limbs = p->alloc_limbs = limbs;
     p->batch = batch;
     p->owned = false;
     *out = p;
     return LR_OK;
+    });
 }
 
 extern "C" int lr_poly_free(lr_poly *p) {
+    return guarded([&]() -> int {
     if (!p) return LR_OK;
     if (p->owned && p->d) {
         (void)hipSetDevice(p->device);
-        (void)hipStreamSynchronize(shared_stream(p->device));
+        (void)hipDeviceSynchronize();   // the handle's work may be on its contexts' caller-supplied stream
         (void)hipFree(p->d);
         (void)hipGetLastError();
     }
     delete p;
     return LR_OK;
+    });
 }
 
 extern "C" int lr_poly_info(const lr_poly *p, uint64_t *N, int *limbs, int *batch, void **device_ptr) {
+    return guarded([&]() -> int {
     if (!p) return fail(LR_ERR_ARG, "null poly");
     if (N) *N = p->N;
     if (limbs) *limbs = p->limbs;
     if (batch) *batch = p->batch;
     if (device_ptr) *device_ptr = p->d;
     return LR_OK;
+    });
 }
 
 extern "C" int lr_poly_set_limbs(lr_poly *p, int limbs) {
+    return guarded([&]() -> int {
     if (!p) return fail(LR_ERR_ARG, "null poly");
     if (limbs < 0 || limbs > p->alloc_limbs) return fail(LR_ERR_SHAPE, "limb count exceeds the allocation");
     p->limbs = limbs;
     return LR_OK;
+    });
 }
 
 extern "C" int lr_poly_zero(lr_poly *p) {
+    return guarded([&]() -> int {
     if (!p) return fail(LR_ERR_ARG, "null poly");
     LR_HIP(hipSetDevice(p->device));
-    LR_HIP(hipMemsetAsync(p->d, 0, (size_t)p->batch * p->stride() * sizeof(u64), p->stream));
+    LR_HIP(hipMemsetAsync(p->d, 0, (size_t)p->batch * p->stride() * sizeof(u64), p->ctx->stream));
     return LR_OK;
+    });
 }
 
 extern "C" int lr_poly_upload(lr_poly *p, int batch_index, const uint64_t *const *limb_ptrs, int limbs) {
+    return guarded([&]() -> int {
     if (!p || !limb_ptrs) return fail(LR_ERR_ARG, "null argument");
     if (batch_index < 0 || batch_index >= p->batch || limbs < 0 || limbs > p->limbs)
         return fail(LR_ERR_SHAPE, "upload: batch index or limb count out of range");
@@ -571,13 +695,15 @@ extern "C" int lr_poly_upload(lr_poly *p, int batch_index, const uint64_t *const
     for (int i = 0; i < limbs; ++i) {
         if (!limb_ptrs[i]) return fail(LR_ERR_ARG, "null limb pointer");
         LR_HIP(hipMemcpyAsync(p->d + batch_index * p->stride() + (long long)i * p->N, limb_ptrs[i], row,
-                              hipMemcpyHostToDevice, p->stream));
+                              hipMemcpyHostToDevice, p->ctx->stream));
     }
-    LR_HIP(hipStreamSynchronize(p->stream));
+    LR_HIP(hipStreamSynchronize(p->ctx->stream));
     return LR_OK;
+    });
 }
 
 extern "C" int lr_poly_download(const lr_poly *p, int batch_index, uint64_t *const *limb_ptrs, int limbs) {
+    return guarded([&]() -> int {
     if (!p || !limb_ptrs) return fail(LR_ERR_ARG, "null argument");
     if (batch_index < 0 || batch_index >= p->batch || limbs < 0 || limbs > p->limbs)
         return fail(LR_ERR_SHAPE, "download: batch index or limb count out of range");
@@ -586,17 +712,18 @@ extern "C" int lr_poly_download(const lr_poly *p, int batch_index, uint64_t *con
     for (int i = 0; i < limbs; ++i) {
         if (!limb_ptrs[i]) return fail(LR_ERR_ARG, "null limb pointer");
         LR_HIP(hipMemcpyAsync(limb_ptrs[i], p->d + batch_index * p->stride() + (long long)i * p->N, row,
-                              hipMemcpyDeviceToHost, p->stream));
+                              hipMemcpyDeviceToHost, p->ctx->stream));
     }
-    LR_HIP(hipStreamSynchronize(p->stream));
+    LR_HIP(hipStreamSynchronize(p->ctx->stream));
     return LR_OK;
+    });
 }
 
 static int dense_copy(const lr_poly *p, u64 *host, const u64 *host_src, size_t count) {
     const size_t N = p->N;
     if (count != (size_t)p->batch * p->limbs * N) return fail(LR_ERR_SHAPE, "dense copy: element count != batch*limbs*N");
     LR_HIP(hipSetDevice(p->device));
-    LR_HIP(hipStreamSynchronize(p->stream));
+    LR_HIP(hipStreamSynchronize(p->ctx->stream));
     // logical limbs per poly; the device stride is larger after a rescale re-sliced the poly
     const size_t chunk = (size_t)p->limbs * N;
     const int pieces = p->limbs == p->alloc_limbs ? 1 : p->batch;
@@ -615,6 +742,7 @@ static int dense_copy(const lr_poly *p, u64 *host, const u64 *host_src, size_t c
 // of moduli, then limb-major big-endian words.  The payload goes host <-> device as it is; the byte swap runs on
 // the device.
 extern "C" int lr_poly_unmarshal(lr_poly *p, int batch_index, const uint8_t *data, size_t len) {
+    return guarded([&]() -> int {
     if (!p || !data) return fail(LR_ERR_ARG, "null argument");
     if (batch_index < 0 || batch_index >= p->batch) return fail(LR_ERR_SHAPE, "batch index out of range");
     if (len < 2) return fail(LR_ERR_ARG, "error : invalid polynomial encoding");
@@ -627,15 +755,17 @@ extern "C" int lr_poly_unmarshal(lr_poly *p, int batch_index, const uint8_t *dat
     LR_HIP(hipSetDevice(p->device));
     u64 *stage = nullptr;
     LR_HIP(hipMalloc((void **)&stage, words * 8 + 8));
-    hipError_t e = hipMemcpyAsync(stage, data + 2, words * 8, hipMemcpyHostToDevice, p->stream);
-    if (e == hipSuccess) e = launch_bswap(stage, p->d + (long long)batch_index * p->stride(), words, p->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(p->stream);
+    hipError_t e = hipMemcpyAsync(stage, data + 2, words * 8, hipMemcpyHostToDevice, p->ctx->stream);
+    if (e == hipSuccess) e = launch_bswap(stage, p->d + (long long)batch_index * p->stride(), words, p->ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(p->ctx->stream);
     (void)hipFree(stage);
     LR_HIP(e);
     return LR_OK;
+    });
 }
 
 extern "C" int lr_poly_marshal(const lr_poly *p, int batch_index, uint8_t *data, size_t capacity, size_t *written) {
+    return guarded([&]() -> int {
     if (!p || !data) return fail(LR_ERR_ARG, "null argument");
     if (batch_index < 0 || batch_index >= p->batch) return fail(LR_ERR_SHAPE, "batch index out of range");
     if (p->limbs > 255) return fail(LR_ERR_UNSUPPORTED, "the encoding holds the number of moduli in one byte");
@@ -648,23 +778,28 @@ extern "C" int lr_poly_marshal(const lr_poly *p, int batch_index, uint8_t *data,
     LR_HIP(hipSetDevice(p->device));
     u64 *stage = nullptr;
     LR_HIP(hipMalloc((void **)&stage, words * 8 + 8));
-    hipError_t e = launch_bswap(p->d + (long long)batch_index * p->stride(), stage, words, p->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(data + 2, stage, words * 8, hipMemcpyDeviceToHost, p->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(p->stream);
+    hipError_t e = launch_bswap(p->d + (long long)batch_index * p->stride(), stage, words, p->ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(data + 2, stage, words * 8, hipMemcpyDeviceToHost, p->ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(p->ctx->stream);
     (void)hipFree(stage);
     LR_HIP(e);
     if (written) *written = words * 8 + 2;
     return LR_OK;
+    });
 }
 
 extern "C" int lr_poly_upload_dense(lr_poly *p, const uint64_t *host, size_t count) {
+    return guarded([&]() -> int {
     if (!p || !host) return fail(LR_ERR_ARG, "null argument");
     return dense_copy(p, nullptr, host, count);
+    });
 }
 
 extern "C" int lr_poly_download_dense(const lr_poly *p, uint64_t *host, size_t count) {
+    return guarded([&]() -> int {
     if (!p || !host) return fail(LR_ERR_ARG, "null argument");
     return dense_copy(p, host, nullptr, count);
+    });
 }
 
 // ------------------------------------------------------------------------------------------
@@ -690,14 +825,43 @@ struct NttEpilogue {
 
 bool ntt_epilogue_ok(const lr_context *c) {
     const unsigned logn = c->h.logN;
-    return c->use_asm && c->asm_fwd == 3 && logn >= 12 && logn <= 15 && ntt_asm_available((int)logn) &&
-           std::getenv("LR_NO_EPILOGUE") == nullptr;
+    return c->use_asm && c->asm_fwd == 3 && logn >= 12 && logn <= 15 && ntt_asm_available((int)logn) && !c->opt.no_epilogue;
 }
 
+int run_ntt_launch(lr_context *c, bool inverse, Rows in, Rows out, int mod0, int mod_step, int count, int batch, int hole,
+                   int group, const NttEpilogue *epi);
+
+// The assembly kernels of the integer variants put the polynomial on grid.y (limit 65535): longer plain launches are cut into
+// chunks along the batch on the same kernel (no silent change of code path).  Grouped launches (key-switch digits) beyond
+// the limit are refused: 65536 ciphertexts in one key switch exceed the device memory by orders of magnitude.
 int run_ntt(lr_context *c, bool inverse, Rows in, Rows out, int mod0, int mod_step, int count, int batch, int hole = 0,
             int group = 0, const NttEpilogue *epi = nullptr) {
     if (count <= 0 || batch <= 0) return LR_OK;
     if (hole > 0 && (group <= 0 || batch % group != 0)) return fail(LR_ERR_ARG, "digit groups must divide the batch");
+    // N = 2^16: the streaming top-stage kernel carries poly * limbs on grid.y
+    const int kChunk = c->h.logN == 16 ? std::max(1, 65535 / count) : 65535;
+    if (hole > 0) {
+        if (group > kChunk || batch / group > 65535) return fail(LR_ERR_UNSUPPORTED, "grouped NTT launch: more than 65535 polys per digit group");
+        return run_ntt_launch(c, inverse, in, out, mod0, mod_step, count, batch, hole, group, epi);
+    }
+    for (int b0 = 0; b0 < batch; b0 += kChunk) {
+        const int nb = std::min(kChunk, batch - b0);
+        Rows ci = in, co = out;
+        ci.base = in.base + (long long)b0 * in.stride;
+        co.base = out.base + (long long)b0 * out.stride;
+        NttEpilogue e2;
+        if (epi) {
+            e2 = *epi;
+            e2.x = epi->x + (long long)b0 * epi->x_stride;
+            e2.plus = epi->plus + (long long)b0 * epi->plus_stride;
+        }
+        LR_TRY(run_ntt_launch(c, inverse, ci, co, mod0, mod_step, count, nb, 0, 0, epi ? &e2 : nullptr));
+    }
+    return LR_OK;
+}
+
+int run_ntt_launch(lr_context *c, bool inverse, Rows in, Rows out, int mod0, int mod_step, int count, int batch, int hole,
+                   int group, const NttEpilogue *epi) {
     const unsigned logn = c->h.logN;
     if (logn < 1 || logn > 16)
         return fail(LR_ERR_UNSUPPORTED, "NTT kernels cover 2 <= N <= 2^16");
@@ -732,12 +896,12 @@ int run_ntt(lr_context *c, bool inverse, Rows in, Rows out, int mod0, int mod_st
         a.fp_fin_delta = (const char *)(inverse ? c->d_inv_fin_fp : c->d_fwd_fin_fp) - (const char *)a.tw_fin;
         a.fp_lp = c->d_fp_lp;
     }
-    if (logn == 16 && variant >= 0 && c->use_asm && (hole > 0 ? group : batch) <= 65535 && (hole == 0 || batch / group <= 65535) &&
-        ntt_asm_available(16)) {
+    char *kn = c->last_ntt_kernel;
+    if (logn == 16 && variant >= 0 && c->use_asm && ntt_asm_available(16)) {
         // two 2^15 sub-blocks per limb on the assembly kernels + the streaming stage over bit 15
         if (!inverse) {
             if (ntt_rows_disjoint(a, 16)) {
-                LR_HIP(launch_ntt_asm16(a, 0, 's', variant, c->stream));     // top stage fused into the loads
+                LR_HIP(launch_ntt_asm16(a, 0, 's', variant, c->stream, kn));     // top stage fused into the loads
                 return LR_OK;
             }
             LR_HIP(launch_ntt_top(a, 0, c->stream));
@@ -746,10 +910,10 @@ int run_ntt(lr_context *c, bool inverse, Rows in, Rows out, int mod0, int mod_st
             sub.in_poly_stride = a.out_poly_stride;
             sub.in_limb0 = a.out_limb0;
             sub.in_limb_step = a.out_limb_step;
-            LR_HIP(launch_ntt_asm16(sub, 0, 'p', variant, c->stream));
+            LR_HIP(launch_ntt_asm16(sub, 0, 'p', variant, c->stream, kn));
             return LR_OK;
         }
-        LR_HIP(launch_ntt_asm16(a, 1, 's', variant, c->stream));
+        LR_HIP(launch_ntt_asm16(a, 1, 's', variant, c->stream, kn));
         NttLaunch top = a;
         top.in = a.out;
         top.in_poly_stride = a.out_poly_stride;
@@ -765,14 +929,14 @@ int run_ntt(lr_context *c, bool inverse, Rows in, Rows out, int mod0, int mod_st
         a.epi_plus = epi->plus;
         a.epi_plus_stride = epi->plus_stride;
         a.epi_consts = epi->consts;
-        LR_HIP(launch_ntt_asm(a, (int)logn, 0, 4, c->stream));
+        LR_HIP(launch_ntt_asm(a, (int)logn, 0, 4, c->stream, c->opt.asm14_1024, kn));
         return LR_OK;
     }
-    if (logn != 16 && variant >= 0 && c->use_asm && (hole > 0 ? group : batch) <= 65535 && (hole == 0 || batch / group <= 65535) &&
-        ntt_asm_available((int)logn)) {
-        LR_HIP(launch_ntt_asm(a, (int)logn, inverse, variant, c->stream));
+    if (logn != 16 && variant >= 0 && c->use_asm && ntt_asm_available((int)logn)) {
+        LR_HIP(launch_ntt_asm(a, (int)logn, inverse, variant, c->stream, c->opt.asm14_1024, kn));
         return LR_OK;
     }
+    std::snprintf(c->last_ntt_kernel, sizeof c->last_ntt_kernel, "ntt_%s_kernel<%u>", inverse ? "inv" : "fwd", logn);
     LR_HIP(launch_ntt(a, (int)logn, inverse, c->ntt_mode, c->stream));
     return LR_OK;
 }
@@ -798,17 +962,21 @@ Rows rows_of(const lr_poly *p, int limb0 = 0, int step = 1, bool broadcast_ok = 
 }  // namespace
 
 extern "C" int lr_ntt(lr_context *c, int level, const lr_poly *in, lr_poly *out) {
+    return guarded([&]() -> int {
     LR_TRY(check_pair(c, level, in, out));
     if (in->batch != out->batch) return fail(LR_ERR_SHAPE, "batch mismatch");
     LR_HIP(hipSetDevice(c->device));
     return run_ntt(c, false, rows_of(in), rows_of(out), 0, 1, level + 1, out->batch);
+    });
 }
 
 extern "C" int lr_intt(lr_context *c, int level, const lr_poly *in, lr_poly *out) {
+    return guarded([&]() -> int {
     LR_TRY(check_pair(c, level, in, out));
     if (in->batch != out->batch) return fail(LR_ERR_SHAPE, "batch mismatch");
     LR_HIP(hipSetDevice(c->device));
     return run_ntt(c, true, rows_of(in), rows_of(out), 0, 1, level + 1, out->batch);
+    });
 }
 
 static int ntt_limb(lr_context *c, bool inverse, int mod_index, const lr_poly *in, int in_limb, lr_poly *out, int out_limb) {
@@ -822,10 +990,14 @@ static int ntt_limb(lr_context *c, bool inverse, int mod_index, const lr_poly *i
 }
 
 extern "C" int lr_ntt_limb(lr_context *c, int mod_index, const lr_poly *in, int in_limb, lr_poly *out, int out_limb) {
+    return guarded([&]() -> int {
     return ntt_limb(c, false, mod_index, in, in_limb, out, out_limb);
+    });
 }
 extern "C" int lr_intt_limb(lr_context *c, int mod_index, const lr_poly *in, int in_limb, lr_poly *out, int out_limb) {
+    return guarded([&]() -> int {
     return ntt_limb(c, true, mod_index, in, in_limb, out, out_limb);
+    });
 }
 
 static int ntt_host(lr_context *c, bool inverse, int level, const uint64_t *const *in_limbs, uint64_t *const *out_limbs) {
@@ -841,10 +1013,14 @@ static int ntt_host(lr_context *c, bool inverse, int level, const uint64_t *cons
 }
 
 extern "C" int lr_ntt_host(lr_context *c, int level, const uint64_t *const *in_limbs, uint64_t *const *out_limbs) {
+    return guarded([&]() -> int {
     return ntt_host(c, false, level, in_limbs, out_limbs);
+    });
 }
 extern "C" int lr_intt_host(lr_context *c, int level, const uint64_t *const *in_limbs, uint64_t *const *out_limbs) {
+    return guarded([&]() -> int {
     return ntt_host(c, true, level, in_limbs, out_limbs);
+    });
 }
 
 // ------------------------------------------------------------------------------------------
@@ -879,6 +1055,7 @@ int run_ewise(lr_context *c, int op, int limbs, int batch, const u64 *a, long lo
 
 extern "C" int lr_ewise(lr_context *c, int op, int level, const lr_poly *a, const lr_poly *b, lr_poly *out,
                         const uint64_t *scalars) {
+    return guarded([&]() -> int {
     if (!c || !a || !out) return fail(LR_ERR_ARG, "null argument");
     if (op < 0 || op >= LR_EWISE_OP_COUNT) return fail(LR_ERR_ARG, "unknown coefficient-wise op");
     LR_TRY(check_pair(c, level, a, out));
@@ -915,6 +1092,7 @@ extern "C" int lr_ewise(lr_context *c, int op, int level, const lr_poly *a, cons
         LR_TRY(run_ewise(c, LR_MFORM, limbs, batch, a->d, as, nullptr, 0, out->d, out->stride(), nullptr));
     }
     return run_ewise(c, op, limbs, batch, a->d, as, needs_b ? b->d : nullptr, bs, out->d, out->stride(), scp);
+    });
 }
 
 // ------------------------------------------------------------------------------------------
@@ -942,27 +1120,39 @@ static int permute_common(lr_context *c, int level, const lr_poly *in, u64 gen, 
 }
 
 extern "C" int lr_permute_ntt(lr_context *c, int level, const lr_poly *in, uint64_t gen, lr_poly *out) {
+    return guarded([&]() -> int {
     if (!c || !in || !out) return fail(LR_ERR_ARG, "null argument");
     return permute_common(c, level, in, gen, out, true);
+    });
 }
 
 extern "C" int lr_permute(lr_context *c, const lr_poly *in, uint64_t gen, lr_poly *out) {
+    return guarded([&]() -> int {
     if (!c || !in || !out) return fail(LR_ERR_ARG, "null argument");
     return permute_common(c, c->h.L() - 1, in, gen, out, false);
+    });
 }
 
 extern "C" int lr_mult_by_monomial(lr_context *c, const lr_poly *in, uint64_t monomial_deg, lr_poly *out) {
+    return guarded([&]() -> int {
     if (!c || !in || !out) return fail(LR_ERR_ARG, "null argument");
     const int level = c->h.L() - 1;
     LR_TRY(check_pair(c, level, in, out));
     if (in->batch != out->batch) return fail(LR_ERR_SHAPE, "batch mismatch");
-    if (in->d == out->d) return fail(LR_ERR_ARG, "MultByMonomial needs distinct input and output here (the reference copies through a temporary)");
     LR_HIP(hipSetDevice(c->device));
     GaloisLaunch L;
     L.in = in->d;
     L.out = out->d;
     L.in_stride = in->stride();
     L.out_stride = out->stride();
+    // in place: through a temporary, as the reference does for every call (tmpx, ring/ring.go:682-693)
+    ScratchLease tmp;
+    const bool alias = in->d == out->d;
+    if (alias) {
+        LR_TRY(tmp.take(&c->scratch, (size_t)out->batch * (size_t)in->stride()));
+        LR_HIP(hipMemcpyAsync(tmp.d(), in->d, (size_t)out->batch * (size_t)in->stride() * sizeof(u64), hipMemcpyDeviceToDevice, c->stream));
+        L.in = tmp.d();
+    }
     L.n = (int)c->h.N;
     L.logn = (int)c->h.logN;
     L.ntt_domain = 0;
@@ -970,9 +1160,11 @@ extern "C" int lr_mult_by_monomial(lr_context *c, const lr_poly *in, uint64_t mo
     L.lp = c->d_lp;
     LR_HIP(launch_monomial(L, level + 1, out->batch, c->stream));
     return LR_OK;
+    });
 }
 
 extern "C" int lr_permute_ntt_index(uint64_t gen, uint64_t power, uint64_t N, uint64_t *index) {
+    return guarded([&]() -> int {
     if (!index) return fail(LR_ERR_ARG, "null argument");
     if (N == 0 || (N & (N - 1)) != 0) return fail(LR_ERR_INVALID_DEGREE, "invalid ring degree (must be a power of 2)");
     const u64 gen_pow = mod_exp(gen, power, 2 * N);
@@ -985,6 +1177,7 @@ extern "C" int lr_permute_ntt_index(uint64_t gen, uint64_t power, uint64_t N, ui
         index[i] = bit_reverse(t2, logn);
     }
     return LR_OK;
+    });
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1051,9 +1244,18 @@ int same_degree(const lr_context *a, const lr_context *b) {
     return LR_OK;
 }
 
+// The pipelines interleave launches of contextQ and contextP; both must be on ONE stream or the kernels race.
+// (lr_context_set_stream changes one context: call it on both, or on neither.)
+int same_stream(const lr_context *a, const lr_context *b) {
+    if (a->stream != b->stream)
+        return fail(LR_ERR_ARG, "the contexts of this handle run on different streams: call lr_context_set_stream on both");
+    return LR_OK;
+}
+
 }  // namespace
 
 extern "C" int lr_bext_create(lr_context *cQ, lr_context *cP, lr_bext **out) {
+    return guarded([&]() -> int {
     if (!cQ || !cP || !out) return fail(LR_ERR_ARG, "null argument");
     *out = nullptr;
     LR_TRY(same_degree(cQ, cP));
@@ -1062,8 +1264,9 @@ extern "C" int lr_bext_create(lr_context *cQ, lr_context *cP, lr_bext **out) {
     b->cQ = cQ;
     b->cP = cP;
     b->device = cQ->device;
-    LR_TRY(b->qp.init(cQ->h.q, cP->h.q));
-    LR_TRY(b->pq.init(cP->h.q, cQ->h.q));
+    const bool narrow = Options::from_env().ext_narrow;
+    LR_TRY(b->qp.init(cQ->h.q, cP->h.q, narrow));
+    LR_TRY(b->pq.init(cP->h.q, cQ->h.q, narrow));
     b->moddown_pq = build_moddown(cQ->h, cP->h);  // genModDownParams(contextQ, contextP), ring_basis_extension.go:66
     b->moddown_qp = build_moddown(cP->h, cQ->h);  // :67
     LR_TRY(to_device(&b->d_moddown_pq, b->moddown_pq.data(), b->moddown_pq.size()));
@@ -1078,26 +1281,32 @@ extern "C" int lr_bext_create(lr_context *cQ, lr_context *cP, lr_bext **out) {
     }
     *out = b.release();
     return LR_OK;
+    });
 }
 
 extern "C" int lr_bext_destroy(lr_bext *b) {
+    return guarded([&]() -> int {
     if (!b) return LR_OK;
     (void)hipSetDevice(b->device);
-    (void)hipStreamSynchronize(shared_stream(b->device));
+    (void)hipDeviceSynchronize();   // the handle's work may be on its contexts' caller-supplied stream
     delete b;
     return LR_OK;
+    });
 }
 
 extern "C" int lr_bext_get_table(const lr_bext *b, int which, uint64_t *dst, size_t dst_count) {
+    return guarded([&]() -> int {
     if (!b || !dst) return fail(LR_ERR_ARG, "null argument");
     const std::vector<u64> &src = which == 0 ? b->moddown_pq : b->moddown_qp;
     if (which < 0 || which > 1) return fail(LR_ERR_ARG, "unknown table id");
     if (dst_count != src.size()) return fail(LR_ERR_SHAPE, "table size mismatch");
     std::memcpy(dst, src.data(), src.size() * sizeof(u64));
     return LR_OK;
+    });
 }
 
 extern "C" int lr_modup_split_qp(lr_bext *b, int level, const lr_poly *p1, lr_poly *p2) {
+    return guarded([&]() -> int {
     if (!b || !p1 || !p2) return fail(LR_ERR_ARG, "null argument");
     const int nP = b->cP->h.L();
     if (level < 0 || level + 1 > b->cQ->h.L() || level + 1 > p1->limbs || nP > p2->limbs)
@@ -1106,9 +1315,11 @@ extern "C" int lr_modup_split_qp(lr_bext *b, int level, const lr_poly *p1, lr_po
     LR_HIP(hipSetDevice(b->cQ->device));
     return run_ext(b->cQ, b->qp, level + 1, rows_of(p1), p2->batch, segment(p2->d, p2->stride(), 0, 0, nP),
                    segment(nullptr, 0, 0, 0, 0));
+    });
 }
 
 extern "C" int lr_modup_split_pq(lr_bext *b, int level, const lr_poly *p1, lr_poly *p2) {
+    return guarded([&]() -> int {
     if (!b || !p1 || !p2) return fail(LR_ERR_ARG, "null argument");
     const int nQ = b->cQ->h.L();
     if (level < 0 || level + 1 > b->cP->h.L() || level + 1 > p1->limbs || nQ > p2->limbs)
@@ -1117,6 +1328,7 @@ extern "C" int lr_modup_split_pq(lr_bext *b, int level, const lr_poly *p1, lr_po
     LR_HIP(hipSetDevice(b->cQ->device));
     return run_ext(b->cQ, b->pq, level + 1, rows_of(p1), p2->batch, segment(p2->d, p2->stride(), 0, 0, nQ),
                    segment(nullptr, 0, 0, 0, 0));
+    });
 }
 
 namespace {
@@ -1140,50 +1352,63 @@ int moddown_pq_core(lr_bext *b, int level, const u64 *p1Q, long long p1Q_stride,
 }  // namespace
 
 extern "C" int lr_moddown_ntt_pq(lr_bext *b, int level, lr_poly *p1, lr_poly *p2) {
+    return guarded([&]() -> int {
     if (!b || !p1 || !p2) return fail(LR_ERR_ARG, "null argument");
     const int nQ = b->cQ->h.L(), nP = b->cP->h.L();
     if (level < 0 || level + 1 > nQ || p1->limbs < nQ + nP || p2->limbs < level + 1)
         return fail(LR_ERR_SHAPE, "ModDownNTTPQ: limb counts");
     if (p1->batch != p2->batch) return fail(LR_ERR_SHAPE, "batch mismatch");
+    LR_TRY(same_stream(b->cQ, b->cP));
     LR_HIP(hipSetDevice(b->cQ->device));
     Rows pP = rows_of(p1, nQ, 1);
     LR_TRY(run_ntt(b->cP, true, pP, pP, 0, 1, nP, p1->batch));  // ring_basis_extension.go:172-174
     return moddown_pq_core(b, level, p1->d, p1->stride(), pP, p1->batch, p2, true);
+    });
 }
 
 extern "C" int lr_moddown_split_ntt_pq(lr_bext *b, int level, const lr_poly *p1Q, lr_poly *p1P, lr_poly *p2) {
+    return guarded([&]() -> int {
     if (!b || !p1Q || !p1P || !p2) return fail(LR_ERR_ARG, "null argument");
     const int nQ = b->cQ->h.L(), nP = b->cP->h.L();
     if (level < 0 || level + 1 > nQ || p1Q->limbs < level + 1 || p1P->limbs < nP || p2->limbs < level + 1)
         return fail(LR_ERR_SHAPE, "ModDownSplitedNTTPQ: limb counts");
     if (p1Q->batch != p2->batch || p1P->batch != p2->batch) return fail(LR_ERR_SHAPE, "batch mismatch");
+    LR_TRY(same_stream(b->cQ, b->cP));
     LR_HIP(hipSetDevice(b->cQ->device));
     Rows pP = rows_of(p1P);
     LR_TRY(run_ntt(b->cP, true, pP, pP, 0, 1, nP, p2->batch));  // :215
     return moddown_pq_core(b, level, p1Q->d, p1Q->stride(), pP, p2->batch, p2, true);
+    });
 }
 
 extern "C" int lr_moddown_pq(lr_bext *b, int level, const lr_poly *p1, lr_poly *p2) {
+    return guarded([&]() -> int {
     if (!b || !p1 || !p2) return fail(LR_ERR_ARG, "null argument");
     const int nQ = b->cQ->h.L(), nP = b->cP->h.L();
     if (level < 0 || level + 1 > nQ || p1->limbs < level + 1 + nP || p2->limbs < level + 1)
         return fail(LR_ERR_SHAPE, "ModDownPQ: limb counts");
     if (p1->batch != p2->batch) return fail(LR_ERR_SHAPE, "batch mismatch");
+    LR_TRY(same_stream(b->cQ, b->cP));
     LR_HIP(hipSetDevice(b->cQ->device));
     return moddown_pq_core(b, level, p1->d, p1->stride(), rows_of(p1, level + 1, 1), p1->batch, p2, false);
+    });
 }
 
 extern "C" int lr_moddown_split_pq(lr_bext *b, int level, const lr_poly *p1Q, const lr_poly *p1P, lr_poly *p2) {
+    return guarded([&]() -> int {
     if (!b || !p1Q || !p1P || !p2) return fail(LR_ERR_ARG, "null argument");
     const int nQ = b->cQ->h.L(), nP = b->cP->h.L();
     if (level < 0 || level + 1 > nQ || p1Q->limbs < level + 1 || p1P->limbs < nP || p2->limbs < level + 1)
         return fail(LR_ERR_SHAPE, "ModDownSplitedPQ: limb counts");
     if (p1Q->batch != p2->batch || p1P->batch != p2->batch) return fail(LR_ERR_SHAPE, "batch mismatch");
+    LR_TRY(same_stream(b->cQ, b->cP));
     LR_HIP(hipSetDevice(b->cQ->device));
     return moddown_pq_core(b, level, p1Q->d, p1Q->stride(), rows_of(p1P), p2->batch, p2, false);
+    });
 }
 
 extern "C" int lr_moddown_split_qp(lr_bext *b, int levelQ, int levelP, const lr_poly *p1Q, const lr_poly *p1P, lr_poly *p2) {
+    return guarded([&]() -> int {
     if (!b || !p1Q || !p1P || !p2) return fail(LR_ERR_ARG, "null argument");
     lr_context *cP = b->cP;
     const int nQ = b->cQ->h.L(), nP = cP->h.L();
@@ -1191,6 +1416,7 @@ extern "C" int lr_moddown_split_qp(lr_bext *b, int levelQ, int levelP, const lr_
         p1P->limbs < levelP + 1 || p2->limbs < levelP + 1)
         return fail(LR_ERR_SHAPE, "ModDownSplitedQP: limb counts");
     if (p1Q->batch != p2->batch || p1P->batch != p2->batch) return fail(LR_ERR_SHAPE, "batch mismatch");
+    LR_TRY(same_stream(b->cQ, b->cP));
     LR_HIP(hipSetDevice(cP->device));
     const int batch = p2->batch;
     const long long pool_stride = (long long)nP * (long long)cP->h.N;
@@ -1200,6 +1426,7 @@ extern "C" int lr_moddown_split_qp(lr_bext *b, int levelQ, int levelP, const lr_
                    segment(nullptr, 0, 0, 0, 0)));
     return run_submul(cP, levelP + 1, batch, p1P->d, p1P->stride(), b->poolP.d, pool_stride, (long long)cP->h.N, p2->d,
                       p2->stride(), b->d_moddown_qp, false, nullptr);
+    });
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1209,6 +1436,7 @@ extern "C" int lr_moddown_split_qp(lr_bext *b, int levelQ, int levelP, const lr_
 // SimpleScaler (ring/ring_scaling.go:166-300)
 // ------------------------------------------------------------------------------------------
 extern "C" int lr_simple_scaler_create(lr_context *c, uint64_t t, lr_simple_scaler **out) {
+    return guarded([&]() -> int {
     if (!out) return fail(LR_ERR_ARG, "out is null");
     *out = nullptr;
     if (!c) return fail(LR_ERR_ARG, "null context");
@@ -1227,17 +1455,21 @@ extern "C" int lr_simple_scaler_create(lr_context *c, uint64_t t, lr_simple_scal
     LR_TRY(to_device(&s->d_ti, ti.data(), ti.size()));
     *out = s.release();
     return LR_OK;
+    });
 }
 
 extern "C" int lr_simple_scaler_destroy(lr_simple_scaler *s) {
+    return guarded([&]() -> int {
     if (!s) return LR_OK;
     (void)hipSetDevice(s->device);
-    (void)hipStreamSynchronize(shared_stream(s->device));
+    (void)hipDeviceSynchronize();   // the handle's work may be on its contexts' caller-supplied stream
     delete s;
     return LR_OK;
+    });
 }
 
 extern "C" int lr_simple_scaler_tables(const lr_simple_scaler *s, uint64_t *wi, double *ti, int count) {
+    return guarded([&]() -> int {
     if (!s || !wi || !ti) return fail(LR_ERR_ARG, "null argument");
     if (count != (int)s->h.wi.size()) return fail(LR_ERR_SHAPE, "table size mismatch");
     for (int i = 0; i < count; ++i) {
@@ -1246,9 +1478,11 @@ extern "C" int lr_simple_scaler_tables(const lr_simple_scaler *s, uint64_t *wi, 
         ti[2 * i + 1] = s->h.ti[i].lo;
     }
     return LR_OK;
+    });
 }
 
 extern "C" int lr_simple_scale(lr_simple_scaler *s, const lr_poly *p1, lr_poly *p2) {
+    return guarded([&]() -> int {
     if (!s || !p1 || !p2) return fail(LR_ERR_ARG, "null argument");
     lr_context *c = s->ctx;
     if (p1->N != c->h.N || p2->N != c->h.N) return fail(LR_ERR_SHAPE, "ring degree mismatch");
@@ -1272,9 +1506,11 @@ extern "C" int lr_simple_scale(lr_simple_scaler *s, const lr_poly *p1, lr_poly *
     L.n = (int)c->h.N;
     LR_HIP(launch_simple_scale(L, p1->batch, c->stream));
     return LR_OK;
+    });
 }
 
 extern "C" int lr_decomposer_create(lr_context *cQ, lr_context *cP, lr_decomposer **out) {
+    return guarded([&]() -> int {
     if (!cQ || !cP || !out) return fail(LR_ERR_ARG, "null argument");
     *out = nullptr;
     LR_TRY(same_degree(cQ, cP));
@@ -1293,24 +1529,28 @@ extern "C" int lr_decomposer_create(lr_context *cQ, lr_context *cP, lr_decompose
     std::vector<u64> QP(Q);
     QP.insert(QP.end(), P.begin(), P.end());
     d->modup.resize(d->beta);
+    const bool narrow = Options::from_env().ext_narrow;
     for (int i = 0; i < d->beta; ++i) {
         for (int j = 0; j + 1 < d->xalpha[i]; ++j) {
             std::vector<u64> Qi(Q.begin() + (size_t)i * d->alpha, Q.begin() + (size_t)i * d->alpha + j + 2);
             std::unique_ptr<DevModup> m(new DevModup());
-            LR_TRY(m->init(Qi, QP));
+            LR_TRY(m->init(Qi, QP, narrow));
             d->modup[i].push_back(std::move(m));
         }
     }
     *out = d.release();
     return LR_OK;
+    });
 }
 
 extern "C" int lr_decomposer_destroy(lr_decomposer *d) {
+    return guarded([&]() -> int {
     if (!d) return LR_OK;
     (void)hipSetDevice(d->device);
-    (void)hipStreamSynchronize(shared_stream(d->device));
+    (void)hipDeviceSynchronize();   // the handle's work may be on its contexts' caller-supplied stream
     delete d;
     return LR_OK;
+    });
 }
 
 namespace {
@@ -1360,37 +1600,30 @@ int decompose_core(lr_decomposer *d, int level, int crt, Rows in, int batch, u64
 }  // namespace
 
 extern "C" int lr_decompose(lr_decomposer *d, int level, int crt, const lr_poly *p0, lr_poly *p1) {
+    return guarded([&]() -> int {
     if (!d || !p0 || !p1) return fail(LR_ERR_ARG, "null argument");
     if (p0->limbs < level + 1 || p1->limbs < level + 1 + d->nP) return fail(LR_ERR_SHAPE, "Decompose: limb counts");
     if (p0->batch != p1->batch) return fail(LR_ERR_SHAPE, "batch mismatch");
     LR_HIP(hipSetDevice(d->cQ->device));
     return decompose_core(d, level, crt, rows_of(p0), p1->batch, p1->d, p1->stride(), nullptr, 0, false);
+    });
 }
 
 extern "C" int lr_decompose_and_split(lr_decomposer *d, int level, int crt, const lr_poly *p0, lr_poly *p1Q, lr_poly *p1P) {
+    return guarded([&]() -> int {
     if (!d || !p0 || !p1Q || !p1P) return fail(LR_ERR_ARG, "null argument");
     if (p0->limbs < level + 1 || p1Q->limbs < level + 1 || p1P->limbs < d->nP)
         return fail(LR_ERR_SHAPE, "DecomposeAndSplit: limb counts");
     if (p0->batch != p1Q->batch || p0->batch != p1P->batch) return fail(LR_ERR_SHAPE, "batch mismatch");
     LR_HIP(hipSetDevice(d->cQ->device));
     return decompose_core(d, level, crt, rows_of(p0), p1Q->batch, p1Q->d, p1Q->stride(), p1P->d, p1P->stride(), true);
+    });
 }
 
 // ------------------------------------------------------------------------------------------
 // RNS rescale (ring/ring_scaling.go:9-164)
 // ------------------------------------------------------------------------------------------
 namespace {
-
-int ensure_scratch(lr_context *c, size_t words) {
-    if (words <= c->scratch_words) return LR_OK;
-    LR_HIP(hipStreamSynchronize(c->stream));
-    if (c->scratch) LR_HIP(hipFree(c->scratch));
-    c->scratch = nullptr;
-    c->scratch_words = 0;
-    LR_HIP(hipMalloc((void **)&c->scratch, words * sizeof(u64)));
-    c->scratch_words = words;
-    return LR_OK;
-}
 
 int check_rescale(lr_context *c, lr_poly *p0) {
     if (!c || !p0) return fail(LR_ERR_ARG, "null argument");
@@ -1430,35 +1663,44 @@ int rescale_coeff_domain(lr_context *c, lr_poly *p0, bool round) {
 // polynomial is transformed as it is (one source row for all limbs, like the floor variant) and the constant vector joins
 // the subtract-multiply as its `plus` operand, already multiplied by -rescaleParams[i]: the same canonical residue without the
 // pass that writes `level` shifted copies of the row.  The table depends on the level only and is built once.
-int rescale_round_table(lr_context *c, int level, const u64 **out) {
+int rescale_round_table(lr_context *c, int level, const u64 **out, const EpiLimb **epi_out) {
     std::lock_guard<std::mutex> lock(c->rescale_mu);
-    auto it = c->rescale_round_plus.find(level);
-    if (it != c->rescale_round_plus.end()) {
-        *out = it->second;
+    auto it = c->rescale_round.find(level);
+    if (it != c->rescale_round.end()) {
+        *out = it->second.plus;
+        *epi_out = it->second.epi;
         return LR_OK;
     }
+    // built into locals; the cache only ever holds complete tables (a failure below leaves no entry behind)
     const int n = (int)c->h.N;
     const long long words = (long long)level * n;
-    u64 *table = nullptr;
-    LR_HIP(hipMalloc((void **)&table, (size_t)words * sizeof(u64)));
-    c->rescale_round_plus[level] = table;
-    LR_TRY(ensure_scratch(c, (size_t)words));
-    LR_HIP(hipMemsetAsync(table, 0, (size_t)words * sizeof(u64), c->stream));
+    struct Guard {
+        u64 *table = nullptr;
+        EpiLimb *epi = nullptr;
+        ~Guard() {
+            if (table) (void)hipFree(table);
+            if (epi) (void)hipFree(epi);
+        }
+    } g;
+    ScratchLease tmpbuf;
+    LR_TRY(tmpbuf.take(&c->scratch, (size_t)words));
+    LR_HIP(hipMalloc((void **)&g.table, (size_t)words * sizeof(u64)));
+    LR_HIP(hipMemsetAsync(g.table, 0, (size_t)words * sizeof(u64), c->stream));
     const u64 pj = c->h.q[level], phalf = (pj - 1) >> 1;
     RowAddLaunch M;
-    M.in = table;                       // a row of zeros
+    M.in = g.table;                     // a row of zeros
     M.in_stride = 0;
-    M.out = c->scratch;
+    M.out = tmpbuf.d();
     M.out_stride = words;
     M.n = n;
     M.q = 0;
     std::memset(&M.adds, 0, sizeof(M.adds));
     for (int i = 0; i < level; ++i) M.adds.v[i] = c->h.q[i] - bred_add(phalf, c->h.q[i], c->h.bred[i].hi);   // pHalfNegQi
     LR_HIP(launch_rowadd(M, level, 1, c->stream));
-    Rows tmp{c->scratch, words, 0, 1};
+    Rows tmp{tmpbuf.d(), words, 0, 1};
     LR_TRY(run_ntt(c, false, tmp, tmp, 0, 1, level, 1));
     // table = MRed(0 + (q - NTT(a_i * ones)), rescaleParams[i])
-    LR_TRY(run_submul(c, level, 1, table, words, c->scratch, words, (long long)n, table, words,
+    LR_TRY(run_submul(c, level, 1, g.table, words, tmpbuf.d(), words, (long long)n, g.table, words,
                       c->d_rescale + (size_t)(level - 1) * c->h.L(), false, nullptr));
     {
         std::vector<EpiLimb> ec(c->h.L());
@@ -1466,11 +1708,13 @@ int rescale_round_table(lr_context *c, int level, const u64 **out) {
             const u64 q = c->h.q[i], cc = inv_mform(c->h.rescale[(size_t)(level - 1) * c->h.L() + i], q, c->h.mred[i]);
             ec[i] = q < kFpLimit ? EpiLimb{(double)cc, (double)cc / (double)q} : EpiLimb{0.0, 0.0};
         }
-        EpiLimb *d = nullptr;
-        LR_TRY(to_device(&d, ec.data(), ec.size()));
-        c->rescale_epi[level] = d;
+        LR_TRY(to_device(&g.epi, ec.data(), ec.size()));
     }
-    *out = table;
+    c->rescale_round[level] = lr_context::RoundTable{g.table, g.epi};
+    *out = g.table;
+    *epi_out = g.epi;
+    g.table = nullptr;
+    g.epi = nullptr;
     return LR_OK;
 }
 
@@ -1478,11 +1722,13 @@ int rescale_ntt_domain(lr_context *c, lr_poly *p0, bool round) {
     const int level = p0->limbs - 1, n = (int)c->h.N, batch = p0->batch;
     const long long tmp_stride = (long long)level * n;
     const u64 *plus = nullptr;
-    if (round && std::getenv("LR_RESCALE_UNFUSED") == nullptr) LR_TRY(rescale_round_table(c, level, &plus));
-    LR_TRY(ensure_scratch(c, (size_t)batch * tmp_stride));
+    const EpiLimb *ec = nullptr;
+    if (round && !c->opt.rescale_unfused) LR_TRY(rescale_round_table(c, level, &plus, &ec));
+    ScratchLease scratch;
+    LR_TRY(scratch.take(&c->scratch, (size_t)batch * tmp_stride));
     Rows last{p0->d, p0->stride(), level, 0};
     LR_TRY(run_ntt(c, true, last, last, level, 0, 1, batch));  // :15 / :80
-    Rows tmp{c->scratch, tmp_stride, 0, 1};
+    Rows tmp{scratch.d(), tmp_stride, 0, 1};
     if (round) {
         const u64 pj = c->h.q[level], phalf = (pj - 1) >> 1;
         RowAddLaunch L;
@@ -1497,7 +1743,6 @@ int rescale_ntt_domain(lr_context *c, lr_poly *p0, bool round) {
     }
     if (round && plus && ntt_epilogue_ok(c)) {
         // (x - NTT_i(t)) * rescaleParams[i] + plus inside the forward transform's copy-out for the runs of limbs below 2^46
-        const EpiLimb *ec = c->rescale_epi[level];
         const long long n64 = (long long)n;
         int l0 = 0;
         while (l0 < level) {
@@ -1509,9 +1754,9 @@ int rescale_ntt_domain(lr_context *c, lr_poly *p0, bool round) {
                 Rows dst{p0->d, p0->stride(), l0, 1};
                 LR_TRY(run_ntt(c, false, last, dst, l0, 1, l1 - l0, batch, 0, 0, &ep));
             } else {
-                Rows dst{c->scratch, tmp_stride, l0, 1};
+                Rows dst{scratch.d(), tmp_stride, l0, 1};
                 LR_TRY(run_ntt(c, false, last, dst, l0, 1, l1 - l0, batch));
-                LR_TRY(run_submul(c, l1 - l0, batch, p0->d + l0 * n64, p0->stride(), c->scratch + l0 * n64, tmp_stride, n64,
+                LR_TRY(run_submul(c, l1 - l0, batch, p0->d + l0 * n64, p0->stride(), scratch.d() + l0 * n64, tmp_stride, n64,
                                   p0->d + l0 * n64, p0->stride(), c->d_rescale + (size_t)(level - 1) * c->h.L() + l0, false, nullptr,
                                   plus + l0 * n64, 0, nullptr, l0));
             }
@@ -1527,7 +1772,7 @@ int rescale_ntt_domain(lr_context *c, lr_poly *p0, bool round) {
         RowAddLaunch M;
         M.in = p0->d + (long long)level * n;
         M.in_stride = p0->stride();
-        M.out = c->scratch;
+        M.out = scratch.d();
         M.out_stride = tmp_stride;
         M.n = n;
         M.q = 0;
@@ -1538,7 +1783,7 @@ int rescale_ntt_domain(lr_context *c, lr_poly *p0, bool round) {
     } else {
         LR_TRY(run_ntt(c, false, last, tmp, 0, 1, level, batch));  // :19: NTT of the last limb under modulus i
     }
-    LR_TRY(run_submul(c, level, batch, p0->d, p0->stride(), c->scratch, tmp_stride, (long long)n, p0->d, p0->stride(),
+    LR_TRY(run_submul(c, level, batch, p0->d, p0->stride(), scratch.d(), tmp_stride, (long long)n, p0->d, p0->stride(),
                       c->d_rescale + (size_t)(level - 1) * c->h.L(), false, nullptr, plus, 0));
     p0->limbs = level;
     return LR_OK;
@@ -1547,24 +1792,32 @@ int rescale_ntt_domain(lr_context *c, lr_poly *p0, bool round) {
 }  // namespace
 
 extern "C" int lr_div_floor_by_last_modulus_ntt(lr_context *c, lr_poly *p0) {
+    return guarded([&]() -> int {
     LR_TRY(check_rescale(c, p0));
     LR_HIP(hipSetDevice(c->device));
     return rescale_ntt_domain(c, p0, false);
+    });
 }
 extern "C" int lr_div_floor_by_last_modulus(lr_context *c, lr_poly *p0) {
+    return guarded([&]() -> int {
     LR_TRY(check_rescale(c, p0));
     LR_HIP(hipSetDevice(c->device));
     return rescale_coeff_domain(c, p0, false);
+    });
 }
 extern "C" int lr_div_round_by_last_modulus_ntt(lr_context *c, lr_poly *p0) {
+    return guarded([&]() -> int {
     LR_TRY(check_rescale(c, p0));
     LR_HIP(hipSetDevice(c->device));
     return rescale_ntt_domain(c, p0, true);
+    });
 }
 extern "C" int lr_div_round_by_last_modulus(lr_context *c, lr_poly *p0) {
+    return guarded([&]() -> int {
     LR_TRY(check_rescale(c, p0));
     LR_HIP(hipSetDevice(c->device));
     return rescale_coeff_domain(c, p0, true);
+    });
 }
 
 static int rescale_many(lr_context *c, lr_poly *p0, int nb, int ntt_domain, bool round) {
@@ -1578,16 +1831,21 @@ static int rescale_many(lr_context *c, lr_poly *p0, int nb, int ntt_domain, bool
     return LR_OK;
 }
 extern "C" int lr_div_floor_by_last_modulus_many(lr_context *c, lr_poly *p0, int nb, int ntt_domain) {
+    return guarded([&]() -> int {
     return rescale_many(c, p0, nb, ntt_domain, false);
+    });
 }
 extern "C" int lr_div_round_by_last_modulus_many(lr_context *c, lr_poly *p0, int nb, int ntt_domain) {
+    return guarded([&]() -> int {
     return rescale_many(c, p0, nb, ntt_domain, true);
+    });
 }
 
 // ------------------------------------------------------------------------------------------
 // ckks.Evaluator call sequences
 // ------------------------------------------------------------------------------------------
 extern "C" int lr_ckks_plan_create(lr_context *cQ, lr_context *cP, int max_batch, lr_ckks_plan **out) {
+    return guarded([&]() -> int {
     if (!cQ || !cP || !out) return fail(LR_ERR_ARG, "null argument");
     *out = nullptr;
     if (max_batch < 1) return fail(LR_ERR_ARG, "max_batch must be >= 1");
@@ -1597,6 +1855,7 @@ extern "C" int lr_ckks_plan_create(lr_context *cQ, lr_context *cP, int max_batch
     p->cP = cP;
     p->device = cQ->device;
     p->max_batch = max_batch;
+    p->opt = Options::from_env();
     LR_TRY(lr_bext_create(cQ, cP, &p->bext));
     int rc = lr_decomposer_create(cQ, cP, &p->dec);
     if (rc != LR_OK) {
@@ -1605,16 +1864,19 @@ extern "C" int lr_ckks_plan_create(lr_context *cQ, lr_context *cP, int max_batch
     }
     *out = p.release();
     return LR_OK;
+    });
 }
 
 extern "C" int lr_ckks_plan_destroy(lr_ckks_plan *p) {
+    return guarded([&]() -> int {
     if (!p) return LR_OK;
     (void)hipSetDevice(p->device);
-    (void)hipStreamSynchronize(shared_stream(p->device));
+    (void)hipDeviceSynchronize();   // the handle's work may be on its contexts' caller-supplied stream
     lr_bext_destroy(p->bext);
     lr_decomposer_destroy(p->dec);
     delete p;
     return LR_OK;
+    });
 }
 
 namespace {
@@ -1663,7 +1925,7 @@ int ks_decompose(lr_ckks_plan *pl, int level, int batch, const u64 *cx, long lon
     // N = 2^16: a forward transform whose input and output rows are disjoint computes its top stage while loading (one
     // launch); in place it needs a separate streaming pass first.  The extensions therefore land in staging buffers of the
     // same shape and the transforms write the pools the consumers read.
-    const bool staged = cQ->h.logN == 16 && cQ->use_asm && cQ->asm_fwd >= 0 && std::getenv("LR_NO_STAGING") == nullptr;
+    const bool staged = cQ->h.logN == 16 && cQ->use_asm && cQ->asm_fwd >= 0 && !pl->opt.no_staging;
     if (staged) {
         LR_TRY(pl->stageQ.ensure(cQ, (size_t)beta * dQ));
         LR_TRY(pl->stageP.ensure(cQ, (size_t)beta * dP));
@@ -1734,8 +1996,8 @@ int ks_accumulate(lr_ckks_plan *pl, int level, int batch, const u64 *digQ, const
         K.key_limb0 = 0;
         K.out0 = p0;
         K.out1 = p1;
-        if (p0_stride != p1_stride) return fail(LR_ERR_SHAPE, "key switch outputs must share their stride");
         K.out_stride = p0_stride;
+        K.out1_stride = p1_stride;
         K.lp = cQ->d_lp;
         K.own = own;
         K.own_stride = own_stride;
@@ -1748,6 +2010,7 @@ int ks_accumulate(lr_ckks_plan *pl, int level, int batch, const u64 *digQ, const
         K.out0 = pool2P;
         K.out1 = pool3P;
         K.out_stride = sP;
+        K.out1_stride = sP;
         K.lp = cP->d_lp;
         K.own = nullptr;
         K.own_stride = 0;
@@ -1761,7 +2024,7 @@ int ks_accumulate(lr_ckks_plan *pl, int level, int batch, const u64 *digQ, const
         LR_TRY(run_ntt(cP, true, pr, pr, 0, 1, nP, 2 * batch));
         LR_TRY(bx->poolQ.ensure(cQ, (size_t)2 * batch * sQ));
         u64 *ext_out = bx->poolQ.d;
-        if (cQ->h.logN == 16 && cQ->use_asm && cQ->asm_fwd >= 0 && std::getenv("LR_NO_STAGING") == nullptr) {
+        if (cQ->h.logN == 16 && cQ->use_asm && cQ->asm_fwd >= 0 && !pl->opt.no_staging) {
             LR_TRY(pl->stageQ.ensure(cQ, (size_t)2 * batch * sQ));     // (the digits' staging area is free again)
             ext_out = pl->stageQ.d;
         }
@@ -1844,6 +2107,7 @@ int check_ct(const lr_ckks_plan *pl, int level, const lr_poly *p, int batch) {
 }  // namespace
 
 extern "C" int lr_ckks_switch_keys(lr_ckks_plan *pl, int level, const lr_poly *cx, const lr_poly *evk, lr_poly *p0, lr_poly *p1) {
+    return guarded([&]() -> int {
     if (!pl || !cx || !evk || !p0 || !p1) return fail(LR_ERR_ARG, "null argument");
     if (level < 0 || level + 1 > pl->cQ->h.L()) return fail(LR_ERR_SHAPE, "level out of range");
     const int batch = cx->batch;
@@ -1851,8 +2115,10 @@ extern "C" int lr_ckks_switch_keys(lr_ckks_plan *pl, int level, const lr_poly *c
     LR_TRY(check_ct(pl, level, cx, batch));
     LR_TRY(check_ct(pl, level, p0, batch));
     LR_TRY(check_ct(pl, level, p1, batch));
+    LR_TRY(same_stream(pl->cQ, pl->cP));
     LR_HIP(hipSetDevice(pl->cQ->device));
     return switch_keys_core(pl, level, batch, cx->d, cx->stride(), evk, p0->d, p0->stride(), p1->d, p1->stride());
+    });
 }
 
 // permuteNTT (ckks/evaluator.go:1448-1468): RotateColumns with a specific rotation key / Conjugate.
@@ -1860,6 +2126,7 @@ extern "C" int lr_ckks_switch_keys(lr_ckks_plan *pl, int level, const lr_poly *c
 // ride on the last ModDown pass.
 extern "C" int lr_ckks_rotate(lr_ckks_plan *pl, int level, const lr_poly *c0, const lr_poly *c1, uint64_t gen, const lr_poly *rotkey,
                               lr_poly *o0, lr_poly *o1) {
+    return guarded([&]() -> int {
     if (!pl || !c0 || !c1 || !rotkey || !o0 || !o1) return fail(LR_ERR_ARG, "null argument");
     if (level < 0 || level + 1 > pl->cQ->h.L()) return fail(LR_ERR_SHAPE, "level out of range");
     const int batch = c0->batch;
@@ -1867,6 +2134,7 @@ extern "C" int lr_ckks_rotate(lr_ckks_plan *pl, int level, const lr_poly *c0, co
     for (const lr_poly *p : {c0, c1, (const lr_poly *)o0, (const lr_poly *)o1}) LR_TRY(check_ct(pl, level, p, batch));
     if (o0->stride() != o1->stride()) return fail(LR_ERR_SHAPE, "output polys must share their stride");
     lr_context *cQ = pl->cQ;
+    LR_TRY(same_stream(pl->cQ, pl->cP));
     LR_HIP(hipSetDevice(cQ->device));
     const int n = (int)cQ->h.N, L1 = level + 1;
     const long long s = (long long)L1 * n;
@@ -1875,6 +2143,7 @@ extern "C" int lr_ckks_rotate(lr_ckks_plan *pl, int level, const lr_poly *c0, co
     LR_TRY(run_permute_ntt(cQ, L1, batch, c1->d, c1->stride(), pl->c2x.d, s, gen));   // :1459
     KeySwitchEpilogue fin{o0->d, o1->d, o0->stride(), pl->c0.d, nullptr, s};
     return switch_keys_core(pl, level, batch, pl->c2x.d, s, rotkey, pl->q1.d, s, pl->q2.d, s, &fin);   // :1464-1467
+    });
 }
 
 // RotateHoisted + switchKeyHoisted (ckks/evaluator.go:1252-1391): n_rot rotations of one ciphertext share the
@@ -1882,6 +2151,7 @@ extern "C" int lr_ckks_rotate(lr_ckks_plan *pl, int level, const lr_poly *c0, co
 extern "C" int lr_ckks_rotate_hoisted(lr_ckks_plan *pl, int level, const lr_poly *c0, const lr_poly *c1, int n_rot,
                                       const uint64_t *gens, const lr_poly *const *rotkeys, lr_poly *const *outs0,
                                       lr_poly *const *outs1) {
+    return guarded([&]() -> int {
     if (!pl || !c0 || !c1 || !gens || !rotkeys || !outs0 || !outs1) return fail(LR_ERR_ARG, "null argument");
     if (n_rot < 0) return fail(LR_ERR_ARG, "negative rotation count");
     if (level < 0 || level + 1 > pl->cQ->h.L()) return fail(LR_ERR_SHAPE, "level out of range");
@@ -1890,6 +2160,7 @@ extern "C" int lr_ckks_rotate_hoisted(lr_ckks_plan *pl, int level, const lr_poly
     LR_TRY(check_ct(pl, level, c0, batch));
     LR_TRY(check_ct(pl, level, c1, batch));
     lr_context *cQ = pl->cQ, *cP = pl->cP;
+    LR_TRY(same_stream(pl->cQ, pl->cP));
     LR_HIP(hipSetDevice(cQ->device));
     const int nQ = cQ->h.L(), nP = cP->h.L(), n = (int)cQ->h.N, L1 = level + 1;
     const int alpha = pl->dec->alpha;
@@ -1915,16 +2186,19 @@ extern "C" int lr_ckks_rotate_hoisted(lr_ckks_plan *pl, int level, const lr_poly
         LR_TRY(ks_accumulate(pl, level, batch, pl->permQ.d, pl->permP.d, nullptr, 0, rotkeys[r], pl->q1.d, s, pl->q2.d, s, &fin));
     }
     return LR_OK;
+    });
 }
 
 extern "C" int lr_ckks_mulrelin(lr_ckks_plan *pl, int level, const lr_poly *a0, const lr_poly *a1, const lr_poly *b0,
                                 const lr_poly *b1, const lr_poly *evk, lr_poly *o0, lr_poly *o1) {
+    return guarded([&]() -> int {
     if (!pl || !a0 || !a1 || !b0 || !b1 || !evk || !o0 || !o1) return fail(LR_ERR_ARG, "null argument");
     if (level < 0 || level + 1 > pl->cQ->h.L()) return fail(LR_ERR_SHAPE, "level out of range");
     const int batch = a0->batch;
     if (batch > pl->max_batch) return fail(LR_ERR_SHAPE, "batch exceeds the plan's max_batch");
     for (const lr_poly *p : {a0, a1, b0, b1, (const lr_poly *)o0, (const lr_poly *)o1}) LR_TRY(check_ct(pl, level, p, batch));
     lr_context *cQ = pl->cQ;
+    LR_TRY(same_stream(pl->cQ, pl->cP));
     LR_HIP(hipSetDevice(cQ->device));
     const int n = (int)cQ->h.N, L1 = level + 1;
     const long long s = (long long)L1 * n;
@@ -1936,7 +2210,7 @@ extern "C" int lr_ckks_mulrelin(lr_ckks_plan *pl, int level, const lr_poly *a0, 
         T.a0 = a0->d; T.a1 = a1->d; T.b0 = b0->d; T.b1 = b1->d;
         T.a0_stride = a0->stride(); T.a1_stride = a1->stride(); T.b0_stride = b0->stride(); T.b1_stride = b1->stride();
         T.c0 = pl->c0.d; T.c1 = pl->c1.d; T.c2 = pl->c2x.d;
-        T.c_stride = s;
+        T.c_stride = T.c1_stride = T.c2_stride = s;
         T.n = n;
         T.lp = cQ->d_lp;
         LR_HIP(launch_tensor(T, L1, batch, cQ->stream));
@@ -1945,12 +2219,148 @@ extern "C" int lr_ckks_mulrelin(lr_ckks_plan *pl, int level, const lr_poly *a0, 
     KeySwitchEpilogue fin{o0->d, o1->d, o0->stride(), pl->c0.d, pl->c1.d, s};
     LR_TRY(switch_keys_core(pl, level, batch, pl->c2x.d, s, evk, pl->q1.d, s, pl->q2.d, s, &fin));
     return LR_OK;
+    });
+}
+
+// MulRelin with evakey == nil (ckks/evaluator.go:1038-1111): the degree-2 tensor, no key switch.  The squaring branch
+// (:1083-1088, c1 = 2 c0 c1 by AddLvl) and the regular one (:1090-1096, MulCoeffsMontgomeryAndAddLvl) produce the same canonical
+// residues when ct0 == ct1, so one kernel serves both.  Outputs may alias the inputs (the reference goes through its pools then).
+extern "C" int lr_ckks_mul_norelin(lr_ckks_plan *pl, int level, const lr_poly *a0, const lr_poly *a1, const lr_poly *b0,
+                                   const lr_poly *b1, lr_poly *o0, lr_poly *o1, lr_poly *o2) {
+    return guarded([&]() -> int {
+    if (!pl || !a0 || !a1 || !b0 || !b1 || !o0 || !o1 || !o2) return fail(LR_ERR_ARG, "null argument");
+    if (level < 0 || level + 1 > pl->cQ->h.L()) return fail(LR_ERR_SHAPE, "level out of range");
+    const int batch = a0->batch;
+    if (batch > pl->max_batch) return fail(LR_ERR_SHAPE, "batch exceeds the plan's max_batch");
+    for (const lr_poly *p : {a0, a1, b0, b1, (const lr_poly *)o0, (const lr_poly *)o1, (const lr_poly *)o2}) LR_TRY(check_ct(pl, level, p, batch));
+    lr_context *cQ = pl->cQ;
+    LR_HIP(hipSetDevice(cQ->device));
+    TensorLaunch T;
+    T.a0 = a0->d; T.a1 = a1->d; T.b0 = b0->d; T.b1 = b1->d;
+    T.a0_stride = a0->stride(); T.a1_stride = a1->stride(); T.b0_stride = b0->stride(); T.b1_stride = b1->stride();
+    T.c0 = o0->d; T.c1 = o1->d; T.c2 = o2->d;
+    T.c_stride = o0->stride(); T.c1_stride = o1->stride(); T.c2_stride = o2->stride();
+    T.n = (int)cQ->h.N;
+    T.lp = cQ->d_lp;
+    LR_HIP(launch_tensor(T, level + 1, batch, cQ->stream));
+    return LR_OK;
+    });
+}
+
+// MulRelin, plaintext x ciphertext (ckks/evaluator.go:1113-1131): out_k = MRed(MForm(pt), ct_k), k = 0, 1
+extern "C" int lr_ckks_mul_plain(lr_ckks_plan *pl, int level, const lr_poly *pt, const lr_poly *c0, const lr_poly *c1,
+                                 lr_poly *o0, lr_poly *o1) {
+    return guarded([&]() -> int {
+    if (!pl || !pt || !c0 || !c1 || !o0 || !o1) return fail(LR_ERR_ARG, "null argument");
+    if (level < 0 || level + 1 > pl->cQ->h.L()) return fail(LR_ERR_SHAPE, "level out of range");
+    const int batch = c0->batch;
+    if (batch > pl->max_batch) return fail(LR_ERR_SHAPE, "batch exceeds the plan's max_batch");
+    for (const lr_poly *p : {c0, c1, (const lr_poly *)o0, (const lr_poly *)o1}) LR_TRY(check_ct(pl, level, p, batch));
+    if (pt->N != pl->cQ->h.N || pt->limbs < level + 1 || (pt->batch != batch && pt->batch != 1)) return fail(LR_ERR_SHAPE, "plaintext: limbs or batch");
+    lr_context *cQ = pl->cQ;
+    LR_HIP(hipSetDevice(cQ->device));
+    const int n = (int)cQ->h.N, L1 = level + 1;
+    const long long s = (long long)L1 * n;
+    LR_TRY(pl->c0.ensure(cQ, (size_t)pt->batch * s));
+    LR_TRY(run_ewise(cQ, LR_MFORM, L1, pt->batch, pt->d, pt->stride(), nullptr, 0, pl->c0.d, s, nullptr));            // :1129
+    const long long ms = pt->batch == 1 && batch > 1 ? 0 : s;
+    LR_TRY(run_ewise(cQ, LR_MUL_MONT, L1, batch, pl->c0.d, ms, c0->d, c0->stride(), o0->d, o0->stride(), nullptr));   // :1130
+    return run_ewise(cQ, LR_MUL_MONT, L1, batch, pl->c0.d, ms, c1->d, c1->stride(), o1->d, o1->stride(), nullptr);    // :1131
+    });
+}
+
+// pkEncryptor.encrypt, the branch through the special primes, after the sampling (ckks/encryptor.go:205-234).
+// u, pk0, pk1, e0, e1 hold |Q|+|P| limbs (the layout of contextQP); pk0 / pk1 may have batch 1.
+extern "C" int lr_ckks_encrypt_pk(lr_ckks_plan *pl, int level, const lr_poly *u, const lr_poly *pk0, const lr_poly *pk1,
+                                  const lr_poly *e0, const lr_poly *e1, const lr_poly *pt, lr_poly *o0, lr_poly *o1) {
+    return guarded([&]() -> int {
+    if (!pl || !u || !pk0 || !pk1 || !e0 || !e1 || !pt || !o0 || !o1) return fail(LR_ERR_ARG, "null argument");
+    lr_context *cQ = pl->cQ, *cP = pl->cP;
+    const int nQ = cQ->h.L(), nP = cP->h.L(), n = (int)cQ->h.N;
+    if (level < 0 || level + 1 > nQ) return fail(LR_ERR_SHAPE, "level out of range");
+    const int batch = u->batch;
+    if (batch > pl->max_batch) return fail(LR_ERR_SHAPE, "batch exceeds the plan's max_batch");
+    for (const lr_poly *p : {u, pk0, pk1, e0, e1}) {
+        if (p->N != cQ->h.N || p->limbs < nQ + nP) return fail(LR_ERR_SHAPE, "encrypt: u, pk and e hold |Q|+|P| limbs");
+        if (p->batch != batch && !((p == pk0 || p == pk1) && p->batch == 1)) return fail(LR_ERR_SHAPE, "batch mismatch");
+    }
+    LR_TRY(check_ct(pl, level, o0, batch));
+    LR_TRY(check_ct(pl, level, o1, batch));
+    if (pt->N != cQ->h.N || pt->limbs < level + 1 || (pt->batch != batch && pt->batch != 1)) return fail(LR_ERR_SHAPE, "plaintext: limbs or batch");
+    LR_TRY(same_stream(cQ, cP));
+    LR_HIP(hipSetDevice(cQ->device));
+    const long long sQP = (long long)(nQ + nP) * n, offP = (long long)nQ * n;
+    LR_TRY(pl->encQ.ensure(cQ, (size_t)2 * batch * sQP));
+    u64 *const pool[2] = {pl->encQ.d, pl->encQ.d + (long long)batch * sQP};
+    const lr_poly *pk[2] = {pk0, pk1}, *e[2] = {e0, e1};
+    lr_poly *outs[2] = {o0, o1};
+    for (int k = 0; k < 2; ++k) {
+        const long long ks = pk[k]->batch == 1 && batch > 1 ? 0 : pk[k]->stride();
+        // :209-211 contextQP.MulCoeffsMontgomery(u, pk[k], pool[k]): the Q rows under contextQ's moduli, the P rows under contextP's
+        LR_TRY(run_ewise(cQ, LR_MUL_MONT, nQ, batch, u->d, u->stride(), pk[k]->d, ks, pool[k], sQP, nullptr));
+        LR_TRY(run_ewise(cP, LR_MUL_MONT, nP, batch, u->d + offP, u->stride(), pk[k]->d + offP, ks, pool[k] + offP, sQP, nullptr));
+    }
+    {   // :214-215 contextQP.InvNTT, both polys in one launch per basis
+        Rows q{pool[0], sQP, 0, 1}, p{pool[0], sQP, nQ, 1};
+        LR_TRY(run_ntt(cQ, true, q, q, 0, 1, nQ, 2 * batch));
+        LR_TRY(run_ntt(cP, true, p, p, 0, 1, nP, 2 * batch));
+    }
+    for (int k = 0; k < 2; ++k) {
+        // :218-220 SampleAndAdd: CRed(x + e) per coefficient (ring/gaussianSampler.go:268)
+        LR_TRY(run_ewise(cQ, LR_ADD, nQ, batch, pool[k], sQP, e[k]->d, e[k]->stride(), pool[k], sQP, nullptr));
+        LR_TRY(run_ewise(cP, LR_ADD, nP, batch, pool[k] + offP, sQP, e[k]->d + offP, e[k]->stride(), pool[k] + offP, sQP, nullptr));
+        // :223-226 ModDownPQ(level, pool[k], ct[k]): the P part is read at rows level+1.. (ring_basis_extension.go:255)
+        Rows pP{pool[k], sQP, level + 1, 1};
+        LR_TRY(moddown_pq_core(pl->bext, level, pool[k], sQP, pP, batch, outs[k], false));
+        Rows r = rows_of(outs[k]);
+        LR_TRY(run_ntt(cQ, false, r, r, 0, 1, level + 1, batch));                                                     // :229-230
+    }
+    const long long ps = pt->batch == 1 && batch > 1 ? 0 : pt->stride();
+    return run_ewise(cQ, LR_ADD, level + 1, batch, o0->d, o0->stride(), pt->d, ps, o0->d, o0->stride(), nullptr);     // :234
+    });
+}
+
+// decryptor.Decrypt (ckks/decryptor.go:53-78): Horner evaluation of the ciphertext at the secret key
+extern "C" int lr_ckks_decrypt(lr_ckks_plan *pl, int level, const lr_poly *const *ct, int degree, const lr_poly *sk, lr_poly *pt) {
+    return guarded([&]() -> int {
+    if (!pl || !ct || !sk || !pt) return fail(LR_ERR_ARG, "null argument");
+    if (degree < 0) return fail(LR_ERR_ARG, "negative degree");
+    lr_context *cQ = pl->cQ;
+    if (level < 0 || level + 1 > cQ->h.L()) return fail(LR_ERR_SHAPE, "level out of range");
+    const int batch = pt->batch, L1 = level + 1;
+    for (int i = 0; i <= degree; ++i) {
+        if (!ct[i]) return fail(LR_ERR_ARG, "null argument");
+        LR_TRY(check_ct(pl, level, ct[i], batch));
+    }
+    LR_TRY(check_ct(pl, level, pt, batch));
+    if (sk->N != cQ->h.N || sk->limbs < L1 || (sk->batch != batch && sk->batch != 1)) return fail(LR_ERR_SHAPE, "secret key: limbs or batch");
+    LR_HIP(hipSetDevice(cQ->device));
+    const long long ss = sk->batch == 1 && batch > 1 ? 0 : sk->stride();
+    LR_TRY(run_ewise(cQ, LR_COPY, L1, batch, ct[degree]->d, ct[degree]->stride(), nullptr, 0, pt->d, pt->stride(), nullptr));   // :61
+    for (int i = degree; i > 0; --i) {
+        LR_TRY(run_ewise(cQ, LR_MUL_MONT, L1, batch, pt->d, pt->stride(), sk->d, ss, pt->d, pt->stride(), nullptr));            // :67
+        LR_TRY(run_ewise(cQ, LR_ADD, L1, batch, pt->d, pt->stride(), ct[i - 1]->d, ct[i - 1]->stride(), pt->d, pt->stride(), nullptr));   // :68
+        if ((i & 7) == 7) LR_TRY(run_ewise(cQ, LR_REDUCE, L1, batch, pt->d, pt->stride(), nullptr, 0, pt->d, pt->stride(), nullptr));     // :70
+    }
+    if ((degree & 7) != 7) LR_TRY(run_ewise(cQ, LR_REDUCE, L1, batch, pt->d, pt->stride(), nullptr, 0, pt->d, pt->stride(), nullptr));    // :75
+    return LR_OK;
+    });
+}
+
+extern "C" int lr_context_last_ntt_kernel(const lr_context *c, char *buf, size_t capacity) {
+    return guarded([&]() -> int {
+    if (!c || !buf || capacity == 0) return fail(LR_ERR_ARG, "null argument");
+    std::snprintf(buf, capacity, "%s", c->last_ntt_kernel);
+    return LR_OK;
+    });
 }
 
 extern "C" int lr_ckks_rescale(lr_ckks_plan *pl, lr_poly *c0, lr_poly *c1) {
+    return guarded([&]() -> int {
     if (!pl || !c0 || !c1) return fail(LR_ERR_ARG, "null argument");
     LR_TRY(lr_div_round_by_last_modulus_ntt(pl->cQ, c0));  // ckks/evaluator.go:958-960
     return lr_div_round_by_last_modulus_ntt(pl->cQ, c1);
+    });
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1990,6 +2400,7 @@ void half_product_residues(const std::vector<u64> &moduli, const std::vector<u64
 }  // namespace
 
 extern "C" int lr_bfv_plan_create(lr_context *cQ, lr_context *cM, uint64_t t, int max_batch, lr_bfv_plan **out) {
+    return guarded([&]() -> int {
     if (!cQ || !cM || !out) return fail(LR_ERR_ARG, "null argument");
     *out = nullptr;
     if (max_batch < 1) return fail(LR_ERR_ARG, "max_batch must be >= 1");
@@ -2005,19 +2416,23 @@ extern "C" int lr_bfv_plan_create(lr_context *cQ, lr_context *cM, uint64_t t, in
     LR_TRY(lr_bext_create(cQ, cM, &p->bext));
     *out = p.release();
     return LR_OK;
+    });
 }
 
 extern "C" int lr_bfv_plan_destroy(lr_bfv_plan *p) {
+    return guarded([&]() -> int {
     if (!p) return LR_OK;
     (void)hipSetDevice(p->device);
-    (void)hipStreamSynchronize(shared_stream(p->device));
+    (void)hipDeviceSynchronize();   // the handle's work may be on its contexts' caller-supplied stream
     lr_bext_destroy(p->bext);
     delete p;
     return LR_OK;
+    });
 }
 
 extern "C" int lr_bfv_mul(lr_bfv_plan *pl, const lr_poly *a0, const lr_poly *a1, const lr_poly *b0, const lr_poly *b1,
                           lr_poly *o0, lr_poly *o1, lr_poly *o2) {
+    return guarded([&]() -> int {
     if (!pl || !a0 || !a1 || !b0 || !b1 || !o0 || !o1 || !o2) return fail(LR_ERR_ARG, "null argument");
     lr_context *cQ = pl->cQ, *cM = pl->cM;
     const int nQ = cQ->h.L(), nM = cM->h.L(), n = (int)cQ->h.N;
@@ -2026,6 +2441,7 @@ extern "C" int lr_bfv_mul(lr_bfv_plan *pl, const lr_poly *a0, const lr_poly *a1,
     for (const lr_poly *p : {a0, a1, b0, b1, (const lr_poly *)o0, (const lr_poly *)o1, (const lr_poly *)o2}) {
         if (p->N != cQ->h.N || p->limbs < nQ || p->batch != batch) return fail(LR_ERR_SHAPE, "BFV Mul: operands must hold |Q| limbs and share the batch");
     }
+    LR_TRY(same_stream(cQ, cM));
     LR_HIP(hipSetDevice(cQ->device));
     const long long sQ = (long long)nQ * n, sM = (long long)nM * n;
     const lr_poly *A[2] = {a0, a1}, *B[2] = {b0, b1};
@@ -2066,7 +2482,7 @@ extern "C" int lr_bfv_mul(lr_bfv_plan *pl, const lr_poly *a0, const lr_poly *a1,
         T.c0 = base == 0 ? pl->cQ3[0].d : pl->cM3[0].d;
         T.c1 = base == 0 ? pl->cQ3[1].d : pl->cM3[1].d;
         T.c2 = base == 0 ? pl->cQ3[2].d : pl->cM3[2].d;
-        T.c_stride = sx;
+        T.c_stride = T.c1_stride = T.c2_stride = sx;
         T.n = n;
         T.lp = cx->d_lp;
         LR_HIP(launch_tensor(T, base == 0 ? nQ : nM, batch, cx->stream));
@@ -2099,23 +2515,28 @@ extern "C" int lr_bfv_mul(lr_bfv_plan *pl, const lr_poly *a0, const lr_poly *a1,
         }
     }
     return LR_OK;
+    });
 }
 
 // ------------------------------------------------------------------------------------------
 // measurement
 // ------------------------------------------------------------------------------------------
 extern "C" int lr_timer_start(lr_context *c) {
+    return guarded([&]() -> int {
     if (!c) return fail(LR_ERR_ARG, "null context");
     LR_HIP(hipSetDevice(c->device));
     LR_HIP(hipEventRecord(c->ev0, c->stream));
     return LR_OK;
+    });
 }
 
 extern "C" int lr_timer_stop(lr_context *c, float *elapsed_ms) {
+    return guarded([&]() -> int {
     if (!c || !elapsed_ms) return fail(LR_ERR_ARG, "null argument");
     LR_HIP(hipSetDevice(c->device));
     LR_HIP(hipEventRecord(c->ev1, c->stream));
     LR_HIP(hipEventSynchronize(c->ev1));
     LR_HIP(hipEventElapsedTime(elapsed_ms, c->ev0, c->ev1));
     return LR_OK;
+    });
 }

@@ -60,20 +60,20 @@ AsmKernels *kernels_for_current_device() {
 bool ntt_asm_available(int logn) { return logn >= 12 && logn <= 16 && kernels_for_current_device() != nullptr; }
 
 // variant = lazy-correction mode of asmgen/gen_ntt.py (forward 0, 1, 2) / gen_intt.py (inverse 0, 1)
-hipError_t launch_ntt_asm(const NttLaunch &a, int logn, int inverse, int variant, hipStream_t stream) {
+hipError_t launch_ntt_asm(const NttLaunch &a, int logn, int inverse, int variant, hipStream_t stream, bool wide14, char *kernel_name) {
     AsmKernels *k = kernels_for_current_device();
     if (!k || logn < 12 || logn > 15) return hipErrorNotSupported;
     // N = 2^12 (256 threads, four columns per thread, 36 KiB LDS image) and N = 2^13, 2^14 (512 threads, two columns,
     // 72 KiB) run several workgroups per CU: one
-    // covers the other's load and store phases.  LR_ASM_14_1024=1 selects the 1024-thread kernels (testing aid).
-    const bool wide14 = std::getenv("LR_ASM_14_1024") != nullptr;
+    // covers the other's load and store phases.  wide14 (Options::asm14_1024) selects the 1024-thread kernels (testing aid).
     const bool x = logn <= 13 || (logn == 14 && !wide14);
     char name[32];
     std::snprintf(name, sizeof name, "lr_ntt_%s%d%s_m%d", inverse ? "inv" : "fwd", logn, x ? "x" : "", variant);
     auto it = k->fn.find(name);
     if (it == k->fn.end()) return hipErrorNotSupported;
+    if (kernel_name) std::snprintf(kernel_name, 32, "%s", name);
     if (a.n_items <= 0 || a.batch <= 0) return hipSuccess;
-    if (a.batch > 65535) return hipErrorInvalidValue;
+    if (variant < 3 && a.hole == 0 && a.batch > 65535) return hipErrorInvalidValue;   // run_ntt chunks such launches
     NttLaunch args = a;
     size_t size = sizeof(NttLaunch);
     void *extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
@@ -96,13 +96,14 @@ hipError_t launch_ntt_asm(const NttLaunch &a, int logn, int inverse, int variant
 // N = 2^16 runs as two 2^15 sub-blocks per limb (grid x = 2 * n_items).  kind: 's' = forward with the stage over
 // bit 15 fused into the loads (out of place only) / inverse sub-blocks (lazy outputs, ntt_top_kernel follows),
 // 'p' = forward sub-blocks after a separate ntt_top_kernel pass (in place allowed).
-hipError_t launch_ntt_asm16(const NttLaunch &a, int inverse, char kind, int variant, hipStream_t stream) {
+hipError_t launch_ntt_asm16(const NttLaunch &a, int inverse, char kind, int variant, hipStream_t stream, char *kernel_name) {
     AsmKernels *k = kernels_for_current_device();
     if (!k) return hipErrorNotSupported;
     char name[32];
     std::snprintf(name, sizeof name, "lr_ntt_%s16%c_m%d", inverse ? "inv" : "fwd", kind, variant);
     auto it = k->fn.find(name);
     if (it == k->fn.end()) return hipErrorNotSupported;
+    if (kernel_name) std::snprintf(kernel_name, 32, "%s", name);
     if (a.n_items <= 0 || a.batch <= 0) return hipSuccess;
     NttLaunch args = a;
     args.sub_log = 1;

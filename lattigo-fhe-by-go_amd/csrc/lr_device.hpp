@@ -23,6 +23,23 @@ struct LimbParams {
 };
 
 constexpr int kMaxLimbs = 64;
+
+// Testing / diagnostic switches.  The environment is read ONCE PER HANDLE, when the handle is created
+// (lr_context_create, lr_bext_create, lr_decomposer_create, lr_*_plan_create): a caller's environment cannot change the code
+// path of a live handle in the middle of a run.
+struct Options {
+    bool no_asm = false;           // LR_NO_ASM: C++ NTT kernels only
+    bool no_fp = false;            // LR_NO_FP: integer bodies for every modulus
+    bool no_epilogue = false;      // LR_NO_EPILOGUE: separate subtract-multiply instead of the forward kernels' epilogue
+    bool rescale_unfused = false;  // LR_RESCALE_UNFUSED: the rounding rescale with explicit shifted copies
+    bool no_staging = false;       // LR_NO_STAGING: N = 2^16 key switch with in-place forward transforms
+    bool ext_narrow = false;       // LR_EXT_NARROW: per-term basis extension instead of the 128-bit column sums
+    bool asm14_1024 = false;       // LR_ASM_14_1024: the 1024-thread plan at N = 2^14
+    bool no_ingest = false;        // LR_NO_INGEST: key-switch digits through the extension kernel + staging instead of the fused ingest
+    int ntt_mode = -1;             // LR_NTT_MODE
+    int asm_variant = -1;          // LR_ASM_VARIANT
+    static Options from_env();
+};
 // small per-limb host values travelling in the kernel-argument segment (no host->device copy)
 struct LimbScalars { u64 v[kMaxLimbs]; };
 
@@ -118,10 +135,11 @@ hipError_t launch_scalar_pair(const ScalarPairLaunch &L, int limbs, int batch, h
 struct TensorLaunch {
     const u64 *a0, *a1, *b0, *b1;
     long long a0_stride, a1_stride, b0_stride, b1_stride;
-    u64 *c0, *c1, *c2;
-    long long c_stride;
+    u64 *c0, *c1, *c2;        // may alias the inputs (every thread reads its four operands before it writes)
+    long long c_stride;       // of c0
     int n;
     const LimbParams *lp;
+    long long c1_stride, c2_stride;
 };
 hipError_t launch_tensor(const TensorLaunch &L, int limbs, int batch, hipStream_t stream);
 
@@ -144,7 +162,7 @@ struct KeyMacLaunch {
     long long key_poly_stride;     // between key polys
     int key_limb0;                 // first key limb of this segment (0 for Q, |Q| for P)
     u64 *out0, *out1;
-    long long out_stride;
+    long long out_stride;          // of out0
     int n, beta;
     const LimbParams *lp;
     // limbs [i*alpha, (i+1)*alpha) of digit i are the NTT-domain input itself (ckks/evaluator.go:1579-1584):
@@ -152,6 +170,7 @@ struct KeyMacLaunch {
     const u64 *own;
     long long own_stride;
     int alpha;
+    long long out1_stride;         // of out1 (the two outputs of lr_ckks_switch_keys may have different allocations)
 };
 hipError_t launch_keymac(const KeyMacLaunch &L, int limbs, int batch, hipStream_t stream);
 
@@ -254,8 +273,10 @@ __device__ __forceinline__ void st_stream(ulonglong2 *p, ulonglong2 v) {
 hipError_t launch_ntt(const NttLaunch &a, int logn, bool inverse, int mode, hipStream_t stream);
 // hand-scheduled assembly forward NTT (lr_asm.cpp); N = 2^14 / 2^15, lazy mode 1 only
 bool ntt_asm_available(int logn);
-hipError_t launch_ntt_asm(const NttLaunch &a, int logn, int inverse, int variant, hipStream_t stream);
-hipError_t launch_ntt_asm16(const NttLaunch &a, int inverse, char kind, int variant, hipStream_t stream);
+// kernel_name (optional, >= 32 bytes): receives the name of the code object that was launched
+hipError_t launch_ntt_asm(const NttLaunch &a, int logn, int inverse, int variant, hipStream_t stream, bool wide14 = false,
+                          char *kernel_name = nullptr);
+hipError_t launch_ntt_asm16(const NttLaunch &a, int inverse, char kind, int variant, hipStream_t stream, char *kernel_name = nullptr);
 // N = 2^16 helpers (lr_ntt.hip): the streaming stage over bit 15, and whether no input row of a launch is an output row
 hipError_t launch_ntt_top(const NttLaunch &a, int inverse, hipStream_t stream);
 bool ntt_rows_disjoint(const NttLaunch &a, int logn);

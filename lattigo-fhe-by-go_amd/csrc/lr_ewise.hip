@@ -169,8 +169,8 @@ __global__ __launch_bounds__(256) void tensor_kernel(TensorLaunch L) {
     const ulonglong2 *pb0 = reinterpret_cast<const ulonglong2 *>(L.b0 + b * L.b0_stride + row);
     const ulonglong2 *pb1 = reinterpret_cast<const ulonglong2 *>(L.b1 + b * L.b1_stride + row);
     ulonglong2 *pc0 = reinterpret_cast<ulonglong2 *>(L.c0 + b * L.c_stride + row);
-    ulonglong2 *pc1 = reinterpret_cast<ulonglong2 *>(L.c1 + b * L.c_stride + row);
-    ulonglong2 *pc2 = reinterpret_cast<ulonglong2 *>(L.c2 + b * L.c_stride + row);
+    ulonglong2 *pc1 = reinterpret_cast<ulonglong2 *>(L.c1 + b * L.c1_stride + row);
+    ulonglong2 *pc2 = reinterpret_cast<ulonglong2 *>(L.c2 + b * L.c2_stride + row);
     const int pairs = L.n >> 1;
     for (int e = blockIdx.x * 256 + threadIdx.x; e < pairs; e += gridDim.x * 256) {
         const ulonglong2 a0 = ld_stream(pa0 + e), a1 = ld_stream(pa1 + e), b0 = ld_stream(pb0 + e), b1 = ld_stream(pb1 + e);
@@ -381,7 +381,7 @@ __global__ __launch_bounds__(256) void keymac_kernel(KeyMacLaunch L) {
     const ulonglong2 *pc = reinterpret_cast<const ulonglong2 *>(L.c2 + b * L.c2_poly_stride + row);
     const ulonglong2 *pk = reinterpret_cast<const ulonglong2 *>(L.key + (long long)(L.key_limb0 + limb) * L.n);
     ulonglong2 *po0 = reinterpret_cast<ulonglong2 *>(L.out0 + b * L.out_stride + row);
-    ulonglong2 *po1 = reinterpret_cast<ulonglong2 *>(L.out1 + b * L.out_stride + row);
+    ulonglong2 *po1 = reinterpret_cast<ulonglong2 *>(L.out1 + b * L.out1_stride + row);
     const long long cd = L.c2_digit_stride >> 1, kd = L.key_poly_stride >> 1;   // in 16-byte units
     const ulonglong2 *pown = L.alpha > 0 ? reinterpret_cast<const ulonglong2 *>(L.own + b * L.own_stride + row) : nullptr;
     const int own_digit = L.alpha > 0 ? limb / L.alpha : -1;

@@ -51,6 +51,13 @@ class Poly:
             _handle = h
         self.h = _handle
 
+    @classmethod
+    def wrap(cls, ctx, device_ptr, limbs, batch):
+        """A Poly over caller-owned device memory (e.g. a torch int64 tensor's data_ptr()), no copy (lr_poly_wrap)."""
+        h = C.c_void_p()
+        check(lib().lr_poly_wrap(ctx.h, C.c_void_p(device_ptr), limbs, batch, C.byref(h)))
+        return cls(ctx, limbs, batch, _handle=h)
+
     # --- reference accessors -----------------------------------------------------------
     def GetLenModuli(self):  # ring/ring_object.go:55
         n = C.c_int()
@@ -304,6 +311,12 @@ class Context:
         check(lib().lr_context_ntt_variants(self.h, C.byref(f), C.byref(i)))
         return f.value, i.value
 
+    def last_ntt_kernel(self):
+        """name of the kernel the last NTT / InvNTT launch of this context dispatched (diagnostics)"""
+        buf = C.create_string_buffer(64)
+        check(lib().lr_context_last_ntt_kernel(self.h, buf, len(buf)))
+        return buf.value.decode()
+
     def MultByMonomial(self, p1, monomialDeg, p2):  # ring/ring.go:663
         check(lib().lr_mult_by_monomial(self.h, p1.h, int(monomialDeg), p2.h))
 
@@ -497,44 +510,32 @@ class CkksPlan:
         check(lib().lr_ckks_switch_keys(self.h, level, cx.h, evakey.h, p0.h, p1.h))
 
     def MulRelin(self, level, ct0, ct1, evakey, ctOut):
-        """ct0, ct1, ctOut: pairs (value[0], value[1]) of Poly."""
-        check(lib().lr_ckks_mulrelin(self.h, level, ct0[0].h, ct0[1].h, ct1[0].h, ct1[1].h, evakey.h,
-                                     ctOut[0].h, ctOut[1].h))
+        """evaluator.MulRelin (ckks/evaluator.go:1016).  ct0, ct1: tuples of Poly -- (value[0], value[1]) for a ciphertext,
+        (value[0],) for a plaintext; ctOut: pair, or triple when evakey is None and both operands are ciphertexts
+        (degree-2 result, :1061-1066)."""
+        if len(ct0) + len(ct1) == 3:                                     # plaintext x ciphertext, :1113-1131
+            pt, ct = (ct0, ct1) if len(ct0) == 1 else (ct1, ct0)
+            check(lib().lr_ckks_mul_plain(self.h, level, pt[0].h, ct[0].h, ct[1].h, ctOut[0].h, ctOut[1].h))
+        elif evakey is None:
+            check(lib().lr_ckks_mul_norelin(self.h, level, ct0[0].h, ct0[1].h, ct1[0].h, ct1[1].h,
+                                            ctOut[0].h, ctOut[1].h, ctOut[2].h))
+        else:
+            check(lib().lr_ckks_mulrelin(self.h, level, ct0[0].h, ct0[1].h, ct1[0].h, ct1[1].h, evakey.h,
+                                         ctOut[0].h, ctOut[1].h))
 
     def Rescale(self, ct):
         check(lib().lr_ckks_rescale(self.h, ct[0].h, ct[1].h))
 
-    def EncryptPk(self, contextQP, baseconverter, level, u, pk, e, plaintext, ctOut):
-        """pkEncryptor.encrypt, the branch through the special primes (ckks/encryptor.go:207-243), after the sampling:
+    def EncryptPk(self, level, u, pk, e, plaintext, ctOut):
+        """pkEncryptor.encrypt, the branch through the special primes (ckks/encryptor.go:205-234), after the sampling:
         u = SampleTernaryMontgomeryNTT over QP, e = the two Gaussian samples as residues over QP (coefficient domain,
-        what SampleAndAdd adds, ring/gaussianSampler.go:254-274), pk = (pk0, pk1) over QP, plaintext over Q (NTT).
-        Compositions of entry points of the ring: MulCoeffsMontgomery x2, InvNTT x2, Add x2, ModDownPQ x2, NTT x2, Add."""
-        cQ = self.contextQ
-        p0, p1 = contextQP.NewPoly(u.batch), contextQP.NewPoly(u.batch)
-        contextQP.MulCoeffsMontgomery(u, pk[0], p0)                     # :213
-        contextQP.MulCoeffsMontgomery(u, pk[1], p1)                     # :215
-        contextQP.InvNTT(p0, p0)                                        # :218
-        contextQP.InvNTT(p1, p1)
-        contextQP.Add(p0, e[0], p0)                                     # :222 SampleAndAdd
-        contextQP.Add(p1, e[1], p1)
-        baseconverter.ModDownPQ(level, p0, ctOut[0])                    # :227
-        baseconverter.ModDownPQ(level, p1, ctOut[1])
-        cQ.NTTLvl(level, ctOut[0], ctOut[0])                            # :233
-        cQ.NTTLvl(level, ctOut[1], ctOut[1])
-        cQ.AddLvl(level, ctOut[0], plaintext, ctOut[0])                 # :238
+        what SampleAndAdd adds, ring/gaussianSampler.go:254-274), pk = (pk0, pk1) over QP, plaintext over Q (NTT)."""
+        check(lib().lr_ckks_encrypt_pk(self.h, level, u.h, pk[0].h, pk[1].h, e[0].h, e[1].h, plaintext.h, ctOut[0].h, ctOut[1].h))
 
     def Decrypt(self, level, ct, sk, ptOut):
         """decryptor.Decrypt (ckks/decryptor.go:53-78): Horner evaluation at the secret key (Montgomery NTT form)."""
-        cQ = self.contextQ
-        degree = len(ct) - 1
-        cQ.CopyLvl(level, ct[degree], ptOut)
-        for i in range(degree, 0, -1):
-            cQ.MulCoeffsMontgomeryLvl(level, ptOut, sk, ptOut)
-            cQ.AddLvl(level, ptOut, ct[i - 1], ptOut)
-            if i & 7 == 7:
-                cQ.ReduceLvl(level, ptOut, ptOut)
-        if degree & 7 != 7:
-            cQ.ReduceLvl(level, ptOut, ptOut)
+        arr = (C.c_void_p * len(ct))(*[c.h.value for c in ct])
+        check(lib().lr_ckks_decrypt(self.h, level, arr, len(ct) - 1, sk.h, ptOut.h))
 
     def PermuteNTT(self, level, ct0, gen, rotkey, ctOut):
         """evaluator.permuteNTT (ckks/evaluator.go:1448): RotateColumns with the key of that rotation, or Conjugate.

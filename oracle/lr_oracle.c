@@ -962,6 +962,81 @@ void oc_ckks_mulrelin(oc_ckks_plan *p, int level, const u64 *ct0, const u64 *ct1
     free(c00); free(c01); free(c0); free(c1); free(c2); free(q1); free(q2);
 }
 
+/* MulRelin with evakey == nil, ckks/evaluator.go:1038-1111: the degree-2 result (c0, c1, c2).  squaring != 0 takes the
+ * el0 == el1 branch (:1083-1088: c1 = 2 * c0 * c1 through AddLvl), otherwise the regular one (:1090-1096). */
+void oc_ckks_mul_norelin(oc_ckks_plan *p, int level, const u64 *ct0, const u64 *ct1, int squaring, u64 *out) {
+    const oc_context *cQ = p->cQ;
+    const u64 N = cQ->N;
+    size_t sz = (size_t)(level + 1) * N;
+    u64 *c00 = (u64 *)malloc(sz * 8), *c01 = (u64 *)malloc(sz * 8);
+    u64 *c0 = out, *c1 = out + sz, *c2 = out + 2 * sz;
+    oc_ewise(cQ, OC_MFORM, level, ct0, NULL, c00, NULL);                      /* :1080 */
+    oc_ewise(cQ, OC_MFORM, level, ct0 + sz, NULL, c01, NULL);                 /* :1081 */
+    if (squaring) {
+        oc_ewise(cQ, OC_MUL_MONT, level, c00, ct1, c0, NULL);                 /* :1085 */
+        oc_ewise(cQ, OC_MUL_MONT, level, c00, ct1 + sz, c1, NULL);            /* :1086 */
+        oc_ewise(cQ, OC_ADD, level, c1, c1, c1, NULL);                        /* :1087 */
+        oc_ewise(cQ, OC_MUL_MONT, level, c01, ct1 + sz, c2, NULL);            /* :1088 */
+    } else {
+        oc_ewise(cQ, OC_MUL_MONT, level, c00, ct1, c0, NULL);                 /* :1092 */
+        oc_ewise(cQ, OC_MUL_MONT, level, c00, ct1 + sz, c1, NULL);            /* :1093 */
+        oc_ewise(cQ, OC_MUL_MONT_AND_ADD, level, c01, ct1, c1, NULL);         /* :1094 */
+        oc_ewise(cQ, OC_MUL_MONT, level, c01, ct1 + sz, c2, NULL);            /* :1095 */
+    }
+    free(c00); free(c01);
+}
+
+/* MulRelin, plaintext x ciphertext branch, ckks/evaluator.go:1113-1131: pt = the degree-0 operand's value[0] */
+void oc_ckks_mul_plain(oc_ckks_plan *p, int level, const u64 *pt, const u64 *ct, u64 *out) {
+    const oc_context *cQ = p->cQ;
+    size_t sz = (size_t)(level + 1) * cQ->N;
+    u64 *c00 = (u64 *)calloc(sz, 8);                                          /* :1127 c00.Zero() */
+    oc_ewise(cQ, OC_MFORM, level, pt, NULL, c00, NULL);                       /* :1129 */
+    oc_ewise(cQ, OC_MUL_MONT, level, c00, ct, out, NULL);                     /* :1130 */
+    oc_ewise(cQ, OC_MUL_MONT, level, c00, ct + sz, out + sz, NULL);           /* :1131 */
+    free(c00);
+}
+
+/* pkEncryptor.encrypt, the branch through the special primes, after the sampling (ckks/encryptor.go:205-234).
+ * cQP: the context over Q||P.  u = SampleTernaryMontgomeryNTT over QP (:206), pk = (pk0, pk1) over QP, e0 / e1 = the
+ * residues SampleAndAdd adds (ring/gaussianSampler.go:254-274: CRed(x + e) per coefficient, e in [0, q]), pt over
+ * Q[0..level] in the NTT domain.  ct = [2][level+1][N].  The reference transforms with Context.NTT (:229-230), which walks every
+ * modulus of contextQ: for level < |Q|-1 Go panics there; limbs 0..level are transformed here. */
+void oc_ckks_encrypt_pk(oc_ckks_plan *p, const oc_context *cQP, int level, const u64 *u, const u64 *pk0, const u64 *pk1,
+                        const u64 *e0, const u64 *e1, const u64 *pt, u64 *ct) {
+    const oc_context *cQ = p->cQ;
+    const u64 N = cQ->N;
+    const int lQP = cQP->L - 1;
+    size_t sz = (size_t)(level + 1) * N, szQP = (size_t)cQP->L * N;
+    u64 *p0 = (u64 *)malloc(szQP * 8), *p1 = (u64 *)malloc(szQP * 8);
+    oc_ewise(cQP, OC_MUL_MONT, lQP, u, pk0, p0, NULL);                        /* :209 */
+    oc_ewise(cQP, OC_MUL_MONT, lQP, u, pk1, p1, NULL);                        /* :211 */
+    oc_intt_lvl(cQP, lQP, p0, p0);                                            /* :214 */
+    oc_intt_lvl(cQP, lQP, p1, p1);                                            /* :215 */
+    oc_ewise(cQP, OC_ADD, lQP, p0, e0, p0, NULL);                             /* :218 SampleAndAdd */
+    oc_ewise(cQP, OC_ADD, lQP, p1, e1, p1, NULL);                             /* :220 */
+    oc_moddown_pq(p->bext, level, p0, ct);                                    /* :223 */
+    oc_moddown_pq(p->bext, level, p1, ct + sz);                               /* :226 */
+    oc_ntt_lvl(cQ, level, ct, ct);                                            /* :229 */
+    oc_ntt_lvl(cQ, level, ct + sz, ct + sz);                                  /* :230 */
+    oc_ewise(cQ, OC_ADD, level, ct, pt, ct, NULL);                            /* :234 */
+    free(p0); free(p1);
+}
+
+/* decryptor.Decrypt, ckks/decryptor.go:53-78: Horner evaluation at the secret key (NTT + Montgomery form).
+ * ct = [degree+1][level+1][N] */
+void oc_ckks_decrypt(oc_ckks_plan *p, int level, const u64 *ct, int degree, const u64 *sk, u64 *pt) {
+    const oc_context *cQ = p->cQ;
+    size_t sz = (size_t)(level + 1) * cQ->N;
+    oc_ewise(cQ, OC_COPY, level, ct + (size_t)degree * sz, NULL, pt, NULL);   /* :61 */
+    for (int i = degree; i > 0; i--) {                                         /* :65 */
+        oc_ewise(cQ, OC_MUL_MONT, level, pt, sk, pt, NULL);                   /* :67 */
+        oc_ewise(cQ, OC_ADD, level, pt, ct + (size_t)(i - 1) * sz, pt, NULL); /* :68 */
+        if ((i & 7) == 7) oc_ewise(cQ, OC_REDUCE, level, pt, NULL, pt, NULL); /* :70-72 */
+    }
+    if ((degree & 7) != 7) oc_ewise(cQ, OC_REDUCE, level, pt, NULL, pt, NULL); /* :75-77 */
+}
+
 /* ==================== bfv/evaluator.go caller sequence ==================== */
 
 /* tensorAndRescale, bfv/evaluator.go:278-464 (both operands of degree 1, ct0 != ct1) */
@@ -1243,7 +1318,7 @@ void oc_simple_scaler_new(const oc_context *c, u64 t, u64 *wi, double *ti, u64 p
     } else {
         oc_bred_params(t, ut);
         params[0] = ut[0];                                             /* :216 */
-        params[1] = oc_mred_params(t);                                 /* :217 */
+        params[1] = oc_mred_params(t);                                 /* :214 */
     }
     for (int i = 0; i < c->L; i++) {
         const u64 qi = c->q[i];

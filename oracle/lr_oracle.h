@@ -184,6 +184,13 @@ void oc_ckks_mulrelin(oc_ckks_plan *p, int level, const uint64_t *ct0, const uin
                       const uint64_t *evk, uint64_t *out);
 
 /* permuteNTT (ckks/evaluator.go:1448-1468): ct, out = [2][level+1][N]; gen = Galois element; evk as above. */
+/* MulRelin without evaluation key (degree-2 output), plaintext x ciphertext: ckks/evaluator.go:1038-1111, :1113-1131 */
+void oc_ckks_mul_norelin(oc_ckks_plan *p, int level, const uint64_t *ct0, const uint64_t *ct1, int squaring, uint64_t *out);
+void oc_ckks_mul_plain(oc_ckks_plan *p, int level, const uint64_t *pt, const uint64_t *ct, uint64_t *out);
+/* pkEncryptor.encrypt after the sampling (ckks/encryptor.go:205-234), decryptor.Decrypt (ckks/decryptor.go:53-78) */
+void oc_ckks_encrypt_pk(oc_ckks_plan *p, const oc_context *cQP, int level, const uint64_t *u, const uint64_t *pk0,
+                        const uint64_t *pk1, const uint64_t *e0, const uint64_t *e1, const uint64_t *pt, uint64_t *ct);
+void oc_ckks_decrypt(oc_ckks_plan *p, int level, const uint64_t *ct, int degree, const uint64_t *sk, uint64_t *pt);
 void oc_ckks_permute_ntt(oc_ckks_plan *p, int level, const uint64_t *ct, uint64_t gen, const uint64_t *evk,
                          uint64_t *out);
 /* RotateHoisted + switchKeyHoisted (:1252-1391): out = [n_rot][2][level+1][N]. */

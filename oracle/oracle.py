@@ -50,6 +50,28 @@ class _CBext(C.Structure):
 
 
 _lib = None
+_NATIVE_DIR = os.path.join(_HERE, "_native")
+_NATIVE_PATH = os.path.join(_NATIVE_DIR, "liblr_oracle_native.so")
+native_loaded = False
+
+
+def use_native():
+    """Switch this process to a build of the SAME source with ``-O2 -march=native``, compiled on the machine it runs on
+    (bench.py's cpu_baseline on the GPU box).  The portable build (oracle/Makefile, no -march) is what
+    travels and what the tests use.  Returns True if the native build is in use."""
+    global _lib, native_loaded
+    if native_loaded:
+        return True
+    try:
+        os.makedirs(_NATIVE_DIR, exist_ok=True)
+        src = os.path.join(_HERE, "lr_oracle.c")
+        subprocess.check_call(["gcc", "-O2", "-march=native", "-fPIC", "-std=c11", "-ffp-contract=off", "-fno-fast-math",
+                               "-shared", "-o", _NATIVE_PATH, src, "-lm"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        _lib = _bind(C.CDLL(_NATIVE_PATH))
+        native_loaded = True
+    except Exception:
+        native_loaded = False
+    return native_loaded
 
 
 def lib():
@@ -57,7 +79,11 @@ def lib():
     if _lib is not None:
         return _lib
     build()
-    L = C.CDLL(_LIB_PATH)
+    _lib = _bind(C.CDLL(_LIB_PATH))
+    return _lib
+
+
+def _bind(L):
     vp = C.c_void_p
     i = C.c_int
 
@@ -118,6 +144,10 @@ def lib():
     sig("oc_ckks_switch_keys", None, vp, i, vp, vp, vp, vp)
     sig("oc_ckks_mulrelin", None, vp, i, vp, vp, vp, vp)
     sig("oc_ckks_permute_ntt", None, vp, i, vp, u64, vp, vp)
+    sig("oc_ckks_mul_norelin", None, vp, i, vp, vp, i, vp)
+    sig("oc_ckks_mul_plain", None, vp, i, vp, vp, vp)
+    sig("oc_ckks_encrypt_pk", None, vp, vp, i, vp, vp, vp, vp, vp, vp, vp)
+    sig("oc_ckks_decrypt", None, vp, i, vp, i, vp, vp)
     sig("oc_ckks_rotate_hoisted", None, vp, i, vp, i, vp, vp, vp)
     sig("oc_bfv_mul", None, vp, u64, vp, vp, vp, vp, vp)
     sig("oc_permute_ntt_index", None, u64, u64, u64, vp)
@@ -135,7 +165,6 @@ def lib():
     sig("oc_f128_div", None, dp, dp, dp)
     sig("oc_simple_scaler_new", None, vp, u64, u64p, dp, u64p)
     sig("oc_simple_scale", None, vp, u64, u64p, dp, u64p, vp, vp, i)
-    _lib = L
     return L
 
 
@@ -519,6 +548,34 @@ class CkksPlan:
         g = (C.c_uint64 * n)(*[int(x) for x in gens])
         ptrs = (C.c_void_p * n)(*[e.ctypes.data for e in evks])
         lib().oc_ckks_rotate_hoisted(self.h, level, _ptr(ct), n, g, ptrs, _ptr(out))
+        return out
+
+    def mul_norelin(self, level, ct0, ct1, squaring=False):
+        """MulRelin with evakey == nil (ckks/evaluator.go:1038-1111): degree-2 output [3, level+1, N]"""
+        ct0, ct1 = _arr(ct0), _arr(ct1)
+        out = np.zeros((3, level + 1, self.cQ.N), dtype=np.uint64)
+        lib().oc_ckks_mul_norelin(self.h, level, _ptr(ct0), _ptr(ct1), 1 if squaring else 0, _ptr(out))
+        return out
+
+    def mul_plain(self, level, pt, ct):
+        """MulRelin, plaintext x ciphertext (ckks/evaluator.go:1113-1131)"""
+        pt, ct = _arr(pt), _arr(ct)
+        out = np.zeros((2, level + 1, self.cQ.N), dtype=np.uint64)
+        lib().oc_ckks_mul_plain(self.h, level, _ptr(pt), _ptr(ct), _ptr(out))
+        return out
+
+    def encrypt_pk(self, ctxQP, level, u, pk0, pk1, e0, e1, pt):
+        """pkEncryptor.encrypt after the sampling (ckks/encryptor.go:205-234)"""
+        u, pk0, pk1, e0, e1, pt = (_arr(x) for x in (u, pk0, pk1, e0, e1, pt))
+        out = np.zeros((2, level + 1, self.cQ.N), dtype=np.uint64)
+        lib().oc_ckks_encrypt_pk(self.h, ctxQP.h, level, _ptr(u), _ptr(pk0), _ptr(pk1), _ptr(e0), _ptr(e1), _ptr(pt), _ptr(out))
+        return out
+
+    def decrypt(self, level, ct, sk):
+        """decryptor.Decrypt (ckks/decryptor.go:53-78); ct = [degree+1, level+1, N]"""
+        ct, sk = _arr(ct), _arr(sk)
+        out = np.zeros((level + 1, self.cQ.N), dtype=np.uint64)
+        lib().oc_ckks_decrypt(self.h, level, _ptr(ct), ct.shape[0] - 1, _ptr(sk), _ptr(out))
         return out
 
     def mulrelin(self, level, ct0, ct1, evk):

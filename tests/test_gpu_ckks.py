@@ -177,3 +177,117 @@ def test_mulrelin_and_rescale_without_epilogue(gpu_pkg, oracle, logn, nq, np_, l
     """ModDown and the rounding rescale with the separate subtract-multiply pass instead of the forward kernels' epilogue"""
     monkeypatch.setenv("LR_NO_EPILOGUE", "1")
     test_mulrelin_and_rescale(gpu_pkg, oracle, logn, nq, np_, level)
+
+
+# ---- MulRelin's other branches (ckks/evaluator.go:1038-1131) ---------------------------------------------------------------
+@pytest.mark.parametrize("logn,nq,np_,level", [(10, 6, 2, 5), (13, 6, 2, 3), (15, 18, 3, 17)])
+def test_mul_without_relinearisation_key(gpu_pkg, oracle, logn, nq, np_, level):
+    """evakey == nil: the degree-2 tensor (:1061-1066, :1105-1111); regular case, squaring case (el0 == el1, :1083-1088) and the
+    receiver being one of the inputs"""
+    N, Q, P, cQ, cP, plan, oplan, evk, pevk = _ckks(gpu_pkg, oracle, logn, nq, np_, 2)
+    mk = lambda s: gpu_pkg.sampling.uniform_poly(Q[:level + 1], N, 2, seed=s)
+    a0, a1, b0, b1 = mk(1), mk(2), mk(3), mk(4)
+    P_ = lambda x: cQ.NewPolyLvl(level, 2).set(x)
+    ct0, ct1 = (P_(a0), P_(a1)), (P_(b0), P_(b1))
+    out = tuple(cQ.NewPolyLvl(level, 2) for _ in range(3))
+    plan.MulRelin(level, ct0, ct1, None, out)
+    for b in range(2):
+        want = oplan.mul_norelin(level, np.stack([a0[b], a1[b]]), np.stack([b0[b], b1[b]]))
+        for k in range(3):
+            assert np.array_equal(out[k].get()[b], want[k]), (b, k)
+    # squaring: the same operand handles on both sides, against the oracle's restatement of the el0 == el1 branch
+    plan.MulRelin(level, ct0, ct0, None, out)
+    for b in range(2):
+        ct = np.stack([a0[b], a1[b]])
+        want = oplan.mul_norelin(level, ct, ct, squaring=True)
+        assert np.array_equal(want, oplan.mul_norelin(level, ct, ct, squaring=False))     # the two branches agree
+        for k in range(3):
+            assert np.array_equal(out[k].get()[b], want[k]), (b, k)
+    # ctOut == ct0: components 0 and 1 of the result overwrite the first operand (:1105-1111)
+    c2 = cQ.NewPolyLvl(level, 2)
+    plan.MulRelin(level, ct0, ct1, None, (ct0[0], ct0[1], c2))
+    for b in range(2):
+        want = oplan.mul_norelin(level, np.stack([a0[b], a1[b]]), np.stack([b0[b], b1[b]]))
+        assert np.array_equal(ct0[0].get()[b], want[0]) and np.array_equal(ct0[1].get()[b], want[1]) and np.array_equal(c2.get()[b], want[2])
+
+
+@pytest.mark.parametrize("logn,nq,np_,level,pt_batch", [(10, 6, 2, 5, 1), (13, 6, 2, 3, 2), (15, 18, 3, 17, 1)])
+def test_mul_plaintext_ciphertext(gpu_pkg, oracle, logn, nq, np_, level, pt_batch):
+    """plaintext x ciphertext and ciphertext x plaintext (:1113-1131), a shared plaintext (batch 1) and one per ciphertext"""
+    N, Q, P, cQ, cP, plan, oplan, evk, pevk = _ckks(gpu_pkg, oracle, logn, nq, np_, 2)
+    mk = lambda s, n=2: gpu_pkg.sampling.uniform_poly(Q[:level + 1], N, n, seed=s).reshape(n, level + 1, N)
+    a0, a1, m = mk(1), mk(2), mk(7, pt_batch)
+    ct = (cQ.NewPolyLvl(level, 2).set(a0), cQ.NewPolyLvl(level, 2).set(a1))
+    pt = (cQ.NewPolyLvl(level, pt_batch).set(m),)
+    for ops in ((pt, ct), (ct, pt)):
+        out = (cQ.NewPolyLvl(level, 2), cQ.NewPolyLvl(level, 2))
+        plan.MulRelin(level, ops[0], ops[1], None, out)
+        for b in range(2):
+            want = oplan.mul_plain(level, m[b % pt_batch], np.stack([a0[b], a1[b]]))
+            assert np.array_equal(out[0].get()[b], want[0]) and np.array_equal(out[1].get()[b], want[1]), b
+
+
+def test_switch_keys_outputs_with_different_strides(gpu_pkg, oracle):
+    """p0 and p1 allocated with different limb counts (strides): the inner product carries one stride per output"""
+    logn, nq, np_, level = 12, 6, 2, 4
+    N, Q, P, cQ, cP, plan, oplan, evk, pevk = _ckks(gpu_pkg, oracle, logn, nq, np_, 2)
+    cx = gpu_pkg.sampling.uniform_poly(Q[:level + 1], N, 2, seed=3)
+    pcx = cQ.NewPolyLvl(level, 2).set(cx)
+    p0, p1 = cQ.NewPolyLvl(level, 2), cQ.NewPoly(2)
+    plan.SwitchKeysInPlace(level, pcx, pevk, p0, p1)
+    for b in range(2):
+        w0, w1 = oplan.switch_keys(level, cx[b], evk)
+        assert np.array_equal(p0.get()[b], w0)
+        assert np.array_equal(p1.get()[b][:level + 1], w1)
+
+
+# ---- encrypt / decrypt tails (SURVEY 8(f)2) as C-ABI entry points ------------------------------------------------------------
+@pytest.mark.parametrize("logn,nq,np_,batch", [(10, 4, 2, 2), (13, 6, 3, 3), (15, 18, 3, 2)])
+def test_encrypt_pk_and_decrypt_against_oracle(gpu_pkg, oracle, logn, nq, np_, batch):
+    """lr_ckks_encrypt_pk (ckks/encryptor.go:205-234, after the sampling) and lr_ckks_decrypt (ckks/decryptor.go:53-78) against
+    the oracle's restatement on the same synthetic operands, bit for bit; (15, 18, 3) is DefaultParams[PN15QP880] at full size"""
+    N, Q, P, cQ, cP, plan, oplan, evk, pevk = _ckks(gpu_pkg, oracle, logn, nq, np_, batch)
+    QP = Q + P
+    level = nq - 1
+    ocQP = oracle.Context(N, QP)
+    uni = lambda s, n: gpu_pkg.sampling.uniform_poly(QP, N, n, seed=s).reshape(n, nq + np_, N)
+    u, e0, e1 = uni(1, batch), uni(2, batch), uni(3, batch)
+    for i, q in enumerate(QP):
+        e0[0, i, 0] = q                                   # SampleAndAdd's residue of -0 (ring/gaussianSampler.go:268)
+    pk0, pk1 = uni(4, 1), uni(5, 1)
+    pt = gpu_pkg.sampling.uniform_poly(Q, N, batch, seed=6).reshape(batch, nq, N)
+    QPpoly = lambda x: gpu_pkg.ring.Poly(cQ, nq + np_, x.shape[0]).set(x)
+    ct = (cQ.NewPoly(batch), cQ.NewPoly(batch))
+    plan.EncryptPk(level, QPpoly(u), (QPpoly(pk0), QPpoly(pk1)), (QPpoly(e0), QPpoly(e1)), cQ.NewPoly(batch).set(pt), ct)
+    wants = []
+    for b in range(batch):
+        want = oplan.encrypt_pk(ocQP, level, u[b], pk0[0], pk1[0], e0[b], e1[b], pt[b])
+        wants.append(want)
+        assert np.array_equal(ct[0].get().reshape(batch, nq, N)[b], want[0]), b
+        assert np.array_equal(ct[1].get().reshape(batch, nq, N)[b], want[1]), b
+    sk = gpu_pkg.sampling.uniform_poly(Q, N, 1, seed=8).reshape(1, nq, N)
+    psk = cQ.NewPoly(1).set(sk)
+    # degree 1 (fresh ciphertext) and degree 2 (a product before relinearisation): Horner with the reference's cadence
+    extra = gpu_pkg.sampling.uniform_poly(Q, N, batch, seed=9).reshape(batch, nq, N)
+    pextra = cQ.NewPoly(batch).set(extra)
+    for cts, stack in (((ct[0], ct[1]), lambda b: np.stack([wants[b][0], wants[b][1]])),
+                       ((ct[0], ct[1], pextra), lambda b: np.stack([wants[b][0], wants[b][1], extra[b]]))):
+        out = cQ.NewPoly(batch)
+        plan.Decrypt(level, cts, psk, out)
+        for b in range(batch):
+            assert np.array_equal(out.get().reshape(batch, nq, N)[b], oplan.decrypt(level, stack(b), sk[0])), (len(cts), b)
+
+
+def test_decrypt_degree_seven_reduction_cadence(gpu_pkg, oracle):
+    """degree 7 and 8: the `i&7 == 7` lazy reduction inside the loop and the skipped final one (ckks/decryptor.go:70-77)"""
+    logn, nq, np_ = 8, 3, 1
+    N, Q, P, cQ, cP, plan, oplan, evk, pevk = _ckks(gpu_pkg, oracle, logn, nq, np_, 1)
+    level = nq - 1
+    sk = gpu_pkg.sampling.uniform_poly(Q, N, 1, seed=1).reshape(1, nq, N)
+    psk = cQ.NewPoly(1).set(sk)
+    for degree in (7, 8):
+        ct = gpu_pkg.sampling.uniform_poly(Q, N, degree + 1, seed=degree).reshape(degree + 1, nq, N)
+        polys = [cQ.NewPoly(1).set(ct[i][None]) for i in range(degree + 1)]
+        out = cQ.NewPoly(1)
+        plan.Decrypt(level, polys, psk, out)
+        assert np.array_equal(out.get().reshape(nq, N), oplan.decrypt(level, ct, sk[0])), degree

@@ -245,7 +245,6 @@ def test_encrypt_mulrelin_decrypt_chain(gpu_pkg, oracle):
     ring = gpu_pkg.ring
     cQ, cP, cQP = ring.NewContextWithParams(N, Q), ring.NewContextWithParams(N, P), ring.NewContextWithParams(N, QP)
     plan = ring.CkksPlan(cQ, cP, 1)
-    bc = ring.NewFastBasisExtender(cQ, cP)
 
     s = _small(N, 1, 31)
     s_ntt = ocQP.ntt(_residues(s, QP))
@@ -273,7 +272,7 @@ def test_encrypt_mulrelin_decrypt_chain(gpu_pkg, oracle):
         e = [cQP.NewPoly(1).set(_residues(_small(N, 6, seed + 1 + k), QP)[None]) for k in range(2)]
         pt = cQ.NewPolyLvl(level, 1).set(ocQ.ntt(_residues(m, Q))[None])
         ct = (cQ.NewPolyLvl(level, 1), cQ.NewPolyLvl(level, 1))
-        plan.EncryptPk(cQP, bc, level, pu, ppk, e, pt, ct)
+        plan.EncryptPk(level, pu, ppk, e, pt, ct)            # lr_ckks_encrypt_pk
         return ct
 
     def decrypt(ct):

@@ -522,3 +522,92 @@ def test_rescale_at_baseline_shapes(gpu_pkg, oracle, logn, limbs, batch, name):
     got = p.get().reshape(batch, limbs - 1, N)
     for b in range(batch):
         assert np.array_equal(got[b], oc.rescale_op(oname, x[b])), (name, b)
+
+
+# ---- boundary behaviour added in round 2 ----------------------------------------------------------------------------------------
+def test_mult_by_monomial_in_place(gpu_pkg, oracle):
+    """p1 == p2 is legal in the reference (it always copies through tmpx, ring/ring.go:682)"""
+    N, moduli = 256, list(gpu_pkg.params.Qi60()[-3:])
+    ctx, oc = gpu_pkg.ring.NewContextWithParams(N, moduli), oracle.Context(N, moduli)
+    x = gpu_pkg.sampling.uniform_poly(moduli, N, 2, seed=21)
+    for deg in (1, 100, 256 + 17):
+        p = ctx.NewPoly(2).set(x)
+        ctx.MultByMonomial(p, deg, p)
+        for b in range(2):
+            assert np.array_equal(p.get()[b], oc.mult_by_monomial(x[b], deg)), (deg, b)
+
+
+def test_last_ntt_kernel_is_reported(gpu_pkg):
+    """the dispatched kernel is observable: assembly code object where one exists, the C++ kernel otherwise"""
+    ring, params = gpu_pkg.ring, gpu_pkg.params
+    N, moduli = params.DefaultParamsQi(15)
+    ctx = ring.NewContextWithParams(N, list(moduli))
+    p = ctx.NewPoly(1)
+    ctx.NTT(p, p)
+    assert ctx.last_ntt_kernel() == "lr_ntt_fwd15_m1"
+    ctx.InvNTT(p, p)
+    assert ctx.last_ntt_kernel() == "lr_ntt_inv15_m1"
+    small = ring.NewContextWithParams(256, list(params.Qi60()[-2:]))
+    q = small.NewPoly(1)
+    small.NTT(q, q)
+    assert small.last_ntt_kernel() == "ntt_fwd_kernel<8>"
+
+
+def test_ntt_batch_beyond_grid_limit_is_chunked_on_the_same_kernel(gpu_pkg, oracle):
+    """more than 65535 polys in one call: the launch is cut into chunks on the assembly kernel (grid.y limit), no change of
+    code path; every poly of the batch is checked (identical inputs -> identical outputs, one of them against the oracle)"""
+    N, moduli = 1 << 12, list(gpu_pkg.params.Qi60()[-1:])
+    batch = 65535 + 70
+    ctx, oc = gpu_pkg.ring.NewContextWithParams(N, moduli), oracle.Context(N, moduli)
+    x = gpu_pkg.sampling.uniform_poly(moduli, N, 2, seed=4).reshape(2, 1, N)
+    host = np.empty((batch, 1, N), dtype=np.uint64)
+    host[0::2], host[1::2] = x[0], x[1]
+    src, dst = ctx.NewPoly(batch).set(host), ctx.NewPoly(batch)
+    ctx.NTT(src, dst)
+    assert ctx.last_ntt_kernel() == "lr_ntt_fwd12x_m1"
+    got = dst.get().reshape(batch, 1, N)
+    w0, w1 = oc.ntt(x[0]), oc.ntt(x[1])
+    assert np.array_equal(got[0::2], np.broadcast_to(w0, got[0::2].shape))
+    assert np.array_equal(got[1::2], np.broadcast_to(w1, got[1::2].shape))
+    ctx.InvNTT(dst, dst)
+    assert np.array_equal(dst.get().reshape(batch, 1, N), host)
+
+
+def test_shared_context_two_threads(gpu_pkg, oracle):
+    """One Context shared by two threads, each with its own polys (the reference's goroutine-per-evaluator model,
+    examples/dbfv/psi/psi.go:221): the rescale temporaries are leased per call, so interleaved calls do not see each
+    other's scratch.  Different batch sizes make the two threads' scratch needs differ (the regrow path)."""
+    import threading
+    N = 1 << 12
+    _, Q, _ = gpu_pkg.params.ckks_moduli("PN15QP880")
+    Q = Q[:6]
+    ctx, oc = gpu_pkg.ring.NewContextWithParams(N, Q), oracle.Context(N, Q)
+    results, errors = {}, []
+
+    def work(tid, batch):
+        try:
+            x = gpu_pkg.sampling.uniform_poly(Q, N, batch, seed=100 + tid).reshape(batch, len(Q), N)
+            outs = []
+            for it in range(12):
+                p = ctx.NewPoly(batch).set(x)
+                ctx.DivRoundByLastModulusNTT(p)
+                if it % 3 == 0:
+                    ctx.DivFloorByLastModulusNTT(p)
+                outs.append((it % 3 == 0, p.get().reshape(batch, -1, N)))
+            results[tid] = (x, outs)
+        except Exception as exc:      # noqa: BLE001
+            errors.append(exc)
+
+    threads = [threading.Thread(target=work, args=(t, b)) for t, b in ((0, 3), (1, 7))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for tid, (x, outs) in results.items():
+        for twice, got in outs:
+            for b in (0, x.shape[0] - 1):
+                want = oc.rescale_op("oc_div_round_by_last_modulus_ntt", x[b])
+                if twice:
+                    want = oc.rescale_op("oc_div_floor_by_last_modulus_ntt", want)
+                assert np.array_equal(got[b], want), (tid, twice, b)
