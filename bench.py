@@ -87,36 +87,108 @@ def timed_region(step, steps, warmup, sync, barrier, all_max, ev_start=None, ev_
 # CPU baseline: the oracle (kind "port") on the host cores of this machine
 # ------------------------------------------------------------------------------------------------------------------------
 def host_cores():
+    """Threads worth starting on this machine: the CPUs this process may run on, capped by the cgroup CPU quota (a GPU box
+    hands one GPU's share of the host, e.g. 16 of 256 hardware threads, to the job), overridable with LR_BENCH_CPU_THREADS."""
+    if os.environ.get("LR_BENCH_CPU_THREADS"):
+        return max(1, int(os.environ["LR_BENCH_CPU_THREADS"]))
     try:
-        return max(1, len(os.sched_getaffinity(0)))
+        n = len(os.sched_getaffinity(0))
     except Exception:
-        return max(1, os.cpu_count() or 1)
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(-(-int(txt[0]) // int(txt[1])))))
+            else:
+                quota = int(txt[0])
+                period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if quota > 0:
+                    n = min(n, max(1, -(-quota // period)))
+            break
+        except Exception:
+            continue
+    return max(1, n)
+
+
+_EFFECTIVE = [None]
+
+
+def effective_cores():
+    """host_cores(), checked against what the machine really grants: when more than 32 CPUs are visible and no cgroup quota is
+    published, a short calibration (the oracle's NTT on a small ring, T threads against one) measures the parallel speed-up
+    and the thread count is cut to it -- starting 256 threads on a 16-core share only lengthens the sample."""
+    if _EFFECTIVE[0] is not None:
+        return _EFFECTIVE[0]
+    n = host_cores()
+    if n > 32 and not os.environ.get("LR_BENCH_CPU_THREADS"):
+        import concurrent.futures as cf
+
+        import numpy as np
+
+        import __graft_entry__ as graft
+        oracle = graft.load_oracle()
+        oc = oracle.Context(1 << 12, [1152921504606584833])
+        lib = oracle.lib()
+        bufs = [(np.ones((1, 1 << 12), dtype=np.uint64), np.empty((1, 1 << 12), dtype=np.uint64)) for _ in range(n)]
+
+        def spin(i, calls):
+            a, b = bufs[i]
+            for _ in range(calls):
+                lib.oc_ntt_lvl(oc.h, 0, a.ctypes.data, b.ctypes.data)
+
+        t0 = time.perf_counter()
+        spin(0, 200)
+        t1 = (time.perf_counter() - t0) / 200
+        calls = max(50, int(0.4 / t1))
+        with cf.ThreadPoolExecutor(max_workers=n) as ex:
+            t0 = time.perf_counter()
+            list(ex.map(lambda i: spin(i, calls), range(n)))
+            tn = (time.perf_counter() - t0) / calls
+        speedup = n * t1 / tn
+        n = max(1, min(n, int(round(speedup))))
+    _EFFECTIVE[0] = n
+    return n
+
+
+def progress(msg):
+    print("[bench %6.1fs] %s" % (time.perf_counter() - _T0, msg), file=sys.stderr, flush=True)
+
+
+_T0 = time.perf_counter()
 
 
 def cpu_baseline(make_worker, units_per_call, unit, what, target_seconds):
     """make_worker(i) -> a no-argument callable doing ONE call of the reference's method on thread i's own operands
     (FastBasisExtender and the evaluators own scratch: one object per thread, like one per goroutine,
-    examples/dbfv/psi/psi.go:219-233).  Times one call on one thread, then T threads x k calls."""
+    examples/dbfv/psi/psi.go:219-233).  Times one call on one thread, then one call on each of T threads at once (this
+    calibrates the sample: the machine may grant fewer cores than it shows), then T threads x k calls for about
+    `target_seconds`."""
     import concurrent.futures as cf
 
     import __graft_entry__ as graft
     oracle = graft.load_oracle()
-    cores = host_cores()
+    cores = effective_cores()
     workers = [make_worker(i) for i in range(cores)]
     t0 = time.perf_counter()
     workers[0]()
     t_one = time.perf_counter() - t0
-    per_thread = max(1, min(8192, int(target_seconds / max(t_one, 1e-6))))
 
-    def work(i):
-        for _ in range(per_thread):
-            workers[i]()
+    def run(per_thread):
+        def work(i):
+            for _ in range(per_thread):
+                workers[i]()
+        with cf.ThreadPoolExecutor(max_workers=cores) as ex:
+            t0 = time.perf_counter()
+            list(ex.map(work, range(cores)))
+            return time.perf_counter() - t0
 
-    with cf.ThreadPoolExecutor(max_workers=cores) as ex:
-        t0 = time.perf_counter()
-        list(ex.map(work, range(cores)))
-        dt = time.perf_counter() - t0
+    t_round = run(1)                                    # one call on every thread, concurrently
+    per_thread = max(1, min(8192, int(target_seconds / max(t_round, 1e-6))))
+    dt = run(per_thread)
     calls = cores * per_thread
+    progress("cpu baseline: %s done" % what)
     return {
         "value": calls * units_per_call / dt,
         "unit": unit,
@@ -144,6 +216,15 @@ def main():
     ap.add_argument("--config5-units", type=int, default=128, help="PN16QP1761 ciphertext products per GPU")
     ap.add_argument("--config5-chunk", type=int, default=32, help="products per lr_ckks_mulrelin call")
     args = ap.parse_args()
+
+    # the contract is ONE JSON line on stdout: libraries that print there (RCCL's version banner at communicator creation)
+    # are sent to stderr for the whole run, the JSON line goes to the saved descriptor
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(obj):
+        os.write(json_fd, (json.dumps(obj) + "\n").encode())
 
     import numpy as np
     import torch
@@ -293,7 +374,7 @@ def main():
                    "config": {"workload": "BASELINE config 5: %d independent CKKS MulRelin per GPU at PN16QP1761, contiguous blocks, RCCL gather" % args.config5_units,
                               "units_per_gpu": args.config5_units},
                    "roofline": c5.pop("roofline"), "config5": c5}
-            print(json.dumps(out), flush=True)
+            emit(out)
         if use_dist:
             dist.barrier()
             dist.destroy_process_group()
@@ -324,6 +405,7 @@ def main():
     seconds, dev_ms = timed_region(step, args.steps, args.warmup, sync, barrier, all_max, ctx.TimerStart, ctx.TimerStop)
     kernel_ms = dev_ms / args.steps
     kernel_name = ctx.last_ntt_kernel()
+    progress("headline NTT timed: %.4f ms per launch, kernel %s" % (kernel_ms, kernel_name))
 
     # parity spot-check inside the bench: first and last poly against the oracle (checker only)
     bit_exact = None
@@ -393,6 +475,7 @@ def main():
         ct1 = (ccQ.NewPoly(cB).set(tile(cbase[2])), ccQ.NewPoly(cB).set(tile(cbase[3])))
         cto = (ccQ.NewPoly(cB), ccQ.NewPoly(cB))
         cms = timed_on(ccQ, lambda: plan.MulRelin(clevel, ct0, ct1, evk, cto), 10)
+        progress("ckks MulRelin PN15QP880 timed: %.3f ms per batch of %d" % (cms, cB))
         oplan = oracle.CkksPlan(oracle.Context(cN, cQm), oracle.Context(cN, cPm))
         idx = cB - 1
         want = oplan.mulrelin(clevel, np.stack([cbase[0][idx % 2], cbase[1][idx % 2]]), np.stack([cbase[2][idx % 2], cbase[3][idx % 2]]),
@@ -411,7 +494,7 @@ def main():
                 op = oracle.CkksPlan(oracle.Context(cN, cQm), oracle.Context(cN, cPm))
                 a, b, k = np.stack([cbase[0][0], cbase[1][0]]), np.stack([cbase[2][0], cbase[3][0]]), evk_h.reshape(cbeta, 2, nq + np_, cN)
                 return lambda: op.mulrelin(clevel, a, b, k)
-            out["ckks_mulrelin"]["cpu_baseline"] = cpu_baseline(mk_mulrelin, 1, "MulRelin/s", "oracle MulRelin PN15QP880 level 17", 2.0)
+            out["ckks_mulrelin"]["cpu_baseline"] = cpu_baseline(mk_mulrelin, 1, "MulRelin/s", "oracle MulRelin PN15QP880 level 17", 4.0)
         del plan, ct0, ct1, cto, evk
 
         # BASELINE.json config 4: BFV DefaultParams[PN14QP438] Evaluator.Mul (tensorAndRescale, bfv/evaluator.go:278),
@@ -426,6 +509,7 @@ def main():
         b1 = (bcQ.NewPoly(bB).set(btile(bbase[2])), bcQ.NewPoly(bB).set(btile(bbase[3])))
         bo = (bcQ.NewPoly(bB), bcQ.NewPoly(bB), bcQ.NewPoly(bB))
         bms = timed_on(bcQ, lambda: bplan.Mul(b0, b1, bo), 10)
+        progress("bfv Mul PN14QP438 timed: %.3f ms per batch of %d" % (bms, bB))
         obplan = oracle.BfvPlan(oracle.Context(bN, bQ), oracle.Context(bN, bQMul), 65537)
         bidx = bB - 1
         bwant = obplan.mul(np.stack([bbase[0][bidx % 2], bbase[1][bidx % 2]]), np.stack([bbase[2][bidx % 2], bbase[3][bidx % 2]]))
@@ -437,7 +521,7 @@ def main():
                 op = oracle.BfvPlan(oracle.Context(bN, bQ), oracle.Context(bN, bQMul), 65537)
                 a, b = np.stack([bbase[0][0], bbase[1][0]]), np.stack([bbase[2][0], bbase[3][0]])
                 return lambda: op.mul(a, b)
-            out["bfv_mul"]["cpu_baseline"] = cpu_baseline(mk_bfv, 1, "Mul/s", "oracle bfv Mul PN14QP438", 2.0)
+            out["bfv_mul"]["cpu_baseline"] = cpu_baseline(mk_bfv, 1, "Mul/s", "oracle bfv Mul PN14QP438", 3.0)
         del bplan, b0, b1, bo
 
     if not args.no_extras and rank == 0:
@@ -467,7 +551,7 @@ def main():
                 a, b, o = x_last.copy(), x_last.copy(), np.empty_like(x_last)
                 lib = oracle.lib()
                 return lambda: lib.oc_ewise(oc.h, oracle.OP["MUL_MONT"], L - 1, a.ctypes.data, b.ctypes.data, o.ctypes.data, None)
-            extras["mulcoeffs_montgomery"]["cpu_baseline"] = cpu_baseline(mk_mul, 1, "poly/s", "oracle MulCoeffsMontgomery R15", 1.0)
+            extras["mulcoeffs_montgomery"]["cpu_baseline"] = cpu_baseline(mk_mul, 1, "poly/s", "oracle MulCoeffsMontgomery R15", 2.0)
         _, pmod = params.DefaultParamsPi(args.logn)
         ctxP = ring.NewContextWithParams(N, pmod, device=local)
         bext = ring.NewFastBasisExtender(ctx, ctxP)
@@ -483,7 +567,7 @@ def main():
             def mk_modup(i):
                 be = oracle.BasisExtender(oracle.Context(N, moduli), oracle.Context(N, pmod))
                 return lambda: be.modup_split_qp(L - 1, x_last)
-            extras["modup_split_qp"]["cpu_baseline"] = cpu_baseline(mk_modup, 1, "poly/s", "oracle ModUpSplitQP R15 16->16", 2.0)
+            extras["modup_split_qp"]["cpu_baseline"] = cpu_baseline(mk_modup, 1, "poly/s", "oracle ModUpSplitQP R15 16->16", 3.0)
         del outP, bext
         if 12 <= args.logn <= 15:
             # the same transform on CKKS-size moduli (DefaultParams[PN15QP880]'s first limbs at N = 2^15: one of 50 bits, the rest
@@ -503,21 +587,24 @@ def main():
                                                  "bit_exact": bool(np.array_equal(cdst.get().reshape(my_polys, L, N)[last], ofn(cb[last % cb.shape[0]])))}
             del csrc, cdst, ctxC
         out["extras"] = extras
+        progress("extras timed")
 
     del src, dst
     if not args.no_config5 and not args.no_ckks:
+        progress("config 5 leg: PN16QP1761, %d products per GPU" % args.config5_units)
         c5 = config5_leg(3, 1)
         if rank == 0:
             out["config5"] = c5
+        progress("config 5 leg done")
 
     if want_cpu:
         def mk_ntt(i):
             a, b = base[0].copy(), np.empty_like(base[0])
             lib = oracle.lib()
             return lambda: lib.oc_ntt_lvl(oc.h, L - 1, a.ctypes.data, b.ctypes.data)
-        out["cpu_baseline"] = cpu_baseline(mk_ntt, L, "limb-NTT/s", "oracle Context.NTT on R15 (N=2^%d, %d limbs), one poly per call" % (args.logn, L), 8.0)
+        out["cpu_baseline"] = cpu_baseline(mk_ntt, L, "limb-NTT/s", "oracle Context.NTT on R15 (N=2^%d, %d limbs), one poly per call" % (args.logn, L), 10.0)
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        emit(out)
     if use_dist:
         import torch.distributed as dist
         dist.barrier()

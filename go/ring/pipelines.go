@@ -20,7 +20,7 @@ type CkksPlan struct {
 
 func NewCkksPlan(contextQ, contextP *Context, maxBatch int) *CkksPlan {
 	p := &CkksPlan{contextQ: contextQ, contextP: contextP}
-	check(C.lr_ckks_plan_create(contextQ.h, contextP.h, C.int(maxBatch), &p.h))
+	call(func() C.int { return C.lr_ckks_plan_create(contextQ.h, contextP.h, C.int(maxBatch), &p.h) })
 	runtime.SetFinalizer(p, func(p *CkksPlan) { C.lr_ckks_plan_destroy(p.h) })
 	return p
 }
@@ -29,14 +29,16 @@ func NewCkksPlan(contextQ, contextP *Context, maxBatch int) *CkksPlan {
 // polynomial with batch = 2*beta, which is what the key-switching entry points take.
 func (p *CkksPlan) SwitchingKeyImage(evakey [][2]*Poly) *Poly {
 	limbs := len(evakey[0][0].Coeffs)
-	img := &Poly{resident: true}
-	check(C.lr_poly_alloc(p.contextQ.h, C.int(limbs), C.int(2*len(evakey)), &img.d)) // limbs beyond |Q| follow contextP: see lr_ckks_switch_keys
+	img := &Poly{resident: true, dLimbs: limbs}
+	call(func() C.int { return C.lr_poly_alloc(p.contextQ.h, C.int(limbs), C.int(2*len(evakey)), &img.d) }) // limbs beyond |Q| follow contextP: see lr_ckks_switch_keys
 	for i := range evakey {
 		for k := 0; k < 2; k++ {
 			var pin runtime.Pinner
 			src := evakey[i][k]
+			src.hostView()
 			ptrs, free := src.limbPtrs(&pin)
-			check(C.lr_poly_upload(img.d, C.int(2*i+k), ptrs, C.int(limbs)))
+			idx := C.int(2*i + k)
+			call(func() C.int { return C.lr_poly_upload(img.d, idx, ptrs, C.int(limbs)) })
 			free()
 			pin.Unpin()
 		}
@@ -47,39 +49,95 @@ func (p *CkksPlan) SwitchingKeyImage(evakey [][2]*Poly) *Poly {
 
 // SwitchKeysInPlace = evaluator.switchKeysInPlace (ckks/evaluator.go:1475).
 func (p *CkksPlan) SwitchKeysInPlace(level uint64, cx, evakey, p0, p1 *Poly) {
-	in(cx)
-	check(C.lr_ckks_switch_keys(p.h, C.int(level), cx.d, evakey.d, p0.d, p1.d))
-	out(p0, p1)
+	p.contextQ.use(cx)
+	p.contextQ.want(p0, p1)
+	call(func() C.int { return C.lr_ckks_switch_keys(p.h, C.int(level), cx.d, evakey.d, p0.d, p1.d) })
+	done(p0, p1)
 }
 
-// MulRelin = the degree-1 x degree-1 branch of evaluator.MulRelin with an evaluation key (ckks/evaluator.go:1016-1133).
-func (p *CkksPlan) MulRelin(level uint64, ct0, ct1 [2]*Poly, evakey *Poly, ctOut [2]*Poly) {
-	in(ct0[0], ct0[1], ct1[0], ct1[1])
-	check(C.lr_ckks_mulrelin(p.h, C.int(level), ct0[0].d, ct0[1].d, ct1[0].d, ct1[1].d, evakey.d, ctOut[0].d, ctOut[1].d))
-	out(ctOut[0], ctOut[1])
+// MulRelin = evaluator.MulRelin (ckks/evaluator.go:1016-1133) on the ring level.  ct0 / ct1: value slices of the two operands
+// (two polynomials for a ciphertext, one for a plaintext); evakey: the key image, or nil for the degree-2 result
+// (:1061-1066), in which case ctOut holds three polynomials.
+func (p *CkksPlan) MulRelin(level uint64, ct0, ct1 []*Poly, evakey *Poly, ctOut []*Poly) {
+	q := p.contextQ
+	q.use(ct0...)
+	q.use(ct1...)
+	q.want(ctOut...)
+	switch {
+	case len(ct0)+len(ct1) == 3: // plaintext x ciphertext, :1113-1131
+		pt, ct := ct0, ct1
+		if len(ct0) == 2 {
+			pt, ct = ct1, ct0
+		}
+		call(func() C.int { return C.lr_ckks_mul_plain(p.h, C.int(level), pt[0].d, ct[0].d, ct[1].d, ctOut[0].d, ctOut[1].d) })
+	case evakey == nil:
+		call(func() C.int {
+			return C.lr_ckks_mul_norelin(p.h, C.int(level), ct0[0].d, ct0[1].d, ct1[0].d, ct1[1].d, ctOut[0].d, ctOut[1].d, ctOut[2].d)
+		})
+	default:
+		call(func() C.int {
+			return C.lr_ckks_mulrelin(p.h, C.int(level), ct0[0].d, ct0[1].d, ct1[0].d, ct1[1].d, evakey.d, ctOut[0].d, ctOut[1].d)
+		})
+	}
+	done(ctOut...)
+}
+
+// EncryptPk = pkEncryptor.encrypt, the branch through the special primes, after the sampling (ckks/encryptor.go:205-234).
+// u, pk, e: polynomials of contextQP (|Q|+|P| limbs); the sampling itself stays in the reference's Go code.
+func (p *CkksPlan) EncryptPk(level uint64, u *Poly, pk, e [2]*Poly, plaintext *Poly, ctOut [2]*Poly) {
+	q := p.contextQ
+	q.use(u, pk[0], pk[1], e[0], e[1], plaintext)
+	q.want(ctOut[0], ctOut[1])
+	call(func() C.int {
+		return C.lr_ckks_encrypt_pk(p.h, C.int(level), u.d, pk[0].d, pk[1].d, e[0].d, e[1].d, plaintext.d, ctOut[0].d, ctOut[1].d)
+	})
+	done(ctOut[0], ctOut[1])
+}
+
+// Decrypt = decryptor.Decrypt (ckks/decryptor.go:53-78).
+func (p *CkksPlan) Decrypt(level uint64, ct []*Poly, sk, ptOut *Poly) {
+	q := p.contextQ
+	q.use(ct...)
+	q.use(sk)
+	q.want(ptOut)
+	n := len(ct)
+	raw := C.malloc(C.size_t(n) * C.size_t(unsafe.Sizeof(uintptr(0))))
+	defer C.free(raw)
+	arr := unsafe.Slice((**C.lr_poly)(raw), n)
+	for i := range ct {
+		arr[i] = ct[i].d
+	}
+	call(func() C.int { return C.lr_ckks_decrypt(p.h, C.int(level), (**C.lr_poly)(raw), C.int(n-1), sk.d, ptOut.d) })
+	done(ptOut)
 }
 
 // Rescale = one iteration of evaluator.Rescale's loop (ckks/evaluator.go:958-960) on both components.
 func (p *CkksPlan) Rescale(ct [2]*Poly) {
-	in(ct[0], ct[1])
-	check(C.lr_ckks_rescale(p.h, ct[0].d, ct[1].d))
+	p.contextQ.use(ct[0], ct[1])
+	call(func() C.int { return C.lr_ckks_rescale(p.h, ct[0].d, ct[1].d) })
 	for _, q := range ct {
 		q.Coeffs = q.Coeffs[:len(q.Coeffs)-1]
 	}
-	out(ct[0], ct[1])
+	done(ct[0], ct[1])
 }
 
 // PermuteNTT = evaluator.permuteNTT (ckks/evaluator.go:1448): RotateColumns with the key of that rotation, Conjugate.
 func (p *CkksPlan) PermuteNTT(level uint64, ct0 [2]*Poly, galEl uint64, rotkey *Poly, ctOut [2]*Poly) {
-	in(ct0[0], ct0[1])
-	check(C.lr_ckks_rotate(p.h, C.int(level), ct0[0].d, ct0[1].d, C.uint64_t(galEl), rotkey.d, ctOut[0].d, ctOut[1].d))
-	out(ctOut[0], ctOut[1])
+	p.contextQ.use(ct0[0], ct0[1])
+	p.contextQ.want(ctOut[0], ctOut[1])
+	call(func() C.int {
+		return C.lr_ckks_rotate(p.h, C.int(level), ct0[0].d, ct0[1].d, C.uint64_t(galEl), rotkey.d, ctOut[0].d, ctOut[1].d)
+	})
+	done(ctOut[0], ctOut[1])
 }
 
 // RotateHoisted = evaluator.RotateHoisted (ckks/evaluator.go:1252) for the rotations galEls[r] with keys rotkeys[r].
 func (p *CkksPlan) RotateHoisted(level uint64, ct0 [2]*Poly, galEls []uint64, rotkeys []*Poly, ctOuts [][2]*Poly) {
-	in(ct0[0], ct0[1])
+	p.contextQ.use(ct0[0], ct0[1])
 	n := len(galEls)
+	for r := 0; r < n; r++ {
+		p.contextQ.want(ctOuts[r][0], ctOuts[r][1])
+	}
 	sz := C.size_t(n) * C.size_t(unsafe.Sizeof(uintptr(0)))
 	keys := (**C.lr_poly)(C.malloc(sz))
 	o0 := (**C.lr_poly)(C.malloc(sz))
@@ -91,27 +149,33 @@ func (p *CkksPlan) RotateHoisted(level uint64, ct0 [2]*Poly, galEls []uint64, ro
 	for r := 0; r < n; r++ {
 		ks[r], a0[r], a1[r] = rotkeys[r].d, ctOuts[r][0].d, ctOuts[r][1].d
 	}
-	check(C.lr_ckks_rotate_hoisted(p.h, C.int(level), ct0[0].d, ct0[1].d, C.int(n), (*C.uint64_t)(unsafe.Pointer(&galEls[0])), keys, o0, o1))
+	call(func() C.int {
+		return C.lr_ckks_rotate_hoisted(p.h, C.int(level), ct0[0].d, ct0[1].d, C.int(n), (*C.uint64_t)(unsafe.Pointer(&galEls[0])), keys, o0, o1)
+	})
 	for r := 0; r < n; r++ {
-		out(ctOuts[r][0], ctOuts[r][1])
+		done(ctOuts[r][0], ctOuts[r][1])
 	}
 }
 
 // BfvPlan: what bfv.NewEvaluator builds for Mul (bfv/evaluator.go:89-112) and tensorAndRescale (:278-464).
 type BfvPlan struct {
-	h *C.lr_bfv_plan
+	contextQ *Context
+	h        *C.lr_bfv_plan
 }
 
 func NewBfvPlan(contextQ, contextQMul *Context, t uint64, maxBatch int) *BfvPlan {
-	p := &BfvPlan{}
-	check(C.lr_bfv_plan_create(contextQ.h, contextQMul.h, C.uint64_t(t), C.int(maxBatch), &p.h))
+	p := &BfvPlan{contextQ: contextQ}
+	call(func() C.int { return C.lr_bfv_plan_create(contextQ.h, contextQMul.h, C.uint64_t(t), C.int(maxBatch), &p.h) })
 	runtime.SetFinalizer(p, func(p *BfvPlan) { C.lr_bfv_plan_destroy(p.h) })
 	return p
 }
 
 // Mul = evaluator.Mul for two degree-1 ciphertexts (bfv/evaluator.go:467 -> tensorAndRescale).
 func (p *BfvPlan) Mul(ct0, ct1 [2]*Poly, ctOut [3]*Poly) {
-	in(ct0[0], ct0[1], ct1[0], ct1[1])
-	check(C.lr_bfv_mul(p.h, ct0[0].d, ct0[1].d, ct1[0].d, ct1[1].d, ctOut[0].d, ctOut[1].d, ctOut[2].d))
-	out(ctOut[0], ctOut[1], ctOut[2])
+	p.contextQ.use(ct0[0], ct0[1], ct1[0], ct1[1])
+	p.contextQ.want(ctOut[0], ctOut[1], ctOut[2])
+	call(func() C.int {
+		return C.lr_bfv_mul(p.h, ct0[0].d, ct0[1].d, ct1[0].d, ct1[1].d, ctOut[0].d, ctOut[1].d, ctOut[2].d)
+	})
+	done(ctOut[0], ctOut[1], ctOut[2])
 }

@@ -108,6 +108,9 @@ int lr_context_get_table(const lr_context *ctx, int which, uint64_t *dst, size_t
 int lr_poly_alloc(lr_context *ctx, int limbs, int batch, lr_poly **out);
 /* wrap caller-owned device memory (e.g. a torch uint64/int64 tensor) without copying */
 int lr_poly_wrap(lr_context *ctx, void *device_ptr, int limbs, int batch, lr_poly **out);
+/* the same with `poly_stride_words` uint64 elements between consecutive polys (>= limbs * N): a component of an array of
+ * ciphertexts laid out [ciphertext][component][limb][N] is one lr_poly with the stride of a whole ciphertext */
+int lr_poly_wrap_strided(lr_context *ctx, void *device_ptr, int limbs, int batch, long long poly_stride_words, lr_poly **out);
 int lr_poly_free(lr_poly *p);
 int lr_poly_info(const lr_poly *p, uint64_t *N, int *limbs, int *batch, void **device_ptr);
 /* Go boundary: gather from / scatter to the per-limb slices of one Poly ([][]uint64 cannot be

@@ -32,6 +32,7 @@ SYMBOLS = {
     "lr_context_get_table": [vp, i32, u64p, C.c_size_t],
     "lr_poly_alloc": [vp, i32, i32, C.POINTER(vp)],
     "lr_poly_wrap": [vp, vp, i32, i32, C.POINTER(vp)],
+    "lr_poly_wrap_strided": [vp, vp, i32, i32, C.c_longlong, C.POINTER(vp)],
     "lr_poly_free": [vp],
     "lr_poly_info": [vp, u64p, C.POINTER(i32), C.POINTER(i32), C.POINTER(vp)],
     "lr_poly_upload": [vp, i32, C.POINTER(u64p), i32],

@@ -5,6 +5,23 @@ cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -I../../include -I. -Wall -Wno-unused-function"
 mkdir -p build
+link() {
+  $HIPCC --offload-arch=gfx950 -shared -fPIC -o ../liblattigo_ring_hip.so build/lr_ntt.o build/lr_ewise.o build/lr_bext.o build/lr_abi.o build/lr_precompute.o build/lr_asm.o build/lr_asm_blob.o
+  echo "built $(cd .. && pwd)/liblattigo_ring_hip.so"
+}
+# developer shortcut: `build.sh lr_abi.cpp lr_ewise.hip` recompiles only the named sources and relinks (everything else must
+# have been built before); without arguments the whole library is built from scratch, which is what __graft_entry__.build() runs
+if [ $# -gt 0 ]; then
+  for f in "$@"; do
+    case $f in
+      *.hip) $HIPCC $FLAGS -c $f -o build/${f%.hip}.o & ;;
+      *.cpp) $HIPCC $FLAGS -x hip -c $f -o build/${f%.cpp}.o & ;;
+    esac
+  done
+  wait
+  link
+  exit 0
+fi
 # hand-scheduled assembly kernels: generate -> assemble -> embed
 LLVM=${LLVM:-/opt/rocm/lib/llvm/bin}
 # forward: modes 0 (q < 2^61), 1 (q <= 2^60), 2 (q < 2^57); inverse: modes 0 and 1
@@ -73,5 +90,4 @@ pids+=($!)
 g++ -O1 -fPIC -c build/lr_asm_blob.cpp -o build/lr_asm_blob.o &
 pids+=($!)
 for p in "${pids[@]}"; do wait $p; done
-$HIPCC --offload-arch=gfx950 -shared -fPIC -o ../liblattigo_ring_hip.so build/lr_ntt.o build/lr_ewise.o build/lr_bext.o build/lr_abi.o build/lr_precompute.o build/lr_asm.o build/lr_asm_blob.o
-echo "built $(cd .. && pwd)/liblattigo_ring_hip.so"
+link

@@ -201,9 +201,10 @@ struct lr_poly {
     u64 *d = nullptr;
     bool owned = false;
     int limbs = 0;        // logical limb count (rescale shrinks it)
-    int alloc_limbs = 0;  // stride, fixed at allocation
+    int alloc_limbs = 0;  // limbs the storage holds per poly, fixed at allocation
     int batch = 0;
-    long long stride() const { return (long long)alloc_limbs * (long long)N; }
+    long long stride_words = 0;   // u64 elements between consecutive batch polys (alloc_limbs * N unless wrapped with a stride)
+    long long stride() const { return stride_words; }
 };
 
 namespace {
@@ -613,6 +614,7 @@ extern "C" int lr_poly_alloc(lr_context *c, int limbs, int batch, lr_poly **out)
     p->device = c->device;
     p->N = c->h.N;
     p->limbs = p->alloc_limbs = limbs;
+    p->stride_words = (long long)limbs * (long long)c->h.N;
     p->batch = batch;
     p->owned = true;
     const size_t bytes = (size_t)batch * limbs * c->h.N * sizeof(u64);
@@ -623,22 +625,36 @@ extern "C" int lr_poly_alloc(lr_context *c, int limbs, int batch, lr_poly **out)
     });
 }
 
-extern "C" int lr_poly_wrap(lr_context *c, void *device_ptr, int limbs, int batch, lr_poly **out) {
-    return guarded([&]() -> int {
+static int poly_wrap(lr_context *c, void *device_ptr, int limbs, int batch, long long stride_words, lr_poly **out) {
     if (!c || !out || !device_ptr) return fail(LR_ERR_ARG, "null argument");
     *out = nullptr;
     if (limbs <= 0 || limbs > kMaxLimbs || batch <= 0) return fail(LR_ERR_SHAPE, "limbs must be 1..64 and batch >= 1");
     if (((uintptr_t)device_ptr & 15) != 0) return fail(LR_ERR_ARG, "device pointer must be 16-byte aligned");
+    if (stride_words < (long long)limbs * (long long)c->h.N || (stride_words & 1) != 0)
+        return fail(LR_ERR_SHAPE, "poly stride must be an even number of words and at least limbs * N");
     lr_poly *p = new lr_poly();
     p->ctx = c;
     p->device = c->device;
     p->N = c->h.N;
     p->d = (u64 *)device_ptr;
     p->limbs = p->alloc_limbs = limbs;
+    p->stride_words = stride_words;
     p->batch = batch;
     p->owned = false;
     *out = p;
     return LR_OK;
+}
+
+extern "C" int lr_poly_wrap(lr_context *c, void *device_ptr, int limbs, int batch, lr_poly **out) {
+    return guarded([&]() -> int {
+    if (!c) return fail(LR_ERR_ARG, "null argument");
+    return poly_wrap(c, device_ptr, limbs, batch, (long long)limbs * (long long)c->h.N, out);
+    });
+}
+
+extern "C" int lr_poly_wrap_strided(lr_context *c, void *device_ptr, int limbs, int batch, long long poly_stride_words, lr_poly **out) {
+    return guarded([&]() -> int {
+    return poly_wrap(c, device_ptr, limbs, batch, poly_stride_words, out);
     });
 }
 
@@ -726,8 +742,9 @@ static int dense_copy(const lr_poly *p, u64 *host, const u64 *host_src, size_t c
     LR_HIP(hipStreamSynchronize(p->ctx->stream));
     // logical limbs per poly; the device stride is larger after a rescale re-sliced the poly
     const size_t chunk = (size_t)p->limbs * N;
-    const int pieces = p->limbs == p->alloc_limbs ? 1 : p->batch;
-    const size_t piece = p->limbs == p->alloc_limbs ? count : chunk;
+    const bool dense = p->stride() == (long long)chunk;
+    const int pieces = dense ? 1 : p->batch;
+    const size_t piece = dense ? count : chunk;
     for (int b = 0; b < pieces; ++b) {
         u64 *dev = p->d + (long long)b * p->stride();
         if (host_src)

@@ -58,6 +58,13 @@ class Poly:
         check(lib().lr_poly_wrap(ctx.h, C.c_void_p(device_ptr), limbs, batch, C.byref(h)))
         return cls(ctx, limbs, batch, _handle=h)
 
+    @classmethod
+    def wrap_strided(cls, ctx, device_ptr, limbs, batch, stride_limbs):
+        """the same with `stride_limbs` limbs between consecutive polys (lr_poly_wrap_strided)"""
+        h = C.c_void_p()
+        check(lib().lr_poly_wrap_strided(ctx.h, C.c_void_p(device_ptr), limbs, batch, stride_limbs * ctx.N, C.byref(h)))
+        return cls(ctx, limbs, batch, _handle=h)
+
     # --- reference accessors -----------------------------------------------------------
     def GetLenModuli(self):  # ring/ring_object.go:55
         n = C.c_int()

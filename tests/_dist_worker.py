@@ -1,5 +1,9 @@
-"""Worker for test_dist_gloo.py: the N>1 harness of bench.py (sharding, barrier, max-over-ranks timing) on the
-CPU with the gloo backend.  The per-unit work is the CPU oracle (the HIP path cannot run without a GPU)."""
+"""Worker for test_dist_gloo.py: the N>1 data path of bench.py -- contiguous blocks of independent units per rank, the
+max-over-ranks timing harness, and the gather of results to rank 0 (sharding.gather_blocks, the same function bench.py's
+config-5 leg calls on the nccl backend) -- with the gloo backend.
+
+Per-unit work: the product (HIP path through the C ABI) when this process sees a device; in the build container, which has
+none, the CPU oracle stands in so that partition, timing and result placement are still exercised end to end."""
 import json
 import os
 import sys
@@ -21,17 +25,30 @@ def main():
     dist.init_process_group(backend="gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     pkg = graft.load_package()
-    oracle = graft.load_oracle()
+    sharding = pkg.sharding
     N, moduli = 1 << 10, list(pkg.params.Qi60()[-2:])
-    oc = oracle.Context(N, moduli)
-    start, count = bench.shard_units(total_units, rank, world)
+    L = len(moduli)
+    on_device = pkg._native.device_count() > 0 and os.environ.get("LR_DIST_FORCE_CPU") != "1"
+    start, count = sharding.shard_units(total_units, rank, world)
+    assert (start, count) == bench.shard_units(total_units, rank, world)
     # unit g (global index) has its own seeded input: the shards of all ranks tile the single-process batch
-    results = {}
+    x = np.stack([pkg.sampling.uniform_poly(moduli, N, 1, seed=1000 + g)[0] for g in range(start, start + count)]) \
+        if count else np.zeros((0, L, N), dtype=np.uint64)
+    result = [None]
+    if on_device:
+        ctx = pkg.ring.NewContextWithParams(N, moduli, device=0)
+        src, dst = ctx.NewPoly(max(count, 1)), ctx.NewPoly(max(count, 1))
+        if count:
+            src.set(x)
 
-    def step():
-        for g in range(start, start + count):
-            x = pkg.sampling.uniform_poly(moduli, N, 1, seed=1000 + g)[0]
-            results[g] = int(oc.ntt(x).sum(dtype=np.uint64))
+        def step():
+            ctx.NTT(src, dst)
+            result[0] = dst.get().reshape(-1, L, N)[:count]
+    else:
+        oc = graft.load_oracle().Context(N, moduli)
+
+        def step():
+            result[0] = np.stack([oc.ntt(x[j]) for j in range(count)]) if count else np.zeros((0, L, N), dtype=np.uint64)
 
     def barrier():
         dist.barrier()
@@ -42,11 +59,17 @@ def main():
         return float(t.item())
 
     seconds, _ = bench.timed_region(step, steps=2, warmup=1, sync=lambda: None, barrier=barrier, all_max=all_max)
-    gathered = [None] * world
-    dist.all_gather_object(gathered, (rank, start, count, results, seconds))
+    local = torch.from_numpy(np.ascontiguousarray(result[0]).view(np.int64).reshape(count, L * N))
+    gathered = sharding.gather_blocks(local, total_units, rank, world, dst=0)
+    times = [None] * world
+    dist.all_gather_object(times, (rank, start, count, seconds))
     if rank == 0:
+        assert gathered is not None and gathered.shape == (total_units, L * N)
+        np.save(out_path + ".npy", gathered.numpy().view(np.uint64).reshape(total_units, L, N))
         with open(out_path, "w") as f:
-            json.dump({"world": world, "parts": [[r, s, c, {str(k): v for k, v in res.items()}, t] for r, s, c, res, t in gathered]}, f)
+            json.dump({"world": world, "on_device": bool(on_device), "parts": times}, f)
+    else:
+        assert gathered is None
     dist.barrier()
     dist.destroy_process_group()
 
