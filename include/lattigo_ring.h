@@ -83,6 +83,11 @@ int lr_context_set_stream(lr_context *ctx, void *hip_stream);
 /* diagnostics: name of the kernel the last NTT / InvNTT launch of this context dispatched, e.g. "lr_ntt_fwd15_m1" (assembly
  * code object) or "ntt_fwd_kernel<15>" (C++ kernel); bench.py reports it next to the roofline figures */
 int lr_context_last_ntt_kernel(const lr_context *ctx, char *buf, size_t capacity);
+/* diagnostics: a context created with LR_NTT_TIMELINE=1 runs its forward N = 2^15 launches of the 60-bit integer kernel on a
+ * build of the same kernel that stamps the shader clock (low word of s_memtime) at 13 phase boundaries in every wave.  Copies
+ * the stamps of the last such launch to dst: [workgroup = poly * limbs + limb][wave 0..15][16] uint32 (tools/timeline.py names
+ * the phases).  dst == NULL: only *count (words needed).  Synchronises.  The transform's results are unchanged. */
+int lr_context_timeline(lr_context *ctx, uint32_t *dst, size_t capacity, size_t *count);
 int lr_context_sync(lr_context *ctx);       /* hipStreamSynchronize on the context's stream */
 int lr_context_info(const lr_context *ctx, uint64_t *N, int *n_moduli, int *device);
 

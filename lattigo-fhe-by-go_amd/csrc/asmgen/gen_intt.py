@@ -13,7 +13,7 @@ generation time inside a pass and applied unconditionally on the first stage of 
 15 VALU instructions per butterfly without correction, 19 with.  Inputs must be below 4q.
 
     python gen_intt.py 15 out.s
-    python gen_intt.py 15 --selftest
+    python ../../../tests/asm_emulate.py 15 --selftest-inverse      (emulator check against the oracle)
 """
 import sys
 
@@ -97,12 +97,17 @@ class GenInv(Gen):
         ops = self.ops_sum_diff(ts, U, V)
         mm = self.ops_modmul_inplace(ts, V, tw)
         if correct:
+            # U in [0, 2B) -> U - B if that is non-negative (B = 8q or 4q, at most 2^63): D = U - B has bit 63 set exactly
+            # when U < B; U = D + (B & mask).  Two full-rate instructions and three plain 32-bit ones instead of four full-rate.
             D = ts.R
-            ops += [("v_lshl_add_u64", D, U, 0, self.NQ8),
-                    ("v_cmp_lt_u32", ts.CY, D.hi(), U.hi())]
-            ops += mm[:2]
-            ops += [("v_cndmask_b32", U.lo(), U.lo(), D.lo(), ts.CY),
-                    ("v_cndmask_b32", U.hi(), U.hi(), D.hi(), ts.CY)]
+            M = ts.C.lo()                                     # free until the product's cross terms start
+            ops += [("v_lshl_add_u64", D, U, 0, self.NQ8)]
+            ops += mm[:1]
+            ops += [("v_ashrrev_i32", M, 31, D.hi()),
+                    ("v_and_b32", U.lo(), self.Q8.lo(), M)]
+            ops += mm[1:2]
+            ops += [("v_and_b32", U.hi(), self.Q8.hi(), M),
+                    ("v_lshl_add_u64", U, U, 0, D)]
             ops += mm[2:]
         else:
             ops += mm
@@ -110,15 +115,18 @@ class GenInv(Gen):
 
     def ops_canon4(self, ts, X):
         """[0,4q) -> [0,q)"""
-        D = ts.R
+        D, M = ts.R, ts.T0
+        # twice "X - c if non-negative" by the sign of the difference as a mask (X < 4q < 2^63): c = 2q, then c = q
         return [("v_lshl_add_u64", D, X, 0, self.NQ2),
-                ("v_cmp_lt_u32", ts.CY, D.hi(), X.hi()),
-                ("v_cndmask_b32", X.lo(), X.lo(), D.lo(), ts.CY),
-                ("v_cndmask_b32", X.hi(), X.hi(), D.hi(), ts.CY),
+                ("v_ashrrev_i32", M, 31, D.hi()),
+                ("v_and_b32", X.lo(), self.Qm.lo(), M),
+                ("v_and_b32", X.hi(), self.Qm.hi(), M),
+                ("v_lshl_add_u64", X, X, 1, D),              # D + 2 * (q & mask)
                 ("v_lshl_add_u64", D, X, 0, self.NQ),
-                ("v_cmp_gt_i32", ts.CY, 0, D.hi()),
-                ("v_cndmask_b32", X.lo(), D.lo(), X.lo(), ts.CY),
-                ("v_cndmask_b32", X.hi(), D.hi(), X.hi(), ts.CY)]
+                ("v_ashrrev_i32", M, 31, D.hi()),
+                ("v_and_b32", X.lo(), self.Qm.lo(), M),
+                ("v_and_b32", X.hi(), self.Qm.hi(), M),
+                ("v_lshl_add_u64", X, X, 0, D)]
 
     def ops_last(self, ts, U, V, tw_n, tw_wn):
         """last stage fused with the scaling: canonical (U+V)*N^-1 and (U-V)*psi_inv[1]*N^-1"""
@@ -473,18 +481,8 @@ class GenInv(Gen):
         return self.p
 
 
-def selftest(logn, threads=1024):
-    import gen_ntt
-    return gen_ntt.selftest(logn, inverse=True, threads=threads)
-
-
 if __name__ == "__main__":
     logn = int(sys.argv[1])
-    if len(sys.argv) > 2 and sys.argv[2] == "--selftest":
-        if logn == 16:
-            import gen_ntt
-            sys.exit(0 if gen_ntt.selftest_sub(inverse=True) else 1)
-        sys.exit(0 if selftest(logn, int(sys.argv[3]) if len(sys.argv) > 3 else 1024) else 1)
     mode = int(sys.argv[3]) if len(sys.argv) > 3 else 1
     threads = int(sys.argv[4]) if len(sys.argv) > 4 else 1024
     # mode 3: FP64 body for the limbs below 2^46, the integer body of mode 1 for the others

@@ -28,8 +28,12 @@ class Gen:
          2: q <  2^57, no corrections at all (15 stages x 4q of growth stay below 2^64);
          0: q <  2^61, U <- U - 4q (if U >= 4q) before every stage."""
 
-    def __init__(self, logn, mode=1, threads=1024, sub=False, fused=True, fp=False, dual=False, epi=False):
+    def __init__(self, logn, mode=1, threads=1024, sub=False, fused=True, fp=False, dual=False, epi=False, profile=False):
         assert logn in (12, 13, 14, 15) and mode in (0, 1, 2) and threads in (256, 512, 1024)
+        # profile: the timeline build of a plain integer kernel (diagnostics only, Options::timeline): every wave stamps the shader
+        # clock at the phase boundaries and the stamps go to the buffer NttLaunch::epi_x points at; the transform itself is unchanged
+        assert not profile or not (sub or fp or dual or epi)
+        self.profile = profile
         # dual: the kernel carries two bodies behind one prologue (class Dual): `fp` = the FP64 body for moduli below 2^46
         # (error-free products by v_mul_f64 / v_fma_f64, quotients by v_rndne_f64, no lazy corrections: 8 instructions per
         # butterfly), otherwise the integer body of `mode`; the workgroup picks by its limb's entry in NttLaunch::fp_lp
@@ -166,6 +170,45 @@ class Gen:
         off = kk * 9216 + c * self.T * 9
         return (a0, off) if off < 65536 else (a1, off - 4608)
 
+    N_STAMPS = 16
+
+    def stamp(self, idx):
+        """timeline builds: wave w parks the low word of the shader clock in the padding of row idx of its LDS block (bytes
+        w*9216 + idx*144 + 128, never touched by the transform); flush_stamps() copies them out at the end.  s[32:33] is the
+        carry-out dump of the multiply-adds (always dead), v126 / v127 are outside the integer kernels' register map."""
+        if not self.profile:
+            return
+        assert idx < self.N_STAMPS
+        e, J = self.e, self.JUNK
+        e("s_memtime", J)
+        e("s_waitcnt", "lgkmcnt(0)")
+        e("v_mov_b32", v(127), J.lo())
+        e("s_mul_i32", J.lo(), self.WAVE, 9216)
+        e("s_add_u32", J.lo(), J.lo(), idx * 144 + 128)
+        e("v_mov_b32", v(126), J.lo())
+        e("ds_write_b32", v(126), v(127))
+
+    def flush_stamps(self, count):
+        """stamp buffer (NttLaunch::epi_x): [workgroup = poly * n_items + item][wave][N_STAMPS] u32"""
+        e, sc = self.e, self.SC
+        e("s_waitcnt", "vmcnt(0) lgkmcnt(0)")
+        e("s_load_dwordx2", self.TMP, self.KARG, 128)
+        e("s_load_dword", sc[0], self.KARG, 56)               # n_items
+        e("s_waitcnt", "lgkmcnt(0)")
+        e("s_mul_i32", sc[0], self.WGY, sc[0])
+        e("s_add_u32", sc[0], sc[0], self.WGX)
+        e("s_lshl_b32", sc[0], sc[0], 4)
+        e("s_add_u32", sc[0], sc[0], self.WAVE)
+        e("s_lshl_b32", sc[0], sc[0], 6)                        # x N_STAMPS x 4 bytes
+        e("v_mov_b32", v(126), sc[0])
+        e("s_mul_i32", sc[1], self.WAVE, 9216)
+        e("v_mov_b32", v(0), sc[1])
+        for idx in range(count):
+            e("ds_read_b32", v(1), v(0), offset=idx * 144 + 128)
+            e("s_waitcnt", "lgkmcnt(0)")
+            e("global_store_dword", v(126), v(1), self.TMP, offset=idx * 4)
+        e("s_waitcnt", "vmcnt(0)")
+
     def tw_slot(self, i):
         return v(self.tw_base + 4 * i, 4)
 
@@ -229,12 +272,18 @@ class Gen:
         hi = [("v_mul_hi_u32", ts.T0, V.hi(), s0),
               ("v_mul_hi_u32", ts.T2, V.lo(), s1)]
         if correct:
-            D = ts.C
-            ops += [("v_lshl_add_u64", D, U, 0, self.NQ8),
-                    ("v_cmp_lt_u32", ts.CY, D.hi(), U.hi())]
-            ops += hi                                       # the two mul_hi sit between compare and select
-            ops += [("v_cndmask_b32", U.lo(), U.lo(), D.lo(), ts.CY),
-                    ("v_cndmask_b32", U.hi(), U.hi(), D.hi(), ts.CY)]
+            # U <- U - B (B = 8q in mode 1, 4q in mode 0) iff bit 63 of U is set.  Invariant: U < 2^64 before a corrected stage;
+            # afterwards U < max(2^63, 2^64 - B), and the stages up to the next correction add at most B <= 2^63, so the
+            # values stay below 2^64 (B <= 2^63 because q <= 2^60 resp. q < 2^61).  The test is the sign bit: one full-rate
+            # instruction (the 64-bit add) and three plain 32-bit ones that issue in the shadow of the multiplies, instead
+            # of add + compare + two selects at full cost each (tools/asm_ubench: v_add_u32 class 2.3 clocks, the others 4.2-4.7).
+            M = ts.C
+            ops += [("v_ashrrev_i32", M.hi(), 31, U.hi())]
+            ops += hi[:1]
+            ops += [("v_and_b32", M.lo(), self.NQ8.lo(), M.hi()),
+                    ("v_and_b32", M.hi(), self.NQ8.hi(), M.hi())]
+            ops += hi[1:]
+            ops += [("v_lshl_add_u64", U, U, 0, M)]
         else:
             ops += hi
         ops += [
@@ -268,11 +317,14 @@ class Gen:
         if self.fp:
             return self.ops_canon_fp(ts, X)
         D = ts.C
+        # X in [0, 2q) -> X - q if that is non-negative: the sign of D = X - q as a mask (X < 2q <= 2^62, so bit 63 of D is
+        # set exactly when X < q), X = D + (q & mask)
         return self.ops_reduce_2q(ts, X) + [
             ("v_lshl_add_u64", D, X, 0, self.NQ),
-            ("v_cmp_gt_i32", ts.CY, 0, D.hi()),
-            ("v_cndmask_b32", X.lo(), D.lo(), X.lo(), ts.CY),
-            ("v_cndmask_b32", X.hi(), D.hi(), X.hi(), ts.CY),
+            ("v_ashrrev_i32", ts.T0, 31, D.hi()),
+            ("v_and_b32", X.lo(), self.Qm.lo(), ts.T0),
+            ("v_and_b32", X.hi(), self.Qm.hi(), ts.T0),
+            ("v_lshl_add_u64", X, X, 0, D),
         ]
 
     def zip_emit(self, items):
@@ -495,6 +547,7 @@ class Gen:
             self.fused_top()
             return
         self.c("coalesced load of the columns {k*S + t + c*T}")
+        self.stamp(0)
         # order 0, RA/2, 1, RA/2+1, ... (per column): the first-stage butterflies can start after two loads
         e("s_add_u32", self.TMP.lo(), self.SRC.lo(), (self.RA // 2) * self.S * 8)
         e("s_addc_u32", self.TMP.hi(), self.SRC.hi(), 0)
@@ -574,6 +627,8 @@ class Gen:
                     pend.extend(blist)
             if c > 0:
                 self.butterflies(pend)
+            else:
+                self.stamp(1)                 # every column load has returned, stage 0 is done
 
     # ------------------------------------------------------------------ LDS phase
     # After pass A the resident half consists of 16 independent sub-transforms of 1024 coefficients
@@ -923,15 +978,28 @@ class Gen:
                 e("s_add_u32", self.TMP.lo(), self.TMP.lo(), 1024)
                 e("s_addc_u32", self.TMP.hi(), self.TMP.hi(), 0)
 
+    # stamps of the timeline build, in order (tools/timeline.py names the intervals between them)
+    STAMP_NAMES = ["start", "loads returned + stage 0", "pass A done"] + [
+        "%s (half %d)" % (n, h) for h in range(2) for n in ("column exchange", "stages over bits 9..7", "stages over bits 6..4",
+                                                             "last four stages", "copy-out issued")]
+
     def build(self):
         self.prologue()
         self.pass_a()
+        self.stamp(2)
         for half in range(self.HALVES):
             self.lds_write_columns(half)
+            self.stamp(3 + 5 * half)
             self.lds_pass_uniform(half)
+            self.stamp(4 + 5 * half)
             self.lds_pass_lane(half)
+            self.stamp(5 + 5 * half)
             self.lds_pass_final(half)
+            self.stamp(6 + 5 * half)
             self.copy_out(half)
+            self.stamp(7 + 5 * half)
+        if self.profile:
+            self.flush_stamps(3 + 5 * self.HALVES)
         self.e("s_endpgm")
         return self.p
 
@@ -1022,354 +1090,11 @@ amdhsa.version: [1, 2]
     return hdr + prog.text() + desc
 
 
-# ------------------------------------------------------------------------------------------
-# self test on the numpy emulator
-# ------------------------------------------------------------------------------------------
-def emulate(gen, inverse=False, q=None, geom=None):
-    # geom = (x, y, z, hole, group, rows per poly): workgroup ids and the digit-group arguments of NttLaunch
-    """run one workgroup of the generated program on the numpy emulator; returns (bit-exact?, summary text)"""
-    import numpy as np
-
-    from isa import Machine
-    sys.path.insert(0, __import__("os").path.join(__import__("os").path.dirname(__file__), "..", "..", ".."))
-    import __graft_entry__ as graft
-    oracle = graft.load_oracle()
-    pkg = graft.load_package()
-    logn = gen.logn
-    N = 1 << logn
-    q = q or pkg.params.Qi60()[-3]
-    oc = oracle.Context(N, [q])
-    x = pkg.sampling.random_u64((N,), seed=5)                 # full 64-bit inputs
-    x[:4] = np.uint64(0xFFFFFFFFFFFFFFFF)
-    if inverse:
-        x = (x % np.uint64(4 * q)).astype(np.uint64)          # the inverse accepts [0, 4q)
-        x[:4] = np.uint64(4 * q - 1)
-    canon = np.array([[int(val) % q for val in x]], dtype=np.uint64)
-    want = (oc.intt(canon) if inverse else oc.ntt(canon))[0]
-
-    # host-side tables exactly as lr_abi.cpp builds them
-    table = oc.ntt_psi_inv[0] if inverse else oc.ntt_psi[0]
-    psi = [int(oracle.inv_mform(int(w), q)) for w in table]
-    n_inv = pow(N, -1, q)
-    if inverse:
-        psi[0] = psi[1] * n_inv % q                           # constant of the fused last stage
-    tw = np.zeros((N, 2), dtype=np.uint64)
-    for i, w in enumerate(psi):
-        tw[i, 0] = w
-        tw[i, 1] = (w << 64) // q
-    blocks = N // 16
-    twf = np.zeros((15, blocks, 2), dtype=np.uint64)
-    for cc in range(4):
-        for j in range(1 << cc):
-            for bk in range(blocks):
-                twf[(1 << cc) - 1 + j, bk] = tw[((blocks + bk) << cc) + j]
-    qh = (q >> 32) + 1
-    g = qh.bit_length() - 1
-    red_m = min((1 << (32 + g)) // qh, 0xFFFFFFFF)
-    lp = np.zeros(8, dtype=np.uint64)
-    lp[0] = q
-    lp[2] = (1 << 128) // q >> 64
-    lp[5] = n_inv
-    lp[6] = (n_inv << 64) // q
-    lp[7] = red_m | (g << 32)
-
-    # flat memory image (byte addresses)
-    def place(arr, addr):
-        words = np.ascontiguousarray(arr).view(np.uint32).ravel()
-        mem[addr // 4: addr // 4 + words.size] = words
-
-    gx, gy, gz, hole, group, rows = geom or (0, 0, 0, 0, 0, 1)
-    item = gx + (hole if gx >= gz * hole else 0)
-    where = ((gz * group + gy) * rows + item) * 8 * N          # byte offset of the addressed row
-    span = ((gz * group + gy + 1) * rows + 1) * 8 * N
-    A_KARG, A_IN = 0x800, 0x1000
-    A_OUT = A_IN + span
-    A_LP = A_OUT + span
-    A_TW = A_LP + 0x1000
-    A_TWF = A_TW + 16 * N + 0x1000
-    A_FTW = A_TWF + 16 * 15 * blocks + 0x1000
-    A_FTWF = A_FTW + 16 * N + 0x1000
-    A_FLP = A_FTWF + 16 * 15 * blocks + 0x1000
-    mem = np.zeros((A_FLP + 0x1000) // 4, dtype=np.uint32)
-    place(x, A_IN + where)
-    place(lp, A_LP)
-    place(tw, A_TW)
-    place(twf, A_TWF)
-    fp_tables(np, q, n_inv, tw, twf, lambda a, b, c: (place(a, A_FTW), place(b, A_FTWF), place(c, A_FLP)))
-    karg = np.zeros(21, dtype=np.uint64)
-    karg[13], karg[14], karg[15] = A_FTW - A_TW, A_FTWF - A_TWF, A_FLP
-    if getattr(gen, "epi", False) and q < FP_LIMIT:
-        # x and plus: canonical polys laid out like the output; c: a random constant in (w, w / q) form
-        rng = np.random.default_rng(7)
-        xe = (rng.integers(0, 1 << 62, N, dtype=np.uint64) % np.uint64(q)).astype(np.uint64)
-        pe = (rng.integers(0, 1 << 62, N, dtype=np.uint64) % np.uint64(q)).astype(np.uint64)
-        xe[:3], pe[:3] = [0, q - 1, q - 1], [q - 1, 0, q - 1]
-        ce = int(rng.integers(1, q))
-        A_X, A_P, A_EC = mem.size * 4, mem.size * 4 + span, mem.size * 4 + 2 * span
-        mem = np.concatenate([mem, np.zeros((2 * span + 0x1000) // 4, dtype=np.uint32)])
-        place(xe, A_X + where)
-        place(pe, A_P + where)
-        place(np.array([ce, np.float64(ce) / np.float64(q)], dtype=np.float64), A_EC)      # modulus index 0
-        karg[16], karg[17], karg[18], karg[19], karg[20] = A_X, rows * N, A_P, rows * N, A_EC
-        want = np.array([((int(a) - int(b)) * ce + int(c)) % q for a, b, c in zip(xe, want, pe)], dtype=np.uint64)
-    karg[0], karg[1], karg[2], karg[3] = A_IN, A_OUT, rows * N, rows * N
-    karg[4] = 0 | (1 << 32)        # in_limb0, in_limb_step
-    karg[5] = 0 | (1 << 32)        # out_limb0, out_limb_step
-    karg[6] = 0 | (0 << 32)        # mod0, mod_step: one modulus serves every row of this harness
-    karg[11] = 0 | (hole << 32)    # sub_log, hole
-    karg[12] = group               # group, pad
-    karg[7] = 1 | (1 << 32)        # n_items, batch
-    karg[8], karg[9], karg[10] = A_LP, A_TW, A_TWF
-    place(karg, A_KARG)
-
-    prog = gen.build()
-    m = Machine(gen.T, 160 * 1024, mem.size)
-    m.mem = mem
-    m.vgpr[0] = np.arange(gen.T, dtype=np.uint32)
-    m.vdef[0] = True
-    m.sgpr[0], m.sgpr[1] = A_KARG, 0
-    m.sgpr[gen.WGX.idx], m.sgpr[gen.WGY.idx], m.sgpr[4] = gx, gy, gz
-    m.sdef[0:5] = True
-    m.run(prog)
-    got = m.mem[(A_OUT + where) // 4: (A_OUT + where) // 4 + 2 * N].view(np.uint64)
-    ok = np.array_equal(got, want)
-    cnt = prog.count()
-    valu = sum(n for op, n in cnt.items() if op.startswith("v_"))
-    bf = (1 << gen.A) * logn // 2
-    info = "%d instructions, %d VALU = %.1f per butterfly, s_nop %d" % (len(prog.ins), valu, valu / bf, cnt.get("s_nop", 0))
-    if getattr(gen, "gf", None) is not None:
-        ran = sum(n for op, n in m.executed.items() if op.startswith("v_"))
-        info = "%s body, %d VALU executed = %.1f per butterfly" % ("FP64" if m.executed.get("v_fma_f64") else "integer", ran, ran / bf)
-        ok = ok and bool(m.executed.get("v_fma_f64")) == (q < FP_LIMIT)
-    if not ok:
-        bad = np.nonzero(got != want)[0]
-        info += "\n  mismatches: %d first: %s %s %s" % (bad.size, bad[:8], [hex(int(got[i])) for i in bad[:3]],
-                                                       [hex(int(want[i])) for i in bad[:3]])
-    return ok, info
-
-
 FP_LIMIT = 1 << 46
-
-
-def fp_tables(np, q, n_inv, tw, twf, put):
-    """what lr_abi.cpp builds for the FP body: every (w, floor(w 2^64 / q)) becomes the pair of doubles (w, RN(w / q));
-    FpLimb = {q, RN(1/q), N^-1 mod q, RN(N^-1 / q)}, all zero for a modulus the FP body does not take"""
-    def conv(t):
-        w = t[..., 0].astype(np.float64)
-        out = np.zeros(t.shape, dtype=np.float64)
-        out[..., 0] = w
-        out[..., 1] = w / np.float64(q)
-        return out
-    flp = np.zeros(4, dtype=np.float64)
-    if q < FP_LIMIT:
-        flp[:] = [q, np.float64(1.0) / np.float64(q), n_inv, np.float64(n_inv) / np.float64(q)]
-        put(conv(tw), conv(twf), flp)
-    else:
-        put(np.zeros(tw.shape), np.zeros(twf.shape), flp)
-
-
-def test_moduli(logn, mode):
-    """moduli at both ends of the range the mode accepts"""
-    sys.path.insert(0, __import__("os").path.join(__import__("os").path.dirname(__file__), "..", "..", ".."))
-    import __graft_entry__ as graft
-    params = graft.load_package().params
-    lo = params.GenerateNTTPrimes(34, logn, 1)[0]
-    if mode == 2:
-        return [lo, params.GenerateNTTPrimes(56, logn, 2)[1]]
-    if mode == 1:
-        return [params.Qi60()[-3], params.Qi60()[0], lo]
-    above = [p for p in params.GenerateNTTPrimes(60, logn, 4) if p > (1 << 60)]
-    return [above[-1], lo]
-
-
-def fp_test_moduli(logn):
-    """dual kernels: the largest NTT prime below 2^46 (the FP body's range bounds at their tightest), a 30-bit one (below what the
-    integer bodies accept) and one just above 2^46 (integer body of the same kernel)"""
-    sys.path.insert(0, __import__("os").path.join(__import__("os").path.dirname(__file__), "..", "..", ".."))
-    import __graft_entry__ as graft
-    params = graft.load_package().params
-    step = 2 << logn
-    p = FP_LIMIT - step + 1
-    while not params.is_prime(p):
-        p -= step
-    return [p, params.GenerateNTTPrimes(30, logn, 1)[0], params.GenerateNTTPrimes(46, logn, 1)[0]]
-
-
-def emulate_sub(make_gen, inverse, q, pretop=False):
-    """N = 2^16 through the two sub-block workgroups of one limb; returns (bit-exact?, summary)"""
-    import numpy as np
-
-    from isa import Machine
-    sys.path.insert(0, __import__("os").path.join(__import__("os").path.dirname(__file__), "..", "..", ".."))
-    import __graft_entry__ as graft
-    oracle = graft.load_oracle()
-    pkg = graft.load_package()
-    N, NF = 1 << 15, 1 << 16
-    oc = oracle.Context(NF, [q])
-    x = pkg.sampling.random_u64((NF,), seed=9)
-    x[:4] = np.uint64(0xFFFFFFFFFFFFFFFF)
-    if inverse:
-        x = (x % np.uint64(4 * q)).astype(np.uint64)
-    canon = np.array([[int(val) % q for val in x]], dtype=np.uint64)
-    want = (oc.intt(canon) if inverse else oc.ntt(canon))[0]
-    table = oc.ntt_psi_inv[0] if inverse else oc.ntt_psi[0]
-    psi = [int(oracle.inv_mform(int(w), q)) for w in table]
-    n_inv = pow(NF, -1, q)
-    psi[0] = psi[1] * n_inv % q if inverse else q - psi[1]     # lr_abi.cpp fills the unused heap entry 0 like this
-    tw = np.zeros((NF, 2), dtype=np.uint64)
-    for i, w in enumerate(psi):
-        tw[i, 0] = w
-        tw[i, 1] = (w << 64) // q
-    blocks = NF // 16
-    twf = np.zeros((15, blocks, 2), dtype=np.uint64)
-    for cc in range(4):
-        for j in range(1 << cc):
-            for bk in range(blocks):
-                twf[(1 << cc) - 1 + j, bk] = tw[((blocks + bk) << cc) + j]
-    lp = np.zeros(8, dtype=np.uint64)
-    lp[0] = q
-    lp[2] = (1 << 128) // q >> 64
-    lp[5] = n_inv
-    lp[6] = (n_inv << 64) // q
-    A_KARG, A_IN = 0x800, 0x1000
-    A_OUT = A_IN + 8 * NF + 0x1000
-    A_LP = A_OUT + 8 * NF + 0x1000
-    A_TW = A_LP + 0x1000
-    A_TWF = A_TW + 16 * NF + 0x1000
-    A_FTW = A_TWF + 16 * 15 * blocks + 0x1000
-    A_FTWF = A_FTW + 16 * NF + 0x1000
-    A_FLP = A_FTWF + 16 * 15 * blocks + 0x1000
-    mem = np.zeros((A_FLP + 0x1000) // 4, dtype=np.uint32)
-
-    def place(arr, addr):
-        words = np.ascontiguousarray(arr).view(np.uint32).ravel()
-        mem[addr // 4: addr // 4 + words.size] = words
-
-    if pretop:
-        # what ntt_top_kernel leaves for the plain forward sub-blocks: X = U + V*psi[1], Y = U - V*psi[1] (lazy, < 8q)
-        xs = [int(a) % q for a in x]
-        w = psi[1]
-        x = np.array([(xs[j] + xs[j + N] * w) % q + q for j in range(N)] + [(xs[j] - xs[j + N] * w) % q + 3 * q for j in range(N)],
-                     dtype=np.uint64)
-    place(x, A_IN)
-    place(lp, A_LP)
-    place(tw, A_TW)
-    place(twf, A_TWF)
-    fp_tables(np, q, n_inv, tw, twf, lambda a, b, c: (place(a, A_FTW), place(b, A_FTWF), place(c, A_FLP)))
-    karg = np.zeros(16, dtype=np.uint64)
-    karg[13], karg[14], karg[15] = A_FTW - A_TW, A_FTWF - A_TWF, A_FLP
-    karg[0], karg[1], karg[2], karg[3] = A_IN, A_OUT, NF, NF
-    karg[4] = 0 | (1 << 32)
-    karg[5] = 0 | (1 << 32)
-    karg[6] = 0
-    karg[7] = 1 | (1 << 32)
-    karg[8], karg[9], karg[10] = A_LP, A_TW, A_TWF
-    karg[11] = 1                   # sub_log = 1, hole = 0
-    karg[12] = 1                   # group
-    place(karg, A_KARG)
-    info = ""
-    for blk in range(2):
-        gen = make_gen()
-        prog = gen.build()
-        m = Machine(gen.T, 160 * 1024, mem.size)
-        m.mem = mem
-        m.vgpr[0] = np.arange(gen.T, dtype=np.uint32)
-        m.vdef[0] = True
-        m.sgpr[0], m.sgpr[1] = A_KARG, 0
-        m.sgpr[gen.WGX.idx], m.sgpr[gen.WGY.idx], m.sgpr[4] = blk, 0, 0
-        m.sdef[0:5] = True
-        m.run(prog)
-        mem = m.mem
-        cnt = prog.count()
-        info = "%d instructions, %d VALU" % (len(prog.ins), sum(n for op, n in cnt.items() if op.startswith("v_")))
-    got = mem[A_OUT // 4: A_OUT // 4 + 2 * NF].view(np.uint64).copy()
-    if inverse:
-        # what ntt_top_kernel does next: last Gentleman-Sande stage and the scaling
-        U = [int(a) for a in got[:N]]
-        V = [int(a) for a in got[N:]]
-        assert max(max(U), max(V)) < 8 * q
-        w1n = psi[0]
-        got = np.array([(u + v) * n_inv % q for u, v in zip(U, V)] + [(u - v) * w1n % q for u, v in zip(U, V)], dtype=np.uint64)
-    ok = bool(np.array_equal(got, want))
-    return ok, info
-
-
-def selftest(logn, inverse=False, threads=1024):
-    ok = True
-    for mode in ((0, 1) if inverse else (0, 1, 2)):
-        for q in test_moduli(logn, mode):
-            if inverse:
-                from gen_intt import GenInv
-                gen = GenInv(logn, mode, threads)
-            else:
-                gen = Gen(logn, mode, threads)
-            # the last modulus of each mode also exercises the digit-group addressing (grid z, skipped limbs)
-            geom = (2, 1, 1, 2, 3, 6) if q == test_moduli(logn, mode)[-1] else None
-            good, info = emulate(gen, inverse, q, geom)
-            ok = ok and good
-            print("%s logN=%d T=%d mode %d q=%d (%d bits): %s; %s" % ("inverse" if inverse else "forward", logn, threads, mode, q, q.bit_length(),
-                                                             "bit-exact vs oracle" if good else "MISMATCH", info), flush=True)
-    for q in fp_test_moduli(logn):
-        if inverse:
-            from gen_intt import GenInv
-            gen = Dual(lambda fp: GenInv(logn, 1, threads, fp=fp, dual=True))
-        else:
-            gen = Dual(lambda fp: Gen(logn, 2, threads, fp=fp, dual=True))
-        geom = (2, 1, 1, 2, 3, 6) if q == fp_test_moduli(logn)[0] else None
-        good, info = emulate(gen, inverse, q, geom)
-        ok = ok and good
-        print("%s logN=%d T=%d dual q=%d (%d bits): %s; %s" % ("inverse" if inverse else "forward", logn, threads, q, q.bit_length(),
-                                                        "bit-exact vs oracle" if good else "MISMATCH", info), flush=True)
-    if not inverse:
-        # the epilogue kernels: out = (x - NTT(in)) * c + plus on the FP64 body, plain and with the digit-group addressing
-        for q in fp_test_moduli(logn)[:2]:
-            for geom in (None, (2, 1, 1, 2, 3, 6)):
-                good, info = emulate(Dual(lambda fp: Gen(logn, 2, threads, fp=fp, dual=True, epi=True)), False, q, geom)
-                ok = ok and good
-                print("forward logN=%d T=%d epilogue q=%d (%d bits): %s; %s" % (logn, threads, q, q.bit_length(),
-                                                                          "bit-exact vs oracle" if good else "MISMATCH", info), flush=True)
-    return ok
-
-
-def selftest_sub(inverse=False):
-    """the sub-block kernels of N = 2^16"""
-    ok = True
-    for mode in ((0, 1) if inverse else (0, 1, 2)):
-        q = test_moduli(16, mode)[0]
-        if inverse:
-            from gen_intt import GenInv
-            make = lambda: GenInv(15, mode, 1024, sub=True)
-        else:
-            make = lambda: Gen(15, mode, 1024, sub=True)
-        good, info = emulate_sub(make, inverse, q)
-        if not inverse:
-            # the plain variant continues from the output of the separate top-stage pass
-            good2, _ = emulate_sub(lambda: Gen(15, mode, 1024, sub=True, fused=False), inverse, q, pretop=True)
-            good = good and good2
-        ok = ok and good
-        print("%s N=2^16 sub-blocks mode %d q=%d (%d bits): %s; %s" % ("inverse" if inverse else "forward", mode, q, q.bit_length(),
-                                                                    "bit-exact vs oracle" if good else "MISMATCH", info), flush=True)
-    for q in fp_test_moduli(16)[:2]:
-        if inverse:
-            from gen_intt import GenInv
-            good, info = emulate_sub(lambda: Dual(lambda fp: GenInv(15, 1, 1024, sub=True, fp=fp, dual=True)), True, q)
-        else:
-            good, info = emulate_sub(lambda: Dual(lambda fp: Gen(15, 2, 1024, sub=True, fp=fp, dual=True)), False, q)
-            good2, _ = emulate_sub(lambda: Dual(lambda fp: Gen(15, 2, 1024, sub=True, fused=False, fp=fp, dual=True)), False, q, pretop=True)
-            good = good and good2
-        ok = ok and good
-        print("%s N=2^16 sub-blocks dual q=%d (%d bits): %s; %s" % ("inverse" if inverse else "forward", q, q.bit_length(),
-                                                             "bit-exact vs oracle" if good else "MISMATCH", info), flush=True)
-    return ok
 
 
 if __name__ == "__main__":
     logn = int(sys.argv[1])
-    if len(sys.argv) > 2 and sys.argv[2] == "--selftest":
-        if logn == 16:
-            sys.exit(0 if selftest_sub() else 1)
-        threads = int(sys.argv[3]) if len(sys.argv) > 3 else 1024
-        sys.exit(0 if selftest(logn, threads=threads) else 1)
     mode = int(sys.argv[3]) if len(sys.argv) > 3 else 1
     threads = int(sys.argv[4]) if len(sys.argv) > 4 else 1024
     # mode 3: FP64 body for the limbs below 2^46, the integer body of mode 2 for the others (every modulus below 2^57)
@@ -1384,6 +1109,9 @@ if __name__ == "__main__":
         fused = not (len(sys.argv) > 5 and sys.argv[5] == "plain")
         open(sys.argv[2], "w").write(kernel_text_for(make(15, 1024, sub=True, fused=fused),
                                                      "lr_ntt_fwd16%s_m%d" % ("s" if fused else "p", mode)))
+        sys.exit(0)
+    if len(sys.argv) > 5 and sys.argv[5] == "timeline":      # diagnostics build with per-phase clock stamps (Options::timeline)
+        open(sys.argv[2], "w").write(kernel_text_for(Gen(logn, mode, threads, profile=True), "lr_ntt_fwd%d_m%dt" % (logn, mode)))
         sys.exit(0)
     name = "lr_ntt_fwd%d%s_m%d" % (logn, "x" if threads < 1024 else "", mode)     # x: several workgroups per CU
     open(sys.argv[2], "w").write(kernel_text_for(make(logn, threads), name))

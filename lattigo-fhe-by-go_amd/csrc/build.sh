@@ -57,6 +57,10 @@ gen_sub inv 16s 3 & gpids+=($!)
 # mode 4: the dual forward kernels with the subtract-multiply-add epilogue on the FP64 body (ModDown inside the key switch)
 gen_one fwd 14 4 & gpids+=($!); gen_one fwd 15 4 & gpids+=($!)
 gen_one fwd 14 4 512 & gpids+=($!); gen_one fwd 13 4 256 & gpids+=($!); gen_one fwd 12 4 256 & gpids+=($!)
+# diagnostics: the 2^15 integer kernel with per-phase clock stamps (LR_NTT_TIMELINE=1, tools/timeline.py)
+( python3 asmgen/gen_ntt.py 15 build/ntt_fwd15_m1t.s 1 1024 timeline
+  $LLVM/clang -x assembler -target amdgcn-amd-amdhsa -mcpu=gfx950 -c build/ntt_fwd15_m1t.s -o build/ntt_fwd15_m1t.o
+  $LLVM/ld.lld -shared build/ntt_fwd15_m1t.o -o build/ntt_fwd15_m1t.hsaco ) & gpids+=($!)
 for p in "${gpids[@]}"; do wait $p; done
 python3 - <<'PY'
 out = ['struct lr_asm_blob { const char *name; const unsigned char *data; unsigned long size; };']
@@ -64,14 +68,15 @@ names = [("fwd", n, m) for n in (14, 15) for m in (0, 1, 2)] + [("inv", n, m) fo
 names += [("fwd", n, m) for n in ("12x", "13x", "14x", "16s", "16p") for m in (0, 1, 2)] + [("inv", n, m) for n in ("12x", "13x", "14x", "16s") for m in (0, 1)]
 names += [("fwd", n, 3) for n in (14, 15, "12x", "13x", "14x", "16s", "16p")] + [("inv", n, 3) for n in (14, 15, "12x", "13x", "14x", "16s")]
 names += [("fwd", n, 4) for n in (14, 15, "12x", "13x", "14x")]
+names = [(k, n, str(m)) for k, n, m in names] + [("fwd", 15, "1t")]
 for k, n, m in names:
-    data = open("build/ntt_%s%s_m%d.hsaco" % (k, n, m), "rb").read()
-    out.append('static const unsigned char blob_%s%s_m%d[] __attribute__((aligned(4096))) = {' % (k, n, m))
+    data = open("build/ntt_%s%s_m%s.hsaco" % (k, n, m), "rb").read()
+    out.append('static const unsigned char blob_%s%s_m%s[] __attribute__((aligned(4096))) = {' % (k, n, m))
     out.append(",".join(str(b) for b in data))
     out.append("};")
 out.append('extern "C" const lr_asm_blob lr_asm_blobs[] = {')
 for k, n, m in names:
-    out.append('  {"lr_ntt_%s%s_m%d", blob_%s%s_m%d, sizeof(blob_%s%s_m%d)},' % (k, n, m, k, n, m, k, n, m))
+    out.append('  {"lr_ntt_%s%s_m%s", blob_%s%s_m%s, sizeof(blob_%s%s_m%s)},' % (k, n, m, k, n, m, k, n, m))
 out.append("};")
 out.append('extern "C" const int lr_asm_blob_count = %d;' % len(names))
 open("build/lr_asm_blob.cpp", "w").write("\n".join(out) + "\n")

@@ -159,6 +159,7 @@ lr::Options lr::Options::from_env() {
     o.ext_narrow = std::getenv("LR_EXT_NARROW") != nullptr;
     o.asm14_1024 = std::getenv("LR_ASM_14_1024") != nullptr;
     o.no_ingest = std::getenv("LR_NO_INGEST") != nullptr;
+    o.timeline = std::getenv("LR_NTT_TIMELINE") != nullptr;
     if (const char *v = std::getenv("LR_NTT_MODE")) o.ntt_mode = std::atoi(v);
     if (const char *v = std::getenv("LR_ASM_VARIANT")) o.asm_variant = std::atoi(v);
     return o;
@@ -180,6 +181,8 @@ struct lr_context {
     Options opt;                // environment switches, read once at creation
     ScratchPool scratch;        // rescale / staging temporaries, leased per call (thread-safe)
     char last_ntt_kernel[32] = "";   // name of the kernel the last NTT launch of this context dispatched (diagnostics, bench.py)
+    u32 *d_stamps = nullptr;    // timeline builds (Options::timeline): [workgroup][wave 16][stamp 16] of the last stamped launch
+    size_t stamp_words = 0, stamp_used = 0;
     // DivRoundByLastModulusNTT: per level, -(pHalfNegQi[i] * NTT_i(1 + X + ... + X^(N-1))) * rescaleParams[i] for i < level,
     // [level][N], built on first use (rescale_round_table)
     struct RoundTable { u64 *plus; EpiLimb *epi; };
@@ -529,6 +532,7 @@ extern "C" int lr_context_destroy(lr_context *c) {
     for (void *p : {(void *)c->d_lp, (void *)c->d_fwd, (void *)c->d_inv, (void *)c->d_fwd_fin, (void *)c->d_inv_fin, (void *)c->d_rescale,
                     (void *)c->d_fwd_fp, (void *)c->d_inv_fp, (void *)c->d_fwd_fin_fp, (void *)c->d_inv_fin_fp, (void *)c->d_fp_lp})
         if (p) (void)hipFree(p);
+    if (c->d_stamps) (void)hipFree(c->d_stamps);
     for (auto &kv : c->rescale_round) {
         if (kv.second.plus) (void)hipFree(kv.second.plus);
         if (kv.second.epi) (void)hipFree(kv.second.epi);
@@ -950,6 +954,22 @@ int run_ntt_launch(lr_context *c, bool inverse, Rows in, Rows out, int mod0, int
         return LR_OK;
     }
     if (logn != 16 && variant >= 0 && c->use_asm && ntt_asm_available((int)logn)) {
+        if (c->opt.timeline && logn == 15 && !inverse && variant == 1 && hole == 0) {
+            // diagnostics: the stamped build of the same kernel; stamps land in the context's buffer (lr_context_timeline)
+            const size_t words = (size_t)batch * (size_t)count * 16 * 16;
+            if (words > c->stamp_words) {
+                LR_HIP(hipStreamSynchronize(c->stream));
+                if (c->d_stamps) LR_HIP(hipFree(c->d_stamps));
+                c->d_stamps = nullptr;
+                c->stamp_words = 0;
+                LR_HIP(hipMalloc((void **)&c->d_stamps, words * sizeof(u32)));
+                c->stamp_words = words;
+            }
+            c->stamp_used = words;
+            a.epi_x = reinterpret_cast<const u64 *>(c->d_stamps);
+            LR_HIP(launch_ntt_asm(a, (int)logn, 0, variant, c->stream, false, kn, true));
+            return LR_OK;
+        }
         LR_HIP(launch_ntt_asm(a, (int)logn, inverse, variant, c->stream, c->opt.asm14_1024, kn));
         return LR_OK;
     }
@@ -2360,6 +2380,19 @@ extern "C" int lr_ckks_decrypt(lr_ckks_plan *pl, int level, const lr_poly *const
         if ((i & 7) == 7) LR_TRY(run_ewise(cQ, LR_REDUCE, L1, batch, pt->d, pt->stride(), nullptr, 0, pt->d, pt->stride(), nullptr));     // :70
     }
     if ((degree & 7) != 7) LR_TRY(run_ewise(cQ, LR_REDUCE, L1, batch, pt->d, pt->stride(), nullptr, 0, pt->d, pt->stride(), nullptr));    // :75
+    return LR_OK;
+    });
+}
+
+extern "C" int lr_context_timeline(lr_context *c, uint32_t *dst, size_t capacity, size_t *count) {
+    return guarded([&]() -> int {
+    if (!c || !count) return fail(LR_ERR_ARG, "null argument");
+    *count = c->stamp_used;
+    if (!dst) return LR_OK;                                   // size query
+    if (capacity < c->stamp_used) return fail(LR_ERR_SHAPE, "timeline: destination too small");
+    LR_HIP(hipSetDevice(c->device));
+    LR_HIP(hipStreamSynchronize(c->stream));
+    if (c->stamp_used) LR_HIP(hipMemcpy(dst, c->d_stamps, c->stamp_used * sizeof(u32), hipMemcpyDeviceToHost));
     return LR_OK;
     });
 }

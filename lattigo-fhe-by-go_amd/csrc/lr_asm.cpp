@@ -60,7 +60,7 @@ AsmKernels *kernels_for_current_device() {
 bool ntt_asm_available(int logn) { return logn >= 12 && logn <= 16 && kernels_for_current_device() != nullptr; }
 
 // variant = lazy-correction mode of asmgen/gen_ntt.py (forward 0, 1, 2) / gen_intt.py (inverse 0, 1)
-hipError_t launch_ntt_asm(const NttLaunch &a, int logn, int inverse, int variant, hipStream_t stream, bool wide14, char *kernel_name) {
+hipError_t launch_ntt_asm(const NttLaunch &a, int logn, int inverse, int variant, hipStream_t stream, bool wide14, char *kernel_name, bool timeline) {
     AsmKernels *k = kernels_for_current_device();
     if (!k || logn < 12 || logn > 15) return hipErrorNotSupported;
     // N = 2^12 (256 threads, four columns per thread, 36 KiB LDS image) and N = 2^13, 2^14 (512 threads, two columns,
@@ -68,7 +68,7 @@ hipError_t launch_ntt_asm(const NttLaunch &a, int logn, int inverse, int variant
     // covers the other's load and store phases.  wide14 (Options::asm14_1024) selects the 1024-thread kernels (testing aid).
     const bool x = logn <= 13 || (logn == 14 && !wide14);
     char name[32];
-    std::snprintf(name, sizeof name, "lr_ntt_%s%d%s_m%d", inverse ? "inv" : "fwd", logn, x ? "x" : "", variant);
+    std::snprintf(name, sizeof name, "lr_ntt_%s%d%s_m%d%s", inverse ? "inv" : "fwd", logn, x ? "x" : "", variant, timeline ? "t" : "");
     auto it = k->fn.find(name);
     if (it == k->fn.end()) return hipErrorNotSupported;
     if (kernel_name) std::snprintf(kernel_name, 32, "%s", name);

@@ -35,6 +35,7 @@ struct Options {
     bool no_staging = false;       // LR_NO_STAGING: N = 2^16 key switch with in-place forward transforms
     bool ext_narrow = false;       // LR_EXT_NARROW: per-term basis extension instead of the 128-bit column sums
     bool asm14_1024 = false;       // LR_ASM_14_1024: the 1024-thread plan at N = 2^14
+    bool timeline = false;         // LR_NTT_TIMELINE: forward 2^15 launches of the integer kernel run the stamped diagnostics build
     bool no_ingest = false;        // LR_NO_INGEST: key-switch digits through the extension kernel + staging instead of the fused ingest
     int ntt_mode = -1;             // LR_NTT_MODE
     int asm_variant = -1;          // LR_ASM_VARIANT
@@ -275,7 +276,7 @@ hipError_t launch_ntt(const NttLaunch &a, int logn, bool inverse, int mode, hipS
 bool ntt_asm_available(int logn);
 // kernel_name (optional, >= 32 bytes): receives the name of the code object that was launched
 hipError_t launch_ntt_asm(const NttLaunch &a, int logn, int inverse, int variant, hipStream_t stream, bool wide14 = false,
-                          char *kernel_name = nullptr);
+                          char *kernel_name = nullptr, bool timeline = false);
 hipError_t launch_ntt_asm16(const NttLaunch &a, int inverse, char kind, int variant, hipStream_t stream, char *kernel_name = nullptr);
 // N = 2^16 helpers (lr_ntt.hip): the streaming stage over bit 15, and whether no input row of a launch is an output row
 hipError_t launch_ntt_top(const NttLaunch &a, int inverse, hipStream_t stream);

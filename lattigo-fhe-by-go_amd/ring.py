@@ -324,6 +324,16 @@ class Context:
         check(lib().lr_context_last_ntt_kernel(self.h, buf, len(buf)))
         return buf.value.decode()
 
+    def timeline(self):
+        """clock stamps of the last launch of the stamped diagnostics kernel (context created under LR_NTT_TIMELINE=1):
+        uint32 array [workgroups, 16 waves, 16 stamps]"""
+        n = C.c_size_t(0)
+        check(lib().lr_context_timeline(self.h, None, 0, C.byref(n)))
+        out = np.zeros(n.value, dtype=np.uint32)
+        if n.value:
+            check(lib().lr_context_timeline(self.h, out.ctypes.data_as(C.c_void_p), out.size, C.byref(n)))
+        return out.reshape(-1, 16, 16)
+
     def MultByMonomial(self, p1, monomialDeg, p2):  # ring/ring.go:663
         check(lib().lr_mult_by_monomial(self.h, p1.h, int(monomialDeg), p2.h))
 

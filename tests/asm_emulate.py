@@ -1,0 +1,374 @@
+"""Emulator harness of the assembly NTT kernels (test infrastructure: imports the oracle).
+
+Runs one workgroup of a generated instruction stream (asmgen/gen_ntt.py, gen_intt.py) on the numpy SIMT emulator of
+asmgen/isa.py and compares it with the CPU oracle: the same checks the device tests make, without a GPU.
+
+    python tests/asm_emulate.py 15 --selftest [threads]          # forward kernels of 2^15
+    python tests/asm_emulate.py 15 --selftest-inverse [threads]
+    python tests/asm_emulate.py 16 --selftest | --selftest-inverse   # the 2^15 sub-block kernels of N = 2^16
+"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "lattigo-fhe-by-go_amd", "csrc", "asmgen"))
+
+from gen_ntt import FP_LIMIT, Dual, Gen  # noqa: E402,F401
+from isa import Machine, Program  # noqa: E402,F401
+
+
+# ------------------------------------------------------------------------------------------
+# self test on the numpy emulator
+# ------------------------------------------------------------------------------------------
+def emulate(gen, inverse=False, q=None, geom=None):
+    # geom = (x, y, z, hole, group, rows per poly): workgroup ids and the digit-group arguments of NttLaunch
+    """run one workgroup of the generated program on the numpy emulator; returns (bit-exact?, summary text)"""
+    import numpy as np
+
+    from isa import Machine
+    sys.path.insert(0, __import__("os").path.join(__import__("os").path.dirname(__file__), "..", "..", ".."))
+    import __graft_entry__ as graft
+    oracle = graft.load_oracle()
+    pkg = graft.load_package()
+    logn = gen.logn
+    N = 1 << logn
+    q = q or pkg.params.Qi60()[-3]
+    oc = oracle.Context(N, [q])
+    x = pkg.sampling.random_u64((N,), seed=5)                 # full 64-bit inputs
+    x[:4] = np.uint64(0xFFFFFFFFFFFFFFFF)
+    if inverse:
+        x = (x % np.uint64(4 * q)).astype(np.uint64)          # the inverse accepts [0, 4q)
+        x[:4] = np.uint64(4 * q - 1)
+    canon = np.array([[int(val) % q for val in x]], dtype=np.uint64)
+    want = (oc.intt(canon) if inverse else oc.ntt(canon))[0]
+
+    # host-side tables exactly as lr_abi.cpp builds them
+    table = oc.ntt_psi_inv[0] if inverse else oc.ntt_psi[0]
+    psi = [int(oracle.inv_mform(int(w), q)) for w in table]
+    n_inv = pow(N, -1, q)
+    if inverse:
+        psi[0] = psi[1] * n_inv % q                           # constant of the fused last stage
+    tw = np.zeros((N, 2), dtype=np.uint64)
+    for i, w in enumerate(psi):
+        tw[i, 0] = w
+        tw[i, 1] = (w << 64) // q
+    blocks = N // 16
+    twf = np.zeros((15, blocks, 2), dtype=np.uint64)
+    for cc in range(4):
+        for j in range(1 << cc):
+            for bk in range(blocks):
+                twf[(1 << cc) - 1 + j, bk] = tw[((blocks + bk) << cc) + j]
+    qh = (q >> 32) + 1
+    g = qh.bit_length() - 1
+    red_m = min((1 << (32 + g)) // qh, 0xFFFFFFFF)
+    lp = np.zeros(8, dtype=np.uint64)
+    lp[0] = q
+    lp[2] = (1 << 128) // q >> 64
+    lp[5] = n_inv
+    lp[6] = (n_inv << 64) // q
+    lp[7] = red_m | (g << 32)
+
+    # flat memory image (byte addresses)
+    def place(arr, addr):
+        words = np.ascontiguousarray(arr).view(np.uint32).ravel()
+        mem[addr // 4: addr // 4 + words.size] = words
+
+    gx, gy, gz, hole, group, rows = geom or (0, 0, 0, 0, 0, 1)
+    item = gx + (hole if gx >= gz * hole else 0)
+    where = ((gz * group + gy) * rows + item) * 8 * N          # byte offset of the addressed row
+    span = ((gz * group + gy + 1) * rows + 1) * 8 * N
+    A_KARG, A_IN = 0x800, 0x1000
+    A_OUT = A_IN + span
+    A_LP = A_OUT + span
+    A_TW = A_LP + 0x1000
+    A_TWF = A_TW + 16 * N + 0x1000
+    A_FTW = A_TWF + 16 * 15 * blocks + 0x1000
+    A_FTWF = A_FTW + 16 * N + 0x1000
+    A_FLP = A_FTWF + 16 * 15 * blocks + 0x1000
+    A_STAMPS = A_FLP + 0x1000                                   # timeline builds: NttLaunch::epi_x
+    mem = np.zeros((A_STAMPS + 0x2000) // 4, dtype=np.uint32)
+    place(x, A_IN + where)
+    place(lp, A_LP)
+    place(tw, A_TW)
+    place(twf, A_TWF)
+    fp_tables(np, q, n_inv, tw, twf, lambda a, b, c: (place(a, A_FTW), place(b, A_FTWF), place(c, A_FLP)))
+    karg = np.zeros(21, dtype=np.uint64)
+    karg[13], karg[14], karg[15] = A_FTW - A_TW, A_FTWF - A_TWF, A_FLP
+    if getattr(gen, "epi", False) and q < FP_LIMIT:
+        # x and plus: canonical polys laid out like the output; c: a random constant in (w, w / q) form
+        rng = np.random.default_rng(7)
+        xe = (rng.integers(0, 1 << 62, N, dtype=np.uint64) % np.uint64(q)).astype(np.uint64)
+        pe = (rng.integers(0, 1 << 62, N, dtype=np.uint64) % np.uint64(q)).astype(np.uint64)
+        xe[:3], pe[:3] = [0, q - 1, q - 1], [q - 1, 0, q - 1]
+        ce = int(rng.integers(1, q))
+        A_X, A_P, A_EC = mem.size * 4, mem.size * 4 + span, mem.size * 4 + 2 * span
+        mem = np.concatenate([mem, np.zeros((2 * span + 0x1000) // 4, dtype=np.uint32)])
+        place(xe, A_X + where)
+        place(pe, A_P + where)
+        place(np.array([ce, np.float64(ce) / np.float64(q)], dtype=np.float64), A_EC)      # modulus index 0
+        karg[16], karg[17], karg[18], karg[19], karg[20] = A_X, rows * N, A_P, rows * N, A_EC
+        want = np.array([((int(a) - int(b)) * ce + int(c)) % q for a, b, c in zip(xe, want, pe)], dtype=np.uint64)
+    karg[0], karg[1], karg[2], karg[3] = A_IN, A_OUT, rows * N, rows * N
+    karg[4] = 0 | (1 << 32)        # in_limb0, in_limb_step
+    karg[5] = 0 | (1 << 32)        # out_limb0, out_limb_step
+    karg[6] = 0 | (0 << 32)        # mod0, mod_step: one modulus serves every row of this harness
+    karg[11] = 0 | (hole << 32)    # sub_log, hole
+    karg[12] = group               # group, pad
+    karg[7] = 1 | (1 << 32)        # n_items, batch
+    karg[8], karg[9], karg[10] = A_LP, A_TW, A_TWF
+    if getattr(gen, "profile", False):
+        karg[16] = A_STAMPS
+    place(karg, A_KARG)
+
+    prog = gen.build()
+    m = Machine(gen.T, 160 * 1024, mem.size)
+    m.mem = mem
+    m.vgpr[0] = np.arange(gen.T, dtype=np.uint32)
+    m.vdef[0] = True
+    m.sgpr[0], m.sgpr[1] = A_KARG, 0
+    m.sgpr[gen.WGX.idx], m.sgpr[gen.WGY.idx], m.sgpr[4] = gx, gy, gz
+    m.sdef[0:5] = True
+    m.count_lds = bool(__import__("os").environ.get("LR_EMU_LDS_STATS"))
+    m.run(prog)
+    got = m.mem[(A_OUT + where) // 4: (A_OUT + where) // 4 + 2 * N].view(np.uint64)
+    ok = np.array_equal(got, want)
+    if m.count_lds:
+        gen.lds_stats = m.lds_stats
+        gen.last_prog = prog
+    cnt = prog.count()
+    valu = sum(n for op, n in cnt.items() if op.startswith("v_"))
+    bf = (1 << gen.A) * logn // 2
+    info = "%d instructions, %d VALU = %.1f per butterfly, s_nop %d" % (len(prog.ins), valu, valu / bf, cnt.get("s_nop", 0))
+    if getattr(gen, "gf", None) is not None:
+        ran = sum(n for op, n in m.executed.items() if op.startswith("v_"))
+        info = "%s body, %d VALU executed = %.1f per butterfly" % ("FP64" if m.executed.get("v_fma_f64") else "integer", ran, ran / bf)
+        ok = ok and bool(m.executed.get("v_fma_f64")) == (q < FP_LIMIT)
+    if not ok:
+        bad = np.nonzero(got != want)[0]
+        info += "\n  mismatches: %d first: %s %s %s" % (bad.size, bad[:8], [hex(int(got[i])) for i in bad[:3]],
+                                                       [hex(int(want[i])) for i in bad[:3]])
+    return ok, info
+
+
+
+
+def fp_tables(np, q, n_inv, tw, twf, put):
+    """what lr_abi.cpp builds for the FP body: every (w, floor(w 2^64 / q)) becomes the pair of doubles (w, RN(w / q));
+    FpLimb = {q, RN(1/q), N^-1 mod q, RN(N^-1 / q)}, all zero for a modulus the FP body does not take"""
+    def conv(t):
+        w = t[..., 0].astype(np.float64)
+        out = np.zeros(t.shape, dtype=np.float64)
+        out[..., 0] = w
+        out[..., 1] = w / np.float64(q)
+        return out
+    flp = np.zeros(4, dtype=np.float64)
+    if q < FP_LIMIT:
+        flp[:] = [q, np.float64(1.0) / np.float64(q), n_inv, np.float64(n_inv) / np.float64(q)]
+        put(conv(tw), conv(twf), flp)
+    else:
+        put(np.zeros(tw.shape), np.zeros(twf.shape), flp)
+
+
+def test_moduli(logn, mode):
+    """moduli at both ends of the range the mode accepts"""
+    sys.path.insert(0, __import__("os").path.join(__import__("os").path.dirname(__file__), "..", "..", ".."))
+    import __graft_entry__ as graft
+    params = graft.load_package().params
+    lo = params.GenerateNTTPrimes(34, logn, 1)[0]
+    if mode == 2:
+        return [lo, params.GenerateNTTPrimes(56, logn, 2)[1]]
+    if mode == 1:
+        return [params.Qi60()[-3], params.Qi60()[0], lo]
+    above = [p for p in params.GenerateNTTPrimes(60, logn, 4) if p > (1 << 60)]
+    return [above[-1], lo]
+
+
+def fp_test_moduli(logn):
+    """dual kernels: the largest NTT prime below 2^46 (the FP body's range bounds at their tightest), a 30-bit one (below what the
+    integer bodies accept) and one just above 2^46 (integer body of the same kernel)"""
+    sys.path.insert(0, __import__("os").path.join(__import__("os").path.dirname(__file__), "..", "..", ".."))
+    import __graft_entry__ as graft
+    params = graft.load_package().params
+    step = 2 << logn
+    p = FP_LIMIT - step + 1
+    while not params.is_prime(p):
+        p -= step
+    return [p, params.GenerateNTTPrimes(30, logn, 1)[0], params.GenerateNTTPrimes(46, logn, 1)[0]]
+
+
+def emulate_sub(make_gen, inverse, q, pretop=False):
+    """N = 2^16 through the two sub-block workgroups of one limb; returns (bit-exact?, summary)"""
+    import numpy as np
+
+    from isa import Machine
+    sys.path.insert(0, __import__("os").path.join(__import__("os").path.dirname(__file__), "..", "..", ".."))
+    import __graft_entry__ as graft
+    oracle = graft.load_oracle()
+    pkg = graft.load_package()
+    N, NF = 1 << 15, 1 << 16
+    oc = oracle.Context(NF, [q])
+    x = pkg.sampling.random_u64((NF,), seed=9)
+    x[:4] = np.uint64(0xFFFFFFFFFFFFFFFF)
+    if inverse:
+        x = (x % np.uint64(4 * q)).astype(np.uint64)
+    canon = np.array([[int(val) % q for val in x]], dtype=np.uint64)
+    want = (oc.intt(canon) if inverse else oc.ntt(canon))[0]
+    table = oc.ntt_psi_inv[0] if inverse else oc.ntt_psi[0]
+    psi = [int(oracle.inv_mform(int(w), q)) for w in table]
+    n_inv = pow(NF, -1, q)
+    psi[0] = psi[1] * n_inv % q if inverse else q - psi[1]     # lr_abi.cpp fills the unused heap entry 0 like this
+    tw = np.zeros((NF, 2), dtype=np.uint64)
+    for i, w in enumerate(psi):
+        tw[i, 0] = w
+        tw[i, 1] = (w << 64) // q
+    blocks = NF // 16
+    twf = np.zeros((15, blocks, 2), dtype=np.uint64)
+    for cc in range(4):
+        for j in range(1 << cc):
+            for bk in range(blocks):
+                twf[(1 << cc) - 1 + j, bk] = tw[((blocks + bk) << cc) + j]
+    lp = np.zeros(8, dtype=np.uint64)
+    lp[0] = q
+    lp[2] = (1 << 128) // q >> 64
+    lp[5] = n_inv
+    lp[6] = (n_inv << 64) // q
+    A_KARG, A_IN = 0x800, 0x1000
+    A_OUT = A_IN + 8 * NF + 0x1000
+    A_LP = A_OUT + 8 * NF + 0x1000
+    A_TW = A_LP + 0x1000
+    A_TWF = A_TW + 16 * NF + 0x1000
+    A_FTW = A_TWF + 16 * 15 * blocks + 0x1000
+    A_FTWF = A_FTW + 16 * NF + 0x1000
+    A_FLP = A_FTWF + 16 * 15 * blocks + 0x1000
+    mem = np.zeros((A_FLP + 0x1000) // 4, dtype=np.uint32)
+
+    def place(arr, addr):
+        words = np.ascontiguousarray(arr).view(np.uint32).ravel()
+        mem[addr // 4: addr // 4 + words.size] = words
+
+    if pretop:
+        # what ntt_top_kernel leaves for the plain forward sub-blocks: X = U + V*psi[1], Y = U - V*psi[1] (lazy, < 8q)
+        xs = [int(a) % q for a in x]
+        w = psi[1]
+        x = np.array([(xs[j] + xs[j + N] * w) % q + q for j in range(N)] + [(xs[j] - xs[j + N] * w) % q + 3 * q for j in range(N)],
+                     dtype=np.uint64)
+    place(x, A_IN)
+    place(lp, A_LP)
+    place(tw, A_TW)
+    place(twf, A_TWF)
+    fp_tables(np, q, n_inv, tw, twf, lambda a, b, c: (place(a, A_FTW), place(b, A_FTWF), place(c, A_FLP)))
+    karg = np.zeros(16, dtype=np.uint64)
+    karg[13], karg[14], karg[15] = A_FTW - A_TW, A_FTWF - A_TWF, A_FLP
+    karg[0], karg[1], karg[2], karg[3] = A_IN, A_OUT, NF, NF
+    karg[4] = 0 | (1 << 32)
+    karg[5] = 0 | (1 << 32)
+    karg[6] = 0
+    karg[7] = 1 | (1 << 32)
+    karg[8], karg[9], karg[10] = A_LP, A_TW, A_TWF
+    karg[11] = 1                   # sub_log = 1, hole = 0
+    karg[12] = 1                   # group
+    place(karg, A_KARG)
+    info = ""
+    for blk in range(2):
+        gen = make_gen()
+        prog = gen.build()
+        m = Machine(gen.T, 160 * 1024, mem.size)
+        m.mem = mem
+        m.vgpr[0] = np.arange(gen.T, dtype=np.uint32)
+        m.vdef[0] = True
+        m.sgpr[0], m.sgpr[1] = A_KARG, 0
+        m.sgpr[gen.WGX.idx], m.sgpr[gen.WGY.idx], m.sgpr[4] = blk, 0, 0
+        m.sdef[0:5] = True
+        m.run(prog)
+        mem = m.mem
+        cnt = prog.count()
+        info = "%d instructions, %d VALU" % (len(prog.ins), sum(n for op, n in cnt.items() if op.startswith("v_")))
+    got = mem[A_OUT // 4: A_OUT // 4 + 2 * NF].view(np.uint64).copy()
+    if inverse:
+        # what ntt_top_kernel does next: last Gentleman-Sande stage and the scaling
+        U = [int(a) for a in got[:N]]
+        V = [int(a) for a in got[N:]]
+        assert max(max(U), max(V)) < 8 * q
+        w1n = psi[0]
+        got = np.array([(u + v) * n_inv % q for u, v in zip(U, V)] + [(u - v) * w1n % q for u, v in zip(U, V)], dtype=np.uint64)
+    ok = bool(np.array_equal(got, want))
+    return ok, info
+
+
+def selftest(logn, inverse=False, threads=1024):
+    ok = True
+    for mode in ((0, 1) if inverse else (0, 1, 2)):
+        for q in test_moduli(logn, mode):
+            if inverse:
+                from gen_intt import GenInv
+                gen = GenInv(logn, mode, threads)
+            else:
+                gen = Gen(logn, mode, threads)
+            # the last modulus of each mode also exercises the digit-group addressing (grid z, skipped limbs)
+            geom = (2, 1, 1, 2, 3, 6) if q == test_moduli(logn, mode)[-1] else None
+            good, info = emulate(gen, inverse, q, geom)
+            ok = ok and good
+            print("%s logN=%d T=%d mode %d q=%d (%d bits): %s; %s" % ("inverse" if inverse else "forward", logn, threads, mode, q, q.bit_length(),
+                                                             "bit-exact vs oracle" if good else "MISMATCH", info), flush=True)
+    for q in fp_test_moduli(logn):
+        if inverse:
+            from gen_intt import GenInv
+            gen = Dual(lambda fp: GenInv(logn, 1, threads, fp=fp, dual=True))
+        else:
+            gen = Dual(lambda fp: Gen(logn, 2, threads, fp=fp, dual=True))
+        geom = (2, 1, 1, 2, 3, 6) if q == fp_test_moduli(logn)[0] else None
+        good, info = emulate(gen, inverse, q, geom)
+        ok = ok and good
+        print("%s logN=%d T=%d dual q=%d (%d bits): %s; %s" % ("inverse" if inverse else "forward", logn, threads, q, q.bit_length(),
+                                                        "bit-exact vs oracle" if good else "MISMATCH", info), flush=True)
+    if not inverse:
+        # the epilogue kernels: out = (x - NTT(in)) * c + plus on the FP64 body, plain and with the digit-group addressing
+        for q in fp_test_moduli(logn)[:2]:
+            for geom in (None, (2, 1, 1, 2, 3, 6)):
+                good, info = emulate(Dual(lambda fp: Gen(logn, 2, threads, fp=fp, dual=True, epi=True)), False, q, geom)
+                ok = ok and good
+                print("forward logN=%d T=%d epilogue q=%d (%d bits): %s; %s" % (logn, threads, q, q.bit_length(),
+                                                                          "bit-exact vs oracle" if good else "MISMATCH", info), flush=True)
+    return ok
+
+
+def selftest_sub(inverse=False):
+    """the sub-block kernels of N = 2^16"""
+    ok = True
+    for mode in ((0, 1) if inverse else (0, 1, 2)):
+        q = test_moduli(16, mode)[0]
+        if inverse:
+            from gen_intt import GenInv
+            make = lambda: GenInv(15, mode, 1024, sub=True)
+        else:
+            make = lambda: Gen(15, mode, 1024, sub=True)
+        good, info = emulate_sub(make, inverse, q)
+        if not inverse:
+            # the plain variant continues from the output of the separate top-stage pass
+            good2, _ = emulate_sub(lambda: Gen(15, mode, 1024, sub=True, fused=False), inverse, q, pretop=True)
+            good = good and good2
+        ok = ok and good
+        print("%s N=2^16 sub-blocks mode %d q=%d (%d bits): %s; %s" % ("inverse" if inverse else "forward", mode, q, q.bit_length(),
+                                                                    "bit-exact vs oracle" if good else "MISMATCH", info), flush=True)
+    for q in fp_test_moduli(16)[:2]:
+        if inverse:
+            from gen_intt import GenInv
+            good, info = emulate_sub(lambda: Dual(lambda fp: GenInv(15, 1, 1024, sub=True, fp=fp, dual=True)), True, q)
+        else:
+            good, info = emulate_sub(lambda: Dual(lambda fp: Gen(15, 2, 1024, sub=True, fp=fp, dual=True)), False, q)
+            good2, _ = emulate_sub(lambda: Dual(lambda fp: Gen(15, 2, 1024, sub=True, fused=False, fp=fp, dual=True)), False, q, pretop=True)
+            good = good and good2
+        ok = ok and good
+        print("%s N=2^16 sub-blocks dual q=%d (%d bits): %s; %s" % ("inverse" if inverse else "forward", q, q.bit_length(),
+                                                             "bit-exact vs oracle" if good else "MISMATCH", info), flush=True)
+    return ok
+
+
+if __name__ == "__main__":
+    logn = int(sys.argv[1])
+    inverse = len(sys.argv) > 2 and sys.argv[2] == "--selftest-inverse"
+    if logn == 16:
+        sys.exit(0 if selftest_sub(inverse=inverse) else 1)
+    threads = int(sys.argv[3]) if len(sys.argv) > 3 else 1024
+    sys.exit(0 if selftest(logn, inverse=inverse, threads=threads) else 1)

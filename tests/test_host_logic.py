@@ -54,3 +54,21 @@ def test_precompute_under_sanitizers(tmp_path):
                            "-I" + os.path.join(ROOT, "include"), src, os.path.join(csrc, "lr_precompute.cpp"), "-o", exe])
     out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and out.stdout.startswith("ok "), out.stdout + out.stderr
+
+
+def test_kernel_argument_block_size_is_one_number():
+    """The assembly code objects declare the size of their kernel-argument block (.amdhsa_kernarg_size and the metadata's
+    .kernarg_segment_size); the host passes sizeof(NttLaunch).  A launch whose block is smaller than the declared size makes
+    the runtime hand the GPU a short buffer: the kernel reads past it and the process dies with a GPU memory fault / abort
+    (reproduced in round 2 with tools/asm_ubench's runner, and the likely cause of round 1's abort while NttLaunch was being
+    grown for the dual kernels, DESIGN.md "Incidents").  Pin the three numbers to each other."""
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hpp = open(os.path.join(root, "lattigo-fhe-by-go_amd", "csrc", "lr_device.hpp")).read()
+    host = int(re.search(r"static_assert\(sizeof\(NttLaunch\) == (\d+)", hpp).group(1))
+    gen = open(os.path.join(root, "lattigo-fhe-by-go_amd", "csrc", "asmgen", "gen_ntt.py")).read()
+    declared = set(int(x) for x in re.findall(r"\.amdhsa_kernarg_size (\d+)", gen)) | set(int(x) for x in re.findall(r"\.kernarg_segment_size: (\d+)", gen))
+    assert declared == {host}, (declared, host)
+    runner = open(os.path.join(root, "tools", "asm_ubench", "run.cpp")).read()
+    assert "sizeof(args) == %d" % host in runner

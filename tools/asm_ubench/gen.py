@@ -71,6 +71,47 @@ class Probe(Gen):
                         e(*b[k])
                     n += 16
             return n
+        if var.startswith("xchg_"):
+            # 16 butterflies (one radix-2 stage over the 32 coefficients a thread holds) followed by one exchange of the 16
+            # V-side coefficients between lanes, the way a stage boundary of the LDS passes moves data:
+            #   xchg_none   no exchange (baseline)
+            #   xchg_lds    through the LDS: 16 ds_write_b64 + 16 ds_read_b64 (what the kernels do; no VALU slot used)
+            #   xchg_perm   two index bits (lane bits 5 and 4) by v_permlane32_swap / v_permlane16_swap: 2 x 16 VALU
+            #   xchg_dpp    one index bit inside a row by DPP moves: 3 v_mov_b32_dpp per 32-bit register pair = 48 VALU
+            # (north_star's "wavefront shuffles for the intra-warp stages": a transposition of k index bits costs
+            # 16 / 16 / 48 ... VALU instructions per bit on top of the butterflies; the LDS round trip costs none)
+            self.butterflies([(X[i], X[i + 16], tw, False) for i in range(16)])
+            n = 16 * 14
+            if var == "xchg_lds":
+                e("v_lshlrev_b32", self.A_[0], 3, self.TID)
+                e("v_add_u32", self.A_[1], 0x10000, self.A_[0])
+                for i in range(16):
+                    e("ds_write_b64", self.A_[i // 8], X[16 + i], offset=8192 * (i % 8))
+                e("s_waitcnt", "lgkmcnt(0)")
+                for i in range(16):
+                    j = (i + 1) % 16
+                    e("ds_read_b64", X[16 + i], self.A_[j // 8], offset=8192 * (j % 8))
+                e("s_waitcnt", "lgkmcnt(0)")
+            elif var == "xchg_perm":
+                for i in range(0, 16, 2):
+                    a, b = X[16 + i], X[16 + i + 1]
+                    e("v_permlane32_swap_b32", a.lo(), b.lo())
+                    e("v_permlane32_swap_b32", a.hi(), b.hi())
+                for i in range(0, 16, 2):
+                    a, b = X[16 + i], X[16 + (i + 2) % 16]
+                    e("v_permlane16_swap_b32", a.lo(), b.lo())
+                    e("v_permlane16_swap_b32", a.hi(), b.hi())
+                n += 32
+            elif var == "xchg_dpp":
+                T = self.ts[0].T0
+                for i in range(0, 16, 2):
+                    for half in ("lo", "hi"):
+                        a, b = getattr(X[16 + i], half)(), getattr(X[16 + i + 1], half)()
+                        e("v_mov_b32_dpp", T, b, dpp="quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")
+                        e("v_mov_b32_dpp", b, a, dpp="quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0x5")
+                        e("v_mov_b32_dpp", a, T, dpp="quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xa")
+                n += 48
+            return n
         if var == "bfly_nc_seq":      # no interleaving of two butterflies
             for i in range(16):
                 for op in self.ops_butterfly(self.ts[0], X[i], X[i + 16], tw, False):
@@ -252,7 +293,7 @@ class Probe(Gen):
         return self.p
 
 
-VARIANTS = ["bfly_nc", "fp64_bfly", "bfly_nc", "fp64_bfly"]
+VARIANTS = ["mad_add_mix", "mulhi_add_mix", "xchg_none", "xchg_lds", "xchg_perm", "xchg_dpp", "mulhi_vs", "mad_vs0", "mad_vsv", "lshl_add", "add_u32", "sub_co_pair", "cndmask_vcc", "fma_f64", "bfly_nc", "bfly_c"]
 _OLD2 = ["cfg_98_36", "cfg_32_36", "cfg_2_36", "cfg_32_68", "cfg_vcc_68", "cfg_98_92", "cfg_98_40", "cfg_34_64", "cfg_2_36_c", "cfg_98_36_c", "cfg_32_36_c"]
 _OLD = ["bfly_nc", "bfly_c", "bfly_nc_seq", "bfly_c_seq", "bfly_nc_2sgpr", "inv_c", "mad_sdst_vcc", "mad_sdst_alt", "subb_sgpr", "cmp_vcc", "cmp_sgpr",
             "cndmask_vcc2", "cndmask_e64_vcc", "mad_add_mix", "mulhi_add_mix", "xor_b32", "and_or", "add3", "lshl_add_u32", "mov", "mad_vsv", "mad_vvv", "mad_vs0", "mulhi_vs", "mulhi_vv", "mullo_vv",

@@ -15,14 +15,21 @@ int main(int argc, char **argv) {
     int clk_khz = 0; CK(hipDeviceGetAttribute(&clk_khz, hipDeviceAttributeClockRate, 0));
     int cus = 0; CK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0));
     printf("device clock %d kHz, %d CUs\n", clk_khz, cus);
+    fflush(stdout);
+    const std::string only = argc > 2 ? argv[2] : "";
     while (list >> name >> count) {
+        if (!only.empty() && only.find("," + name + ",") == std::string::npos) continue;
+        printf("running %s\n", name.c_str());
+        fflush(stdout);
         std::ifstream f(dir + "/" + name + ".hsaco", std::ios::binary);
         std::vector<char> img((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
         hipModule_t mod; hipFunction_t fn;
         CK(hipModuleLoadData(&mod, img.data()));
         CK(hipModuleGetFunction(&fn, mod, ("probe_" + name).c_str()));
-        struct { unsigned long long a, b; void *out; void *in; char pad[72]; } args = {0x0123456789ABCDEFull, 0x0FEDCBA987654321ull, out, big, {0}};
-        size_t size = 104;
+        // the code objects declare the 168-byte kernel-argument block of the NTT kernels (NttLaunch); pass exactly that size
+        struct { unsigned long long a, b; void *out; void *in; char pad[136]; } args = {0x0123456789ABCDEFull, 0x0FEDCBA987654321ull, out, big, {0}};
+        static_assert(sizeof(args) == 168, "kernarg block");
+        size_t size = sizeof(args);
         void *extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
         hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
         const int rounds = 4;
@@ -43,6 +50,7 @@ int main(int argc, char **argv) {
                 printf("%-14s %8.3f ms  %6.2f cycles/instr at %d MHz (nominal)\n", name.c_str(), ms, ms * 1e-3 * clk_khz * 1e3 / instr, clk_khz / 1000);
             }
         }
+        fflush(stdout);
         CK(hipModuleUnload(mod));
     }
     return 0;

@@ -1,6 +1,8 @@
 import sys, os
 import numpy as np
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", ".."))
+_ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..")
+sys.path.insert(0, _ROOT)
+sys.path.insert(0, os.path.join(_ROOT, "lattigo-fhe-by-go_amd", "csrc", "asmgen"))
 import __graft_entry__ as graft
 from isa import Machine, Program
 import gen_ntt as G
