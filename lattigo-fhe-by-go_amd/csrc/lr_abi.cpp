@@ -158,7 +158,7 @@ lr::Options lr::Options::from_env() {
     o.no_staging = std::getenv("LR_NO_STAGING") != nullptr;
     o.ext_narrow = std::getenv("LR_EXT_NARROW") != nullptr;
     o.asm14_1024 = std::getenv("LR_ASM_14_1024") != nullptr;
-    o.no_ingest = std::getenv("LR_NO_INGEST") != nullptr;
+    o.no_exttop = std::getenv("LR_NO_EXTTOP") != nullptr;
     o.timeline = std::getenv("LR_NTT_TIMELINE") != nullptr;
     if (const char *v = std::getenv("LR_NTT_MODE")) o.ntt_mode = std::atoi(v);
     if (const char *v = std::getenv("LR_ASM_VARIANT")) o.asm_variant = std::atoi(v);
@@ -850,20 +850,22 @@ bool ntt_epilogue_ok(const lr_context *c) {
 }
 
 int run_ntt_launch(lr_context *c, bool inverse, Rows in, Rows out, int mod0, int mod_step, int count, int batch, int hole,
-                   int group, const NttEpilogue *epi);
+                   int group, const NttEpilogue *epi, bool pretop);
 
 // The assembly kernels of the integer variants put the polynomial on grid.y (limit 65535): longer plain launches are cut into
 // chunks along the batch on the same kernel (no silent change of code path).  Grouped launches (key-switch digits) beyond
 // the limit are refused: 65536 ciphertexts in one key switch exceed the device memory by orders of magnitude.
+// pretop (N = 2^16, forward, assembly kernels): the producer of the input rows has already applied the stage over index bit 15
+// (ext_sum_kernel<.., true>); the launch goes straight to the plain sub-block kernels, which read their own half only.
 int run_ntt(lr_context *c, bool inverse, Rows in, Rows out, int mod0, int mod_step, int count, int batch, int hole = 0,
-            int group = 0, const NttEpilogue *epi = nullptr) {
+            int group = 0, const NttEpilogue *epi = nullptr, bool pretop = false) {
     if (count <= 0 || batch <= 0) return LR_OK;
     if (hole > 0 && (group <= 0 || batch % group != 0)) return fail(LR_ERR_ARG, "digit groups must divide the batch");
     // N = 2^16: the streaming top-stage kernel carries poly * limbs on grid.y
     const int kChunk = c->h.logN == 16 ? std::max(1, 65535 / count) : 65535;
     if (hole > 0) {
         if (group > kChunk || batch / group > 65535) return fail(LR_ERR_UNSUPPORTED, "grouped NTT launch: more than 65535 polys per digit group");
-        return run_ntt_launch(c, inverse, in, out, mod0, mod_step, count, batch, hole, group, epi);
+        return run_ntt_launch(c, inverse, in, out, mod0, mod_step, count, batch, hole, group, epi, pretop);
     }
     for (int b0 = 0; b0 < batch; b0 += kChunk) {
         const int nb = std::min(kChunk, batch - b0);
@@ -876,13 +878,13 @@ int run_ntt(lr_context *c, bool inverse, Rows in, Rows out, int mod0, int mod_st
             e2.x = epi->x + (long long)b0 * epi->x_stride;
             e2.plus = epi->plus + (long long)b0 * epi->plus_stride;
         }
-        LR_TRY(run_ntt_launch(c, inverse, ci, co, mod0, mod_step, count, nb, 0, 0, epi ? &e2 : nullptr));
+        LR_TRY(run_ntt_launch(c, inverse, ci, co, mod0, mod_step, count, nb, 0, 0, epi ? &e2 : nullptr, pretop));
     }
     return LR_OK;
 }
 
 int run_ntt_launch(lr_context *c, bool inverse, Rows in, Rows out, int mod0, int mod_step, int count, int batch, int hole,
-                   int group, const NttEpilogue *epi) {
+                   int group, const NttEpilogue *epi, bool pretop) {
     const unsigned logn = c->h.logN;
     if (logn < 1 || logn > 16)
         return fail(LR_ERR_UNSUPPORTED, "NTT kernels cover 2 <= N <= 2^16");
@@ -921,6 +923,10 @@ int run_ntt_launch(lr_context *c, bool inverse, Rows in, Rows out, int mod0, int
     if (logn == 16 && variant >= 0 && c->use_asm && ntt_asm_available(16)) {
         // two 2^15 sub-blocks per limb on the assembly kernels + the streaming stage over bit 15
         if (!inverse) {
+            if (pretop) {
+                LR_HIP(launch_ntt_asm16(a, 0, 'p', variant, c->stream, kn));
+                return LR_OK;
+            }
             if (ntt_rows_disjoint(a, 16)) {
                 LR_HIP(launch_ntt_asm16(a, 0, 's', variant, c->stream, kn));     // top stage fused into the loads
                 return LR_OK;
@@ -943,6 +949,7 @@ int run_ntt_launch(lr_context *c, bool inverse, Rows in, Rows out, int mod0, int
         LR_HIP(launch_ntt_top(top, 1, c->stream));
         return LR_OK;
     }
+    if (pretop) return fail(LR_ERR_ARG, "pre-applied top stage: only for forward N = 2^16 launches on the assembly kernels");
     if (epi) {
         if (inverse || hole > 0 || !ntt_epilogue_ok(c)) return fail(LR_ERR_ARG, "NTT epilogue: not available for this launch");
         a.epi_x = epi->x;
@@ -1243,6 +1250,8 @@ ExtSegment segment(u64 *out, long long stride, int limb0, int col0, int count) {
     s.limb0 = limb0;
     s.col0 = col0;
     s.count = count;
+    s.top_tw = nullptr;
+    s.top_mod0 = 0;
     return s;
 }
 
@@ -1593,8 +1602,17 @@ extern "C" int lr_decomposer_destroy(lr_decomposer *d) {
 namespace {
 
 // Decompose (split == false, outP ignored) / DecomposeAndSplit.  in: rows of p0 (coefficient domain).
+// does digit `crt` at `level` go through the extension kernel (false: the trivial-copy branch, :490-497 / :613-623)?
+bool digit_is_extended(const lr_decomposer *d, int level, int crt) {
+    const int alphai = d->xalpha[crt];
+    const int ed = crt * d->alpha + alphai;
+    return !((ed > level + 1 && (level + 1) % d->nP == 1) || alphai == 1);
+}
+
+// top: write the first forward stage over index bit logN - 1 instead of the plain extension (N = 2^16 key switch; split form only,
+// extended digits only -- the caller checks digit_is_extended and ext_top_supported)
 int decompose_core(lr_decomposer *d, int level, int crt, Rows in, int batch, u64 *outQ, long long outQ_stride, u64 *outP,
-                   long long outP_stride, bool split) {
+                   long long outP_stride, bool split, bool top = false) {
     lr_context *c = d->cQ;
     if (crt < 0 || crt >= d->beta) return fail(LR_ERR_SHAPE, "crtDecompLevel out of range");
     if (level < 0 || level + 1 > d->nQ) return fail(LR_ERR_SHAPE, "level out of range");
@@ -1603,6 +1621,7 @@ int decompose_core(lr_decomposer *d, int level, int crt, Rows in, int batch, u64
     if (st > level) return fail(LR_ERR_SHAPE, "digit lies above the level");
     const int n = (int)c->h.N;
     if ((ed > level + 1 && (level + 1) % d->nP == 1) || alphai == 1) {
+        if (top) return fail(LR_ERR_ARG, "top-stage extension requested for a digit that takes the copy branch");
         // no reconstruction needed: every target limb receives limb p0idxst, :490-497 / :613-623
         RowAddLaunch L;
         L.in = in.base + (long long)(in.limb0 + st) * n;
@@ -1631,6 +1650,11 @@ int decompose_core(lr_decomposer *d, int level, int crt, Rows in, int batch, u64
     // the special primes take columns nQ.., written to the P poly or to rows level+1.. of p1.
     ExtSegment sq = segment(outQ, outQ_stride, 0, 0, level + 1);
     ExtSegment sp = split ? segment(outP, outP_stride, 0, d->nQ, d->nP) : segment(outQ, outQ_stride, level + 1, d->nQ, d->nP);
+    if (top) {
+        if (!split) return fail(LR_ERR_ARG, "top-stage extension: split form only");
+        sq.top_tw = d->cQ->d_fwd;      // rows 0..level of the Q part are the context's limbs 0..level
+        sp.top_tw = d->cP->d_fwd;
+    }
     return run_ext(c, m, index + 2, digit, batch, sq, sp);
 }
 
@@ -1962,7 +1986,21 @@ int ks_decompose(lr_ckks_plan *pl, int level, int batch, const u64 *cx, long lon
     // N = 2^16: a forward transform whose input and output rows are disjoint computes its top stage while loading (one
     // launch); in place it needs a separate streaming pass first.  The extensions therefore land in staging buffers of the
     // same shape and the transforms write the pools the consumers read.
-    const bool staged = cQ->h.logN == 16 && cQ->use_asm && cQ->asm_fwd >= 0 && !pl->opt.no_staging;
+    const bool asm16 = cQ->h.logN == 16 && cQ->use_asm && cQ->asm_fwd >= 0 && cP->use_asm && cP->asm_fwd >= 0;
+    // ... or, better, the extension itself applies the stage over index bit 15 (each of its threads holds the coefficients j and
+    // j + N/2) and the plain sub-block kernels transform in place, reading their own half only.  Possible when every digit of
+    // this level goes through the sum-form extension kernel (no trivial-copy digit).
+    bool exttop = asm16 && !pl->opt.no_exttop;
+    for (int i = 0; i < beta && exttop; ++i) {
+        if (!digit_is_extended(dec, level, i)) {
+            exttop = false;
+            break;
+        }
+        const int alphai = dec->xalpha[i];
+        const int index = level >= alphai + i * dec->alpha ? alphai - 2 : (level - 1) % dec->alpha;
+        exttop = ext_top_supported(dec->modup[i][index]->tables(), index + 2, n);
+    }
+    const bool staged = asm16 && !exttop && !pl->opt.no_staging;
     if (staged) {
         LR_TRY(pl->stageQ.ensure(cQ, (size_t)beta * dQ));
         LR_TRY(pl->stageP.ensure(cQ, (size_t)beta * dP));
@@ -1975,7 +2013,7 @@ int ks_decompose(lr_ckks_plan *pl, int level, int batch, const u64 *cx, long lon
     for (int i = 0; i < beta; ++i) {
         u64 *dq = pl->c2QiQ.d + (long long)i * dQ;
         // decomposeAndSplitNTT, :1561-1591
-        LR_TRY(decompose_core(dec, level, i, c2r, batch, srcQ + (long long)i * dQ, sQ, srcP + (long long)i * dP, sP, true));
+        LR_TRY(decompose_core(dec, level, i, c2r, batch, srcQ + (long long)i * dQ, sQ, srcP + (long long)i * dP, sP, true, exttop));
         const int d0 = i * alpha;
         int d1 = d0 + dec->xalpha[i];
         if (d1 > level + 1) d1 = level + 1;
@@ -1987,7 +2025,7 @@ int ks_decompose(lr_ckks_plan *pl, int level, int batch, const u64 *cx, long lon
     if (full > 0 && level + 1 - alpha > 0) {
         // limbs outside each digit's own block, all full digits at once (grid z = digit)
         Rows in{srcQ, sQ, 0, 1}, all{pl->c2QiQ.d, sQ, 0, 1};
-        LR_TRY(run_ntt(cQ, false, in, all, 0, 1, level + 1 - alpha, full * batch, alpha, batch));
+        LR_TRY(run_ntt(cQ, false, in, all, 0, 1, level + 1 - alpha, full * batch, alpha, batch, nullptr, exttop));
     }
     for (int i = full; i < beta; ++i) {
         u64 *dq = pl->c2QiQ.d + (long long)i * dQ, *sq = srcQ + (long long)i * dQ;
@@ -1995,13 +2033,13 @@ int ks_decompose(lr_ckks_plan *pl, int level, int batch, const u64 *cx, long lon
         int d1 = d0 + dec->xalpha[i];
         if (d1 > level + 1) d1 = level + 1;
         Rows lo{dq, sQ, 0, 1}, lo_in{sq, sQ, 0, 1};
-        LR_TRY(run_ntt(cQ, false, lo_in, lo, 0, 1, d0, batch));                  // limbs below the digit
+        LR_TRY(run_ntt(cQ, false, lo_in, lo, 0, 1, d0, batch, 0, 0, nullptr, exttop));                  // limbs below the digit
         Rows hi{dq, sQ, d1, 1}, hi_in{sq, sQ, d1, 1};
-        LR_TRY(run_ntt(cQ, false, hi_in, hi, d1, 1, level + 1 - d1, batch));     // limbs above the digit
+        LR_TRY(run_ntt(cQ, false, hi_in, hi, d1, 1, level + 1 - d1, batch, 0, 0, nullptr, exttop));     // limbs above the digit
     }
     {
         Rows pr{pl->c2QiP.d, sP, 0, 1}, pr_in{srcP, sP, 0, 1};                   // :1590, every digit's P rows
-        LR_TRY(run_ntt(cP, false, pr_in, pr, 0, 1, nP, beta * batch));
+        LR_TRY(run_ntt(cP, false, pr_in, pr, 0, 1, nP, beta * batch, 0, 0, nullptr, exttop));
     }
     return LR_OK;
 }
@@ -2061,11 +2099,15 @@ int ks_accumulate(lr_ckks_plan *pl, int level, int batch, const u64 *digQ, const
         LR_TRY(run_ntt(cP, true, pr, pr, 0, 1, nP, 2 * batch));
         LR_TRY(bx->poolQ.ensure(cQ, (size_t)2 * batch * sQ));
         u64 *ext_out = bx->poolQ.d;
-        if (cQ->h.logN == 16 && cQ->use_asm && cQ->asm_fwd >= 0 && !pl->opt.no_staging) {
+        const bool asm16 = cQ->h.logN == 16 && cQ->use_asm && cQ->asm_fwd >= 0;
+        const bool exttop = asm16 && !pl->opt.no_exttop && ext_top_supported(bx->pq.tables(), nP, n);
+        if (asm16 && !exttop && !pl->opt.no_staging) {
             LR_TRY(pl->stageQ.ensure(cQ, (size_t)2 * batch * sQ));     // (the digits' staging area is free again)
             ext_out = pl->stageQ.d;
         }
-        LR_TRY(run_ext(cQ, bx->pq, nP, pr, 2 * batch, segment(ext_out, sQ, 0, 0, level + 1), segment(nullptr, 0, 0, 0, 0)));
+        ExtSegment mseg = segment(ext_out, sQ, 0, 0, level + 1);
+        if (exttop) mseg.top_tw = cQ->d_fwd;                           // the ModDown transform's top stage inside the extension
+        LR_TRY(run_ext(cQ, bx->pq, nP, pr, 2 * batch, mseg, segment(nullptr, 0, 0, 0, 0)));
         Rows qr{bx->poolQ.d, sQ, 0, 1}, qr_in{ext_out, sQ, 0, 1};
         if (ntt_epilogue_ok(cQ)) {
             // the subtract-multiply and the addition of MulRelin / the rotations inside the forward transform's copy-out, for
@@ -2111,7 +2153,7 @@ int ks_accumulate(lr_ckks_plan *pl, int level, int batch, const u64 *digQ, const
             }
             return LR_OK;
         }
-        LR_TRY(run_ntt(cQ, false, qr_in, qr, 0, 1, level + 1, 2 * batch));
+        LR_TRY(run_ntt(cQ, false, qr_in, qr, 0, 1, level + 1, 2 * batch, 0, 0, nullptr, exttop));
     }
     for (int k = 0; k < 2; ++k) {
         u64 *pq = k == 0 ? p0 : p1;

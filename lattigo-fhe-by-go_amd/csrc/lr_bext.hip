@@ -167,38 +167,49 @@ __device__ __forceinline__ u64 bred_word(u64 x, u64 p, u64 p2, u32 u) {
     return csub_borrow(csub_borrow(r, p2), p);
 }
 
-template <int NIN, int W>
+// TOP (N = 2^16 key switch): a thread takes the coefficient pairs at j and at j + N/2 and writes, instead of the extension x of the
+// two halves, the first forward stage over them -- X = x[j] + psi[1] * x[j + N/2], Y = x[j] - psi[1] * x[j + N/2] (lazy, below 3p),
+// psi[1] from the target limb's forward table -- so that the 2^15 sub-block transforms that follow read their own half only
+// (the "p" kernels) instead of both halves (the fused "s" kernels, 1.5 x the traffic).  The transform is the canonical one either
+// way: its first stage has merely moved into the kernel that produces its input.
+template <int NIN, int W, bool TOP>
 __global__ __launch_bounds__(256) void ext_sum_kernel(ExtLaunch L) {
+    constexpr int C = TOP ? 2 * W : W;                         // coefficient columns per thread
     const int xw = blockIdx.x * 256 + threadIdx.x;
-    if (W * xw >= L.n) return;
+    const int span = TOP ? L.n >> 1 : L.n;
+    if (W * xw >= span) return;
     const long long b = blockIdx.y;
     const u64 *in = L.in + b * L.in_stride + (long long)L.in_limb0 * L.n + W * xw;
-    u32 y0[W][NIN], y1[W][NIN];
-    double vf[W];
+    u32 y0[C][NIN], y1[C][NIN];
+    double vf[C];
 #pragma unroll
-    for (int w = 0; w < W; ++w) vf[w] = 0.0;
+    for (int w = 0; w < C; ++w) vf[w] = 0.0;
 #pragma unroll
     for (int i = 0; i < NIN; ++i) {
         const u64 qi = L.t.Q[i];
-        u64 v[W];
-        if (W == 2) {
-            const ulonglong2 t = ld_stream(reinterpret_cast<const ulonglong2 *>(in + (long long)i * L.n));
-            v[0] = t.x;
-            v[W - 1] = t.y;
-        } else {
-            v[0] = ld_stream(in + (long long)i * L.n);
+        u64 v[C];
+#pragma unroll
+        for (int h = 0; h < C / W; ++h) {
+            const u64 *src = in + (long long)i * L.n + (long long)h * span;
+            if (W == 2) {
+                const ulonglong2 t = ld_stream(reinterpret_cast<const ulonglong2 *>(src));
+                v[h * W] = t.x;
+                v[h * W + W - 1] = t.y;
+            } else {
+                v[h * W] = ld_stream(src);
+            }
         }
 #pragma unroll
-        for (int w = 0; w < W; ++w) {
+        for (int w = 0; w < C; ++w) {
             const u64 y = mred(v[w], L.t.qib_mont[i], qi, L.t.mredQ[i]);
             vf[w] += (double)y / (double)qi;
             y0[w][i] = (u32)y;
             y1[w][i] = (u32)(y >> 32);
         }
     }
-    u32 vi[W];
+    u32 vi[C];
 #pragma unroll
-    for (int w = 0; w < W; ++w) vi[w] = (u32)(u64)vf[w];
+    for (int w = 0; w < C; ++w) vi[w] = (u32)(u64)vf[w];
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
         const ExtSegment sg = L.seg[s];
@@ -207,15 +218,15 @@ __global__ __launch_bounds__(256) void ext_sum_kernel(ExtLaunch L) {
             const int col = sg.col0 + jj;
             const u64 pj = ld_const(L.t.P + col), bh = ld_const(L.t.bredP_hi + col);
             const u64 nq = ld_const(L.t.qpj_inv + (long long)col * (L.t.nQ + 1) + 1);
-            u64 lo[W], hi[W], qs[W], xs[W];
+            u64 lo[C], hi[C], qs[C], xs[C];
 #pragma unroll
-            for (int w = 0; w < W; ++w) lo[w] = hi[w] = qs[w] = xs[w] = 0;
+            for (int w = 0; w < C; ++w) lo[w] = hi[w] = qs[w] = xs[w] = 0;
 #pragma unroll
             for (int i = 0; i < NIN; ++i) {
                 const ulonglong2 c = ld_const(L.t.qispj_shoup + (long long)i * L.t.nP + col);
                 const u32 w0 = (u32)c.x, w1 = (u32)(c.x >> 32), s0 = (u32)c.y, s1 = (u32)(c.y >> 32);
 #pragma unroll
-                for (int w = 0; w < W; ++w) {
+                for (int w = 0; w < C; ++w) {
                     lo[w] = mad_word(w0, y0[w][i], lo[w]);
                     hi[w] = mad_word(w1, y0[w][i], hi[w]);
                     hi[w] = mad_word(w0, y1[w][i], hi[w]);
@@ -231,9 +242,9 @@ __global__ __launch_bounds__(256) void ext_sum_kernel(ExtLaunch L) {
             }
             const u64 np = 0 - pj;
             const u32 n0 = (u32)np, n1 = (u32)(np >> 32), c0 = (u32)nq, c1 = (u32)(nq >> 32);
-            u64 r[W];
+            u64 r[C];
 #pragma unroll
-            for (int w = 0; w < W; ++w) {
+            for (int w = 0; w < C; ++w) {
                 const u32 h0 = (u32)qs[w], h1 = (u32)(qs[w] >> 32);
                 lo[w] = mad_word(n0, h0, lo[w]);
                 hi[w] = mad_word(n1, h0, hi[w]);
@@ -242,8 +253,22 @@ __global__ __launch_bounds__(256) void ext_sum_kernel(ExtLaunch L) {
                 hi[w] = mad_word(c1, vi[w], hi[w]);
                 r[w] = bred_word(lo[w] + (hi[w] << 32), pj, pj << 1, (u32)bh);
             }
-            if (W == 2) st_stream(reinterpret_cast<ulonglong2 *>(out + (long long)jj * L.n), make_ulonglong2(r[0], r[W - 1]));
-            else st_stream(out + (long long)jj * L.n, r[0]);
+            if constexpr (TOP) {
+                // twiddle of the stage over index bit logN - 1: heap entry 1 of the target limb's forward table {w, floor(w 2^64 / p)}
+                const ulonglong2 tw = ld_const(reinterpret_cast<const ulonglong2 *>(sg.top_tw) + ((long long)(sg.top_mod0 + jj) * L.n + 1));
+#pragma unroll
+                for (int w = 0; w < W; ++w) {
+                    const u64 t = mul_shoup_exact(r[W + w], tw.x, tw.y, pj);       // in [0, 2p)
+                    r[W + w] = r[w] + (pj << 1) - t;                                  // Y in (0, 3p)
+                    r[w] = r[w] + t;                                                  // X in [0, 3p)
+                }
+            }
+#pragma unroll
+            for (int h = 0; h < C / W; ++h) {
+                u64 *dst = out + (long long)jj * L.n + (long long)h * span;
+                if (W == 2) st_stream(reinterpret_cast<ulonglong2 *>(dst), make_ulonglong2(r[h * W], r[h * W + W - 1]));
+                else st_stream(dst, r[h * W]);
+            }
         }
     }
 }
@@ -348,7 +373,20 @@ static hipError_t launch_n(const ExtLaunch &L, int batch, hipStream_t stream) {
         // two coefficients per thread while their y_i fit comfortably in registers
         constexpr int W = NIN <= 20 ? 2 : 1;
         const dim3 grid((unsigned)((L.n / W + 255) / 256), (unsigned)batch), block(256);
-        if (L.t.lazy_terms >= (NIN < 2 ? 2 : NIN) && L.t.word_barrett) hipLaunchKernelGGL((ext_sum_kernel<NIN, W>), grid, block, 0, stream, L);
+        if (L.seg[0].top_tw != nullptr) {
+            // top-stage variant (ext_top_supported() has vetted the tables): half the threads, four columns each
+            if constexpr (NIN <= 8) {
+                // one column per half and thread beyond three input limbs: with two, four digits' worth of y_i push the kernel to
+                // 85 VGPRs (5 waves per SIMD instead of 8)
+                constexpr int WT = NIN <= 3 ? 2 : 1;
+                const dim3 gtop((unsigned)((L.n / 2 / WT + 255) / 256), (unsigned)batch);
+                hipLaunchKernelGGL((ext_sum_kernel<NIN, WT, true>), gtop, block, 0, stream, L);
+                return hipGetLastError();
+            } else {
+                return hipErrorInvalidValue;
+            }
+        }
+        if (L.t.lazy_terms >= (NIN < 2 ? 2 : NIN) && L.t.word_barrett) hipLaunchKernelGGL((ext_sum_kernel<NIN, W, false>), grid, block, 0, stream, L);
         else if (L.t.lazy_terms >= NIN) hipLaunchKernelGGL((ext_shoup_kernel<NIN, 0, W>), grid, block, 0, stream, L);
         else if (L.t.wide_ok >= NIN) hipLaunchKernelGGL((ext_wide_kernel<NIN, W, NIN>), grid, block, 0, stream, L);
         else if (L.t.wide_ok >= 16 && NIN > 16) hipLaunchKernelGGL((ext_wide_kernel<NIN, W, (NIN > 16 ? 16 : NIN)>), grid, block, 0, stream, L);
@@ -360,6 +398,11 @@ static hipError_t launch_n(const ExtLaunch &L, int batch, hipStream_t stream) {
     const dim3 grid((unsigned)((L.n + 255) / 256), (unsigned)batch), block(256);
     hipLaunchKernelGGL(ext_kernel<NIN>, grid, block, 0, stream, L);
     return hipGetLastError();
+}
+
+// the top-stage variant exists for the sum-form kernel with at most eight input limbs (the key-switch digits have alpha <= 8)
+bool ext_top_supported(const ExtTables &t, int n_in, int n) {
+    return (n & 3) == 0 && n_in >= 1 && n_in <= 8 && t.exact_terms >= 4 && t.word_barrett && t.lazy_terms >= (n_in < 2 ? 2 : n_in);
 }
 
 hipError_t launch_ext(const ExtLaunch &L, int n_in, int batch, hipStream_t stream) {

@@ -36,7 +36,7 @@ struct Options {
     bool ext_narrow = false;       // LR_EXT_NARROW: per-term basis extension instead of the 128-bit column sums
     bool asm14_1024 = false;       // LR_ASM_14_1024: the 1024-thread plan at N = 2^14
     bool timeline = false;         // LR_NTT_TIMELINE: forward 2^15 launches of the integer kernel run the stamped diagnostics build
-    bool no_ingest = false;        // LR_NO_INGEST: key-switch digits through the extension kernel + staging instead of the fused ingest
+    bool no_exttop = false;        // LR_NO_EXTTOP: N = 2^16 key switch with staged extensions and fused-top transforms instead of the top stage inside the extension
     int ntt_mode = -1;             // LR_NTT_MODE
     int asm_variant = -1;          // LR_ASM_VARIANT
     static Options from_env();
@@ -230,6 +230,10 @@ struct ExtSegment {       // rows [limb0, limb0+count) of `out` receive table co
     u64 *out;
     long long stride;     // u64 elements between batch polys
     int limb0, col0, count;
+    // top-stage variant (N = 2^16 key switch, ext_sum_kernel<.., true>): forward twiddle table of the context that owns the segment's
+    // output moduli ([L][N] entries {w, floor(w 2^64 / q)}) and the modulus index of the segment's first row; nullptr = plain extension
+    const Twiddle *top_tw;
+    int top_mod0;
 };
 
 struct ExtLaunch {
@@ -285,5 +289,6 @@ hipError_t launch_ewise(int op, const EwiseLaunch &L, int limbs, int batch, hipS
 hipError_t launch_submul(const SubMulLaunch &L, int limbs, int batch, hipStream_t stream);
 hipError_t launch_rowadd(const RowAddLaunch &L, int rows, int batch, hipStream_t stream);
 hipError_t launch_ext(const ExtLaunch &L, int n_in, int batch, hipStream_t stream);
+bool ext_top_supported(const ExtTables &t, int n_in, int n);
 
 }  // namespace lr

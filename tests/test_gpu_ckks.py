@@ -96,7 +96,7 @@ def _galois(gpu_pkg, N, k):
     return pow(5, k, 2 * N)
 
 
-@pytest.mark.parametrize("logn,nq,np_,level,k", [(10, 6, 2, 5, 1), (11, 7, 3, 6, 5), (10, 6, 2, 3, 17), (14, 6, 2, 5, 3), (12, 18, 3, 17, 2)])
+@pytest.mark.parametrize("logn,nq,np_,level,k", [(10, 6, 2, 5, 1), (11, 7, 3, 6, 5), (10, 6, 2, 3, 17), (14, 6, 2, 5, 3), (12, 18, 3, 17, 2), (16, 6, 2, 5, 7)])
 def test_rotate_columns(gpu_pkg, oracle, logn, nq, np_, level, k):
     """evaluator.permuteNTT (ckks/evaluator.go:1448) = RotateColumns with the key of that rotation: both components
     permuted, the second key-switched, against the oracle's restatement; also in place and the conjugation element"""
@@ -117,7 +117,8 @@ def test_rotate_columns(gpu_pkg, oracle, logn, nq, np_, level, k):
         assert np.array_equal(ct[0].get(), got[0]) and np.array_equal(ct[1].get(), got[1])
 
 
-@pytest.mark.parametrize("logn,nq,np_,level", [(10, 6, 2, 5), (11, 7, 3, 6), (10, 6, 2, 2), (14, 6, 2, 4)])
+# (16, 6, 2, 5): N = 2^16 with the top stage inside the extension kernel and the own limbs copied into the digits
+@pytest.mark.parametrize("logn,nq,np_,level", [(10, 6, 2, 5), (11, 7, 3, 6), (10, 6, 2, 2), (14, 6, 2, 4), (16, 6, 2, 5), (16, 5, 2, 4)])
 def test_rotate_hoisted(gpu_pkg, oracle, logn, nq, np_, level):
     """RotateHoisted (ckks/evaluator.go:1252): several rotations share one digit decomposition; every output equals
     the oracle's restatement of switchKeyHoisted.  (Hoisted and plain rotations are not bit-identical: permuting the
@@ -166,10 +167,19 @@ def test_rotate_columns_pow2_chain(gpu_pkg, oracle):
         assert np.array_equal(out[0].get()[b], want[0]) and np.array_equal(out[1].get()[b], want[1])
 
 
-def test_mulrelin_2p16_without_staging(gpu_pkg, oracle, monkeypatch):
-    """N = 2^16 with in-place forward transforms (separate top-stage pass) instead of the staged, fused ones"""
-    monkeypatch.setenv("LR_NO_STAGING", "1")
-    test_mulrelin_and_rescale(gpu_pkg, oracle, 16, 5, 2, 4)
+@pytest.mark.parametrize("nq,np_,level", [(5, 2, 4), (6, 2, 5), (7, 3, 5), (10, 4, 9)])
+def test_mulrelin_2p16_paths(gpu_pkg, oracle, nq, np_, level, monkeypatch):
+    """N = 2^16, the three ways the key switch feeds its forward transforms: the top stage applied by the extension kernel + plain
+    sub-block kernels in place (default where every digit is extended: (6,2,5), (7,3,5), (10,4,9); (5,2,4) ends in a one-limb
+    digit and falls back), staged extensions + fused-top kernels (LR_NO_EXTTOP), in-place transforms behind the separate top-stage
+    pass (LR_NO_EXTTOP + LR_NO_STAGING)"""
+    for env in ({}, {"LR_NO_EXTTOP": "1"}, {"LR_NO_EXTTOP": "1", "LR_NO_STAGING": "1"}):
+        for k in ("LR_NO_EXTTOP", "LR_NO_STAGING"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        test_mulrelin_and_rescale(gpu_pkg, oracle, 16, nq, np_, level)
+        test_switch_keys(gpu_pkg, oracle, 16, nq, np_, level)
 
 
 @pytest.mark.parametrize("logn,nq,np_,level", [(12, 18, 3, 17), (15, 5, 2, 4)])
