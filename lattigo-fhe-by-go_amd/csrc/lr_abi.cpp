@@ -1229,7 +1229,10 @@ extern "C" int lr_permute_ntt_index(uint64_t gen, uint64_t power, uint64_t N, ui
 // ------------------------------------------------------------------------------------------
 namespace {
 
-int run_ext(lr_context *c, const DevModup &m, int n_in, Rows in, int batch, ExtSegment s0, ExtSegment s1) {
+ExtSegment segment(u64 *out, long long stride, int limb0, int col0, int count);
+
+int run_ext(lr_context *c, const DevModup &m, int n_in, Rows in, int batch, ExtSegment s0, ExtSegment s1,
+            const ExtSegment *s2 = nullptr) {
     if (n_in < 1 || n_in > 40 || n_in > (int)m.h.Q.size()) return fail(LR_ERR_UNSUPPORTED, "basis extension from 1..40 limbs");
     ExtLaunch L;
     L.t = m.tables();
@@ -1239,6 +1242,7 @@ int run_ext(lr_context *c, const DevModup &m, int n_in, Rows in, int batch, ExtS
     L.n = (int)c->h.N;
     L.seg[0] = s0;
     L.seg[1] = s1;
+    L.seg[2] = s2 ? *s2 : segment(nullptr, 0, 0, 0, 0);
     LR_HIP(launch_ext(L, n_in, batch, c->stream));
     return LR_OK;
 }
@@ -1611,8 +1615,9 @@ bool digit_is_extended(const lr_decomposer *d, int level, int crt) {
 
 // top: write the first forward stage over index bit logN - 1 instead of the plain extension (N = 2^16 key switch; split form only,
 // extended digits only -- the caller checks digit_is_extended and ext_top_supported)
+// skip_own: do not write the rows the digit owns (the key switch reads them from the NTT-domain input, or copies them in)
 int decompose_core(lr_decomposer *d, int level, int crt, Rows in, int batch, u64 *outQ, long long outQ_stride, u64 *outP,
-                   long long outP_stride, bool split, bool top = false) {
+                   long long outP_stride, bool split, bool top = false, bool skip_own = false) {
     lr_context *c = d->cQ;
     if (crt < 0 || crt >= d->beta) return fail(LR_ERR_SHAPE, "crtDecompLevel out of range");
     if (level < 0 || level + 1 > d->nQ) return fail(LR_ERR_SHAPE, "level out of range");
@@ -1654,6 +1659,15 @@ int decompose_core(lr_decomposer *d, int level, int crt, Rows in, int batch, u64
         if (!split) return fail(LR_ERR_ARG, "top-stage extension: split form only");
         sq.top_tw = d->cQ->d_fwd;      // rows 0..level of the Q part are the context's limbs 0..level
         sp.top_tw = d->cP->d_fwd;
+    }
+    if (skip_own && split) {
+        // rows [st, own_end) are the digit's own: two Q segments around them
+        const int own_end = ed > level + 1 ? level + 1 : ed;
+        ExtSegment lo = segment(outQ, outQ_stride, 0, 0, st);
+        ExtSegment hi = segment(outQ, outQ_stride, own_end, own_end, level + 1 - own_end);
+        lo.top_tw = hi.top_tw = sq.top_tw;
+        hi.top_mod0 = own_end;
+        return run_ext(c, m, index + 2, digit, batch, lo, hi, &sp);
     }
     return run_ext(c, m, index + 2, digit, batch, sq, sp);
 }
@@ -2013,7 +2027,7 @@ int ks_decompose(lr_ckks_plan *pl, int level, int batch, const u64 *cx, long lon
     for (int i = 0; i < beta; ++i) {
         u64 *dq = pl->c2QiQ.d + (long long)i * dQ;
         // decomposeAndSplitNTT, :1561-1591
-        LR_TRY(decompose_core(dec, level, i, c2r, batch, srcQ + (long long)i * dQ, sQ, srcP + (long long)i * dP, sP, true, exttop));
+        LR_TRY(decompose_core(dec, level, i, c2r, batch, srcQ + (long long)i * dQ, sQ, srcP + (long long)i * dP, sP, true, exttop, true));
         const int d0 = i * alpha;
         int d1 = d0 + dec->xalpha[i];
         if (d1 > level + 1) d1 = level + 1;

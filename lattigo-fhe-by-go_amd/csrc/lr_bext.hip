@@ -31,7 +31,7 @@ __global__ __launch_bounds__(256) void ext_kernel(ExtLaunch L) {
     }
     const u64 v = (u64)vi;
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
+    for (int s = 0; s < kExtSegments; ++s) {
         const ExtSegment sg = L.seg[s];
         u64 *out = sg.out + b * sg.stride + (long long)sg.limb0 * L.n + x;
         for (int jj = 0; jj < sg.count; ++jj) {
@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256) void ext_shoup_kernel(ExtLaunch L) {
 #pragma unroll
     for (int w = 0; w < W; ++w) vi[w] = (u64)vf[w];
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
+    for (int s = 0; s < kExtSegments; ++s) {
         const ExtSegment sg = L.seg[s];
         u64 *out = sg.out + b * sg.stride + (long long)sg.limb0 * L.n + W * xw;
         for (int jj = 0; jj < sg.count; ++jj) {
@@ -211,7 +211,7 @@ __global__ __launch_bounds__(256) void ext_sum_kernel(ExtLaunch L) {
 #pragma unroll
     for (int w = 0; w < C; ++w) vi[w] = (u32)(u64)vf[w];
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
+    for (int s = 0; s < kExtSegments; ++s) {
         const ExtSegment sg = L.seg[s];
         u64 *out = sg.out + b * sg.stride + (long long)sg.limb0 * L.n + W * xw;
         for (int jj = 0; jj < sg.count; ++jj) {
@@ -319,7 +319,7 @@ __global__ __launch_bounds__(256) void ext_wide_kernel(ExtLaunch L) {
 #pragma unroll
     for (int w = 0; w < W; ++w) vi[w] = (u32)(u64)vf[w];
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
+    for (int s = 0; s < kExtSegments; ++s) {
         const ExtSegment sg = L.seg[s];
         u64 *out = sg.out + b * sg.stride + (long long)sg.limb0 * L.n + W * xw;
         for (int jj = 0; jj < sg.count; ++jj) {

@@ -226,6 +226,8 @@ struct ExtTables {        // device pointers; modupParams of ring_basis_extensio
     int wide_ok;          // how many input terms keep n * max q_i below 2^64 (ext_wide_kernel: one Montgomery reduction per group)
 };
 
+constexpr int kExtSegments = 3;   // key-switch digits: rows below the digit, rows above it, the special primes
+
 struct ExtSegment {       // rows [limb0, limb0+count) of `out` receive table columns [col0, col0+count)
     u64 *out;
     long long stride;     // u64 elements between batch polys
@@ -242,7 +244,7 @@ struct ExtLaunch {
     long long in_stride;
     int in_limb0;
     int n;
-    ExtSegment seg[2];
+    ExtSegment seg[kExtSegments];   // unused segments have count == 0
 };
 
 #if defined(__HIPCC__)
