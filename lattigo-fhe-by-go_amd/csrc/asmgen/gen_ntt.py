@@ -352,10 +352,40 @@ class Gen:
         return stage >= 2 and stage % 2 == 0
 
     # ------------------------------------------------------------------ kernel sections
+    def stagger(self):
+        """De-synchronise the CUs (NttLaunch::stagger_unit > 0).  All workgroups of a launch start together, one per CU, so every
+        CU is in its load phase at the same time (HBM saturated: the phase takes 22 k clocks where the first wave's data is back
+        after 6 k), then all compute (HBM idle), then all store.  The workgroups of the first round -- linear id below 256 -- wait
+        ((7 * id) mod 16) * stagger_unit kilo-clocks before they start; every CU keeps that phase offset for the rest of the launch
+        because its next workgroup starts when this one ends.  Raw hardware ids: x = s2, y = s3, z = s4 (before the prologue
+        rewrites them); stagger_gx = the grid's x extent."""
+        e, sc = self.e, self.SC
+        e("s_load_dwordx2", self.TMP, self.KARG, 168)          # stagger_gx, stagger_unit
+        e("s_waitcnt", "lgkmcnt(0)")
+        e("s_cmp_eq_u32", self.TMP.hi(), 0)
+        e("s_cbranch_scc1", "L_go")
+        e("s_cmp_lg_u32", s(4), 0)
+        e("s_cbranch_scc1", "L_go")
+        e("s_mul_i32", sc[0], s(3), self.TMP.lo())
+        e("s_add_u32", sc[0], sc[0], s(2))
+        e("s_cmp_ge_u32", sc[0], 256)
+        e("s_cbranch_scc1", "L_go")
+        e("s_mul_i32", sc[0], sc[0], 7)
+        e("s_and_b32", sc[0], sc[0], 15)
+        e("s_mul_i32", sc[0], sc[0], self.TMP.hi())
+        e("s_cmp_eq_u32", sc[0], 0)
+        e("s_cbranch_scc1", "L_go")
+        self.p.label("L_wait")
+        e("s_sleep", 16)                                        # ~1024 clocks
+        e("s_sub_u32", sc[0], sc[0], 1)
+        e("s_cmp_lg_u32", sc[0], 0)
+        e("s_cbranch_scc1", "L_wait")
+        self.p.label("L_go")
+
     def prologue(self):
         e, S_ = self.e, self
         logn, N = self.logn, self.N
-        self.c("kernel arguments (NttLaunch, 168 bytes)")
+        self.c("kernel arguments (NttLaunch, 176 bytes)")
         e("s_load_dwordx8", s(36, 8), self.KARG, 0)
         e("s_load_dwordx8", s(44, 8), self.KARG, 32)
         e("s_load_dwordx4", s(52, 4), self.KARG, 64)
@@ -375,6 +405,7 @@ class Gen:
         e("s_lshr_b32", self.WAVE, self.WAVE, 6)
         e("s_waitcnt", "lgkmcnt(0)")
         sc = self.SC
+        self.stagger()
         if self.sub:
             e("s_and_b32", self.BLK1, self.WGX, 1)
             e("s_add_u32", self.BLK1, self.BLK1, 1)      # 1 + blk: heap root 2 + blk = 1 + BLK1
@@ -1017,7 +1048,7 @@ class Dual:
         pf, pi = self.gf.build(), self.gi.build()
         mf, mi = self.gf.mark, self.gi.mark
         assert mf is not None and mf == mi and repr(pf.ins[:mf]) == repr(pi.ins[:mi]), "the two bodies must share their prologue"
-        assert not any(op == "@" for op, _, _ in pf.ins + pi.ins)
+        assert not any(op == "@" for op, _, _ in pf.ins[mf:] + pi.ins[mi:])       # labels only in the shared prologue (stagger)
         p = Program()
         p.ins = list(pf.ins)
         p.label("INT_BODY")
@@ -1047,7 +1078,7 @@ def kernel_text_for(g, name):
   .amdhsa_kernel {name}
     .amdhsa_group_segment_fixed_size {lds}
     .amdhsa_private_segment_fixed_size 0
-    .amdhsa_kernarg_size 168
+    .amdhsa_kernarg_size 176
     .amdhsa_user_sgpr_count 2
     .amdhsa_user_sgpr_kernarg_segment_ptr 1
     .amdhsa_system_sgpr_workgroup_id_x 1
@@ -1070,11 +1101,11 @@ def kernel_text_for(g, name):
 amdhsa.kernels:
   - .args:
       - .offset: 0
-        .size: 168
+        .size: 176
         .value_kind: by_value
     .group_segment_fixed_size: {lds}
     .kernarg_segment_align: 8
-    .kernarg_segment_size: 168
+    .kernarg_segment_size: 176
     .max_flat_workgroup_size: {threads}
     .name: {name}
     .private_segment_fixed_size: 0

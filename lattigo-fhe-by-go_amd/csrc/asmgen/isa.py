@@ -462,6 +462,12 @@ class Machine:
     def i_s_load_dwordx16(self, d, base, off):
         self._s_load(d, base, off, 16)
 
+    def i_s_sleep(self, n):
+        pass
+
+    def i_s_cmp_lg_u32(self, a, b):
+        self.scc = self.rs(a) != self.rs(b)
+
     def i_s_memtime(self, d):
         self._clock = getattr(self, "_clock", 0) + 1000
         self.ws(d, np.full(self.W, self._clock, dtype=np.uint32), 0)

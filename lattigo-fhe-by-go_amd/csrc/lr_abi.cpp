@@ -161,6 +161,7 @@ lr::Options lr::Options::from_env() {
     o.no_exttop = std::getenv("LR_NO_EXTTOP") != nullptr;
     o.timeline = std::getenv("LR_NTT_TIMELINE") != nullptr;
     if (const char *v = std::getenv("LR_NTT_MODE")) o.ntt_mode = std::atoi(v);
+    if (const char *v = std::getenv("LR_NTT_STAGGER")) o.stagger = std::atoi(v);
     if (const char *v = std::getenv("LR_ASM_VARIANT")) o.asm_variant = std::atoi(v);
     return o;
 }
@@ -914,6 +915,7 @@ int run_ntt_launch(lr_context *c, bool inverse, Rows in, Rows out, int mod0, int
     a.epi_x = a.epi_plus = nullptr;
     a.epi_x_stride = a.epi_plus_stride = 0;
     a.epi_consts = nullptr;
+    a.stagger_gx = a.stagger_unit = 0;
     if (variant == 3) {
         a.fp_tw_delta = (const char *)(inverse ? c->d_inv_fp : c->d_fwd_fp) - (const char *)a.tw;
         a.fp_fin_delta = (const char *)(inverse ? c->d_inv_fin_fp : c->d_fwd_fin_fp) - (const char *)a.tw_fin;
@@ -924,11 +926,11 @@ int run_ntt_launch(lr_context *c, bool inverse, Rows in, Rows out, int mod0, int
         // two 2^15 sub-blocks per limb on the assembly kernels + the streaming stage over bit 15
         if (!inverse) {
             if (pretop) {
-                LR_HIP(launch_ntt_asm16(a, 0, 'p', variant, c->stream, kn));
+                LR_HIP(launch_ntt_asm16(a, 0, 'p', variant, c->stream, kn, c->opt.stagger));
                 return LR_OK;
             }
             if (ntt_rows_disjoint(a, 16)) {
-                LR_HIP(launch_ntt_asm16(a, 0, 's', variant, c->stream, kn));     // top stage fused into the loads
+                LR_HIP(launch_ntt_asm16(a, 0, 's', variant, c->stream, kn, c->opt.stagger));     // top stage fused into the loads
                 return LR_OK;
             }
             LR_HIP(launch_ntt_top(a, 0, c->stream));
@@ -937,10 +939,10 @@ int run_ntt_launch(lr_context *c, bool inverse, Rows in, Rows out, int mod0, int
             sub.in_poly_stride = a.out_poly_stride;
             sub.in_limb0 = a.out_limb0;
             sub.in_limb_step = a.out_limb_step;
-            LR_HIP(launch_ntt_asm16(sub, 0, 'p', variant, c->stream, kn));
+            LR_HIP(launch_ntt_asm16(sub, 0, 'p', variant, c->stream, kn, c->opt.stagger));
             return LR_OK;
         }
-        LR_HIP(launch_ntt_asm16(a, 1, 's', variant, c->stream, kn));
+        LR_HIP(launch_ntt_asm16(a, 1, 's', variant, c->stream, kn, c->opt.stagger));
         NttLaunch top = a;
         top.in = a.out;
         top.in_poly_stride = a.out_poly_stride;
@@ -957,7 +959,7 @@ int run_ntt_launch(lr_context *c, bool inverse, Rows in, Rows out, int mod0, int
         a.epi_plus = epi->plus;
         a.epi_plus_stride = epi->plus_stride;
         a.epi_consts = epi->consts;
-        LR_HIP(launch_ntt_asm(a, (int)logn, 0, 4, c->stream, c->opt.asm14_1024, kn));
+        LR_HIP(launch_ntt_asm(a, (int)logn, 0, 4, c->stream, c->opt.asm14_1024, kn, false, c->opt.stagger));
         return LR_OK;
     }
     if (logn != 16 && variant >= 0 && c->use_asm && ntt_asm_available((int)logn)) {
@@ -974,10 +976,10 @@ int run_ntt_launch(lr_context *c, bool inverse, Rows in, Rows out, int mod0, int
             }
             c->stamp_used = words;
             a.epi_x = reinterpret_cast<const u64 *>(c->d_stamps);
-            LR_HIP(launch_ntt_asm(a, (int)logn, 0, variant, c->stream, false, kn, true));
+            LR_HIP(launch_ntt_asm(a, (int)logn, 0, variant, c->stream, false, kn, true, c->opt.stagger));
             return LR_OK;
         }
-        LR_HIP(launch_ntt_asm(a, (int)logn, inverse, variant, c->stream, c->opt.asm14_1024, kn));
+        LR_HIP(launch_ntt_asm(a, (int)logn, inverse, variant, c->stream, c->opt.asm14_1024, kn, false, c->opt.stagger));
         return LR_OK;
     }
     std::snprintf(c->last_ntt_kernel, sizeof c->last_ntt_kernel, "ntt_%s_kernel<%u>", inverse ? "inv" : "fwd", logn);

@@ -57,10 +57,20 @@ AsmKernels *kernels_for_current_device() {
 }
 }  // namespace
 
+// Start-up stagger of the first round of workgroups (gen_ntt.py: stagger): kilo-clocks per step of the 16-step offset.
+// request: Options::stagger (-1 = default).  Default: one sixteenth of a workgroup's life for the one-workgroup-per-CU kernels
+// (1024 threads: 84 k clocks on the integer bodies, 67 k on the FP64 ones) when the launch has at least four rounds of workgroups.
+static int stagger_unit(int request, bool one_wg_per_cu, bool dual, unsigned long long workgroups) {
+    if (request >= 0) return request;
+    if (!one_wg_per_cu || workgroups < 4ull * 256ull) return 0;
+    return dual ? 4 : 5;
+}
+
 bool ntt_asm_available(int logn) { return logn >= 12 && logn <= 16 && kernels_for_current_device() != nullptr; }
 
 // variant = lazy-correction mode of asmgen/gen_ntt.py (forward 0, 1, 2) / gen_intt.py (inverse 0, 1)
-hipError_t launch_ntt_asm(const NttLaunch &a, int logn, int inverse, int variant, hipStream_t stream, bool wide14, char *kernel_name, bool timeline) {
+hipError_t launch_ntt_asm(const NttLaunch &a, int logn, int inverse, int variant, hipStream_t stream, bool wide14, char *kernel_name, bool timeline,
+                          int stagger) {
     AsmKernels *k = kernels_for_current_device();
     if (!k || logn < 12 || logn > 15) return hipErrorNotSupported;
     // N = 2^12 (256 threads, four columns per thread, 36 KiB LDS image) and N = 2^13, 2^14 (512 threads, two columns,
@@ -89,14 +99,16 @@ hipError_t launch_ntt_asm(const NttLaunch &a, int logn, int inverse, int variant
         gz = (unsigned)(a.batch / a.group);
     }
     const unsigned threads = !x ? 1024 : (logn == 12 || (logn == 13 && !inverse)) ? 256 : 512;
-    if (variant >= 3) return hipModuleLaunchKernel(it->second, gy, (unsigned)a.n_items, gz, threads, 1, 1, 0, stream, nullptr, extra);
-    return hipModuleLaunchKernel(it->second, (unsigned)a.n_items, gy, gz, threads, 1, 1, 0, stream, nullptr, extra);
+    const unsigned gx = variant >= 3 ? gy : (unsigned)a.n_items, gyy = variant >= 3 ? (unsigned)a.n_items : gy;
+    args.stagger_gx = (int)gx;
+    args.stagger_unit = stagger_unit(stagger, threads == 1024, variant >= 3, (unsigned long long)gx * gyy * gz);
+    return hipModuleLaunchKernel(it->second, gx, gyy, gz, threads, 1, 1, 0, stream, nullptr, extra);
 }
 
 // N = 2^16 runs as two 2^15 sub-blocks per limb (grid x = 2 * n_items).  kind: 's' = forward with the stage over
 // bit 15 fused into the loads (out of place only) / inverse sub-blocks (lazy outputs, ntt_top_kernel follows),
 // 'p' = forward sub-blocks after a separate ntt_top_kernel pass (in place allowed).
-hipError_t launch_ntt_asm16(const NttLaunch &a, int inverse, char kind, int variant, hipStream_t stream, char *kernel_name) {
+hipError_t launch_ntt_asm16(const NttLaunch &a, int inverse, char kind, int variant, hipStream_t stream, char *kernel_name, int stagger) {
     AsmKernels *k = kernels_for_current_device();
     if (!k) return hipErrorNotSupported;
     char name[32];
@@ -117,6 +129,8 @@ hipError_t launch_ntt_asm16(const NttLaunch &a, int inverse, char kind, int vari
         gz = (unsigned)(a.batch / a.group);
     }
     if (gz > 65535u) return hipErrorInvalidValue;
+    args.stagger_gx = (int)gy;
+    args.stagger_unit = stagger_unit(stagger, true, variant >= 3, (unsigned long long)gy * 2u * (unsigned)a.n_items * gz);
     return hipModuleLaunchKernel(it->second, gy, 2u * (unsigned)a.n_items, gz, 1024, 1, 1, 0, stream, nullptr, extra);
 }
 

@@ -37,6 +37,7 @@ struct Options {
     bool asm14_1024 = false;       // LR_ASM_14_1024: the 1024-thread plan at N = 2^14
     bool timeline = false;         // LR_NTT_TIMELINE: forward 2^15 launches of the integer kernel run the stamped diagnostics build
     bool no_exttop = false;        // LR_NO_EXTTOP: N = 2^16 key switch with staged extensions and fused-top transforms instead of the top stage inside the extension
+    int stagger = -1;              // LR_NTT_STAGGER: start-up stagger of the assembly NTT kernels in kilo-clocks per step (0 = off)
     int ntt_mode = -1;             // LR_NTT_MODE
     int asm_variant = -1;          // LR_ASM_VARIANT
     static Options from_env();
@@ -88,8 +89,11 @@ struct NttLaunch {
     const u64 *epi_plus;
     long long epi_plus_stride;
     const EpiLimb *epi_consts;  // [L]: c and RN(c / q) as doubles, indexed like lp
+    // assembly kernels: start-up stagger of the first round of workgroups (gen_ntt.py: stagger), set by the launcher
+    int stagger_gx;             // the grid's x extent (linear workgroup id = x + stagger_gx * y)
+    int stagger_unit;           // kilo-clocks per step of the 16-step start offset; 0 = all workgroups start at once
 };
-static_assert(sizeof(NttLaunch) == 168, "NttLaunch layout is shared with asmgen/gen_ntt.py (fields are read at fixed offsets)");
+static_assert(sizeof(NttLaunch) == 176, "NttLaunch layout is shared with asmgen/gen_ntt.py (fields are read at fixed offsets)");
 
 // ---- coefficient-wise launches (lr_ewise.hip) ----
 struct EwiseLaunch {
@@ -281,9 +285,11 @@ hipError_t launch_ntt(const NttLaunch &a, int logn, bool inverse, int mode, hipS
 // hand-scheduled assembly forward NTT (lr_asm.cpp); N = 2^14 / 2^15, lazy mode 1 only
 bool ntt_asm_available(int logn);
 // kernel_name (optional, >= 32 bytes): receives the name of the code object that was launched
+// stagger: Options::stagger (kilo-clocks per step; 0 = off, -1 = the launcher's default for the kernel)
 hipError_t launch_ntt_asm(const NttLaunch &a, int logn, int inverse, int variant, hipStream_t stream, bool wide14 = false,
-                          char *kernel_name = nullptr, bool timeline = false);
-hipError_t launch_ntt_asm16(const NttLaunch &a, int inverse, char kind, int variant, hipStream_t stream, char *kernel_name = nullptr);
+                          char *kernel_name = nullptr, bool timeline = false, int stagger = -1);
+hipError_t launch_ntt_asm16(const NttLaunch &a, int inverse, char kind, int variant, hipStream_t stream, char *kernel_name = nullptr,
+                            int stagger = -1);
 // N = 2^16 helpers (lr_ntt.hip): the streaming stage over bit 15, and whether no input row of a launch is an output row
 hipError_t launch_ntt_top(const NttLaunch &a, int inverse, hipStream_t stream);
 bool ntt_rows_disjoint(const NttLaunch &a, int logn);

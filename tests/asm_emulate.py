@@ -93,7 +93,7 @@ def emulate(gen, inverse=False, q=None, geom=None):
     place(tw, A_TW)
     place(twf, A_TWF)
     fp_tables(np, q, n_inv, tw, twf, lambda a, b, c: (place(a, A_FTW), place(b, A_FTWF), place(c, A_FLP)))
-    karg = np.zeros(21, dtype=np.uint64)
+    karg = np.zeros(22, dtype=np.uint64)
     karg[13], karg[14], karg[15] = A_FTW - A_TW, A_FTWF - A_TWF, A_FLP
     if getattr(gen, "epi", False) and q < FP_LIMIT:
         # x and plus: canonical polys laid out like the output; c: a random constant in (w, w / q) form
@@ -258,7 +258,7 @@ def emulate_sub(make_gen, inverse, q, pretop=False):
     place(tw, A_TW)
     place(twf, A_TWF)
     fp_tables(np, q, n_inv, tw, twf, lambda a, b, c: (place(a, A_FTW), place(b, A_FTWF), place(c, A_FLP)))
-    karg = np.zeros(16, dtype=np.uint64)
+    karg = np.zeros(22, dtype=np.uint64)
     karg[13], karg[14], karg[15] = A_FTW - A_TW, A_FTWF - A_TWF, A_FLP
     karg[0], karg[1], karg[2], karg[3] = A_IN, A_OUT, NF, NF
     karg[4] = 0 | (1 << 32)

@@ -26,9 +26,9 @@ int main(int argc, char **argv) {
         hipModule_t mod; hipFunction_t fn;
         CK(hipModuleLoadData(&mod, img.data()));
         CK(hipModuleGetFunction(&fn, mod, ("probe_" + name).c_str()));
-        // the code objects declare the 168-byte kernel-argument block of the NTT kernels (NttLaunch); pass exactly that size
-        struct { unsigned long long a, b; void *out; void *in; char pad[136]; } args = {0x0123456789ABCDEFull, 0x0FEDCBA987654321ull, out, big, {0}};
-        static_assert(sizeof(args) == 168, "kernarg block");
+        // the code objects declare the 176-byte kernel-argument block of the NTT kernels (NttLaunch); pass exactly that size
+        struct { unsigned long long a, b; void *out; void *in; char pad[144]; } args = {0x0123456789ABCDEFull, 0x0FEDCBA987654321ull, out, big, {0}};
+        static_assert(sizeof(args) == 176, "kernarg block");
         size_t size = sizeof(args);
         void *extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
         hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
