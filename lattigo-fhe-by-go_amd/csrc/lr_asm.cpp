@@ -58,12 +58,14 @@ AsmKernels *kernels_for_current_device() {
 }  // namespace
 
 // Start-up stagger of the first round of workgroups (gen_ntt.py: stagger): kilo-clocks per step of the 16-step offset.
-// request: Options::stagger (-1 = default).  Default: one sixteenth of a workgroup's life for the one-workgroup-per-CU kernels
-// (1024 threads: 84 k clocks on the integer bodies, 67 k on the FP64 ones) when the launch has at least four rounds of workgroups.
+// request: Options::stagger (LR_NTT_STAGGER; -1 = default).  Default OFF: measured on R15 x 256 polys with 0 / 2 / 4 / 5 / 6 / 8 / 12
+// kilo-clocks per step (tools/dbg/stagger_sweep.py, profiles/r02/stagger_sweep.txt), every setting was 0-5 % slower than none
+// on the integer and on the FP64 bodies alike -- the CUs do not run in a bandwidth convoy that a phase offset could break.
 static int stagger_unit(int request, bool one_wg_per_cu, bool dual, unsigned long long workgroups) {
-    if (request >= 0) return request;
-    if (!one_wg_per_cu || workgroups < 4ull * 256ull) return 0;
-    return dual ? 4 : 5;
+    (void)one_wg_per_cu;
+    (void)dual;
+    (void)workgroups;
+    return request > 0 ? request : 0;
 }
 
 bool ntt_asm_available(int logn) { return logn >= 12 && logn <= 16 && kernels_for_current_device() != nullptr; }
