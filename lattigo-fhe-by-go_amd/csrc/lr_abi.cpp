@@ -159,6 +159,7 @@ lr::Options lr::Options::from_env() {
     o.ext_narrow = std::getenv("LR_EXT_NARROW") != nullptr;
     o.asm14_1024 = std::getenv("LR_ASM_14_1024") != nullptr;
     o.no_exttop = std::getenv("LR_NO_EXTTOP") != nullptr;
+    o.keymac_narrow = std::getenv("LR_KEYMAC_NARROW") != nullptr;
     o.timeline = std::getenv("LR_NTT_TIMELINE") != nullptr;
     if (const char *v = std::getenv("LR_NTT_MODE")) o.ntt_mode = std::atoi(v);
     if (const char *v = std::getenv("LR_NTT_STAGGER")) o.stagger = std::atoi(v);
@@ -2060,6 +2061,14 @@ int ks_decompose(lr_ckks_plan *pl, int level, int batch, const u64 *cx, long lon
     return LR_OK;
 }
 
+// exact 128-bit sums in the key inner product: beta products below q^2 each must stay below q * 2^64
+bool keymac_wide_ok(const lr_ckks_plan *pl, const lr_context *c, int beta) {
+    if (pl->opt.keymac_narrow) return false;
+    u64 qmax = 0;
+    for (u64 q : c->h.q) qmax = q > qmax ? q : qmax;
+    return (u128)qmax * (u128)beta < ((u128)1 << 64);
+}
+
 // Inner product of the digits with a switching key and the two ModDownSplitedNTTPQ (:1511-1557 / :1339-1387).
 // digQ/digP: [beta][batch][|Q| resp. |P|][N]; own/own_stride: where the digits' own limbs live when they were not
 // copied (nullptr: inside digQ).
@@ -2077,6 +2086,8 @@ int ks_accumulate(lr_ckks_plan *pl, int level, int batch, const u64 *digQ, const
     // sum over the digits of evakey[i][0/1] (*) c2_i, canonical, Q part then P part
     {
         KeyMacLaunch K;
+        K.tile8 = 0;
+        K.wide = 0;
         K.key = evk->d;
         K.key_poly_stride = evk->stride();
         K.n = n;
@@ -2090,6 +2101,7 @@ int ks_accumulate(lr_ckks_plan *pl, int level, int batch, const u64 *digQ, const
         K.out_stride = p0_stride;
         K.out1_stride = p1_stride;
         K.lp = cQ->d_lp;
+        K.wide = keymac_wide_ok(pl, cQ, beta) ? 1 : 0;
         K.own = own;
         K.own_stride = own_stride;
         K.alpha = own ? alpha : 0;
@@ -2103,6 +2115,7 @@ int ks_accumulate(lr_ckks_plan *pl, int level, int batch, const u64 *digQ, const
         K.out_stride = sP;
         K.out1_stride = sP;
         K.lp = cP->d_lp;
+        K.wide = keymac_wide_ok(pl, cP, beta) ? 1 : 0;
         K.own = nullptr;
         K.own_stride = 0;
         K.alpha = 0;

@@ -36,6 +36,7 @@ struct Options {
     bool ext_narrow = false;       // LR_EXT_NARROW: per-term basis extension instead of the 128-bit column sums
     bool asm14_1024 = false;       // LR_ASM_14_1024: the 1024-thread plan at N = 2^14
     bool timeline = false;         // LR_NTT_TIMELINE: forward 2^15 launches of the integer kernel run the stamped diagnostics build
+    bool keymac_narrow = false;    // LR_KEYMAC_NARROW: one Montgomery product per term in the key inner product instead of the 128-bit sums
     bool no_exttop = false;        // LR_NO_EXTTOP: N = 2^16 key switch with staged extensions and fused-top transforms instead of the top stage inside the extension
     int stagger = -1;              // LR_NTT_STAGGER: start-up stagger of the assembly NTT kernels in kilo-clocks per step (0 = off)
     int ntt_mode = -1;             // LR_NTT_MODE
@@ -176,6 +177,8 @@ struct KeyMacLaunch {
     long long own_stride;
     int alpha;
     long long out1_stride;         // of out1 (the two outputs of lr_ckks_switch_keys may have different allocations)
+    int tile8;                     // set by the launcher: grid x = poly * 8 + (chunk mod 8) (one XCD per key tile)
+    int wide;                      // 1: exact 128-bit sums + one Montgomery reduction per output (needs beta * max q < 2^64, q < 2^61)
 };
 hipError_t launch_keymac(const KeyMacLaunch &L, int limbs, int batch, hipStream_t stream);
 

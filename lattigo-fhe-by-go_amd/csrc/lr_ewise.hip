@@ -373,9 +373,14 @@ hipError_t launch_rowadd(const RowAddLaunch &L, int rows, int batch, hipStream_t
 template <int BETA>
 __global__ __launch_bounds__(256) void keymac_kernel(KeyMacLaunch L) {
     // x = poly of the batch (fastest): the workgroups that run together share one tile of the key, which therefore
-    // stays in L2 instead of being re-read from the Infinity Cache once per poly
+    // stays in L2 instead of being re-read from the Infinity Cache once per poly.  tile8: x = poly * 8 + (chunk mod 8), so that
+    // the workgroups of one tile have equal linear ids modulo 8 and land on ONE XCD (consecutive workgroups are dealt out to the
+    // eight XCDs in turn): the tile is fetched into one L2 instead of eight -- at N = 2^16 the key (342 MB) does not fit the
+    // Infinity Cache and the eight fetches were 26 % of the kernel's HBM traffic
     const int limb = blockIdx.y;
-    const long long b = blockIdx.x;
+    const long long b = L.tile8 ? (long long)(blockIdx.x >> 3) : (long long)blockIdx.x;
+    const int chunk = L.tile8 ? (int)(blockIdx.z * 8 + (blockIdx.x & 7)) : (int)blockIdx.z;
+    const int chunks = L.tile8 ? (int)gridDim.z * 8 : (int)gridDim.z;
     const LimbParams lp = L.lp[limb];
     const long long row = (long long)limb * L.n;
     const ulonglong2 *pc = reinterpret_cast<const ulonglong2 *>(L.c2 + b * L.c2_poly_stride + row);
@@ -387,7 +392,7 @@ __global__ __launch_bounds__(256) void keymac_kernel(KeyMacLaunch L) {
     const int own_digit = L.alpha > 0 ? limb / L.alpha : -1;
     const int pairs = L.n >> 1;
     const int beta = BETA > 0 ? BETA : L.beta;
-    for (int e = blockIdx.z * 256 + threadIdx.x; e < pairs; e += gridDim.z * 256) {
+    for (int e = chunk * 256 + threadIdx.x; e < pairs; e += chunks * 256) {
         u64 a0x = 0, a0y = 0, a1x = 0, a1y = 0;
         if constexpr (BETA > 0) {
             // groups of at most G digits: all loads of a group are in flight before its first multiply; beyond six digits one
@@ -446,18 +451,128 @@ __global__ __launch_bounds__(256) void keymac_kernel(KeyMacLaunch L) {
     }
 }
 
+// The same inner product with the beta products of an output summed EXACTLY in 128 bits and reduced once: sum_i MRed(k_i, c_i)
+// and MRed(sum_i k_i * c_i) are the same residue modulo q, and the canonical result is what the reference's chain of
+// MulCoeffsMontgomeryAndAddNoMod + Reduce leaves.  By columns, with k = k1 2^32 + k0 and c = c1 2^32 + c0:
+//   lo += k0 c0 (carry-out counted), mid += k0 c1 + k1 c0 (folded every four digits: eight products below 2^61), hi += k1 c1
+// -- five multiply-adds and a carry add per product instead of the ~25 instructions of a Montgomery product: at beta = 9 the
+// per-term kernel was bound by its arithmetic (1.1 ms of VALU issue in a 1.85 ms launch), not by the 7 GB it moves.
+// Needs every key value below q < 2^61 and beta * q < 2^64 (KeyMacLaunch::wide, set by the host); the digit values may be any
+// 64-bit word in at most one term (the digit's own limbs come from the caller): the reduction is a congruence for any 128-bit sum,
+// and the final BRedAdd takes the whole 64-bit range.
+__device__ __forceinline__ void mac128(u64 k, u64 c, u64 &lo, u64 &mid, u64 &hi, u32 &cy) {
+    const u32 k0 = (u32)k, k1 = (u32)(k >> 32), c0 = (u32)c, c1 = (u32)(c >> 32);
+    asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc" : "+v"(lo), "+v"(cy) : "v"(k0), "v"(c0) : "vcc");
+    u64 junk;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0" : "+v"(mid), "=s"(junk) : "v"(k0), "v"(c1));
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0" : "+v"(mid), "=s"(junk) : "v"(k1), "v"(c0));
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0" : "+v"(hi), "=s"(junk) : "v"(k1), "v"(c1));
+}
+__device__ __forceinline__ void fold128(u64 &lo, u64 &mid, u64 &hi) {
+    const u64 low_part = mid << 32;
+    lo += low_part;
+    hi += (mid >> 32) + (lo < low_part ? 1 : 0);
+    mid = 0;
+}
+__device__ __forceinline__ u64 reduce128(u64 lo, u64 hi, u32 cy, const LimbParams &lp) {
+    const u64 th = hi + cy;                                        // the sum is th * 2^64 + lo
+    const u64 H = mul_hi64(lo * lp.qinv, lp.q);                   // Montgomery reduction of the 128-bit sum
+    return bred_add(th - H + lp.q, lp.q, lp.bred_hi);
+}
+
+template <int BETA>
+__global__ __launch_bounds__(256) void keymac_wide_kernel(KeyMacLaunch L) {
+    const int limb = blockIdx.y;
+    const long long b = L.tile8 ? (long long)(blockIdx.x >> 3) : (long long)blockIdx.x;
+    const int chunk = L.tile8 ? (int)(blockIdx.z * 8 + (blockIdx.x & 7)) : (int)blockIdx.z;
+    const int chunks = L.tile8 ? (int)gridDim.z * 8 : (int)gridDim.z;
+    const LimbParams lp = L.lp[limb];
+    const long long row = (long long)limb * L.n;
+    const ulonglong2 *pc = reinterpret_cast<const ulonglong2 *>(L.c2 + b * L.c2_poly_stride + row);
+    const ulonglong2 *pk = reinterpret_cast<const ulonglong2 *>(L.key + (long long)(L.key_limb0 + limb) * L.n);
+    ulonglong2 *po0 = reinterpret_cast<ulonglong2 *>(L.out0 + b * L.out_stride + row);
+    ulonglong2 *po1 = reinterpret_cast<ulonglong2 *>(L.out1 + b * L.out1_stride + row);
+    const long long cd = L.c2_digit_stride >> 1, kd = L.key_poly_stride >> 1;   // in 16-byte units
+    const ulonglong2 *pown = L.alpha > 0 ? reinterpret_cast<const ulonglong2 *>(L.own + b * L.own_stride + row) : nullptr;
+    const int own_digit = L.alpha > 0 ? limb / L.alpha : -1;
+    const int pairs = L.n >> 1;
+    const int beta = BETA > 0 ? BETA : L.beta;
+    constexpr int G = BETA > 0 ? (BETA <= 6 ? BETA : (BETA + 1) / 2) : 1;      // digits whose loads are in flight together
+    for (int e = chunk * 256 + threadIdx.x; e < pairs; e += chunks * 256) {
+        u64 lo[4] = {0, 0, 0, 0}, mid[4] = {0, 0, 0, 0}, hi[4] = {0, 0, 0, 0};
+        u32 cy[4] = {0, 0, 0, 0};
+        if constexpr (BETA > 0) {
+#pragma unroll
+            for (int g0 = 0; g0 < BETA; g0 += G) {
+                ulonglong2 c[G], k0[G], k1[G];
+#pragma unroll
+                for (int u = 0; u < G; ++u) {
+                    const int i = g0 + u;
+                    if (i < BETA) {
+                        c[u] = ld_stream(i == own_digit ? pown + e : pc + e + i * cd);
+                        k0[u] = pk[e + (2 * i) * kd];
+                        k1[u] = pk[e + (2 * i + 1) * kd];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < G; ++u) {
+                    const int i = g0 + u;
+                    if (i < BETA) {
+                        mac128(k0[u].x, c[u].x, lo[0], mid[0], hi[0], cy[0]);
+                        mac128(k0[u].y, c[u].y, lo[1], mid[1], hi[1], cy[1]);
+                        mac128(k1[u].x, c[u].x, lo[2], mid[2], hi[2], cy[2]);
+                        mac128(k1[u].y, c[u].y, lo[3], mid[3], hi[3], cy[3]);
+                        if ((i & 3) == 3 || i == BETA - 1) {
+#pragma unroll
+                            for (int a = 0; a < 4; ++a) fold128(lo[a], mid[a], hi[a]);
+                        }
+                    }
+                }
+                if (g0 + G < BETA) __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+            for (int i = 0; i < beta; ++i) {
+                const ulonglong2 c = ld_stream(i == own_digit ? pown + e : pc + e + i * cd);
+                const ulonglong2 k0 = pk[e + (2 * i) * kd], k1 = pk[e + (2 * i + 1) * kd];
+                mac128(k0.x, c.x, lo[0], mid[0], hi[0], cy[0]);
+                mac128(k0.y, c.y, lo[1], mid[1], hi[1], cy[1]);
+                mac128(k1.x, c.x, lo[2], mid[2], hi[2], cy[2]);
+                mac128(k1.y, c.y, lo[3], mid[3], hi[3], cy[3]);
+                if ((i & 3) == 3 || i == beta - 1) {
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) fold128(lo[a], mid[a], hi[a]);
+                }
+            }
+        }
+        st_stream(po0 + e, make_ulonglong2(reduce128(lo[0], hi[0], cy[0], lp), reduce128(lo[1], hi[1], cy[1], lp)));
+        st_stream(po1 + e, make_ulonglong2(reduce128(lo[2], hi[2], cy[2], lp), reduce128(lo[3], hi[3], cy[3], lp)));
+    }
+}
+
 hipError_t launch_keymac(const KeyMacLaunch &L, int limbs, int batch, hipStream_t stream) {
     if (limbs <= 0 || batch <= 0) return hipSuccess;
     int gx = ((L.n >> 1) + 255) / 256;
     if (gx > 64) gx = 64;
-    const dim3 grid((unsigned)batch, (unsigned)limbs, (unsigned)gx), block(256);
+    KeyMacLaunch K = L;
+    K.tile8 = (gx % 8 == 0 && (long long)batch * 8 < (1ll << 31)) ? 1 : 0;
+    const dim3 grid(K.tile8 ? (unsigned)batch * 8u : (unsigned)batch, (unsigned)limbs, K.tile8 ? (unsigned)gx / 8u : (unsigned)gx), block(256);
     (void)hipGetLastError();
+    if (K.wide) {
+        switch (L.beta) {
+#define LR_KMW(B) \
+    case B: hipLaunchKernelGGL(keymac_wide_kernel<B>, grid, block, 0, stream, K); break;
+            LR_KMW(1) LR_KMW(2) LR_KMW(3) LR_KMW(4) LR_KMW(5) LR_KMW(6) LR_KMW(7) LR_KMW(8) LR_KMW(9) LR_KMW(10)
+#undef LR_KMW
+        default: hipLaunchKernelGGL(keymac_wide_kernel<0>, grid, block, 0, stream, K); break;
+        }
+        return hipGetLastError();
+    }
     switch (L.beta) {
 #define LR_KM(B) \
-    case B: hipLaunchKernelGGL(keymac_kernel<B>, grid, block, 0, stream, L); break;
+    case B: hipLaunchKernelGGL(keymac_kernel<B>, grid, block, 0, stream, K); break;
         LR_KM(1) LR_KM(2) LR_KM(3) LR_KM(4) LR_KM(5) LR_KM(6) LR_KM(7) LR_KM(8) LR_KM(9) LR_KM(10)
 #undef LR_KM
-    default: hipLaunchKernelGGL(keymac_kernel<0>, grid, block, 0, stream, L); break;
+    default: hipLaunchKernelGGL(keymac_kernel<0>, grid, block, 0, stream, K); break;
     }
     return hipGetLastError();
 }

@@ -301,3 +301,29 @@ def test_decrypt_degree_seven_reduction_cadence(gpu_pkg, oracle):
         out = cQ.NewPoly(1)
         plan.Decrypt(level, polys, psk, out)
         assert np.array_equal(out.get().reshape(nq, N), oplan.decrypt(level, ct, sk[0])), degree
+
+
+@pytest.mark.parametrize("logn,nq,np_,level", [(12, 18, 3, 17), (14, 7, 3, 6), (16, 10, 4, 9)])
+def test_key_inner_product_per_term_fallback(gpu_pkg, oracle, logn, nq, np_, level, monkeypatch):
+    """the key inner product with one Montgomery product per term (LR_KEYMAC_NARROW) instead of the exact 128-bit sums"""
+    monkeypatch.setenv("LR_KEYMAC_NARROW", "1")
+    test_switch_keys(gpu_pkg, oracle, logn, nq, np_, level)
+
+
+def test_switch_keys_accepts_non_canonical_own_limbs(gpu_pkg, oracle):
+    """cx values in [q, 2q) -- what the reference's lazy operations leave and its InvNTT still takes -- reach the
+    inner product unreduced in the limbs a digit owns (ckks/evaluator.go:1579-1584): MRed accepts them, and so does the
+    128-bit sum (its final BRedAdd takes the whole 64-bit range)"""
+    logn, nq, np_, level = 12, 6, 2, 5
+    N, Q, P, cQ, cP, plan, oplan, evk, pevk = _ckks(gpu_pkg, oracle, logn, nq, np_, 2)
+    cx = gpu_pkg.sampling.uniform_poly(Q[:level + 1], N, 2, seed=5)
+    for i, q in enumerate(Q[:level + 1]):
+        cx[0, i, :8] = np.uint64(2 * q - 1)
+        cx[1, i, 1] = np.uint64(2 * q - 1)
+        cx[1, i, 2] = np.uint64(q)
+    pcx = cQ.NewPolyLvl(level, 2).set(cx)
+    p0, p1 = cQ.NewPolyLvl(level, 2), cQ.NewPolyLvl(level, 2)
+    plan.SwitchKeysInPlace(level, pcx, pevk, p0, p1)
+    for b in range(2):
+        w0, w1 = oplan.switch_keys(level, cx[b], evk)
+        assert np.array_equal(p0.get()[b], w0) and np.array_equal(p1.get()[b], w1)
