@@ -43,9 +43,13 @@ def main():
         ctx.NTT(src, dst)
     ms = ctx.TimerStop() / 10
     assert ctx.last_ntt_kernel() == "lr_ntt_fwd15_m1t", ctx.last_ntt_kernel()
-    # the stamped build computes the same transform
-    oc = g.load_oracle().Context(N, list(moduli))
-    assert np.array_equal(dst.get().reshape(B, L, N)[1], oc.ntt(base[1]))
+    # the stamped build computes the same transform as the shipped kernel (a second context created without the switch)
+    os.environ.pop("LR_NTT_TIMELINE")
+    plain = ring.NewContextWithParams(N, moduli)
+    ref = plain.NewPoly(2)
+    plain.NTT(plain.NewPoly(2).set(base), ref)
+    assert plain.last_ntt_kernel() == "lr_ntt_fwd15_m1"
+    assert np.array_equal(dst.get().reshape(B, L, N)[:2], ref.get().reshape(2, L, N))
     st = ctx.timeline().astype(np.int64)[:, :, :13]                 # [workgroup, wave, stamp]
     d = (np.diff(st, axis=2)) & 0xFFFFFFFF                           # low-word differences, wrap-safe
     life = (st[:, :, 12] - st[:, :, 0]) & 0xFFFFFFFF
