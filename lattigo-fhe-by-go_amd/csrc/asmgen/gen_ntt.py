@@ -41,7 +41,8 @@ class Gen:
         # epi: the FP64 body ends in out = (x - NTT(in)) * c + plus (mod q) instead of out = NTT(in): the subtract-multiply of
         # ModDownSplitedNTTPQ (ring_basis_extension.go:237-239) with the addition that follows it in MulRelin
         # (ckks/evaluator.go:1103-1104), x / plus addressed like the output rows (NttLaunch::epi_*).  Launched on FP64 limbs only.
-        assert not epi or (dual and not sub)
+        # (N = 2^16: only the plain sub-block kernels, i.e. after the top stage has been applied by the basis extension)
+        assert not epi or dual
         self.fp, self.dual, self.epi = fp, dual, epi
         self.mark = None
         assert not sub or (logn == 15 and threads == 1024)
@@ -406,6 +407,8 @@ class Gen:
         e("s_waitcnt", "lgkmcnt(0)")
         sc = self.SC
         self.stagger()
+        if self.sub and self.epi:
+            self.park_kernarg()
         if self.sub:
             e("s_and_b32", self.BLK1, self.WGX, 1)
             e("s_add_u32", self.BLK1, self.BLK1, 1)      # 1 + blk: heap root 2 + blk = 1 + BLK1
@@ -418,6 +421,8 @@ class Gen:
         e("s_add_u32", self.WGX, self.WGX, sc[1])
         e("s_mul_i32", sc[0], self.WGZ, s(62))
         e("s_add_u32", self.WGY, self.WGY, sc[0])
+        if self.sub and self.epi:
+            self.park_ids()
         e("s_mul_i32", sc[0], self.WGX, s(49))
         e("s_add_u32", sc[0], sc[0], s(48))          # modulus index
         e("s_mul_i32", sc[1], self.WGX, s(45))
@@ -466,6 +471,37 @@ class Gen:
             e("s_addc_u32", self.DST.hi(), self.DST.hi(), 0)
             self.sub_source(sc[3])
         self.prologue_tail()
+
+    def park_kernarg(self):
+        """sub-block kernels reuse s[0:3] (BLK1, HI / TWS): what the epilogue needs of them -- the kernel-argument pointer, the
+        limb and the polynomial of the workgroup -- waits in the padding of row 0 of the wave's LDS block (bytes w*9216 + 128 ..
+        143, never touched by the transform; the timeline build keeps its stamps in the same padding)"""
+        e = self.e
+        e("s_mul_i32", self.SC[0], self.WAVE, 9216)
+        e("s_add_u32", self.SC[0], self.SC[0], 128)
+        e("v_mov_b32", v(4), self.SC[0])
+        e("v_mov_b32", v(2), self.KARG.lo())
+        e("v_mov_b32", v(3), self.KARG.hi())
+        e("ds_write_b64", v(4), v(2, 2))
+
+    def park_ids(self):
+        e = self.e
+        e("v_mov_b32", v(2), self.WGX)
+        e("v_mov_b32", v(3), self.WGY)
+        e("ds_write_b64", v(4), v(2, 2), offset=8)
+
+    def unpark(self, dst):
+        """dst[0:1] <- kernel-argument pointer, dst[2] <- limb of the launch, dst[3] <- polynomial"""
+        e = self.e
+        ts = self.ts[0]
+        e("s_mul_i32", self.SC[0], self.WAVE, 9216)
+        e("s_add_u32", self.SC[0], self.SC[0], 128)
+        e("v_mov_b32", ts.T0, self.SC[0])
+        e("ds_read_b128", v(ts.Q.idx, 4), ts.T0)
+        e("s_waitcnt", "lgkmcnt(0)")
+        for i in range(4):
+            e("v_readfirstlane_b32", dst.sub(i), v(ts.Q.idx + i))
+        e("s_nop", 4)
 
     def sub_source(self, blk_bytes):
         """forward: SRC stays at the low half, HI = the high half (fused top stage reads both); without the fusion
@@ -945,28 +981,36 @@ class Gen:
         e = self.e
         sc = self.SC
         K = 36                                       # the uniform-twiddle buffer is idle here: scratch SGPRs
-        e("s_load_dwordx8", s(K, 8), self.KARG, 128)          # epi_x, epi_x_stride, epi_plus, epi_plus_stride
-        e("s_load_dwordx2", s(K + 8, 2), self.KARG, 160)      # epi_consts
-        e("s_load_dwordx4", s(K + 12, 4), self.KARG, 40)      # out_limb0, out_limb_step, mod0, mod_step
+        KA, WX, WY = self.KARG, self.WGX, self.WGY
+        if self.sub:
+            KA, WX, WY = s(K + 16, 2), s(K + 18), s(K + 19)
+            self.unpark(s(K + 16, 4))
+        e("s_load_dwordx8", s(K, 8), KA, 128)                 # epi_x, epi_x_stride, epi_plus, epi_plus_stride
+        e("s_load_dwordx2", s(K + 8, 2), KA, 160)             # epi_consts
+        e("s_load_dwordx4", s(K + 12, 4), KA, 40)             # out_limb0, out_limb_step, mod0, mod_step
         e("s_waitcnt", "lgkmcnt(0)")
-        e("s_mul_i32", sc[0], self.WGX, s(K + 13))
+        e("s_mul_i32", sc[0], WX, s(K + 13))
         e("s_add_u32", sc[0], sc[0], s(K + 12))               # output row
-        e("s_mul_i32", sc[1], self.WGX, s(K + 15))
+        e("s_mul_i32", sc[1], WX, s(K + 15))
         e("s_add_u32", sc[1], sc[1], s(K + 14))               # modulus index
         rows = []
         for base, stride, dst in ((s(K, 2), s(K + 2, 2), s(K + 20, 2)), (s(K + 4, 2), s(K + 6, 2), s(K + 22, 2))):
-            e("s_mul_i32", self.TMP.lo(), self.WGY, stride.lo())
-            e("s_mul_hi_u32", self.TMP.hi(), self.WGY, stride.lo())
-            e("s_mul_i32", sc[3], self.WGY, stride.hi())
+            e("s_mul_i32", self.TMP.lo(), WY, stride.lo())
+            e("s_mul_hi_u32", self.TMP.hi(), WY, stride.lo())
+            e("s_mul_i32", sc[3], WY, stride.hi())
             e("s_add_u32", self.TMP.hi(), self.TMP.hi(), sc[3])
-            e("s_lshl_b32", sc[3], sc[0], self.logn)
+            e("s_lshl_b32", sc[3], sc[0], self.logn + (1 if self.sub else 0))
             e("s_add_u32", self.TMP.lo(), self.TMP.lo(), sc[3])
             e("s_addc_u32", self.TMP.hi(), self.TMP.hi(), 0)
             e("s_lshl_b64", self.TMP, self.TMP, 3)
             e("s_add_u32", dst.lo(), base.lo(), self.TMP.lo())
             e("s_addc_u32", dst.hi(), base.hi(), self.TMP.hi())
-            # this wave's 8 KiB: (half * SPH + wave) * 8192 bytes into the row
+            # this wave's 8 KiB: (half * SPH + wave) * 8192 bytes into the row (+ the sub-block's half of the limb)
             e("s_lshl_b32", sc[3], self.WAVE, 13)
+            if self.sub:
+                e("s_sub_u32", sc[5], self.BLK1, 1)
+                e("s_lshl_b32", sc[5], sc[5], self.logn + 3)
+                e("s_add_u32", sc[3], sc[3], sc[5])
             e("s_add_u32", sc[3], sc[3], half * self.SPH * 8192)
             e("s_add_u32", dst.lo(), dst.lo(), sc[3])
             e("s_addc_u32", dst.hi(), dst.hi(), 0)

@@ -57,6 +57,7 @@ gen_sub inv 16s 3 & gpids+=($!)
 # mode 4: the dual forward kernels with the subtract-multiply-add epilogue on the FP64 body (ModDown inside the key switch)
 gen_one fwd 14 4 & gpids+=($!); gen_one fwd 15 4 & gpids+=($!)
 gen_one fwd 14 4 512 & gpids+=($!); gen_one fwd 13 4 256 & gpids+=($!); gen_one fwd 12 4 256 & gpids+=($!)
+gen_sub fwd 16s 4 & gpids+=($!); gen_sub fwd 16p 4 plain & gpids+=($!)
 # diagnostics: the 2^15 integer kernel with per-phase clock stamps (LR_NTT_TIMELINE=1, tools/timeline.py)
 ( python3 asmgen/gen_ntt.py 15 build/ntt_fwd15_m1t.s 1 1024 timeline
   $LLVM/clang -x assembler -target amdgcn-amd-amdhsa -mcpu=gfx950 -c build/ntt_fwd15_m1t.s -o build/ntt_fwd15_m1t.o
@@ -67,7 +68,7 @@ out = ['struct lr_asm_blob { const char *name; const unsigned char *data; unsign
 names = [("fwd", n, m) for n in (14, 15) for m in (0, 1, 2)] + [("inv", n, m) for n in (14, 15) for m in (0, 1)]
 names += [("fwd", n, m) for n in ("12x", "13x", "14x", "16s", "16p") for m in (0, 1, 2)] + [("inv", n, m) for n in ("12x", "13x", "14x", "16s") for m in (0, 1)]
 names += [("fwd", n, 3) for n in (14, 15, "12x", "13x", "14x", "16s", "16p")] + [("inv", n, 3) for n in (14, 15, "12x", "13x", "14x", "16s")]
-names += [("fwd", n, 4) for n in (14, 15, "12x", "13x", "14x")]
+names += [("fwd", n, 4) for n in (14, 15, "12x", "13x", "14x", "16s", "16p")]
 names = [(k, n, str(m)) for k, n, m in names] + [("fwd", 15, "1t")]
 for k, n, m in names:
     data = open("build/ntt_%s%s_m%s.hsaco" % (k, n, m), "rb").read()

@@ -846,9 +846,10 @@ struct NttEpilogue {
     const EpiLimb *consts;
 };
 
+// N = 2^16: the input rows either carry the top stage already (`pretop`) or are disjoint from the output rows
 bool ntt_epilogue_ok(const lr_context *c) {
     const unsigned logn = c->h.logN;
-    return c->use_asm && c->asm_fwd == 3 && logn >= 12 && logn <= 15 && ntt_asm_available((int)logn) && !c->opt.no_epilogue;
+    return c->use_asm && c->asm_fwd == 3 && logn >= 12 && logn <= 16 && ntt_asm_available((int)logn) && !c->opt.no_epilogue;
 }
 
 int run_ntt_launch(lr_context *c, bool inverse, Rows in, Rows out, int mod0, int mod_step, int count, int batch, int hole,
@@ -923,6 +924,20 @@ int run_ntt_launch(lr_context *c, bool inverse, Rows in, Rows out, int mod0, int
         a.fp_lp = c->d_fp_lp;
     }
     char *kn = c->last_ntt_kernel;
+    if (epi) {
+        if (inverse || hole > 0 || !ntt_epilogue_ok(c) || (logn == 16 && !pretop && !ntt_rows_disjoint(a, 16)))
+            return fail(LR_ERR_ARG, "NTT epilogue: not available for this launch");
+        a.epi_x = epi->x;
+        a.epi_x_stride = epi->x_stride;
+        a.epi_plus = epi->plus;
+        a.epi_plus_stride = epi->plus_stride;
+        a.epi_consts = epi->consts;
+        if (logn == 16)
+            LR_HIP(launch_ntt_asm16(a, 0, pretop ? 'p' : 's', 4, c->stream, kn, c->opt.stagger));
+        else
+            LR_HIP(launch_ntt_asm(a, (int)logn, 0, 4, c->stream, c->opt.asm14_1024, kn, false, c->opt.stagger));
+        return LR_OK;
+    }
     if (logn == 16 && variant >= 0 && c->use_asm && ntt_asm_available(16)) {
         // two 2^15 sub-blocks per limb on the assembly kernels + the streaming stage over bit 15
         if (!inverse) {
@@ -953,16 +968,6 @@ int run_ntt_launch(lr_context *c, bool inverse, Rows in, Rows out, int mod0, int
         return LR_OK;
     }
     if (pretop) return fail(LR_ERR_ARG, "pre-applied top stage: only for forward N = 2^16 launches on the assembly kernels");
-    if (epi) {
-        if (inverse || hole > 0 || !ntt_epilogue_ok(c)) return fail(LR_ERR_ARG, "NTT epilogue: not available for this launch");
-        a.epi_x = epi->x;
-        a.epi_x_stride = epi->x_stride;
-        a.epi_plus = epi->plus;
-        a.epi_plus_stride = epi->plus_stride;
-        a.epi_consts = epi->consts;
-        LR_HIP(launch_ntt_asm(a, (int)logn, 0, 4, c->stream, c->opt.asm14_1024, kn, false, c->opt.stagger));
-        return LR_OK;
-    }
     if (logn != 16 && variant >= 0 && c->use_asm && ntt_asm_available((int)logn)) {
         if (c->opt.timeline && logn == 15 && !inverse && variant == 1 && hole == 0) {
             // diagnostics: the stamped build of the same kernel; stamps land in the context's buffer (lr_context_timeline)
@@ -2164,11 +2169,11 @@ int ks_accumulate(lr_ckks_plan *pl, int level, int batch, const u64 *digQ, const
                         const u64 *plus = pluses[k];
                         const NttEpilogue ep{k == 0 ? p0 : p1, k == 0 ? p0_stride : p1_stride, plus ? plus : pl->zerosQ.d,
                                              plus ? plus_stride : 0, bx->d_moddown_pq_epi};
-                        LR_TRY(run_ntt(cQ, false, src, dst, l0, 1, l1 - l0, batch, 0, 0, &ep));
+                        LR_TRY(run_ntt(cQ, false, src, dst, l0, 1, l1 - l0, batch, 0, 0, &ep, exttop));
                     }
                 } else {
                     Rows src{ext_out, sQ, l0, 1}, dst{bx->poolQ.d, sQ, l0, 1};
-                    LR_TRY(run_ntt(cQ, false, src, dst, l0, 1, l1 - l0, 2 * batch));
+                    LR_TRY(run_ntt(cQ, false, src, dst, l0, 1, l1 - l0, 2 * batch, 0, 0, nullptr, exttop));
                     for (int k = 0; k < 2; ++k) {
                         const u64 *pq = (k == 0 ? p0 : p1) + l0 * n64;
                         const u64 *ext = bx->poolQ.d + (long long)k * batch * sQ + l0 * n64;

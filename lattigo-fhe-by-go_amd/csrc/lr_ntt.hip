@@ -553,7 +553,16 @@ bool ntt_rows_disjoint(const NttLaunch &a, int logn) {
     const u64 *out_lo = a.out + (long long)a.out_limb0 * n_full;
     const u64 *out_hi = a.out + (long long)(a.batch - 1) * a.out_poly_stride + ((long long)a.out_limb0 + last * a.out_limb_step + 1) * n_full;
     const bool positive = a.in_poly_stride >= 0 && a.out_poly_stride >= 0 && a.in_limb_step >= 0 && a.out_limb_step >= 0;
-    return positive && (in_hi <= out_lo || out_hi <= in_lo);
+    if (!positive) return false;
+    if (in_hi <= out_lo || out_hi <= in_lo) return true;
+    // rows of the same polys (Rescale: the last limb's row into the rows below it): compare the row sets inside one poly
+    if (a.in != a.out || a.in_poly_stride != a.out_poly_stride || a.n_items > 256) return false;
+    const long long top_row = std::max((long long)a.in_limb0 + last * a.in_limb_step, (long long)a.out_limb0 + last * a.out_limb_step);
+    if (a.batch > 1 && a.in_poly_stride < (top_row + 1) * n_full) return false;
+    for (long long i = 0; i <= last; ++i)
+        for (long long j = 0; j <= last; ++j)
+            if (a.in_limb0 + i * a.in_limb_step == a.out_limb0 + j * a.out_limb_step) return false;
+    return true;
 }
 
 hipError_t launch_ntt(const NttLaunch &a, int logn, bool inverse, int mode, hipStream_t stream) {

@@ -268,6 +268,22 @@ def emulate_sub(make_gen, inverse, q, pretop=False):
     karg[8], karg[9], karg[10] = A_LP, A_TW, A_TWF
     karg[11] = 1                   # sub_log = 1, hole = 0
     karg[12] = 1                   # group
+    if getattr(make_gen(), "epi", False) and q < FP_LIMIT:
+        # the epilogue of the plain forward sub-blocks: out = (x - NTT(in)) * c + plus, x / plus laid out like the output
+        rng = np.random.default_rng(11)
+        xe = (rng.integers(0, 1 << 62, NF, dtype=np.uint64) % np.uint64(q)).astype(np.uint64)
+        pe = (rng.integers(0, 1 << 62, NF, dtype=np.uint64) % np.uint64(q)).astype(np.uint64)
+        xe[:3], pe[:3] = [0, q - 1, q - 1], [q - 1, 0, q - 1]
+        xe[N:N + 3], pe[N:N + 3] = [q - 1, 0, q - 1], [0, q - 1, q - 1]
+        ce = int(rng.integers(1, q))
+        A_X = mem.size * 4
+        A_P, A_EC = A_X + 8 * NF + 0x1000, A_X + 16 * NF + 0x2000
+        mem = np.concatenate([mem, np.zeros((16 * NF + 0x3000) // 4, dtype=np.uint32)])
+        place(xe, A_X)
+        place(pe, A_P)
+        place(np.array([ce, np.float64(ce) / np.float64(q)], dtype=np.float64), A_EC)
+        karg[16], karg[17], karg[18], karg[19], karg[20] = A_X, NF, A_P, NF, A_EC
+        want = np.array([((int(a) - int(b)) * ce + int(c)) % q for a, b, c in zip(xe, want, pe)], dtype=np.uint64)
     place(karg, A_KARG)
     info = ""
     for blk in range(2):
@@ -358,6 +374,8 @@ def selftest_sub(inverse=False):
         else:
             good, info = emulate_sub(lambda: Dual(lambda fp: Gen(15, 2, 1024, sub=True, fp=fp, dual=True)), False, q)
             good2, _ = emulate_sub(lambda: Dual(lambda fp: Gen(15, 2, 1024, sub=True, fused=False, fp=fp, dual=True)), False, q, pretop=True)
+            good3, _ = emulate_sub(lambda: Dual(lambda fp: Gen(15, 2, 1024, sub=True, fused=False, fp=fp, dual=True, epi=True)), False, q, pretop=True)
+            good2 = good2 and good3
             good = good and good2
         ok = ok and good
         print("%s N=2^16 sub-blocks dual q=%d (%d bits): %s; %s" % ("inverse" if inverse else "forward", q, q.bit_length(),

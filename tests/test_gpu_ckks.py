@@ -182,7 +182,23 @@ def test_mulrelin_2p16_paths(gpu_pkg, oracle, nq, np_, level, monkeypatch):
         test_switch_keys(gpu_pkg, oracle, 16, nq, np_, level)
 
 
-@pytest.mark.parametrize("logn,nq,np_,level", [(12, 18, 3, 17), (15, 5, 2, 4)])
+def test_2p16_epilogue_kernels_are_the_ones_that_run(gpu_pkg, oracle, monkeypatch):
+    """N = 2^16: ModDown's subtract-multiply-add rides in the copy-out of the plain sub-block kernels (input rows carry the top
+    stage from the extension kernel) and Rescale's in the fused-top ones (the last limb's row is read by every other row's
+    transform, batch > 1 included); parity of both is test_mulrelin_and_rescale / test_mulrelin_2p16_paths"""
+    for k in ("LR_NO_EXTTOP", "LR_NO_STAGING", "LR_NO_EPILOGUE"):
+        monkeypatch.delenv(k, raising=False)
+    N, Q, P, cQ, cP, plan, oplan, evk, pevk = _ckks(gpu_pkg, oracle, 16, 6, 2, 2)
+    level = 5
+    mk = lambda s: cQ.NewPolyLvl(level, 2).set(gpu_pkg.sampling.uniform_poly(Q[:level + 1], N, 2, seed=s))
+    out = (cQ.NewPolyLvl(level, 2), cQ.NewPolyLvl(level, 2))
+    plan.MulRelin(level, (mk(1), mk(2)), (mk(3), mk(4)), pevk, out)
+    assert cQ.last_ntt_kernel() == "lr_ntt_fwd16p_m4"
+    plan.Rescale(out)
+    assert cQ.last_ntt_kernel() == "lr_ntt_fwd16s_m4"
+
+
+@pytest.mark.parametrize("logn,nq,np_,level", [(12, 18, 3, 17), (15, 5, 2, 4), (16, 6, 2, 5)])
 def test_mulrelin_and_rescale_without_epilogue(gpu_pkg, oracle, logn, nq, np_, level, monkeypatch):
     """ModDown and the rounding rescale with the separate subtract-multiply pass instead of the forward kernels' epilogue"""
     monkeypatch.setenv("LR_NO_EPILOGUE", "1")
