@@ -209,6 +209,8 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="polynomials per GPU (workload ntt)")
     ap.add_argument("--logn", type=int, default=15)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-rings", action="store_true", help="skip the R13..R16 table (NTT / InvNTT / MulCoeffsMontgomery / ModUpSplitQP on every rank)")
+    ap.add_argument("--rings-bytes", type=int, default=1 << 30, help="bytes per operand of the R13..R16 table")
     ap.add_argument("--no-extras", action="store_true", help="skip the InvNTT / MulCoeffsMontgomery / ModUp timings")
     ap.add_argument("--no-ckks", action="store_true", help="skip the CKKS MulRelin / BFV Mul legs")
     ap.add_argument("--no-config5", action="store_true", help="skip the PN16QP1761 sharded MulRelin + gather leg")
@@ -379,6 +381,59 @@ def main():
             dist.barrier()
             dist.destroy_process_group()
         return
+
+    # --------------------------------------------------------------------------------------------------------------------
+    # the reference's benchmark rings R13..R16 (ring/params.go:10-25, ring/ring_test.go:30-36): NTT, InvNTT, MulCoeffsMontgomery and
+    # ModUpSplitQP, 1 GiB per operand on every rank (weak scaling), whole-job throughput = units of all ranks / slowest rank's time
+    # --------------------------------------------------------------------------------------------------------------------
+    def rings_leg():
+        rows = []
+        for logn in (13, 14, 15, 16):
+            Nr, Qr = params.DefaultParamsQi(logn)
+            _, Pr = params.DefaultParamsPi(logn)
+            Lr, Kr = len(Qr), len(Pr)
+            Br = max(2, args.rings_bytes // (8 * Nr * Lr)) & ~1
+            cq, cp = ring.NewContextWithParams(Nr, Qr, device=local), ring.NewContextWithParams(Nr, Pr, device=local)
+            pair = sampling.uniform_poly(Qr, Nr, 2, seed=(logn << 8) ^ rank)
+            a = cq.NewPoly(Br).set(np.concatenate([pair] * (Br // 2)))
+            b, c, pp = cq.NewPoly(Br), cq.NewPoly(Br), cp.NewPoly(Br)
+            cq.Copy(a, b)
+            be = ring.NewFastBasisExtender(cq, cp)
+            row = {"ring": "R%d" % logn, "N": Nr, "limbs": Lr, "polys_per_gpu": Br, "n_gpus": world}
+            checks = {}
+            for name, fn, nbytes, reps in (("ntt", lambda: cq.NTT(a, c), 16 * Nr * Lr * Br, 20),
+                                           ("intt", lambda: cq.InvNTT(a, c), 16 * Nr * Lr * Br, 20),
+                                           ("mulcoeffs_montgomery", lambda: cq.MulCoeffsMontgomery(a, b, c), 24 * Nr * Lr * Br, 20),
+                                           ("modup_split_qp", lambda: be.ModUpSplitQP(Lr - 1, a, pp), 8 * Nr * (Lr + Kr) * Br, 10)):
+                t_up = time.perf_counter()        # bring the device clock up (see warm_clock): ~0.1 s of the same launches
+                while time.perf_counter() - t_up < 0.1:
+                    for _ in range(reps):
+                        fn()
+                    cq.Sync()
+                barrier()
+                cq.TimerStart()
+                for _ in range(reps):
+                    fn()
+                ms = all_max(cq.TimerStop() / reps)
+                row[name] = {"poly_per_s": Br * world / (ms * 1e-3), "ms": ms, "frac_hbm_per_gpu": nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                if name in ("ntt", "intt"):
+                    row[name]["limb_ntt_per_s"] = Br * world * Lr / (ms * 1e-3)
+                    row[name]["kernel"] = cq.last_ntt_kernel()
+                if rank == 0:      # the last poly of the output against the oracle (checker only)
+                    ocr = oracle.Context(Nr, Qr)
+                    x = pair[(Br - 1) % 2]
+                    if name == "modup_split_qp":
+                        want = oracle.BasisExtender(ocr, oracle.Context(Nr, Pr)).modup_split_qp(Lr - 1, x)
+                        got = np.stack(pp.get_limb_slices(Br - 1))
+                    else:
+                        want = {"ntt": ocr.ntt, "intt": ocr.intt, "mulcoeffs_montgomery": lambda v: ocr.ewise("MUL_MONT", v, v)}[name](x)
+                        got = np.stack(c.get_limb_slices(Br - 1))
+                    checks[name] = bool(np.array_equal(got, want))
+            if rank == 0:
+                row["bit_exact"] = all(checks.values())
+            rows.append(row)
+            del a, b, c, pp, be, cq, cp
+        return rows
 
     # --------------------------------------------------------------------------------------------------------------------
     # headline: forward NTT on R15
@@ -590,6 +645,12 @@ def main():
         progress("extras timed")
 
     del src, dst
+    if not args.no_rings:
+        progress("rings R13..R16: NTT / InvNTT / MulCoeffsMontgomery / ModUpSplitQP on every rank")
+        rings = rings_leg()
+        if rank == 0:
+            out["rings"] = rings
+        progress("rings timed")
     if not args.no_config5 and not args.no_ckks:
         progress("config 5 leg: PN16QP1761, %d products per GPU" % args.config5_units)
         c5 = config5_leg(3, 1)
