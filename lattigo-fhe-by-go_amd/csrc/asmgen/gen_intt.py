@@ -18,16 +18,22 @@ generation time inside a pass and applied unconditionally on the first stage of 
 import sys
 
 from gen_ntt import T, Dual, Gen, kernel_text_for
-from isa import Neg, s, v
+from isa import EXEC, Neg, s, v
 
 
 class GenInv(Gen):
     """mode 1: every modulus in (2^33, 2^60], bound B = 8q as described above;
        mode 0: moduli up to 2^61: B = 4q and every butterfly corrects."""
 
-    def __init__(self, logn, mode=1, threads=1024, sub=False, fp=False, dual=False):
+    def __init__(self, logn, mode=1, threads=1024, sub=False, fp=False, dual=False, fuse_last=False):
         assert mode in (0, 1)
         super().__init__(logn, mode, threads, sub, fp=fp, dual=dual)
+        # fuse_last (sub-block kernels of N = 2^16): no ntt_top_kernel pass afterwards.  Every wave stores its lazy rows, makes them
+        # visible to the device and bumps the flag it shares with the same wave of the limb's other sub-block; the wave that finds
+        # the flag already bumped (its partner's rows are complete) loads them and finishes both halves: last stage + scaling.
+        # Nothing ever waits for the other block, so the order in which the two run does not matter.
+        assert not fuse_last or sub
+        self.fuse_last = fuse_last
         # FP64 body: inputs below 2^52 (the contract is < 4q, q < 2^46).  A Gentleman-Sande stage doubles the bound of its
         # sums; products come back within q.  With B the bound in units of q (4 on entry), a stage needs B <= 16 (|U - V| <=
         # 2^51 keeps the quotient estimate within one); the sums of the stage that would leave B = 32 are reduced to q/2.
@@ -444,7 +450,7 @@ class GenInv(Gen):
                         items.append(lambda ts, U=X[col * RA + i], V=X[col * RA + (i | (1 << b))]: self.ops_last(ts, U, V, tw_n, tw_wn))
                 self.zip_emit(items)
 
-    def store_columns(self):
+    def store_columns(self, hint="nt"):
         e = self.e
         self.c("coalesced store of the columns {k*S + t + c*T}")
         e("v_lshlrev_b32", self.GOFF, 3, self.TID)
@@ -456,9 +462,95 @@ class GenInv(Gen):
         for k in range(self.RA):
             for col in range(self.C):
                 off, imm = self.col_addr(col)
-                e("global_store_dwordx2", off, self.X[col * self.RA + k], self.DST, offset=imm, hint="nt")
+                e("global_store_dwordx2", off, self.X[col * self.RA + k], self.DST, offset=imm, hint=hint)
             e("s_add_u32", self.DST.lo(), self.DST.lo(), self.S * 8)
             e("s_addc_u32", self.DST.hi(), self.DST.hi(), 0)
+
+    def fused_last(self):
+        e, X, sc = self.e, self.X, self.SC
+        ts0 = self.ts[0]
+        assert self.C == 1 and self.RA == 32
+        tag = "fp" if self.fp else "int"
+        # own half (lazy / canonical integers) with device-scope stores: written through this XCD's L2, complete when vmcnt says so
+        # (a buffer_wbl2 per wave instead would sweep the whole L2 every time: measured 4x slower for the launch); DST ends at own base + 8N
+        self.store_columns(hint="sc1")
+        self.c("release: the rows are visible to the device, then the pair flag")
+        e("s_waitcnt", "vmcnt(0)")
+        K = 36
+        self.unpark(s(K, 4))                                  # s[K:K+1] flag address, s[K+2:K+3] LimbParams address
+        # one increment per wave, by lane 0 alone (64 lanes on one address would queue 1024 operations per workgroup on the one
+        # cache line its sixteen flags share)
+        e("v_mov_b32", ts0.T0, 0)
+        e("v_mov_b32", ts0.T2, 1)
+        e("s_mov_b64", EXEC, 1)
+        e("global_atomic_add", ts0.Q.lo(), ts0.T0, ts0.T2, s(K, 2), hint="sc0")
+        e("s_mov_b64", EXEC, -1)
+        W = tuple(s(K + 4 + i) for i in range(4))              # psi_inv[1] * N^-1: index 0 of the inverse table (FP table in the FP body)
+        e("s_load_dwordx4", s(K + 4, 4), self.TW, 0)
+        if self.fp:
+            tw_n = (self.NINV.lo(), self.NINV.hi(), self.NINVQ.lo(), self.NINVQ.hi())
+        else:
+            tw_n = tuple(s(K + 8 + i) for i in range(4))
+            e("s_load_dwordx4", s(K + 8, 4), s(K + 2, 2), 40)  # LimbParams: N^-1 and its Shoup companion (dwords 10..13)
+        e("s_waitcnt", "vmcnt(0) lgkmcnt(0)")
+        e("v_readfirstlane_b32", sc[0], ts0.Q.lo())
+        e("s_nop", 4)
+        e("s_cmp_ge_u32", sc[0], 1)
+        e("s_cbranch_scc1", "L_second_" + tag)
+        e("s_endpgm")                                          # first of the pair: the partner finishes the limb
+        self.p.label("L_second_" + tag)
+        # acquire: the partner's rows are read with device-scope loads below (no buffer_inv: it would drop the XCD's whole L2,
+        # twiddle tables included, once per wave); the flag goes back to 0
+        e("s_mov_b64", EXEC, 1)
+        e("global_store_dword", ts0.T0, ts0.T0, s(K, 2))
+        e("s_mov_b64", EXEC, -1)
+        # bases: low half = DST - BLK1 * 8N (DST sits 8N past this block's rows), the partner's rows = the other half
+        LOB, HIB, PART = s(K + 16, 2), s(K + 18, 2), s(K + 20, 2)
+        e("s_lshl_b32", sc[1], self.BLK1, self.logn + 3)
+        e("s_sub_u32", LOB.lo(), self.DST.lo(), sc[1])
+        e("s_subb_u32", LOB.hi(), self.DST.hi(), 0)
+        e("s_add_u32", HIB.lo(), LOB.lo(), self.N * 8)
+        e("s_addc_u32", HIB.hi(), LOB.hi(), 0)
+        # (mine - partner) * w' with w' = w for block 0 and -w for block 1, so that the products are (A - B) * w either way
+        NW = tuple(s(K + 12 + i) for i in range(4))
+        if self.fp:
+            e("s_mov_b32", NW[0], W[0])
+            e("s_xor_b32", NW[1], W[1], 0x80000000)
+            e("s_mov_b32", NW[2], W[2])
+            e("s_xor_b32", NW[3], W[3], 0x80000000)
+        else:
+            e("s_sub_u32", NW[0], self.Qm.lo(), W[0])
+            e("s_subb_u32", NW[1], self.Qm.hi(), W[1])
+            e("s_not_b32", NW[2], W[2])                       # floor((q - w) * 2^64 / q) = 2^64 - 1 - floor(w * 2^64 / q), 0 < w < q
+            e("s_not_b32", NW[3], W[3])
+        e("s_cmp_eq_u32", self.BLK1, 1)
+        for i in range(4):
+            e("s_cselect_b32", W[i], W[i], NW[i])
+        e("s_cselect_b32", PART.lo(), HIB.lo(), LOB.lo())
+        e("s_cselect_b32", PART.hi(), HIB.hi(), LOB.hi())
+        P = [v(self.tw_base + 2 * i, 2) for i in range(16)]
+        for chunk in range(2):
+            for i in range(16):
+                e("global_load_dwordx2", P[i], self.GOFF, PART, hint="sc1")
+                e("s_add_u32", PART.lo(), PART.lo(), self.S * 8)
+                e("s_addc_u32", PART.hi(), PART.hi(), 0)
+            for i in range(0, 16, 2):
+                # loads return in order; the stores of the previous chunk still in flight only make the wait longer
+                e("s_waitcnt", "vmcnt(%d)" % (14 - i))
+                items = []
+                for d in range(2):
+                    U, V = X[16 * chunk + i + d], P[i + d]
+                    if self.fp:
+                        items.append(lambda ts, U=U, V=V: self.ops_ingest_small(ts, U) + self.ops_ingest_small(ts, V) + self.ops_last(ts, U, V, tw_n, W))
+                    else:
+                        items.append(lambda ts, U=U, V=V: self.ops_last(ts, U, V, tw_n, W))
+                self.zip_emit(items)
+            for i in range(16):
+                e("global_store_dwordx2", self.GOFF, X[16 * chunk + i], LOB, hint="nt")
+                e("global_store_dwordx2", self.GOFF, P[i], HIB, hint="nt")
+                for ptr in (LOB, HIB):
+                    e("s_add_u32", ptr.lo(), ptr.lo(), self.S * 8)
+                    e("s_addc_u32", ptr.hi(), ptr.hi(), 0)
 
     def build(self):
         self.plan = self.chunk_plan()
@@ -476,7 +568,10 @@ class GenInv(Gen):
                 self.chunk_load(1)
             self.column_read(half)
         self.pass_a()
-        self.store_columns()
+        if self.fuse_last:
+            self.fused_last()
+        else:
+            self.store_columns()
         self.e("s_endpgm")
         return self.p
 
@@ -491,8 +586,9 @@ if __name__ == "__main__":
             return Dual(lambda fp: GenInv(logn_, 1, threads_, fp=fp, dual=True, **kw))
         return GenInv(logn_, mode, threads_, **kw)
 
-    if logn == 16:
-        open(sys.argv[2], "w").write(kernel_text_for(make(15, 1024, sub=True), "lr_ntt_inv16s_m%d" % mode))
+    if logn == 16:      # "s": lazy sub-blocks, ntt_top_kernel follows; "f": the last stage fused (pair flags in NttLaunch::epi_x)
+        fused = len(sys.argv) > 5 and sys.argv[5] == "fused"
+        open(sys.argv[2], "w").write(kernel_text_for(make(15, 1024, sub=True, fuse_last=fused), "lr_ntt_inv16%s_m%d" % ("f" if fused else "s", mode)))
         sys.exit(0)
     name = "lr_ntt_inv%d%s_m%d" % (logn, "x" if threads < 1024 else "", mode)
     open(sys.argv[2], "w").write(kernel_text_for(make(logn, threads), name))

@@ -44,6 +44,7 @@ class Gen:
         # (N = 2^16: only the plain sub-block kernels, i.e. after the top stage has been applied by the basis extension)
         assert not epi or dual
         self.fp, self.dual, self.epi = fp, dual, epi
+        self.fuse_last = False        # inverse sub-block kernels (gen_intt.py): the last stage by whichever block of the pair finishes second
         self.mark = None
         assert not sub or (logn == 15 and threads == 1024)
         self.fused = fused            # forward sub-block kernels: compute the top stage while loading (out of place only)
@@ -395,6 +396,8 @@ class Gen:
         if self.dual:
             e("s_load_dwordx4", s(84, 4), self.KARG, 104)     # fp_tw_delta, fp_fin_delta
             e("s_load_dwordx2", s(92, 2), self.KARG, 120)     # fp_lp
+        if self.fuse_last:
+            e("s_load_dwordx2", s(64, 2), self.KARG, 128)     # epi_x: the pair flags of the launch
         e("v_mov_b32", self.TID, v(0))
         for ts in self.ts:
             e("v_mov_b32", ts.Z1, 0)
@@ -446,6 +449,8 @@ class Gen:
         e("s_add_u32", self.TMP.lo(), s(52), sc[3])
         e("s_addc_u32", self.TMP.hi(), s(53), 0)
         e("s_load_dwordx16", s(68, 16), self.TMP, 0)
+        if self.fuse_last:
+            self.park_pair_state(sc)
         if self.dual:
             # FpLimb (32 bytes) of this modulus: q = 0.0 marks a limb the FP body does not take
             e("s_lshl_b32", sc[3], sc[0], 5)
@@ -483,6 +488,27 @@ class Gen:
         e("v_mov_b32", v(2), self.KARG.lo())
         e("v_mov_b32", v(3), self.KARG.hi())
         e("ds_write_b64", v(4), v(2, 2))
+
+    def park_pair_state(self, sc):
+        """inverse sub-block kernels with the fused last stage: the address of this wave's pair flag (flags[(poly * n_items + limb) * 16
+        + wave], u32) and of the limb's LimbParams wait in the same padding as park_kernarg's"""
+        e = self.e
+        e("s_mul_i32", sc[3], self.WGY, s(50))                 # poly * n_items
+        e("s_add_u32", sc[3], sc[3], self.WGX)
+        e("s_lshl_b32", sc[3], sc[3], 4)
+        e("s_add_u32", sc[3], sc[3], self.WAVE)
+        e("s_lshl_b32", sc[3], sc[3], 2)
+        e("s_add_u32", s(64), s(64), sc[3])
+        e("s_addc_u32", s(65), s(65), 0)
+        e("s_mul_i32", sc[3], self.WAVE, 9216)
+        e("s_add_u32", sc[3], sc[3], 128)
+        e("v_mov_b32", v(4), sc[3])
+        e("v_mov_b32", v(2), s(64))
+        e("v_mov_b32", v(3), s(65))
+        e("ds_write_b64", v(4), v(2, 2))
+        e("v_mov_b32", v(2), self.TMP.lo())
+        e("v_mov_b32", v(3), self.TMP.hi())
+        e("ds_write_b64", v(4), v(2, 2), offset=8)
 
     def park_ids(self):
         e = self.e
@@ -1084,7 +1110,7 @@ class Dual:
 
     def __init__(self, make):
         self.gf, self.gi = make(True), make(False)
-        for k in ("logn", "T", "SPH", "A", "N", "sub", "WGX", "WGY", "epi"):
+        for k in ("logn", "T", "SPH", "A", "N", "sub", "WGX", "WGY", "epi", "fuse_last"):
             setattr(self, k, getattr(self.gf, k))
         self.p = None
 
@@ -1092,7 +1118,8 @@ class Dual:
         pf, pi = self.gf.build(), self.gi.build()
         mf, mi = self.gf.mark, self.gi.mark
         assert mf is not None and mf == mi and repr(pf.ins[:mf]) == repr(pi.ins[:mi]), "the two bodies must share their prologue"
-        assert not any(op == "@" for op, _, _ in pf.ins[mf:] + pi.ins[mi:])       # labels only in the shared prologue (stagger)
+        body_labels = [a[0] for op, a, _ in pf.ins[mf:] + pi.ins[mi:] if op == "@"]
+        assert len(body_labels) == len(set(body_labels))                          # the bodies' own labels must not collide
         p = Program()
         p.ins = list(pf.ins)
         p.label("INT_BODY")

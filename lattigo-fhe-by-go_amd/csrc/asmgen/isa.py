@@ -19,6 +19,8 @@ class Reg:
         self.kind, self.idx, self.n = kind, idx, n
 
     def __repr__(self):
+        if self.kind == "exec":
+            return "exec"
         if self.kind == "vcc":
             return "vcc"
         if self.n == 1:
@@ -52,6 +54,7 @@ def s(i, n=1):
 
 
 VCC = Reg("vcc", 0, 2)
+EXEC = Reg("exec", 0, 2)      # written by s_mov_b64 only; the emulator lets nothing but the flag atomics / stores run under a partial mask
 
 
 class Neg:
@@ -219,6 +222,7 @@ class Machine:
         """branches must be workgroup-uniform (the kernels only loop on launch-wide counters)"""
         labels = {args[0]: k for k, (op, args, _) in enumerate(prog.ins) if op == "@"}
         self.executed = {}
+        self.exec_lanes = np.ones(self.T, dtype=bool)
         pc = 0
         with np.errstate(over="ignore"):
             while pc < len(prog.ins):
@@ -233,6 +237,8 @@ class Machine:
                     continue
                 if op == "s_endpgm":
                     break
+                if not self.exec_lanes.all():
+                    assert op in ("global_atomic_add", "global_store_dword", "s_mov_b64", "s_waitcnt", "s_nop"), "%s under a partial exec mask" % op
                 self.executed[op] = self.executed.get(op, 0) + 1
                 self.cur_pc = pc - 1
                 getattr(self, "i_" + op)(*args, **mods)
@@ -376,6 +382,11 @@ class Machine:
         self.ws(d, np.full(self.W, int(a) & 0xFFFFFFFF, dtype=np.uint32))
 
     def i_s_mov_b64(self, d, a):
+        if d.kind == "exec":
+            assert not isinstance(a, Reg)
+            m = int(a) & 0xFFFFFFFFFFFFFFFF
+            self.exec_lanes = np.tile(np.array([(m >> l) & 1 for l in range(WAVE)], dtype=bool), self.W)
+            return
         if isinstance(a, Reg):
             self.ws(d, self.rs(a, 0), 0)
             self.ws(d, self.rs(a, 1), 1)
@@ -435,6 +446,12 @@ class Machine:
     def i_s_or_b32(self, d, a, b):
         self.ws(d, self.rs(a) | self.rs(b))
 
+    def i_s_xor_b32(self, d, a, b):
+        self.ws(d, self.rs(a) ^ self.rs(b))
+
+    def i_s_not_b32(self, d, a):
+        self.ws(d, ~self.rs(a))
+
     def i_s_lshl_b64(self, d, a, b):
         r = self.rs64(a) << (self.rs(b).astype(np.uint64) & np.uint64(63))
         self.ws(d, r & np.uint64(0xFFFFFFFF), 0)
@@ -483,7 +500,26 @@ class Machine:
 
     def i_global_store_dword(self, voff, data, sbase, offset=0, hint=""):
         addr = self._gaddr(voff, sbase, offset)
-        self.mem[(addr // 4).astype(np.int64)] = self.rv(data)
+        m = self.exec_lanes
+        self.mem[(addr // 4).astype(np.int64)[m]] = self.rv(data)[m]
+
+    def i_global_atomic_add(self, d, voff, data, sbase, offset=0, hint=""):
+        """32-bit add with the pre-op value returned (sc0); the lanes of the workgroup take their turns in lane order"""
+        assert "sc0" in hint
+        idx = (self._gaddr(voff, sbase, offset) // 4).astype(np.int64)
+        add = self.rv(data)
+        old = np.zeros(self.T, dtype=np.uint32)
+        for lane in np.nonzero(self.exec_lanes)[0]:
+            old[lane] = self.mem[idx[lane]]
+            self.mem[idx[lane]] = np.uint32((int(old[lane]) + int(add[lane])) & 0xFFFFFFFF)
+        self.wv(d, old)
+
+    # cache maintenance: the emulator's memory is always coherent
+    def i_buffer_wbl2(self, hint=""):
+        pass
+
+    def i_buffer_inv(self, hint=""):
+        pass
 
     def i_s_waitcnt(self, *a, **m):
         pass

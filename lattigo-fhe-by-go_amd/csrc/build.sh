@@ -39,21 +39,22 @@ done
 # measured best plan per degree and direction: 2^14: 512 threads; 2^13: 256 forward / 512 inverse; 2^12: 256
 for m in 0 1 2; do gen_one fwd 14 $m 512 & gpids+=($!); gen_one fwd 13 $m 256 & gpids+=($!); gen_one fwd 12 $m 256 & gpids+=($!); done
 for m in 0 1; do gen_one inv 14 $m 512 & gpids+=($!); gen_one inv 13 $m 512 & gpids+=($!); gen_one inv 12 $m 256 & gpids+=($!); done
-# N = 2^16: 2^15 sub-block kernels (forward with the top stage fused into the loads = s, plain = p; inverse = s)
+# N = 2^16: 2^15 sub-block kernels (forward with the top stage fused into the loads = s, plain = p; inverse: lazy = s, with the
+# last stage by the second finisher of each pair = f)
 gen_sub() {  # kind tag mode [plain]
   python3 asmgen/gen_$( [ "$1" = fwd ] && echo ntt || echo intt ).py 16 build/ntt_$1$2_m$3.s $3 1024 $4
   $LLVM/clang -x assembler -target amdgcn-amd-amdhsa -mcpu=gfx950 -c build/ntt_$1$2_m$3.s -o build/ntt_$1$2_m$3.o
   $LLVM/ld.lld -shared build/ntt_$1$2_m$3.o -o build/ntt_$1$2_m$3.hsaco
 }
 for m in 0 1 2; do gen_sub fwd 16s $m & gpids+=($!); gen_sub fwd 16p $m plain & gpids+=($!); done
-for m in 0 1; do gen_sub inv 16s $m & gpids+=($!); done
+for m in 0 1; do gen_sub inv 16s $m & gpids+=($!); gen_sub inv 16f $m fused & gpids+=($!); done
 # dual kernels (mode 3): FP64 body for the limbs below 2^46, integer mode-2 body for the others
 gen_one fwd 14 3 & gpids+=($!); gen_one fwd 15 3 & gpids+=($!)
 gen_one fwd 14 3 512 & gpids+=($!); gen_one fwd 13 3 256 & gpids+=($!); gen_one fwd 12 3 256 & gpids+=($!)
 gen_sub fwd 16s 3 & gpids+=($!); gen_sub fwd 16p 3 plain & gpids+=($!)
 gen_one inv 14 3 & gpids+=($!); gen_one inv 15 3 & gpids+=($!)
 gen_one inv 14 3 512 & gpids+=($!); gen_one inv 13 3 512 & gpids+=($!); gen_one inv 12 3 256 & gpids+=($!)
-gen_sub inv 16s 3 & gpids+=($!)
+gen_sub inv 16s 3 & gpids+=($!); gen_sub inv 16f 3 fused & gpids+=($!)
 # mode 4: the dual forward kernels with the subtract-multiply-add epilogue on the FP64 body (ModDown inside the key switch)
 gen_one fwd 14 4 & gpids+=($!); gen_one fwd 15 4 & gpids+=($!)
 gen_one fwd 14 4 512 & gpids+=($!); gen_one fwd 13 4 256 & gpids+=($!); gen_one fwd 12 4 256 & gpids+=($!)
@@ -66,8 +67,8 @@ for p in "${gpids[@]}"; do wait $p; done
 python3 - <<'PY'
 out = ['struct lr_asm_blob { const char *name; const unsigned char *data; unsigned long size; };']
 names = [("fwd", n, m) for n in (14, 15) for m in (0, 1, 2)] + [("inv", n, m) for n in (14, 15) for m in (0, 1)]
-names += [("fwd", n, m) for n in ("12x", "13x", "14x", "16s", "16p") for m in (0, 1, 2)] + [("inv", n, m) for n in ("12x", "13x", "14x", "16s") for m in (0, 1)]
-names += [("fwd", n, 3) for n in (14, 15, "12x", "13x", "14x", "16s", "16p")] + [("inv", n, 3) for n in (14, 15, "12x", "13x", "14x", "16s")]
+names += [("fwd", n, m) for n in ("12x", "13x", "14x", "16s", "16p") for m in (0, 1, 2)] + [("inv", n, m) for n in ("12x", "13x", "14x", "16s", "16f") for m in (0, 1)]
+names += [("fwd", n, 3) for n in (14, 15, "12x", "13x", "14x", "16s", "16p")] + [("inv", n, 3) for n in (14, 15, "12x", "13x", "14x", "16s", "16f")]
 names += [("fwd", n, 4) for n in (14, 15, "12x", "13x", "14x", "16s", "16p")]
 names = [(k, n, str(m)) for k, n, m in names] + [("fwd", 15, "1t")]
 for k, n, m in names:

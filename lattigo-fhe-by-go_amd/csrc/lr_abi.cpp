@@ -159,6 +159,7 @@ lr::Options lr::Options::from_env() {
     o.ext_narrow = std::getenv("LR_EXT_NARROW") != nullptr;
     o.asm14_1024 = std::getenv("LR_ASM_14_1024") != nullptr;
     o.no_exttop = std::getenv("LR_NO_EXTTOP") != nullptr;
+    o.no_invfuse = std::getenv("LR_NO_INVFUSE") != nullptr;
     o.keymac_narrow = std::getenv("LR_KEYMAC_NARROW") != nullptr;
     o.timeline = std::getenv("LR_NTT_TIMELINE") != nullptr;
     if (const char *v = std::getenv("LR_NTT_MODE")) o.ntt_mode = std::atoi(v);
@@ -956,6 +957,17 @@ int run_ntt_launch(lr_context *c, bool inverse, Rows in, Rows out, int mod0, int
             sub.in_limb0 = a.out_limb0;
             sub.in_limb_step = a.out_limb_step;
             LR_HIP(launch_ntt_asm16(sub, 0, 'p', variant, c->stream, kn, c->opt.stagger));
+            return LR_OK;
+        }
+        if (!c->opt.no_invfuse && hole == 0) {
+            // the last stage inside the sub-block kernels: the wave that finishes second of a limb's two sub-blocks combines both
+            // halves (gen_intt.py: fused_last); one u32 flag per wave pair, zeroed here, addressed through NttLaunch::epi_x
+            ScratchLease flags;
+            const size_t flag_bytes = (size_t)batch * (size_t)count * 16 * sizeof(u32);
+            LR_TRY(flags.take(&c->scratch, (flag_bytes + 7) / 8));
+            LR_HIP(hipMemsetAsync(flags.d(), 0, flag_bytes, c->stream));
+            a.epi_x = flags.d();
+            LR_HIP(launch_ntt_asm16(a, 1, 'f', variant, c->stream, kn, c->opt.stagger));
             return LR_OK;
         }
         LR_HIP(launch_ntt_asm16(a, 1, 's', variant, c->stream, kn, c->opt.stagger));

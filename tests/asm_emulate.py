@@ -197,7 +197,7 @@ def fp_test_moduli(logn):
     return [p, params.GenerateNTTPrimes(30, logn, 1)[0], params.GenerateNTTPrimes(46, logn, 1)[0]]
 
 
-def emulate_sub(make_gen, inverse, q, pretop=False):
+def emulate_sub(make_gen, inverse, q, pretop=False, order=(0, 1)):
     """N = 2^16 through the two sub-block workgroups of one limb; returns (bit-exact?, summary)"""
     import numpy as np
 
@@ -268,6 +268,12 @@ def emulate_sub(make_gen, inverse, q, pretop=False):
     karg[8], karg[9], karg[10] = A_LP, A_TW, A_TWF
     karg[11] = 1                   # sub_log = 1, hole = 0
     karg[12] = 1                   # group
+    fuse_last = getattr(make_gen(), "fuse_last", False)
+    if fuse_last:
+        # inverse with the fused last stage: the launch's pair flags (one u32 per wave of a limb's two sub-blocks), zeroed by the host
+        A_FLAGS = mem.size * 4
+        mem = np.concatenate([mem, np.zeros(0x1000 // 4, dtype=np.uint32)])
+        karg[16] = A_FLAGS
     if getattr(make_gen(), "epi", False) and q < FP_LIMIT:
         # the epilogue of the plain forward sub-blocks: out = (x - NTT(in)) * c + plus, x / plus laid out like the output
         rng = np.random.default_rng(11)
@@ -286,7 +292,7 @@ def emulate_sub(make_gen, inverse, q, pretop=False):
         want = np.array([((int(a) - int(b)) * ce + int(c)) % q for a, b, c in zip(xe, want, pe)], dtype=np.uint64)
     place(karg, A_KARG)
     info = ""
-    for blk in range(2):
+    for blk in order:
         gen = make_gen()
         prog = gen.build()
         m = Machine(gen.T, 160 * 1024, mem.size)
@@ -301,7 +307,9 @@ def emulate_sub(make_gen, inverse, q, pretop=False):
         cnt = prog.count()
         info = "%d instructions, %d VALU" % (len(prog.ins), sum(n for op, n in cnt.items() if op.startswith("v_")))
     got = mem[A_OUT // 4: A_OUT // 4 + 2 * NF].view(np.uint64).copy()
-    if inverse:
+    if fuse_last:
+        assert not mem[A_FLAGS // 4: A_FLAGS // 4 + 0x400].any(), "the pair flags must be back at zero"
+    elif inverse:
         # what ntt_top_kernel does next: last Gentleman-Sande stage and the scaling
         U = [int(a) for a in got[:N]]
         V = [int(a) for a in got[N:]]
@@ -360,6 +368,11 @@ def selftest_sub(inverse=False):
         else:
             make = lambda: Gen(15, mode, 1024, sub=True)
         good, info = emulate_sub(make, inverse, q)
+        if inverse:
+            # the pair-flag kernels (last stage by whichever sub-block finishes second), both orders
+            for order in ((0, 1), (1, 0)):
+                g2, _ = emulate_sub(lambda: GenInv(15, mode, 1024, sub=True, fuse_last=True), True, q, order=order)
+                good = good and g2
         if not inverse:
             # the plain variant continues from the output of the separate top-stage pass
             good2, _ = emulate_sub(lambda: Gen(15, mode, 1024, sub=True, fused=False), inverse, q, pretop=True)
@@ -371,6 +384,9 @@ def selftest_sub(inverse=False):
         if inverse:
             from gen_intt import GenInv
             good, info = emulate_sub(lambda: Dual(lambda fp: GenInv(15, 1, 1024, sub=True, fp=fp, dual=True)), True, q)
+            for order in ((0, 1), (1, 0)):
+                g2, _ = emulate_sub(lambda: Dual(lambda fp: GenInv(15, 1, 1024, sub=True, fp=fp, dual=True, fuse_last=True)), True, q, order=order)
+                good = good and g2
         else:
             good, info = emulate_sub(lambda: Dual(lambda fp: Gen(15, 2, 1024, sub=True, fp=fp, dual=True)), False, q)
             good2, _ = emulate_sub(lambda: Dual(lambda fp: Gen(15, 2, 1024, sub=True, fused=False, fp=fp, dual=True)), False, q, pretop=True)

@@ -281,6 +281,43 @@ def test_cxx_and_asm_inverse_paths_agree(gpu_pkg, oracle, logn, kind, force, mon
         assert np.array_equal(p.get(), np.stack([[x[b, i] % np.uint64(q) for i, q in enumerate(moduli)] for b in range(2)]))
 
 
+@pytest.mark.parametrize("kind,force,kernel", [("qi60", None, "lr_ntt_inv16f_m1"), ("qi60", "0", "lr_ntt_inv16f_m0"), ("fpedge", None, "lr_ntt_inv16f_m3")])
+def test_inverse_2p16_pair_flag_kernels(gpu_pkg, oracle, kind, force, kernel, monkeypatch):
+    """N = 2^16 inverse: the two sub-block workgroups of a limb finish in either order and on different XCDs; whichever wave of
+    a pair comes second combines both halves (gen_intt.py: fused_last).  A batch large enough that partners run far apart
+    (256 polys x 3..4 limbs = 1500..2000 workgroups on 256 CUs), every output compared with the oracle, launched repeatedly (the
+    flags are zeroed per launch), out of place and in place; then the same through the separate last-stage pass (LR_NO_INVFUSE)"""
+    N = 1 << 16
+    moduli = _asm_moduli(gpu_pkg, kind, 16)[:4]
+    limbs = len(moduli)
+    oc = oracle.Context(N, moduli)
+    x = gpu_pkg.sampling.random_u64((2, limbs, N), seed=161)
+    for i, q in enumerate(moduli):
+        x[:, i] %= np.uint64(4 * q)
+    want = [oc.intt(np.array([[int(v) % q for v in x[b, i]] for i, q in enumerate(moduli)], dtype=np.uint64)) for b in range(2)]
+    if force is not None:
+        monkeypatch.setenv("LR_ASM_VARIANT", force)
+    else:
+        monkeypatch.delenv("LR_ASM_VARIANT", raising=False)
+    B = 256
+    tiled = np.concatenate([x] * (B // 2))
+    for unfused in (False, True):
+        if unfused:
+            monkeypatch.setenv("LR_NO_INVFUSE", "1")
+        else:
+            monkeypatch.delenv("LR_NO_INVFUSE", raising=False)
+        ctx = gpu_pkg.ring.NewContextWithParams(N, moduli)
+        p, r = ctx.NewPoly(B).set(tiled), ctx.NewPoly(B)
+        for rep in range(3):
+            ctx.InvNTT(p, r)
+        assert ctx.last_ntt_kernel() == (kernel.replace("16f", "16s") if unfused else kernel)
+        got = r.get()
+        for b in range(B):
+            assert np.array_equal(got[b], want[b % 2]), (unfused, b)
+        ctx.InvNTT(p, p)
+        assert np.array_equal(p.get(), got), unfused
+
+
 @pytest.mark.parametrize("kind", ["qi60", "ckks", "bfv60", "fp"])
 def test_asm_2p14_both_plans(gpu_pkg, oracle, kind, monkeypatch):
     """N = 2^14 has two assembly plans: 512 threads / two columns per thread / two workgroups per CU (default) and
