@@ -172,6 +172,22 @@ __device__ __forceinline__ u64 bred_word(u64 x, u64 p, u64 p2, u32 u) {
 // psi[1] from the target limb's forward table -- so that the 2^15 sub-block transforms that follow read their own half only
 // (the "p" kernels) instead of both halves (the fused "s" kernels, 1.5 x the traffic).  The transform is the canonical one either
 // way: its first stage has merely moved into the kernel that produces its input.
+// constants of one target limb (column of the extension tables), wave-uniform
+template <int NIN>
+struct ExtColumn {
+    u64 pj, bh, nq;
+    ulonglong2 c[NIN], tw;
+    __device__ __forceinline__ void load(const ExtTables &t, int col, const Twiddle *top_tw, int top_mod, int n) {
+        pj = ld_const(t.P + col);
+        bh = ld_const(t.bredP_hi + col);
+        nq = ld_const(t.qpj_inv + (long long)col * (t.nQ + 1) + 1);
+#pragma unroll
+        for (int i = 0; i < NIN; ++i) c[i] = ld_const(t.qispj_shoup + (long long)i * t.nP + col);
+        // twiddle of the stage over index bit logN - 1: heap entry 1 of the target limb's forward table {w, floor(w 2^64 / p)}
+        tw = top_tw ? ld_const(reinterpret_cast<const ulonglong2 *>(top_tw) + ((long long)top_mod * n + 1)) : make_ulonglong2(0, 0);
+    }
+};
+
 template <int NIN, int W, bool TOP>
 __global__ __launch_bounds__(256) void ext_sum_kernel(ExtLaunch L) {
     constexpr int C = TOP ? 2 * W : W;                         // coefficient columns per thread
@@ -214,16 +230,20 @@ __global__ __launch_bounds__(256) void ext_sum_kernel(ExtLaunch L) {
     for (int s = 0; s < kExtSegments; ++s) {
         const ExtSegment sg = L.seg[s];
         u64 *out = sg.out + b * sg.stride + (long long)sg.limb0 * L.n + W * xw;
+        // the per-target constants of column jj + 1 are requested (scalar loads) before column jj's arithmetic starts, so that their
+        // latency runs under ~200 vector instructions instead of in front of them
+        ExtColumn<NIN> next;
+        if (sg.count > 0) next.load(L.t, sg.col0, TOP ? sg.top_tw : nullptr, sg.top_mod0, L.n);
         for (int jj = 0; jj < sg.count; ++jj) {
-            const int col = sg.col0 + jj;
-            const u64 pj = ld_const(L.t.P + col), bh = ld_const(L.t.bredP_hi + col);
-            const u64 nq = ld_const(L.t.qpj_inv + (long long)col * (L.t.nQ + 1) + 1);
+            const ExtColumn<NIN> cur = next;
+            if (jj + 1 < sg.count) next.load(L.t, sg.col0 + jj + 1, TOP ? sg.top_tw : nullptr, sg.top_mod0 + jj + 1, L.n);
+            const u64 pj = cur.pj, bh = cur.bh, nq = cur.nq;
             u64 lo[C], hi[C], qs[C], xs[C];
 #pragma unroll
             for (int w = 0; w < C; ++w) lo[w] = hi[w] = qs[w] = xs[w] = 0;
 #pragma unroll
             for (int i = 0; i < NIN; ++i) {
-                const ulonglong2 c = ld_const(L.t.qispj_shoup + (long long)i * L.t.nP + col);
+                const ulonglong2 c = cur.c[i];
                 const u32 w0 = (u32)c.x, w1 = (u32)(c.x >> 32), s0 = (u32)c.y, s1 = (u32)(c.y >> 32);
 #pragma unroll
                 for (int w = 0; w < C; ++w) {
@@ -254,8 +274,7 @@ __global__ __launch_bounds__(256) void ext_sum_kernel(ExtLaunch L) {
                 r[w] = bred_word(lo[w] + (hi[w] << 32), pj, pj << 1, (u32)bh);
             }
             if constexpr (TOP) {
-                // twiddle of the stage over index bit logN - 1: heap entry 1 of the target limb's forward table {w, floor(w 2^64 / p)}
-                const ulonglong2 tw = ld_const(reinterpret_cast<const ulonglong2 *>(sg.top_tw) + ((long long)(sg.top_mod0 + jj) * L.n + 1));
+                const ulonglong2 tw = cur.tw;
 #pragma unroll
                 for (int w = 0; w < W; ++w) {
                     const u64 t = mul_shoup_exact(r[W + w], tw.x, tw.y, pj);       // in [0, 2p)
