@@ -88,6 +88,10 @@ int lr_context_last_ntt_kernel(const lr_context *ctx, char *buf, size_t capacity
  * the stamps of the last such launch to dst: [workgroup = poly * limbs + limb][wave 0..15][16] uint32 (tools/timeline.py names
  * the phases).  dst == NULL: only *count (words needed).  Synchronises.  The transform's results are unchanged. */
 int lr_context_timeline(lr_context *ctx, uint32_t *dst, size_t capacity, size_t *count);
+/* Diagnostics: the basis extension divides float64(y_i) by float64(q_i) (ring/ring_basis_extension.go:372) with a reciprocal from the
+ * host and two residual corrections instead of the generic IEEE expansion; this runs both on `samples` pseudo-random and adversarial
+ * operand pairs on the device and counts the quotients that differ in any bit (must be 0). */
+int lr_selftest_division(lr_context *ctx, uint64_t samples, uint64_t seed, uint64_t *mismatches);
 int lr_context_sync(lr_context *ctx);       /* hipStreamSynchronize on the context's stream */
 int lr_context_info(const lr_context *ctx, uint64_t *N, int *n_moduli, int *device);
 

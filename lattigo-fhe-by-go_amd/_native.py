@@ -89,6 +89,7 @@ SYMBOLS = {
     "lr_ckks_decrypt": [vp, i32, C.POINTER(vp), i32, vp, vp],
     "lr_context_last_ntt_kernel": [vp, C.c_char_p, C.c_size_t],
     "lr_context_timeline": [vp, vp, C.c_size_t, C.POINTER(C.c_size_t)],
+    "lr_selftest_division": [vp, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64)],
     "lr_ckks_rotate": [vp, i32, vp, vp, u64, vp, vp, vp],
     "lr_ckks_rotate_hoisted": [vp, i32, vp, vp, i32, u64p, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)],
     "lr_bfv_plan_create": [vp, vp, u64, i32, C.POINTER(vp)],

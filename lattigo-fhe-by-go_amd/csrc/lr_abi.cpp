@@ -220,6 +220,7 @@ struct DevModup {
     u64 *Q = nullptr, *mredQ = nullptr, *qib = nullptr, *P = nullptr, *mredP = nullptr, *bredP_hi = nullptr,
         *qispj = nullptr, *qpj_inv = nullptr;
     ulonglong2 *qispj_shoup = nullptr;
+    double *Qrcp = nullptr;
     int lazy_terms = 0, exact_terms = 0, word_barrett = 0, wide_ok = 0;
     int init(const std::vector<u64> &Qv, const std::vector<u64> &Pv, bool ext_narrow) {
         h = build_modup(Qv, Pv);
@@ -243,6 +244,12 @@ struct DevModup {
                 sh[i * nP + j] = make_ulonglong2(plain, shoup_companion(plain, h.P[j]));
             }
         LR_TRY(to_device(&qispj_shoup, sh.data(), sh.size()));
+        {
+            // correctly rounded reciprocals of the moduli as the reference's float64(q_i) sees them (div_by_const, lr_bext.hip)
+            std::vector<double> rc(nQ);
+            for (size_t i = 0; i < nQ; ++i) rc[i] = 1.0 / (double)h.Q[i];
+            LR_TRY(to_device(&Qrcp, rc.data(), rc.size()));
+        }
         const u128 room = ((u128)1 << 64) - pmax;
         lazy_terms = (int)std::min<u128>(room / ((u128)5 * pmax), 1 << 20);   // 4p per term + p per unit of the correction v <= terms
         exact_terms = (int)std::min<u128>(room / ((u128)2 * pmax), 1 << 20);
@@ -263,6 +270,7 @@ struct DevModup {
         t.Q = Q; t.mredQ = mredQ; t.qib_mont = qib; t.P = P; t.mredP = mredP; t.bredP_hi = bredP_hi;
         t.qispj_mont = qispj; t.qpj_inv = qpj_inv;
         t.qispj_shoup = qispj_shoup;
+        t.Qrcp = Qrcp;
         t.lazy_terms = lazy_terms;
         t.exact_terms = exact_terms;
         t.word_barrett = word_barrett;
@@ -273,6 +281,7 @@ struct DevModup {
         for (u64 *p : {Q, mredQ, qib, P, mredP, bredP_hi, qispj, qpj_inv})
             if (p) (void)hipFree(p);
         if (qispj_shoup) (void)hipFree(qispj_shoup);
+        if (Qrcp) (void)hipFree(Qrcp);
     }
 };
 
@@ -2469,6 +2478,28 @@ extern "C" int lr_ckks_decrypt(lr_ckks_plan *pl, int level, const lr_poly *const
     }
     if ((degree & 7) != 7) LR_TRY(run_ewise(cQ, LR_REDUCE, L1, batch, pt->d, pt->stride(), nullptr, 0, pt->d, pt->stride(), nullptr));    // :75
     return LR_OK;
+    });
+}
+
+// diagnostics: the basis extension's division by a table constant (lr_bext.hip: div_by_const) against the IEEE division of
+// ring/ring_basis_extension.go:372 on `samples` pseudo-random and adversarial operand pairs; *mismatches must come back 0
+extern "C" int lr_selftest_division(lr_context *c, uint64_t samples, uint64_t seed, uint64_t *mismatches) {
+    return guarded([&]() -> int {
+        if (!c || !mismatches) return fail(LR_ERR_ARG, "null argument");
+        LR_HIP(hipSetDevice(c->device));
+        unsigned long long *d = nullptr;
+        LR_HIP(hipMalloc((void **)&d, sizeof(unsigned long long)));
+        const int per_thread = 4096;
+        const int blocks = (int)std::min<uint64_t>(std::max<uint64_t>(1, samples / (256ull * per_thread)), 1u << 20);
+        hipError_t e = hipMemsetAsync(d, 0, sizeof(unsigned long long), c->stream);
+        if (e == hipSuccess) e = launch_div_selftest(seed, blocks, per_thread, d, c->stream);
+        unsigned long long h = 0;
+        if (e == hipSuccess) e = hipMemcpyAsync(&h, d, sizeof h, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        (void)hipFree(d);
+        LR_HIP(e);
+        *mismatches = h;
+        return LR_OK;
     });
 }
 

@@ -12,6 +12,18 @@
 
 namespace lr {
 
+// a / b, correctly rounded, for a divisor that is a table constant: r = RN(1 / b) comes from the host.  q0 = RN(a r) is within
+// two ulps of a / b; one residual step makes it faithful; a second one, on a faithful quotient with the exactly representable
+// residual a - b q1, rounds to RN(a / b) (Markstein 1990; Muller et al., Handbook of Floating-Point Arithmetic, 4.7).  No scaling
+// or fix-up is needed: 0 <= a < 2^64 and 2^29 < b < 2^62 keep every intermediate far from the overflow and subnormal ranges.
+// Five full-rate instructions instead of the eleven of the generic IEEE expansion (v_div_scale x2, v_rcp, four Newton FMAs, multiply,
+// residual, v_div_fmas, v_div_fixup), bit for bit the same quotient (lr_selftest_division compares the two on the device).
+__device__ __forceinline__ double div_by_const(double a, double b, double r) {
+    const double q0 = a * r;
+    const double q1 = __builtin_fma(__builtin_fma(-b, q0, a), r, q0);
+    return __builtin_fma(__builtin_fma(-b, q1, a), r, q1);
+}
+
 
 
 
@@ -69,6 +81,7 @@ __global__ __launch_bounds__(256) void ext_shoup_kernel(ExtLaunch L) {
 #pragma unroll
     for (int i = 0; i < NIN; ++i) {
         const u64 qi = L.t.Q[i];
+        const double qr = L.t.Qrcp[i];
         u64 v[W];
         if (W == 2) {
             const ulonglong2 t = ld_stream(reinterpret_cast<const ulonglong2 *>(in + (long long)i * L.n));
@@ -80,7 +93,7 @@ __global__ __launch_bounds__(256) void ext_shoup_kernel(ExtLaunch L) {
 #pragma unroll
         for (int w = 0; w < W; ++w) {
             y[w][i] = mred(v[w], L.t.qib_mont[i], qi, L.t.mredQ[i]);
-            vf[w] += (double)y[w][i] / (double)qi;
+            vf[w] += div_by_const((double)y[w][i], (double)qi, qr);
         }
     }
     u64 vi[W];
@@ -203,6 +216,7 @@ __global__ __launch_bounds__(256) void ext_sum_kernel(ExtLaunch L) {
 #pragma unroll
     for (int i = 0; i < NIN; ++i) {
         const u64 qi = L.t.Q[i];
+        const double qr = L.t.Qrcp[i];
         u64 v[C];
 #pragma unroll
         for (int h = 0; h < C / W; ++h) {
@@ -218,7 +232,7 @@ __global__ __launch_bounds__(256) void ext_sum_kernel(ExtLaunch L) {
 #pragma unroll
         for (int w = 0; w < C; ++w) {
             const u64 y = mred(v[w], L.t.qib_mont[i], qi, L.t.mredQ[i]);
-            vf[w] += (double)y / (double)qi;
+            vf[w] += div_by_const((double)y, (double)qi, qr);
             y0[w][i] = (u32)y;
             y1[w][i] = (u32)(y >> 32);
         }
@@ -318,6 +332,7 @@ __global__ __launch_bounds__(256) void ext_wide_kernel(ExtLaunch L) {
 #pragma unroll
     for (int i = 0; i < NIN; ++i) {
         const u64 qi = L.t.Q[i];
+        const double qr = L.t.Qrcp[i];
         u64 v[W];
         if (W == 2) {
             const ulonglong2 t = ld_stream(reinterpret_cast<const ulonglong2 *>(in + (long long)i * L.n));
@@ -329,10 +344,13 @@ __global__ __launch_bounds__(256) void ext_wide_kernel(ExtLaunch L) {
 #pragma unroll
         for (int w = 0; w < W; ++w) {
             const u64 y = mred(v[w], L.t.qib_mont[i], qi, L.t.mredQ[i]);
-            vf[w] += (double)y / (double)qi;
+            vf[w] += div_by_const((double)y, (double)qi, qr);
             y0[w][i] = (u32)y;
             y1[w][i] = (u32)(y >> 32);
         }
+        // long inputs: keep the scheduler from pulling every limb's load (and its 64-bit temporaries) to the top -- with 32 limbs
+        // that cost 131 instead of 98 VGPRs, i.e. three instead of five waves per SIMD
+        if (NIN > 16 && (i & 7) == 7) __builtin_amdgcn_sched_barrier(0);
     }
     u32 vi[W];
 #pragma unroll
@@ -422,6 +440,51 @@ static hipError_t launch_n(const ExtLaunch &L, int batch, hipStream_t stream) {
 // the top-stage variant exists for the sum-form kernel with at most eight input limbs (the key-switch digits have alpha <= 8)
 bool ext_top_supported(const ExtTables &t, int n_in, int n) {
     return (n & 3) == 0 && n_in >= 1 && n_in <= 8 && t.exact_terms >= 4 && t.word_barrett && t.lazy_terms >= (n_in < 2 ? 2 : n_in);
+}
+
+// ---- diagnostics: div_by_const against the IEEE division it replaces ---------------------------------------------------------
+// Every thread walks `per_thread` (a, b) pairs from a splitmix64 stream: divisors of every size the extension tables can hold
+// (30 .. 61 bits, odd and even, plus powers of two and their neighbours), dividends uniform over 64 bits, below the divisor (the
+// product's case: y_i < q_i), multiples of the divisor +- 1 and values around 2^53 where the uint64 -> double conversion rounds.
+__global__ __launch_bounds__(256) void div_selftest_kernel(u64 seed, int per_thread, unsigned long long *mismatches) {
+    u64 state = seed + ((u64)blockIdx.x * 256 + threadIdx.x) * 0x9E3779B97F4A7C15ull;
+    auto next = [&]() {
+        u64 z = (state += 0x9E3779B97F4A7C15ull);
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        return z ^ (z >> 31);
+    };
+    unsigned bad = 0;
+    for (int k = 0; k < per_thread; ++k) {
+        const u64 r0 = next(), r1 = next();
+        const int bits = 30 + (int)(r0 % 32);                       // 30 .. 61
+        u64 q = ((u64)1 << (bits - 1)) | (r1 >> (65 - bits));
+        switch ((r0 >> 8) & 7) {
+        case 0: q |= 1; break;                                       // odd, like every modulus
+        case 1: q = (u64)1 << (bits - 1); break;                     // power of two
+        case 2: q = ((u64)1 << bits) - 1; break;                     // all ones
+        case 3: q = ((u64)1 << (bits - 1)) + 1; break;
+        default: q |= 1; break;
+        }
+        u64 y = next();
+        switch ((r0 >> 16) & 7) {
+        case 0: break;                                               // any 64-bit value
+        case 1: y = (y >> 11) % 64 * q + ((r0 >> 20) & 3) - 1; break;   // small multiples of q, +- 1
+        case 2: y = ((u64)1 << 53) + (y & 0xFFF) - 0x800; break;     // where the conversion to double starts rounding
+        case 3: y = q - 1 - (y & 3); break;
+        default: y %= q; break;                                      // the product's case
+        }
+        const double a = (double)y, b = (double)q;
+        const double want = a / b, got = div_by_const(a, b, 1.0 / b);
+        bad += __double_as_longlong(want) != __double_as_longlong(got) ? 1u : 0u;
+    }
+    if (bad) atomicAdd(mismatches, (unsigned long long)bad);
+}
+
+hipError_t launch_div_selftest(u64 seed, int blocks, int per_thread, unsigned long long *d_mismatches, hipStream_t stream) {
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(div_selftest_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, seed, per_thread, d_mismatches);
+    return hipGetLastError();
 }
 
 hipError_t launch_ext(const ExtLaunch &L, int n_in, int batch, hipStream_t stream) {

@@ -228,6 +228,7 @@ struct ExtTables {        // device pointers; modupParams of ring_basis_extensio
     // the same (Q/q_i) mod p_j out of Montgomery form, with the Shoup companion floor(c * 2^64 / p_j): the
     // products y_i * c accumulate lazily and are reduced once, to the same canonical residue
     const ulonglong2 *qispj_shoup;  // [nQ][nP] {c, companion}
+    const double *Qrcp;   // [nQ] RN(1 / float64(q_i)): div_by_const
     int lazy_terms;       // how many [0,4p) terms, each with one p of the correction v * qpjInv[1], fit in 64 bits
     int exact_terms;      // the same for [0,2p) terms
     int word_barrett;     // every p_j > 2^32: floor(2^64 / p_j) fits one word (ext_sum_kernel's final reduction)
@@ -302,5 +303,6 @@ hipError_t launch_submul(const SubMulLaunch &L, int limbs, int batch, hipStream_
 hipError_t launch_rowadd(const RowAddLaunch &L, int rows, int batch, hipStream_t stream);
 hipError_t launch_ext(const ExtLaunch &L, int n_in, int batch, hipStream_t stream);
 bool ext_top_supported(const ExtTables &t, int n_in, int n);
+hipError_t launch_div_selftest(u64 seed, int blocks, int per_thread, unsigned long long *d_mismatches, hipStream_t stream);
 
 }  // namespace lr

@@ -324,6 +324,12 @@ class Context:
         check(lib().lr_context_last_ntt_kernel(self.h, buf, len(buf)))
         return buf.value.decode()
 
+    def selftest_division(self, samples, seed=1):
+        """diagnostics: quotients of the extension's constant-divisor division that differ from IEEE division (must be 0)"""
+        n = C.c_uint64(0)
+        check(lib().lr_selftest_division(self.h, samples, seed, C.byref(n)))
+        return int(n.value)
+
     def timeline(self):
         """clock stamps of the last launch of the stamped diagnostics kernel (context created under LR_NTT_TIMELINE=1):
         uint32 array [workgroups, 16 waves, 16 stamps]"""

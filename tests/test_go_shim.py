@@ -79,7 +79,7 @@ def test_every_c_call_matches_the_header():
     unused = sorted(set(arity) - seen - {"lr_build_info", "lr_device_count", "lr_timer_start", "lr_timer_stop", "lr_context_info",
                                          "lr_poly_info", "lr_poly_wrap", "lr_poly_wrap_strided", "lr_poly_upload_dense",
                                          "lr_poly_download_dense", "lr_context_ntt_variants", "lr_context_last_ntt_kernel",
-                                         "lr_ntt_limb", "lr_intt_limb", "lr_bext_get_table", "lr_simple_scaler_tables", "lr_context_timeline"})
+                                         "lr_ntt_limb", "lr_intt_limb", "lr_bext_get_table", "lr_simple_scaler_tables", "lr_context_timeline", "lr_selftest_division"})
     assert not unused, unused
 
 

@@ -486,6 +486,17 @@ def test_two_operand_ops_at_baseline_shapes(gpu_pkg, oracle, logn, limbs, batch)
         assert np.array_equal(got[i], oc.ewise("MUL_SCALAR", a[i], scalars=[0x123456789ABCDEF1])), i
 
 
+def test_extension_division_is_the_ieee_quotient(gpu_pkg):
+    """the float64 correction index of modUpExact divides by a table constant; the kernels do that with a host reciprocal and two
+    residual corrections (lr_bext.hip: div_by_const).  2^32 operand pairs on the device -- every divisor size, powers of two and
+    all-ones patterns, dividends over 64 bits, below the divisor, at multiples of it +- 1 and around 2^53 -- must give the IEEE
+    quotient bit for bit"""
+    N, moduli = gpu_pkg.params.DefaultParamsQi(12)
+    ctx = gpu_pkg.ring.NewContextWithParams(N, moduli)
+    for seed in (1, 0x4C415454):
+        assert ctx.selftest_division(1 << 31, seed) == 0
+
+
 @pytest.mark.parametrize("logn,limbs,batch", REAL_SHAPES)
 def test_modup_split_qp_at_baseline_shapes(gpu_pkg, oracle, logn, limbs, batch):
     """ModUpSplitQP 8 -> 8 at N = 2^14 (config 2's ring) and 16 -> 16 at N = 2^15 (the benched extension), every coefficient"""
