@@ -5,8 +5,9 @@
 // coefficient column computes y_i = x_i * (Q/q_i)^-1 mod q_i and the float64 correction index
 // v = floor(sum y_i / q_i) ONCE, then walks the output limbs.  The float path is the
 // reference's, operation for operation: uint64->double (round to nearest even), IEEE
-// division, left-to-right accumulation, truncation; this file is compiled
-// with -ffp-contract=off and without fast-math.  All table constants are wave-uniform and
+// division (div_by_const below: the same quotient bit for bit, computed with the host's
+// reciprocal of the constant divisor), left-to-right accumulation, truncation;
+// this file is compiled with -ffp-contract=off and without fast-math.  All table constants are wave-uniform and
 // come in through scalar loads.
 #include "lr_device.hpp"
 
