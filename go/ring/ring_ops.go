@@ -215,6 +215,28 @@ func (c *Context) MultByMonomial(p1 *Poly, monomialDeg uint64, p2 *Poly) {
 	call(func() C.int { return C.lr_mult_by_monomial(c.h, p1.d, C.uint64_t(monomialDeg), p2.d) })
 	done(p2)
 }
+// Shift (ring/ring.go:575): p2 = p1 rotated left by n positions.  The reference re-slices p2.Coeffs; here p2's device image is written.
+func (c *Context) Shift(p1 *Poly, n uint64, p2 *Poly) {
+	c.use(p1)
+	c.want(p2)
+	call(func() C.int { return C.lr_shift(c.h, p1.d, C.uint64_t(n), p2.d) })
+	done(p2)
+}
+
+// Rotate (ring/ring.go:775): the reference writes into p1 whatever p2 is (`p1tmp, p2tmp := p1.Coeffs[i], p1.Coeffs[i]`, :791).
+func (c *Context) Rotate(p1 *Poly, n uint64, p2 *Poly) {
+	c.use(p1)
+	call(func() C.int { return C.lr_rotate(c.h, p1.d, C.uint64_t(n)) })
+	done(p1)
+}
+
+// Exp (ring/ring.go:440-464): as written upstream its observable effect is p1 <- NTT(p1) and, by its last statement, p2 <- InvNTT(p1)
+// (the powers it computes in between are overwritten).  No caller in the module; kept so that the identifier exists.
+func (c *Context) Exp(p1 *Poly, e uint64, p2 *Poly) {
+	c.NTT(p1, p1)
+	c.InvNTT(p1, p2)
+}
+
 func (c *Context) MultByMonomialNew(p1 *Poly, monomialDeg uint64) *Poly {
 	p2 := c.NewPoly()
 	c.MultByMonomial(p1, monomialDeg, p2)

@@ -208,6 +208,13 @@ int lr_permute(lr_context *ctx, const lr_poly *in, uint64_t gen, lr_poly *out);
  * (staged through a temporary, as the reference's tmpx, :682). */
 int lr_mult_by_monomial(lr_context *ctx, const lr_poly *in, uint64_t monomial_deg, lr_poly *out);
 
+/* Context.Shift (ring/ring.go:575): out = in rotated left by n coefficient positions, every limb (n masked with (1 << N) - 1 as Go
+ * evaluates it: all ones for N >= 64); n > N is the reference's slice panic: LR_ERR_ARG.  in == out is allowed. */
+int lr_shift(lr_context *ctx, const lr_poly *in, uint64_t n, lr_poly *out);
+/* Context.Rotate (ring/ring.go:775): coefficient j of every limb times omega^(n j), omega = psi^2, j = 1 .. N-1, canonical; coefficient 0
+ * untouched.  The reference writes into p1 whatever its p2 argument is (:791), hence one poly here. */
+int lr_rotate(lr_context *ctx, lr_poly *p1, uint64_t n);
+
 /* ------------------------------------------------------------------ SimpleScaler --- */
 /* NewSimpleScaler(t, context) (ring/ring_scaling.go:186): per modulus qi the integer part wi and the double-double
  * fractional part ti of ((Q/qi)^-1 mod qi) * t / qi, computed with the operation sequence of ring/float128.go.

@@ -54,6 +54,8 @@ SYMBOLS = {
     "lr_permute_ntt_index": [u64, u64, u64, u64p],
     "lr_permute": [vp, vp, u64, vp],
     "lr_mult_by_monomial": [vp, vp, u64, vp],
+    "lr_shift": [vp, vp, u64, vp],
+    "lr_rotate": [vp, vp, u64],
     "lr_simple_scaler_create": [vp, u64, C.POINTER(vp)],
     "lr_simple_scaler_destroy": [vp],
     "lr_simple_scaler_tables": [vp, u64p, C.POINTER(C.c_double), i32],

@@ -1236,6 +1236,89 @@ extern "C" int lr_mult_by_monomial(lr_context *c, const lr_poly *in, uint64_t mo
     });
 }
 
+// Context.Shift (ring/ring.go:575-580): p2 = p1 rotated left by n coefficient positions, every limb.  The reference masks n with
+// (1 << N) - 1, which in Go is all ones for N >= 64 and 2^N - 1 below, and slices p1.Coeffs[i][n:]: n > N panics (here: LR_ERR_ARG).
+extern "C" int lr_shift(lr_context *c, const lr_poly *in, uint64_t n, lr_poly *out) {
+    return guarded([&]() -> int {
+    if (!c || !in || !out) return fail(LR_ERR_ARG, "null argument");
+    const int level = c->h.L() - 1;
+    LR_TRY(check_pair(c, level, in, out));
+    if (in->batch != out->batch) return fail(LR_ERR_SHAPE, "batch mismatch");
+    const u64 N = c->h.N;
+    const u64 m = N >= 64 ? n : (n & (((u64)1 << N) - 1));
+    if (m > N) return fail(LR_ERR_ARG, "Shift: n exceeds the ring degree (the reference's slice expression panics)");
+    LR_HIP(hipSetDevice(c->device));
+    const u64 *src = in->d;
+    ScratchLease tmp;
+    if (in->d == out->d) {
+        LR_TRY(tmp.take(&c->scratch, (size_t)out->batch * (size_t)in->stride()));
+        LR_HIP(hipMemcpyAsync(tmp.d(), in->d, (size_t)out->batch * (size_t)in->stride() * sizeof(u64), hipMemcpyDeviceToDevice, c->stream));
+        src = tmp.d();
+    }
+    const size_t pitch = (size_t)N * sizeof(u64), rows = (size_t)(level + 1);
+    for (int b = 0; b < out->batch; ++b) {
+        const u64 *s = src + (long long)b * in->stride();
+        u64 *d = out->d + (long long)b * out->stride();
+        if (m < N) LR_HIP(hipMemcpy2DAsync(d, pitch, s + m, pitch, (size_t)(N - m) * sizeof(u64), rows, hipMemcpyDeviceToDevice, c->stream));
+        if (m > 0) LR_HIP(hipMemcpy2DAsync(d + (N - m), pitch, s, pitch, (size_t)m * sizeof(u64), rows, hipMemcpyDeviceToDevice, c->stream));
+    }
+    return LR_OK;
+    });
+}
+
+// Context.Rotate (ring/ring.go:775-800): coefficient j of every limb is multiplied by omega^(n j), omega = psi^2, for j = 1 .. N-1;
+// coefficient 0 is left as it is.  The reference writes the result into p1 whatever p2 is (`p1tmp, p2tmp := p1.Coeffs[i], p1.Coeffs[i]`,
+// :791), so this entry point takes one poly.  n is masked like Shift's.  The factors gal_j = MForm(omega^(n j)) are canonical residues and
+// MRed(x, gal_j) is the canonical x * omega^(n j): the table is built on the host per call (the reference's only caller is its test
+// suite, ring_test.go:435) and applied by the Montgomery product kernel.
+extern "C" int lr_rotate(lr_context *c, lr_poly *p1, uint64_t n) {
+    return guarded([&]() -> int {
+    if (!c || !p1) return fail(LR_ERR_ARG, "null argument");
+    const int level = c->h.L() - 1;
+    LR_TRY(check_pair(c, level, p1, p1));
+    const u64 N = c->h.N;
+    if (N < 2) return fail(LR_ERR_UNSUPPORTED, "N must be at least 2");
+    const u64 m = N >= 64 ? n : (n & (((u64)1 << N) - 1));
+    LR_HIP(hipSetDevice(c->device));
+    const int L = level + 1;
+    std::vector<u64> gal((size_t)L * N);
+    for (int i = 0; i < L; ++i) {
+        const u64 q = c->h.q[i], qinv = c->h.mred[i];
+        const BarrettConst bc = c->h.bred[i];
+        const u64 omega = mred(c->h.psi_mont[i], c->h.psi_mont[i], q, qinv);              // psi^2 in Montgomery form (:785)
+        // root = omega^m in Montgomery form (:787): square and multiply on Montgomery residues
+        u64 root = mform(1, q, bc.hi, bc.lo), base = omega;
+        for (u64 e = m; e > 0; e >>= 1) {
+            if (e & 1) root = mred(root, base, q, qinv);
+            base = mred(base, base, q, qinv);
+        }
+        u64 g = mform(1, q, bc.hi, bc.lo);                                               // :789
+        gal[(size_t)i * N] = g;
+        for (u64 j = 1; j < N; ++j) {
+            g = mred(g, root, q, qinv);                                                  // :795
+            gal[(size_t)i * N + j] = g;
+        }
+    }
+    ScratchLease table, heads;
+    const size_t rows = (size_t)p1->batch * (size_t)L;
+    LR_TRY(table.take(&c->scratch, gal.size()));
+    LR_TRY(heads.take(&c->scratch, rows));
+    // the multiply below is not ordered against a host buffer that dies with this call: finish the upload first
+    LR_HIP(hipMemcpyAsync(table.d(), gal.data(), gal.size() * sizeof(u64), hipMemcpyHostToDevice, c->stream));
+    LR_HIP(hipStreamSynchronize(c->stream));
+    const size_t pitch = (size_t)N * sizeof(u64);
+    // coefficient 0 of every row is not touched by the reference (the loop starts at j = 1): keep it aside, put it back afterwards
+    for (int b = 0; b < p1->batch; ++b)
+        LR_HIP(hipMemcpy2DAsync(heads.d() + (size_t)b * L, sizeof(u64), p1->d + (long long)b * p1->stride(), pitch, sizeof(u64), (size_t)L,
+                                hipMemcpyDeviceToDevice, c->stream));
+    LR_TRY(run_ewise(c, LR_MUL_MONT, L, p1->batch, p1->d, p1->stride(), table.d(), 0, p1->d, p1->stride(), nullptr));
+    for (int b = 0; b < p1->batch; ++b)
+        LR_HIP(hipMemcpy2DAsync(p1->d + (long long)b * p1->stride(), pitch, heads.d() + (size_t)b * L, sizeof(u64), sizeof(u64), (size_t)L,
+                                hipMemcpyDeviceToDevice, c->stream));
+    return LR_OK;
+    });
+}
+
 extern "C" int lr_permute_ntt_index(uint64_t gen, uint64_t power, uint64_t N, uint64_t *index) {
     return guarded([&]() -> int {
     if (!index) return fail(LR_ERR_ARG, "null argument");

@@ -343,6 +343,12 @@ class Context:
     def MultByMonomial(self, p1, monomialDeg, p2):  # ring/ring.go:663
         check(lib().lr_mult_by_monomial(self.h, p1.h, int(monomialDeg), p2.h))
 
+    def Shift(self, p1, n, p2):  # ring/ring.go:575
+        check(lib().lr_shift(self.h, p1.h, int(n), p2.h))
+
+    def Rotate(self, p1, n, p2=None):  # ring/ring.go:775 -- the reference writes into p1 and ignores p2 (:791)
+        check(lib().lr_rotate(self.h, p1.h, int(n)))
+
     def PermuteNTTLvl(self, level, polIn, gen, polOut):  # package-level PermuteNTT (:55) on limbs 0..level
         check(lib().lr_permute_ntt(self.h, level, polIn.h, int(gen), polOut.h))
 

@@ -1210,6 +1210,52 @@ void oc_ckks_rotate_hoisted(oc_ckks_plan *p, int level, const u64 *ct, int n_rot
 }
 
 
+/* Context.Shift, ring/ring.go:575-580: p2.Coeffs[i] = append(p1.Coeffs[i][n&mask:], p1.Coeffs[i][:n&mask]...), mask = (1 << N) - 1
+ * (Go: a shift count >= 64 gives 0, so the mask is all ones for N >= 64).  Returns -1 where the slice expression would panic. */
+int oc_shift(const oc_context *c, const u64 *p1, u64 n, u64 *p2) {
+    const u64 N = c->N;
+    const u64 mask = N >= 64 ? ~(u64)0 : (((u64)1 << N) - 1);
+    const u64 m = n & mask;
+    if (m > N) return -1;
+    u64 *tmp = (u64 *)malloc(sizeof(u64) * N);
+    for (int i = 0; i < c->L; i++) {
+        const u64 *row = p1 + (size_t)i * N;
+        for (u64 j = 0; j < N - m; j++) tmp[j] = row[m + j];
+        for (u64 j = 0; j < m; j++) tmp[N - m + j] = row[j];
+        memcpy(p2 + (size_t)i * N, tmp, sizeof(u64) * N);
+    }
+    free(tmp);
+    return 0;
+}
+
+/* modexpMontgomery, ring/utils.go:39-50 */
+static u64 modexp_montgomery(u64 x, u64 e, u64 q, u64 qinv, const u64 u[2]) {
+    u64 result = oc_mform(1, q, u);
+    for (u64 i = e; i > 0; i >>= 1) {
+        if (i & 1) result = oc_mred(result, x, q, qinv);
+        x = oc_mred(x, x, q, qinv);
+    }
+    return result;
+}
+
+/* Context.Rotate, ring/ring.go:775-800.  Writes into p1 (p1tmp, p2tmp := p1.Coeffs[i], p1.Coeffs[i], :791); coefficient 0 untouched. */
+void oc_rotate(const oc_context *c, u64 *p1, u64 n) {
+    const u64 N = c->N;
+    n &= N >= 64 ? ~(u64)0 : (((u64)1 << N) - 1);                                   /* :779 */
+    for (int i = 0; i < c->L; i++) {
+        const u64 qi = c->q[i], qinv = c->mred[i];
+        const u64 *u = &c->bred[2 * i];
+        u64 root = oc_mred(c->psi_mont[i], c->psi_mont[i], qi, qinv);                 /* :785 */
+        root = modexp_montgomery(root, n, qi, qinv, u);                               /* :787 */
+        u64 gal = oc_mform(1, qi, u);                                                 /* :789 */
+        u64 *row = p1 + (size_t)i * N;
+        for (u64 j = 1; j < N; j++) {
+            gal = oc_mred(gal, root, qi, qinv);                                       /* :795 */
+            row[j] = oc_mred(row[j], gal, qi, qinv);                                  /* :797 */
+        }
+    }
+}
+
 /* Context.MultByMonomial, ring/ring.go:663-727 (through the temporary tmpx, so p1 may equal p2) */
 void oc_mult_by_monomial(const oc_context *c, const u64 *p1, u64 monomial_deg, u64 *p2) {
     const u64 N = c->N;

@@ -197,6 +197,8 @@ void oc_ckks_permute_ntt(oc_ckks_plan *p, int level, const uint64_t *ct, uint64_
 void oc_ckks_rotate_hoisted(oc_ckks_plan *p, int level, const uint64_t *ct, int n_rot, const uint64_t *gens,
                             const uint64_t *const *evks, uint64_t *out);
 
+int oc_shift(const oc_context *c, const uint64_t *p1, uint64_t n, uint64_t *p2);     /* ring/ring.go:575 */
+void oc_rotate(const oc_context *c, uint64_t *p1, uint64_t n);                      /* ring/ring.go:775 (in place on p1) */
 void oc_mult_by_monomial(const oc_context *c, const uint64_t *p1, uint64_t monomial_deg, uint64_t *p2);   /* ring/ring.go:663 */
 
 /* ---- Galois automorphisms: ring/ring_galois.go -------------------------------- */

@@ -155,6 +155,8 @@ def _bind(L):
     sig("oc_permute_ntt_with_index", None, vp, vp, vp, i, u64)
     sig("oc_permute", None, vp, vp, u64, vp)
     sig("oc_mult_by_monomial", None, vp, vp, u64, vp)
+    sig("oc_shift", i, vp, vp, u64, vp)
+    sig("oc_rotate", None, vp, vp, u64)
     dp = C.POINTER(C.c_double)
     sig("oc_f128_set_uint53", None, u64, dp)
     sig("oc_f128_set_uint64", None, u64, dp)
@@ -319,6 +321,16 @@ class Context:
         p = _arr(p)
         out = np.zeros_like(p)
         lib().oc_mult_by_monomial(self.h, _ptr(p), int(deg), _ptr(out))
+        return out
+
+    def shift(self, p, n):                   # Context.Shift (ring/ring.go:575); None where the reference panics
+        p = _arr(p)
+        out = np.zeros_like(p)
+        return out if lib().oc_shift(self.h, _ptr(p), int(n), _ptr(out)) == 0 else None
+
+    def rotate(self, p, n):                  # Context.Rotate (ring/ring.go:775): the new contents of p1
+        out = _arr(p).copy()
+        lib().oc_rotate(self.h, _ptr(out), int(n))
         return out
 
     def rescale_op(self, name, p, nb=None, ntt=False):

@@ -548,6 +548,58 @@ def test_mult_by_monomial_in_place(gpu_pkg, oracle):
             assert np.array_equal(p.get()[b], oc.mult_by_monomial(x[b], deg)), (deg, b)
 
 
+@pytest.mark.parametrize("logn,limbs", [(3, 2), (5, 2), (8, 3), (12, 2)])
+def test_shift_and_rotate(gpu_pkg, oracle, logn, limbs):
+    """Context.Shift (ring/ring.go:575) and Context.Rotate (:775, which writes into p1): against the restatement, out of place and
+    in place, and the reference's own property testGaloisShift (ring_test.go:422-449): BitReverse, InvNTT, Rotate by 1, NTT,
+    BitReverse, Reduce of a uniform poly equals Shift by 1.  N = 8 and 32 are below 64, where Go's mask (1 << N) - 1 is not all
+    ones: n = 2^N + 3 shifts by 3 there"""
+    N = 1 << logn
+    moduli = list(gpu_pkg.params.Qi60()[-limbs:])
+    ctx, oc = gpu_pkg.ring.NewContextWithParams(N, moduli), oracle.Context(N, moduli)
+    x = gpu_pkg.sampling.uniform_poly(moduli, N, 2, seed=31)
+    for n in (0, 1, 5, N - 1, N):
+        p, r = ctx.NewPoly(2).set(x), ctx.NewPoly(2)
+        ctx.Shift(p, n, r)
+        for b in range(2):
+            assert np.array_equal(r.get()[b], oc.shift(x[b], n)), (n, b)
+        ctx.Shift(p, n, p)
+        assert np.array_equal(p.get(), r.get()), n
+    if N < 64:
+        p, r = ctx.NewPoly(2).set(x), ctx.NewPoly(2)
+        ctx.Shift(p, (1 << N) + 3, r)
+        assert np.array_equal(r.get()[0], oc.shift(x[0], 3))
+    else:
+        assert oc.shift(x[0], N + 1) is None                     # the reference's slice expression panics
+        with pytest.raises(gpu_pkg._native.LatticeRingError):
+            ctx.Shift(ctx.NewPoly(2).set(x), N + 1, ctx.NewPoly(2))
+    full = gpu_pkg.sampling.random_u64((2, limbs, N), seed=32)    # Rotate reduces what it multiplies; coefficient 0 stays as it is
+    for n in (0, 1, 7, N + 3):
+        for src in (x, full):
+            p = ctx.NewPoly(2).set(src)
+            ctx.Rotate(p, n, None)
+            for b in range(2):
+                assert np.array_equal(p.get()[b], oc.rotate(src[b], n)), (n, b)
+    # ring_test.go: testGaloisShift
+    rev = np.array([int(format(j, "0%db" % logn)[::-1], 2) for j in range(N)])
+    bitrev = lambda a: _bit_reverse(a, rev)
+    want = ctx.NewPoly(2).set(x)
+    test = ctx.NewPoly(2).set(bitrev(x))
+    ctx.InvNTT(test, test)
+    ctx.Rotate(test, 1, test)
+    ctx.NTT(test, test)
+    got = bitrev(test.get())
+    ctx.Shift(want, 1, want)
+    assert np.array_equal(got, want.get())
+
+
+def _bit_reverse(a, rev):
+    """Context.BitReverse (ring/ring.go:749): out[rev(j)] = in[j]"""
+    out = np.empty_like(a)
+    out[..., rev] = a
+    return out
+
+
 def test_last_ntt_kernel_is_reported(gpu_pkg):
     """the dispatched kernel is observable: assembly code object where one exists, the C++ kernel otherwise"""
     ring, params = gpu_pkg.ring, gpu_pkg.params

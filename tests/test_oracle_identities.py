@@ -283,3 +283,29 @@ def test_ckks_switch_keys_is_linear_in_the_key(oracle):
     p0, p1 = plan.switch_keys(level, cx, evk)
     assert np.array_equal(p1, np.zeros_like(p1))
     assert np.array_equal(p0, cx)
+
+
+@pytest.mark.parametrize("logn", [3, 5, 8, 11])
+def test_galois_shift_property_of_the_reference(oracle, logn):
+    """ring_test.go:422-449 (testGaloisShift) on the restatement: BitReverse, InvNTT, Rotate by 1, NTT, BitReverse, Reduce of a uniform
+    poly equals Shift by 1 -- pins oc_rotate (ring/ring.go:775) and oc_shift (:575) on the reference's own test"""
+    import __graft_entry__ as graft
+    pkg = graft.load_package()
+    N = 1 << logn
+    moduli = list(pkg.params.Qi60()[-2:])
+    oc = oracle.Context(N, moduli)
+    x = pkg.sampling.uniform_poly(moduli, N, 1, seed=logn)[0]
+    rev = np.array([int(format(j, "0%db" % logn)[::-1], 2) for j in range(N)])
+
+    def bit_reverse(a):                      # Context.BitReverse, ring/ring.go:749
+        out = np.empty_like(a)
+        out[..., rev] = a
+        return out
+
+    t = bit_reverse(oc.ntt(oc.rotate(oc.intt(bit_reverse(x)), 1)))
+    assert np.array_equal(t, oc.shift(x, 1))
+    assert np.array_equal(oc.shift(x, 0), x) and np.array_equal(oc.shift(x, N), x)
+    if N >= 64:
+        assert oc.shift(x, N + 1) is None    # p1.Coeffs[i][n:] with n > N panics in the reference
+    else:
+        assert np.array_equal(oc.shift(x, (1 << N) + 2), oc.shift(x, 2))   # Go's mask (1 << N) - 1
