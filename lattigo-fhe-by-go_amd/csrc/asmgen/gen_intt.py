@@ -17,7 +17,7 @@ generation time inside a pass and applied unconditionally on the first stage of 
 """
 import sys
 
-from gen_ntt import T, Dual, Gen, kernel_text_for
+from gen_ntt import CROSS32, T, Dual, Gen, kernel_text_for
 from isa import EXEC, Neg, s, v
 
 
@@ -60,6 +60,21 @@ class GenInv(Gen):
         """V <- V * w - qhat * q (lazy, [0,4q)) for any 64-bit V"""
         w0, w1, s0, s1 = tw
         J = self.JUNK
+        if CROSS32:      # gen_ntt.py: the cross terms by 32-bit low products and three-input adds
+            return [
+                ("v_mul_hi_u32", ts.T0, V.hi(), s0),
+                ("v_mul_hi_u32", ts.T2, V.lo(), s1),
+                ("v_mad_u64_u32", ts.Q, J, V.hi(), s1, ts.T01),
+                ("v_mul_lo_u32", ts.C.lo(), V.lo(), w1),
+                ("v_lshl_add_u64", ts.Q, ts.Q, 0, ts.T23),
+                ("v_mul_lo_u32", ts.C.hi(), V.hi(), w0),
+                ("v_mad_u64_u32", V, J, V.lo(), w0, 0),
+                ("v_mad_u64_u32", V, J, ts.Q.lo(), self.NQ.lo(), V),
+                ("v_mul_lo_u32", ts.T0, ts.Q.lo(), self.NQ.hi()),
+                ("v_mul_lo_u32", ts.T2, ts.Q.hi(), self.NQ.lo()),
+                ("v_add3_u32", ts.C.lo(), ts.C.lo(), ts.C.hi(), ts.T0),
+                ("v_add3_u32", V.hi(), V.hi(), ts.C.lo(), ts.T2),
+            ]
         return [
             ("v_mul_hi_u32", ts.T0, V.hi(), s0),
             ("v_mul_hi_u32", ts.T2, V.lo(), s1),

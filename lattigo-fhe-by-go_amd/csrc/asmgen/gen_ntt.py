@@ -14,12 +14,17 @@ the context's largest modulus allows and falls back to the C++ kernels for small
     python gen_ntt.py 15 out.s [mode] # assembly text
     python gen_ntt.py 15 --selftest   # emulate one workgroup with numpy and compare with a reference NTT
 """
+import os
 import sys
 
 from isa import VCC, Neg, Program, Reg, s, v
 
 T = 1024
 LOGT = 10
+
+
+# experiment switch: cross terms of the 64-bit products by 32-bit low multiplies (LR_GEN_CROSS32=1 at generation time)
+CROSS32 = bool(os.environ.get("LR_GEN_CROSS32"))
 
 
 class Gen:
@@ -288,6 +293,25 @@ class Gen:
             ops += [("v_lshl_add_u64", U, U, 0, M)]
         else:
             ops += hi
+        if CROSS32:
+            # the four cross terms only feed bits 32..63 of the result: 32-bit low products summed by three-input adds instead of
+            # 64-bit multiply-adds chained through a 64-bit register (profiles/r02/asm_energy.txt: v_mul_lo_u32 0.65 nJ against
+            # 1.8 nJ for v_mad_u64_u32 with a VGPR addend; the kernel runs at the package power limit)
+            ops += [
+                ("v_lshl_add_u64", ts.R, U, 1, self.Q4),        # 2U + 4q
+                ("v_mad_u64_u32", ts.Q, J, V.hi(), s1, ts.T01),
+                ("v_mad_u64_u32", U, J, V.lo(), w0, U),
+                ("v_mul_lo_u32", ts.C.lo(), V.lo(), w1),
+                ("v_lshl_add_u64", ts.Q, ts.Q, 0, ts.T23),      # T0 / T2 are free from here on
+                ("v_mul_lo_u32", ts.C.hi(), V.hi(), w0),
+                ("v_mad_u64_u32", U, J, ts.Q.lo(), self.NQ.lo(), U),
+                ("v_mul_lo_u32", ts.T0, ts.Q.lo(), self.NQ.hi()),
+                ("v_mul_lo_u32", ts.T2, ts.Q.hi(), self.NQ.lo()),
+                ("v_add3_u32", ts.C.lo(), ts.C.lo(), ts.C.hi(), ts.T0),
+                ("v_add3_u32", U.hi(), U.hi(), ts.C.lo(), ts.T2),   # X
+                ("v_sub_co_u32", V.lo(), ts.CY, ts.R.lo(), U.lo()),
+                ("v_subb_co_u32", V.hi(), ts.CY, ts.R.hi(), U.hi(), ts.CY)]   # Y
+            return ops
         ops += [
             ("v_lshl_add_u64", ts.R, U, 1, self.Q4),        # 2U + 4q
             ("v_mad_u64_u32", ts.Q, J, V.hi(), s1, ts.T01),

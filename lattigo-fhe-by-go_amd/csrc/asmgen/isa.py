@@ -271,6 +271,10 @@ class Machine:
         self._const_bus((a, b))
         self.wv(d, self.rv(a) + self.rv(b))
 
+    def i_v_add3_u32(self, d, a, b, c):
+        self._const_bus((a, b, c))
+        self.wv(d, self.rv(a) + self.rv(b) + self.rv(c))
+
     def i_v_sub_u32(self, d, a, b):
         self._const_bus((a, b))
         self.wv(d, self.rv(a) - self.rv(b))

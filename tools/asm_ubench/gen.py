@@ -293,6 +293,7 @@ class Probe(Gen):
         return self.p
 
 
+ENERGY = ["mov", "xor_b32", "add_u32", "lshl_add", "lshl_add_vvv", "mullo_vv", "mulhi_vv", "mulhi_vs", "mad_vs0", "mad_vsv", "mad_vvv", "fma_f32", "fma_f64", "bfly_nc", "bfly_c", "fp64_bfly", "xchg_lds"]
 VARIANTS = ["mad_add_mix", "mulhi_add_mix", "xchg_none", "xchg_lds", "xchg_perm", "xchg_dpp", "mulhi_vs", "mad_vs0", "mad_vsv", "lshl_add", "add_u32", "sub_co_pair", "cndmask_vcc", "fma_f64", "bfly_nc", "bfly_c"]
 _OLD2 = ["cfg_98_36", "cfg_32_36", "cfg_2_36", "cfg_32_68", "cfg_vcc_68", "cfg_98_92", "cfg_98_40", "cfg_34_64", "cfg_2_36_c", "cfg_98_36_c", "cfg_32_36_c"]
 _OLD = ["bfly_nc", "bfly_c", "bfly_nc_seq", "bfly_c_seq", "bfly_nc_2sgpr", "inv_c", "mad_sdst_vcc", "mad_sdst_alt", "subb_sgpr", "cmp_vcc", "cmp_sgpr",
@@ -303,7 +304,7 @@ if __name__ == "__main__":
     out = sys.argv[1]
     os.makedirs(out, exist_ok=True)
     meta = []
-    for var in VARIANTS:
+    for var in (ENERGY if len(sys.argv) > 2 and sys.argv[2] == "energy" else VARIANTS):
         g = Probe(var)
         text = kernel_text_for(g, "probe_" + var)
         open(os.path.join(out, var + ".s"), "w").write(text)

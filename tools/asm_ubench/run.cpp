@@ -1,6 +1,8 @@
 // Loads the probe code objects produced by gen.py and reports cycles per wave-instruction per SIMD.
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstring>
+#include <ctime>
 #include <fstream>
 #include <iterator>
 #include <string>
@@ -17,6 +19,9 @@ int main(int argc, char **argv) {
     printf("device clock %d kHz, %d CUs\n", clk_khz, cus);
     fflush(stdout);
     const std::string only = argc > 2 ? argv[2] : "";
+    // energy mode (third argument "energy"): every variant runs for about three seconds back to back while rocm-smi is read once in the
+    // middle: package power and shader clock next to the instruction rate -> energy per wave-instruction above the idle floor
+    const bool energy = argc > 3 && std::string(argv[3]) == "energy";
     while (list >> name >> count) {
         if (!only.empty() && only.find("," + name + ",") == std::string::npos) continue;
         printf("running %s\n", name.c_str());
@@ -33,6 +38,44 @@ int main(int argc, char **argv) {
         void *extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
         hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
         const int rounds = 4;
+        if (energy) {
+            float ms = 0;
+            for (int rep = 0; rep < 2; ++rep) {
+                CK(hipEventRecord(e0, 0));
+                CK(hipModuleLaunchKernel(fn, cus * rounds, 1, 1, 1024, 1, 1, 0, 0, nullptr, extra));
+                CK(hipEventRecord(e1, 0));
+                CK(hipEventSynchronize(e1));
+                CK(hipEventElapsedTime(&ms, e0, e1));
+            }
+            const int reps = (int)(3000.0f / ms) + 1;
+            CK(hipEventRecord(e0, 0));
+            for (int r = 0; r < reps; ++r) CK(hipModuleLaunchKernel(fn, cus * rounds, 1, 1, 1024, 1, 1, 0, 0, nullptr, extra));
+            CK(hipEventRecord(e1, 0));
+            struct timespec ts = {1, 500000000};
+            nanosleep(&ts, nullptr);
+            std::string smi;
+            if (FILE *p = popen("/opt/rocm/bin/rocm-smi --showpower --showclocks --json 2>/dev/null", "r")) {
+                char buf[4096];
+                size_t n;
+                while ((n = fread(buf, 1, sizeof buf, p)) > 0) smi.append(buf, n);
+                pclose(p);
+            }
+            CK(hipEventSynchronize(e1));
+            float total; CK(hipEventElapsedTime(&total, e0, e1));
+            auto field = [&](const char *key) {
+                const size_t at = smi.find(key);
+                if (at == std::string::npos) return std::string("?");
+                const size_t q0 = smi.find('"', at + strlen(key) + 1), q1 = smi.find('"', q0 + 1);
+                return smi.substr(q0 + 1, q1 - q0 - 1);
+            };
+            // wave-instructions per second on the whole chip: reps launches x (cus x rounds) workgroups x 16 waves x count
+            const double wi = (double)reps * cus * rounds * 16 * (double)count / (total * 1e-3);
+            printf("%-14s %7.0f ms  %8.3f G wave-instr/s  power %s W  sclk %s\n", name.c_str(), total, wi / 1e9,
+                   field("Package Power (W)\"").c_str(), field("sclk clock speed:\"").c_str());
+            fflush(stdout);
+            CK(hipModuleUnload(mod));
+            continue;
+        }
         for (int rep = 0; rep < 3; ++rep) {
             CK(hipEventRecord(e0, 0));
             CK(hipModuleLaunchKernel(fn, cus * rounds, 1, 1, 1024, 1, 1, 0, 0, nullptr, extra));
