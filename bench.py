@@ -313,9 +313,10 @@ def main():
             # component k of units u0..u0+nb as an lr_poly over the tensor's memory: poly stride = t.shape[1] * nq limbs
             return ring.Poly.wrap_strided(cQ, t.data_ptr() + ((u0 * t.shape[1] + k) * nq * cN) * esz, nq, nb, t.shape[1] * nq)
 
-        calls = []
+        calls, spans = [], []
         for u0 in range(0, count, chunk):
             nb = min(chunk, count - u0)
+            spans.append((u0, nb))
             calls.append(((comp(dev_in, u0, nb, 0), comp(dev_in, u0, nb, 1)), (comp(dev_in, u0, nb, 2), comp(dev_in, u0, nb, 3)),
                           (comp(dev_out, u0, nb, 0), comp(dev_out, u0, nb, 1))))
 
@@ -324,8 +325,19 @@ def main():
                 plan.MulRelin(level, ct0, ct1, evk, out)
 
         gathered = [None]
+        # the gather runs chunk by chunk behind the products: chunk k moves over xGMI (RCCL, its own stream) while chunk k + 1 is
+        # computed (sharding.ChunkedGather); rank 0's result buffer is allocated once
+        overlapped = use_dist and total % world == 0
+        root_out = torch.empty((total, 2, nq, cN), dtype=torch.int64, device="cuda") if overlapped and rank == 0 else None
 
         def step():
+            if overlapped:
+                cg = sharding.ChunkedGather(dev_out, total, rank, world, dst=0, out=root_out)
+                for (ct0, ct1, out), (u0, nb) in zip(calls, spans):
+                    plan.MulRelin(level, ct0, ct1, evk, out)
+                    cg.submit(u0, nb)
+                gathered[0] = cg.wait()
+                return
             compute()
             gathered[0] = sharding.gather_blocks(dev_out, total, rank, world, dst=0) if use_dist else dev_out
 
@@ -338,7 +350,8 @@ def main():
             "units_total": total, "units_per_gpu": per_gpu, "chunk": chunk, "n_gpus": world,
             "ms_per_step_compute_and_gather": seconds / steps * 1e3, "ms_per_step_compute_only": comp_seconds / steps * 1e3,
             "compute_only_value": total * steps / comp_seconds,
-            "gather": ("torch.distributed.gather(nccl=RCCL) of %d x %.1f MiB to rank 0" % (total, 2 * nq * cN * 8 / 2**20)) if use_dist else "none (single process)",
+            "gather": ("torch.distributed.gather(nccl=RCCL) of %d x %.1f MiB to rank 0%s" % (total, 2 * nq * cN * 8 / 2**20,
+                       ", in chunks of %d products per rank overlapped with the next chunk's kernels" % chunk if overlapped else "")) if use_dist else "none (single process)",
             "gather_bytes_to_root": (total - count) * 2 * nq * cN * 8 if use_dist else 0,
             "roofline": {"bound": "hbm", "achieved": mulrelin_bytes(cN, nq, np_, count) / (comp_ms / steps * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "traffic": None, "pipeline_ms": comp_ms / steps,

@@ -64,3 +64,51 @@ def gather_blocks(local, total, rank, world, dst=0):
         return out
     dist.gather(send, gather_list=None, dst=dst)
     return None
+
+
+class ChunkedGather:
+    """The gather of results overlapped with the computation that produces them ("overlapped with the tail of
+    compute").  A rank's block is produced in chunks; as soon as a chunk is final on the current stream it is handed to
+    ``submit``, which starts an asynchronous ``torch.distributed.gather`` of that chunk from every rank straight into its place of
+    the result on `dst` (zero-copy views, so the blocks must be equal: total % world == 0).  On the nccl backend (RCCL) the
+    collective runs on the communicator's stream behind an event of the current stream, i.e. concurrently with the next chunk's
+    kernels; ``wait`` joins the outstanding collectives into the current stream and returns the [total, ...] result on `dst`
+    (None elsewhere).  Every rank must submit the same chunk boundaries in the same order.
+    """
+
+    def __init__(self, local, total, rank, world, dst=0, out=None):
+        import torch
+        if total % world != 0:
+            raise ValueError("ChunkedGather needs equal blocks (total %d, world %d); use gather_blocks" % (total, world))
+        self.local, self.total, self.rank, self.world, self.dst = local, total, rank, world, dst
+        self.per = total // world
+        if local.shape[0] != self.per:
+            raise ValueError("rank %d holds %d units, its block has %d" % (rank, local.shape[0], self.per))
+        self.out = None
+        if rank == dst:
+            self.out = out if out is not None else torch.empty((total,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+            if tuple(self.out.shape) != (total,) + tuple(local.shape[1:]):
+                raise ValueError("result buffer has the wrong shape")
+        self.works = []
+
+    def submit(self, u0, nb):
+        """units [u0, u0 + nb) of this rank's block are final (on the current stream under nccl)"""
+        import torch.distributed as dist
+        if u0 < 0 or nb <= 0 or u0 + nb > self.per:
+            raise ValueError("chunk [%d, %d) outside the block of %d units" % (u0, u0 + nb, self.per))
+        send = self.local[u0:u0 + nb]
+        if self.world == 1 and not (dist.is_available() and dist.is_initialized()):
+            if self.out.data_ptr() != self.local.data_ptr():
+                self.out[u0:u0 + nb].copy_(send)
+            return
+        if self.rank == self.dst:
+            slots = [self.out[r * self.per + u0:r * self.per + u0 + nb] for r in range(self.world)]
+            self.works.append(dist.gather(send, gather_list=slots, dst=self.dst, async_op=True))
+        else:
+            self.works.append(dist.gather(send, gather_list=None, dst=self.dst, async_op=True))
+
+    def wait(self):
+        for w in self.works:
+            w.wait()
+        self.works = []
+        return self.out

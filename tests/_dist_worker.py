@@ -61,6 +61,17 @@ def main():
     seconds, _ = bench.timed_region(step, steps=2, warmup=1, sync=lambda: None, barrier=barrier, all_max=all_max)
     local = torch.from_numpy(np.ascontiguousarray(result[0]).view(np.int64).reshape(count, L * N))
     gathered = sharding.gather_blocks(local, total_units, rank, world, dst=0)
+    if total_units % world == 0 and count >= 2:
+        # the same gather in chunks handed over as they become final (bench.py's config-5 leg overlaps it with the next chunk)
+        cg = sharding.ChunkedGather(local, total_units, rank, world, dst=0)
+        half = count // 2
+        cg.submit(0, half)
+        cg.submit(half, count - half)
+        chunked = cg.wait()
+        if rank == 0:
+            assert torch.equal(chunked, gathered)
+        else:
+            assert chunked is None
     times = [None] * world
     dist.all_gather_object(times, (rank, start, count, seconds))
     if rank == 0:
