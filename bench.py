@@ -448,6 +448,47 @@ def main():
             del a, b, c, pp, be, cq, cp
         return rows
 
+    # CKKS MulRelin on the default parameter sets of the same degrees (ckks/params.go:36-76; N = 2^16 is the config-5 leg), every rank
+    # on its own batch, whole-job products per second
+    def mulrelin_sets_leg():
+        rows = []
+        for name, mb in (("PN13QP218", 512), ("PN14QP438", 256), ("PN15QP880", 128)):
+            mN, mQ, mP = params.ckks_moduli(name)
+            nq, np_ = len(mQ), len(mP)
+            mcQ, mcP = ring.NewContextWithParams(mN, mQ, device=local), ring.NewContextWithParams(mN, mP, device=local)
+            mplan = ring.CkksPlan(mcQ, mcP, mb)
+            mlevel, mbeta = nq - 1, -(-nq // np_)
+            key_h = sampling.uniform_poly(mQ + mP, mN, 2 * mbeta, seed=9)
+            key = mplan.NewSwitchingKey().set(key_h)
+            ops = [sampling.uniform_poly(mQ, mN, 2, seed=(40 + k) ^ (rank << 8)) for k in range(4)]
+            tile = lambda x: np.concatenate([x] * (mb // 2))
+            c0 = (mcQ.NewPoly(mb).set(tile(ops[0])), mcQ.NewPoly(mb).set(tile(ops[1])))
+            c1 = (mcQ.NewPoly(mb).set(tile(ops[2])), mcQ.NewPoly(mb).set(tile(ops[3])))
+            co = (mcQ.NewPoly(mb), mcQ.NewPoly(mb))
+            fn = lambda: mplan.MulRelin(mlevel, c0, c1, key, co)
+            t_up = time.perf_counter()
+            while time.perf_counter() - t_up < 0.1:
+                for _ in range(3):
+                    fn()
+                mcQ.Sync()
+            barrier()
+            mcQ.TimerStart()
+            for _ in range(5):
+                fn()
+            ms = all_max(mcQ.TimerStop() / 5)
+            row = {"params": name, "N": mN, "limbs_Q": nq, "limbs_P": np_, "batch_per_gpu": mb, "n_gpus": world, "ms_per_batch": ms,
+                   "mulrelin_per_s": mb * world / (ms * 1e-3),
+                   "frac_hbm_per_gpu": mulrelin_bytes(mN, nq, np_, mb) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+            if rank == 0:
+                op = oracle.CkksPlan(oracle.Context(mN, mQ), oracle.Context(mN, mP))
+                j = (mb - 1) % 2
+                want = op.mulrelin(mlevel, np.stack([ops[0][j], ops[1][j]]), np.stack([ops[2][j], ops[3][j]]), key_h.reshape(mbeta, 2, nq + np_, mN))
+                row["bit_exact"] = bool(np.array_equal(np.stack(co[0].get_limb_slices(mb - 1)), want[0]) and
+                                        np.array_equal(np.stack(co[1].get_limb_slices(mb - 1)), want[1]))
+            rows.append(row)
+            del c0, c1, co, key, mplan, mcQ, mcP
+        return rows
+
     # --------------------------------------------------------------------------------------------------------------------
     # headline: forward NTT on R15
     # --------------------------------------------------------------------------------------------------------------------
@@ -664,6 +705,11 @@ def main():
         if rank == 0:
             out["rings"] = rings
         progress("rings timed")
+        if not args.no_ckks:
+            sets = mulrelin_sets_leg()
+            if rank == 0:
+                out["mulrelin_sets"] = sets
+            progress("MulRelin on PN13QP218 / PN14QP438 / PN15QP880 timed on every rank")
     if not args.no_config5 and not args.no_ckks:
         progress("config 5 leg: PN16QP1761, %d products per GPU" % args.config5_units)
         c5 = config5_leg(3, 1)
