@@ -179,6 +179,24 @@ class Probe(Gen):
                     e("v_mad_u64_u32", d, self.JUNK, a.lo(), s(36), d)
                 else:
                     e("v_add_u32", d.lo(), a.lo(), d.hi())
+            elif var.startswith("madadd_"):
+                # runs of k multiply-adds followed by k plain adds: do adjacent plain 32-bit instructions issue at their own (double) rate
+                # inside a multiply stream?
+                k = int(var.split("_")[1])
+                if (i // k) % 2 == 0:
+                    e("v_mad_u64_u32", d, self.JUNK, a.lo(), s(36), d)
+                else:
+                    e("v_add_u32", d.lo(), a.lo(), d.hi())
+            elif var.startswith("madsub_"):
+                # the same with the carry pair the butterfly ends in: k x (v_sub_co_u32 on distinct registers), then k x v_subb_co_u32
+                k = int(var.split("_")[1])
+                ph = (i // k) % 4
+                if ph in (0, 1):
+                    e("v_mad_u64_u32", d, self.JUNK, a.lo(), s(36), d)
+                elif ph == 2:
+                    e("v_sub_co_u32", d.lo(), VCC if i % 2 else s(100, 2), a.lo(), d.lo())
+                else:
+                    e("v_subb_co_u32", d.hi(), VCC if i % 2 else s(100, 2), a.hi(), d.hi(), VCC if i % 2 else s(100, 2))
             elif var == "mulhi_add_mix":
                 if i % 2 == 0:
                     e("v_mul_hi_u32", d.lo(), a.hi(), s(36))
@@ -293,6 +311,7 @@ class Probe(Gen):
         return self.p
 
 
+PAIRING = ["mad_vsv", "add_u32", "madadd_1", "madadd_2", "madadd_4", "madadd_8", "madsub_2", "madsub_4"]
 ENERGY = ["mov", "xor_b32", "add_u32", "lshl_add", "lshl_add_vvv", "mullo_vv", "mulhi_vv", "mulhi_vs", "mad_vs0", "mad_vsv", "mad_vvv", "fma_f32", "fma_f64", "bfly_nc", "bfly_c", "fp64_bfly", "xchg_lds"]
 VARIANTS = ["mad_add_mix", "mulhi_add_mix", "xchg_none", "xchg_lds", "xchg_perm", "xchg_dpp", "mulhi_vs", "mad_vs0", "mad_vsv", "lshl_add", "add_u32", "sub_co_pair", "cndmask_vcc", "fma_f64", "bfly_nc", "bfly_c"]
 _OLD2 = ["cfg_98_36", "cfg_32_36", "cfg_2_36", "cfg_32_68", "cfg_vcc_68", "cfg_98_92", "cfg_98_40", "cfg_34_64", "cfg_2_36_c", "cfg_98_36_c", "cfg_32_36_c"]
@@ -304,7 +323,7 @@ if __name__ == "__main__":
     out = sys.argv[1]
     os.makedirs(out, exist_ok=True)
     meta = []
-    for var in (ENERGY if len(sys.argv) > 2 and sys.argv[2] == "energy" else VARIANTS):
+    for var in ({"energy": ENERGY, "pairing": PAIRING}.get(sys.argv[2] if len(sys.argv) > 2 else "", VARIANTS)):
         g = Probe(var)
         text = kernel_text_for(g, "probe_" + var)
         open(os.path.join(out, var + ".s"), "w").write(text)
