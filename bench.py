@@ -246,7 +246,9 @@ def main():
         import torch.distributed as dist
         if "MASTER_ADDR" not in os.environ:
             os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=os.environ.get("MASTER_PORT", "29533"), RANK="0", WORLD_SIZE="1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+        import datetime
+        # a collective that a peer never joins ends the run after five minutes instead of holding the node
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local), timeout=datetime.timedelta(seconds=300))
         tok = torch.zeros(1, device="cuda")
 
         def barrier():
@@ -699,22 +701,28 @@ def main():
         progress("extras timed")
 
     del src, dst
+
+    def secondary(name, leg):
+        # the legs after the headline must not take the headline's line with them: a failure is reported in the leg's place
+        # (deterministic failures hit every rank alike, so the ranks stay in step)
+        try:
+            res = leg()
+        except Exception as ex:     # noqa: BLE001 -- reported, not swallowed
+            res = {"error": "%s: %s" % (type(ex).__name__, ex)}
+            progress("%s leg failed: %s" % (name, res["error"]))
+        if rank == 0:
+            out[name] = res
+
     if not args.no_rings:
         progress("rings R13..R16: NTT / InvNTT / MulCoeffsMontgomery / ModUpSplitQP on every rank")
-        rings = rings_leg()
-        if rank == 0:
-            out["rings"] = rings
+        secondary("rings", rings_leg)
         progress("rings timed")
         if not args.no_ckks:
-            sets = mulrelin_sets_leg()
-            if rank == 0:
-                out["mulrelin_sets"] = sets
+            secondary("mulrelin_sets", mulrelin_sets_leg)
             progress("MulRelin on PN13QP218 / PN14QP438 / PN15QP880 timed on every rank")
     if not args.no_config5 and not args.no_ckks:
         progress("config 5 leg: PN16QP1761, %d products per GPU" % args.config5_units)
-        c5 = config5_leg(3, 1)
-        if rank == 0:
-            out["config5"] = c5
+        secondary("config5", lambda: config5_leg(3, 1))
         progress("config 5 leg done")
 
     if want_cpu:
