@@ -1368,6 +1368,10 @@ ExtSegment segment(u64 *out, long long stride, int limb0, int col0, int count) {
     s.count = count;
     s.top_tw = nullptr;
     s.top_mod0 = 0;
+    s.epi_mode = 0;
+    s.epi_x = nullptr;
+    s.epi_x_stride = 0;
+    s.epi_c = s.epi_s = nullptr;
     return s;
 }
 
@@ -2624,8 +2628,15 @@ struct lr_bfv_plan {
     lr_bext *bext = nullptr;
     u64 t = 0;
     LimbScalars phalf_q, phalf_m;     // pHalf = (prod QMul) >> 1 reduced modulo each prime
+    LimbScalars t_mont;               // MForm(t mod q_i), bfv/evaluator.go:462
+    u64 *d_phalf_q = nullptr, *d_phalf_m = nullptr, *d_t_mont = nullptr;   // the same as device arrays (extension epilogues)
     int max_batch = 0;
+    bool no_ext_epilogue = false;     // LR_BFV_NO_EXT_EPILOGUE: separate subtract-multiply / scalar passes after the extensions
     Pool aQ[2], aM[2], bQ[2], bM[2], cQ3[3], cM3[3];
+    ~lr_bfv_plan() {
+        for (u64 *p : {d_phalf_q, d_phalf_m, d_t_mont})
+            if (p) (void)hipFree(p);
+    }
 };
 
 namespace {
@@ -2665,6 +2676,14 @@ extern "C" int lr_bfv_plan_create(lr_context *cQ, lr_context *cM, uint64_t t, in
     p->max_batch = max_batch;
     half_product_residues(cM->h.q, cQ->h.q, p->phalf_q);
     half_product_residues(cM->h.q, cM->h.q, p->phalf_m);
+    std::memset(&p->t_mont, 0, sizeof(p->t_mont));
+    for (int i = 0; i < cQ->h.L(); ++i)
+        p->t_mont.v[i] = mform(bred_add(t, cQ->h.q[i], cQ->h.bred[i].hi), cQ->h.q[i], cQ->h.bred[i].hi, cQ->h.bred[i].lo);
+    LR_HIP(hipSetDevice(cQ->device));
+    LR_TRY(to_device(&p->d_phalf_q, p->phalf_q.v, (size_t)cQ->h.L()));
+    LR_TRY(to_device(&p->d_phalf_m, p->phalf_m.v, (size_t)cM->h.L()));
+    LR_TRY(to_device(&p->d_t_mont, p->t_mont.v, (size_t)cQ->h.L()));
+    p->no_ext_epilogue = std::getenv("LR_BFV_NO_EXT_EPILOGUE") != nullptr;
     LR_TRY(lr_bext_create(cQ, cM, &p->bext));
     *out = p.release();
     return LR_OK;
@@ -2740,22 +2759,40 @@ extern "C" int lr_bfv_mul(lr_bfv_plan *pl, const lr_poly *a0, const lr_poly *a1,
         LR_HIP(launch_tensor(T, base == 0 ? nQ : nM, batch, cx->stream));
     }
     // :423-463 back to coefficients, divide by Q (result over QMul), centre, back to Q, times t
-    LimbScalars tsc;
-    for (int i = 0; i < nQ; ++i) tsc.v[i] = mform(bred_add(pl->t, cQ->h.q[i], cQ->h.bred[i].hi), cQ->h.q[i], cQ->h.bred[i].hi, cQ->h.bred[i].lo);
+    const LimbScalars &tsc = pl->t_mont;
     const long long poolM_stride = sM;
-    LR_TRY(bx->poolP.ensure(cM, (size_t)batch * poolM_stride));
+    // the element-wise tails ride in the extensions' stores where the extension kernel in use has the epilogue (ExtSegment::epi_mode)
+    const bool fuse_down = !pl->no_ext_epilogue && ext_epilogue_supported(bx->qp.tables(), nQ, n);
+    const bool fuse_up = !pl->no_ext_epilogue && ext_epilogue_supported(bx->pq.tables(), nM, n);
+    if (!fuse_down) LR_TRY(bx->poolP.ensure(cM, (size_t)batch * poolM_stride));
     for (int i = 0; i < 3; ++i) {
         Rows q1{pl->cQ3[i].d, sQ, 0, 1}, q2{pl->cM3[i].d, sM, 0, 1};
         LR_TRY(run_ntt(cQ, true, q1, q1, 0, 1, nQ, batch));
         LR_TRY(run_ntt(cM, true, q2, q2, 0, 1, nM, batch));
-        // ModDownSplitedQP(levelQ, levelQMul, c2Q1, c2Q2, c2Q2), ring_basis_extension.go:314
-        LR_TRY(run_ext(cQ, bx->qp, nQ, q1, batch, segment(bx->poolP.d, poolM_stride, 0, 0, nM), segment(nullptr, 0, 0, 0, 0)));
-        // the subtract-multiply of the ModDown with the AddScalarBigint(pHalf) of :457 as its epilogue
-        LR_TRY(run_submul(cM, nM, batch, pl->cM3[i].d, sM, bx->poolP.d, poolM_stride, (long long)n, pl->cM3[i].d, sM, bx->d_moddown_qp, false, nullptr,
-                          nullptr, 0, &pl->phalf_m));
-        LR_TRY(run_ext(cQ, bx->pq, nM, q2, batch, segment(O[i]->d, O[i]->stride(), 0, 0, nQ), segment(nullptr, 0, 0, 0, 0)));       // :458 ModUpSplitPQ
-        {
-            ScalarPairLaunch S;                                                                                                     // :459 + :462
+        // ModDownSplitedQP(levelQ, levelQMul, c2Q1, c2Q2, c2Q2), ring_basis_extension.go:314, with the AddScalarBigint(pHalf) of :457
+        if (fuse_down) {
+            ExtSegment sd = segment(pl->cM3[i].d, sM, 0, 0, nM);
+            sd.epi_mode = 1;
+            sd.epi_x = pl->cM3[i].d;               // read and written at the same position by the same thread
+            sd.epi_x_stride = sM;
+            sd.epi_c = bx->d_moddown_qp;
+            sd.epi_s = pl->d_phalf_m;
+            LR_TRY(run_ext(cQ, bx->qp, nQ, q1, batch, sd, segment(nullptr, 0, 0, 0, 0)));
+        } else {
+            LR_TRY(run_ext(cQ, bx->qp, nQ, q1, batch, segment(bx->poolP.d, poolM_stride, 0, 0, nM), segment(nullptr, 0, 0, 0, 0)));
+            LR_TRY(run_submul(cM, nM, batch, pl->cM3[i].d, sM, bx->poolP.d, poolM_stride, (long long)n, pl->cM3[i].d, sM, bx->d_moddown_qp, false, nullptr,
+                              nullptr, 0, &pl->phalf_m));
+        }
+        // :458 ModUpSplitPQ, :459 SubScalarBigint(pHalf), :462 MulScalar(t)
+        if (fuse_up) {
+            ExtSegment su = segment(O[i]->d, O[i]->stride(), 0, 0, nQ);
+            su.epi_mode = 2;
+            su.epi_c = pl->d_t_mont;
+            su.epi_s = pl->d_phalf_q;
+            LR_TRY(run_ext(cQ, bx->pq, nM, q2, batch, su, segment(nullptr, 0, 0, 0, 0)));
+        } else {
+            LR_TRY(run_ext(cQ, bx->pq, nM, q2, batch, segment(O[i]->d, O[i]->stride(), 0, 0, nQ), segment(nullptr, 0, 0, 0, 0)));
+            ScalarPairLaunch S;
             S.in = O[i]->d;
             S.out = O[i]->d;
             S.in_stride = S.out_stride = O[i]->stride();

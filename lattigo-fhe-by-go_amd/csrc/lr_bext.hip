@@ -186,6 +186,13 @@ __device__ __forceinline__ u64 bred_word(u64 x, u64 p, u64 p2, u32 u) {
 // psi[1] from the target limb's forward table -- so that the 2^15 sub-block transforms that follow read their own half only
 // (the "p" kernels) instead of both halves (the fused "s" kernels, 1.5 x the traffic).  The transform is the canonical one either
 // way: its first stage has merely moved into the kernel that produces its input.
+
+// ExtSegment::epi_mode on one canonical extension value
+__device__ __forceinline__ u64 ext_epilogue(int mode, u64 e, u64 x, u64 p, u64 pinv, u64 c, u64 sc) {
+    if (mode == 1) return cred(mred(x + (p - e), c, p, pinv) + sc, p);
+    return mred(cred(e + (p - sc), p), c, p, pinv);
+}
+
 // constants of one target limb (column of the extension tables), wave-uniform
 template <int NIN>
 struct ExtColumn {
@@ -297,6 +304,13 @@ __global__ __launch_bounds__(256) void ext_sum_kernel(ExtLaunch L) {
                     r[w] = r[w] + t;                                                  // X in [0, 3p)
                 }
             }
+            if (!TOP && sg.epi_mode) {
+                const int col = sg.col0 + jj;
+                const u64 pinv = ld_const(L.t.mredP + col), ec = ld_const(sg.epi_c + col), es = ld_const(sg.epi_s + col);
+                const u64 *px = sg.epi_x + b * sg.epi_x_stride + (long long)(sg.limb0 + jj) * L.n + W * xw;
+#pragma unroll
+                for (int w = 0; w < W; ++w) r[w] = ext_epilogue(sg.epi_mode, r[w], sg.epi_mode == 1 ? ld_stream(px + w) : 0, pj, pinv, ec, es);
+            }
 #pragma unroll
             for (int h = 0; h < C / W; ++h) {
                 u64 *dst = out + (long long)jj * L.n + (long long)h * span;
@@ -398,6 +412,12 @@ __global__ __launch_bounds__(256) void ext_wide_kernel(ExtLaunch L) {
                     }
                 }
             }
+            if (sg.epi_mode) {
+                const u64 ec = ld_const(sg.epi_c + col), es = ld_const(sg.epi_s + col);
+                const u64 *px = sg.epi_x + b * sg.epi_x_stride + (long long)(sg.limb0 + jj) * L.n + W * xw;
+#pragma unroll
+                for (int w = 0; w < W; ++w) r[w] = ext_epilogue(sg.epi_mode, r[w], sg.epi_mode == 1 ? ld_stream(px + w) : 0, pj, pinv, ec, es);
+            }
             if (W == 2) st_stream(reinterpret_cast<ulonglong2 *>(out + (long long)jj * L.n), make_ulonglong2(r[0], r[W - 1]));
             else st_stream(out + (long long)jj * L.n, r[0]);
         }
@@ -441,6 +461,14 @@ static hipError_t launch_n(const ExtLaunch &L, int batch, hipStream_t stream) {
 // the top-stage variant exists for the sum-form kernel with at most eight input limbs (the key-switch digits have alpha <= 8)
 bool ext_top_supported(const ExtTables &t, int n_in, int n) {
     return (n & 3) == 0 && n_in >= 1 && n_in <= 8 && t.exact_terms >= 4 && t.word_barrett && t.lazy_terms >= (n_in < 2 ? 2 : n_in);
+}
+
+// ExtSegment::epi_mode is implemented by the sum-form and the 128-bit-sum kernels: does launch_n pick one of them for this shape?
+bool ext_epilogue_supported(const ExtTables &t, int n_in, int n) {
+    if ((n & 1) != 0 || t.exact_terms < 4) return false;
+    if (t.lazy_terms >= (n_in < 2 ? 2 : n_in) && t.word_barrett) return true;
+    if (t.lazy_terms >= n_in) return false;
+    return t.wide_ok >= n_in || (t.wide_ok >= 16 && n_in > 16) || (t.wide_ok >= 8 && n_in > 8);
 }
 
 // ---- diagnostics: div_by_const against the IEEE division it replaces ---------------------------------------------------------

@@ -245,6 +245,14 @@ struct ExtSegment {       // rows [limb0, limb0+count) of `out` receive table co
     // output moduli ([L][N] entries {w, floor(w 2^64 / q)}) and the modulus index of the segment's first row; nullptr = plain extension
     const Twiddle *top_tw;
     int top_mod0;
+    // epilogue on the canonical extension value e of a row (target modulus p, table column col), plain (non-top) kernels only:
+    //   1: out = CRed(MRed(x + (p - e), c[col]) + s[col])   x = the row of `epi_x` at the output's position: the subtract-multiply of a
+    //      ModDown (ring_basis_extension.go:237-239) with the scalar addition that follows it in bfv/evaluator.go:457
+    //   2: out = MRed(CRed(e + (p - s[col])), c[col])          bfv/evaluator.go:459,462 (SubScalarBigint, MulScalar)
+    int epi_mode;               // 0 = none
+    const u64 *epi_x;
+    long long epi_x_stride;
+    const u64 *epi_c, *epi_s;   // device arrays over the table columns
 };
 
 struct ExtLaunch {
@@ -303,6 +311,7 @@ hipError_t launch_submul(const SubMulLaunch &L, int limbs, int batch, hipStream_
 hipError_t launch_rowadd(const RowAddLaunch &L, int rows, int batch, hipStream_t stream);
 hipError_t launch_ext(const ExtLaunch &L, int n_in, int batch, hipStream_t stream);
 bool ext_top_supported(const ExtTables &t, int n_in, int n);
+bool ext_epilogue_supported(const ExtTables &t, int n_in, int n);
 hipError_t launch_div_selftest(u64 seed, int blocks, int per_thread, unsigned long long *d_mismatches, hipStream_t stream);
 
 }  // namespace lr

@@ -91,6 +91,14 @@ def test_bfv_mul(gpu_pkg, oracle, name, logn):
             assert np.array_equal(out[k].get()[b], want[k]), (b, k)
 
 
+@pytest.mark.parametrize("name,logn", [("PN13QP218", 11), ("PN14QP438", 14)])
+def test_bfv_mul_without_extension_epilogues(gpu_pkg, oracle, name, logn, monkeypatch):
+    """the same with the subtract-multiply of the ModDown and the SubScalar / MulScalar tail as separate passes instead of in the
+    extension kernels' stores (the switch is read when the plan is created)"""
+    monkeypatch.setenv("LR_BFV_NO_EXT_EPILOGUE", "1")
+    test_bfv_mul(gpu_pkg, oracle, name, logn)
+
+
 def _galois(gpu_pkg, N, k):
     """Galois element of a left rotation by k: 5^k mod 2N (ckks/keygen.go:281-286 GenRot... -> ring.PermuteNTTIndex(GaloisGen, k, N))"""
     return pow(5, k, 2 * N)
