@@ -1505,6 +1505,15 @@ int moddown_pq_core(lr_bext *b, int level, const u64 *p1Q, long long p1Q_stride,
     lr_context *cQ = b->cQ;
     const int nP = b->cP->h.L();
     const long long pool_stride = (long long)cQ->h.L() * (long long)cQ->h.N;
+    if (!ntt && !cQ->opt.no_epilogue && ext_epilogue_supported(b->pq.tables(), nP, (int)cQ->h.N)) {
+        // coefficient domain: the subtract-multiply rides in the extension's stores (ExtSegment::epi_mode 1)
+        ExtSegment sd = segment(p2->d, p2->stride(), 0, 0, level + 1);
+        sd.epi_mode = 1;
+        sd.epi_x = p1Q;
+        sd.epi_x_stride = p1Q_stride;
+        sd.epi_c = b->d_moddown_pq;
+        return run_ext(cQ, b->pq, nP, pP, batch, sd, segment(nullptr, 0, 0, 0, 0));
+    }
     LR_TRY(b->poolQ.ensure(cQ, (size_t)batch * pool_stride));
     LR_TRY(run_ext(cQ, b->pq, nP, pP, batch, segment(b->poolQ.d, pool_stride, 0, 0, level + 1), segment(nullptr, 0, 0, 0, 0)));
     if (ntt) {
@@ -1586,6 +1595,14 @@ extern "C" int lr_moddown_split_qp(lr_bext *b, int levelQ, int levelP, const lr_
     LR_HIP(hipSetDevice(cP->device));
     const int batch = p2->batch;
     const long long pool_stride = (long long)nP * (long long)cP->h.N;
+    if (!cP->opt.no_epilogue && ext_epilogue_supported(b->qp.tables(), levelQ + 1, (int)cP->h.N)) {
+        ExtSegment sd = segment(p2->d, p2->stride(), 0, 0, levelP + 1);
+        sd.epi_mode = 1;
+        sd.epi_x = p1P->d;
+        sd.epi_x_stride = p1P->stride();
+        sd.epi_c = b->d_moddown_qp;
+        return run_ext(b->cQ, b->qp, levelQ + 1, rows_of(p1Q), batch, sd, segment(nullptr, 0, 0, 0, 0));
+    }
     LR_TRY(b->poolP.ensure(cP, (size_t)batch * pool_stride));
     // ModUpSplitQP(levelQ, p1Q, polypool), :332
     LR_TRY(run_ext(b->cQ, b->qp, levelQ + 1, rows_of(p1Q), batch, segment(b->poolP.d, pool_stride, 0, 0, nP),

@@ -306,7 +306,7 @@ __global__ __launch_bounds__(256) void ext_sum_kernel(ExtLaunch L) {
             }
             if (!TOP && sg.epi_mode) {
                 const int col = sg.col0 + jj;
-                const u64 pinv = ld_const(L.t.mredP + col), ec = ld_const(sg.epi_c + col), es = ld_const(sg.epi_s + col);
+                const u64 pinv = ld_const(L.t.mredP + col), ec = ld_const(sg.epi_c + col), es = sg.epi_s ? ld_const(sg.epi_s + col) : 0;
                 const u64 *px = sg.epi_x + b * sg.epi_x_stride + (long long)(sg.limb0 + jj) * L.n + W * xw;
 #pragma unroll
                 for (int w = 0; w < W; ++w) r[w] = ext_epilogue(sg.epi_mode, r[w], sg.epi_mode == 1 ? ld_stream(px + w) : 0, pj, pinv, ec, es);
@@ -413,7 +413,7 @@ __global__ __launch_bounds__(256) void ext_wide_kernel(ExtLaunch L) {
                 }
             }
             if (sg.epi_mode) {
-                const u64 ec = ld_const(sg.epi_c + col), es = ld_const(sg.epi_s + col);
+                const u64 ec = ld_const(sg.epi_c + col), es = sg.epi_s ? ld_const(sg.epi_s + col) : 0;
                 const u64 *px = sg.epi_x + b * sg.epi_x_stride + (long long)(sg.limb0 + jj) * L.n + W * xw;
 #pragma unroll
                 for (int w = 0; w < W; ++w) r[w] = ext_epilogue(sg.epi_mode, r[w], sg.epi_mode == 1 ? ld_stream(px + w) : 0, pj, pinv, ec, es);

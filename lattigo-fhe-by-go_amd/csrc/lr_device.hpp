@@ -252,7 +252,7 @@ struct ExtSegment {       // rows [limb0, limb0+count) of `out` receive table co
     int epi_mode;               // 0 = none
     const u64 *epi_x;
     long long epi_x_stride;
-    const u64 *epi_c, *epi_s;   // device arrays over the table columns
+    const u64 *epi_c, *epi_s;   // device arrays over the table columns (epi_s == nullptr: zeros)
 };
 
 struct ExtLaunch {

@@ -192,6 +192,15 @@ def test_moddown_variants(gpu_pkg, oracle, nq, np_, level):
         assert np.array_equal(outp.get()[b], obe.moddown_split_qp(level, np_ - 1, xq[b], xp[b]))
 
 
+@pytest.mark.parametrize("nq,np_,level", [(4, 2, 3), (18, 3, 17)])
+def test_moddown_variants_with_separate_passes(gpu_pkg, oracle, nq, np_, level, monkeypatch):
+    """the coefficient-domain ModDowns write MRed(x + (q - ext), c) from the extension kernel's stores by default; LR_NO_EPILOGUE (read
+    when the contexts are created) keeps the extension -> pool -> subtract-multiply passes"""
+    monkeypatch.setenv("LR_NO_EPILOGUE", "1")
+    test_moddown_variants(gpu_pkg, oracle, nq, np_, level)
+
+
+
 @pytest.mark.parametrize("nq,np_,level", [(6, 2, 5), (6, 2, 4), (6, 2, 2), (7, 3, 6), (7, 3, 3), (5, 1, 4), (18, 3, 17),
                                           (18, 3, 9)])
 def test_decomposer(gpu_pkg, oracle, nq, np_, level):
