@@ -66,6 +66,36 @@ def gather_blocks(local, total, rank, world, dst=0):
     return None
 
 
+def all_gather_blocks(local, total, rank, world):
+    """Every rank receives every rank's block in global unit order ("ncclAllGather if every rank needs all outputs").
+    Equal blocks go through one ``all_gather_into_tensor``; unequal ones are padded to the largest block and trimmed on arrival.
+    Note the cost on xGMI: every block crosses every rank's links, seven times the root gather's traffic per link."""
+    import torch
+    import torch.distributed as dist
+
+    start, count = shard_units(total, rank, world)
+    if local.shape[0] != count:
+        raise ValueError("rank %d holds %d units, its block has %d" % (rank, local.shape[0], count))
+    if world == 1 and not (dist.is_available() and dist.is_initialized()):
+        return local
+    biggest = -(-total // world)
+    send = local.contiguous()
+    if total % world == 0:
+        out = torch.empty((total,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        dist.all_gather_into_tensor(out, send)
+        return out
+    if count < biggest:
+        pad = torch.zeros((biggest - count,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        send = torch.cat([send, pad], dim=0)
+    recv = [torch.empty_like(send) for _ in range(world)]
+    dist.all_gather(recv, send)
+    out = torch.empty((total,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    for r in range(world):
+        s, c = shard_units(total, r, world)
+        out[s:s + c] = recv[r][:c]
+    return out
+
+
 class ChunkedGather:
     """The gather of results overlapped with the computation that produces them ("overlapped with the tail of
     compute").  A rank's block is produced in chunks; as soon as a chunk is final on the current stream it is handed to

@@ -72,6 +72,13 @@ def main():
             assert torch.equal(chunked, gathered)
         else:
             assert chunked is None
+    everywhere = sharding.all_gather_blocks(local, total_units, rank, world)
+    assert everywhere.shape == (total_units, L * N)
+    if rank == 0:
+        assert torch.equal(everywhere, gathered)
+    else:
+        # every rank holds its own block at its place of the result
+        assert torch.equal(everywhere[start:start + count], local)
     times = [None] * world
     dist.all_gather_object(times, (rank, start, count, seconds))
     if rank == 0:
