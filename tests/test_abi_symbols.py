@@ -3,6 +3,8 @@ import ctypes
 import os
 import re
 
+import pytest
+
 from conftest import ROOT
 
 
@@ -41,3 +43,20 @@ def test_argument_errors_do_not_need_a_device(pkg):
     assert lib.lr_context_create(1 << 12, bad, 1, 0, ctypes.byref(h)) == 2
     assert b"does not allow NTT" in lib.lr_last_error_string()
     assert lib.lr_context_create(1 << 12, None, 1, 0, ctypes.byref(h)) == 4
+
+
+def test_product_refuses_to_run_without_its_library(pkg, monkeypatch):
+    """no CPU fallback: with the shared library missing, the first call of the binding raises and names the build step; and with the
+    library present but no device, creating a context reports the HIP error instead of computing anywhere else"""
+    nat = pkg._native
+    monkeypatch.setattr(nat, "_lib", None)
+    monkeypatch.setattr(nat, "LIB_PATH", nat.LIB_PATH + ".missing")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        nat.lib()
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        pkg.ring.NewContextWithParams(16, [pkg.params.Qi60()[-1]])
+    monkeypatch.undo()
+    if nat.device_count() == 0:
+        with pytest.raises(nat.LatticeRingError) as e:
+            pkg.ring.NewContextWithParams(16, [pkg.params.Qi60()[-1]])
+        assert e.value.code == 5                                                 # LR_ERR_HIP: no device to create the context on
