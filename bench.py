@@ -18,8 +18,10 @@ compute+gather times are reported separately.  The default run carries this leg 
 
 Prints one JSON line (rank 0).  `value` = units per second over all GPUs; `roofline.achieved` = algorithmic bytes
  / device time measured with HIP events on the launch stream inside this run; `roofline.kernel` is the
-kernel the library reports it dispatched.  `roofline.traffic` is null here: PMC counters need their own rocprofv3 passes
-(tools/collect_profiles.sh writes them to profiles/, named in `traffic_profile`).  `cpu_baseline` objects time the CPU oracle
+kernel the library reports it dispatched.  `roofline.traffic` (HBM bytes per launch, and per product on the MulRelin leg) is counted in
+the run at N = 1: PMC counters need their own rocprofv3 passes, so four short child runs of `rocprofv3 --pmc` (FETCH_SIZE, WRITE_SIZE, one
+counter each) execute the same kernel / pipeline on the same shape at the end; null with the reason in `traffic_source` if the profiler
+cannot run (--no-traffic skips it; tools/collect_profiles.sh writes the committed figures named in `traffic_profile`).  `cpu_baseline` objects time the CPU oracle
 (C restatement of the Go algorithm, rebuilt -O2 -march=native on this machine; Go itself is not installable here) on the
 host cores, rank 0 at N=1 only, on bounded samples.
 """
@@ -152,6 +154,74 @@ def effective_cores():
     return n
 
 
+def _pmc_passes(script_args, pick, timeout=180):
+    """Two child runs of `rocprofv3 --pmc` (FETCH_SIZE, WRITE_SIZE: one counter per pass, no trace domains) over a script under tools/dbg;
+    pick(rows, stdout) turns a pass's counter rows into one number of KB.  Returns ({counter: KB}, None) or (None, reason)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    kb = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        out_dir = tempfile.mkdtemp(prefix="lr_pmc_", dir="/tmp")
+        try:
+            env = dict(os.environ, TMPDIR="/tmp")
+            # the profiled program goes directly after `--`: the interpreter binary itself, no wrapper
+            cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", out_dir, "-o", "p", "--", os.path.realpath(sys.executable)] + script_args
+            res = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=timeout)
+            rows = []
+            for f in glob.glob(os.path.join(out_dir, "**", "*counter_collection.csv"), recursive=True):
+                rows += [r for r in csv.DictReader(open(f)) if r["Counter_Name"] == counter]
+            val = pick(rows, res.stdout.decode(errors="replace")) if res.returncode == 0 and rows else None
+            if val is None:
+                return None, "%s pass: rc %d, %d counter rows" % (counter, res.returncode, len(rows))
+            kb[counter] = val
+        except Exception as ex:     # noqa: BLE001 -- the measurement is optional, the reason is reported
+            return None, "%s pass: %s" % (counter, ex)
+        finally:
+            shutil.rmtree(out_dir, ignore_errors=True)
+    return kb, None
+
+
+def _tool(name):
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "dbg", name)
+
+
+def measure_hbm_traffic(kernel_name, logn):
+    """HBM bytes of one launch of the headline kernel, counted now: tools/dbg/pmc_run.py launches the same kernel on the same shape
+    under the profiler; per-launch median, FETCH_SIZE doubled per the gfx950 correction of the microarch guide.  Returns (bytes, detail)
+    or (None, reason): the line then carries null and points at the committed profile."""
+    import statistics
+
+    def pick(rows, _stdout):
+        vals = [float(r["Counter_Value"]) for r in rows if r["Kernel_Name"] == kernel_name]
+        return statistics.median(vals) if vals else None
+
+    kb, why = _pmc_passes([_tool("pmc_run.py"), str(logn)], pick)
+    if kb is None:
+        return None, why
+    return 2 * kb["FETCH_SIZE"] * 1024 + kb["WRITE_SIZE"] * 1024, {"FETCH_SIZE_KB": kb["FETCH_SIZE"], "WRITE_SIZE_KB": kb["WRITE_SIZE"]}
+
+
+def measure_mulrelin_traffic(name, batch, calls):
+    """HBM bytes per ciphertext product of the MulRelin pipeline: every kernel of tools/dbg/mulrelin_pmc.py summed (the runtime's own fill /
+    copy kernels of the set-up excluded) and divided by the products it executed."""
+    def pick(rows, stdout):
+        marks = [l for l in stdout.splitlines() if l.startswith("PRODUCTS")]
+        if not marks:
+            return None
+        return sum(float(r["Counter_Value"]) for r in rows if "rocclr" not in r["Kernel_Name"]) / int(marks[-1].split()[1])
+
+    kb, why = _pmc_passes([_tool("mulrelin_pmc.py"), name, str(batch), str(calls)], pick)
+    if kb is None:
+        return None, why
+    return 2 * kb["FETCH_SIZE"] * 1024 + kb["WRITE_SIZE"] * 1024, {"FETCH_SIZE_KB_per_product": kb["FETCH_SIZE"], "WRITE_SIZE_KB_per_product": kb["WRITE_SIZE"]}
+
+
 def progress(msg):
     print("[bench %6.1fs] %s" % (time.perf_counter() - _T0, msg), file=sys.stderr, flush=True)
 
@@ -209,6 +279,7 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="polynomials per GPU (workload ntt)")
     ap.add_argument("--logn", type=int, default=15)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 --pmc child runs that fill roofline.traffic (N = 1, default shape)")
     ap.add_argument("--no-rings", action="store_true", help="skip the R13..R16 table (NTT / InvNTT / MulCoeffsMontgomery / ModUpSplitQP on every rank)")
     ap.add_argument("--rings-bytes", type=int, default=1 << 30, help="bytes per operand of the R13..R16 table")
     ap.add_argument("--no-extras", action="store_true", help="skip the InvNTT / MulCoeffsMontgomery / ModUp timings")
@@ -550,8 +621,8 @@ def main():
         "bit_exact": bit_exact,
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS,
-                     # PMC counters cannot be read inside this run (rocprofv3 --pmc needs its own passes): null here, the
-                     # collected figure for this kernel and shape lives in the file below (tools/collect_profiles.sh)
+                     # PMC counters need their own rocprofv3 passes: filled at the end of the run by two child runs on the same
+                     # kernel and shape (measure_hbm_traffic); null if that is skipped or fails, the committed figure is in the file
                      "traffic": None, "traffic_profile": "profiles/r02/pmc_hbm.json",
                      "kernel": kernel_name, "asm_variant": fwd_variant, "kernel_ms": kernel_ms,
                      "algorithmic_bytes_per_launch": ntt_bytes(N, L, my_polys),
@@ -724,6 +795,24 @@ def main():
         progress("config 5 leg: PN16QP1761, %d products per GPU" % args.config5_units)
         secondary("config5", lambda: config5_leg(3, 1))
         progress("config 5 leg done")
+
+    if rank == 0 and world == 1 and not use_dist and not args.no_traffic and B == (1 << 30) // (8 * N * L):
+        progress("HBM traffic of one %s launch: two rocprofv3 --pmc child runs" % kernel_name)
+        traffic, detail = measure_hbm_traffic(kernel_name, args.logn)
+        out["roofline"]["traffic"] = traffic
+        out["roofline"]["traffic_source"] = ({"how": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate child passes over tools/dbg/pmc_run.py in this run; "
+                                                     "2 x FETCH_SIZE + WRITE_SIZE (KB) per launch, median", **detail,
+                                              "ratio_to_algorithmic": traffic / ntt_bytes(N, L, my_polys)} if traffic is not None
+                                             else {"how": "not measured in this run: %s" % detail})
+        progress("traffic: %s" % (("%.4f x algorithmic" % (traffic / ntt_bytes(N, L, my_polys))) if traffic is not None else detail))
+        if "ckks_mulrelin" in out and "roofline" in out["ckks_mulrelin"]:
+            mt, md = measure_mulrelin_traffic("PN15QP880", 64, 4)
+            mr = out["ckks_mulrelin"]["roofline"]
+            mr["traffic"] = mt
+            mr["traffic_source"] = ({"how": "rocprofv3 --pmc child passes over tools/dbg/mulrelin_pmc.py PN15QP880 64 4 in this run, all kernels summed, per product",
+                                     **md, "ratio_to_algorithmic": mt / mr["algorithmic_bytes_per_product"]} if mt is not None
+                                    else {"how": "not measured in this run: %s" % md})
+            progress("MulRelin traffic: %s" % (("%.1f MB per product = %.3f x algorithmic" % (mt / 1e6, mt / mr["algorithmic_bytes_per_product"])) if mt is not None else md))
 
     if want_cpu:
         def mk_ntt(i):

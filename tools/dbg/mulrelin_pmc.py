@@ -1,8 +1,9 @@
 """One launch pattern for counter collection: K calls of lr_ckks_mulrelin (PN15QP880 or PN16QP1761), nothing else after set-up.
     python tools/dbg/mulrelin_pmc.py PN15QP880 64 4
 Prints the number of ciphertext products executed, so that the collector can divide the summed counters by it."""
+import os
 import sys
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import __graft_entry__ as g
 pkg = g.load_package()

@@ -1,6 +1,7 @@
 """One launch pattern for counter collection: forward NTT R15 (batch 256), a few launches."""
+import os
 import sys
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import __graft_entry__ as g
 pkg = g.load_package()
