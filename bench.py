@@ -813,6 +813,14 @@ def main():
                                      **md, "ratio_to_algorithmic": mt / mr["algorithmic_bytes_per_product"]} if mt is not None
                                     else {"how": "not measured in this run: %s" % md})
             progress("MulRelin traffic: %s" % (("%.1f MB per product = %.3f x algorithmic" % (mt / 1e6, mt / mr["algorithmic_bytes_per_product"])) if mt is not None else md))
+        if isinstance(out.get("config5"), dict) and "roofline" in out["config5"]:
+            mt, md = measure_mulrelin_traffic("PN16QP1761", 32, 2)
+            mr = out["config5"]["roofline"]
+            mr["traffic"] = mt
+            mr["traffic_source"] = ({"how": "rocprofv3 --pmc child passes over tools/dbg/mulrelin_pmc.py PN16QP1761 32 2 in this run, all kernels summed, per product",
+                                     **md, "ratio_to_algorithmic": mt / mr["algorithmic_bytes_per_product"]} if mt is not None
+                                    else {"how": "not measured in this run: %s" % md})
+            progress("config-5 MulRelin traffic: %s" % (("%.2f GB per product = %.3f x algorithmic" % (mt / 1e9, mt / mr["algorithmic_bytes_per_product"])) if mt is not None else md))
 
     if want_cpu:
         def mk_ntt(i):
