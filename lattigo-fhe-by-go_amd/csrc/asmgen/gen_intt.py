@@ -25,9 +25,10 @@ class GenInv(Gen):
     """mode 1: every modulus in (2^33, 2^60], bound B = 8q as described above;
        mode 0: moduli up to 2^61: B = 4q and every butterfly corrects."""
 
-    def __init__(self, logn, mode=1, threads=1024, sub=False, fp=False, dual=False, fuse_last=False):
+    def __init__(self, logn, mode=1, threads=1024, sub=False, fp=False, dual=False, fuse_last=False, profile=False):
         assert mode in (0, 1)
-        super().__init__(logn, mode, threads, sub, fp=fp, dual=dual)
+        super().__init__(logn, mode, threads, sub, fp=fp, dual=dual, profile=profile)
+        self.karg_parked = profile
         # fuse_last (sub-block kernels of N = 2^16): no ntt_top_kernel pass afterwards.  Every wave stores its lazy rows, makes them
         # visible to the device and bumps the flag it shares with the same wave of the limb's other sub-block; the wave that finds
         # the flag already bumped (its partner's rows are complete) loads them and finishes both halves: last stage + scaling.
@@ -196,6 +197,14 @@ class GenInv(Gen):
     # ------------------------------------------------------------------ sections
     def prologue_tail(self):
         e = self.e
+        if self.profile:
+            # s[0:1] becomes the LimbParams pointer below: flush_stamps() finds the kernel-argument pointer in the row-0 padding
+            e("s_mul_i32", self.SC[3], self.WAVE, 9216)
+            e("v_mov_b32", v(4), self.SC[3])
+            e("v_mov_b32", v(2), self.KARG.lo())
+            e("v_mov_b32", v(3), self.KARG.hi())
+            e("ds_write_b64", v(4), v(2, 2), offset=136)
+            self.stamp(0)
         if self.dual:
             self.mark = len(self.p.ins)
         if self.fp:
@@ -567,6 +576,11 @@ class GenInv(Gen):
                     e("s_add_u32", ptr.lo(), ptr.lo(), self.S * 8)
                     e("s_addc_u32", ptr.hi(), ptr.hi(), 0)
 
+    # stamps of the timeline build, in order (tools/timeline.py names the intervals between them)
+    STAMP_NAMES = ["start"] + ["%s (half %d)" % (n, h) for h in range(2) for n in (
+        "copy-in: loads returned, LDS written", "stages over bits 0..3", "stages over bits 4..6", "stages over bits 7..9",
+        "column exchange")] + ["top stages + last stage", "stores issued"]
+
     def build(self):
         self.plan = self.chunk_plan()
         self.prologue()
@@ -576,17 +590,26 @@ class GenInv(Gen):
             if last:
                 self.chunk_load(0)
             self.copy_in(half)
+            self.stamp(1 + 5 * half)
             self.pass_low(half)
+            self.stamp(2 + 5 * half)
             self.pass_lane(half)
+            self.stamp(3 + 5 * half)
             self.pass_uniform(half)
+            self.stamp(4 + 5 * half)
             if last:
                 self.chunk_load(1)
             self.column_read(half)
+            self.stamp(5 + 5 * half)
         self.pass_a()
+        self.stamp(1 + 5 * self.HALVES)
         if self.fuse_last:
             self.fused_last()
         else:
             self.store_columns()
+        self.stamp(2 + 5 * self.HALVES)
+        if self.profile:
+            self.flush_stamps(3 + 5 * self.HALVES)
         self.e("s_endpgm")
         return self.p
 
@@ -604,6 +627,9 @@ if __name__ == "__main__":
     if logn == 16:      # "s": lazy sub-blocks, ntt_top_kernel follows; "f": the last stage fused (pair flags in NttLaunch::epi_x)
         fused = len(sys.argv) > 5 and sys.argv[5] == "fused"
         open(sys.argv[2], "w").write(kernel_text_for(make(15, 1024, sub=True, fuse_last=fused), "lr_ntt_inv16%s_m%d" % ("f" if fused else "s", mode)))
+        sys.exit(0)
+    if len(sys.argv) > 5 and sys.argv[5] == "timeline":      # diagnostics build with per-phase clock stamps (Options::timeline)
+        open(sys.argv[2], "w").write(kernel_text_for(make(logn, threads, profile=True), "lr_ntt_inv%d_m%dt" % (logn, mode)))
         sys.exit(0)
     name = "lr_ntt_inv%d%s_m%d" % (logn, "x" if threads < 1024 else "", mode)
     open(sys.argv[2], "w").write(kernel_text_for(make(logn, threads), name))

@@ -37,7 +37,7 @@ class Gen:
         assert logn in (12, 13, 14, 15) and mode in (0, 1, 2) and threads in (256, 512, 1024)
         # profile: the timeline build of a plain integer kernel (diagnostics only, Options::timeline): every wave stamps the shader
         # clock at the phase boundaries and the stamps go to the buffer NttLaunch::epi_x points at; the transform itself is unchanged
-        assert not profile or not (sub or fp or dual or epi)
+        assert not profile or not (sub or epi)
         self.profile = profile
         # dual: the kernel carries two bodies behind one prologue (class Dual): `fp` = the FP64 body for moduli below 2^46
         # (error-free products by v_mul_f64 / v_fma_f64, quotients by v_rndne_f64, no lazy corrections: 8 instructions per
@@ -49,6 +49,7 @@ class Gen:
         # (N = 2^16: only the plain sub-block kernels, i.e. after the top stage has been applied by the basis extension)
         assert not epi or dual
         self.fp, self.dual, self.epi = fp, dual, epi
+        self.karg_parked = False      # timeline builds of the inverse kernels (gen_intt.py)
         self.fuse_last = False        # inverse sub-block kernels (gen_intt.py): the last stage by whichever block of the pair finishes second
         self.mark = None
         assert not sub or (logn == 15 and threads == 1024)
@@ -182,25 +183,38 @@ class Gen:
     def stamp(self, idx):
         """timeline builds: wave w parks the low word of the shader clock in the padding of row idx of its LDS block (bytes
         w*9216 + idx*144 + 128, never touched by the transform); flush_stamps() copies them out at the end.  s[32:33] is the
-        carry-out dump of the multiply-adds (always dead), v126 / v127 are outside the integer kernels' register map."""
+        carry-out dump of the multiply-adds (always dead); the stamps sit between phases, where the first butterfly's temporaries
+        Q are free in the integer and in the FP64 body alike."""
         if not self.profile:
             return
         assert idx < self.N_STAMPS
         e, J = self.e, self.JUNK
+        va, vd = self.ts[0].Q.lo(), self.ts[0].Q.hi()
         e("s_memtime", J)
         e("s_waitcnt", "lgkmcnt(0)")
-        e("v_mov_b32", v(127), J.lo())
+        e("v_mov_b32", vd, J.lo())
         e("s_mul_i32", J.lo(), self.WAVE, 9216)
         e("s_add_u32", J.lo(), J.lo(), idx * 144 + 128)
-        e("v_mov_b32", v(126), J.lo())
-        e("ds_write_b32", v(126), v(127))
+        e("v_mov_b32", va, J.lo())
+        e("ds_write_b32", va, vd)
 
     def flush_stamps(self, count):
         """stamp buffer (NttLaunch::epi_x): [workgroup = poly * n_items + item][wave][N_STAMPS] u32"""
         e, sc = self.e, self.SC
         e("s_waitcnt", "vmcnt(0) lgkmcnt(0)")
-        e("s_load_dwordx2", self.TMP, self.KARG, 128)
-        e("s_load_dword", sc[0], self.KARG, 56)               # n_items
+        KA = self.KARG
+        if self.karg_parked:
+            # the inverse kernels reuse s[0:1]: the kernel-argument pointer waits in bytes 136..143 of the wave's row-0 padding
+            KA = s(36, 2)
+            e("s_mul_i32", sc[1], self.WAVE, 9216)
+            e("v_mov_b32", v(0), sc[1])
+            e("ds_read_b64", v(2, 2), v(0), offset=136)
+            e("s_waitcnt", "lgkmcnt(0)")
+            e("v_readfirstlane_b32", KA.lo(), v(2))
+            e("v_readfirstlane_b32", KA.hi(), v(3))
+            e("s_nop", 4)
+        e("s_load_dwordx2", self.TMP, KA, 128)
+        e("s_load_dword", sc[0], KA, 56)               # n_items
         e("s_waitcnt", "lgkmcnt(0)")
         e("s_mul_i32", sc[0], self.WGY, sc[0])
         e("s_add_u32", sc[0], sc[0], self.WGX)
@@ -1237,7 +1251,7 @@ if __name__ == "__main__":
                                                      "lr_ntt_fwd16%s_m%d" % ("s" if fused else "p", mode)))
         sys.exit(0)
     if len(sys.argv) > 5 and sys.argv[5] == "timeline":      # diagnostics build with per-phase clock stamps (Options::timeline)
-        open(sys.argv[2], "w").write(kernel_text_for(Gen(logn, mode, threads, profile=True), "lr_ntt_fwd%d_m%dt" % (logn, mode)))
+        open(sys.argv[2], "w").write(kernel_text_for(make(logn, threads, profile=True), "lr_ntt_fwd%d_m%dt" % (logn, mode)))
         sys.exit(0)
     name = "lr_ntt_fwd%d%s_m%d" % (logn, "x" if threads < 1024 else "", mode)     # x: several workgroups per CU
     open(sys.argv[2], "w").write(kernel_text_for(make(logn, threads), name))

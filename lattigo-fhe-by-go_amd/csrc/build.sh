@@ -59,10 +59,13 @@ gen_sub inv 16s 3 & gpids+=($!); gen_sub inv 16f 3 fused & gpids+=($!)
 gen_one fwd 14 4 & gpids+=($!); gen_one fwd 15 4 & gpids+=($!)
 gen_one fwd 14 4 512 & gpids+=($!); gen_one fwd 13 4 256 & gpids+=($!); gen_one fwd 12 4 256 & gpids+=($!)
 gen_sub fwd 16s 4 & gpids+=($!); gen_sub fwd 16p 4 plain & gpids+=($!)
-# diagnostics: the 2^15 integer kernel with per-phase clock stamps (LR_NTT_TIMELINE=1, tools/timeline.py)
-( python3 asmgen/gen_ntt.py 15 build/ntt_fwd15_m1t.s 1 1024 timeline
-  $LLVM/clang -x assembler -target amdgcn-amd-amdhsa -mcpu=gfx950 -c build/ntt_fwd15_m1t.s -o build/ntt_fwd15_m1t.o
-  $LLVM/ld.lld -shared build/ntt_fwd15_m1t.o -o build/ntt_fwd15_m1t.hsaco ) & gpids+=($!)
+# diagnostics: the 2^15 kernels with per-phase clock stamps (LR_NTT_TIMELINE=1, tools/timeline.py): integer and dual, both directions
+gen_tl() {  # kind mode
+  python3 asmgen/gen_$( [ "$1" = fwd ] && echo ntt || echo intt ).py 15 build/ntt_${1}15_m${2}t.s $2 1024 timeline
+  $LLVM/clang -x assembler -target amdgcn-amd-amdhsa -mcpu=gfx950 -c build/ntt_${1}15_m${2}t.s -o build/ntt_${1}15_m${2}t.o
+  $LLVM/ld.lld -shared build/ntt_${1}15_m${2}t.o -o build/ntt_${1}15_m${2}t.hsaco
+}
+for k in fwd inv; do for m in 1 3; do gen_tl $k $m & gpids+=($!); done; done
 for p in "${gpids[@]}"; do wait $p; done
 python3 - <<'PY'
 out = ['struct lr_asm_blob { const char *name; const unsigned char *data; unsigned long size; };']
@@ -70,7 +73,7 @@ names = [("fwd", n, m) for n in (14, 15) for m in (0, 1, 2)] + [("inv", n, m) fo
 names += [("fwd", n, m) for n in ("12x", "13x", "14x", "16s", "16p") for m in (0, 1, 2)] + [("inv", n, m) for n in ("12x", "13x", "14x", "16s", "16f") for m in (0, 1)]
 names += [("fwd", n, 3) for n in (14, 15, "12x", "13x", "14x", "16s", "16p")] + [("inv", n, 3) for n in (14, 15, "12x", "13x", "14x", "16s", "16f")]
 names += [("fwd", n, 4) for n in (14, 15, "12x", "13x", "14x", "16s", "16p")]
-names = [(k, n, str(m)) for k, n, m in names] + [("fwd", 15, "1t")]
+names = [(k, n, str(m)) for k, n, m in names] + [(k, 15, m) for k in ("fwd", "inv") for m in ("1t", "3t")]
 for k, n, m in names:
     data = open("build/ntt_%s%s_m%s.hsaco" % (k, n, m), "rb").read()
     out.append('static const unsigned char blob_%s%s_m%s[] __attribute__((aligned(4096))) = {' % (k, n, m))

@@ -990,7 +990,7 @@ int run_ntt_launch(lr_context *c, bool inverse, Rows in, Rows out, int mod0, int
     }
     if (pretop) return fail(LR_ERR_ARG, "pre-applied top stage: only for forward N = 2^16 launches on the assembly kernels");
     if (logn != 16 && variant >= 0 && c->use_asm && ntt_asm_available((int)logn)) {
-        if (c->opt.timeline && logn == 15 && !inverse && variant == 1 && hole == 0) {
+        if (c->opt.timeline && logn == 15 && (variant == 1 || variant == 3) && hole == 0) {
             // diagnostics: the stamped build of the same kernel; stamps land in the context's buffer (lr_context_timeline)
             const size_t words = (size_t)batch * (size_t)count * 16 * 16;
             if (words > c->stamp_words) {
@@ -1003,7 +1003,7 @@ int run_ntt_launch(lr_context *c, bool inverse, Rows in, Rows out, int mod0, int
             }
             c->stamp_used = words;
             a.epi_x = reinterpret_cast<const u64 *>(c->d_stamps);
-            LR_HIP(launch_ntt_asm(a, (int)logn, 0, variant, c->stream, false, kn, true, c->opt.stagger));
+            LR_HIP(launch_ntt_asm(a, (int)logn, inverse, variant, c->stream, false, kn, true, c->opt.stagger));
             return LR_OK;
         }
         LR_HIP(launch_ntt_asm(a, (int)logn, inverse, variant, c->stream, c->opt.asm14_1024, kn, false, c->opt.stagger));

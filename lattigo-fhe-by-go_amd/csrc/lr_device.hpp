@@ -35,7 +35,7 @@ struct Options {
     bool no_staging = false;       // LR_NO_STAGING: N = 2^16 key switch with in-place forward transforms
     bool ext_narrow = false;       // LR_EXT_NARROW: per-term basis extension instead of the 128-bit column sums
     bool asm14_1024 = false;       // LR_ASM_14_1024: the 1024-thread plan at N = 2^14
-    bool timeline = false;         // LR_NTT_TIMELINE: forward 2^15 launches of the integer kernel run the stamped diagnostics build
+    bool timeline = false;         // LR_NTT_TIMELINE: plain 2^15 launches (forward / inverse, integer variant 1 and dual variant 3) run the stamped diagnostics builds
     bool keymac_narrow = false;    // LR_KEYMAC_NARROW: one Montgomery product per term in the key inner product instead of the 128-bit sums
     bool no_invfuse = false;       // LR_NO_INVFUSE: N = 2^16 inverse transforms as lazy sub-blocks + the separate last-stage pass (ntt_top_kernel) instead of the pair-flag kernels
     bool no_exttop = false;        // LR_NO_EXTTOP: N = 2^16 key switch with staged extensions and fused-top transforms instead of the top stage inside the extension
