@@ -270,6 +270,73 @@ def cpu_baseline(make_worker, units_per_call, unit, what, target_seconds):
     }
 
 
+def launcher_argv(gpus, port, passthrough):
+    """The command the parent of a multi-GPU run starts as a child process: one rank per GPU of this node under
+    torch.distributed.run, rendezvous on 127.0.0.1 (the container hostname may not resolve)."""
+    return [os.path.realpath(sys.executable), "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus),
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(passthrough)
+
+
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def self_launch(args, argv):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: this process -- which has not imported torch nor touched a
+    GPU -- starts `python -m torch.distributed.run --nproc-per-node N bench.py ...` as a child, relays rank 0's JSON line (the
+    child's stdout) and exits with the child's code.  Under a launcher (WORLD_SIZE set) bench.py runs as a rank instead."""
+    import subprocess
+    port = int(os.environ.get("MASTER_PORT") or free_port())
+    cmd = launcher_argv(args.gpus, port, argv)
+    if args.dry_launch:
+        print(json.dumps({"launch": cmd}))
+        return 0
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    print("[bench] --gpus %d without a launcher: starting %s" % (args.gpus, " ".join(cmd)), file=sys.stderr, flush=True)
+    child = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, cwd=ROOT)
+    lines = 0
+    for raw in child.stdout:
+        line = raw.decode(errors="replace").rstrip("\n")
+        try:
+            json.loads(line)
+        except ValueError:
+            print(line, file=sys.stderr, flush=True)      # anything else a rank printed on stdout
+            continue
+        print(line, flush=True)
+        lines += 1
+    rc = child.wait()
+    if rc == 0 and lines != 1:
+        print("[bench] the ranks exited cleanly but printed %d JSON lines" % lines, file=sys.stderr)
+        return 4
+    return rc
+
+
+def launch_check():
+    """--launch-check: what a rank does in the self-launch rehearsal (tests/test_bench_launch.py, no GPU): rendezvous over gloo with the
+    environment the launcher gave it, the barrier + max-over-ranks of the timing harness, the error-flag agreement of the legs, one JSON
+    line from rank 0."""
+    import datetime
+
+    import torch
+    import torch.distributed as dist
+    rank, world, _ = dist_env()
+    dist.init_process_group(backend="gloo", timeout=datetime.timedelta(seconds=120))
+    t = torch.tensor([float(rank)], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    flag = torch.tensor([1.0 if (os.environ.get("LR_BENCH_CHECK_FAIL_RANK") == str(rank)) else 0.0], dtype=torch.float64)
+    dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+    dist.barrier()
+    if rank == 0:
+        print(json.dumps({"launch_check": True, "world": world, "max_rank": int(t.item()), "a_rank_failed": bool(flag.item()),
+                          "master": "%s:%s" % (os.environ.get("MASTER_ADDR"), os.environ.get("MASTER_PORT"))}), flush=True)
+    dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -288,7 +355,16 @@ def main():
     ap.add_argument("--ckks-batch", type=int, default=128)
     ap.add_argument("--config5-units", type=int, default=128, help="PN16QP1761 ciphertext products per GPU")
     ap.add_argument("--config5-chunk", type=int, default=32, help="products per lr_ckks_mulrelin call")
+    ap.add_argument("--dry-launch", action="store_true", help="with --gpus N > 1 and no launcher: print the child command as JSON and exit")
+    ap.add_argument("--launch-check", action="store_true", help="ranks only rendezvous over gloo and print one line (CPU rehearsal of the self-launch path)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher around this process: become the launcher (before torch is imported or a GPU is touched)
+        raise SystemExit(self_launch(args, [a for a in sys.argv[1:] if a != "--dry-launch"]))
+    if args.launch_check:
+        launch_check()
+        return
 
     # the contract is ONE JSON line on stdout: libraries that print there (RCCL's version banner at communicator creation)
     # are sent to stderr for the whole run, the JSON line goes to the saved descriptor
@@ -337,7 +413,7 @@ def main():
         def all_max(v):
             return v
 
-    ring, params, sampling, sharding = pkg.ring, pkg.params, pkg.sampling, pkg.sharding
+    ring, params, sampling, sharding, nat = pkg.ring, pkg.params, pkg.sampling, pkg.sharding, pkg._native
     sync = torch.cuda.synchronize
     oracle = graft.load_oracle() if rank == 0 else None
     want_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline
@@ -356,7 +432,45 @@ def main():
     # --------------------------------------------------------------------------------------------------------------------
     # config 5: PN16QP1761 MulRelin on this rank's block of independent ciphertext products, then the gather to rank 0
     # --------------------------------------------------------------------------------------------------------------------
-    def config5_leg(steps, warmup):
+    def checked(fn, default):
+        """rank-0-only oracle comparisons: an exception there must not separate rank 0 from the ranks waiting at the next agreement"""
+        try:
+            return fn(), None
+        except Exception as ex:     # noqa: BLE001 -- reported in the leg's object
+            return default, "%s: %s" % (type(ex).__name__, ex)
+
+    def secondary(name, prepare, run, store=None):
+        """A leg after the headline, in two phases.  prepare(): set-up WITHOUT collectives (contexts, allocations, uploads) -> state;
+        run(state): the timing, whose barrier / max-over-ranks are collectives.  All ranks agree on the outcome of prepare (max of an
+        error flag: one all-reduce) before any of them enters run, so a rank that failed in set-up never leaves the others waiting in
+        a collective it will not join; the leg is then reported as failed on every rank.  An exception inside run on a multi-rank job
+        ends this rank with a non-zero code (the launcher stops the others) instead of a 300 s collective timeout."""
+        err, state = None, None
+        try:
+            state = prepare()
+        except Exception as ex:     # noqa: BLE001 -- reported, not swallowed
+            err = "%s: %s" % (type(ex).__name__, ex)
+        if all_max(1.0 if err else 0.0) > 0:
+            res = {"error": err or "set-up failed on another rank"}
+            progress("%s leg skipped on every rank: %s" % (name, res["error"]))
+        else:
+            try:
+                res = run(state)
+            except Exception as ex:     # noqa: BLE001
+                if world > 1:
+                    progress("%s leg failed inside its timed part on rank %d: %s: %s -- ending the job" % (name, rank, type(ex).__name__, ex))
+                    sys.stderr.flush()
+                    os._exit(3)
+                res = {"error": "%s: %s" % (type(ex).__name__, ex)}
+                progress("%s leg failed: %s" % (name, res["error"]))
+        del state
+        if rank == 0:
+            if store is not None:
+                store.append(res)
+            else:
+                out[name] = res
+
+    def config5_prepare():
         cN, cQm, cPm = params.ckks_moduli("PN16QP1761")
         nq, np_ = len(cQm), len(cPm)
         level, beta = nq - 1, -(-nq // np_)
@@ -365,21 +479,28 @@ def main():
         start, count = sharding.shard_units(total, rank, world)
         chunk = min(args.config5_chunk, count)
         cQ, cP = ring.NewContextWithParams(cN, cQm, device=local), ring.NewContextWithParams(cN, cPm, device=local)
-        # every launch of this leg goes on torch's current stream, so the collective is ordered after the products
-        # without a host synchronisation in between
-        stream = torch.cuda.current_stream().cuda_stream
-        cQ.SetStream(stream)
-        cP.SetStream(stream)
+        # Every launch of this leg goes on ONE explicit torch stream: the products (both contexts moved to it) and, under
+        # torch.cuda.stream(s), the point ProcessGroupNCCL orders its collectives behind -- so a gather of a chunk starts after the
+        # kernels that wrote it, without a host synchronisation.  torch's default stream has handle 0, which lr_context_set_stream
+        # reads as "the library's own stream": that stream does not synchronise with the legacy default stream, so the default
+        # stream must not be used here (tests/test_gpu_bench_contract.py::test_config5_leg_under_rccl_is_ordered poisons the
+        # outputs to catch exactly that).
+        st = torch.cuda.Stream()
+        cQ.SetStream(st.cuda_stream)
+        cP.SetStream(st.cuda_stream)
         plan = ring.CkksPlan(cQ, cP, chunk)
         evk_h = sampling.uniform_poly(cQm + cPm, cN, 2 * beta, seed=9)       # replicated on every rank
         evk = plan.NewSwitchingKey().set(evk_h)
-        # unit g of the global batch has its own seeded operands; a few distinct ones tiled over the block (generation cost)
+        # unit g of the global batch has its own seeded operands; a few distinct ones are uploaded and tiled over the block ON THE
+        # DEVICE (the host never holds more than the distinct units: 4 x 4 x 34 x 65536 words = 285 MB, not 9 GB per rank)
         distinct = min(count, 4)
-        base = [sampling.uniform_poly(cQm, cN, 4, seed=0xC5 * 1000 + ((start + j) % 64)).reshape(4, nq, cN) for j in range(distinct)]
-        host = np.stack([base[j % distinct] for j in range(count)])           # [count, 4 (a0 a1 b0 b1), nq, N]
-        dev_in = torch.from_numpy(host.view(np.int64)).to("cuda")             # resident before timing
-        dev_out = torch.empty((count, 2, nq, cN), dtype=torch.int64, device="cuda")
-        del host
+        base = np.stack([sampling.uniform_poly(cQm, cN, 4, seed=0xC5 * 1000 + ((start + j) % 64)).reshape(4, nq, cN) for j in range(distinct)])
+        with torch.cuda.stream(st):
+            dev_base = torch.from_numpy(base.view(np.int64)).to("cuda")                                     # [distinct, 4, nq, N]
+            dev_in = dev_base[torch.arange(count, device="cuda") % distinct].contiguous()                   # [count, 4 (a0 a1 b0 b1), nq, N]
+            dev_out = torch.empty((count, 2, nq, cN), dtype=torch.int64, device="cuda")
+        st.synchronize()
+        del dev_base, base
         esz = 8
 
         def comp(t, u0, nb, k):
@@ -392,37 +513,57 @@ def main():
             spans.append((u0, nb))
             calls.append(((comp(dev_in, u0, nb, 0), comp(dev_in, u0, nb, 1)), (comp(dev_in, u0, nb, 2), comp(dev_in, u0, nb, 3)),
                           (comp(dev_out, u0, nb, 0), comp(dev_out, u0, nb, 1))))
+        overlapped = use_dist and total % world == 0
+        with torch.cuda.stream(st):
+            root_out = torch.empty((total, 2, nq, cN), dtype=torch.int64, device="cuda") if overlapped and rank == 0 else None
+        return dict(cN=cN, cQm=cQm, cPm=cPm, nq=nq, np_=np_, level=level, beta=beta, per_gpu=per_gpu, total=total, start=start, count=count,
+                    chunk=chunk, cQ=cQ, cP=cP, st=st, plan=plan, evk_h=evk_h, evk=evk, dev_in=dev_in, dev_out=dev_out, calls=calls,
+                    spans=spans, overlapped=overlapped, root_out=root_out)
+
+    def config5_run(c, steps, warmup):
+        cN, cQm, cPm, nq, np_, level, beta = c["cN"], c["cQm"], c["cPm"], c["nq"], c["np_"], c["level"], c["beta"]
+        total, count, chunk, cQ, st, plan, evk = c["total"], c["count"], c["chunk"], c["cQ"], c["st"], c["plan"], c["evk"]
+        dev_out, calls, spans, overlapped, root_out = c["dev_out"], c["calls"], c["spans"], c["overlapped"], c["root_out"]
 
         def compute():
             for ct0, ct1, out in calls:
                 plan.MulRelin(level, ct0, ct1, evk, out)
 
         gathered = [None]
-        # the gather runs chunk by chunk behind the products: chunk k moves over xGMI (RCCL, its own stream) while chunk k + 1 is
-        # computed (sharding.ChunkedGather); rank 0's result buffer is allocated once
-        overlapped = use_dist and total % world == 0
-        root_out = torch.empty((total, 2, nq, cN), dtype=torch.int64, device="cuda") if overlapped and rank == 0 else None
 
+        # the gather runs chunk by chunk behind the products: chunk k moves over xGMI (RCCL, its own stream, behind an event of `st`)
+        # while chunk k + 1 is computed (sharding.ChunkedGather); rank 0's result buffer is allocated once
         def step():
-            if overlapped:
-                cg = sharding.ChunkedGather(dev_out, total, rank, world, dst=0, out=root_out)
-                for (ct0, ct1, out), (u0, nb) in zip(calls, spans):
-                    plan.MulRelin(level, ct0, ct1, evk, out)
-                    cg.submit(u0, nb)
-                gathered[0] = cg.wait()
-                return
-            compute()
-            gathered[0] = sharding.gather_blocks(dev_out, total, rank, world, dst=0) if use_dist else dev_out
+            with torch.cuda.stream(st):
+                if overlapped:
+                    cg = sharding.ChunkedGather(dev_out, total, rank, world, dst=0, out=root_out)
+                    for (ct0, ct1, out), (u0, nb) in zip(calls, spans):
+                        plan.MulRelin(level, ct0, ct1, evk, out)
+                        cg.submit(u0, nb)
+                    gathered[0] = cg.wait()
+                    return
+                compute()
+                gathered[0] = sharding.gather_blocks(dev_out, total, rank, world, dst=0) if use_dist else dev_out
 
         warm_clock(compute, cQ)
         seconds, dev_ms = timed_region(step, steps, warmup, sync, barrier, all_max, cQ.TimerStart, cQ.TimerStop)
         # compute only, same block, no collective
         comp_seconds, comp_ms = timed_region(compute, steps, 1, sync, barrier, all_max, cQ.TimerStart, cQ.TimerStop)
+        # the checked result comes from one more step on POISONED buffers: every warm-up and timed step wrote the same values, so a
+        # gather that ran ahead of the kernels would otherwise find yesterday's (identical) data and pass
+        with torch.cuda.stream(st):
+            dev_out.fill_(-1)
+            if root_out is not None:
+                root_out.fill_(-1)
+        step()
+        sync()
+        barrier()
         res = {
             "value": total * steps / seconds, "unit": "MulRelin/s", "params": "PN16QP1761 (N=2^16, %d Q + %d P limbs, beta=%d), level %d" % (nq, np_, beta, level),
-            "units_total": total, "units_per_gpu": per_gpu, "chunk": chunk, "n_gpus": world,
+            "units_total": total, "units_per_gpu": c["per_gpu"], "chunk": chunk, "n_gpus": world,
             "ms_per_step_compute_and_gather": seconds / steps * 1e3, "ms_per_step_compute_only": comp_seconds / steps * 1e3,
             "compute_only_value": total * steps / comp_seconds,
+            "stream": "explicit torch stream shared by the products and the collective's ordering point",
             "gather": ("torch.distributed.gather(nccl=RCCL) of %d x %.1f MiB to rank 0%s" % (total, 2 * nq * cN * 8 / 2**20,
                        ", in chunks of %d products per rank overlapped with the next chunk's kernels" % chunk if overlapped else "")) if use_dist else "none (single process)",
             "gather_bytes_to_root": (total - count) * 2 * nq * cN * 8 if use_dist else 0,
@@ -432,27 +573,33 @@ def main():
         }
         res["roofline"]["frac"] = res["roofline"]["achieved"] / HBM_PEAK_GBS
         if rank == 0:
-            # placement + parity: global unit 0 (this rank's) and, when gathered, the first unit of the last rank's block
-            oplan = oracle.CkksPlan(oracle.Context(cN, cQm), oracle.Context(cN, cPm))
-            full = gathered[0] if gathered[0] is not None else dev_out
-            checks = {0}
-            if use_dist and world > 1:
-                checks.add(sharding.shard_units(total, world - 1, world)[0])
-            ok = True
-            for g in sorted(checks):
-                owner = sharding.unit_owner(g, total, world)
-                s_owner, c_owner = sharding.shard_units(total, owner, world)
-                d_owner = min(c_owner, 4)
-                opnd = sampling.uniform_poly(cQm, cN, 4, seed=0xC5 * 1000 + ((s_owner + (g - s_owner) % d_owner) % 64)).reshape(4, nq, cN)
-                want = oplan.mulrelin(level, opnd[0:2], opnd[2:4], evk_h.reshape(beta, 2, nq + np_, cN))
-                got = full[g].cpu().numpy().view(np.uint64)
-                ok = ok and bool(np.array_equal(got, want))
-            res["bit_exact"] = ok
-            res["checked_units"] = sorted(checks)
+            # placement + parity on the poisoned-then-recomputed buffers: global unit 0 (this rank's), the last unit of this rank's
+            # block and, when gathered, the first and last unit of the last rank's block
+            def check():
+                oplan = oracle.CkksPlan(oracle.Context(cN, cQm), oracle.Context(cN, cPm))
+                full = gathered[0] if gathered[0] is not None else dev_out
+                checks = {0, count - 1}
+                if use_dist and world > 1:
+                    s_last, c_last = sharding.shard_units(total, world - 1, world)
+                    checks |= {s_last, s_last + c_last - 1}
+                ok = True
+                for g in sorted(checks):
+                    owner = sharding.unit_owner(g, total, world)
+                    s_owner, c_owner = sharding.shard_units(total, owner, world)
+                    d_owner = min(c_owner, 4)
+                    opnd = sampling.uniform_poly(cQm, cN, 4, seed=0xC5 * 1000 + ((s_owner + (g - s_owner) % d_owner) % 64)).reshape(4, nq, cN)
+                    want = oplan.mulrelin(level, opnd[0:2], opnd[2:4], c["evk_h"].reshape(beta, 2, nq + np_, cN))
+                    got = full[g].cpu().numpy().view(np.uint64)
+                    ok = ok and bool(np.array_equal(got, want))
+                return ok, sorted(checks)
+            (res["bit_exact"], res["checked_units"]), err = checked(check, (None, []))
+            res["checked_after"] = "outputs poisoned (-1) on every rank and on the root, then one more step"
+            if err:
+                res["check_error"] = err
         return res
 
     if args.workload == "ckks16":
-        c5 = config5_leg(max(1, min(args.steps, 10)), max(1, min(args.warmup, 2)))
+        c5 = config5_run(config5_prepare(), max(1, min(args.steps, 10)), max(1, min(args.warmup, 2)))
         if rank == 0:
             steps = max(1, min(args.steps, 10))
             out = {"metric": "CKKS homomorphic-mul/s at N=2^16 (MulRelin, DefaultParams[PN16QP1761]), sharded batch + gather to rank 0",
@@ -472,95 +619,137 @@ def main():
     # the reference's benchmark rings R13..R16 (ring/params.go:10-25, ring/ring_test.go:30-36): NTT, InvNTT, MulCoeffsMontgomery and
     # ModUpSplitQP, 1 GiB per operand on every rank (weak scaling), whole-job throughput = units of all ranks / slowest rank's time
     # --------------------------------------------------------------------------------------------------------------------
-    def rings_leg():
-        rows = []
-        for logn in (13, 14, 15, 16):
-            Nr, Qr = params.DefaultParamsQi(logn)
-            _, Pr = params.DefaultParamsPi(logn)
-            Lr, Kr = len(Qr), len(Pr)
-            Br = max(2, args.rings_bytes // (8 * Nr * Lr)) & ~1
-            cq, cp = ring.NewContextWithParams(Nr, Qr, device=local), ring.NewContextWithParams(Nr, Pr, device=local)
-            pair = sampling.uniform_poly(Qr, Nr, 2, seed=(logn << 8) ^ rank)
-            a = cq.NewPoly(Br).set(np.concatenate([pair] * (Br // 2)))
-            b, c, pp = cq.NewPoly(Br), cq.NewPoly(Br), cp.NewPoly(Br)
-            cq.Copy(a, b)
-            be = ring.NewFastBasisExtender(cq, cp)
-            row = {"ring": "R%d" % logn, "N": Nr, "limbs": Lr, "polys_per_gpu": Br, "n_gpus": world}
-            checks = {}
-            for name, fn, nbytes, reps in (("ntt", lambda: cq.NTT(a, c), 16 * Nr * Lr * Br, 20),
-                                           ("intt", lambda: cq.InvNTT(a, c), 16 * Nr * Lr * Br, 20),
-                                           ("mulcoeffs_montgomery", lambda: cq.MulCoeffsMontgomery(a, b, c), 24 * Nr * Lr * Br, 20),
-                                           ("modup_split_qp", lambda: be.ModUpSplitQP(Lr - 1, a, pp), 8 * Nr * (Lr + Kr) * Br, 10)):
-                t_up = time.perf_counter()        # bring the device clock up (see warm_clock): ~0.1 s of the same launches
-                while time.perf_counter() - t_up < 0.1:
-                    for _ in range(reps):
-                        fn()
-                    cq.Sync()
-                barrier()
-                cq.TimerStart()
+    def ring_prepare(logn):
+        Nr, Qr = params.DefaultParamsQi(logn)
+        _, Pr = params.DefaultParamsPi(logn)
+        Lr, Kr = len(Qr), len(Pr)
+        Br = max(2, args.rings_bytes // (8 * Nr * Lr)) & ~1
+        cq, cp = ring.NewContextWithParams(Nr, Qr, device=local), ring.NewContextWithParams(Nr, Pr, device=local)
+        pair = sampling.uniform_poly(Qr, Nr, 2, seed=(logn << 8) ^ rank)
+        a = cq.NewPoly(Br).set(np.concatenate([pair] * (Br // 2)))
+        b, c, pp = cq.NewPoly(Br), cq.NewPoly(Br), cp.NewPoly(Br)
+        cq.Copy(a, b)
+        be = ring.NewFastBasisExtender(cq, cp)
+        return dict(logn=logn, Nr=Nr, Qr=Qr, Pr=Pr, Lr=Lr, Kr=Kr, Br=Br, cq=cq, cp=cp, pair=pair, a=a, b=b, c=c, pp=pp, be=be)
+
+    def ring_run(r):
+        logn, Nr, Qr, Pr, Lr, Kr, Br, cq, pair, a, b, c, pp, be = (r[k] for k in ("logn", "Nr", "Qr", "Pr", "Lr", "Kr", "Br", "cq", "pair", "a", "b", "c", "pp", "be"))
+        row = {"ring": "R%d" % logn, "N": Nr, "limbs": Lr, "polys_per_gpu": Br, "n_gpus": world}
+        checks = {}
+
+        def rescale():
+            # Context.DivRoundByLastModulusNTT (ring/ring_scaling.go:72) works in place and drops the last limb: the operand is the
+            # copy in c with its limb count put back up (the values differ from call to call; the checked call starts from a)
+            nat.check(nat.lib().lr_poly_set_limbs(c.h, Lr))
+            cq.DivRoundByLastModulusNTT(c)
+
+        for name, fn, nbytes, reps in (("ntt", lambda: cq.NTT(a, c), 16 * Nr * Lr * Br, 20),
+                                       ("intt", lambda: cq.InvNTT(a, c), 16 * Nr * Lr * Br, 20),
+                                       ("mulcoeffs_montgomery", lambda: cq.MulCoeffsMontgomery(a, b, c), 24 * Nr * Lr * Br, 20),
+                                       ("modup_split_qp", lambda: be.ModUpSplitQP(Lr - 1, a, pp), 8 * Nr * (Lr + Kr) * Br, 10),
+                                       ("div_round_by_last_modulus_ntt", rescale, 8 * Nr * (2 * Lr - 1) * Br, 10)):
+            t_up = time.perf_counter()        # bring the device clock up (see warm_clock): ~0.1 s of the same launches
+            while time.perf_counter() - t_up < 0.1:
                 for _ in range(reps):
                     fn()
-                ms = all_max(cq.TimerStop() / reps)
-                row[name] = {"poly_per_s": Br * world / (ms * 1e-3), "ms": ms, "frac_hbm_per_gpu": nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
-                if name in ("ntt", "intt"):
-                    row[name]["limb_ntt_per_s"] = Br * world * Lr / (ms * 1e-3)
-                    row[name]["kernel"] = cq.last_ntt_kernel()
-                if rank == 0:      # the last poly of the output against the oracle (checker only)
+                cq.Sync()
+            barrier()
+            cq.TimerStart()
+            for _ in range(reps):
+                fn()
+            ms = all_max(cq.TimerStop() / reps)
+            row[name] = {"poly_per_s": Br * world / (ms * 1e-3), "ms": ms, "frac_hbm_per_gpu": nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+            if name in ("ntt", "intt"):
+                row[name]["limb_ntt_per_s"] = Br * world * Lr / (ms * 1e-3)
+                row[name]["kernel"] = cq.last_ntt_kernel()
+            if rank == 0:      # the last poly of the output against the oracle (checker only)
+                def check(name=name):
                     ocr = oracle.Context(Nr, Qr)
                     x = pair[(Br - 1) % 2]
                     if name == "modup_split_qp":
                         want = oracle.BasisExtender(ocr, oracle.Context(Nr, Pr)).modup_split_qp(Lr - 1, x)
                         got = np.stack(pp.get_limb_slices(Br - 1))
+                    elif name == "div_round_by_last_modulus_ntt":
+                        cq.Copy(a, c)
+                        nat.check(nat.lib().lr_poly_set_limbs(c.h, Lr))
+                        cq.DivRoundByLastModulusNTT(c)
+                        want = ocr.rescale_op("oc_div_round_by_last_modulus_ntt", x)
+                        got = np.stack(c.get_limb_slices(Br - 1))[:Lr - 1]
+                        nat.check(nat.lib().lr_poly_set_limbs(c.h, Lr))
                     else:
                         want = {"ntt": ocr.ntt, "intt": ocr.intt, "mulcoeffs_montgomery": lambda v: ocr.ewise("MUL_MONT", v, v)}[name](x)
                         got = np.stack(c.get_limb_slices(Br - 1))
-                    checks[name] = bool(np.array_equal(got, want))
-            if rank == 0:
-                row["bit_exact"] = all(checks.values())
-            rows.append(row)
-            del a, b, c, pp, be, cq, cp
-        return rows
+                    return bool(np.array_equal(got, want))
+                checks[name], err = checked(check, None)
+                if err:
+                    row.setdefault("check_errors", {})[name] = err
+        if rank == 0:
+            row["bit_exact"] = all(v is True for v in checks.values())
+            if want_cpu:
+                # the CPU restatement beside every ring ("CPU (1 / T threads) next to every ring R13...R16";
+                # ring/ring_benchmark_test.go:154-186 NTT, :349-404 DivRoundByLastModulusNTT): short samples, ~1 s each
+                ocr = oracle.Context(Nr, Qr)
+                x0 = pair[0]
+
+                def mk_ntt(i):
+                    xi, yi = x0.copy(), np.empty_like(x0)
+                    olib = oracle.lib()
+                    return lambda: olib.oc_ntt_lvl(ocr.h, Lr - 1, xi.ctypes.data, yi.ctypes.data)
+
+                def mk_rescale(i):
+                    xi = x0.copy()
+                    return lambda: ocr.rescale_op("oc_div_round_by_last_modulus_ntt", xi)
+                row["ntt"]["cpu_baseline"] = cpu_baseline(mk_ntt, Lr, "limb-NTT/s", "oracle Context.NTT on R%d, one poly per call" % logn, 1.0)
+                row["div_round_by_last_modulus_ntt"]["cpu_baseline"] = cpu_baseline(
+                    mk_rescale, 1, "poly/s", "oracle DivRoundByLastModulusNTT on R%d, one poly per call" % logn, 1.0)
+        return row
 
     # CKKS MulRelin on the default parameter sets of the same degrees (ckks/params.go:36-76; N = 2^16 is the config-5 leg), every rank
     # on its own batch, whole-job products per second
-    def mulrelin_sets_leg():
-        rows = []
-        for name, mb in (("PN13QP218", 512), ("PN14QP438", 256), ("PN15QP880", 128)):
-            mN, mQ, mP = params.ckks_moduli(name)
-            nq, np_ = len(mQ), len(mP)
-            mcQ, mcP = ring.NewContextWithParams(mN, mQ, device=local), ring.NewContextWithParams(mN, mP, device=local)
-            mplan = ring.CkksPlan(mcQ, mcP, mb)
-            mlevel, mbeta = nq - 1, -(-nq // np_)
-            key_h = sampling.uniform_poly(mQ + mP, mN, 2 * mbeta, seed=9)
-            key = mplan.NewSwitchingKey().set(key_h)
-            ops = [sampling.uniform_poly(mQ, mN, 2, seed=(40 + k) ^ (rank << 8)) for k in range(4)]
-            tile = lambda x: np.concatenate([x] * (mb // 2))
-            c0 = (mcQ.NewPoly(mb).set(tile(ops[0])), mcQ.NewPoly(mb).set(tile(ops[1])))
-            c1 = (mcQ.NewPoly(mb).set(tile(ops[2])), mcQ.NewPoly(mb).set(tile(ops[3])))
-            co = (mcQ.NewPoly(mb), mcQ.NewPoly(mb))
-            fn = lambda: mplan.MulRelin(mlevel, c0, c1, key, co)
-            t_up = time.perf_counter()
-            while time.perf_counter() - t_up < 0.1:
-                for _ in range(3):
-                    fn()
-                mcQ.Sync()
-            barrier()
-            mcQ.TimerStart()
-            for _ in range(5):
+    def mulrelin_set_prepare(name, mb):
+        mN, mQ, mP = params.ckks_moduli(name)
+        nq, np_ = len(mQ), len(mP)
+        mcQ, mcP = ring.NewContextWithParams(mN, mQ, device=local), ring.NewContextWithParams(mN, mP, device=local)
+        mplan = ring.CkksPlan(mcQ, mcP, mb)
+        mlevel, mbeta = nq - 1, -(-nq // np_)
+        key_h = sampling.uniform_poly(mQ + mP, mN, 2 * mbeta, seed=9)
+        key = mplan.NewSwitchingKey().set(key_h)
+        ops = [sampling.uniform_poly(mQ, mN, 2, seed=(40 + k) ^ (rank << 8)) for k in range(4)]
+        tile = lambda x: np.concatenate([x] * (mb // 2))
+        c0 = (mcQ.NewPoly(mb).set(tile(ops[0])), mcQ.NewPoly(mb).set(tile(ops[1])))
+        c1 = (mcQ.NewPoly(mb).set(tile(ops[2])), mcQ.NewPoly(mb).set(tile(ops[3])))
+        co = (mcQ.NewPoly(mb), mcQ.NewPoly(mb))
+        return dict(name=name, mb=mb, mN=mN, mQ=mQ, mP=mP, nq=nq, np_=np_, mcQ=mcQ, mcP=mcP, mplan=mplan, mlevel=mlevel, mbeta=mbeta,
+                    key_h=key_h, key=key, ops=ops, c0=c0, c1=c1, co=co)
+
+    def mulrelin_set_run(m):
+        name, mb, mN, mQ, mP, nq, np_, mcQ, mplan, mlevel, mbeta, key_h, key, ops, c0, c1, co = (m[k] for k in (
+            "name", "mb", "mN", "mQ", "mP", "nq", "np_", "mcQ", "mplan", "mlevel", "mbeta", "key_h", "key", "ops", "c0", "c1", "co"))
+        fn = lambda: mplan.MulRelin(mlevel, c0, c1, key, co)
+        t_up = time.perf_counter()
+        while time.perf_counter() - t_up < 0.1:
+            for _ in range(3):
                 fn()
-            ms = all_max(mcQ.TimerStop() / 5)
-            row = {"params": name, "N": mN, "limbs_Q": nq, "limbs_P": np_, "batch_per_gpu": mb, "n_gpus": world, "ms_per_batch": ms,
-                   "mulrelin_per_s": mb * world / (ms * 1e-3),
-                   "frac_hbm_per_gpu": mulrelin_bytes(mN, nq, np_, mb) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
-            if rank == 0:
+            mcQ.Sync()
+        barrier()
+        mcQ.TimerStart()
+        for _ in range(5):
+            fn()
+        ms = all_max(mcQ.TimerStop() / 5)
+        row = {"params": name, "N": mN, "limbs_Q": nq, "limbs_P": np_, "batch_per_gpu": mb, "n_gpus": world, "ms_per_batch": ms,
+               "mulrelin_per_s": mb * world / (ms * 1e-3),
+               "frac_hbm_per_gpu": mulrelin_bytes(mN, nq, np_, mb) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        if rank == 0:
+            def check():
                 op = oracle.CkksPlan(oracle.Context(mN, mQ), oracle.Context(mN, mP))
                 j = (mb - 1) % 2
                 want = op.mulrelin(mlevel, np.stack([ops[0][j], ops[1][j]]), np.stack([ops[2][j], ops[3][j]]), key_h.reshape(mbeta, 2, nq + np_, mN))
-                row["bit_exact"] = bool(np.array_equal(np.stack(co[0].get_limb_slices(mb - 1)), want[0]) and
-                                        np.array_equal(np.stack(co[1].get_limb_slices(mb - 1)), want[1]))
-            rows.append(row)
-            del c0, c1, co, key, mplan, mcQ, mcP
-        return rows
+                return bool(np.array_equal(np.stack(co[0].get_limb_slices(mb - 1)), want[0]) and
+                            np.array_equal(np.stack(co[1].get_limb_slices(mb - 1)), want[1]))
+            row["bit_exact"], err = checked(check, None)
+            if err:
+                row["check_error"] = err
+        return row
 
     # --------------------------------------------------------------------------------------------------------------------
     # headline: forward NTT on R15
@@ -773,27 +962,24 @@ def main():
 
     del src, dst
 
-    def secondary(name, leg):
-        # the legs after the headline must not take the headline's line with them: a failure is reported in the leg's place
-        # (deterministic failures hit every rank alike, so the ranks stay in step)
-        try:
-            res = leg()
-        except Exception as ex:     # noqa: BLE001 -- reported, not swallowed
-            res = {"error": "%s: %s" % (type(ex).__name__, ex)}
-            progress("%s leg failed: %s" % (name, res["error"]))
-        if rank == 0:
-            out[name] = res
-
     if not args.no_rings:
-        progress("rings R13..R16: NTT / InvNTT / MulCoeffsMontgomery / ModUpSplitQP on every rank")
-        secondary("rings", rings_leg)
+        progress("rings R13..R16: NTT / InvNTT / MulCoeffsMontgomery / ModUpSplitQP / DivRoundByLastModulusNTT on every rank")
+        rows = []
+        for lg in (13, 14, 15, 16):
+            secondary("rings", lambda lg=lg: ring_prepare(lg), ring_run, store=rows)
+        if rank == 0:
+            out["rings"] = rows
         progress("rings timed")
         if not args.no_ckks:
-            secondary("mulrelin_sets", mulrelin_sets_leg)
+            rows = []
+            for sname, mb in (("PN13QP218", 512), ("PN14QP438", 256), ("PN15QP880", 128)):
+                secondary("mulrelin_sets", lambda sname=sname, mb=mb: mulrelin_set_prepare(sname, mb), mulrelin_set_run, store=rows)
+            if rank == 0:
+                out["mulrelin_sets"] = rows
             progress("MulRelin on PN13QP218 / PN14QP438 / PN15QP880 timed on every rank")
     if not args.no_config5 and not args.no_ckks:
         progress("config 5 leg: PN16QP1761, %d products per GPU" % args.config5_units)
-        secondary("config5", lambda: config5_leg(3, 1))
+        secondary("config5", config5_prepare, lambda c: config5_run(c, 3, 1))
         progress("config 5 leg done")
 
     if rank == 0 and world == 1 and not use_dist and not args.no_traffic and B == (1 << 30) // (8 * N * L):

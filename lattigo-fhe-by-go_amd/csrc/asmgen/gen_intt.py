@@ -25,10 +25,16 @@ class GenInv(Gen):
     """mode 1: every modulus in (2^33, 2^60], bound B = 8q as described above;
        mode 0: moduli up to 2^61: B = 4q and every butterfly corrects."""
 
-    def __init__(self, logn, mode=1, threads=1024, sub=False, fp=False, dual=False, fuse_last=False, profile=False):
+    def __init__(self, logn, mode=1, threads=1024, sub=False, fp=False, dual=False, fuse_last=False, profile=False, pre1=None):
         assert mode in (0, 1)
         super().__init__(logn, mode, threads, sub, fp=fp, dual=dual, profile=profile)
         self.karg_parked = profile
+        # pre1 (plans with two LDS images, one column per thread): the copy-in loads of half 1 are issued during half 0's LDS phase
+        # into v32..v63, which are idle until half 0's results are parked there -- the second copy-in's memory latency (10 k of a
+        # wave's 62 k clocks on the FP64 body, profiles/r03/timeline_inv15_ckks.json) hides behind arithmetic.  Half 0's columns are
+        # read back into v0..v31 first and move to v32..v63 once half 1's raw data has left for the LDS image (32 v_mov_b32).
+        self.pre1 = (self.HALVES == 2 and self.C == 1) if pre1 is None else pre1
+        assert not self.pre1 or (self.HALVES == 2 and self.C == 1)
         # fuse_last (sub-block kernels of N = 2^16): no ntt_top_kernel pass afterwards.  Every wave stores its lazy rows, makes them
         # visible to the device and bumps the flag it shares with the same wave of the limb's other sub-block; the wave that finds
         # the flag already bumped (its partner's rows are complete) loads them and finishes both halves: last stage + scaling.
@@ -198,12 +204,7 @@ class GenInv(Gen):
     def prologue_tail(self):
         e = self.e
         if self.profile:
-            # s[0:1] becomes the LimbParams pointer below: flush_stamps() finds the kernel-argument pointer in the row-0 padding
-            e("s_mul_i32", self.SC[3], self.WAVE, 9216)
-            e("v_mov_b32", v(4), self.SC[3])
-            e("v_mov_b32", v(2), self.KARG.lo())
-            e("v_mov_b32", v(3), self.KARG.hi())
-            e("ds_write_b64", v(4), v(2, 2), offset=136)
+            # (s[0:1] becomes the LimbParams pointer below: park_stamp_slot() has put the kernel-argument pointer into the row-0 padding)
             self.stamp(0)
         if self.dual:
             self.mark = len(self.p.ins)
@@ -255,12 +256,10 @@ class GenInv(Gen):
         e("s_add_u32", self.TMP.lo(), self.SRC.lo(), self.SC[5])
         e("s_addc_u32", self.TMP.hi(), self.SRC.hi(), 0)
         n = 8
-        regs = [v(4 * i, 4) for i in range(n)]
-        for i in range(n):
-            if i == 4:                                        # the immediate offset is 13-bit signed
-                e("s_add_u32", self.TMP.lo(), self.TMP.lo(), 4096)
-                e("s_addc_u32", self.TMP.hi(), self.TMP.hi(), 0)
-            e("global_load_dwordx4", regs[i], a2, self.TMP, offset=(i % 4) * 1024, hint="nt")
+        early = self.pre1 and half == 1                       # the loads were issued by prefetch_half1()
+        regs = [v((32 if early else 0) + 4 * i, 4) for i in range(n)]
+        if not early:
+            self.copy_in_loads(regs, a2)
         if half + 1 < self.HALVES:
             e("s_add_u32", self.SRC.lo(), self.SRC.lo(), self.M * 8)
             e("s_addc_u32", self.SRC.hi(), self.SRC.hi(), 0)
@@ -277,6 +276,32 @@ class GenInv(Gen):
         for i in range(n):
             e("s_waitcnt", "vmcnt(%d)" % (younger + n - 1 - i))
             e("ds_write_b128", a0, regs[i], offset=i * 1152)
+        if early:
+            # half 0's columns waited in v0..v31 (column_read) for these registers
+            for k in range(self.SPH):
+                for part in range(2):
+                    e("v_mov_b32", self.X[k].sub(part), v(2 * k + part))
+
+    def copy_in_loads(self, regs, a2):
+        """8 x 16 bytes per lane of this wave's 8 KiB at TMP, a2 = lane * 16"""
+        e = self.e
+        for i in range(len(regs)):
+            if i == 4:                                        # the immediate offset is 13-bit signed
+                e("s_add_u32", self.TMP.lo(), self.TMP.lo(), 4096)
+                e("s_addc_u32", self.TMP.hi(), self.TMP.hi(), 0)
+            e("global_load_dwordx4", regs[i], a2, self.TMP, offset=(i % 4) * 1024, hint="nt")
+
+    def prefetch_half1(self):
+        """pre1: half 1's raw rows on their way into v32..v63 while half 0 is in its last LDS pass (no twiddle stream is live here:
+        the vector-memory queue holds nothing younger than these loads until copy_in(1) starts its stream)"""
+        e = self.e
+        a2 = self.A_[2]
+        self.c("prefetch of half 1's copy-in (SRC already points at half 1)")
+        e("v_lshlrev_b32", a2, 4, self.LANE)
+        e("s_lshl_b32", self.SC[5], self.WAVE, 13)
+        e("s_add_u32", self.TMP.lo(), self.SRC.lo(), self.SC[5])
+        e("s_addc_u32", self.TMP.hi(), self.SRC.hi(), 0)
+        self.copy_in_loads([v(32 + 4 * i, 4) for i in range(8)], a2)
 
     def pass_low(self, half):
         """bits 0..3: lane l owns the 16 contiguous coefficients of block l of its wave"""
@@ -345,6 +370,8 @@ class GenInv(Gen):
         """bits 7..9: lane l owns the columns l and l + 64 of its wave's block; twiddles in SGPRs"""
         e = self.e
         a0, a1 = self.A_[0], self.A_[1]
+        if self.pre1 and half == 0:
+            self.prefetch_half1()
         self.c("stages over bits 7..9 (wave-local)")
         e("v_lshrrev_b32", a1, 4, self.LANE)
         e("v_lshlrev_b32", a1, 4, a1)
@@ -380,7 +407,10 @@ class GenInv(Gen):
         for c in range(self.C):
             for kk in range(self.SPH):
                 base, off = self.lds_col(c, kk, a0, a1)
-                e("ds_read_b64", self.X[c * self.RA + self.SPH * half + kk], base, offset=off)
+                dst = self.X[c * self.RA + self.SPH * half + kk]
+                if self.pre1 and half == 0:
+                    dst = v(2 * kk, 2)                        # v32..v63 carry half 1's raw rows until copy_in(1) has stored them
+                e("ds_read_b64", dst, base, offset=off)
         if half + 1 < self.HALVES:
             e("s_waitcnt", "lgkmcnt(0)")
             e("s_barrier")

@@ -33,8 +33,17 @@ class Gen:
          2: q <  2^57, no corrections at all (15 stages x 4q of growth stay below 2^64);
          0: q <  2^61, U <- U - 4q (if U >= 4q) before every stage."""
 
-    def __init__(self, logn, mode=1, threads=1024, sub=False, fused=True, fp=False, dual=False, epi=False, profile=False):
+    def __init__(self, logn, mode=1, threads=1024, sub=False, fused=True, fp=False, dual=False, epi=False, profile=False, persist=False):
         assert logn in (12, 13, 14, 15) and mode in (0, 1, 2) and threads in (256, 512, 1024)
+        # persist (forward 2^15, 1024 threads): the workgroup transforms NttLaunch::fuse_top (= polys per workgroup here) consecutive
+        # polys of ONE limb in a loop -- constants, table bases and the wave's LDS block stay; the next poly's column loads are
+        # issued while this one is in its second LDS image (rows 16..31 into the registers that image has just left, rows 0..15 behind
+        # the last copy-out's stores), so the load phase that a one-poly workgroup waits out with nothing else to run (12 k of a
+        # wave's 51 k clocks on the FP64 body, 21 k for the wave the first barrier waits for: profiles/r03/timeline_fwd15_ckks.json)
+        # and the launch gap between two workgroups of a CU overlap with arithmetic
+        assert not persist or (logn == 15 and threads == 1024 and not sub and not epi)
+        self.persist = persist
+        self.karg_parked = False      # timeline builds of kernels that reuse s[0:1]: the inverse ones (gen_intt.py), the persistent ones
         # profile: the timeline build of a plain integer kernel (diagnostics only, Options::timeline): every wave stamps the shader
         # clock at the phase boundaries and the stamps go to the buffer NttLaunch::epi_x points at; the transform itself is unchanged
         assert not profile or not (sub or epi)
@@ -49,7 +58,7 @@ class Gen:
         # (N = 2^16: only the plain sub-block kernels, i.e. after the top stage has been applied by the basis extension)
         assert not epi or dual
         self.fp, self.dual, self.epi = fp, dual, epi
-        self.karg_parked = False      # timeline builds of the inverse kernels (gen_intt.py)
+        self.karg_parked = bool(profile and persist)
         self.fuse_last = False        # inverse sub-block kernels (gen_intt.py): the last stage by whichever block of the pair finishes second
         self.mark = None
         assert not sub or (logn == 15 and threads == 1024)
@@ -133,6 +142,8 @@ class Gen:
         self.MAGIC = s(18, 2)                         # 2^52
         self.NINV, self.NINVQ = s(20, 2), s(22, 2)
         self.BIAS = v(126, 2)                         # 1/(2q), per lane (a second scalar operand is not allowed)
+        # persistent kernels: s[0:3] (kernel-argument pointer, workgroup ids) are dead after the prologue
+        self.IN_STEP, self.OUT_STEP, self.CNT = s(0, 2), s(2, 2), s(23)
         assert self.vgpr_count <= 126
 
     # ------------------------------------------------------------------ emission helpers
@@ -198,32 +209,44 @@ class Gen:
         e("v_mov_b32", va, J.lo())
         e("ds_write_b32", va, vd)
 
+    def park_stamp_slot(self):
+        """timeline builds, in the prologue: the byte offset of this wave's stamps in the stamp buffer -- [workgroup = y * n_items +
+        item][wave][N_STAMPS] u32, y = the workgroup's poly (persistent kernels: its chunk of polys) -- waits in bytes 132..135 of
+        the wave's row-0 padding, the kernel-argument pointer in bytes 136..143 where the kernel reuses s[0:1]"""
+        if not self.profile:
+            return
+        e, sc = self.e, self.SC
+        e("s_mul_i32", sc[0], self.WGY, s(50))                  # n_items
+        e("s_add_u32", sc[0], sc[0], self.WGX)
+        e("s_lshl_b32", sc[0], sc[0], 4)
+        e("s_add_u32", sc[0], sc[0], self.WAVE)
+        e("s_lshl_b32", sc[0], sc[0], 6)                        # x N_STAMPS x 4 bytes
+        e("s_mul_i32", sc[1], self.WAVE, 9216)
+        e("v_mov_b32", v(4), sc[1])
+        e("v_mov_b32", v(2), sc[0])
+        e("ds_write_b32", v(4), v(2), offset=132)
+        if self.karg_parked:
+            e("v_mov_b32", v(2), self.KARG.lo())
+            e("v_mov_b32", v(3), self.KARG.hi())
+            e("ds_write_b64", v(4), v(2, 2), offset=136)
+
     def flush_stamps(self, count):
-        """stamp buffer (NttLaunch::epi_x): [workgroup = poly * n_items + item][wave][N_STAMPS] u32"""
+        """stamp buffer (NttLaunch::epi_x): [workgroup][wave][N_STAMPS] u32"""
         e, sc = self.e, self.SC
         e("s_waitcnt", "vmcnt(0) lgkmcnt(0)")
         KA = self.KARG
+        e("s_mul_i32", sc[1], self.WAVE, 9216)
+        e("v_mov_b32", v(0), sc[1])
         if self.karg_parked:
-            # the inverse kernels reuse s[0:1]: the kernel-argument pointer waits in bytes 136..143 of the wave's row-0 padding
             KA = s(36, 2)
-            e("s_mul_i32", sc[1], self.WAVE, 9216)
-            e("v_mov_b32", v(0), sc[1])
             e("ds_read_b64", v(2, 2), v(0), offset=136)
             e("s_waitcnt", "lgkmcnt(0)")
             e("v_readfirstlane_b32", KA.lo(), v(2))
             e("v_readfirstlane_b32", KA.hi(), v(3))
             e("s_nop", 4)
         e("s_load_dwordx2", self.TMP, KA, 128)
-        e("s_load_dword", sc[0], KA, 56)               # n_items
+        e("ds_read_b32", v(126), v(0), offset=132)
         e("s_waitcnt", "lgkmcnt(0)")
-        e("s_mul_i32", sc[0], self.WGY, sc[0])
-        e("s_add_u32", sc[0], sc[0], self.WGX)
-        e("s_lshl_b32", sc[0], sc[0], 4)
-        e("s_add_u32", sc[0], sc[0], self.WAVE)
-        e("s_lshl_b32", sc[0], sc[0], 6)                        # x N_STAMPS x 4 bytes
-        e("v_mov_b32", v(126), sc[0])
-        e("s_mul_i32", sc[1], self.WAVE, 9216)
-        e("v_mov_b32", v(0), sc[1])
         for idx in range(count):
             e("ds_read_b32", v(1), v(0), offset=idx * 144 + 128)
             e("s_waitcnt", "lgkmcnt(0)")
@@ -448,8 +471,15 @@ class Gen:
         e("s_waitcnt", "lgkmcnt(0)")
         sc = self.SC
         self.stagger()
+        self.park_stamp_slot()
         if self.sub and self.epi:
             self.park_kernarg()
+        if self.persist:
+            # grid y counts chunks of s63 (NttLaunch::fuse_top = polys per workgroup) polys inside the group of s62 polys (the host
+            # passes group = batch for plain launches): first poly y * P, count = min(P, group - y * P) >= 1
+            e("s_mul_i32", self.WGY, self.WGY, s(63))
+            e("s_sub_u32", self.CNT, s(62), self.WGY)
+            e("s_min_u32", self.CNT, self.CNT, s(63))
         if self.sub:
             e("s_and_b32", self.BLK1, self.WGX, 1)
             e("s_add_u32", self.BLK1, self.BLK1, 1)      # 1 + blk: heap root 2 + blk = 1 + BLK1
@@ -513,6 +543,12 @@ class Gen:
             e("s_add_u32", self.DST.lo(), self.DST.lo(), sc[3])
             e("s_addc_u32", self.DST.hi(), self.DST.hi(), 0)
             self.sub_source(sc[3])
+        if self.persist:
+            # loop state: bytes from one poly of the launch to the next (the output pointer has moved on by one LDS image per poly)
+            e("s_lshl_b64", self.IN_STEP, s(40, 2), 3)
+            e("s_lshl_b64", self.OUT_STEP, s(42, 2), 3)
+            e("s_sub_u32", self.OUT_STEP.lo(), self.OUT_STEP.lo(), self.M * 8 * (self.HALVES - 1))
+            e("s_subb_u32", self.OUT_STEP.hi(), self.OUT_STEP.hi(), 0)
         self.prologue_tail()
 
     def park_kernarg(self):
@@ -653,7 +689,7 @@ class Gen:
             e("s_waitcnt", "lgkmcnt(0)")
             e("s_cmp_eq_u32", self.FPL.sub(1), 0)
             e("s_cbranch_scc1", "INT_BODY")
-            for i, dst in enumerate((self.QD, self.QINV, self.NINV, self.NINVQ)):
+            for i, dst in enumerate((self.QD, self.QINV)):       # (N^-1 is the inverse's; s23 counts polys in the persistent kernels)
                 e("s_mov_b64", dst, self.FPL.sub(2 * i, 2))
             for ptr, d in ((self.TW, self.DTW), (self.TWF, self.DTWF)):
                 e("s_add_u32", ptr.lo(), ptr.lo(), d.lo())
@@ -677,6 +713,12 @@ class Gen:
         if self.sub and self.fused:
             self.fused_top()
             return
+        if self.persist:
+            self.c("first poly: rows 16..31, then rows 0..15 (the order every later poly's prefetch has)")
+            self.load_rows(self.RA // 2, self.RA)
+            self.load_rows(0, self.RA // 2)
+            self.constants()
+            return
         self.c("coalesced load of the columns {k*S + t + c*T}")
         self.stamp(0)
         # order 0, RA/2, 1, RA/2+1, ... (per column): the first-stage butterflies can start after two loads
@@ -693,6 +735,31 @@ class Gen:
                 e("s_add_u32", ptr.lo(), ptr.lo(), self.S * 8)
                 e("s_addc_u32", ptr.hi(), ptr.hi(), 0)
         self.constants()
+
+    def load_rows(self, k0, k1):
+        """persistent kernels: column loads of rows k0..k1-1 of the poly at SRC (t*8 is recomputed: GOFF is a scratch register of the
+        LDS passes); TMP walks, SRC stays"""
+        e = self.e
+        e("v_lshlrev_b32", self.GOFF, 3, self.TID)
+        e("s_add_u32", self.TMP.lo(), self.SRC.lo(), k0 * self.S * 8)
+        e("s_addc_u32", self.TMP.hi(), self.SRC.hi(), 0)
+        for k in range(k0, k1):
+            e("global_load_dwordx2", self.X[k], self.GOFF, self.TMP, hint="nt")
+            if k + 1 < k1:
+                e("s_add_u32", self.TMP.lo(), self.TMP.lo(), self.S * 8)
+                e("s_addc_u32", self.TMP.hi(), self.TMP.hi(), 0)
+
+    def prefetch_rows(self, k0, k1, advance):
+        """persistent kernels: the next poly's rows k0..k1-1, if there is a next poly (CNT counts this one too)"""
+        e = self.e
+        tag = "%s_%d" % ("fp" if self.fp else "int", k0)
+        e("s_cmp_lt_u32", self.CNT, 2)
+        e("s_cbranch_scc1", "L_nopf_" + tag)
+        if advance:
+            e("s_add_u32", self.SRC.lo(), self.SRC.lo(), self.IN_STEP.lo())
+            e("s_addc_u32", self.SRC.hi(), self.SRC.hi(), self.IN_STEP.hi())
+        self.load_rows(k0, k1)
+        self.p.label("L_nopf_" + tag)
 
     def pass_a(self):
         e = self.e
@@ -746,7 +813,11 @@ class Gen:
                 if c == 0:
                     # loads were issued in the order of this list: pair i needs the first 2i+2
                     for i in range(0, len(blist), 2):
-                        e("s_waitcnt", "vmcnt(%d)" % max(self.NX - 2 * (i + 2), 0))
+                        if self.persist:
+                            # rows 16..31 were issued first; rows 0..15 are the youngest operations of the queue, in order
+                            e("s_waitcnt", "vmcnt(%d)" % (self.RA // 2 - 2 - i))
+                        else:
+                            e("s_waitcnt", "vmcnt(%d)" % max(self.NX - 2 * (i + 2), 0))
                         # first-stage U operands: any 64-bit value is accepted
                         if self.fp:
                             if not (self.sub and self.fused):     # (the fused top stage has converted its operands)
@@ -786,6 +857,8 @@ class Gen:
         e = self.e
         a0, a1, a2 = self.A_[0], self.A_[1], self.A_[2]
         self.c("half %d -> LDS image (16 B of padding per 16 coefficients)" % half)
+        if self.persist and half == 0:
+            e("s_barrier")            # every wave has read the previous poly's last image out (its copy-out loads have returned)
         self.uniform_twiddle_loads(half)
         e("v_lshrrev_b32", a2, 4, self.TID)
         e("v_lshlrev_b32", a2, 4, a2)
@@ -1028,6 +1101,11 @@ class Gen:
             e("s_addc_u32", self.DST.hi(), self.DST.hi(), 0)
             e("s_waitcnt", "lgkmcnt(0)")
             e("s_barrier")
+        elif self.persist:
+            # v0..v31 are free once the last store has been issued (a store reads its data when it issues)
+            self.prefetch_rows(0, self.RA // 2, advance=False)
+            e("s_add_u32", self.DST.lo(), self.DST.lo(), self.OUT_STEP.lo())
+            e("s_addc_u32", self.DST.hi(), self.DST.hi(), self.OUT_STEP.hi())
 
     def ops_epilogue(self, ts, Y, X, P, EC):
         """Y (the transform's value, a lazy double) <- canonical ((x - Y) * c + plus) mod q; X, P: canonical 64-bit integers"""
@@ -1124,10 +1202,17 @@ class Gen:
 
     def build(self):
         self.prologue()
+        tag = "fp" if self.fp else "int"
+        if self.persist:
+            self.p.label("L_poly_" + tag)
+            self.stamp(0)
         self.pass_a()
         self.stamp(2)
         for half in range(self.HALVES):
             self.lds_write_columns(half)
+            if self.persist and half == 1:
+                # v32..v63 have just gone to the LDS image: the next poly's rows 16..31 travel while this image is worked on
+                self.prefetch_rows(self.RA // 2, self.RA, advance=True)
             self.stamp(3 + 5 * half)
             self.lds_pass_uniform(half)
             self.stamp(4 + 5 * half)
@@ -1137,8 +1222,12 @@ class Gen:
             self.stamp(6 + 5 * half)
             self.copy_out(half)
             self.stamp(7 + 5 * half)
+        if self.persist:
+            self.e("s_sub_u32", self.CNT, self.CNT, 1)
+            self.e("s_cmp_lg_u32", self.CNT, 0)
+            self.e("s_cbranch_scc1", "L_poly_" + tag)
         if self.profile:
-            self.flush_stamps(3 + 5 * self.HALVES)
+            self.flush_stamps(3 + 5 * self.HALVES)     # (persistent kernels: the stamps of the workgroup's last poly)
         self.e("s_endpgm")
         return self.p
 
@@ -1252,6 +1341,10 @@ if __name__ == "__main__":
         sys.exit(0)
     if len(sys.argv) > 5 and sys.argv[5] == "timeline":      # diagnostics build with per-phase clock stamps (Options::timeline)
         open(sys.argv[2], "w").write(kernel_text_for(make(logn, threads, profile=True), "lr_ntt_fwd%d_m%dt" % (logn, mode)))
+        sys.exit(0)
+    if len(sys.argv) > 5 and sys.argv[5] in ("persist", "persist-timeline"):    # several polys per workgroup, next poly's loads prefetched
+        tl = sys.argv[5] == "persist-timeline"
+        open(sys.argv[2], "w").write(kernel_text_for(make(logn, threads, persist=True, profile=tl), "lr_ntt_fwd%dp_m%d%s" % (logn, mode, "t" if tl else "")))
         sys.exit(0)
     name = "lr_ntt_fwd%d%s_m%d" % (logn, "x" if threads < 1024 else "", mode)     # x: several workgroups per CU
     open(sys.argv[2], "w").write(kernel_text_for(make(logn, threads), name))

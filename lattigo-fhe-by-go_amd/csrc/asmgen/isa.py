@@ -5,7 +5,11 @@ workgroup-uniform loop over the polys a workgroup processes, so one workgroup ca
 every SGPR as a vector over its waves.  The emulator covers exactly the instruction subset the
 generator emits and checks the structural rules the assembler will not (even alignment of 64-bit
 VGPR operands, one constant-bus operand per VALU instruction, no read of an unwritten register).
-It does NOT model s_waitcnt / hazards: those are handled by construction in the generator.
+It does not model time, but it does model the asynchronous-return counters: every vector-memory operation joins an in-order queue
+(vmcnt), every LDS operation and scalar load the lgkm queues; a register that is the destination of an operation still in its queue is
+"in flight", and any instruction that reads or writes it before an s_waitcnt has retired that operation fails the run.  A wrong
+vmcnt / lgkmcnt count -- the bug class of prefetch loops -- therefore shows up on the CPU.  VALU hazards (carry wait states) are
+handled by construction in the generator.
 """
 import numpy as np
 
@@ -140,6 +144,39 @@ class Machine:
         self.lds = np.zeros(lds_bytes // 4, dtype=np.uint32)
         self.mem = np.zeros(mem_words, dtype=np.uint32)  # flat memory, byte address = 4*index
         self.lane_wave = np.arange(threads) // WAVE
+        # asynchronous returns: in-order queues of destination-register lists, and per-register in-flight counts
+        self.vmq, self.ldsq, self.smemq = [], [], []
+        self.vfly = np.zeros(256, dtype=np.int32)
+        self.sfly = np.zeros(108, dtype=np.int32)
+        self.max_vm_outstanding = 0
+
+    # -- asynchronous-return model
+    def _issue_vm(self, dst=None):
+        regs = list(range(dst.idx, dst.idx + dst.n)) if dst is not None else []
+        for r in regs:
+            assert self.vfly[r] == 0, "second load into v%d while one is in flight" % r
+            self.vfly[r] += 1
+        self.vmq.append(regs)
+        self.max_vm_outstanding = max(self.max_vm_outstanding, len(self.vmq))
+        assert len(self.vmq) <= 64, "more than 63 vector-memory operations outstanding: vmcnt is a 6-bit counter"
+
+    def _issue_lds(self, dst=None):
+        regs = list(range(dst.idx, dst.idx + dst.n)) if dst is not None else []
+        for r in regs:
+            assert self.vfly[r] == 0, "LDS read into v%d while an operation into it is in flight" % r
+            self.vfly[r] += 1
+        self.ldsq.append(regs)
+
+    def _issue_smem(self, dst, n):
+        regs = list(range(dst.idx, dst.idx + n))
+        for r in regs:
+            self.sfly[r] += 1
+        self.smemq.append(regs)
+
+    def _retire(self, q, keep, fly):
+        while len(q) > keep:
+            for r in q.pop(0):
+                fly[r] -= 1
 
     # -- operand access
     def rv(self, a, part=0):
@@ -147,9 +184,11 @@ class Machine:
         if isinstance(a, Reg):
             if a.kind == "v":
                 assert self.vdef[a.idx + part], "read of unwritten v%d" % (a.idx + part)
+                assert self.vfly[a.idx + part] == 0, "read of v%d while an operation into it is in flight (pc %d)" % (a.idx + part, getattr(self, "cur_pc", -1))
                 return self.vgpr[a.idx + part].copy()   # never a view: destinations may alias sources
             if a.kind == "s":
                 assert self.sdef[a.idx + part], "read of unwritten s%d" % (a.idx + part)
+                assert self.sfly[a.idx + part] == 0, "read of s%d while a scalar load into it is in flight (pc %d)" % (a.idx + part, getattr(self, "cur_pc", -1))
                 return self.sgpr[a.idx + part][self.lane_wave]
             raise ValueError(a)
         val = int(a) & 0xFFFFFFFF
@@ -164,9 +203,10 @@ class Machine:
                 assert a.idx % 2 == 0
         return self.rv(a, 0).astype(np.uint64) | (self.rv(a, 1).astype(np.uint64) << np.uint64(32))
 
-    def wv(self, d, val, part=0):
+    def wv(self, d, val, part=0, landing=False):
         assert isinstance(d, Reg) and d.kind == "v"
         assert d.idx + part < 128, "VGPR budget of a 1024-thread workgroup exceeded: v%d" % (d.idx + part)
+        assert landing or self.vfly[d.idx + part] == 0, "write of v%d while an operation into it is in flight (pc %d)" % (d.idx + part, getattr(self, "cur_pc", -1))
         self.vgpr[d.idx + part] = val.astype(np.uint32)
         self.vdef[d.idx + part] = True
 
@@ -179,13 +219,15 @@ class Machine:
         if isinstance(a, Reg):
             assert a.kind == "s"
             assert self.sdef[a.idx + part], "read of unwritten s%d" % (a.idx + part)
+            assert self.sfly[a.idx + part] == 0, "read of s%d while a scalar load into it is in flight (pc %d)" % (a.idx + part, getattr(self, "cur_pc", -1))
             return self.sgpr[a.idx + part]
         return np.full(self.W, int(a) & 0xFFFFFFFF, dtype=np.uint32)
 
     def rs64(self, a):
         return self.rs(a, 0).astype(np.uint64) | (self.rs(a, 1).astype(np.uint64) << np.uint64(32))
 
-    def ws(self, d, val, part=0):
+    def ws(self, d, val, part=0, landing=False):
+        assert landing or self.sfly[d.idx + part] == 0, "write of s%d while a scalar load into it is in flight (pc %d)" % (d.idx + part, getattr(self, "cur_pc", -1))
         self.sgpr[d.idx + part] = val.astype(np.uint32)
         self.sdef[d.idx + part] = True
 
@@ -429,6 +471,9 @@ class Machine:
     def i_s_cmp_ge_u32(self, a, b):
         self.scc = self.rs(a) >= self.rs(b)
 
+    def i_s_cmp_lt_u32(self, a, b):
+        self.scc = self.rs(a) < self.rs(b)
+
     def i_s_cselect_b32(self, d, a, b):
         self.ws(d, np.where(self.scc, self.rs(a), self.rs(b)))
 
@@ -465,8 +510,10 @@ class Machine:
         addr = self.rs64(base) + (self.rs(off).astype(np.uint64) if isinstance(off, Reg) else np.uint64(off))
         assert np.all(addr % 4 == 0)
         idx = (addr // 4).astype(np.int64)
+        assert np.all(idx >= 0) and np.all(idx + n <= self.mem.size), "scalar load outside the memory image"
         for k in range(n):
             self.ws(d, self.mem[idx + k], k)
+        self._issue_smem(d, n)
 
     def i_s_load_dword(self, d, base, off):
         self._s_load(d, base, off, 1)
@@ -493,19 +540,26 @@ class Machine:
         self._clock = getattr(self, "_clock", 0) + 1000
         self.ws(d, np.full(self.W, self._clock, dtype=np.uint32), 0)
         self.ws(d, np.zeros(self.W, dtype=np.uint32), 1)
+        self._issue_smem(d, 2)
+
+    def i_s_memrealtime(self, d):
+        self.i_s_memtime(d)
 
     def i_ds_write_b32(self, addr, data, offset=0):
         idx = self._lds_idx(addr, offset, 4)
         self.lds[idx] = self.rv(data)
+        self._issue_lds()
 
     def i_ds_read_b32(self, d, addr, offset=0):
         idx = self._lds_idx(addr, offset, 4)
         self.wv(d, self.lds[idx])
+        self._issue_lds(d)
 
     def i_global_store_dword(self, voff, data, sbase, offset=0, hint=""):
         addr = self._gaddr(voff, sbase, offset)
         m = self.exec_lanes
         self.mem[(addr // 4).astype(np.int64)[m]] = self.rv(data)[m]
+        self._issue_vm()
 
     def i_global_atomic_add(self, d, voff, data, sbase, offset=0, hint=""):
         """32-bit add with the pre-op value returned (sc0); the lanes of the workgroup take their turns in lane order"""
@@ -517,6 +571,7 @@ class Machine:
             old[lane] = self.mem[idx[lane]]
             self.mem[idx[lane]] = np.uint32((int(old[lane]) + int(add[lane])) & 0xFFFFFFFF)
         self.wv(d, old)
+        self._issue_vm(d)
 
     # cache maintenance: the emulator's memory is always coherent
     def i_buffer_wbl2(self, hint=""):
@@ -525,8 +580,19 @@ class Machine:
     def i_buffer_inv(self, hint=""):
         pass
 
-    def i_s_waitcnt(self, *a, **m):
-        pass
+    def i_s_waitcnt(self, spec):
+        """vmcnt(N): all but the N youngest vector-memory operations have returned (in issue order).  lgkmcnt(N): LDS operations
+        return in order, scalar loads in any order, both count -- so with N > 0 only LDS operations are known to be done (the
+        oldest ones beyond N, as if every scalar load had returned already), with N = 0 everything is."""
+        import re
+        for name, n in re.findall(r"(vmcnt|lgkmcnt)\((\d+)\)", spec):
+            n = int(n)
+            if name == "vmcnt":
+                self._retire(self.vmq, n, self.vfly)
+            else:
+                self._retire(self.ldsq, n, self.vfly)
+                if n == 0:
+                    self._retire(self.smemq, 0, self.sfly)
 
     def i_s_barrier(self):
         pass
@@ -542,8 +608,10 @@ class Machine:
         addr = self._gaddr(voff, sbase, offset)
         assert np.all(addr % (4 * min(n, 4)) == 0), "misaligned global access"
         idx = (addr // 4).astype(np.int64)
+        assert np.all(idx >= 0) and np.all(idx + n <= self.mem.size), "global load outside the memory image"
         for k in range(n):
             self.wv(d, self.mem[idx + k], k)
+        self._issue_vm(d)
 
     # `hint` (nt / sc0 / sc1 cache policy bits) does not change what is loaded or stored
     def i_global_load_dwordx2(self, d, voff, sbase, offset=0, hint=""):
@@ -559,15 +627,19 @@ class Machine:
         addr = self._gaddr(voff, sbase, offset)
         assert np.all(addr % 16 == 0)
         idx = (addr // 4).astype(np.int64)
+        assert np.all(idx >= 0) and np.all(idx + 4 <= self.mem.size), "global store outside the memory image"
         for k in range(4):
             self.mem[idx + k] = self.rv(data, k)
+        self._issue_vm()
 
     def i_global_store_dwordx2(self, voff, data, sbase, offset=0, hint=""):
         assert data.n == 2
         addr = self._gaddr(voff, sbase, offset)
         idx = (addr // 4).astype(np.int64)
+        assert np.all(idx >= 0) and np.all(idx + 2 <= self.mem.size), "global store outside the memory image"
         for k in range(2):
             self.mem[idx + k] = self.rv(data, k)
+        self._issue_vm()
 
     # LDS banking of gfx950 (MI355X_MICROARCH.md, LDS): a wave64 access is serviced in fixed lane groups, one LDS cycle per
     # group when conflict-free; every extra distinct address on a busy bank within a group adds a cycle.
@@ -618,20 +690,24 @@ class Machine:
         idx = self._lds_idx(addr, offset, 8, 'r64')
         for k in range(2):
             self.wv(d, self.lds[idx + k], k)
+        self._issue_lds(d)
 
     def i_ds_read_b128(self, d, addr, offset=0):
         assert d.n == 4
         idx = self._lds_idx(addr, offset, 16, 'r128')
         for k in range(4):
             self.wv(d, self.lds[idx + k], k)
+        self._issue_lds(d)
 
     def i_ds_write_b64(self, addr, data, offset=0):
         idx = self._lds_idx(addr, offset, 8, 'w64')
         for k in range(2):
             self.lds[idx + k] = self.rv(data, k)
+        self._issue_lds()
 
     def i_ds_write_b128(self, addr, data, offset=0):
         assert data.n == 4
         idx = self._lds_idx(addr, offset, 16, 'w128')
         for k in range(4):
             self.lds[idx + k] = self.rv(data, k)
+        self._issue_lds()

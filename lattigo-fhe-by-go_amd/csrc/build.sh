@@ -66,6 +66,14 @@ gen_tl() {  # kind mode
   $LLVM/ld.lld -shared build/ntt_${1}15_m${2}t.o -o build/ntt_${1}15_m${2}t.hsaco
 }
 for k in fwd inv; do for m in 1 3; do gen_tl $k $m & gpids+=($!); done; done
+# persistent forward 2^15 kernels (several polys per workgroup, next poly's loads prefetched) and their timeline builds
+gen_p() {  # mode flavour suffix
+  python3 asmgen/gen_ntt.py 15 build/ntt_fwd15p_m$1$3.s $1 1024 $2
+  $LLVM/clang -x assembler -target amdgcn-amd-amdhsa -mcpu=gfx950 -c build/ntt_fwd15p_m$1$3.s -o build/ntt_fwd15p_m$1$3.o
+  $LLVM/ld.lld -shared build/ntt_fwd15p_m$1$3.o -o build/ntt_fwd15p_m$1$3.hsaco
+}
+for m in 0 1 2 3; do gen_p $m persist "" & gpids+=($!); done
+for m in 1 3; do gen_p $m persist-timeline t & gpids+=($!); done
 for p in "${gpids[@]}"; do wait $p; done
 python3 - <<'PY'
 out = ['struct lr_asm_blob { const char *name; const unsigned char *data; unsigned long size; };']
@@ -74,6 +82,7 @@ names += [("fwd", n, m) for n in ("12x", "13x", "14x", "16s", "16p") for m in (0
 names += [("fwd", n, 3) for n in (14, 15, "12x", "13x", "14x", "16s", "16p")] + [("inv", n, 3) for n in (14, 15, "12x", "13x", "14x", "16s", "16f")]
 names += [("fwd", n, 4) for n in (14, 15, "12x", "13x", "14x", "16s", "16p")]
 names = [(k, n, str(m)) for k, n, m in names] + [(k, 15, m) for k in ("fwd", "inv") for m in ("1t", "3t")]
+names += [("fwd", "15p", m) for m in ("0", "1", "2", "3", "1t", "3t")]
 for k, n, m in names:
     data = open("build/ntt_%s%s_m%s.hsaco" % (k, n, m), "rb").read()
     out.append('static const unsigned char blob_%s%s_m%s[] __attribute__((aligned(4096))) = {' % (k, n, m))

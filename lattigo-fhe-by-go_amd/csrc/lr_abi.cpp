@@ -164,6 +164,7 @@ lr::Options lr::Options::from_env() {
     o.timeline = std::getenv("LR_NTT_TIMELINE") != nullptr;
     if (const char *v = std::getenv("LR_NTT_MODE")) o.ntt_mode = std::atoi(v);
     if (const char *v = std::getenv("LR_NTT_STAGGER")) o.stagger = std::atoi(v);
+    if (const char *v = std::getenv("LR_NTT_PERSIST")) o.persist = std::atoi(v);
     if (const char *v = std::getenv("LR_ASM_VARIANT")) o.asm_variant = std::atoi(v);
     return o;
 }
@@ -865,6 +866,18 @@ bool ntt_epilogue_ok(const lr_context *c) {
 int run_ntt_launch(lr_context *c, bool inverse, Rows in, Rows out, int mod0, int mod_step, int count, int batch, int hole,
                    int group, const NttEpilogue *epi, bool pretop);
 
+// Polys per workgroup of the persistent forward 2^15 kernels (0 = the one-poly kernels).  LR_NTT_PERSIST overrides; the default keeps
+// at least four rounds of workgroups on the 256 CUs (the dispatcher balances limbs of different cost -- FP64 and integer bodies in one
+// dual launch -- by rounds) and at most kPersistMax polys per workgroup.
+constexpr int kPersistDefault = 0;
+int ntt_persist(const lr_context *c, const NttLaunch &a, unsigned logn, bool inverse) {
+    if (logn != 15 || inverse) return 0;
+    const int polys = a.hole > 0 ? a.group : a.batch;
+    int p = c->opt.persist >= 0 ? c->opt.persist : kPersistDefault;
+    if (p > polys) p = polys;
+    return p >= 2 ? p : 0;
+}
+
 // The assembly kernels of the integer variants put the polynomial on grid.y (limit 65535): longer plain launches are cut into
 // chunks along the batch on the same kernel (no silent change of code path).  Grouped launches (key-switch digits) beyond
 // the limit are refused: 65536 ciphertexts in one key switch exceed the device memory by orders of magnitude.
@@ -1003,10 +1016,10 @@ int run_ntt_launch(lr_context *c, bool inverse, Rows in, Rows out, int mod0, int
             }
             c->stamp_used = words;
             a.epi_x = reinterpret_cast<const u64 *>(c->d_stamps);
-            LR_HIP(launch_ntt_asm(a, (int)logn, inverse, variant, c->stream, false, kn, true, c->opt.stagger));
+            LR_HIP(launch_ntt_asm(a, (int)logn, inverse, variant, c->stream, false, kn, true, c->opt.stagger, ntt_persist(c, a, logn, inverse)));
             return LR_OK;
         }
-        LR_HIP(launch_ntt_asm(a, (int)logn, inverse, variant, c->stream, c->opt.asm14_1024, kn, false, c->opt.stagger));
+        LR_HIP(launch_ntt_asm(a, (int)logn, inverse, variant, c->stream, c->opt.asm14_1024, kn, false, c->opt.stagger, ntt_persist(c, a, logn, inverse)));
         return LR_OK;
     }
     std::snprintf(c->last_ntt_kernel, sizeof c->last_ntt_kernel, "ntt_%s_kernel<%u>", inverse ? "inv" : "fwd", logn);

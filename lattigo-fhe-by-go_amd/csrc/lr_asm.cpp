@@ -71,16 +71,19 @@ static int stagger_unit(int request, bool one_wg_per_cu, bool dual, unsigned lon
 bool ntt_asm_available(int logn) { return logn >= 12 && logn <= 16 && kernels_for_current_device() != nullptr; }
 
 // variant = lazy-correction mode of asmgen/gen_ntt.py (forward 0, 1, 2) / gen_intt.py (inverse 0, 1)
+// persist > 0 (forward 2^15, variants 0..3, no epilogue): the persistent kernels lr_ntt_fwd15p_*, `persist` polys per workgroup in a loop
+// with the next poly's column loads prefetched (gen_ntt.py: persist)
 hipError_t launch_ntt_asm(const NttLaunch &a, int logn, int inverse, int variant, hipStream_t stream, bool wide14, char *kernel_name, bool timeline,
-                          int stagger) {
+                          int stagger, int persist) {
     AsmKernels *k = kernels_for_current_device();
     if (!k || logn < 12 || logn > 15) return hipErrorNotSupported;
+    if (persist > 0 && (logn != 15 || inverse || variant > 3)) persist = 0;
     // N = 2^12 (256 threads, four columns per thread, 36 KiB LDS image) and N = 2^13, 2^14 (512 threads, two columns,
     // 72 KiB) run several workgroups per CU: one
     // covers the other's load and store phases.  wide14 (Options::asm14_1024) selects the 1024-thread kernels (testing aid).
     const bool x = logn <= 13 || (logn == 14 && !wide14);
     char name[32];
-    std::snprintf(name, sizeof name, "lr_ntt_%s%d%s_m%d%s", inverse ? "inv" : "fwd", logn, x ? "x" : "", variant, timeline ? "t" : "");
+    std::snprintf(name, sizeof name, "lr_ntt_%s%d%s_m%d%s", inverse ? "inv" : "fwd", logn, x ? "x" : persist > 0 ? "p" : "", variant, timeline ? "t" : "");
     auto it = k->fn.find(name);
     if (it == k->fn.end()) return hipErrorNotSupported;
     if (kernel_name) std::snprintf(kernel_name, 32, "%s", name);
@@ -101,6 +104,12 @@ hipError_t launch_ntt_asm(const NttLaunch &a, int logn, int inverse, int variant
         gz = (unsigned)(a.batch / a.group);
     }
     const unsigned threads = !x ? 1024 : (logn == 12 || (logn == 13 && !inverse)) ? 256 : 512;
+    if (persist > 0) {
+        // chunks of `persist` consecutive polys of a group per workgroup; the kernel reads the group size for plain launches too
+        args.group = (int)gy;
+        args.fuse_top = persist;
+        gy = (gy + (unsigned)persist - 1) / (unsigned)persist;
+    }
     const unsigned gx = variant >= 3 ? gy : (unsigned)a.n_items, gyy = variant >= 3 ? (unsigned)a.n_items : gy;
     args.stagger_gx = (int)gx;
     args.stagger_unit = stagger_unit(stagger, threads == 1024, variant >= 3, (unsigned long long)gx * gyy * gz);

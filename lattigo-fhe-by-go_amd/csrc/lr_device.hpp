@@ -39,6 +39,7 @@ struct Options {
     bool keymac_narrow = false;    // LR_KEYMAC_NARROW: one Montgomery product per term in the key inner product instead of the 128-bit sums
     bool no_invfuse = false;       // LR_NO_INVFUSE: N = 2^16 inverse transforms as lazy sub-blocks + the separate last-stage pass (ntt_top_kernel) instead of the pair-flag kernels
     bool no_exttop = false;        // LR_NO_EXTTOP: N = 2^16 key switch with staged extensions and fused-top transforms instead of the top stage inside the extension
+    int persist = -1;              // LR_NTT_PERSIST: polys per workgroup of the persistent forward 2^15 kernels (0 = one-poly workgroups, -1 = default)
     int stagger = -1;              // LR_NTT_STAGGER: start-up stagger of the assembly NTT kernels in kilo-clocks per step (0 = off)
     int ntt_mode = -1;             // LR_NTT_MODE
     int asm_variant = -1;          // LR_ASM_VARIANT
@@ -79,7 +80,9 @@ struct NttLaunch {
     int hole;
     int group;
     int fuse_top;               // sub_log = 1, forward, out of place: the sub-transforms compute the stage over bit 15 while
-                                // loading (each reads both halves of the limb), no separate streaming pass
+                                // loading (each reads both halves of the limb), no separate streaming pass.
+                                // Persistent kernels (lr_ntt_fwd15p_*, sub_log = 0): polys per workgroup; grid y (x for the dual
+                                // kernels) counts chunks of that many polys inside a group, and `group` is set for plain launches too
     // dual assembly kernels ("m3"): a limb whose fp_lp entry is set runs on the FP64 body, with twiddles (w, RN(w/q)) as
     // doubles in tables laid out exactly like tw / tw_fin, found at tw + fp_tw_delta / tw_fin + fp_fin_delta (bytes)
     long long fp_tw_delta, fp_fin_delta;
@@ -300,7 +303,7 @@ bool ntt_asm_available(int logn);
 // kernel_name (optional, >= 32 bytes): receives the name of the code object that was launched
 // stagger: Options::stagger (kilo-clocks per step; 0 = off, -1 = the launcher's default for the kernel)
 hipError_t launch_ntt_asm(const NttLaunch &a, int logn, int inverse, int variant, hipStream_t stream, bool wide14 = false,
-                          char *kernel_name = nullptr, bool timeline = false, int stagger = -1);
+                          char *kernel_name = nullptr, bool timeline = false, int stagger = -1, int persist = 0);
 hipError_t launch_ntt_asm16(const NttLaunch &a, int inverse, char kind, int variant, hipStream_t stream, char *kernel_name = nullptr,
                             int stagger = -1);
 // N = 2^16 helpers (lr_ntt.hip): the streaming stage over bit 15, and whether no input row of a launch is an output row

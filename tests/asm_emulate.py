@@ -153,6 +153,118 @@ def emulate(gen, inverse=False, q=None, geom=None):
 
 
 
+def emulate_persist(make_gen, q, polys, per_wg, chunk):
+    """forward persistent kernel: the workgroup of chunk `chunk` transforms polys [chunk * per_wg, min(polys, (chunk + 1) * per_wg)) of a
+    batch of `polys` one-limb polys in its loop; every output row of the batch is compared (rows of other chunks must stay zero)"""
+    import numpy as np
+
+    from isa import Machine
+    import __graft_entry__ as graft
+    oracle = graft.load_oracle()
+    pkg = graft.load_package()
+    gen = make_gen()
+    logn = gen.logn
+    N = 1 << logn
+    q = q or pkg.params.Qi60()[-3]
+    oc = oracle.Context(N, [q])
+    x = pkg.sampling.random_u64((polys, N), seed=21)
+    x[:, :4] = np.uint64(0xFFFFFFFFFFFFFFFF)
+    want = np.zeros((polys, N), dtype=np.uint64)
+    lo, hi = chunk * per_wg, min(polys, (chunk + 1) * per_wg)
+    for b in range(lo, hi):
+        want[b] = oc.ntt(np.array([[int(val) % q for val in x[b]]], dtype=np.uint64))[0]
+    psi = [int(oracle.inv_mform(int(w), q)) for w in oc.ntt_psi[0]]
+    n_inv = pow(N, -1, q)
+    tw = np.zeros((N, 2), dtype=np.uint64)
+    for i, w in enumerate(psi):
+        tw[i, 0] = w
+        tw[i, 1] = (w << 64) // q
+    blocks = N // 16
+    twf = np.zeros((15, blocks, 2), dtype=np.uint64)
+    for cc in range(4):
+        for j in range(1 << cc):
+            for bk in range(blocks):
+                twf[(1 << cc) - 1 + j, bk] = tw[((blocks + bk) << cc) + j]
+    lp = np.zeros(8, dtype=np.uint64)
+    lp[0] = q
+    lp[2] = (1 << 128) // q >> 64
+    lp[5] = n_inv
+    lp[6] = (n_inv << 64) // q
+    stride_in, stride_out = 2 * N, 3 * N          # polys further apart than their rows, and differently on the two sides
+    A_KARG, A_IN = 0x800, 0x1000
+    A_OUT = A_IN + 8 * stride_in * polys + 0x1000
+    A_LP = A_OUT + 8 * stride_out * polys + 0x1000
+    A_TW = A_LP + 0x1000
+    A_TWF = A_TW + 16 * N + 0x1000
+    A_FTW = A_TWF + 16 * 15 * blocks + 0x1000
+    A_FTWF = A_FTW + 16 * N + 0x1000
+    A_FLP = A_FTWF + 16 * 15 * blocks + 0x1000
+    A_STAMPS = A_FLP + 0x1000
+    mem = np.zeros((A_STAMPS + 0x4000) // 4, dtype=np.uint32)
+
+    def place(arr, addr):
+        words = np.ascontiguousarray(arr).view(np.uint32).ravel()
+        mem[addr // 4: addr // 4 + words.size] = words
+
+    for b in range(polys):
+        place(x[b], A_IN + 8 * stride_in * b)
+    place(lp, A_LP)
+    place(tw, A_TW)
+    place(twf, A_TWF)
+    fp_tables(np, q, n_inv, tw, twf, lambda a, b, c: (place(a, A_FTW), place(b, A_FTWF), place(c, A_FLP)))
+    karg = np.zeros(22, dtype=np.uint64)
+    karg[13], karg[14], karg[15] = A_FTW - A_TW, A_FTWF - A_TWF, A_FLP
+    karg[0], karg[1], karg[2], karg[3] = A_IN, A_OUT, stride_in, stride_out
+    karg[4] = 0 | (1 << 32)
+    karg[5] = 0 | (1 << 32)
+    karg[6] = 0
+    karg[7] = 1 | (polys << 32)        # n_items, batch
+    karg[8], karg[9], karg[10] = A_LP, A_TW, A_TWF
+    karg[11] = 0                       # sub_log, hole
+    karg[12] = polys | (per_wg << 32)  # group (= batch for a plain launch), fuse_top = polys per workgroup
+    if getattr(gen, "profile", False):
+        karg[16] = A_STAMPS
+    place(karg, A_KARG)
+    prog = gen.build()
+    m = Machine(gen.T, 160 * 1024, mem.size)
+    m.mem = mem
+    m.vgpr[0] = np.arange(gen.T, dtype=np.uint32)
+    m.vdef[0] = True
+    m.sgpr[0], m.sgpr[1] = A_KARG, 0
+    m.sgpr[gen.WGX.idx], m.sgpr[gen.WGY.idx], m.sgpr[4] = 0, chunk, 0
+    m.sdef[0:5] = True
+    m.run(prog)
+    got = np.stack([m.mem[(A_OUT + 8 * stride_out * b) // 4: (A_OUT + 8 * stride_out * b) // 4 + 2 * N].view(np.uint64) for b in range(polys)])
+    ok = bool(np.array_equal(got, want))
+    ran = sum(n for op, n in m.executed.items() if op.startswith("v_"))
+    info = "%d polys in the loop, %d VALU executed = %.1f per poly, at most %d vector-memory operations in flight" % (
+        hi - lo, ran, ran / (hi - lo), m.max_vm_outstanding)
+    if getattr(gen, "gf", None) is not None:
+        ok = ok and bool(m.executed.get("v_fma_f64")) == (q < FP_LIMIT)
+    if not ok:
+        bad = np.argwhere(got != want)
+        info += "\n  mismatches: %d first: %s" % (len(bad), bad[:4].tolist())
+    return ok, info
+
+
+def selftest_persist(threads=1024):
+    ok = True
+    cases = []
+    for mode in (0, 1, 2):
+        cases.append(("mode %d" % mode, (lambda mode=mode: Gen(15, mode, threads, persist=True)), test_moduli(15, mode)[0]))
+    for q in fp_test_moduli(15):
+        cases.append(("dual", (lambda: Dual(lambda fp: Gen(15, 2, threads, fp=fp, dual=True, persist=True))), q))
+    cases.append(("dual timeline", (lambda: Dual(lambda fp: Gen(15, 2, threads, fp=fp, dual=True, persist=True, profile=True))), fp_test_moduli(15)[0]))
+    for name, make, q in cases:
+        # three polys in one loop (prefetch taken twice, skipped once); a trailing chunk of one poly (no prefetch at all)
+        for polys, per_wg, chunk in ((3, 3, 0), (3, 2, 1)):
+            good, info = emulate_persist(make, q, polys, per_wg, chunk)
+            ok = ok and good
+            print("forward persistent logN=15 %s q=%d (%d bits), chunk %d of %d x %d: %s; %s" % (
+                name, q, q.bit_length(), chunk, polys, per_wg, "bit-exact vs oracle" if good else "MISMATCH", info), flush=True)
+    return ok
+
+
 def fp_tables(np, q, n_inv, tw, twf, put):
     """what lr_abi.cpp builds for the FP body: every (w, floor(w 2^64 / q)) becomes the pair of doubles (w, RN(w / q));
     FpLimb = {q, RN(1/q), N^-1 mod q, RN(N^-1 / q)}, all zero for a modulus the FP body does not take"""
@@ -405,4 +517,6 @@ if __name__ == "__main__":
     if logn == 16:
         sys.exit(0 if selftest_sub(inverse=inverse) else 1)
     threads = int(sys.argv[3]) if len(sys.argv) > 3 else 1024
+    if len(sys.argv) > 2 and sys.argv[2] == "--selftest-persist":
+        sys.exit(0 if selftest_persist() else 1)
     sys.exit(0 if selftest(logn, inverse=inverse, threads=threads) else 1)

@@ -57,7 +57,7 @@ def main():
         fn()
     ms = ctx.TimerStop() / 10
     kname = ctx.last_ntt_kernel()
-    assert kname.endswith("t") and kname.startswith("lr_ntt_%s15_m" % kind), kname
+    assert kname.endswith("t") and (kname.startswith("lr_ntt_%s15_m" % kind) or kname.startswith("lr_ntt_%s15p_m" % kind)), kname
     # the stamped build computes the same transform as the shipped kernel (a second context created without the switch)
     os.environ.pop("LR_NTT_TIMELINE")
     plain = ring.NewContextWithParams(N, moduli)
@@ -75,7 +75,13 @@ def main():
         groups = {"fp64 body (limbs below 2^46)": fp_limb, "integer body (the others)": ~fp_limb}
     elif kname.endswith("m3t"):
         groups = {"fp64 body (limbs below 2^46)": fp_limb}
+    persist = int(os.environ.get("LR_NTT_PERSIST", "0") or 0) if "15p_" in kname else 0
+    if persist:
+        # persistent kernels: one stamp row per workgroup = chunk of polys (the stamps of its last poly), [chunk * L + limb]
+        st_all = st_all[:(-(-B // persist)) * L]
+        limb_of = np.arange(st_all.shape[0]) % L
     res = {"kernel": "%s (stamped build of %s), %d workgroups x 16 waves" % (kname, kname[:-1], st_all.shape[0]),
+           "polys_per_workgroup": persist or 1,
            "moduli_bits": [int(q).bit_length() for q in moduli],
            "launch_ms": ms, "launch_ms_note": "with stamps; the shipped kernel's time is the bench line's",
            "clock_note": "s_memtime ticks = shader clocks; 256 CUs x 16 workgroups each; launch_ms x clock / 16 = clocks per workgroup slot",
