@@ -191,7 +191,12 @@ class Gen:
 
     N_STAMPS = 16
 
-    def stamp(self, idx):
+    def stamp_real(self, idx):
+        """the same with the constant 100 MHz real-time counter: (shader-clock delta) / (real-time delta) x 100 MHz between the two
+        pairs of stamps (13, 14) at the start and (last phase stamp, 15) at the end is the clock the CU ran at"""
+        self.stamp(idx, op="s_memrealtime")
+
+    def stamp(self, idx, op="s_memtime"):
         """timeline builds: wave w parks the low word of the shader clock in the padding of row idx of its LDS block (bytes
         w*9216 + idx*144 + 128, never touched by the transform); flush_stamps() copies them out at the end.  s[32:33] is the
         carry-out dump of the multiply-adds (always dead); the stamps sit between phases, where the first butterfly's temporaries
@@ -201,7 +206,7 @@ class Gen:
         assert idx < self.N_STAMPS
         e, J = self.e, self.JUNK
         va, vd = self.ts[0].Q.lo(), self.ts[0].Q.hi()
-        e("s_memtime", J)
+        e(op, J)
         e("s_waitcnt", "lgkmcnt(0)")
         e("v_mov_b32", vd, J.lo())
         e("s_mul_i32", J.lo(), self.WAVE, 9216)
@@ -229,10 +234,14 @@ class Gen:
             e("v_mov_b32", v(2), self.KARG.lo())
             e("v_mov_b32", v(3), self.KARG.hi())
             e("ds_write_b64", v(4), v(2, 2), offset=136)
+        self.stamp(13)
+        self.stamp_real(14)
 
     def flush_stamps(self, count):
         """stamp buffer (NttLaunch::epi_x): [workgroup][wave][N_STAMPS] u32"""
         e, sc = self.e, self.SC
+        self.stamp_real(15)
+        count = self.N_STAMPS
         e("s_waitcnt", "vmcnt(0) lgkmcnt(0)")
         KA = self.KARG
         e("s_mul_i32", sc[1], self.WAVE, 9216)

@@ -47,6 +47,13 @@ class Probe(Gen):
                 for op in self.ops_butterfly(self.ts[0], X[i], X[i + 16], tw, True):
                     e(*op)
             return 16 * 18
+        if var == "fp_real":
+            # the generator's own FP64 butterflies (gen_ntt.py: ops_butterfly_fp), 16 of them, two interleaved
+            self.fp = True
+            twf = tuple(s(36 + i) for i in range(4))
+            self.butterflies([(X[i], X[i + 16], twf, False) for i in range(16)])
+            self.fp = False
+            return 16 * 8
         if var == "fp64_bfly":
             # the butterfly an FP64 path would use for moduli <= 50 bits: error-free product (mul + fma), quotient by
             # multiplication with 1/q and round-to-nearest, exact remainder by fma, then X = U + r, Y = U - r
@@ -214,6 +221,23 @@ class Probe(Gen):
                 e("v_mov_b32", d.lo(), a.hi())
             elif var == "fma_f64":
                 e("v_fma_f64", d, a, a, d)
+            elif var == "mul_f64":
+                e("v_mul_f64", d, a, d)
+            elif var == "add_f64":
+                e("v_add_f64", d, a, d)
+            elif var == "rndne_f64":
+                e("v_rndne_f64", d, a)
+            elif var == "floor_f64":
+                e("v_floor_f64", d, a)
+            elif var == "cvt_f64_u32":
+                e("v_cvt_f64_u32", d, a.lo())
+            elif var == "ldexp_f64":
+                e("v_ldexp_f64", d, a, 32)
+            elif var == "fma_rnd_mix":      # the FP64 butterfly's mix: seven multiply / add / fma class instructions per v_rndne_f64
+                if i % 8 == 3:
+                    e("v_rndne_f64", d, a)
+                else:
+                    e("v_fma_f64", d, a, a, d)
             elif var == "fma_f32":
                 e("v_fma_f32", d.lo(), a.lo(), a.hi(), d.lo())
             else:
@@ -236,6 +260,8 @@ class Probe(Gen):
         # item base: (workgroup id * ITER) * 256 KiB, wrapped into a 1 GiB buffer by the host-side size choice
         e("s_and_b32", self.SC[0], self.WGX, 255)
         e("s_lshl_b32", self.SC[0], self.SC[0], 24)            # 64 items of 256 KiB per workgroup slot, 4 GiB in all
+        if "l2" in var:
+            e("s_mov_b32", self.SC[0], 0)                       # every workgroup reads the same 256 KiB again and again: L2 hits
         e("s_add_u32", self.SRC.lo(), self.SRC.lo(), self.SC[0])
         e("s_addc_u32", self.SRC.hi(), self.SRC.hi(), 0)
         wide = "x4" in var
@@ -259,8 +285,9 @@ class Probe(Gen):
             # stand-in for the compute phase: ~30 us of dependent VALU per item
             for i in range(2000):
                 e("v_mad_u64_u32", self.X[i % 32], self.JUNK, self.X[(i + 7) % 32].lo(), s(36), self.X[i % 32])
-        e("s_add_u32", self.SRC.lo(), self.SRC.lo(), 262144)
-        e("s_addc_u32", self.SRC.hi(), self.SRC.hi(), 0)
+        if "l2" not in var:
+            e("s_add_u32", self.SRC.lo(), self.SRC.lo(), 262144)
+            e("s_addc_u32", self.SRC.hi(), self.SRC.hi(), 0)
         e("s_sub_u32", self.REM, self.REM, 1)
         e("s_cmp_eq_u32", self.REM, 0)
         e("s_cbranch_scc0", "L_top")
@@ -268,6 +295,10 @@ class Probe(Gen):
         e("global_store_dwordx2", self.GOFF, self.X[0], self.DST)
         e("s_endpgm")
         self.count = 64
+        if "l2" in var or "hbm" in var:
+            self.count = 64 * n // ITER if (64 * n) % ITER == 0 else 64 * n     # energy mode: wave-instructions = count x ITER per wave
+            self.count = 64 * n
+            self.mem_energy = True
         return self.p
 
     def build(self):
@@ -313,6 +344,8 @@ class Probe(Gen):
 
 PAIRING = ["mad_vsv", "add_u32", "madadd_1", "madadd_2", "madadd_4", "madadd_8", "madsub_2", "madsub_4"]
 ENERGY = ["mov", "xor_b32", "add_u32", "lshl_add", "lshl_add_vvv", "mullo_vv", "mulhi_vv", "mulhi_vs", "mad_vs0", "mad_vsv", "mad_vvv", "fma_f32", "fma_f64", "bfly_nc", "bfly_c", "fp64_bfly", "xchg_lds"]
+MEMPOWER = ["mem_hbm_x4", "mem_l2_x4", "mem_hbm_x2", "mem_l2_x2"]
+FP64 = ["fma_f64", "mul_f64", "add_f64", "rndne_f64", "floor_f64", "cvt_f64_u32", "ldexp_f64", "fma_rnd_mix", "fp_real", "bfly_nc", "add_u32"]
 VARIANTS = ["mad_add_mix", "mulhi_add_mix", "xchg_none", "xchg_lds", "xchg_perm", "xchg_dpp", "mulhi_vs", "mad_vs0", "mad_vsv", "lshl_add", "add_u32", "sub_co_pair", "cndmask_vcc", "fma_f64", "bfly_nc", "bfly_c"]
 _OLD2 = ["cfg_98_36", "cfg_32_36", "cfg_2_36", "cfg_32_68", "cfg_vcc_68", "cfg_98_92", "cfg_98_40", "cfg_34_64", "cfg_2_36_c", "cfg_98_36_c", "cfg_32_36_c"]
 _OLD = ["bfly_nc", "bfly_c", "bfly_nc_seq", "bfly_c_seq", "bfly_nc_2sgpr", "inv_c", "mad_sdst_vcc", "mad_sdst_alt", "subb_sgpr", "cmp_vcc", "cmp_sgpr",
@@ -323,9 +356,9 @@ if __name__ == "__main__":
     out = sys.argv[1]
     os.makedirs(out, exist_ok=True)
     meta = []
-    for var in ({"energy": ENERGY, "pairing": PAIRING}.get(sys.argv[2] if len(sys.argv) > 2 else "", VARIANTS)):
+    for var in ({"energy": ENERGY, "pairing": PAIRING, "fp64": FP64, "mempower": MEMPOWER}.get(sys.argv[2] if len(sys.argv) > 2 else "", VARIANTS)):
         g = Probe(var)
         text = kernel_text_for(g, "probe_" + var)
         open(os.path.join(out, var + ".s"), "w").write(text)
-        meta.append("%s %d" % (var, g.count * ITER))
+        meta.append("%s %d" % (var, g.count if getattr(g, "mem_energy", False) else g.count * ITER))
     open(os.path.join(out, "variants.txt"), "w").write("\n".join(meta) + "\n")

@@ -14,7 +14,7 @@ import __graft_entry__ as g
 pkg = g.load_package(); ring, params, sampling = pkg.ring, pkg.params, pkg.sampling
 N, q60 = params.DefaultParamsQi(15)
 res = []
-for name, moduli in (("q60", list(q60)), ("ckks", list(params.ckks_moduli("PN15QP880")[1][:16]))):
+for name, moduli in (("q60", list(q60)), ("ckks", list(params.ckks_moduli("PN15QP880")[1][:16])), ("fp40", params.GenerateNTTPrimes(40, 15, 16))):
     ctx = ring.NewContextWithParams(N, moduli)
     B = 256
     base = sampling.uniform_poly(moduli, N, 7, seed=1)

@@ -67,7 +67,10 @@ def main():
     assert np.array_equal(dst.get().reshape(B, L, N)[:2], ref.get().reshape(2, L, N))
     names = INV_PHASES if inverse else FWD_PHASES
     ns = len(names) + 1
-    st_all = ctx.timeline().astype(np.int64)[:, :, :ns]             # [workgroup = poly * L + limb, wave, stamp]
+    raw = ctx.timeline().astype(np.int64)                           # [workgroup = poly * L + limb, wave, 16 stamps]
+    if os.environ.get("LR_TIMELINE_RAW"):
+        np.savez_compressed(os.environ["LR_TIMELINE_RAW"], stamps=raw.astype(np.uint32), moduli=np.array(moduli, dtype=np.uint64), launch_ms=ms)
+    st_all = raw[:, :, :ns]
     limb_of = np.arange(st_all.shape[0]) % L
     fp_limb = np.array([int(q) < (1 << 46) for q in moduli])
     groups = {"all": np.ones(L, dtype=bool)}
@@ -86,6 +89,14 @@ def main():
            "launch_ms": ms, "launch_ms_note": "with stamps; the shipped kernel's time is the bench line's",
            "clock_note": "s_memtime ticks = shader clocks; 256 CUs x 16 workgroups each; launch_ms x clock / 16 = clocks per workgroup slot",
            "bodies": {}}
+    # the clock the waves ran at: shader-clock ticks (stamp 13 at the start of the kernel .. the last phase stamp) over the ticks of the
+    # constant 100 MHz real-time counter between the same two points (stamps 14 and 15)
+    raw = raw[:st_all.shape[0]]
+    dt_shader = (raw[:, :, ns - 1] - raw[:, :, 13]) & 0xFFFFFFFF
+    dt_real = (raw[:, :, 15] - raw[:, :, 14]) & 0xFFFFFFFF
+    good = dt_real > 0
+    res["in_kernel_clock_GHz_median"] = float(np.median(dt_shader[good] / dt_real[good])) * 0.1
+    res["in_kernel_clock_note"] = "s_memtime delta / s_memrealtime delta x 100 MHz per wave over its whole life (prologue included), median over all waves"
     wg_life_all = ((st_all[:, :, ns - 1].max(axis=1) - st_all[:, :, 0].min(axis=1)) & 0xFFFFFFFF)
     res["effective_shader_clock_GHz"] = float(wg_life_all.sum()) / 256.0 / (ms * 1e-3) / 1e9
     res["effective_shader_clock_note"] = ("sum of the workgroups' lives in shader clocks / 256 CUs / launch wall time: a lower bound "
@@ -126,7 +137,7 @@ def main():
         print(gname, json.dumps(summary), "wave life", total, "wg life", float(np.median(wg_life)))
     os.makedirs(os.path.dirname(os.path.abspath(out_path)), exist_ok=True)
     json.dump(res, open(out_path, "w"), indent=1)
-    print("launch ms", ms, "clock GHz >=", res["effective_shader_clock_GHz"])
+    print("launch ms", ms, "clock GHz >=", res["effective_shader_clock_GHz"], "in-kernel clock GHz", res["in_kernel_clock_GHz_median"])
 
 
 if __name__ == "__main__":
