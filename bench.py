@@ -154,9 +154,17 @@ def effective_cores():
     return n
 
 
-def _pmc_passes(script_args, pick, timeout=180):
-    """Two child runs of `rocprofv3 --pmc` (FETCH_SIZE, WRITE_SIZE: one counter per pass, no trace domains) over a script under tools/dbg;
-    pick(rows, stdout) turns a pass's counter rows into one number of KB.  Returns ({counter: KB}, None) or (None, reason)."""
+NOMINAL_SCLK_HZ = 2.4e9     # MI355X peak engine clock; what the chip sustains under these kernels is reported beside it
+SIMDS = 256 * 4
+
+
+def _under_profiler():
+    return any(k.startswith(("ROCP", "ROCPROF")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "")
+
+
+def _pmc_pass(counters, script_args, timeout=180):
+    """One child run of `rocprofv3 --pmc <counters>` (no trace domains) over a script under tools/dbg: the rows of its counter CSV
+    and its stdout.  Raises RuntimeError with the reason when the profiler cannot run."""
     import csv
     import glob
     import shutil
@@ -164,62 +172,109 @@ def _pmc_passes(script_args, pick, timeout=180):
     import tempfile
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(exe):
-        return None, "rocprofv3 not found"
-    kb = {}
-    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
-        out_dir = tempfile.mkdtemp(prefix="lr_pmc_", dir="/tmp")
-        try:
-            env = dict(os.environ, TMPDIR="/tmp")
-            # the profiled program goes directly after `--`: the interpreter binary itself, no wrapper
-            cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", out_dir, "-o", "p", "--", os.path.realpath(sys.executable)] + script_args
-            res = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=timeout)
-            rows = []
-            for f in glob.glob(os.path.join(out_dir, "**", "*counter_collection.csv"), recursive=True):
-                rows += [r for r in csv.DictReader(open(f)) if r["Counter_Name"] == counter]
-            val = pick(rows, res.stdout.decode(errors="replace")) if res.returncode == 0 and rows else None
-            if val is None:
-                return None, "%s pass: rc %d, %d counter rows" % (counter, res.returncode, len(rows))
-            kb[counter] = val
-        except Exception as ex:     # noqa: BLE001 -- the measurement is optional, the reason is reported
-            return None, "%s pass: %s" % (counter, ex)
-        finally:
-            shutil.rmtree(out_dir, ignore_errors=True)
-    return kb, None
+        raise RuntimeError("rocprofv3 not found")
+    if _under_profiler():
+        raise RuntimeError("this run is itself under a profiler (nested rocprofv3 passes are not attempted)")
+    out_dir = tempfile.mkdtemp(prefix="lr_pmc_", dir="/tmp")
+    try:
+        # a clean environment for the child: no preload / tool variables of an outer profiler
+        env = {k: v for k, v in os.environ.items() if not k.startswith(("ROCP", "ROCPROF")) and k != "LD_PRELOAD"}
+        env["TMPDIR"] = "/tmp"
+        # the profiled program goes directly after `--`: the interpreter binary itself, no wrapper
+        cmd = [exe, "--pmc"] + list(counters) + ["--output-format", "csv", "-d", out_dir, "-o", "p", "--", os.path.realpath(sys.executable)] + script_args
+        res = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=timeout)
+        rows = []
+        for f in glob.glob(os.path.join(out_dir, "**", "*counter_collection.csv"), recursive=True):
+            rows += [r for r in csv.DictReader(open(f)) if r["Counter_Name"] in counters]
+        if res.returncode != 0 or not rows:
+            raise RuntimeError("%s pass: rc %d, %d counter rows" % ("+".join(counters), res.returncode, len(rows)))
+        return rows, res.stdout.decode(errors="replace")
+    finally:
+        shutil.rmtree(out_dir, ignore_errors=True)
+
+
+PMC_PASSES = (("FETCH_SIZE",), ("WRITE_SIZE",), ("SQ_INSTS_VALU", "SQ_WAVES", "GRBM_GUI_ACTIVE"))
+
+
+def _valu_object(insts, waves, shader_cycles, profiled_seconds, run_seconds):
+    """The other roof (VALU utilisation beside GB/s).  One vector instruction occupies its SIMD for 4 clocks (the cost the
+    SQ's own VALU-busy counter charges; plain 32-bit instructions can issue in 2, so a kernel dense in those reads above its true share):
+    issue_frac = instructions x 4 / (1024 SIMDs x shader clocks of the launch).  `nominal` prices the launch at the 2.4 GHz peak clock and
+    the un-profiled duration of this run, `sustained` at the shader clocks the profiled pass counted (GRBM_GUI_ACTIVE / 8 XCDs): the chip
+    runs these kernels at its 1.4 kW package power limit and lowers its clock to stay there."""
+    return {"instr_per_wave": insts / waves if waves else None, "waves": waves, "instructions": insts, "clocks_per_instruction_assumed": 4,
+            "issue_frac_nominal": insts * 4 / (SIMDS * NOMINAL_SCLK_HZ * run_seconds),
+            "issue_frac_sustained": insts * 4 / (SIMDS * shader_cycles) if shader_cycles else None,
+            "sclk_MHz": shader_cycles / profiled_seconds / 1e6 if profiled_seconds else None}
+
+
+def measure_kernel(script_args, kernel_name, run_ms):
+    """HBM bytes and vector-instruction issue of ONE kernel, counted now: three child passes (PMC_PASSES) over a script that launches it on
+    the bench shape; per-launch medians over the dispatches whose name contains `kernel_name`; FETCH_SIZE doubled per the gfx950
+    correction of the microarch guide.  Returns (traffic bytes, traffic detail, valu object) or (None, reason, None)."""
+    import statistics
+    med = {}
+    dur = None
+    try:
+        for counters in PMC_PASSES:
+            rows, _ = _pmc_pass(counters, script_args)
+            mine = [r for r in rows if kernel_name in r["Kernel_Name"]]
+            for c in counters:
+                vals = [float(r["Counter_Value"]) for r in mine if r["Counter_Name"] == c]
+                if not vals:
+                    raise RuntimeError("no %s rows for %s" % (c, kernel_name))
+                med[c] = statistics.median(vals)
+            if "GRBM_GUI_ACTIVE" in counters:
+                dur = statistics.median([(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-9 for r in mine if r["Counter_Name"] == "GRBM_GUI_ACTIVE"])
+    except Exception as ex:     # noqa: BLE001 -- the measurement is optional, the reason is reported
+        return None, str(ex), None
+    traffic = 2 * med["FETCH_SIZE"] * 1024 + med["WRITE_SIZE"] * 1024
+    valu = _valu_object(med["SQ_INSTS_VALU"], med["SQ_WAVES"], med["GRBM_GUI_ACTIVE"] / 8, dur, run_ms * 1e-3)
+    return traffic, {"FETCH_SIZE_KB": med["FETCH_SIZE"], "WRITE_SIZE_KB": med["WRITE_SIZE"]}, valu
+
+
+def measure_pipeline(script_args, run_ms_per_product):
+    """The same for a pipeline of launches (tools/dbg/mulrelin_pmc.py): every kernel summed (the runtime's own fill / copy kernels of
+    the set-up excluded) and divided by the products the script reports."""
+    tot = {}
+    dur = 0.0
+    products = None
+    try:
+        for counters in PMC_PASSES:
+            rows, stdout = _pmc_pass(counters, script_args)
+            marks = [ln for ln in stdout.splitlines() if ln.startswith("PRODUCTS")]
+            if not marks:
+                raise RuntimeError("the script did not report its product count")
+            products = int(marks[-1].split()[1])
+            mine = [r for r in rows if "rocclr" not in r["Kernel_Name"]]
+            for c in counters:
+                tot[c] = sum(float(r["Counter_Value"]) for r in mine if r["Counter_Name"] == c) / products
+            if "GRBM_GUI_ACTIVE" in counters:
+                dur = sum((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-9 for r in mine if r["Counter_Name"] == "GRBM_GUI_ACTIVE") / products
+    except Exception as ex:     # noqa: BLE001
+        return None, str(ex), None
+    traffic = 2 * tot["FETCH_SIZE"] * 1024 + tot["WRITE_SIZE"] * 1024
+    valu = _valu_object(tot["SQ_INSTS_VALU"], tot["SQ_WAVES"], tot["GRBM_GUI_ACTIVE"] / 8, dur, run_ms_per_product * 1e-3)
+    valu["per"] = "product"
+    return traffic, {"FETCH_SIZE_KB_per_product": tot["FETCH_SIZE"], "WRITE_SIZE_KB_per_product": tot["WRITE_SIZE"]}, valu
+
+
+def finish_roofline(r, traffic, detail, valu, how, algorithmic):
+    """fills traffic / traffic_source / valu of a roofline object and names the binding roof: whichever of the HBM fraction and the
+    vector-issue fraction (at the clock the chip sustained) is nearer 1"""
+    r["traffic"] = traffic
+    r["traffic_source"] = ({"how": how, **detail, "ratio_to_algorithmic": traffic / algorithmic} if traffic is not None
+                           else {"how": "not measured in this run: %s" % detail})
+    r["valu"] = valu
+    r["frac_is"] = "hbm: algorithmic bytes / duration / 8 TB/s"
+    if valu and valu.get("issue_frac_sustained") is not None:
+        r["bound"] = "valu" if valu["issue_frac_sustained"] > r["frac"] else "hbm"
+        r["bound_note"] = ("vector-instruction issue at the sustained clock is %.2f of its ceiling, HBM %.2f of 8 TB/s; every kernel of this path runs at the "
+                           "1.4 kW package power limit (clock %.0f MHz of 2400), see DESIGN.md 3.1" % (valu["issue_frac_sustained"], r["frac"], valu["sclk_MHz"] or 0))
 
 
 def _tool(name):
     return os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "dbg", name)
-
-
-def measure_hbm_traffic(kernel_name, logn):
-    """HBM bytes of one launch of the headline kernel, counted now: tools/dbg/pmc_run.py launches the same kernel on the same shape
-    under the profiler; per-launch median, FETCH_SIZE doubled per the gfx950 correction of the microarch guide.  Returns (bytes, detail)
-    or (None, reason): the line then carries null and points at the committed profile."""
-    import statistics
-
-    def pick(rows, _stdout):
-        vals = [float(r["Counter_Value"]) for r in rows if r["Kernel_Name"] == kernel_name]
-        return statistics.median(vals) if vals else None
-
-    kb, why = _pmc_passes([_tool("pmc_run.py"), str(logn)], pick)
-    if kb is None:
-        return None, why
-    return 2 * kb["FETCH_SIZE"] * 1024 + kb["WRITE_SIZE"] * 1024, {"FETCH_SIZE_KB": kb["FETCH_SIZE"], "WRITE_SIZE_KB": kb["WRITE_SIZE"]}
-
-
-def measure_mulrelin_traffic(name, batch, calls):
-    """HBM bytes per ciphertext product of the MulRelin pipeline: every kernel of tools/dbg/mulrelin_pmc.py summed (the runtime's own fill /
-    copy kernels of the set-up excluded) and divided by the products it executed."""
-    def pick(rows, stdout):
-        marks = [l for l in stdout.splitlines() if l.startswith("PRODUCTS")]
-        if not marks:
-            return None
-        return sum(float(r["Counter_Value"]) for r in rows if "rocclr" not in r["Kernel_Name"]) / int(marks[-1].split()[1])
-
-    kb, why = _pmc_passes([_tool("mulrelin_pmc.py"), name, str(batch), str(calls)], pick)
-    if kb is None:
-        return None, why
-    return 2 * kb["FETCH_SIZE"] * 1024 + kb["WRITE_SIZE"] * 1024, {"FETCH_SIZE_KB_per_product": kb["FETCH_SIZE"], "WRITE_SIZE_KB_per_product": kb["WRITE_SIZE"]}
 
 
 def progress(msg):
@@ -351,6 +406,7 @@ def main():
     ap.add_argument("--rings-bytes", type=int, default=1 << 30, help="bytes per operand of the R13..R16 table")
     ap.add_argument("--no-extras", action="store_true", help="skip the InvNTT / MulCoeffsMontgomery / ModUp timings")
     ap.add_argument("--no-ckks", action="store_true", help="skip the CKKS MulRelin / BFV Mul legs")
+    ap.add_argument("--no-threads", action="store_true", help="skip the evaluator-per-host-thread MulRelin leg (T = 1, 4, 16 threads, batch 1 each)")
     ap.add_argument("--no-config5", action="store_true", help="skip the PN16QP1761 sharded MulRelin + gather leg")
     ap.add_argument("--ckks-batch", type=int, default=128)
     ap.add_argument("--config5-units", type=int, default=128, help="PN16QP1761 ciphertext products per GPU")
@@ -895,6 +951,63 @@ def main():
             out["bfv_mul"]["cpu_baseline"] = cpu_baseline(mk_bfv, 1, "Mul/s", "oracle bfv Mul PN14QP438", 3.0)
         del bplan, b0, b1, bo
 
+    if rank == 0 and world == 1 and not args.no_ckks and not args.no_threads:
+        # The reference's concurrency model (examples/dbfv/psi/psi.go:215-233): one evaluator per goroutine, one ciphertext each.  Here: T
+        # host threads, each with its OWN contexts, plan, operands and stream (a context carries its stream, so per-thread streams mean
+        # per-thread contexts; the evaluation key is uploaded once per thread like every evaluator holds its own reference), batch 1
+        # PN15QP880 MulRelin in a loop, no synchronisation inside the loop.  ctypes releases the GIL during a call, so the threads'
+        # launches really overlap on the host.  Aggregate products per second beside the batch-128 figure of one call.
+        import threading
+        tN, tQ, tP = params.ckks_moduli("PN15QP880")
+        tnq, tnp = len(tQ), len(tP)
+        tlevel, tbeta = tnq - 1, -(-tnq // tnp)
+        tkey_h = sampling.uniform_poly(tQ + tP, tN, 2 * tbeta, seed=9)
+        tops = [sampling.uniform_poly(tQ, tN, 1, seed=60 + k) for k in range(4)]
+        rows = []
+        want_t = None
+        for T in (1, 4, 16):
+            workers = []
+            for i in range(T):
+                st_i = torch.cuda.Stream()
+                wq, wp = ring.NewContextWithParams(tN, tQ, device=local), ring.NewContextWithParams(tN, tP, device=local)
+                wq.SetStream(st_i.cuda_stream)
+                wp.SetStream(st_i.cuda_stream)
+                wplan = ring.CkksPlan(wq, wp, 1)
+                wkey = wplan.NewSwitchingKey().set(tkey_h)
+                wc0 = (wq.NewPoly(1).set(tops[0]), wq.NewPoly(1).set(tops[1]))
+                wc1 = (wq.NewPoly(1).set(tops[2]), wq.NewPoly(1).set(tops[3]))
+                wout = (wq.NewPoly(1), wq.NewPoly(1))
+                wplan.MulRelin(tlevel, wc0, wc1, wkey, wout)          # warm-up: pools and scratch exist before the loop
+                wq.Sync()
+                workers.append((st_i, wq, wp, wplan, wkey, wc0, wc1, wout))
+            iters = 200 if T == 1 else 100
+            gate = threading.Barrier(T + 1)
+
+            def loop(w):
+                _, wq, _, wplan, wkey, wc0, wc1, wout = w
+                gate.wait()
+                for _ in range(iters):
+                    wplan.MulRelin(tlevel, wc0, wc1, wkey, wout)
+                wq.Sync()
+            ths = [threading.Thread(target=loop, args=(w,)) for w in workers]
+            for th in ths:
+                th.start()
+            gate.wait()
+            t_w = time.perf_counter()
+            for th in ths:
+                th.join()
+            dt_w = time.perf_counter() - t_w
+            if want_t is None:
+                want_t = oracle.CkksPlan(oracle.Context(tN, tQ), oracle.Context(tN, tP)).mulrelin(
+                    tlevel, np.stack([tops[0][0], tops[1][0]]), np.stack([tops[2][0], tops[3][0]]), tkey_h.reshape(tbeta, 2, tnq + tnp, tN))
+            ok_t = all(np.array_equal(w[7][0].get().reshape(tnq, tN), want_t[0]) and np.array_equal(w[7][1].get().reshape(tnq, tN), want_t[1]) for w in workers)
+            rows.append({"threads": T, "streams": T, "batch_per_call": 1, "calls_per_thread": iters, "mulrelin_per_s": T * iters / dt_w,
+                         "us_per_product_per_thread": dt_w / iters * 1e6, "bit_exact": bool(ok_t)})
+            del workers, ths
+        out["evaluator_threads"] = {"params": "PN15QP880, level 17, batch 1 per call, one plan + contexts + stream per host thread", "rows": rows,
+                                    "reference_model": "one evaluator per goroutine (examples/dbfv/psi/psi.go:215-233)"}
+        progress("evaluator-per-thread MulRelin: " + ", ".join("T=%d %.0f/s" % (r["threads"], r["mulrelin_per_s"]) for r in rows))
+
     if not args.no_extras and rank == 0:
         # the other kernels BASELINE.json's north_star asks throughput for, same ring, same resident batch; after timing,
         # the last poly of every output is compared with the oracle
@@ -904,9 +1017,15 @@ def main():
         x_last = base[last % base.shape[0]]
         timed = lambda fn: timed_on(ctx, fn, reps)
 
+        def leg_roofline(nbytes, ms, kernel):
+            ach = nbytes / (ms * 1e-3) / 1e9
+            return {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                    "kernel": kernel, "kernel_ms": ms, "algorithmic_bytes_per_launch": nbytes}
+
         ms = timed(lambda: ctx.InvNTT(src, dst))
         extras["intt"] = {"limb_ntt_per_s": my_polys * L / (ms * 1e-3), "ms": ms, "kernel": ctx.last_ntt_kernel(),
                           "frac_hbm": ntt_bytes(N, L, my_polys) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                          "roofline": leg_roofline(ntt_bytes(N, L, my_polys), ms, ctx.last_ntt_kernel()),
                           "bit_exact": bool(np.array_equal(dst.get().reshape(my_polys, L, N)[last], oc.intt(x_last)))}
         ctx.Copy(src, dst)
         ms = timed(lambda: ctx.MulCoeffsMontgomery(src, dst, dst))
@@ -923,6 +1042,27 @@ def main():
                 lib = oracle.lib()
                 return lambda: lib.oc_ewise(oc.h, oracle.OP["MUL_MONT"], L - 1, a.ctypes.data, b.ctypes.data, o.ctypes.data, None)
             extras["mulcoeffs_montgomery"]["cpu_baseline"] = cpu_baseline(mk_mul, 1, "poly/s", "oracle MulCoeffsMontgomery R15", 2.0)
+        # Context.DivRoundByLastModulusNTT (ring/ring_scaling.go:72; the reference benches it at ring/ring_benchmark_test.go:349-404):
+        # in place, drops the last limb; the limb count goes back up before every call (values differ from call to call, the checked
+        # call starts from src)
+        def rescale_once():
+            nat.check(nat.lib().lr_poly_set_limbs(dst.h, L))
+            ctx.DivRoundByLastModulusNTT(dst)
+        ctx.Copy(src, dst)
+        ms = timed(rescale_once)
+        ctx.Copy(src, dst)
+        rescale_once()
+        got_rs = dst.get_limb_slices(last)[:L - 1]
+        nat.check(nat.lib().lr_poly_set_limbs(dst.h, L))
+        extras["div_round_by_last_modulus_ntt"] = {
+            "poly_per_s": my_polys / (ms * 1e-3), "ms": ms, "frac_hbm": 8 * N * (2 * L - 1) * my_polys / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "algorithmic_bytes_per_poly": 8 * N * (2 * L - 1),
+            "bit_exact": bool(np.array_equal(np.stack(got_rs), oc.rescale_op("oc_div_round_by_last_modulus_ntt", x_last)))}
+        if want_cpu:
+            def mk_rescale(i):
+                xi = x_last.copy()
+                return lambda: oc.rescale_op("oc_div_round_by_last_modulus_ntt", xi)
+            extras["div_round_by_last_modulus_ntt"]["cpu_baseline"] = cpu_baseline(mk_rescale, 1, "poly/s", "oracle DivRoundByLastModulusNTT R15", 2.0)
         _, pmod = params.DefaultParamsPi(args.logn)
         ctxP = ring.NewContextWithParams(N, pmod, device=local)
         bext = ring.NewFastBasisExtender(ctx, ctxP)
@@ -933,6 +1073,7 @@ def main():
                                     "frac_hbm": 8 * N * (L + len(pmod)) * my_polys / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                     "note": "%d -> %d limbs, %d modular multiplies per coefficient (compute-bound)" %
                                             (L, len(pmod), L + L * len(pmod)),
+                                    "roofline": leg_roofline(8 * N * (L + len(pmod)) * my_polys, ms, "ext_wide_kernel / ext_sum_kernel (lr_bext.hip)"),
                                     "bit_exact": bool(np.array_equal(outP.get().reshape(my_polys, len(pmod), N)[last], obe.modup_split_qp(L - 1, x_last)))}
         if want_cpu:
             def mk_modup(i):
@@ -955,6 +1096,7 @@ def main():
                                                  "frac_hbm": ntt_bytes(N, L, my_polys) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                                  "moduli_bits": [int(q).bit_length() for q in cq],
                                                  "asm_variants": list(ctxC.ntt_variants()), "kernel": ctxC.last_ntt_kernel(),
+                                                 "roofline": leg_roofline(ntt_bytes(N, L, my_polys), ms, ctxC.last_ntt_kernel()),
                                                  "bit_exact": bool(np.array_equal(cdst.get().reshape(my_polys, L, N)[last], ofn(cb[last % cb.shape[0]])))}
             del csrc, cdst, ctxC
         out["extras"] = extras
@@ -983,30 +1125,34 @@ def main():
         progress("config 5 leg done")
 
     if rank == 0 and world == 1 and not use_dist and not args.no_traffic and B == (1 << 30) // (8 * N * L):
-        progress("HBM traffic of one %s launch: two rocprofv3 --pmc child runs" % kernel_name)
-        traffic, detail = measure_hbm_traffic(kernel_name, args.logn)
-        out["roofline"]["traffic"] = traffic
-        out["roofline"]["traffic_source"] = ({"how": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate child passes over tools/dbg/pmc_run.py in this run; "
-                                                     "2 x FETCH_SIZE + WRITE_SIZE (KB) per launch, median", **detail,
-                                              "ratio_to_algorithmic": traffic / ntt_bytes(N, L, my_polys)} if traffic is not None
-                                             else {"how": "not measured in this run: %s" % detail})
-        progress("traffic: %s" % (("%.4f x algorithmic" % (traffic / ntt_bytes(N, L, my_polys))) if traffic is not None else detail))
-        if "ckks_mulrelin" in out and "roofline" in out["ckks_mulrelin"]:
-            mt, md = measure_mulrelin_traffic("PN15QP880", 64, 4)
-            mr = out["ckks_mulrelin"]["roofline"]
-            mr["traffic"] = mt
-            mr["traffic_source"] = ({"how": "rocprofv3 --pmc child passes over tools/dbg/mulrelin_pmc.py PN15QP880 64 4 in this run, all kernels summed, per product",
-                                     **md, "ratio_to_algorithmic": mt / mr["algorithmic_bytes_per_product"]} if mt is not None
-                                    else {"how": "not measured in this run: %s" % md})
-            progress("MulRelin traffic: %s" % (("%.1f MB per product = %.3f x algorithmic" % (mt / 1e6, mt / mr["algorithmic_bytes_per_product"])) if mt is not None else md))
-        if isinstance(out.get("config5"), dict) and "roofline" in out["config5"]:
-            mt, md = measure_mulrelin_traffic("PN16QP1761", 32, 2)
-            mr = out["config5"]["roofline"]
-            mr["traffic"] = mt
-            mr["traffic_source"] = ({"how": "rocprofv3 --pmc child passes over tools/dbg/mulrelin_pmc.py PN16QP1761 32 2 in this run, all kernels summed, per product",
-                                     **md, "ratio_to_algorithmic": mt / mr["algorithmic_bytes_per_product"]} if mt is not None
-                                    else {"how": "not measured in this run: %s" % md})
-            progress("config-5 MulRelin traffic: %s" % (("%.2f GB per product = %.3f x algorithmic" % (mt / 1e9, mt / mr["algorithmic_bytes_per_product"])) if mt is not None else md))
+        # counters need their own rocprofv3 passes: three child runs per kernel / pipeline (FETCH_SIZE, WRITE_SIZE, and the vector-issue
+        # set SQ_INSTS_VALU + SQ_WAVES + GRBM_GUI_ACTIVE) on the same shapes, after all timing
+        progress("counters of one %s launch: three rocprofv3 --pmc child runs" % kernel_name)
+        how = "rocprofv3 --pmc child passes over tools/dbg/%s in this run; 2 x FETCH_SIZE + WRITE_SIZE (KB) per launch, median"
+        traffic, detail, valu = measure_kernel([_tool("pmc_run.py"), str(args.logn), "qi60", "ntt"], kernel_name, kernel_ms)
+        finish_roofline(out["roofline"], traffic, detail, valu, how % ("pmc_run.py %d qi60 ntt" % args.logn), ntt_bytes(N, L, my_polys))
+        progress("traffic: %s" % (("%.4f x algorithmic, vector issue %.2f of its ceiling at %.0f MHz" % (
+            traffic / ntt_bytes(N, L, my_polys), valu["issue_frac_sustained"], valu["sclk_MHz"])) if traffic is not None else detail))
+        ex = out.get("extras", {})
+        for key, op, match in (("intt", "intt", None), ("modup_split_qp", "modup", "ext_")):
+            if key in ex and "roofline" in ex[key]:
+                r = ex[key]["roofline"]
+                t, d, v = measure_kernel([_tool("pmc_run.py"), str(args.logn), "qi60", op], match or r["kernel"], r["kernel_ms"])
+                finish_roofline(r, t, d, v, how % ("pmc_run.py %d qi60 %s" % (args.logn, op)), r["algorithmic_bytes_per_launch"])
+        for key, op in (("ntt_ckks_moduli", "ntt"), ("intt_ckks_moduli", "intt")):
+            if key in ex and "roofline" in ex[key]:
+                r = ex[key]["roofline"]
+                t, d, v = measure_kernel([_tool("pmc_run.py"), str(args.logn), "ckks", op], r["kernel"], r["kernel_ms"])
+                finish_roofline(r, t, d, v, how % ("pmc_run.py %d ckks %s" % (args.logn, op)), r["algorithmic_bytes_per_launch"])
+        progress("counters of InvNTT / ModUpSplitQP / the CKKS-moduli transforms collected")
+        for key, pname, pb, pk in (("ckks_mulrelin", "PN15QP880", 64, 4), ("config5", "PN16QP1761", 32, 2)):
+            if isinstance(out.get(key), dict) and "roofline" in out[key]:
+                mr = out[key]["roofline"]
+                per_product_ms = mr["pipeline_ms"] / (out[key].get("batch") or out[key].get("units_per_gpu") or 1)
+                mt, md, mv = measure_pipeline([_tool("mulrelin_pmc.py"), pname, str(pb), str(pk)], per_product_ms)
+                finish_roofline(mr, mt, md, mv, "rocprofv3 --pmc child passes over tools/dbg/mulrelin_pmc.py %s %d %d in this run, all kernels summed, per product" % (pname, pb, pk),
+                                mr["algorithmic_bytes_per_product"])
+                progress("%s traffic: %s" % (pname, ("%.1f MB per product = %.3f x algorithmic" % (mt / 1e6, mt / mr["algorithmic_bytes_per_product"])) if mt is not None else md))
 
     if want_cpu:
         def mk_ntt(i):

@@ -75,10 +75,17 @@ int lr_context_destroy(lr_context *ctx);
 /* diagnostics: the assembly NTT variant the context's moduli select (forward, inverse): 0..2 = integer lazy-correction modes,
  * 3 = dual kernels (FP64 butterflies for the limbs below 2^46, integer body for the others), -1 = C++ kernels only */
 int lr_context_ntt_variants(const lr_context *ctx, int *forward, int *inverse);
-/* use an externally owned hipStream_t (e.g. torch's current stream); NULL = the device's shared stream.  A stream belongs to a
- * CONTEXT; polys, extenders, decomposers and plans run on the stream their contexts have at call time.  Handles built over two
- * contexts (lr_bext, lr_ckks_plan, lr_bfv_plan) interleave launches of both: set the same stream on both contexts, or the
- * pipeline entry points return LR_ERR_ARG.  Change streams only between calls (after lr_context_sync). */
+/* use an externally owned hipStream_t; NULL = the library's own stream of that device (a non-blocking stream every context of the
+ * device shares by default).  NULL does NOT mean HIP's legacy default stream: handle 0 cannot be expressed here, and the library's
+ * stream does not synchronise with the legacy stream -- a caller whose other work (e.g. a framework's collectives) is ordered on
+ * its "current" stream must create an explicit stream, make it current and pass its handle (bench.py's config-5 leg).
+ * A stream belongs to a CONTEXT; polys, extenders, decomposers and plans run on the stream their contexts have at call time.
+ * Handles built over two contexts (lr_bext, lr_ckks_plan, lr_bfv_plan) interleave launches of both: set the same stream on both
+ * contexts, or the pipeline entry points return LR_ERR_ARG.  Switching is ordered on the device: the new stream waits for an
+ * event recorded on the old one (work already enqueued, and the scratch later calls reuse, stay in order); change streams between
+ * calls, not while another thread is inside a call on this context.
+ * HIP graphs: a pipeline call captured after one warm-up call bakes the addresses of the context's pooled scratch into the graph;
+ * the pool never frees a buffer while the context lives, so replays stay valid until lr_context_destroy. */
 int lr_context_set_stream(lr_context *ctx, void *hip_stream);
 /* diagnostics: name of the kernel the last NTT / InvNTT launch of this context dispatched, e.g. "lr_ntt_fwd15_m1" (assembly
  * code object) or "ntt_fwd_kernel<15>" (C++ kernel); bench.py reports it next to the roofline figures */

@@ -111,14 +111,9 @@ struct ScratchPool {
                 free_list.erase(free_list.begin() + (long)best);
                 return LR_OK;
             }
-            // nothing fits: drop the largest idle buffer (hipFree waits for the device) so repeated growth does not pile up
-            if (!free_list.empty()) {
-                size_t big = 0;
-                for (size_t i = 1; i < free_list.size(); ++i)
-                    if (free_list[i].words > free_list[big].words) big = i;
-                (void)hipFree(free_list[big].d);
-                free_list.erase(free_list.begin() + (long)big);
-            }
+            // nothing fits: the pool grows by one buffer.  Idle buffers are NOT freed while the context lives: their addresses may be
+            // baked into a captured HIP graph (the pair-flag memset node and the temporaries of a captured pipeline call), and work
+            // enqueued on a stream the caller installed later may still use them; everything goes in the destructor.
         }
         LR_HIP(hipMalloc((void **)&out->d, words * sizeof(u64)));
         out->words = words;
@@ -222,7 +217,7 @@ struct DevModup {
         *qispj = nullptr, *qpj_inv = nullptr;
     ulonglong2 *qispj_shoup = nullptr;
     double *Qrcp = nullptr;
-    int lazy_terms = 0, exact_terms = 0, word_barrett = 0, wide_ok = 0;
+    int lazy_terms = 0, exact_terms = 0, word_barrett = 0, wide_ok = 0, fast_div_ok = 1;
     int init(const std::vector<u64> &Qv, const std::vector<u64> &Pv, bool ext_narrow) {
         h = build_modup(Qv, Pv);
         std::vector<u64> bh(h.P.size());
@@ -248,7 +243,18 @@ struct DevModup {
         {
             // correctly rounded reciprocals of the moduli as the reference's float64(q_i) sees them (div_by_const, lr_bext.hip)
             std::vector<double> rc(nQ);
-            for (size_t i = 0; i < nQ; ++i) rc[i] = 1.0 / (double)h.Q[i];
+            for (size_t i = 0; i < nQ; ++i) {
+                const double b = (double)h.Q[i];
+                rc[i] = 1.0 / b;
+                // Markstein's final-rounding step (div_by_const) is proven for divisors whose significand is not all ones; the
+                // quotients stay far from the overflow and subnormal ranges for every 2 <= b < 2^64.  A modulus that fails the check
+                // (none of the reference's parameter sets does) keeps the plain IEEE division of the reference-shaped kernel.
+                u64 bits;
+                std::memcpy(&bits, &b, sizeof bits);
+                const u64 frac = bits & (((u64)1 << 52) - 1);
+                if (h.Q[i] < 2 || frac == (((u64)1 << 52) - 1)) fast_div_ok = 0;
+            }
+            if (std::getenv("LR_EXT_IEEE_DIV")) fast_div_ok = 0;       // testing aid: force the fallback
             LR_TRY(to_device(&Qrcp, rc.data(), rc.size()));
         }
         const u128 room = ((u128)1 << 64) - pmax;
@@ -272,6 +278,7 @@ struct DevModup {
         t.qispj_mont = qispj; t.qpj_inv = qpj_inv;
         t.qispj_shoup = qispj_shoup;
         t.Qrcp = Qrcp;
+        t.fast_div_ok = fast_div_ok;
         t.lazy_terms = lazy_terms;
         t.exact_terms = exact_terms;
         t.word_barrett = word_barrett;
@@ -560,7 +567,19 @@ extern "C" int lr_context_destroy(lr_context *c) {
 extern "C" int lr_context_set_stream(lr_context *c, void *hip_stream) {
     return guarded([&]() -> int {
     if (!c) return fail(LR_ERR_ARG, "null context");
-    c->stream = hip_stream ? (hipStream_t)hip_stream : shared_stream(c->device);
+    LR_HIP(hipSetDevice(c->device));
+    hipStream_t next = hip_stream ? (hipStream_t)hip_stream : shared_stream(c->device);
+    if (next != c->stream) {
+        // work already enqueued through this context (and the scratch it leased, which later calls reuse) is ordered before
+        // whatever follows on the new stream: an event on the old stream that the new one waits for -- no host synchronisation
+        hipEvent_t ev = nullptr;
+        LR_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        hipError_t e1 = hipEventRecord(ev, c->stream);
+        hipError_t e2 = e1 == hipSuccess ? hipStreamWaitEvent(next, ev, 0) : e1;
+        (void)hipEventDestroy(ev);
+        if (e2 != hipSuccess) return fail(LR_ERR_HIP, std::string("set_stream: ") + hipGetErrorString(e2));
+        c->stream = next;
+    }
     return LR_OK;
     });
 }

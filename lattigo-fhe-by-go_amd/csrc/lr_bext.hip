@@ -16,7 +16,9 @@ namespace lr {
 // a / b, correctly rounded, for a divisor that is a table constant: r = RN(1 / b) comes from the host.  q0 = RN(a r) is within
 // two ulps of a / b; one residual step makes it faithful; a second one, on a faithful quotient with the exactly representable
 // residual a - b q1, rounds to RN(a / b) (Markstein 1990; Muller et al., Handbook of Floating-Point Arithmetic, 4.7).  No scaling
-// or fix-up is needed: 0 <= a < 2^64 and 2^29 < b < 2^62 keep every intermediate far from the overflow and subnormal ranges.
+// or fix-up is needed: 0 <= a < 2^64 and 2 <= b < 2^64 keep every intermediate far from the overflow and subnormal ranges.  The
+// theorem's precondition on the divisor -- its significand is not all ones -- is checked on the host for every modulus of a table
+// (ExtTables::fast_div_ok, DevModup::init); a table that fails it runs on the reference-shaped kernel and its plain division.
 // Five full-rate instructions instead of the eleven of the generic IEEE expansion (v_div_scale x2, v_rcp, four Newton FMAs, multiply,
 // residual, v_div_fmas, v_div_fixup), bit for bit the same quotient (lr_selftest_division compares the two on the device).
 __device__ __forceinline__ double div_by_const(double a, double b, double r) {
@@ -427,7 +429,7 @@ __global__ __launch_bounds__(256) void ext_wide_kernel(ExtLaunch L) {
 template <int NIN>
 static hipError_t launch_n(const ExtLaunch &L, int batch, hipStream_t stream) {
     (void)hipGetLastError();  // drop stale (non-sticky) errors of unrelated earlier calls
-    if ((L.n & 1) == 0 && L.t.exact_terms >= 4) {   // exact_terms >= 4 <=> every p < 2^61
+    if ((L.n & 1) == 0 && L.t.exact_terms >= 4 && L.t.fast_div_ok) {   // exact_terms >= 4 <=> every p < 2^61
         // two coefficients per thread while their y_i fit comfortably in registers
         constexpr int W = NIN <= 20 ? 2 : 1;
         const dim3 grid((unsigned)((L.n / W + 255) / 256), (unsigned)batch), block(256);
@@ -460,12 +462,12 @@ static hipError_t launch_n(const ExtLaunch &L, int batch, hipStream_t stream) {
 
 // the top-stage variant exists for the sum-form kernel with at most eight input limbs (the key-switch digits have alpha <= 8)
 bool ext_top_supported(const ExtTables &t, int n_in, int n) {
-    return (n & 3) == 0 && n_in >= 1 && n_in <= 8 && t.exact_terms >= 4 && t.word_barrett && t.lazy_terms >= (n_in < 2 ? 2 : n_in);
+    return (n & 3) == 0 && n_in >= 1 && n_in <= 8 && t.exact_terms >= 4 && t.fast_div_ok && t.word_barrett && t.lazy_terms >= (n_in < 2 ? 2 : n_in);
 }
 
 // ExtSegment::epi_mode is implemented by the sum-form and the 128-bit-sum kernels: does launch_n pick one of them for this shape?
 bool ext_epilogue_supported(const ExtTables &t, int n_in, int n) {
-    if ((n & 1) != 0 || t.exact_terms < 4) return false;
+    if ((n & 1) != 0 || t.exact_terms < 4 || !t.fast_div_ok) return false;
     if (t.lazy_terms >= (n_in < 2 ? 2 : n_in) && t.word_barrett) return true;
     if (t.lazy_terms >= n_in) return false;
     return t.wide_ok >= n_in || (t.wide_ok >= 16 && n_in > 16) || (t.wide_ok >= 8 && n_in > 8);

@@ -232,6 +232,8 @@ struct ExtTables {        // device pointers; modupParams of ring_basis_extensio
     // products y_i * c accumulate lazily and are reduced once, to the same canonical residue
     const ulonglong2 *qispj_shoup;  // [nQ][nP] {c, companion}
     const double *Qrcp;   // [nQ] RN(1 / float64(q_i)): div_by_const
+    int fast_div_ok;      // every float64(q_i) satisfies div_by_const's precondition (significand not all ones, q_i >= 2): checked on the
+                          // host at creation; 0 sends every extension of this table through the reference-shaped kernel and its IEEE division
     int lazy_terms;       // how many [0,4p) terms, each with one p of the correction v * qpjInv[1], fit in 64 bits
     int exact_terms;      // the same for [0,2p) terms
     int word_barrett;     // every p_j > 2^32: floor(2^64 / p_j) fits one word (ext_sum_kernel's final reduction)

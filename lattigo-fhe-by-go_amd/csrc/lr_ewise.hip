@@ -457,9 +457,10 @@ __global__ __launch_bounds__(256) void keymac_kernel(KeyMacLaunch L) {
 //   lo += k0 c0 (carry-out counted), mid += k0 c1 + k1 c0 (folded every four digits: eight products below 2^61), hi += k1 c1
 // -- five multiply-adds and a carry add per product instead of the ~25 instructions of a Montgomery product: at beta = 9 the
 // per-term kernel was bound by its arithmetic (1.1 ms of VALU issue in a 1.85 ms launch), not by the 7 GB it moves.
-// Needs every key value below q < 2^61 and beta * q < 2^64 (KeyMacLaunch::wide, set by the host); the digit values may be any
-// 64-bit word in at most one term (the digit's own limbs come from the caller): the reduction is a congruence for any 128-bit sum,
-// and the final BRedAdd takes the whole 64-bit range.
+// Needs every key value below q < 2^61 and beta * q < 2^64 (KeyMacLaunch::wide, set by the host) and digit values below q, which the
+// transforms that produce the digits guarantee.  The digit's OWN limbs come straight from the caller (any 64-bit word is allowed
+// there, like everywhere a poly enters the library): they are reduced with BRedAdd first (own_operand) -- the middle column is a
+// 64-bit accumulator without a carry-out, eight products below 2^61 fit it, a product with a 32-bit high word would not.
 __device__ __forceinline__ void mac128(u64 k, u64 c, u64 &lo, u64 &mid, u64 &hi, u32 &cy) {
     const u32 k0 = (u32)k, k1 = (u32)(k >> 32), c0 = (u32)c, c1 = (u32)(c >> 32);
     asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc" : "+v"(lo), "+v"(cy) : "v"(k0), "v"(c0) : "vcc");
@@ -478,6 +479,10 @@ __device__ __forceinline__ u64 reduce128(u64 lo, u64 hi, u32 cy, const LimbParam
     const u64 th = hi + cy;                                        // the sum is th * 2^64 + lo
     const u64 H = mul_hi64(lo * lp.qinv, lp.q);                   // Montgomery reduction of the 128-bit sum
     return bred_add(th - H + lp.q, lp.q, lp.bred_hi);
+}
+
+__device__ __forceinline__ ulonglong2 own_operand(ulonglong2 c, const LimbParams &lp) {
+    return make_ulonglong2(bred_add(c.x, lp.q, lp.bred_hi), bred_add(c.y, lp.q, lp.bred_hi));
 }
 
 template <int BETA>
@@ -518,6 +523,7 @@ __global__ __launch_bounds__(256) void keymac_wide_kernel(KeyMacLaunch L) {
                 for (int u = 0; u < G; ++u) {
                     const int i = g0 + u;
                     if (i < BETA) {
+                        if (i == own_digit) c[u] = own_operand(c[u], lp);      // (workgroup-uniform: the limb decides)
                         mac128(k0[u].x, c[u].x, lo[0], mid[0], hi[0], cy[0]);
                         mac128(k0[u].y, c[u].y, lo[1], mid[1], hi[1], cy[1]);
                         mac128(k1[u].x, c[u].x, lo[2], mid[2], hi[2], cy[2]);
@@ -532,7 +538,8 @@ __global__ __launch_bounds__(256) void keymac_wide_kernel(KeyMacLaunch L) {
             }
         } else {
             for (int i = 0; i < beta; ++i) {
-                const ulonglong2 c = ld_stream(i == own_digit ? pown + e : pc + e + i * cd);
+                ulonglong2 c = ld_stream(i == own_digit ? pown + e : pc + e + i * cd);
+                if (i == own_digit) c = own_operand(c, lp);
                 const ulonglong2 k0 = pk[e + (2 * i) * kd], k1 = pk[e + (2 * i + 1) * kd];
                 mac128(k0.x, c.x, lo[0], mid[0], hi[0], cy[0]);
                 mac128(k0.y, c.y, lo[1], mid[1], hi[1], cy[1]);

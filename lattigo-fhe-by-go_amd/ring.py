@@ -198,7 +198,16 @@ class Context:
         check(lib().lr_context_sync(self.h))
 
     def SetStream(self, stream_ptr):
-        check(lib().lr_context_set_stream(self.h, C.c_void_p(stream_ptr)))
+        """an externally owned hipStream_t handle, or None for the library's own stream.  Handle 0 is HIP's legacy default stream,
+        which the C ABI cannot express (NULL there selects the library's stream, and that one does not synchronise with the legacy
+        stream): it is refused here instead of silently running somewhere else than the caller thinks."""
+        if stream_ptr is None:
+            check(lib().lr_context_set_stream(self.h, C.c_void_p(None)))
+            return
+        if int(stream_ptr) == 0:
+            raise LatticeRingError(1, "SetStream(0): the legacy default stream cannot be selected; create an explicit stream "
+                                      "(torch.cuda.Stream()) and pass its handle, or None for the library's own stream")
+        check(lib().lr_context_set_stream(self.h, C.c_void_p(int(stream_ptr))))
 
     # --- allocation (ring/ring_context.go:288,300) -------------------------------------------
     def NewPoly(self, batch=1):

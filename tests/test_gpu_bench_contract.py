@@ -30,7 +30,7 @@ def test_one_json_line_with_roofline_and_cpu_baseline():
     units = d["config"]["polys_per_gpu"] * d["config"]["limbs"]
     assert abs(d["value"] - units / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
     r = d["roofline"]
-    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert r["bound"] in ("hbm", "valu") and r["unit"] == "GB/s" and r["peak"] == 8000.0
     assert r["kernel"] == "lr_ntt_fwd15_m1"
     # HBM bytes of one launch, counted in this run by rocprofv3 --pmc child passes (null only if the profiler could not run)
     assert r["traffic"] is not None, r.get("traffic_source")
@@ -41,3 +41,43 @@ def test_one_json_line_with_roofline_and_cpu_baseline():
     assert 0.2 < r["frac"] < 1.0 and r["kernel_ms"] <= d["ms_per_step"] * 1.05
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["unit"] == d["unit"] and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
+    # the other roof, counted in the same run: vector instructions per wave (the generator's static count), waves of the launch, issue
+    # fraction at the nominal clock and at the clock the profiled pass sustained
+    v = r["valu"]
+    for key in ("instr_per_wave", "waves", "issue_frac_nominal", "issue_frac_sustained", "sclk_MHz"):
+        assert v[key] is not None and v[key] > 0, key
+    assert v["waves"] == units * 16 and 4300 < v["instr_per_wave"] < 4450
+    assert 0.4 < v["issue_frac_nominal"] < 1.0 and v["issue_frac_nominal"] <= v["issue_frac_sustained"] * 1.02 and 1000 < v["sclk_MHz"] <= 2500
+    assert r["bound"] == ("valu" if v["issue_frac_sustained"] > r["frac"] else "hbm")
+
+
+def test_secondary_legs_carry_their_roofs_and_the_rescale_leg():
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "5", "--warmup", "2", "--no-config5", "--no-rings", "--no-ckks", "--no-cpu-baseline"]
+    res = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    d = json.loads([l for l in res.stdout.splitlines() if l.strip()][-1])
+    ex = d["extras"]
+    for key in ("intt", "modup_split_qp", "ntt_ckks_moduli", "intt_ckks_moduli"):
+        r = ex[key]["roofline"]
+        assert ex[key]["bit_exact"] is True
+        assert r["traffic"] is not None and r["valu"]["issue_frac_sustained"] > 0 and r["bound"] in ("hbm", "valu"), (key, r.get("traffic_source"))
+        assert 0.9 < r["traffic"] / r["algorithmic_bytes_per_launch"] < 1.2
+    rs = ex["div_round_by_last_modulus_ntt"]
+    assert rs["bit_exact"] is True and rs["poly_per_s"] > 0 and rs["algorithmic_bytes_per_poly"] == 8 * d["config"]["N"] * (2 * d["config"]["limbs"] - 1)
+
+
+def test_config5_leg_under_rccl_is_ordered():
+    """The config-5 leg on a real RCCL communicator (world size 1: LR_BENCH_FORCE_DIST=1): products and the chunked gather on one
+    explicit stream; the leg poisons its outputs and the root buffer before the step it checks, so a gather that ran ahead of the
+    kernels would be caught."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "ckks16", "--steps", "2", "--warmup", "1", "--config5-units", "8", "--config5-chunk", "4",
+           "--no-cpu-baseline", "--no-traffic"]
+    env = dict(os.environ, LR_BENCH_FORCE_DIST="1", MASTER_PORT="29577")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR"):
+        env.pop(k, None)
+    res = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
+    assert res.returncode == 0, res.stderr[-3000:]
+    d = json.loads([l for l in res.stdout.splitlines() if l.strip()][-1])
+    c5 = d["config5"]
+    assert c5["bit_exact"] is True and c5["checked_units"] == [0, 7] and "poisoned" in c5["checked_after"]
+    assert "RCCL" in c5["gather"] and "chunks of 4" in c5["gather"] and "explicit torch stream" in c5["stream"]

@@ -351,3 +351,35 @@ def test_switch_keys_accepts_non_canonical_own_limbs(gpu_pkg, oracle):
     for b in range(2):
         w0, w1 = oplan.switch_keys(level, cx[b], evk)
         assert np.array_equal(p0.get()[b], w0) and np.array_equal(p1.get()[b], w1)
+
+
+def test_key_inner_product_wide_and_per_term_agree_on_lazy_own_limbs(gpu_pkg, monkeypatch):
+    """60-bit moduli, beta = 4 digits, own limbs anywhere below 4q (the InvNTT's input range): the 128-bit-sum inner product reduces a
+    digit's own operand before it enters the carry-less middle column (lr_ewise.hip: own_operand), so it agrees with the per-term
+    kernel (LR_KEYMAC_NARROW) wherever the caller's values lie"""
+    ring, params, sampling = gpu_pkg.ring, gpu_pkg.params, gpu_pkg.sampling
+    N = 1 << 12
+    Q, P = list(params.Qi60()[:8]), list(params.Pi60()[:2])
+    level, beta = 7, 4
+    evk = sampling.uniform_poly(Q + P, N, 2 * beta, seed=77)
+    cx = sampling.uniform_poly(Q, N, 2, seed=78)
+    rng = np.random.default_rng(3)
+    for i, q in enumerate(Q):
+        k = rng.integers(0, 4, size=(2, N), dtype=np.uint64)
+        cx[:, i, :] += k * np.uint64(q)                     # anywhere in [0, 4q)
+        cx[0, i, :4] = np.uint64(4 * q - 1)
+    got = []
+    for narrow in (False, True):
+        if narrow:
+            monkeypatch.setenv("LR_KEYMAC_NARROW", "1")
+        else:
+            monkeypatch.delenv("LR_KEYMAC_NARROW", raising=False)
+        cQ, cP = ring.NewContextWithParams(N, Q), ring.NewContextWithParams(N, P)
+        plan = ring.CkksPlan(cQ, cP, 2)
+        pevk = plan.NewSwitchingKey().set(evk)
+        p0, p1 = cQ.NewPolyLvl(level, 2), cQ.NewPolyLvl(level, 2)
+        plan.SwitchKeysInPlace(level, cQ.NewPolyLvl(level, 2).set(cx), pevk, p0, p1)
+        got.append((p0.get(), p1.get()))
+    assert np.array_equal(got[0][0], got[1][0]) and np.array_equal(got[0][1], got[1][1])
+    for i, q in enumerate(Q):
+        assert int(got[0][0][:, i].max()) < q and int(got[0][1][:, i].max()) < q

@@ -406,3 +406,32 @@ def test_default_parameter_sets_full_size(gpu_pkg, oracle, scheme, name):
         p.set(y)
         ctx.InvNTT(p, r)
         assert np.array_equal(r.get().reshape(1, limbs, N)[0], oc.intt(np.array([[int(v) % q for v in y[0, i]] for i, q in enumerate(moduli)], dtype=np.uint64)))
+
+
+@pytest.mark.parametrize("per_wg", [2, 3, 16])
+@pytest.mark.parametrize("kind", ["qi60", "ckks", "q61"])
+def test_persistent_forward_kernels(gpu_pkg, oracle, kind, per_wg, monkeypatch):
+    """LR_NTT_PERSIST: the forward 2^15 kernels that transform several polys per workgroup and prefetch the next poly's column loads
+    (lr_ntt_fwd15p_m*; measured no faster than the one-poly kernels at the package power limit and therefore off by default, DESIGN
+    3.1): every output against the oracle, with a batch that leaves a short last chunk (7 polys), in place and out of place"""
+    monkeypatch.setenv("LR_NTT_PERSIST", str(per_wg))
+    ring, params, sampling = gpu_pkg.ring, gpu_pkg.params, gpu_pkg.sampling
+    N = 1 << 15
+    if kind == "qi60":
+        moduli = list(params.DefaultParamsQi(15)[1][:3])
+    elif kind == "ckks":
+        moduli = list(params.ckks_moduli("PN15QP880")[1][:4])       # one 50-bit limb (integer body) + three 41-bit ones (FP64 body)
+    else:
+        moduli = [p for p in params.GenerateNTTPrimes(60, 15, 4) if p > (1 << 60)][:2]
+    ctx = ring.NewContextWithParams(N, moduli)
+    oc = oracle.Context(N, moduli)
+    B = 7
+    x = sampling.uniform_poly(moduli, N, B, seed=per_wg)
+    src, dst = ctx.NewPoly(B).set(x), ctx.NewPoly(B)
+    ctx.NTT(src, dst)
+    assert ctx.last_ntt_kernel().startswith("lr_ntt_fwd15p_m"), ctx.last_ntt_kernel()
+    got = dst.get()
+    for b in range(B):
+        assert np.array_equal(got[b], oc.ntt(x[b])), b
+    ctx.NTT(src, src)
+    assert np.array_equal(src.get(), got)
