@@ -726,8 +726,8 @@ def main():
                         want = oracle.BasisExtender(ocr, oracle.Context(Nr, Pr)).modup_split_qp(Lr - 1, x)
                         got = np.stack(pp.get_limb_slices(Br - 1))
                     elif name == "div_round_by_last_modulus_ntt":
-                        cq.Copy(a, c)
                         nat.check(nat.lib().lr_poly_set_limbs(c.h, Lr))
+                        cq.Copy(a, c)
                         cq.DivRoundByLastModulusNTT(c)
                         want = ocr.rescale_op("oc_div_round_by_last_modulus_ntt", x)
                         got = np.stack(c.get_limb_slices(Br - 1))[:Lr - 1]
@@ -876,9 +876,13 @@ def main():
     }
 
     def timed_on(c, fn, reps):
-        for _ in range(3):
-            fn()
-        c.Sync()
+        # the CPU baselines before a leg leave the device idle for seconds: bring its clock up first (see warm_clock; three launches were
+        # not enough -- the same kernel read 7-15 % slower here than in the R13..R16 table of the same run)
+        t_up = time.perf_counter()
+        while time.perf_counter() - t_up < 0.15:
+            for _ in range(max(3, reps // 2)):
+                fn()
+            c.Sync()
         c.TimerStart()
         for _ in range(reps):
             fn()
@@ -1050,6 +1054,7 @@ def main():
             ctx.DivRoundByLastModulusNTT(dst)
         ctx.Copy(src, dst)
         ms = timed(rescale_once)
+        nat.check(nat.lib().lr_poly_set_limbs(dst.h, L))
         ctx.Copy(src, dst)
         rescale_once()
         got_rs = dst.get_limb_slices(last)[:L - 1]
