@@ -291,6 +291,15 @@ int lr_ckks_plan_destroy(lr_ckks_plan *plan);
  * p0, p1 over Q[0..level] receive the two key-switched components (any strides; neither may alias cx). */
 int lr_ckks_switch_keys(lr_ckks_plan *plan, int level, const lr_poly *cx, const lr_poly *evk,
                         lr_poly *p0, lr_poly *p1);
+/* bfv.evaluator.switchKeys (bfv/evaluator.go:736-812) on the same plan (what bfv.NewEvaluator builds for it -- decomposer,
+ * baseconverterQ1P, key-switch pools, bfv/evaluator.go:100-112 -- is what the CKKS plan holds): cx over all of Q in the
+ * COEFFICIENT domain, evk = SwitchingKey.evakey as for lr_ckks_switch_keys (bfv/keygen.go: NTT + Montgomery form over Q||P);
+ * p0, p1 <- the two key-switched polys over Q, coefficient domain.  cx, p0 and p1 must be distinct polys. */
+int lr_bfv_switch_keys(lr_ckks_plan *plan, const lr_poly *cx, const lr_poly *evk, lr_poly *p0, lr_poly *p1);
+/* bfv.evaluator.Relinearize of a degree-2 ciphertext (bfv/evaluator.go:480-501, 512-524): (out0, out1) = (c0 + p0, c1 + p1) with
+ * (p0, p1) = switchKeys(c2, evakey.evakey[0]); every poly over Q, coefficient domain; out0 / out1 may be c0 / c1. */
+int lr_bfv_relinearize(lr_ckks_plan *plan, const lr_poly *c0, const lr_poly *c1, const lr_poly *c2, const lr_poly *evk,
+                       lr_poly *out0, lr_poly *out1);
 /* MulRelin (ckks/evaluator.go:1016), ciphertext x ciphertext, with evaluation key.
  * ct0_c0/ct0_c1 etc. are the degree-0/1 components (Ciphertext.Value()[0], [1]). */
 int lr_ckks_mulrelin(lr_ckks_plan *plan, int level, const lr_poly *ct0_c0, const lr_poly *ct0_c1,

@@ -83,6 +83,8 @@ SYMBOLS = {
     "lr_ckks_plan_create": [vp, vp, i32, C.POINTER(vp)],
     "lr_ckks_plan_destroy": [vp],
     "lr_ckks_switch_keys": [vp, i32, vp, vp, vp, vp],
+    "lr_bfv_switch_keys": [vp, vp, vp, vp, vp],
+    "lr_bfv_relinearize": [vp, vp, vp, vp, vp, vp, vp],
     "lr_ckks_mulrelin": [vp, i32, vp, vp, vp, vp, vp, vp, vp],
     "lr_ckks_rescale": [vp, vp, vp],
     "lr_ckks_mul_norelin": [vp, i32, vp, vp, vp, vp, vp, vp, vp],

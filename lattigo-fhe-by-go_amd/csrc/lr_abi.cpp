@@ -360,6 +360,7 @@ struct lr_ckks_plan {
     Options opt;           // environment switches, read once at plan creation
     Pool c2QiQ, c2QiP, poolPP, c2, c0, c1, c2x, q1, q2, permQ, permP;
     Pool encQ, encP;       // pk-encryption temporaries over Q||P (lr_ckks_encrypt_pk)
+    Pool bfvP;             // bfv relinearize: keyswitchpool[2], [3] (two polys over Q)
     Pool zerosQ;           // one poly of zeros over Q: the `plus` operand of the NTT epilogue where a caller has none
     Pool stageQ, stageP;   // N = 2^16: the extensions land here and the transforms go out of place (fused top stage, see ks_decompose)
 };
@@ -2151,7 +2152,10 @@ int run_permute_ntt(lr_context *c, int limbs, int batch, const u64 *in, long lon
 // pl->c2QiQ = [beta][batch][|Q|][N], pl->c2QiP = [beta][batch][|P|][N], both in the NTT domain.  The limbs a digit
 // owns are the NTT-domain input itself; they are copied into the digit only when `copy_own` (the hoisted path
 // permutes whole digits), otherwise the inner product reads them in place.
-int ks_decompose(lr_ckks_plan *pl, int level, int batch, const u64 *cx, long long cx_stride, bool copy_own) {
+// coeff_input (bfv.switchKeys, bfv/evaluator.go:736-770): cx is in the coefficient domain -- the digits are decomposed from cx itself
+// and the digits' own limbs are NTT(cx) (:753, kept in pl->c2); otherwise (ckks) cx is in the NTT domain, the digits come from
+// InvNTT(cx) and the own limbs are cx.
+int ks_decompose(lr_ckks_plan *pl, int level, int batch, const u64 *cx, long long cx_stride, bool copy_own, bool coeff_input = false) {
     lr_context *cQ = pl->cQ, *cP = pl->cP;
     lr_decomposer *dec = pl->dec;
     const int nQ = cQ->h.L(), nP = cP->h.L(), n = (int)cQ->h.N;
@@ -2187,7 +2191,12 @@ int ks_decompose(lr_ckks_plan *pl, int level, int batch, const u64 *cx, long lon
     u64 *const srcQ = staged ? pl->stageQ.d : pl->c2QiQ.d, *const srcP = staged ? pl->stageP.d : pl->c2QiP.d;
     Rows cxr{const_cast<u64 *>(cx), cx_stride, 0, 1};
     Rows c2r{pl->c2.d, sQ, 0, 1};
-    LR_TRY(run_ntt(cQ, true, cxr, c2r, 0, 1, level + 1, batch));  // :1503
+    LR_TRY(run_ntt(cQ, !coeff_input, cxr, c2r, 0, 1, level + 1, batch));  // ckks :1503 (InvNTT) / bfv :753 (NTT)
+    if (coeff_input) {
+        // the decomposition reads the caller's coefficient-domain rows; the transformed copy serves the digits' own limbs
+        if (copy_own) return fail(LR_ERR_UNSUPPORTED, "coefficient-domain key switch: own limbs are read in place");
+        c2r = cxr;
+    }
     int full = 0;   // leading digits that own exactly alpha limbs at this level: their transforms share one launch
     for (int i = 0; i < beta; ++i) {
         u64 *dq = pl->c2QiQ.d + (long long)i * dQ;
@@ -2235,7 +2244,8 @@ bool keymac_wide_ok(const lr_ckks_plan *pl, const lr_context *c, int beta) {
 // digQ/digP: [beta][batch][|Q| resp. |P|][N]; own/own_stride: where the digits' own limbs live when they were not
 // copied (nullptr: inside digQ).
 int ks_accumulate(lr_ckks_plan *pl, int level, int batch, const u64 *digQ, const u64 *digP, const u64 *own, long long own_stride,
-                  const lr_poly *evk, u64 *p0, long long p0_stride, u64 *p1, long long p1_stride, const KeySwitchEpilogue *fin) {
+                  const lr_poly *evk, u64 *p0, long long p0_stride, u64 *p1, long long p1_stride, const KeySwitchEpilogue *fin,
+                  bool coeff_out = false) {
     lr_context *cQ = pl->cQ, *cP = pl->cP;
     const int nQ = cQ->h.L(), nP = cP->h.L(), n = (int)cQ->h.N;
     const int alpha = pl->dec->alpha;
@@ -2283,8 +2293,36 @@ int ks_accumulate(lr_ckks_plan *pl, int level, int batch, const u64 *digQ, const
         K.alpha = 0;
         LR_HIP(launch_keymac(K, nP, batch, cQ->stream));
     }
-    // ModDownSplitedNTTPQ x2; the two calls share every launch up to the final subtract-multiply
     lr_bext *bx = pl->bext;
+    if (coeff_out) {
+        // bfv.switchKeys' tail (bfv/evaluator.go:806-811): InvNTT over Q||P, then ModDownPQ in the coefficient domain (in place:
+        // the extension reads x where it stores, ExtSegment::epi_mode 1)
+        if (fin) return fail(LR_ERR_ARG, "coefficient-domain key switch: no epilogue");
+        Rows q0r{p0, p0_stride, 0, 1}, q1r{p1, p1_stride, 0, 1}, pr{pool2P, sP, 0, 1};
+        LR_TRY(run_ntt(cQ, true, q0r, q0r, 0, 1, level + 1, batch));
+        LR_TRY(run_ntt(cQ, true, q1r, q1r, 0, 1, level + 1, batch));
+        LR_TRY(run_ntt(cP, true, pr, pr, 0, 1, nP, 2 * batch));
+        const bool fused = !cQ->opt.no_epilogue && ext_epilogue_supported(bx->pq.tables(), nP, n);
+        for (int k = 0; k < 2; ++k) {
+            u64 *pq = k == 0 ? p0 : p1;
+            const long long pqs = k == 0 ? p0_stride : p1_stride;
+            Rows pk{k == 0 ? pool2P : pool3P, sP, 0, 1};
+            if (fused) {
+                ExtSegment sd = segment(pq, pqs, 0, 0, level + 1);
+                sd.epi_mode = 1;
+                sd.epi_x = pq;
+                sd.epi_x_stride = pqs;
+                sd.epi_c = bx->d_moddown_pq;
+                LR_TRY(run_ext(cQ, bx->pq, nP, pk, batch, sd, segment(nullptr, 0, 0, 0, 0)));
+            } else {
+                LR_TRY(bx->poolQ.ensure(cQ, (size_t)batch * sQ));
+                LR_TRY(run_ext(cQ, bx->pq, nP, pk, batch, segment(bx->poolQ.d, sQ, 0, 0, level + 1), segment(nullptr, 0, 0, 0, 0)));
+                LR_TRY(run_submul(cQ, level + 1, batch, pq, pqs, bx->poolQ.d, sQ, (long long)n, pq, pqs, bx->d_moddown_pq, false, nullptr));
+            }
+        }
+        return LR_OK;
+    }
+    // ModDownSplitedNTTPQ x2; the two calls share every launch up to the final subtract-multiply
     {
         Rows pr{pool2P, sP, 0, 1};
         LR_TRY(run_ntt(cP, true, pr, pr, 0, 1, nP, 2 * batch));
@@ -2394,6 +2432,54 @@ extern "C" int lr_ckks_switch_keys(lr_ckks_plan *pl, int level, const lr_poly *c
 // permuteNTT (ckks/evaluator.go:1448-1468): RotateColumns with a specific rotation key / Conjugate.
 // gen = the Galois element (ring.PermuteNTTIndex's `gen^power`); the two trailing Context calls (:1466-1467)
 // ride on the last ModDown pass.
+// bfv.evaluator.switchKeys (bfv/evaluator.go:736-812): cx in the coefficient domain over all of Q, evk over Q||P in the NTT +
+// Montgomery domain like the reference's SwitchingKey; p0 / p1 <- the two key-switched polys over Q, coefficient domain.  Same
+// machinery as the CKKS key switch (one plan over contextQ / contextP serves both), with the transforms the other way round.
+static int bfv_switch_keys_core(lr_ckks_plan *pl, int batch, const u64 *cx, long long cx_stride, const lr_poly *evk, u64 *p0,
+                                long long p0_stride, u64 *p1, long long p1_stride) {
+    const int level = pl->cQ->h.L() - 1;
+    LR_TRY(ks_decompose(pl, level, batch, cx, cx_stride, false, true));
+    const long long sQ = (long long)pl->cQ->h.L() * (long long)pl->cQ->h.N;
+    return ks_accumulate(pl, level, batch, pl->c2QiQ.d, pl->c2QiP.d, pl->c2.d, sQ, evk, p0, p0_stride, p1, p1_stride, nullptr, true);
+}
+
+extern "C" int lr_bfv_switch_keys(lr_ckks_plan *pl, const lr_poly *cx, const lr_poly *evk, lr_poly *p0, lr_poly *p1) {
+    return guarded([&]() -> int {
+    if (!pl || !cx || !evk || !p0 || !p1) return fail(LR_ERR_ARG, "null argument");
+    const int level = pl->cQ->h.L() - 1;
+    if (cx == p0 || cx == p1 || p0 == p1) return fail(LR_ERR_ARG, "bfv switch keys: cx, p0 and p1 must be distinct polys");
+    LR_TRY(check_ct(pl, level, cx, cx->batch));
+    LR_TRY(check_ct(pl, level, p0, cx->batch));
+    LR_TRY(check_ct(pl, level, p1, cx->batch));
+    if (cx->batch > pl->max_batch) return fail(LR_ERR_SHAPE, "batch exceeds the plan's max_batch");
+    LR_TRY(same_stream(pl->cQ, pl->cP));
+    LR_HIP(hipSetDevice(pl->device));
+    return bfv_switch_keys_core(pl, cx->batch, cx->d, cx->stride(), evk, p0->d, p0->stride(), p1->d, p1->stride());
+    });
+}
+
+// bfv.evaluator.Relinearize on a degree-2 ciphertext (bfv/evaluator.go:480-501, 512-524): out = (c0 + p0, c1 + p1) with
+// (p0, p1) = switchKeys(c2, evakey[0]); all polys over Q in the coefficient domain.  out0 / out1 may be c0 / c1.
+extern "C" int lr_bfv_relinearize(lr_ckks_plan *pl, const lr_poly *c0, const lr_poly *c1, const lr_poly *c2, const lr_poly *evk,
+                                  lr_poly *out0, lr_poly *out1) {
+    return guarded([&]() -> int {
+    if (!pl || !c0 || !c1 || !c2 || !evk || !out0 || !out1) return fail(LR_ERR_ARG, "null argument");
+    lr_context *cQ = pl->cQ;
+    const int level = cQ->h.L() - 1, batch = c2->batch;
+    for (const lr_poly *p : {c0, c1, c2, (const lr_poly *)out0, (const lr_poly *)out1}) LR_TRY(check_ct(pl, level, p, batch));
+    if (out0 == out1 || c2 == out0 || c2 == out1) return fail(LR_ERR_ARG, "bfv relinearize: out0, out1 and c2 must be distinct polys");
+    if (batch > pl->max_batch) return fail(LR_ERR_SHAPE, "batch exceeds the plan's max_batch");
+    LR_TRY(same_stream(pl->cQ, pl->cP));
+    LR_HIP(hipSetDevice(pl->device));
+    const long long sQ = (long long)cQ->h.L() * (long long)cQ->h.N;
+    LR_TRY(pl->bfvP.ensure(cQ, (size_t)2 * batch * sQ));        // keyswitchpool[2], [3] (:489-490)
+    u64 *p0 = pl->bfvP.d, *p1 = pl->bfvP.d + (long long)batch * sQ;
+    LR_TRY(bfv_switch_keys_core(pl, batch, c2->d, c2->stride(), evk, p0, sQ, p1, sQ));
+    LR_TRY(run_ewise(cQ, LR_ADD, level + 1, batch, c0->d, c0->stride(), p0, sQ, out0->d, out0->stride(), nullptr));   // :494
+    return run_ewise(cQ, LR_ADD, level + 1, batch, c1->d, c1->stride(), p1, sQ, out1->d, out1->stride(), nullptr);    // :495
+    });
+}
+
 extern "C" int lr_ckks_rotate(lr_ckks_plan *pl, int level, const lr_poly *c0, const lr_poly *c1, uint64_t gen, const lr_poly *rotkey,
                               lr_poly *o0, lr_poly *o1) {
     return guarded([&]() -> int {

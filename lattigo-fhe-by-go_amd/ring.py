@@ -547,6 +547,16 @@ class CkksPlan:
     def SwitchKeysInPlace(self, level, cx, evakey, p0, p1):
         check(lib().lr_ckks_switch_keys(self.h, level, cx.h, evakey.h, p0.h, p1.h))
 
+    # bfv.NewEvaluator builds the same objects for its key switch (decomposer, baseconverterQ1P, pools: bfv/evaluator.go:100-112):
+    # one plan over (contextQ, contextP) serves both schemes
+    def BfvSwitchKeys(self, cx, evakey, p0, p1):
+        """bfv.evaluator.switchKeys (bfv/evaluator.go:736): coefficient domain in and out, all of Q"""
+        check(lib().lr_bfv_switch_keys(self.h, cx.h, evakey.h, p0.h, p1.h))
+
+    def BfvRelinearize(self, ct, evakey, ctOut):
+        """bfv.evaluator.Relinearize (bfv/evaluator.go:512) of a degree-2 ciphertext: ct = (c0, c1, c2), ctOut = (out0, out1)"""
+        check(lib().lr_bfv_relinearize(self.h, ct[0].h, ct[1].h, ct[2].h, evakey.h, ctOut[0].h, ctOut[1].h))
+
     def MulRelin(self, level, ct0, ct1, evakey, ctOut):
         """evaluator.MulRelin (ckks/evaluator.go:1016).  ct0, ct1: tuples of Poly -- (value[0], value[1]) for a ciphertext,
         (value[0],) for a plaintext; ctOut: pair, or triple when evakey is None and both operands are ciphertexts
@@ -625,3 +635,8 @@ class BfvPlan:
     def Mul(self, ct0, ct1, ctOut):
         """ct0, ct1: pairs of Poly over Q (coefficient domain); ctOut: triple (degree 2)."""
         check(lib().lr_bfv_mul(self.h, ct0[0].h, ct0[1].h, ct1[0].h, ct1[1].h, ctOut[0].h, ctOut[1].h, ctOut[2].h))
+
+    def NewRelinearizer(self, contextP, max_batch=1):
+        """the key-switch half of bfv.NewEvaluator (decomposer, baseconverterQ1P, keyswitchpool: bfv/evaluator.go:100-112) over
+        (contextQ, contextP): a CkksPlan, whose BfvRelinearize / BfvSwitchKeys / NewSwitchingKey serve Evaluator.Relinearize"""
+        return CkksPlan(self.contextQ, contextP, max_batch)

@@ -942,6 +942,76 @@ void oc_ckks_switch_keys(oc_ckks_plan *p, int level, const u64 *cx, const u64 *e
     free(c2QiQ); free(c2QiP); free(pool2P); free(pool3P); free(c2);
 }
 
+/* bfv.evaluator.switchKeys, bfv/evaluator.go:736-812 (test infrastructure like the rest of this file).  cx: [nQ][N] coefficient domain;
+ * evk: [beta][2][nQ+nP][N]; p0, p1: [nQ][N] coefficient domain.  The joined context Q||P of the reference (contextKeys) is the pair
+ * (cQ, cP) here: the tables of a modulus depend on the modulus and N only. */
+void oc_bfv_switch_keys(oc_ckks_plan *p, const u64 *cx, const u64 *evk, u64 *p0out, u64 *p1out) {
+    const oc_context *cQ = p->cQ, *cP = p->cP;
+    const u64 N = cQ->N;
+    const int nQ = cQ->L, nP = cP->L, nQP = nQ + nP;
+    const int level = nQ - 1;                                                  /* :743 */
+    const size_t szQP = (size_t)nQP * N;
+    u64 *c2Qi = (u64 *)calloc(szQP, 8), *c2 = (u64 *)calloc((size_t)nQ * N, 8);
+    u64 *p0 = (u64 *)calloc(szQP, 8), *p1 = (u64 *)calloc(szQP, 8);          /* :745-747 keyswitchpool[i].Zero() */
+    u64 *c2QiNtt = (u64 *)malloc(N * 8);                                      /* :758 */
+    oc_ntt_lvl(cQ, level, cx, c2);                                            /* :753 */
+    int reduce = 0;
+    const int alpha = p->alpha;
+    const int beta = (nQ + alpha - 1) / alpha;                                 /* params.beta */
+    for (int i = 0; i < beta; i++) {
+        const int p0idxst = i * alpha;
+        int p0idxed = p0idxst + p->dec->xalpha[i];
+        oc_decompose(p->dec, level, i, cx, c2Qi, N);                          /* :767 */
+        for (int x = 0; x < nQP; x++) {
+            const oc_context *c = x < nQ ? cQ : cP;
+            const int xi = x < nQ ? x : x - nQ;
+            const u64 qi = c->q[xi], qinv = c->mred[xi];
+            if (p0idxst <= x && x < p0idxed) {
+                memcpy(c2QiNtt, c2 + (size_t)x * N, N * 8);                   /* :775-779 */
+            } else {
+                oc_ntt_limb(c2Qi + (size_t)x * N, c2QiNtt, N, c->ntt_psi + (size_t)xi * N, qi, qinv, c->bred + 2 * xi);   /* :781 */
+            }
+            const u64 *key0 = evk + (((size_t)i * 2 + 0) * nQP + x) * N, *key1 = evk + (((size_t)i * 2 + 1) * nQP + x) * N;
+            u64 *p2tmp = p0 + (size_t)x * N, *p3tmp = p1 + (size_t)x * N;
+            for (u64 y = 0; y < N; y++) {                                     /* :789-792 */
+                p2tmp[y] += oc_mred(key0[y], c2QiNtt[y], qi, qinv);
+                p3tmp[y] += oc_mred(key1[y], c2QiNtt[y], qi, qinv);
+            }
+        }
+        if ((reduce & 7) == 7) {                                              /* :795-798 */
+            oc_ewise(cQ, OC_REDUCE, level, p0, NULL, p0, NULL);
+            oc_ewise(cQ, OC_REDUCE, level, p1, NULL, p1, NULL);
+            oc_ewise(cP, OC_REDUCE, nP - 1, p0 + (size_t)nQ * N, NULL, p0 + (size_t)nQ * N, NULL);
+            oc_ewise(cP, OC_REDUCE, nP - 1, p1 + (size_t)nQ * N, NULL, p1 + (size_t)nQ * N, NULL);
+        }
+        reduce++;
+    }
+    if (((reduce - 1) & 7) != 7) {                                            /* :803-806 */
+        oc_ewise(cQ, OC_REDUCE, level, p0, NULL, p0, NULL);
+        oc_ewise(cQ, OC_REDUCE, level, p1, NULL, p1, NULL);
+        oc_ewise(cP, OC_REDUCE, nP - 1, p0 + (size_t)nQ * N, NULL, p0 + (size_t)nQ * N, NULL);
+        oc_ewise(cP, OC_REDUCE, nP - 1, p1 + (size_t)nQ * N, NULL, p1 + (size_t)nQ * N, NULL);
+    }
+    oc_intt_lvl(cQ, level, p0, p0);                                           /* :808-809: contextKeys.InvNTT, limb by limb */
+    oc_intt_lvl(cQ, level, p1, p1);
+    oc_intt_lvl(cP, nP - 1, p0 + (size_t)nQ * N, p0 + (size_t)nQ * N);
+    oc_intt_lvl(cP, nP - 1, p1 + (size_t)nQ * N, p1 + (size_t)nQ * N);
+    oc_moddown_pq(p->bext, level, p0, p0out);                                 /* :811 */
+    oc_moddown_pq(p->bext, level, p1, p1out);                                 /* :812 */
+    free(c2Qi); free(c2); free(p0); free(p1); free(c2QiNtt);
+}
+
+/* bfv.evaluator.relinearize for a degree-2 ciphertext, bfv/evaluator.go:480-501: ct = [3][nQ][N], out = [2][nQ][N] */
+void oc_bfv_relinearize(oc_ckks_plan *p, const u64 *ct, const u64 *evk, u64 *out) {
+    const oc_context *cQ = p->cQ;
+    const size_t sz = (size_t)cQ->L * cQ->N;
+    u64 *p0 = (u64 *)malloc(sz * 8), *p1 = (u64 *)malloc(sz * 8);
+    oc_bfv_switch_keys(p, ct + 2 * sz, evk, p0, p1);                          /* :493 (deg = 2, evakey[0]) */
+    oc_ewise(cQ, OC_ADD, cQ->L - 1, ct, p0, out, NULL);                       /* :494 */
+    oc_ewise(cQ, OC_ADD, cQ->L - 1, ct + sz, p1, out + sz, NULL);             /* :495 */
+    free(p0); free(p1);
+}
+
 /* MulRelin, ckks/evaluator.go:1016-1133 (ct x ct, regular case, with evaluation key) */
 void oc_ckks_mulrelin(oc_ckks_plan *p, int level, const u64 *ct0, const u64 *ct1, const u64 *evk, u64 *out) {
     const oc_context *cQ = p->cQ;

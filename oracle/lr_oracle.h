@@ -178,6 +178,10 @@ void oc_ckks_plan_free(oc_ckks_plan *p);
  * (NTT + Montgomery, ckks/keygen.go:68-70).  p0, p1 = [level+1][N] outputs. */
 void oc_ckks_switch_keys(oc_ckks_plan *p, int level, const uint64_t *cx, const uint64_t *evk,
                          uint64_t *p0, uint64_t *p1);
+/* bfv.evaluator.switchKeys (bfv/evaluator.go:736-812): cx = [|Q|][N] coefficient domain, evk as above, p0 / p1 = [|Q|][N]
+ * coefficient domain.  oc_bfv_relinearize (:480-501) on a degree-2 ciphertext ct = [3][|Q|][N] -> out = [2][|Q|][N]. */
+void oc_bfv_switch_keys(oc_ckks_plan *p, const uint64_t *cx, const uint64_t *evk, uint64_t *p0, uint64_t *p1);
+void oc_bfv_relinearize(oc_ckks_plan *p, const uint64_t *ct, const uint64_t *evk, uint64_t *out);
 /* MulRelin (:1016), degree-1 x degree-1, regular (non-squaring) case with evaluation key.
  * ct0, ct1, out = [2][level+1][N]. */
 void oc_ckks_mulrelin(oc_ckks_plan *p, int level, const uint64_t *ct0, const uint64_t *ct1,

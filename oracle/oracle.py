@@ -143,6 +143,8 @@ def _bind(L):
     sig("oc_ckks_plan_free", None, vp)
     sig("oc_ckks_switch_keys", None, vp, i, vp, vp, vp, vp)
     sig("oc_ckks_mulrelin", None, vp, i, vp, vp, vp, vp)
+    sig("oc_bfv_switch_keys", None, vp, vp, vp, vp, vp)
+    sig("oc_bfv_relinearize", None, vp, vp, vp, vp)
     sig("oc_ckks_permute_ntt", None, vp, i, vp, u64, vp, vp)
     sig("oc_ckks_mul_norelin", None, vp, i, vp, vp, i, vp)
     sig("oc_ckks_mul_plain", None, vp, i, vp, vp, vp)
@@ -545,6 +547,21 @@ class CkksPlan:
         p1 = np.zeros_like(p0)
         lib().oc_ckks_switch_keys(self.h, level, _ptr(cx), _ptr(evk), _ptr(p0), _ptr(p1))
         return p0, p1
+
+    def bfv_switch_keys(self, cx, evk):
+        """bfv.evaluator.switchKeys (bfv/evaluator.go:736): cx [|Q|, N] coefficient domain -> (p0, p1) coefficient domain"""
+        cx, evk = _arr(cx), _arr(evk)
+        p0 = np.zeros((self.cQ.L, self.cQ.N), dtype=np.uint64)
+        p1 = np.zeros_like(p0)
+        lib().oc_bfv_switch_keys(self.h, _ptr(cx), _ptr(evk), _ptr(p0), _ptr(p1))
+        return p0, p1
+
+    def bfv_relinearize(self, ct, evk):
+        """bfv.evaluator.Relinearize of a degree-2 ciphertext ct [3, |Q|, N] -> [2, |Q|, N]"""
+        ct, evk = _arr(ct), _arr(evk)
+        out = np.zeros((2, self.cQ.L, self.cQ.N), dtype=np.uint64)
+        lib().oc_bfv_relinearize(self.h, _ptr(ct), _ptr(evk), _ptr(out))
+        return out
 
     def permute_ntt(self, level, ct, gen, evk):
         ct, evk = _arr(ct), _arr(evk)

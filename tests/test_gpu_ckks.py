@@ -383,3 +383,53 @@ def test_key_inner_product_wide_and_per_term_agree_on_lazy_own_limbs(gpu_pkg, mo
     assert np.array_equal(got[0][0], got[1][0]) and np.array_equal(got[0][1], got[1][1])
     for i, q in enumerate(Q):
         assert int(got[0][0][:, i].max()) < q and int(got[0][1][:, i].max()) < q
+
+
+@pytest.mark.parametrize("name,logn", [("PN12QP109", 12), ("PN13QP218", 11), ("PN14QP438", 14), ("PN15QP880", 12)])
+def test_bfv_relinearize(gpu_pkg, oracle, name, logn, monkeypatch):
+    """bfv.evaluator.Relinearize / switchKeys (bfv/evaluator.go:480-501, 736-812) on the reference's BFV parameter sets (PN14QP438 =
+    BASELINE config 4 at full size), degree 2 -> 1, coefficient domain in and out, against the oracle's restatement; in place; and
+    with the subtract-multiply of the ModDown as a separate pass (LR_NO_EPILOGUE)"""
+    _, Q, P, _ = gpu_pkg.params.bfv_moduli(name)
+    N = 1 << logn
+    ring = gpu_pkg.ring
+    nq, np_ = len(Q), len(P)
+    beta = -(-nq // np_)
+    evk = gpu_pkg.sampling.uniform_poly(Q + P, N, 2 * beta, seed=41)
+    ct = [gpu_pkg.sampling.uniform_poly(Q, N, 2, seed=50 + k) for k in range(3)]
+    oplan = oracle.CkksPlan(oracle.Context(N, Q), oracle.Context(N, P))
+    wants = [oplan.bfv_relinearize(np.stack([ct[0][b], ct[1][b], ct[2][b]]), evk.reshape(beta, 2, nq + np_, N)) for b in range(2)]
+    for no_epi in (False, True):
+        if no_epi:
+            monkeypatch.setenv("LR_NO_EPILOGUE", "1")
+        cQ, cP = ring.NewContextWithParams(N, Q), ring.NewContextWithParams(N, P)
+        plan = ring.CkksPlan(cQ, cP, 2)
+        pevk = plan.NewSwitchingKey().set(evk)
+        c = [cQ.NewPoly(2).set(x) for x in ct]
+        out = (cQ.NewPoly(2), cQ.NewPoly(2))
+        plan.BfvRelinearize(c, pevk, out)
+        for b in range(2):
+            assert np.array_equal(out[0].get()[b], wants[b][0]), (no_epi, b)
+            assert np.array_equal(out[1].get()[b], wants[b][1]), (no_epi, b)
+        # switchKeys alone
+        p0, p1 = cQ.NewPoly(2), cQ.NewPoly(2)
+        plan.BfvSwitchKeys(c[2], pevk, p0, p1)
+        w0, w1 = oplan.bfv_switch_keys(ct[2][1], evk.reshape(beta, 2, nq + np_, N))
+        assert np.array_equal(p0.get()[1], w0) and np.array_equal(p1.get()[1], w1)
+        # ctOut == ct0 (the reference relinearizes in place when the evaluator is handed the same ciphertext)
+        plan.BfvRelinearize(c, pevk, (c[0], c[1]))
+        assert np.array_equal(c[0].get(), out[0].get()) and np.array_equal(c[1].get(), out[1].get())
+
+
+def test_bfv_relinearize_refuses_aliased_operands(gpu_pkg):
+    _, Q, P, _ = gpu_pkg.params.bfv_moduli("PN12QP109")
+    N = 1 << 10
+    ring = gpu_pkg.ring
+    cQ, cP = ring.NewContextWithParams(N, Q), ring.NewContextWithParams(N, P)
+    plan = ring.CkksPlan(cQ, cP, 1)
+    key = plan.NewSwitchingKey()
+    a, b, c = cQ.NewPoly(1), cQ.NewPoly(1), cQ.NewPoly(1)
+    with pytest.raises(gpu_pkg._native.LatticeRingError):
+        plan.BfvRelinearize((a, b, c), key, (a, c))
+    with pytest.raises(gpu_pkg._native.LatticeRingError):
+        plan.BfvSwitchKeys(c, key, c, a)

@@ -168,6 +168,41 @@ def test_bfv_mul_decrypts_to_the_product(gpu_pkg, oracle):
         got.append(((t * x + Qprod // 2) // Qprod) % t)
     assert got == want
 
+    # Relinearize (bfv/evaluator.go:512) with a key built as the reference builds it: the degree-1 result decrypts to the same product
+    _, _, P, _ = gpu_pkg.params.bfv_moduli(name)
+    QP = list(Q) + list(P)
+    nq, np_ = len(Q), len(P)
+    alpha, beta = np_, -(-nq // np_)
+    ocQP = oracle.Context(N, QP)
+    Pprod = 1
+    for p in P:
+        Pprod *= p
+    sQP = ocQP.ntt(_residues(s, QP))
+    s2QP = _mulmod(sQP, sQP, QP)
+    evk = np.zeros((beta, 2, nq + np_, N), dtype=np.uint64)
+    for i in range(beta):
+        a_i = gpu_pkg.sampling.uniform_poly(QP, N, 1, seed=950 + i)[0]
+        e_i = ocQP.ntt(_residues(_small(N, 6, 960 + i), QP))
+        k0 = _addmod(_negmod(_mulmod(a_i, sQP, QP), QP), e_i, QP)
+        for j in range(alpha):
+            idx = i * alpha + j
+            if idx < nq:
+                q = QP[idx]
+                k0[idx] = np.array([(int(x) + (Pprod % q) * int(y)) % q for x, y in zip(k0[idx], s2QP[idx])], dtype=np.uint64)
+        evk[i, 0], evk[i, 1] = _mont(k0, QP), _mont(a_i, QP)
+    cP = ring.NewContextWithParams(N, P)
+    rl = plan.NewRelinearizer(cP, 1)
+    pevk = rl.NewSwitchingKey().set(evk.reshape(2 * beta, nq + np_, N))
+    lin = (cQ.NewPoly(1), cQ.NewPoly(1))
+    rl.BfvRelinearize(out, pevk, lin)
+    d = [o.get().reshape(len(Q), N) for o in lin]
+    v1 = ocQ.intt(_addmod(ocQ.ntt(d[0]), _mulmod(ocQ.ntt(d[1]), s_ntt, Q), Q))
+    got1 = []
+    for k in range(N):
+        x = sum(int(v1[i][k]) * crt[i] for i in range(len(Q))) % Qprod
+        got1.append(((t * x + Qprod // 2) // Qprod) % t)
+    assert got1 == want
+
 
 @pytest.mark.parametrize("hoisted", [False, True])
 def test_rotation_decrypts_to_the_permuted_plaintext(gpu_pkg, oracle, hoisted):

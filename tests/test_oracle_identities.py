@@ -309,3 +309,58 @@ def test_galois_shift_property_of_the_reference(oracle, logn):
         assert oc.shift(x, N + 1) is None    # p1.Coeffs[i][n:] with n > N panics in the reference
     else:
         assert np.array_equal(oc.shift(x, (1 << N) + 2), oc.shift(x, 2))   # Go's mask (1 << N) - 1
+
+
+def test_bfv_relinearize_decrypts_like_the_degree_two_ciphertext(oracle):
+    """Pins the restatement of bfv.evaluator.switchKeys / relinearize (bfv/evaluator.go:480-501, 736-812), for which the reference holds
+    no vectors: with a relinearisation key built the way the reference builds it (bfv/keygen.go -> newSwitchingKey: for digit i
+    (-a_i*s + e_i + P*s^2 on the limbs of digit i, a_i) over Q||P, NTT + Montgomery form), c0' + c1'*s must equal c0 + c1*s + c2*s^2
+    up to a small noise that is the same integer polynomial modulo every q_i.  Python integers decide."""
+    import __graft_entry__ as graft
+    pkg = graft.load_package()
+    N = 1 << 6
+    Qf, Pf = pkg.params.Qi60(), pkg.params.Pi60()
+    Q, P = list(Qf[:4]), list(Pf[:2])
+    QP = Q + P
+    nq, np_ = len(Q), len(P)
+    alpha, beta = np_, -(-nq // np_)
+    ocQ, ocP, ocQP = oracle.Context(N, Q), oracle.Context(N, P), oracle.Context(N, QP)
+    plan = oracle.CkksPlan(ocQ, ocP)
+    rng = np.random.default_rng(5)
+    res = lambda v, mods: np.array([[int(x) % q for x in v] for q in mods], dtype=np.uint64)
+    mul = lambda a, b, mods: np.array([[int(x) * int(y) % q for x, y in zip(a[i], b[i])] for i, q in enumerate(mods)], dtype=np.uint64)
+    add = lambda a, b, mods: np.array([[(int(x) + int(y)) % q for x, y in zip(a[i], b[i])] for i, q in enumerate(mods)], dtype=np.uint64)
+    neg = lambda a, mods: np.array([[(q - int(x)) % q for x in a[i]] for i, q in enumerate(mods)], dtype=np.uint64)
+    mont = lambda a, mods: np.array([[(int(x) << 64) % q for x in a[i]] for i, q in enumerate(mods)], dtype=np.uint64)
+    Pprod = 1
+    for p in P:
+        Pprod *= p
+    s = rng.integers(-1, 2, size=N)
+    s_ntt = ocQP.ntt(res(s, QP))
+    s2_ntt = mul(s_ntt, s_ntt, QP)
+    evk = np.zeros((beta, 2, nq + np_, N), dtype=np.uint64)
+    for i in range(beta):
+        a_i = pkg.sampling.uniform_poly(QP, N, 1, seed=300 + i)[0]
+        e_i = ocQP.ntt(res(rng.integers(-6, 7, size=N), QP))
+        k0 = add(neg(mul(a_i, s_ntt, QP), QP), e_i, QP)
+        for j in range(alpha):
+            idx = i * alpha + j
+            if idx < nq:
+                q = QP[idx]
+                k0[idx] = np.array([(int(x) + (Pprod % q) * int(y)) % q for x, y in zip(k0[idx], s2_ntt[idx])], dtype=np.uint64)
+        evk[i, 0], evk[i, 1] = mont(k0, QP), mont(a_i, QP)
+    ct = pkg.sampling.uniform_poly(Q, N, 3, seed=7)                       # any degree-2 "ciphertext", coefficient domain
+    out = plan.bfv_relinearize(ct, evk)
+    sq, s2q = s_ntt[:nq], s2_ntt[:nq]
+    lhs = ocQ.intt(add(ocQ.ntt(out[0]), mul(ocQ.ntt(out[1]), sq, Q), Q))
+    rhs = ocQ.intt(add(add(ocQ.ntt(ct[0]), mul(ocQ.ntt(ct[1]), sq, Q), Q), mul(ocQ.ntt(ct[2]), s2q, Q), Q))
+    noise = None
+    for i, q in enumerate(Q):
+        d = [((int(x) - int(y)) % q + q // 2) % q - q // 2 for x, y in zip(lhs[i], rhs[i])]
+        assert max(abs(v) for v in d) < 1 << 24, (i, max(abs(v) for v in d))
+        if noise is None:
+            noise = d
+        assert d == noise                                                  # one integer polynomial, whatever the modulus
+    # and the two halves separately: relinearize = (c0 + p0, c1 + p1) with (p0, p1) = switchKeys(c2)
+    p0, p1 = plan.bfv_switch_keys(ct[2], evk)
+    assert np.array_equal(out[0], add(ct[0], p0, Q)) and np.array_equal(out[1], add(ct[1], p1, Q))
