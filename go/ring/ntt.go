@@ -5,7 +5,6 @@ package ring
 import "C"
 
 import (
-	"runtime"
 	"sync"
 	"unsafe"
 )
@@ -34,7 +33,7 @@ func (c *Context) InvNTTLvl(level uint64, p1, p2 *Poly) {
 // The package-level NTT / InvNTT of the reference (ring/ntt.go:53,89) take one limb as a host slice together with its
 // table and constants; the evaluators call them to transform a limb under a given modulus (ckks/evaluator.go:1586,
 // bfv/evaluator.go:766).  The table argument is redundant with (N, Q) -- GenNTTParams derives it deterministically -- so
-// the call is served by a cached one-modulus context and lr_ntt_host / lr_intt_host (upload, kernel, download).
+// the call is served by a cached one-modulus context and lr_ntt_host_limb (upload, kernel, download).
 var (
 	limbMu  sync.Mutex
 	limbCtx = map[[2]uint64]*Context{}
@@ -57,22 +56,13 @@ func limbContext(N, Q uint64) *Context {
 
 func limbTransform(coeffsIn, coeffsOut []uint64, N, Q uint64, inverse bool) {
 	c := limbContext(N, Q)
-	var pin runtime.Pinner
-	defer pin.Unpin()
-	pin.Pin(&coeffsIn[0])
-	pin.Pin(&coeffsOut[0])
-	raw := C.malloc(2 * C.size_t(unsafe.Sizeof(uintptr(0))))
-	defer C.free(raw)
-	arr := unsafe.Slice((**C.uint64_t)(raw), 2)
-	arr[0] = (*C.uint64_t)(unsafe.Pointer(&coeffsIn[0]))
-	arr[1] = (*C.uint64_t)(unsafe.Pointer(&coeffsOut[0]))
-	in := (**C.uint64_t)(raw)
-	out := (**C.uint64_t)(unsafe.Pointer(uintptr(raw) + unsafe.Sizeof(uintptr(0))))
+	inv := C.int(0)
 	if inverse {
-		call(func() C.int { return C.lr_intt_host(c.h, 0, in, out) })
-	} else {
-		call(func() C.int { return C.lr_ntt_host(c.h, 0, in, out) })
+		inv = 1
 	}
+	in := (*C.uint64_t)(unsafe.Pointer(&coeffsIn[0]))
+	out := (*C.uint64_t)(unsafe.Pointer(&coeffsOut[0]))
+	call(func() C.int { return C.lr_ntt_host_limb(c.h, 0, inv, in, out) })
 }
 
 // NTT (ring/ntt.go:53): forward transform of one limb.  nttPsi, mredParams and bredParams are accepted for source

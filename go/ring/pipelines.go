@@ -33,14 +33,9 @@ func (p *CkksPlan) SwitchingKeyImage(evakey [][2]*Poly) *Poly {
 	call(func() C.int { return C.lr_poly_alloc(p.contextQ.h, C.int(limbs), C.int(2*len(evakey)), &img.d) }) // limbs beyond |Q| follow contextP: see lr_ckks_switch_keys
 	for i := range evakey {
 		for k := 0; k < 2; k++ {
-			var pin runtime.Pinner
 			src := evakey[i][k]
 			src.hostView()
-			ptrs, free := src.limbPtrs(&pin)
-			idx := C.int(2*i + k)
-			call(func() C.int { return C.lr_poly_upload(img.d, idx, ptrs, C.int(limbs)) })
-			free()
-			pin.Unpin()
+			src.uploadTo(img.d, 2*i+k)
 		}
 	}
 	runtime.SetFinalizer(img, func(q *Poly) { C.lr_poly_free(q.d) })
@@ -103,7 +98,7 @@ func (p *CkksPlan) Decrypt(level uint64, ct []*Poly, sk, ptOut *Poly) {
 	n := len(ct)
 	raw := C.malloc(C.size_t(n) * C.size_t(unsafe.Sizeof(uintptr(0))))
 	defer C.free(raw)
-	arr := unsafe.Slice((**C.lr_poly)(raw), n)
+	arr := polyArray(raw, n)
 	for i := range ct {
 		arr[i] = ct[i].d
 	}
@@ -145,7 +140,7 @@ func (p *CkksPlan) RotateHoisted(level uint64, ct0 [2]*Poly, galEls []uint64, ro
 	defer C.free(unsafe.Pointer(keys))
 	defer C.free(unsafe.Pointer(o0))
 	defer C.free(unsafe.Pointer(o1))
-	ks, a0, a1 := unsafe.Slice(keys, n), unsafe.Slice(o0, n), unsafe.Slice(o1, n)
+	ks, a0, a1 := polyArray(unsafe.Pointer(keys), n), polyArray(unsafe.Pointer(o0), n), polyArray(unsafe.Pointer(o1), n)
 	for r := 0; r < n; r++ {
 		ks[r], a0[r], a1[r] = rotkeys[r].d, ctOuts[r][0].d, ctOuts[r][1].d
 	}
@@ -155,6 +150,29 @@ func (p *CkksPlan) RotateHoisted(level uint64, ct0 [2]*Poly, galEls []uint64, ro
 	for r := 0; r < n; r++ {
 		done(ctOuts[r][0], ctOuts[r][1])
 	}
+}
+
+// polyArray views n handle slots of C memory as a Go slice (the pre-go-1.17 spelling of unsafe.Slice)
+func polyArray(raw unsafe.Pointer, n int) []*C.lr_poly {
+	return (*[1 << 28]*C.lr_poly)(raw)[:n:n]
+}
+
+// BfvSwitchKeys = bfv evaluator.switchKeys (bfv/evaluator.go:736-812) on the key-switch plan over (contextQ, contextP): the objects
+// bfv.NewEvaluator builds for it (decomposer, baseconverterQ1P, keyswitchpool, :100-112) are the ones the CKKS plan holds.
+// Coefficient domain in and out; evakey: SwitchingKeyImage of SwitchingKey.evakey.
+func (p *CkksPlan) BfvSwitchKeys(cx, evakey, p0, p1 *Poly) {
+	p.contextQ.use(cx)
+	p.contextQ.want(p0, p1)
+	call(func() C.int { return C.lr_bfv_switch_keys(p.h, cx.d, evakey.d, p0.d, p1.d) })
+	done(p0, p1)
+}
+
+// BfvRelinearize = bfv evaluator.relinearize for a degree-2 ciphertext (bfv/evaluator.go:480-501): ctOut = (c0 + p0, c1 + p1).
+func (p *CkksPlan) BfvRelinearize(ct [3]*Poly, evakey *Poly, ctOut [2]*Poly) {
+	p.contextQ.use(ct[0], ct[1], ct[2])
+	p.contextQ.want(ctOut[0], ctOut[1])
+	call(func() C.int { return C.lr_bfv_relinearize(p.h, ct[0].d, ct[1].d, ct[2].d, evakey.d, ctOut[0].d, ctOut[1].d) })
+	done(ctOut[0], ctOut[1])
 }
 
 // BfvPlan: what bfv.NewEvaluator builds for Mul (bfv/evaluator.go:89-112) and tensorAndRescale (:278-464).

@@ -64,34 +64,28 @@ func (c *Context) bind(ps ...*Poly) {
 	}
 }
 
-// limbPtrs builds the C array of per-limb pointers.  A Go pointer passed to C may not point at memory that
-// holds Go pointers, so Coeffs itself cannot cross: the array lives in C memory and each limb is pinned.
-func (p *Poly) limbPtrs(pin *runtime.Pinner) (**C.uint64_t, func()) {
-	n := len(p.Coeffs)
-	raw := C.malloc(C.size_t(n) * C.size_t(unsafe.Sizeof(uintptr(0))))
-	arr := unsafe.Slice((**C.uint64_t)(raw), n)
+// Host <-> device copies go one limb at a time: a Go pointer may be passed to C for the duration of a call, but it may not be
+// stored in C memory (an array of limb pointers), and runtime.Pinner -- which would allow that -- is go 1.21 while the reference
+// module declares go 1.13 (/go.mod:3).  Each Coeffs[i] is a []uint64 (no Go pointers inside), so &Coeffs[i][0] may cross as it is.
+func (p *Poly) uploadTo(d *C.lr_poly, batchIndex int) {
 	for i := range p.Coeffs {
-		pin.Pin(&p.Coeffs[i][0])
-		arr[i] = (*C.uint64_t)(unsafe.Pointer(&p.Coeffs[i][0]))
+		limb := C.int(i)
+		src := (*C.uint64_t)(unsafe.Pointer(&p.Coeffs[i][0]))
+		call(func() C.int { return C.lr_poly_upload_limb(d, C.int(batchIndex), limb, src) })
 	}
-	return (**C.uint64_t)(raw), func() { C.free(raw) }
 }
 
 func (p *Poly) upload() {
-	var pin runtime.Pinner
-	defer pin.Unpin()
-	ptrs, free := p.limbPtrs(&pin)
-	defer free()
 	call(func() C.int { return C.lr_poly_set_limbs(p.d, C.int(len(p.Coeffs))) })
-	call(func() C.int { return C.lr_poly_upload(p.d, 0, ptrs, C.int(len(p.Coeffs))) })
+	p.uploadTo(p.d, 0)
 }
 
 func (p *Poly) download() {
-	var pin runtime.Pinner
-	defer pin.Unpin()
-	ptrs, free := p.limbPtrs(&pin)
-	defer free()
-	call(func() C.int { return C.lr_poly_download(p.d, 0, ptrs, C.int(len(p.Coeffs))) })
+	for i := range p.Coeffs {
+		limb := C.int(i)
+		dst := (*C.uint64_t)(unsafe.Pointer(&p.Coeffs[i][0]))
+		call(func() C.int { return C.lr_poly_download_limb(p.d, 0, limb, dst) })
+	}
 }
 
 // Pin makes the device image authoritative: methods stop copying this polynomial across PCIe.
@@ -111,6 +105,12 @@ func (p *Poly) Sync() {
 	}
 }
 func (p *Poly) Unpin() { p.Sync(); p.resident = false }
+
+// HostView / HostWritten are what the evaluator overlays (go/ckks/evaluator_device.go, go/bfv/evaluator_device.go) put around the
+// upstream loops that index Coeffs directly: HostView before a loop reads a possibly resident polynomial, HostWritten after a loop
+// has written one.  Both are no-ops for polynomials that are not resident.
+func (p *Poly) HostView()    { p.hostView() }
+func (p *Poly) HostWritten() { p.hostWritten() }
 
 // hostView / hostWritten bracket host-side code that reads / has written Coeffs of a possibly resident polynomial.
 func (p *Poly) hostView() { p.Sync() }

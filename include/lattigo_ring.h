@@ -133,6 +133,10 @@ int lr_poly_info(const lr_poly *p, uint64_t *N, int *limbs, int *batch, void **d
  * passed through cgo as a whole; the shim passes `limbs` pinned *uint64).  Synchronises. */
 int lr_poly_upload(lr_poly *p, int batch_index, const uint64_t *const *limb_ptrs, int limbs);
 int lr_poly_download(const lr_poly *p, int batch_index, uint64_t *const *limb_ptrs, int limbs);
+/* the same one limb at a time (`limb` < the poly's limb count): what a cgo caller under the reference's go 1.13 uses -- a Go slice's
+ * pointer may cross for the duration of a call, an array of such pointers in C memory may not (go/ring/poly.go).  Synchronises. */
+int lr_poly_upload_limb(lr_poly *p, int batch_index, int limb, const uint64_t *src);
+int lr_poly_download_limb(const lr_poly *p, int batch_index, int limb, uint64_t *dst);
 /* Poly.MarshalBinary / UnmarshalBinary image of ONE poly (ring/ring_object.go:159-176,222-229,252-270): byte 0 = log2 N,
  * byte 1 = number of moduli, then limb-major big-endian uint64 (WriteCoeffsTo :146, DecodeCoeffs :197).  The bytes
  * cross PCIe as they are and are swapped on the device, so serialized ciphertexts and keys go disk -> HBM without
@@ -163,6 +167,8 @@ int lr_intt_limb(lr_context *ctx, int mod_index, const lr_poly *in, int in_limb,
  * download.  Synchronises. */
 int lr_ntt_host(lr_context *ctx, int level, const uint64_t *const *in_limbs, uint64_t *const *out_limbs);
 int lr_intt_host(lr_context *ctx, int level, const uint64_t *const *in_limbs, uint64_t *const *out_limbs);
+/* package-level ring.NTT / ring.InvNTT (ring/ntt.go:53,89) on one limb under modulus `mod_index`, host slices, may be in place */
+int lr_ntt_host_limb(lr_context *ctx, int mod_index, int inverse, const uint64_t *in, uint64_t *out);
 
 /* ------------------------------------------------------------------ coefficient-wise -- */
 /* One entry point for the whole ring/ring.go family; `op` selects the method. */

@@ -37,6 +37,9 @@ SYMBOLS = {
     "lr_poly_info": [vp, u64p, C.POINTER(i32), C.POINTER(i32), C.POINTER(vp)],
     "lr_poly_upload": [vp, i32, C.POINTER(u64p), i32],
     "lr_poly_download": [vp, i32, C.POINTER(u64p), i32],
+    "lr_poly_upload_limb": [vp, i32, i32, vp],
+    "lr_poly_download_limb": [vp, i32, i32, vp],
+    "lr_ntt_host_limb": [vp, i32, i32, vp, vp],
     "lr_poly_unmarshal": [vp, i32, C.c_char_p, C.c_size_t],
     "lr_poly_marshal": [vp, i32, vp, C.c_size_t, C.POINTER(C.c_size_t)],
     "lr_poly_upload_dense": [vp, vp, C.c_size_t],

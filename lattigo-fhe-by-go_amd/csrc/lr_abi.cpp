@@ -755,6 +755,35 @@ extern "C" int lr_poly_upload(lr_poly *p, int batch_index, const uint64_t *const
     });
 }
 
+// One limb at a time: the form a cgo caller built for the reference's go 1.13 needs -- a Go pointer may be passed to C for the
+// duration of a call, but it may not be stored in C memory (an array of limb pointers), and runtime.Pinner is go 1.21.  The copy
+// has completed when the call returns.
+extern "C" int lr_poly_upload_limb(lr_poly *p, int batch_index, int limb, const uint64_t *src) {
+    return guarded([&]() -> int {
+    if (!p || !src) return fail(LR_ERR_ARG, "null argument");
+    if (batch_index < 0 || batch_index >= p->batch || limb < 0 || limb >= p->limbs)
+        return fail(LR_ERR_SHAPE, "upload: batch index or limb out of range");
+    LR_HIP(hipSetDevice(p->device));
+    LR_HIP(hipMemcpyAsync(p->d + batch_index * p->stride() + (long long)limb * p->N, src, p->N * sizeof(u64), hipMemcpyHostToDevice,
+                          p->ctx->stream));
+    LR_HIP(hipStreamSynchronize(p->ctx->stream));
+    return LR_OK;
+    });
+}
+
+extern "C" int lr_poly_download_limb(const lr_poly *p, int batch_index, int limb, uint64_t *dst) {
+    return guarded([&]() -> int {
+    if (!p || !dst) return fail(LR_ERR_ARG, "null argument");
+    if (batch_index < 0 || batch_index >= p->batch || limb < 0 || limb >= p->limbs)
+        return fail(LR_ERR_SHAPE, "download: batch index or limb out of range");
+    LR_HIP(hipSetDevice(p->device));
+    LR_HIP(hipMemcpyAsync(dst, p->d + batch_index * p->stride() + (long long)limb * p->N, p->N * sizeof(u64), hipMemcpyDeviceToHost,
+                          p->ctx->stream));
+    LR_HIP(hipStreamSynchronize(p->ctx->stream));
+    return LR_OK;
+    });
+}
+
 extern "C" int lr_poly_download(const lr_poly *p, int batch_index, uint64_t *const *limb_ptrs, int limbs) {
     return guarded([&]() -> int {
     if (!p || !limb_ptrs) return fail(LR_ERR_ARG, "null argument");
@@ -1116,6 +1145,22 @@ static int ntt_host(lr_context *c, bool inverse, int level, const uint64_t *cons
     if (rc == LR_OK) rc = lr_poly_download(tmp, 0, out_limbs, level + 1);
     lr_poly_free(tmp);
     return rc;
+}
+
+// the package-level ring.NTT / ring.InvNTT (ring/ntt.go:53,89): one limb under modulus `mod_index` of the context, host slices in
+// and out (upload, kernel, download); may be in place
+extern "C" int lr_ntt_host_limb(lr_context *c, int mod_index, int inverse, const uint64_t *in, uint64_t *out) {
+    return guarded([&]() -> int {
+    if (!c || !in || !out) return fail(LR_ERR_ARG, "null argument");
+    if (mod_index < 0 || mod_index >= c->h.L()) return fail(LR_ERR_SHAPE, "modulus index out of range");
+    lr_poly *tmp = nullptr;
+    LR_TRY(lr_poly_alloc(c, 1, 1, &tmp));
+    int rc = lr_poly_upload_limb(tmp, 0, 0, in);
+    if (rc == LR_OK) rc = ntt_limb(c, inverse != 0, mod_index, tmp, 0, tmp, 0);
+    if (rc == LR_OK) rc = lr_poly_download_limb(tmp, 0, 0, out);
+    lr_poly_free(tmp);
+    return rc;
+    });
 }
 
 extern "C" int lr_ntt_host(lr_context *c, int level, const uint64_t *const *in_limbs, uint64_t *const *out_limbs) {

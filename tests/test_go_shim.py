@@ -11,10 +11,16 @@ import pytest
 from conftest import ROOT
 
 GO_DIR = os.path.join(ROOT, "go", "ring")
+OVERLAYS = {"ckks": os.path.join(ROOT, "go", "ckks", "evaluator_device.go"), "bfv": os.path.join(ROOT, "go", "bfv", "evaluator_device.go")}
 
 
 def _go_sources():
     return {f: open(os.path.join(GO_DIR, f)).read() for f in sorted(os.listdir(GO_DIR)) if f.endswith(".go")}
+
+
+def _exported_methods(text, receiver):
+    """names of the methods declared on `receiver` (pointer or value) in Go source text"""
+    return set(re.findall(r"func \(\w+ \*?%s\) (\w+)\(" % receiver, text))
 
 
 def _strip(text):
@@ -79,7 +85,10 @@ def test_every_c_call_matches_the_header():
     unused = sorted(set(arity) - seen - {"lr_build_info", "lr_device_count", "lr_timer_start", "lr_timer_stop", "lr_context_info",
                                          "lr_poly_info", "lr_poly_wrap", "lr_poly_wrap_strided", "lr_poly_upload_dense",
                                          "lr_poly_download_dense", "lr_context_ntt_variants", "lr_context_last_ntt_kernel",
-                                         "lr_ntt_limb", "lr_intt_limb", "lr_bext_get_table", "lr_simple_scaler_tables", "lr_context_timeline", "lr_selftest_division"})
+                                         "lr_ntt_limb", "lr_intt_limb", "lr_bext_get_table", "lr_simple_scaler_tables", "lr_context_timeline", "lr_selftest_division",
+                                         # the pointer-array forms serve C / C++ / Python callers; a go 1.13 cgo caller may not store Go pointers in a C
+                                         # array and uses the per-limb forms (lr_poly_upload_limb, lr_poly_download_limb, lr_ntt_host_limb)
+                                         "lr_poly_upload", "lr_poly_download", "lr_ntt_host", "lr_intt_host"})
     assert not unused, unused
 
 
@@ -100,3 +109,78 @@ def test_surface_checklist_is_complete_and_current():
     for ident in ("MRed", "CRed", "MForm", "NTT", "InvNTT", "PermuteNTTWithIndex", "GenGaloisParams", "NewPoly", "NewContext",
                   "Context.SetParameters", "Context.GenNTTParams", "NewDecomposer", "NewFastBasisExtender", "BRedParams", "MRedParams"):
         assert "| `%s` |" % ident in text, ident
+
+
+def test_go_1_13_language_level():
+    """the reference module declares go 1.13 (/go.mod:3): no runtime.Pinner (1.21), no unsafe.Slice (1.17), no generics, no `any`"""
+    texts = dict(_go_sources())
+    for name, path in OVERLAYS.items():
+        texts[name + "/evaluator_device.go"] = open(path).read()
+    for name, text in texts.items():
+        t = _strip(text)
+        assert "runtime.Pinner" not in t and "unsafe.Slice" not in t and "unsafe.String" not in t, name
+        assert not re.search(r"func \w+\[", t), (name, "type parameters")
+        assert not re.search(r"\bany\b", t), name
+
+
+def test_evaluator_overlays_use_only_what_the_shim_exports():
+    """go/ckks/evaluator_device.go and go/bfv/evaluator_device.go: delimiters balance, they are overlays of the upstream packages, every
+    method they call on ring.CkksPlan / ring.BfvPlan / ring.Poly exists in go/ring with the same number of arguments, and the methods
+    the review listed are re-pointed"""
+    ring_text = "\n".join(_go_sources().values())
+    plan_methods = {"CkksPlan": _exported_methods(ring_text, "CkksPlan"), "BfvPlan": _exported_methods(ring_text, "BfvPlan"), "Poly": _exported_methods(ring_text, "Poly")}
+    assert {"MulRelin", "Rescale", "SwitchKeysInPlace", "PermuteNTT", "RotateHoisted", "SwitchingKeyImage", "BfvSwitchKeys", "BfvRelinearize"} <= plan_methods["CkksPlan"]
+    assert {"Pin", "HostView", "HostWritten", "Sync", "Unpin"} <= plan_methods["Poly"]
+
+    def arity_of(receiver, method):
+        m = re.search(r"func \(\w+ \*?%s\) %s\(([^)]*)\)" % (receiver, method), ring_text)
+        assert m, (receiver, method)
+        groups = [g for g in _split_args(m.group(1)) if g.strip()]
+        n = 0
+        pending = 0
+        for g in groups:                       # "a, b *Poly" declares two parameters: names without a type wait for the next typed group
+            parts = g.strip().split()
+            pending += 1
+            if len(parts) >= 2:
+                n += pending
+                pending = 0
+        return n + pending
+
+    for pkg, path in OVERLAYS.items():
+        text = open(path).read()
+        t = _strip(text)
+        for a, b in ("{}", "()", "[]"):
+            assert t.count(a) == t.count(b), (pkg, a)
+        assert t.lstrip().startswith("package " + pkg)
+        assert '"github.com/ldsec/lattigo/ring"' in text
+        for field, receiver in (("plan", "CkksPlan"), ("ks", "CkksPlan"), ("mul", "BfvPlan")):
+            for m in re.finditer(r"eval\.%s\.(\w+)\(" % field, t):
+                meth = m.group(1)
+                assert meth in plan_methods[receiver], (pkg, field, meth)
+                i, depth = m.end(), 1
+                while depth:
+                    depth += {"(": 1, ")": -1}.get(t[i], 0)
+                    i += 1
+                assert len(_split_args(t[m.end():i - 1])) == arity_of(receiver, meth), (pkg, meth)
+        for m in re.finditer(r"\bp\.(HostView|HostWritten|Pin)\(", t):
+            assert m.group(1) in plan_methods["Poly"]
+    ck = open(OVERLAYS["ckks"]).read()
+    for meth in ("MulRelin", "Rescale", "switchKeysInPlace", "permuteNTT", "RotateColumns", "RotateHoisted", "Conjugate", "AddConst", "MultByConst", "MultByi", "DivByi"):
+        assert re.search(r"func \(eval \*deviceEvaluator\) %s\(" % meth, ck), meth
+    bf = open(OVERLAYS["bfv"]).read()
+    for meth in ("Mul", "switchKeys", "relinearize", "Relinearize"):
+        assert re.search(r"func \(eval \*deviceEvaluator\) %s\(" % meth, bf), meth
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/ckks"), reason="the reference tree exists only in the build container")
+def test_overlays_name_upstream_identifiers_that_exist():
+    """every unexported upstream identifier the overlays lean on (fields, helpers) exists in the reference's package sources"""
+    for pkg, idents in (("ckks", ["getElemAndCheckBinary", "ckksContext", "contextQ", "contextP", "evakeyRotColLeft", "evakeyConjugate",
+                                  "permuteNTTLeftIndex", "DropLevel", "GaloisGen", "Alpha()", "Resize(", "DivScale("]),
+                        ("bfv", ["getElemAndCheckBinary", "bfvContext", "contextQMul", "keyswitchpool", "SetValue(", "evakey.evakey"])):
+        src = "\n".join(open(os.path.join("/root/reference", pkg, f)).read() for f in os.listdir(os.path.join("/root/reference", pkg))
+                        if f.endswith(".go") and not f.endswith("_test.go"))
+        overlay = open(OVERLAYS[pkg]).read()
+        for ident in idents:
+            assert ident in overlay, (pkg, ident, "no longer used by the overlay")
+            assert ident in src, (pkg, ident, "not in the reference package")

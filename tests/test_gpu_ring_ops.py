@@ -683,3 +683,38 @@ def test_shared_context_two_threads(gpu_pkg, oracle):
                 if twice:
                     want = oc.rescale_op("oc_div_floor_by_last_modulus_ntt", want)
                 assert np.array_equal(got[b], want), (tid, twice, b)
+
+
+def test_per_limb_upload_download_and_host_limb_transform(gpu_pkg, oracle):
+    """lr_poly_upload_limb / lr_poly_download_limb / lr_ntt_host_limb: the forms the go 1.13 shim uses (one Go pointer per call, none
+    stored in C memory); same bytes as the pointer-array forms, and the package-level ring.NTT / ring.InvNTT on one limb"""
+    import ctypes as C
+    nat = gpu_pkg._native
+    lib = nat.lib()
+    N, moduli = 1 << 11, list(gpu_pkg.params.Qi60()[:3])
+    ctx = gpu_pkg.ring.NewContextWithParams(N, moduli)
+    x = gpu_pkg.sampling.uniform_poly(moduli, N, 2, seed=17)
+    p = ctx.NewPoly(2)
+    for b in range(2):
+        for i in range(3):
+            row = np.ascontiguousarray(x[b, i])
+            nat.check(lib.lr_poly_upload_limb(p.h, b, i, row.ctypes.data_as(C.c_void_p)))
+    assert np.array_equal(p.get(), x)
+    ctx.NTT(p, p)
+    oc = oracle.Context(N, moduli)
+    for b in range(2):
+        want = oc.ntt(x[b])
+        for i in range(3):
+            got = np.empty(N, dtype=np.uint64)
+            nat.check(lib.lr_poly_download_limb(p.h, b, i, got.ctypes.data_as(C.c_void_p)))
+            assert np.array_equal(got, want[i])
+    for bad in ((2, 0), (0, 3), (-1, 0)):
+        assert lib.lr_poly_upload_limb(p.h, bad[0], bad[1], x[0, 0].ctypes.data_as(C.c_void_p)) != 0
+    # one limb under modulus 1, host slices, forward then inverse in place
+    row = np.ascontiguousarray(x[1, 1])
+    out = np.empty(N, dtype=np.uint64)
+    nat.check(lib.lr_ntt_host_limb(ctx.h, 1, 0, row.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p)))
+    assert np.array_equal(out, oc.ntt(x[1])[1])
+    nat.check(lib.lr_ntt_host_limb(ctx.h, 1, 1, out.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p)))
+    assert np.array_equal(out, row)
+    assert lib.lr_ntt_host_limb(ctx.h, 3, 0, row.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p)) != 0
