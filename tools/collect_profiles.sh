@@ -2,12 +2,13 @@
 # Collects the rocprofv3 evidence bench.py's numbers are judged against (run on the GPU box through gpurun):
 #   kernel-trace statistics of the bench command and of the MulRelin loop; PMC passes (separate runs, no trace domains) for
 #   the HBM bytes and VALU / LDS utilisation of the forward NTT launch and for the HBM bytes of one MulRelin product; the
-#   per-phase timeline of the headline kernel.  Output: gpurun_out/prof_r02/* (copy what is to be judged into profiles/r02/).
+#   per-phase timeline of the headline kernel.  The traced bench runs with --no-traffic: bench.py's own rocprofv3 --pmc child passes are
+#   not nested inside the outer profiler (the PMC passes are collected separately below and by tools/collect_r03_pmc.sh).  Output: gpurun_out/prof_r03/* (copy what is to be judged into profiles/r03/).
 set -e
-OUT=/root/repo/gpurun_out/prof_r02
+OUT=/root/repo/gpurun_out/prof_r03
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o bench -- python3 /root/repo/bench.py --no-cpu-baseline --steps 50 --warmup 5 > $OUT/bench_under_rocprof.json 2> $OUT/bench_under_rocprof.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o bench -- python3 /root/repo/bench.py --no-cpu-baseline --no-traffic --no-threads --steps 50 --warmup 5 > $OUT/bench_under_rocprof.json 2> $OUT/bench_under_rocprof.err
 cp $OUT/trace/*kernel_stats.csv $OUT/kernel_stats.csv
 echo "bench trace done"
 for c in FETCH_SIZE WRITE_SIZE; do
@@ -27,7 +28,7 @@ done
 echo "mulrelin pmc done"
 python3 - <<'PY'
 import csv, collections, json, glob, os
-out = "/root/repo/gpurun_out/prof_r02"
+out = "/root/repo/gpurun_out/prof_r03"
 def counters(dirname, keep):
     acc = collections.defaultdict(list)
     for f in glob.glob(os.path.join(out, dirname, "**", "*counter_collection.csv"), recursive=True):
@@ -77,5 +78,5 @@ for tag, name, nq, np_, N in (("mr", "PN15QP880", 18, 3, 32768), ("mr16", "PN16Q
               open(os.path.join(out, "mulrelin_pmc_hbm.json" if tag == "mr" else "mulrelin16_pmc_hbm.json"), "w"), indent=1)
 print(json.dumps(res))
 PY
-LR_NTT_TIMELINE=1 python3 /root/repo/tools/timeline.py $OUT/timeline_fwd15.json
+python3 /root/repo/tools/timeline.py fwd qi60 $OUT/timeline_fwd15_qi60.json
 head -14 $OUT/kernel_stats.csv
