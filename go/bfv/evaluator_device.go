@@ -1,66 +1,73 @@
-// Overlay for github.com/ldsec/lattigo/bfv (v1.3.1): drop this file into the package next to the upstream evaluator.go, with the
-// module's ring package replaced by go/ring of this repository (INTEGRATION.md section 3).
+// Replacement bodies for github.com/ldsec/lattigo/bfv (v1.3.1), evaluator.go: this file is added to the package, the module's ring
+// package is replaced by go/ring of this repository (INTEGRATION.md section 3), and the upstream bodies of the methods defined here are
+// DELETED from evaluator.go (same receivers and signatures: Go has no virtual dispatch, see go/ckks/evaluator_device.go).
 //
 // NOT COMPILED IN THIS REPOSITORY'S PIPELINE (no Go toolchain in the image); statically checked by tests/test_go_shim.py.
 //
-// Method by method (upstream line numbers in bfv/evaluator.go):
+// The patch to upstream bfv/evaluator.go, line numbers of v1.3.1:
 //
-//	Mul / tensorAndRescale :278-470   degree-1 x degree-1: ONE call, BfvPlan.Mul (extension to QMul, transforms, tensor, division by Q
-//	                                  with the float-corrected extension, centring, extension back, times t); other degrees: upstream
-//	relinearize            :480-501   degree 2: ONE call, CkksPlan.BfvRelinearize (key switch + the two Adds); higher degrees: the
-//	                                  upstream loop over switchKeys below
-//	switchKeys             :736-812   CkksPlan.BfvSwitchKeys (the per-modulus loops over Coeffs at :776-792 are inside the pipeline)
-//
-// Direct Coeffs indexing elsewhere in the upstream evaluator: tensorAndRescale's copy into polyBig (:430-436) is inside BfvPlan.Mul for
-// the degree-1 case and runs on the host, bracketed by HostView / HostWritten, for the others.  Add / Sub / Neg / MulScalar go through
-// Context methods and need nothing here; rotations (:560-730) use switchKeys through this type.
+//	delete  Mul          :467-470   -> below: degree 1 x degree 1 is ONE call, BfvPlan.Mul (extension to QMul, transforms, tensor, division by
+//	                                   Q with the float-corrected extension, centring, extension back, times t); other degrees go
+//	                                   through upstream's tensorAndRescale (:278-464, kept) on host views -- its copy loop into
+//	                                   polyBig (:430-436) indexes Coeffs
+//	delete  relinearize  :480-501   -> below: degree 2 is ONE call, CkksPlan.BfvRelinearize (key switch + the two Adds); higher degrees
+//	                                   keep upstream's loop over switchKeys
+//	delete  switchKeys   :736-812   -> below: CkksPlan.BfvSwitchKeys (the per-modulus loops over Coeffs at :776-792 live inside the pipeline)
+//	keep    Relinearize :512, SwitchKeys :539, the rotations :560-730 (they call relinearize / switchKeys / Context.Permute), Add / Sub /
+//	        Neg / MulScalar (Context methods)
 package bfv
 
 import (
+	"sync"
+
 	"github.com/ldsec/lattigo/ring"
 )
 
-type deviceEvaluator struct {
-	*evaluator
+type deviceState struct {
 	mul  *ring.BfvPlan
-	ks   *ring.CkksPlan // decomposer, baseconverterQ1P and key-switch pools of :100-112, on the device
+	ks   *ring.CkksPlan // decomposer, baseconverterQ1P and key-switch pools of :89-112, on the device
 	keys map[*SwitchingKey]*ring.Poly
 }
 
-// NewDeviceEvaluator = NewEvaluator (:89) + the two plans.
-func NewDeviceEvaluator(params *Parameters) Evaluator {
-	base := NewEvaluator(params).(*evaluator)
-	ctx := base.bfvContext
-	ev := &deviceEvaluator{evaluator: base, keys: map[*SwitchingKey]*ring.Poly{}}
-	ev.mul = ring.NewBfvPlan(ctx.contextQ, ctx.contextQMul, params.T, 1)
-	if len(params.Pi) != 0 {
-		ev.ks = ring.NewCkksPlan(ctx.contextQ, ctx.contextP, 1)
+var deviceStates sync.Map // *evaluator -> *deviceState
+
+func (evaluator *evaluator) dev() *deviceState {
+	if s, ok := deviceStates.Load(evaluator); ok {
+		return s.(*deviceState)
 	}
-	return ev
+	ctx := evaluator.bfvContext
+	s := &deviceState{keys: map[*SwitchingKey]*ring.Poly{}}
+	s.mul = ring.NewBfvPlan(ctx.contextQ, ctx.contextQMul, evaluator.params.T, 1)
+	if evaluator.baseconverterQ1P != nil {
+		s.ks = ring.NewCkksPlan(ctx.contextQ, ctx.contextP, 1)
+	}
+	actual, _ := deviceStates.LoadOrStore(evaluator, s)
+	return actual.(*deviceState)
 }
 
-func (eval *deviceEvaluator) keyImage(k *SwitchingKey) *ring.Poly {
-	if img, ok := eval.keys[k]; ok {
+func (evaluator *evaluator) keyImage(k *SwitchingKey) *ring.Poly {
+	s := evaluator.dev()
+	if img, ok := s.keys[k]; ok {
 		return img
 	}
-	img := eval.ks.SwitchingKeyImage(k.evakey)
-	eval.keys[k] = img
+	img := s.ks.SwitchingKeyImage(k.evakey)
+	s.keys[k] = img
 	return img
 }
 
-func (eval *deviceEvaluator) resident(ps ...*ring.Poly) {
-	q := eval.bfvContext.contextQ
+func (evaluator *evaluator) resident(ps ...*ring.Poly) {
+	q := evaluator.bfvContext.contextQ
 	for _, p := range ps {
 		p.Pin(q)
 	}
 }
 
 // Mul (:467): degree-1 x degree-1 on the device; anything else through upstream's tensorAndRescale on host views.
-func (eval *deviceEvaluator) Mul(op0 *Ciphertext, op1 Operand, ctOut *Ciphertext) {
-	el0, el1, elOut := eval.getElemAndCheckBinary(op0, op1, ctOut, op0.Degree()+op1.Degree())
+func (evaluator *evaluator) Mul(op0 *Ciphertext, op1 Operand, ctOut *Ciphertext) {
+	el0, el1, elOut := evaluator.getElemAndCheckBinary(op0, op1, ctOut, op0.Degree()+op1.Degree())
 	if el0.Degree() == 1 && el1.Degree() == 1 {
-		eval.resident(el0.value[0], el0.value[1], el1.value[0], el1.value[1], elOut.value[0], elOut.value[1], elOut.value[2])
-		eval.mul.Mul([2]*ring.Poly{el0.value[0], el0.value[1]}, [2]*ring.Poly{el1.value[0], el1.value[1]},
+		evaluator.resident(el0.value[0], el0.value[1], el1.value[0], el1.value[1], elOut.value[0], elOut.value[1], elOut.value[2])
+		evaluator.dev().mul.Mul([2]*ring.Poly{el0.value[0], el0.value[1]}, [2]*ring.Poly{el1.value[0], el1.value[1]},
 			[3]*ring.Poly{elOut.value[0], elOut.value[1], elOut.value[2]})
 		return
 	}
@@ -70,24 +77,24 @@ func (eval *deviceEvaluator) Mul(op0 *Ciphertext, op1 Operand, ctOut *Ciphertext
 	for _, p := range el1.value {
 		p.HostView()
 	}
-	eval.evaluator.Mul(op0, op1, ctOut)
+	evaluator.tensorAndRescale(el0, el1, elOut)
 	for _, p := range elOut.value {
 		p.HostWritten()
 	}
 }
 
 // switchKeys (:736).
-func (eval *deviceEvaluator) switchKeys(cx *ring.Poly, evakey *SwitchingKey, p0, p1 *ring.Poly) {
-	eval.resident(cx, p0, p1)
-	eval.ks.BfvSwitchKeys(cx, eval.keyImage(evakey), p0, p1)
+func (evaluator *evaluator) switchKeys(cx *ring.Poly, evakey *SwitchingKey, p0, p1 *ring.Poly) {
+	evaluator.resident(cx, p0, p1)
+	evaluator.dev().ks.BfvSwitchKeys(cx, evaluator.keyImage(evakey), p0, p1)
 }
 
 // relinearize (:480).
-func (eval *deviceEvaluator) relinearize(ct0 *Ciphertext, evakey *EvaluationKey, ctOut *Ciphertext) {
-	context := eval.bfvContext.contextQ
+func (evaluator *evaluator) relinearize(ct0 *Ciphertext, evakey *EvaluationKey, ctOut *Ciphertext) {
+	context := evaluator.bfvContext.contextQ
 	if ct0.Degree() == 2 {
-		eval.resident(ct0.value[0], ct0.value[1], ct0.value[2], ctOut.value[0], ctOut.value[1])
-		eval.ks.BfvRelinearize([3]*ring.Poly{ct0.value[0], ct0.value[1], ct0.value[2]}, eval.keyImage(evakey.evakey[0]),
+		evaluator.resident(ct0.value[0], ct0.value[1], ct0.value[2], ctOut.value[0], ctOut.value[1])
+		evaluator.dev().ks.BfvRelinearize([3]*ring.Poly{ct0.value[0], ct0.value[1], ct0.value[2]}, evaluator.keyImage(evakey.evakey[0]),
 			[2]*ring.Poly{ctOut.value[0], ctOut.value[1]})
 		ctOut.SetValue(ctOut.value[:2])
 		return
@@ -96,25 +103,11 @@ func (eval *deviceEvaluator) relinearize(ct0 *Ciphertext, evakey *EvaluationKey,
 		context.Copy(ct0.value[0], ctOut.value[0])
 		context.Copy(ct0.value[1], ctOut.value[1])
 	}
-	p0, p1 := eval.keyswitchpool[2], eval.keyswitchpool[3]
+	p0, p1 := evaluator.keyswitchpool[2], evaluator.keyswitchpool[3]
 	for deg := uint64(ct0.Degree()); deg > 1; deg-- {
-		eval.switchKeys(ct0.value[deg], evakey.evakey[deg-2], p0, p1)
+		evaluator.switchKeys(ct0.value[deg], evakey.evakey[deg-2], p0, p1)
 		context.Add(ctOut.value[0], p0, ctOut.value[0])
 		context.Add(ctOut.value[1], p1, ctOut.value[1])
 	}
 	ctOut.SetValue(ctOut.value[:2])
-}
-
-// Relinearize (:512): upstream's degree checks, then relinearize above.
-func (eval *deviceEvaluator) Relinearize(ct0 *Ciphertext, evakey *EvaluationKey, ctOut *Ciphertext) {
-	if int(ct0.Degree()-1) > len(evakey.evakey) {
-		panic("cannot Relinearize: input ciphertext degree too large to allow relinearization")
-	}
-	if ct0.Degree() < 2 {
-		if ct0 != ctOut {
-			ctOut.Copy(ct0.Element())
-		}
-	} else {
-		eval.relinearize(ct0, evakey, ctOut)
-	}
 }
