@@ -82,19 +82,7 @@ class GenInv(Gen):
                 ("v_add3_u32", ts.C.lo(), ts.C.lo(), ts.C.hi(), ts.T0),
                 ("v_add3_u32", V.hi(), V.hi(), ts.C.lo(), ts.T2),
             ]
-        return [
-            ("v_mul_hi_u32", ts.T0, V.hi(), s0),
-            ("v_mul_hi_u32", ts.T2, V.lo(), s1),
-            ("v_mad_u64_u32", ts.Q, J, V.hi(), s1, ts.T01),
-            ("v_mad_u64_u32", ts.C, J, V.lo(), w1, 0),
-            ("v_lshl_add_u64", ts.Q, ts.Q, 0, ts.T23),
-            ("v_mad_u64_u32", ts.C, J, V.hi(), w0, ts.C),
-            ("v_mad_u64_u32", V, J, V.lo(), w0, 0),
-            ("v_mad_u64_u32", V, J, ts.Q.lo(), self.NQ.lo(), V),
-            ("v_mad_u64_u32", ts.C, J, ts.Q.lo(), self.NQ.hi(), ts.C),
-            ("v_mad_u64_u32", ts.C, J, ts.Q.hi(), self.NQ.lo(), ts.C),
-            ("v_add_u32", V.hi(), V.hi(), ts.C.lo()),
-        ]
+        return self.ops_mulconst(ts, V, tw)
 
     def ops_sum_diff(self, ts, U, V):
         """(U, V) <- (U + V, U + 8q - V)"""

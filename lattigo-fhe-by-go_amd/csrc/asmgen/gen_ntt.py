@@ -42,6 +42,7 @@ class Gen:
         # wave's 51 k clocks on the FP64 body, 21 k for the wave the first barrier waits for: profiles/r03/timeline_fwd15_ckks.json)
         # and the launch gap between two workgroups of a CU overlap with arithmetic
         assert not persist or (logn == 15 and threads == 1024 and not sub and not epi)
+        assert not epi or mode in (1, 2)
         self.persist = persist
         self.karg_parked = False      # timeline builds of kernels that reuse s[0:1]: the inverse ones (gen_intt.py), the persistent ones
         # profile: the timeline build of a plain integer kernel (diagnostics only, Options::timeline): every wave stamps the shader
@@ -56,7 +57,8 @@ class Gen:
         # ModDownSplitedNTTPQ (ring_basis_extension.go:237-239) with the addition that follows it in MulRelin
         # (ckks/evaluator.go:1103-1104), x / plus addressed like the output rows (NttLaunch::epi_*).  Launched on FP64 limbs only.
         # (N = 2^16: only the plain sub-block kernels, i.e. after the top stage has been applied by the basis extension)
-        assert not epi or dual
+        # (the integer bodies carry the same epilogue in integer arithmetic -- ops_epilogue_int -- with the constant as a Shoup pair in the
+        # same 16 bytes: the dual kernels' integer body for the limbs of 2^46 and more, and the pure integer kernels "m1e")
         self.fp, self.dual, self.epi = fp, dual, epi
         self.karg_parked = bool(profile and persist)
         self.fuse_last = False        # inverse sub-block kernels (gen_intt.py): the last stage by whichever block of the pair finishes second
@@ -372,6 +374,34 @@ class Gen:
             ("v_sub_co_u32", V.lo(), ts.CY, ts.R.lo(), U.lo()),
             ("v_subb_co_u32", V.hi(), ts.CY, ts.R.hi(), U.hi(), ts.CY)]   # Y
         return ops
+
+    def ops_mulconst(self, ts, V, tw):
+        """V <- V * w - qhat * q, lazy in [0, 4q), for any 64-bit V (the inverse kernels' in-place product, gen_intt.py)"""
+        w0, w1, s0, s1 = tw
+        J = self.JUNK
+        return [("v_mul_hi_u32", ts.T0, V.hi(), s0),
+                ("v_mul_hi_u32", ts.T2, V.lo(), s1),
+                ("v_mad_u64_u32", ts.Q, J, V.hi(), s1, ts.T01),
+                ("v_mad_u64_u32", ts.C, J, V.lo(), w1, 0),
+                ("v_lshl_add_u64", ts.Q, ts.Q, 0, ts.T23),
+                ("v_mad_u64_u32", ts.C, J, V.hi(), w0, ts.C),
+                ("v_mad_u64_u32", V, J, V.lo(), w0, 0),
+                ("v_mad_u64_u32", V, J, ts.Q.lo(), self.NQ.lo(), V),
+                ("v_mad_u64_u32", ts.C, J, ts.Q.lo(), self.NQ.hi(), ts.C),
+                ("v_mad_u64_u32", ts.C, J, ts.Q.hi(), self.NQ.lo(), ts.C),
+                ("v_add_u32", V.hi(), V.hi(), ts.C.lo())]
+
+    def ops_epilogue_int(self, ts, Y, X, P, EC):
+        """Y (the transform's value, lazy) <- canonical ((x - Y) * c + plus) mod q on the integer pipe; x, plus: any values below 2^63
+        (the callers pass canonical residues); c as the Shoup pair (c, floor(c 2^64 / q)) in the 16 bytes an FP64 limb keeps (c, c/q) in:
+        Y -> [0, 2q) (5), D = x + 4q - Y in (x + 2q, x + 4q] (3), D * c lazy in [0, 4q) (11), + plus (1), canonical (10)"""
+        ops = self.ops_reduce_2q(ts, Y)
+        ops += [("v_lshl_add_u64", X, X, 0, self.Q4),
+                ("v_sub_co_u32", Y.lo(), ts.CY, X.lo(), Y.lo()),
+                ("v_subb_co_u32", Y.hi(), ts.CY, X.hi(), Y.hi(), ts.CY)]
+        ops += self.ops_mulconst(ts, Y, EC)
+        ops += [("v_lshl_add_u64", Y, Y, 0, P)]
+        return ops + self.ops_canon(ts, Y)
 
     def ops_reduce_2q(self, ts, X):
         """X <- X - floor(X * u0 / 2^64) * q in [0, 2q) for any 64-bit X; u0 = floor(2^64 / q) < 2^32
@@ -1093,7 +1123,7 @@ class Gen:
         e("s_addc_u32", self.TMP.hi(), self.DST.hi(), 0)
         n = 8
         regs = [v(4 * i, 4) for i in range(n)]
-        if self.fp and self.epi:
+        if self.epi:
             self.copy_out_epilogue(half, regs, a0, a2)
         else:
             for i in range(n):
@@ -1170,7 +1200,7 @@ class Gen:
         e("s_lshl_b32", sc[3], sc[1], 4)
         e("s_add_u32", self.TMP.lo(), s(K + 8), sc[3])
         e("s_addc_u32", self.TMP.hi(), s(K + 9), 0)
-        e("s_load_dwordx4", s(K + 24, 4), self.TMP, 0)         # EpiLimb: c, c / q as doubles
+        e("s_load_dwordx4", s(K + 24, 4), self.TMP, 0)         # EpiLimb: c, c / q as doubles (FP64 limbs) / c and its Shoup companion
         e("s_waitcnt", "lgkmcnt(0)")                           # (scalar loads return out of order: no counting across them)
         EC = tuple(s(K + 24 + i) for i in range(4))
         # restore the store pointer (TMP was scratch): dst + wave * 8192
@@ -1196,8 +1226,9 @@ class Gen:
                 # loads return in order: at most the 2*(3-i) younger loads of this batch may still be out (stores issued
                 # in between can only make the wait longer)
                 e("s_waitcnt", "vmcnt(%d) lgkmcnt(%d)" % (2 * (3 - i), n - 1 - k))
-                self.zip_emit([(lambda ts, y=r.sub(0, 2), x=XQ[i].sub(0, 2), pp=PQ[i].sub(0, 2): self.ops_epilogue(ts, y, x, pp, EC)),
-                               (lambda ts, y=r.sub(2, 2), x=XQ[i].sub(2, 2), pp=PQ[i].sub(2, 2): self.ops_epilogue(ts, y, x, pp, EC))])
+                epi = self.ops_epilogue if self.fp else self.ops_epilogue_int
+                self.zip_emit([(lambda ts, y=r.sub(0, 2), x=XQ[i].sub(0, 2), pp=PQ[i].sub(0, 2): epi(ts, y, x, pp, EC)),
+                               (lambda ts, y=r.sub(2, 2), x=XQ[i].sub(2, 2), pp=PQ[i].sub(2, 2): epi(ts, y, x, pp, EC))])
             for i in range(4):
                 k = 4 * batch + i
                 e("global_store_dwordx4", a2, regs[k], self.TMP, hint="nt")
@@ -1337,6 +1368,8 @@ if __name__ == "__main__":
     threads = int(sys.argv[4]) if len(sys.argv) > 4 else 1024
     # mode 3: FP64 body for the limbs below 2^46, the integer body of mode 2 for the others (every modulus below 2^57)
     def make(logn_, threads_, **kw):
+        if mode == 5:   # "m5": the integer kernel of mode 1 (q <= 2^60) with the subtract-multiply-add epilogue
+            return Gen(logn_, 1, threads_, epi=True, **kw)
         if mode == 3:
             return Dual(lambda fp: Gen(logn_, 2, threads_, fp=fp, dual=True, **kw))
         if mode == 4:   # mode 3 whose FP64 body ends in the subtract-multiply-add epilogue

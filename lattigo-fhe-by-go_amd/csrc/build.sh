@@ -59,6 +59,11 @@ gen_sub inv 16s 3 & gpids+=($!); gen_sub inv 16f 3 fused & gpids+=($!)
 gen_one fwd 14 4 & gpids+=($!); gen_one fwd 15 4 & gpids+=($!)
 gen_one fwd 14 4 512 & gpids+=($!); gen_one fwd 13 4 256 & gpids+=($!); gen_one fwd 12 4 256 & gpids+=($!)
 gen_sub fwd 16s 4 & gpids+=($!); gen_sub fwd 16p 4 plain & gpids+=($!)
+# mode 5: the integer kernels of mode 1 (q <= 2^60) with the subtract-multiply-add epilogue in integer arithmetic (rescale / ModDown on the
+# reference's 60-bit rings)
+gen_one fwd 14 5 & gpids+=($!); gen_one fwd 15 5 & gpids+=($!)
+gen_one fwd 14 5 512 & gpids+=($!); gen_one fwd 13 5 256 & gpids+=($!); gen_one fwd 12 5 256 & gpids+=($!)
+gen_sub fwd 16s 5 & gpids+=($!); gen_sub fwd 16p 5 plain & gpids+=($!)
 # diagnostics: the 2^15 kernels with per-phase clock stamps (LR_NTT_TIMELINE=1, tools/timeline.py): integer and dual, both directions
 gen_tl() {  # kind mode
   python3 asmgen/gen_$( [ "$1" = fwd ] && echo ntt || echo intt ).py 15 build/ntt_${1}15_m${2}t.s $2 1024 timeline
@@ -81,6 +86,7 @@ names = [("fwd", n, m) for n in (14, 15) for m in (0, 1, 2)] + [("inv", n, m) fo
 names += [("fwd", n, m) for n in ("12x", "13x", "14x", "16s", "16p") for m in (0, 1, 2)] + [("inv", n, m) for n in ("12x", "13x", "14x", "16s", "16f") for m in (0, 1)]
 names += [("fwd", n, 3) for n in (14, 15, "12x", "13x", "14x", "16s", "16p")] + [("inv", n, 3) for n in (14, 15, "12x", "13x", "14x", "16s", "16f")]
 names += [("fwd", n, 4) for n in (14, 15, "12x", "13x", "14x", "16s", "16p")]
+names += [("fwd", n, 5) for n in (14, 15, "12x", "13x", "14x", "16s", "16p")]
 names = [(k, n, str(m)) for k, n, m in names] + [(k, 15, m) for k in ("fwd", "inv") for m in ("1t", "3t")]
 names += [("fwd", "15p", m) for m in ("0", "1", "2", "3", "1t", "3t")]
 for k, n, m in names:

@@ -149,6 +149,7 @@ lr::Options lr::Options::from_env() {
     o.no_asm = std::getenv("LR_NO_ASM") != nullptr;
     o.no_fp = std::getenv("LR_NO_FP") != nullptr;
     o.no_epilogue = std::getenv("LR_NO_EPILOGUE") != nullptr;
+    o.no_int_epilogue = std::getenv("LR_NO_INT_EPILOGUE") != nullptr;
     o.rescale_unfused = std::getenv("LR_RESCALE_UNFUSED") != nullptr;
     o.no_staging = std::getenv("LR_NO_STAGING") != nullptr;
     o.ext_narrow = std::getenv("LR_EXT_NARROW") != nullptr;
@@ -897,7 +898,7 @@ struct Rows {  // a strided view of rows inside a batch buffer
 };
 
 // hole/group: digit groups of NttLaunch (the polys of group g skip the items [g*hole, (g+1)*hole))
-// epilogue of the forward FP64 kernels (NttLaunch::epi_*); every limb of the launch must be below 2^46 (ntt_epilogue_ok)
+// epilogue of the forward kernels (NttLaunch::epi_*); every limb of the launch must take it (ntt_epilogue_limb)
 struct NttEpilogue {
     const u64 *x;
     long long x_stride;
@@ -907,9 +908,28 @@ struct NttEpilogue {
 };
 
 // N = 2^16: the input rows either carry the top stage already (`pretop`) or are disjoint from the output rows
+// The forward kernels with the subtract-multiply-add epilogue: the dual kernels "m4" (FP64 body below 2^46, integer body -- mode 2 -- for
+// the other limbs) where the context runs the dual kernels, the integer kernels "m5" where it runs mode 1 (q <= 2^60: the reference's
+// 60-bit rings).  Contexts on the other integer variants (q up to 2^61, or every modulus in [2^46, 2^57)) keep the separate pass.
 bool ntt_epilogue_ok(const lr_context *c) {
     const unsigned logn = c->h.logN;
-    return c->use_asm && c->asm_fwd == 3 && logn >= 12 && logn <= 16 && ntt_asm_available((int)logn) && !c->opt.no_epilogue;
+    if (!c->use_asm || logn < 12 || logn > 16 || !ntt_asm_available((int)logn) || c->opt.no_epilogue) return false;
+    return c->asm_fwd == 3 || (c->asm_fwd == 1 && !c->opt.no_int_epilogue);
+}
+// does limb l of the context take the epilogue (otherwise: plain transform + submul_kernel)?
+bool ntt_epilogue_limb(const lr_context *c, int l) {
+    if (!ntt_epilogue_ok(c)) return false;
+    return c->asm_fwd == 1 || c->h.q[l] < kFpLimit || !c->opt.no_int_epilogue;
+}
+// the epilogue constant cc (plain domain, below q) of limb l in the form that limb's kernel body reads
+EpiLimb make_epi_limb(const lr_context *c, int l, u64 cc) {
+    const u64 q = c->h.q[l];
+    if (c->asm_fwd == 3 && q < kFpLimit) return EpiLimb{(double)cc, (double)cc / (double)q};
+    const u64 pair[2] = {cc, shoup_companion(cc, q)};
+    EpiLimb e;
+    static_assert(sizeof(e) == sizeof(pair), "EpiLimb is 16 bytes");
+    std::memcpy(&e, pair, sizeof e);
+    return e;
 }
 
 int run_ntt_launch(lr_context *c, bool inverse, Rows in, Rows out, int mod0, int mod_step, int count, int batch, int hole,
@@ -1005,9 +1025,9 @@ int run_ntt_launch(lr_context *c, bool inverse, Rows in, Rows out, int mod0, int
         a.epi_plus_stride = epi->plus_stride;
         a.epi_consts = epi->consts;
         if (logn == 16)
-            LR_HIP(launch_ntt_asm16(a, 0, pretop ? 'p' : 's', 4, c->stream, kn, c->opt.stagger));
+            LR_HIP(launch_ntt_asm16(a, 0, pretop ? 'p' : 's', c->asm_fwd == 3 ? 4 : 5, c->stream, kn, c->opt.stagger));
         else
-            LR_HIP(launch_ntt_asm(a, (int)logn, 0, 4, c->stream, c->opt.asm14_1024, kn, false, c->opt.stagger));
+            LR_HIP(launch_ntt_asm(a, (int)logn, 0, c->asm_fwd == 3 ? 4 : 5, c->stream, c->opt.asm14_1024, kn, false, c->opt.stagger));
         return LR_OK;
     }
     if (logn == 16 && variant >= 0 && c->use_asm && ntt_asm_available(16)) {
@@ -1519,7 +1539,7 @@ extern "C" int lr_bext_create(lr_context *cQ, lr_context *cP, lr_bext **out) {
         std::vector<EpiLimb> ec(cQ->h.L());
         for (int i = 0; i < cQ->h.L(); ++i) {
             const u64 q = cQ->h.q[i], cc = inv_mform(b->moddown_pq[i], q, cQ->h.mred[i]);
-            ec[i] = q < kFpLimit ? EpiLimb{(double)cc, (double)cc / (double)q} : EpiLimb{0.0, 0.0};
+            ec[i] = make_epi_limb(cQ, i, cc);
         }
         LR_TRY(to_device(&b->d_moddown_pq_epi, ec.data(), ec.size()));
     }
@@ -1992,7 +2012,7 @@ int rescale_round_table(lr_context *c, int level, const u64 **out, const EpiLimb
         std::vector<EpiLimb> ec(c->h.L());
         for (int i = 0; i < level; ++i) {
             const u64 q = c->h.q[i], cc = inv_mform(c->h.rescale[(size_t)(level - 1) * c->h.L() + i], q, c->h.mred[i]);
-            ec[i] = q < kFpLimit ? EpiLimb{(double)cc, (double)cc / (double)q} : EpiLimb{0.0, 0.0};
+            ec[i] = make_epi_limb(c, i, cc);
         }
         LR_TRY(to_device(&g.epi, ec.data(), ec.size()));
     }
@@ -2032,9 +2052,9 @@ int rescale_ntt_domain(lr_context *c, lr_poly *p0, bool round) {
         const long long n64 = (long long)n;
         int l0 = 0;
         while (l0 < level) {
-            const bool fpc = c->h.q[l0] < kFpLimit;
+            const bool fpc = ntt_epilogue_limb(c, l0);
             int l1 = l0 + 1;
-            while (l1 < level && (c->h.q[l1] < kFpLimit) == fpc) ++l1;
+            while (l1 < level && ntt_epilogue_limb(c, l1) == fpc) ++l1;
             if (fpc) {
                 const NttEpilogue ep{p0->d, p0->stride(), plus, 0, ec};
                 Rows dst{p0->d, p0->stride(), l0, 1};
@@ -2399,9 +2419,9 @@ int ks_accumulate(lr_ckks_plan *pl, int level, int batch, const u64 *digQ, const
             }
             int l0 = 0;
             while (l0 <= level) {
-                const bool fpc = cQ->h.q[l0] < kFpLimit;
+                const bool fpc = ntt_epilogue_limb(cQ, l0);
                 int l1 = l0 + 1;
-                while (l1 <= level && (cQ->h.q[l1] < kFpLimit) == fpc) ++l1;
+                while (l1 <= level && ntt_epilogue_limb(cQ, l1) == fpc) ++l1;
                 if (fpc) {
                     for (int k = 0; k < 2; ++k) {
                         Rows src{ext_out + (long long)k * batch * sQ, sQ, l0, 1};

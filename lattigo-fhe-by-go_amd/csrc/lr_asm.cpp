@@ -77,7 +77,7 @@ hipError_t launch_ntt_asm(const NttLaunch &a, int logn, int inverse, int variant
                           int stagger, int persist) {
     AsmKernels *k = kernels_for_current_device();
     if (!k || logn < 12 || logn > 15) return hipErrorNotSupported;
-    if (persist > 0 && (logn != 15 || inverse || variant > 3)) persist = 0;
+    if (persist > 0 && (logn != 15 || inverse || variant > 3)) persist = 0;     // (no persistent form of the epilogue kernels m4 / m5)
     // N = 2^12 (256 threads, four columns per thread, 36 KiB LDS image) and N = 2^13, 2^14 (512 threads, two columns,
     // 72 KiB) run several workgroups per CU: one
     // covers the other's load and store phases.  wide14 (Options::asm14_1024) selects the 1024-thread kernels (testing aid).
@@ -88,7 +88,8 @@ hipError_t launch_ntt_asm(const NttLaunch &a, int logn, int inverse, int variant
     if (it == k->fn.end()) return hipErrorNotSupported;
     if (kernel_name) std::snprintf(kernel_name, 32, "%s", name);
     if (a.n_items <= 0 || a.batch <= 0) return hipSuccess;
-    if (variant < 3 && a.hole == 0 && a.batch > 65535) return hipErrorInvalidValue;   // run_ntt chunks such launches
+    const bool swapped = variant == 3 || variant == 4;        // dual kernels: x = polynomial (gen_ntt.py: swap_grid)
+    if (!swapped && a.hole == 0 && a.batch > 65535) return hipErrorInvalidValue;   // run_ntt chunks such launches
     NttLaunch args = a;
     size_t size = sizeof(NttLaunch);
     void *extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
@@ -110,9 +111,9 @@ hipError_t launch_ntt_asm(const NttLaunch &a, int logn, int inverse, int variant
         args.fuse_top = persist;
         gy = (gy + (unsigned)persist - 1) / (unsigned)persist;
     }
-    const unsigned gx = variant >= 3 ? gy : (unsigned)a.n_items, gyy = variant >= 3 ? (unsigned)a.n_items : gy;
+    const unsigned gx = swapped ? gy : (unsigned)a.n_items, gyy = swapped ? (unsigned)a.n_items : gy;
     args.stagger_gx = (int)gx;
-    args.stagger_unit = stagger_unit(stagger, threads == 1024, variant >= 3, (unsigned long long)gx * gyy * gz);
+    args.stagger_unit = stagger_unit(stagger, threads == 1024, swapped, (unsigned long long)gx * gyy * gz);
     return hipModuleLaunchKernel(it->second, gx, gyy, gz, threads, 1, 1, 0, stream, nullptr, extra);
 }
 

@@ -31,6 +31,7 @@ struct Options {
     bool no_asm = false;           // LR_NO_ASM: C++ NTT kernels only
     bool no_fp = false;            // LR_NO_FP: integer bodies for every modulus
     bool no_epilogue = false;      // LR_NO_EPILOGUE: separate subtract-multiply instead of the forward kernels' epilogue
+    bool no_int_epilogue = false;  // LR_NO_INT_EPILOGUE: the epilogue on the FP64 bodies only (limbs of 2^46 and more keep the separate pass)
     bool rescale_unfused = false;  // LR_RESCALE_UNFUSED: the rounding rescale with explicit shifted copies
     bool no_staging = false;       // LR_NO_STAGING: N = 2^16 key switch with in-place forward transforms
     bool ext_narrow = false;       // LR_EXT_NARROW: per-term basis extension instead of the 128-bit column sums
@@ -58,6 +59,8 @@ struct FpLimb {
     double n_inv, n_inv_q;      // N^-1 mod q and RN(n_inv / q): the scaling of the inverse transform
 };
 
+// constant of the forward kernels' epilogue, 16 bytes per limb: (c, RN(c / q)) as doubles for a limb the FP64 body takes, the Shoup pair
+// (c, floor(c 2^64 / q)) as two u64 in the same bytes for a limb on an integer body (make_epi_limb, lr_abi.cpp)
 struct EpiLimb { double c, c_over_q; };
 
 // Addressing of one NTT launch.  Work item (b, i): batch element b, i-th limb of the launch.
@@ -93,7 +96,7 @@ struct NttLaunch {
     long long epi_x_stride;
     const u64 *epi_plus;
     long long epi_plus_stride;
-    const EpiLimb *epi_consts;  // [L]: c and RN(c / q) as doubles, indexed like lp
+    const EpiLimb *epi_consts;  // [L]: per limb (c, RN(c / q)) as doubles or the Shoup pair of c (EpiLimb), indexed like lp
     // assembly kernels: start-up stagger of the first round of workgroups (gen_ntt.py: stagger), set by the launcher
     int stagger_gx;             // the grid's x extent (linear workgroup id = x + stagger_gx * y)
     int stagger_unit;           // kilo-clocks per step of the 16-step start offset; 0 = all workgroups start at once

@@ -95,8 +95,9 @@ def emulate(gen, inverse=False, q=None, geom=None):
     fp_tables(np, q, n_inv, tw, twf, lambda a, b, c: (place(a, A_FTW), place(b, A_FTWF), place(c, A_FLP)))
     karg = np.zeros(22, dtype=np.uint64)
     karg[13], karg[14], karg[15] = A_FTW - A_TW, A_FTWF - A_TWF, A_FLP
-    if getattr(gen, "epi", False) and q < FP_LIMIT:
-        # x and plus: canonical polys laid out like the output; c: a random constant in (w, w / q) form
+    if getattr(gen, "epi", False):
+        # x and plus: canonical polys laid out like the output; c: a random constant in (w, w / q) form on an FP64 limb, as the Shoup
+        # pair (w, floor(w 2^64 / q)) on an integer one
         rng = np.random.default_rng(7)
         xe = (rng.integers(0, 1 << 62, N, dtype=np.uint64) % np.uint64(q)).astype(np.uint64)
         pe = (rng.integers(0, 1 << 62, N, dtype=np.uint64) % np.uint64(q)).astype(np.uint64)
@@ -106,7 +107,10 @@ def emulate(gen, inverse=False, q=None, geom=None):
         mem = np.concatenate([mem, np.zeros((2 * span + 0x1000) // 4, dtype=np.uint32)])
         place(xe, A_X + where)
         place(pe, A_P + where)
-        place(np.array([ce, np.float64(ce) / np.float64(q)], dtype=np.float64), A_EC)      # modulus index 0
+        if q < FP_LIMIT and getattr(gen, "gf", None) is not None:      # a dual kernel runs this limb on its FP64 body
+            place(np.array([ce, np.float64(ce) / np.float64(q)], dtype=np.float64), A_EC)      # modulus index 0
+        else:
+            place(np.array([ce, (ce << 64) // q], dtype=np.uint64), A_EC)
         karg[16], karg[17], karg[18], karg[19], karg[20] = A_X, rows * N, A_P, rows * N, A_EC
         want = np.array([((int(a) - int(b)) * ce + int(c)) % q for a, b, c in zip(xe, want, pe)], dtype=np.uint64)
     karg[0], karg[1], karg[2], karg[3] = A_IN, A_OUT, rows * N, rows * N
@@ -386,7 +390,7 @@ def emulate_sub(make_gen, inverse, q, pretop=False, order=(0, 1)):
         A_FLAGS = mem.size * 4
         mem = np.concatenate([mem, np.zeros(0x1000 // 4, dtype=np.uint32)])
         karg[16] = A_FLAGS
-    if getattr(make_gen(), "epi", False) and q < FP_LIMIT:
+    if getattr(make_gen(), "epi", False):
         # the epilogue of the plain forward sub-blocks: out = (x - NTT(in)) * c + plus, x / plus laid out like the output
         rng = np.random.default_rng(11)
         xe = (rng.integers(0, 1 << 62, NF, dtype=np.uint64) % np.uint64(q)).astype(np.uint64)
@@ -399,7 +403,10 @@ def emulate_sub(make_gen, inverse, q, pretop=False, order=(0, 1)):
         mem = np.concatenate([mem, np.zeros((16 * NF + 0x3000) // 4, dtype=np.uint32)])
         place(xe, A_X)
         place(pe, A_P)
-        place(np.array([ce, np.float64(ce) / np.float64(q)], dtype=np.float64), A_EC)
+        if q < FP_LIMIT and getattr(make_gen(), "gf", None) is not None:
+            place(np.array([ce, np.float64(ce) / np.float64(q)], dtype=np.float64), A_EC)
+        else:
+            place(np.array([ce, (ce << 64) // q], dtype=np.uint64), A_EC)
         karg[16], karg[17], karg[18], karg[19], karg[20] = A_X, NF, A_P, NF, A_EC
         want = np.array([((int(a) - int(b)) * ce + int(c)) % q for a, b, c in zip(xe, want, pe)], dtype=np.uint64)
     place(karg, A_KARG)
@@ -459,6 +466,15 @@ def selftest(logn, inverse=False, threads=1024):
         print("%s logN=%d T=%d dual q=%d (%d bits): %s; %s" % ("inverse" if inverse else "forward", logn, threads, q, q.bit_length(),
                                                         "bit-exact vs oracle" if good else "MISMATCH", info), flush=True)
     if not inverse:
+        # the integer epilogue: the pure integer kernel of mode 1 ("m5") at both ends of its modulus range, and the dual kernels'
+        # integer body on a modulus just above 2^46
+        for q, mk in [(qq, (lambda: Gen(logn, 1, threads, epi=True))) for qq in (test_moduli(logn, 1)[0], test_moduli(logn, 1)[-1])] + \
+                     [(fp_test_moduli(logn)[2], (lambda: Dual(lambda fp: Gen(logn, 2, threads, fp=fp, dual=True, epi=True))))]:
+            for geom in (None, (2, 1, 1, 2, 3, 6)):
+                good, info = emulate(mk(), False, q, geom)
+                ok = ok and good
+                print("forward logN=%d T=%d integer epilogue q=%d (%d bits): %s; %s" % (logn, threads, q, q.bit_length(),
+                                                                                  "bit-exact vs oracle" if good else "MISMATCH", info), flush=True)
         # the epilogue kernels: out = (x - NTT(in)) * c + plus on the FP64 body, plain and with the digit-group addressing
         for q in fp_test_moduli(logn)[:2]:
             for geom in (None, (2, 1, 1, 2, 3, 6)):
@@ -492,6 +508,18 @@ def selftest_sub(inverse=False):
         ok = ok and good
         print("%s N=2^16 sub-blocks mode %d q=%d (%d bits): %s; %s" % ("inverse" if inverse else "forward", mode, q, q.bit_length(),
                                                                     "bit-exact vs oracle" if good else "MISMATCH", info), flush=True)
+    if not inverse:
+        # the integer epilogue on the sub-block kernels: pure integer ("m5", fused top stage and plain), and the dual kernels' integer body
+        q1 = test_moduli(16, 1)[0]
+        for label, mk, pre in (("m5 fused-top", (lambda: Gen(15, 1, 1024, sub=True, epi=True)), False),
+                               ("m5 plain", (lambda: Gen(15, 1, 1024, sub=True, fused=False, epi=True)), True)):
+            good, info = emulate_sub(mk, False, q1, pretop=pre)
+            ok = ok and good
+            print("forward N=2^16 sub-blocks %s q=%d (%d bits): %s; %s" % (label, q1, q1.bit_length(), "bit-exact vs oracle" if good else "MISMATCH", info), flush=True)
+        q2 = fp_test_moduli(16)[2]
+        good, info = emulate_sub(lambda: Dual(lambda fp: Gen(15, 2, 1024, sub=True, fused=False, fp=fp, dual=True, epi=True)), False, q2, pretop=True)
+        ok = ok and good
+        print("forward N=2^16 sub-blocks dual integer-body epilogue q=%d (%d bits): %s; %s" % (q2, q2.bit_length(), "bit-exact vs oracle" if good else "MISMATCH", info), flush=True)
     for q in fp_test_moduli(16)[:2]:
         if inverse:
             from gen_intt import GenInv

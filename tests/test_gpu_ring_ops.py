@@ -718,3 +718,33 @@ def test_per_limb_upload_download_and_host_limb_transform(gpu_pkg, oracle):
     nat.check(lib.lr_ntt_host_limb(ctx.h, 1, 1, out.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p)))
     assert np.array_equal(out, row)
     assert lib.lr_ntt_host_limb(ctx.h, 3, 0, row.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p)) != 0
+
+
+@pytest.mark.parametrize("logn", [12, 13, 14, 15, 16])
+@pytest.mark.parametrize("path", ["m5", "separate"])
+def test_rounding_rescale_on_the_60_bit_rings(gpu_pkg, oracle, logn, path, monkeypatch):
+    """DivRoundByLastModulusNTT on the reference's benchmark moduli (60-bit: integer kernels of mode 1): by default the subtract-
+    multiply-add rides in the copy-out of the forward kernels "m5" (integer arithmetic, Shoup constant); LR_NO_INT_EPILOGUE keeps the
+    separate pass.  Every coefficient against the oracle, values at and above q included, and a second rescale on the shrunk poly."""
+    if path == "separate":
+        monkeypatch.setenv("LR_NO_INT_EPILOGUE", "1")
+    else:
+        monkeypatch.delenv("LR_NO_INT_EPILOGUE", raising=False)
+    N = 1 << logn
+    Q = list(gpu_pkg.params.Qi60()[:4])
+    ctx = gpu_pkg.ring.NewContextWithParams(N, Q)
+    oc = oracle.Context(N, Q)
+    x = gpu_pkg.sampling.uniform_poly(Q, N, 3, seed=logn)
+    for i, q in enumerate(Q):
+        x[0, i, :5] = [0, q - 1, q, q + 1, 2 * q - 1]          # lazy values, as the reference's callers leave them (ring_scaling.go:19,102)
+    p = ctx.NewPoly(3).set(x)
+    ctx.DivRoundByLastModulusNTT(p)
+    kernel = ctx.last_ntt_kernel()
+    assert ("_m5" in kernel) == (path == "m5"), kernel
+    got = p.get()
+    for b in range(3):
+        assert np.array_equal(got[b], oc.rescale_op("oc_div_round_by_last_modulus_ntt", x[b])), b
+    ctx.DivRoundByLastModulusNTT(p)
+    got = p.get()
+    for b in range(3):
+        assert np.array_equal(got[b], oc.rescale_op("oc_div_round_by_last_modulus_ntt", oc.rescale_op("oc_div_round_by_last_modulus_ntt", x[b])))
