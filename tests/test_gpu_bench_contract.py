@@ -62,6 +62,7 @@ def test_secondary_legs_carry_their_roofs_and_the_rescale_leg():
         assert ex[key]["bit_exact"] is True
         assert r["traffic"] is not None and r["valu"]["issue_frac_sustained"] > 0 and r["bound"] in ("hbm", "valu"), (key, r.get("traffic_source"))
         assert 0.9 < r["traffic"] / r["algorithmic_bytes_per_launch"] < 1.2
+    assert ex["mulcoeffs_montgomery"]["bit_exact"] is True
     rs = ex["div_round_by_last_modulus_ntt"]
     assert rs["bit_exact"] is True and rs["poly_per_s"] > 0 and rs["algorithmic_bytes_per_poly"] == 8 * d["config"]["N"] * (2 * d["config"]["limbs"] - 1)
 
