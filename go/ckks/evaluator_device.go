@@ -21,10 +21,16 @@
 //	                                             power-of-two composer rotateColumnsPow2 :1402-1427 call it and stay as they are)
 //	delete  switchKeysInPlace    :1475-1558   -> below (the loops over Coeffs at :1519-1534 live inside the pipeline)
 //	delete  decomposeAndSplitNTT :1561-1591   (no caller left; its loops at :1580-1586 live inside the pipelines)
-//	bracket AddConst :373, MultByConstAndAdd :451, MultByConst :622, MultByi :746, DivByi :795 -- host loops over half-vectors with
-//	        two constants (:429-445, :588-606, :712-730, :765-779, :814-828): first statement `defer eval.hostLoop(ct0, ctOut)()`
-//	        (below: HostView on the operands now, HostWritten on the result when the method returns); correct on resident
-//	        ciphertexts at the price of one PCIe round trip, and off the path BASELINE.json measures
+//	patch   AddConst :373, MultByConstAndAdd :451, MultByConst :622, MultByi :746, DivByi :795 -- their element loops index Coeffs
+//	        with one constant for the coefficients below n/2 and one for the rest (:429-445, :588-606, :712-730, :765-779, :814-828).
+//	        The constant computation per limb (scaleUpExact, MRed by nttPsi[i][1], MForm) stays as it is; inside the limb loop the
+//	        two `for j` / `for u` blocks are replaced by `lo[i], hi[i] = <constant of the first block>, <constant of the second>`
+//	        (lo, hi := make([]uint64, level+1) before the loop), and after the limb loop ONE line runs the element loops on the
+//	        device: `eval.halfScalar(op, level, ct0, ctOut, lo, hi, first)` (below) with op 0 / first = true for AddConst (value[0]
+//	        only, CRed(x + s)), op 2 for MultByConstAndAdd (CRed(out + MRed(x, s))), op 1 for MultByConst, MultByi, DivByi
+//	        (MRed(x, s)).  Polynomial evaluation (EvaluatePoly*, EvaluateCheby*) calls these between its MulRelin / Rescale steps: with
+//	        the patch a whole evaluation stays on the device.  (Unpatched, the first statement `defer eval.hostLoop(ct0, ctOut)()` keeps
+//	        the upstream loops correct on resident ciphertexts at the price of one PCIe round trip per call.)
 //	keep    DropLevel :901 (it re-slices Coeffs: metadata; the device image is sized by cap(Coeffs) and keeps its stride), RescaleMany
 //	        :971 (Context.DivRoundByLastModulusManyNTT is a device call), Add / Sub / Neg / MulByPow2 / Reduce / ScaleUp (Context methods)
 package ckks
@@ -90,6 +96,19 @@ func (eval *evaluator) hostLoop(in, out *Ciphertext) func() {
 		for _, p := range out.value {
 			p.HostWritten()
 		}
+	}
+}
+
+// halfScalar is the device form of the element loops of AddConst / MultByConstAndAdd / MultByConst / MultByi / DivByi (patch list above):
+// lo[i] / hi[i] are the constants upstream computes for limb i and the two halves of the coefficient vector.
+func (eval *evaluator) halfScalar(op int, level uint64, ct0, ctOut *Ciphertext, lo, hi []uint64, first bool) {
+	context := eval.ckksContext.contextQ
+	for u := range ct0.value {
+		if first && u > 0 {
+			break
+		}
+		eval.resident(ct0.value[u], ctOut.value[u])
+		context.HalfScalarOp(op, level, ct0.value[u], lo, hi, ctOut.value[u])
 	}
 }
 

@@ -284,3 +284,20 @@ func (c *Context) BitReverse(p1, p2 *Poly) {
 	}
 	p2.hostWritten()
 }
+
+// HalfScalarOp runs the element loop of the constant-by-ciphertext methods of ckks.Evaluator on the device (ckks/evaluator.go:429-445,
+// 588-606, 712-730, 765-779, 814-828): for the limbs 0..level, p2[i][j] = OP(p1[i][j], lo[i]) for j < N/2 and OP(p1[i][j], hi[i])
+// above, with op 0 = CRed(x + s), 1 = MRed(x, s), 2 = CRed(p2 + MRed(x, s)).  The overlay go/ckks/evaluator_device.go calls it where
+// the upstream methods loop over Coeffs.
+func (c *Context) HalfScalarOp(op int, level uint64, p1 *Poly, lo, hi []uint64, p2 *Poly) {
+	c.use(p1)
+	if op == 2 {
+		c.use(p2)
+	} else {
+		c.want(p2)
+	}
+	plo := (*C.uint64_t)(unsafe.Pointer(&lo[0]))
+	phi := (*C.uint64_t)(unsafe.Pointer(&hi[0]))
+	call(func() C.int { return C.lr_half_scalar_op(c.h, C.int(op), C.int(level), p1.d, plo, phi, p2.d) })
+	done(p2)
+}

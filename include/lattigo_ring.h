@@ -206,6 +206,12 @@ int lr_ewise(lr_context *ctx, int op, int level, const lr_poly *a, const lr_poly
              const uint64_t *scalars);
 
 /* ------------------------------------------------------------------ Galois automorphisms */
+/* The constant-by-ciphertext methods of ckks.Evaluator index Coeffs directly with one scalar for the coefficients below N/2 and one
+ * for the rest (AddConst ckks/evaluator.go:429-445, MultByConstAndAdd :588-606, MultByConst :712-730, MultByi :765-779, DivByi
+ * :814-828): out[i][j] = OP(in[i][j], j < N/2 ? lo[i] : hi[i]) for the limbs 0..level, with the reference's exact element operation,
+ * op 0: CRed(x + s)   op 1: MRed(x, s)   op 2: CRed(out + MRed(x, s)).  lo / hi: level+1 host words each (the scalars as the
+ * reference computes them: scaleUpExact + MForm, or nttPsi[i][1] and its negation).  in may be out. */
+int lr_half_scalar_op(lr_context *ctx, int op, int level, const lr_poly *in, const uint64_t *lo, const uint64_t *hi, lr_poly *out);
 /* ring.PermuteNTT (ring/ring_galois.go:55) on limbs 0..level: out[i][j] = in[i][index(j)], index(j) =
  * bitrev(((gen * (2*bitrev(j)+1) mod 2N) - 1) / 2), computed on the fly.  PermuteNTTWithIndex (:89) with the
  * table of PermuteNTTIndex(gen, power, N) (:29) is the same call with gen^power mod 2N.  Not in place

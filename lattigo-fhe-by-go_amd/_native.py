@@ -53,6 +53,7 @@ SYMBOLS = {
     "lr_ntt_host": [vp, i32, C.POINTER(u64p), C.POINTER(u64p)],
     "lr_intt_host": [vp, i32, C.POINTER(u64p), C.POINTER(u64p)],
     "lr_ewise": [vp, i32, i32, vp, vp, vp, u64p],
+    "lr_half_scalar_op": [vp, i32, i32, vp, vp, vp, vp],
     "lr_permute_ntt": [vp, i32, vp, u64, vp],
     "lr_permute_ntt_index": [u64, u64, u64, u64p],
     "lr_permute": [vp, vp, u64, vp],

@@ -1267,6 +1267,36 @@ extern "C" int lr_ewise(lr_context *c, int op, int level, const lr_poly *a, cons
 }
 
 // ------------------------------------------------------------------------------------------
+// half-vector scalar operations (the constant-by-ciphertext methods of ckks.Evaluator)
+// ------------------------------------------------------------------------------------------
+extern "C" int lr_half_scalar_op(lr_context *c, int op, int level, const lr_poly *in, const uint64_t *lo, const uint64_t *hi, lr_poly *out) {
+    return guarded([&]() -> int {
+    LR_TRY(check_pair(c, level, in, out));
+    if (in->batch != out->batch) return fail(LR_ERR_SHAPE, "batch mismatch");
+    if (!lo || !hi) return fail(LR_ERR_ARG, "null scalar array");
+    if (op < 0 || op > 2) return fail(LR_ERR_ARG, "half-vector scalar op: 0 = add, 1 = multiply, 2 = multiply and add");
+    if (c->h.N < 4) return fail(LR_ERR_UNSUPPORTED, "half-vector scalar op: ring degree below 4");
+    LR_HIP(hipSetDevice(c->device));
+    HalfScalarLaunch L;
+    L.in = in->d;
+    L.out = out->d;
+    L.in_stride = in->stride();
+    L.out_stride = out->stride();
+    L.n = (int)c->h.N;
+    L.op = op;
+    L.lp = c->d_lp;
+    std::memset(&L.lo, 0, sizeof(L.lo));
+    std::memset(&L.hi, 0, sizeof(L.hi));
+    for (int i = 0; i <= level; ++i) {
+        L.lo.v[i] = lo[i];
+        L.hi.v[i] = hi[i];
+    }
+    LR_HIP(launch_half_scalar(L, level + 1, out->batch, c->stream));
+    return LR_OK;
+    });
+}
+
+// ------------------------------------------------------------------------------------------
 // Galois automorphisms (ring/ring_galois.go)
 // ------------------------------------------------------------------------------------------
 static int permute_common(lr_context *c, int level, const lr_poly *in, u64 gen, lr_poly *out, bool ntt_domain) {

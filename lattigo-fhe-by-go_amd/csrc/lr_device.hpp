@@ -166,6 +166,19 @@ struct RowAddLaunch {
     LimbScalars adds; // per output row
 };
 
+// half-vector scalar operations (the constant-by-ciphertext methods of ckks.Evaluator, ckks/evaluator.go:373-830): coefficients
+// j < n/2 of limb i take the scalar lo[i], the others hi[i] (in the NTT domain the two halves are the slots' real and
+// imaginary... conjugate positions: x^(n/2) acts as +i on one half and -i on the other)
+struct HalfScalarLaunch {
+    const u64 *in;
+    u64 *out;
+    long long in_stride, out_stride;
+    int n;
+    int op;                 // 0: out = CRed(in + s)   1: out = MRed(in, s)   2: out = CRed(out + MRed(in, s))
+    const LimbParams *lp;
+    LimbScalars lo, hi;
+};
+
 // key-switch inner product over all digits (lr_ewise.hip)
 struct KeyMacLaunch {
     const u64 *c2;                 // [beta][batch][limbs][N], NTT domain
@@ -317,6 +330,7 @@ bool ntt_rows_disjoint(const NttLaunch &a, int logn);
 hipError_t launch_ewise(int op, const EwiseLaunch &L, int limbs, int batch, hipStream_t stream);
 hipError_t launch_submul(const SubMulLaunch &L, int limbs, int batch, hipStream_t stream);
 hipError_t launch_rowadd(const RowAddLaunch &L, int rows, int batch, hipStream_t stream);
+hipError_t launch_half_scalar(const HalfScalarLaunch &L, int limbs, int batch, hipStream_t stream);
 hipError_t launch_ext(const ExtLaunch &L, int n_in, int batch, hipStream_t stream);
 bool ext_top_supported(const ExtTables &t, int n_in, int n);
 bool ext_epilogue_supported(const ExtTables &t, int n_in, int n);

@@ -362,6 +362,43 @@ hipError_t launch_rowadd(const RowAddLaunch &L, int rows, int batch, hipStream_t
     return hipGetLastError();
 }
 
+// ---- half-vector scalar operations: AddConst / MultByConst / MultByConstAndAdd / MultByi / DivByi of ckks.Evaluator ------------
+// (ckks/evaluator.go:429-445, 588-606, 712-730, 765-779, 814-828): per limb one scalar for the coefficients below n/2 and one for the
+// rest, the reference's exact element operation -- CRed(x + s), MRed(x, s), CRed(y + MRed(x, s)) -- on values that need not be canonical
+__global__ __launch_bounds__(256) void half_scalar_kernel(HalfScalarLaunch L) {
+    const int limb = blockIdx.y;
+    const long long b = blockIdx.z;
+    const LimbParams lp = L.lp[limb];
+    const u64 slo = L.lo.v[limb], shi = L.hi.v[limb];
+    const ulonglong2 *pi = reinterpret_cast<const ulonglong2 *>(L.in + b * L.in_stride + (long long)limb * L.n);
+    ulonglong2 *po = reinterpret_cast<ulonglong2 *>(L.out + b * L.out_stride + (long long)limb * L.n);
+    const int pairs = L.n >> 1, half = L.n >> 2;       // n / 2 coefficients = n / 4 pairs per half
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < pairs; e += gridDim.x * 256) {
+        const u64 sc = e < half ? slo : shi;
+        const ulonglong2 x = ld_stream(pi + e);
+        ulonglong2 r;
+        if (L.op == 0) {
+            r = make_ulonglong2(cred(x.x + sc, lp.q), cred(x.y + sc, lp.q));
+        } else if (L.op == 1) {
+            r = make_ulonglong2(mred(x.x, sc, lp.q, lp.qinv), mred(x.y, sc, lp.q, lp.qinv));
+        } else {
+            const ulonglong2 y = ld_stream(po + e);
+            r = make_ulonglong2(cred(y.x + mred(x.x, sc, lp.q, lp.qinv), lp.q), cred(y.y + mred(x.y, sc, lp.q, lp.qinv), lp.q));
+        }
+        st_stream(po + e, r);
+    }
+}
+
+hipError_t launch_half_scalar(const HalfScalarLaunch &L, int limbs, int batch, hipStream_t stream) {
+    if (limbs <= 0 || batch <= 0) return hipSuccess;
+    int gx = ((L.n >> 1) + 255) / 256;
+    if (gx > 64) gx = 64;
+    const dim3 grid((unsigned)gx, (unsigned)limbs, (unsigned)batch), block(256);
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(half_scalar_kernel, grid, block, 0, stream, L);
+    return hipGetLastError();
+}
+
 // ---- hybrid key-switch inner product (ckks/evaluator.go:1511-1552) ---------------------------------
 // out0 = sum_i key[i][0] (*) c2[i],  out1 = sum_i key[i][1] (*) c2[i]  over the beta digits, Montgomery products,
 // canonical result.  The reference accumulates digit by digit with MulCoeffsMontgomeryAndAddNoMod and lazy

@@ -349,6 +349,16 @@ class Context:
             check(lib().lr_context_timeline(self.h, out.ctypes.data_as(C.c_void_p), out.size, C.byref(n)))
         return out.reshape(-1, 16, 16)
 
+    def HalfScalarOp(self, op, level, p1, lo, hi, p2):
+        """the element loops of ckks.Evaluator's AddConst / MultByConst / MultByConstAndAdd / MultByi / DivByi (ckks/evaluator.go:429-828):
+        op "ADD" CRed(x + s), "MRED" MRed(x, s), "MRED_ADD" CRed(out + MRed(x, s)); s = lo[i] below N/2, hi[i] above"""
+        lo = np.ascontiguousarray(lo, dtype=np.uint64)
+        hi = np.ascontiguousarray(hi, dtype=np.uint64)
+        if lo.size < level + 1 or hi.size < level + 1:
+            raise LatticeRingError(3, "half-vector scalars: need level+1 words each")
+        check(lib().lr_half_scalar_op(self.h, {"ADD": 0, "MRED": 1, "MRED_ADD": 2}[op], level, p1.h, lo.ctypes.data_as(C.c_void_p),
+                                      hi.ctypes.data_as(C.c_void_p), p2.h))
+
     def MultByMonomial(self, p1, monomialDeg, p2):  # ring/ring.go:663
         check(lib().lr_mult_by_monomial(self.h, p1.h, int(monomialDeg), p2.h))
 

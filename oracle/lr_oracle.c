@@ -942,6 +942,25 @@ void oc_ckks_switch_keys(oc_ckks_plan *p, int level, const u64 *cx, const u64 *e
     free(c2QiQ); free(c2QiP); free(pool2P); free(pool3P); free(c2);
 }
 
+/* The element loops of ckks.Evaluator's constant-by-ciphertext methods (test infrastructure like the rest of this file):
+ * AddConst ckks/evaluator.go:429-445 (op 0: CRed(x + s)), MultByConst :712-730 and MultByi / DivByi :765-779, :814-828 (op 1:
+ * MRed(x, s)), MultByConstAndAdd :588-606 (op 2: CRed(out + MRed(x, s))); s = lo[i] for the coefficients below N/2, hi[i] for the rest.
+ * in, out: [level+1][N]. */
+void oc_half_scalar_op(const oc_context *c, int op, int level, const u64 *in, const u64 *lo, const u64 *hi, u64 *out) {
+    const u64 N = c->N;
+    for (int i = 0; i <= level; i++) {
+        const u64 qi = c->q[i], qinv = c->mred[i];
+        const u64 *p0tmp = in + (size_t)i * N;
+        u64 *p1tmp = out + (size_t)i * N;
+        for (u64 j = 0; j < N; j++) {
+            const u64 sc = j < (N >> 1) ? lo[i] : hi[i];
+            if (op == 0) p1tmp[j] = oc_cred(p0tmp[j] + sc, qi);
+            else if (op == 1) p1tmp[j] = oc_mred(p0tmp[j], sc, qi, qinv);
+            else p1tmp[j] = oc_cred(p1tmp[j] + oc_mred(p0tmp[j], sc, qi, qinv), qi);
+        }
+    }
+}
+
 /* bfv.evaluator.switchKeys, bfv/evaluator.go:736-812 (test infrastructure like the rest of this file).  cx: [nQ][N] coefficient domain;
  * evk: [beta][2][nQ+nP][N]; p0, p1: [nQ][N] coefficient domain.  The joined context Q||P of the reference (contextKeys) is the pair
  * (cQ, cP) here: the tables of a modulus depend on the modulus and N only. */

@@ -178,6 +178,8 @@ void oc_ckks_plan_free(oc_ckks_plan *p);
  * (NTT + Montgomery, ckks/keygen.go:68-70).  p0, p1 = [level+1][N] outputs. */
 void oc_ckks_switch_keys(oc_ckks_plan *p, int level, const uint64_t *cx, const uint64_t *evk,
                          uint64_t *p0, uint64_t *p1);
+/* element loops of ckks.Evaluator's AddConst / MultByConst / MultByConstAndAdd / MultByi / DivByi (ckks/evaluator.go:429-828) */
+void oc_half_scalar_op(const oc_context *c, int op, int level, const uint64_t *in, const uint64_t *lo, const uint64_t *hi, uint64_t *out);
 /* bfv.evaluator.switchKeys (bfv/evaluator.go:736-812): cx = [|Q|][N] coefficient domain, evk as above, p0 / p1 = [|Q|][N]
  * coefficient domain.  oc_bfv_relinearize (:480-501) on a degree-2 ciphertext ct = [3][|Q|][N] -> out = [2][|Q|][N]. */
 void oc_bfv_switch_keys(oc_ckks_plan *p, const uint64_t *cx, const uint64_t *evk, uint64_t *p0, uint64_t *p1);

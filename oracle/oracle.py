@@ -143,6 +143,7 @@ def _bind(L):
     sig("oc_ckks_plan_free", None, vp)
     sig("oc_ckks_switch_keys", None, vp, i, vp, vp, vp, vp)
     sig("oc_ckks_mulrelin", None, vp, i, vp, vp, vp, vp)
+    sig("oc_half_scalar_op", None, vp, i, i, vp, vp, vp, vp)
     sig("oc_bfv_switch_keys", None, vp, vp, vp, vp, vp)
     sig("oc_bfv_relinearize", None, vp, vp, vp, vp)
     sig("oc_ckks_permute_ntt", None, vp, i, vp, u64, vp, vp)
@@ -295,6 +296,14 @@ class Context:
         sc = None if scalars is None else np.ascontiguousarray(scalars, dtype=np.uint64)
         lib().oc_ewise(self.h, OP[op] if isinstance(op, str) else op, level, _ptr(a), _ptr(b), _ptr(out), _ptr(sc))
         return out
+
+    def half_scalar_op(self, op, p, lo, hi, out=None):
+        """element loops of ckks.Evaluator's constant methods (ckks/evaluator.go:429-828): op 0 CRed(x+s), 1 MRed(x,s), 2 CRed(out+MRed(x,s))"""
+        p = _arr(p)
+        res = np.zeros_like(p) if out is None else _arr(out).copy()
+        lo_, hi_ = _u64arr(lo), _u64arr(hi)
+        lib().oc_half_scalar_op(self.h, op, p.shape[0] - 1, _ptr(p), lo_, hi_, _ptr(res))
+        return res
 
     def permute_ntt(self, p, gen):           # ring.PermuteNTT (ring/ring_galois.go:55)
         p = _arr(p)

@@ -67,6 +67,13 @@ def build():
     bplan = oracle.BfvPlan(oracle.Context(N, bq), oracle.Context(N, bm), 65537)
     b0, b1 = np.stack([rnd(bq, 21), rnd(bq, 22)]), np.stack([rnd(bq, 23), rnd(bq, 24)])
     case("bfv_mul", {"ct0": b0, "ct1": b1}, np.stack(bplan.mul(b0, b1)), t=65537)
+    # round 3: BFV Relinearize (bfv/evaluator.go:480-501, 736-812) on the same toy key-switch parameters, and the element loops of the
+    # CKKS constant methods (ckks/evaluator.go:429-828)
+    ct3 = np.stack([rnd(Q, 31), rnd(Q, 32), rnd(Q, 33)])
+    case("bfv_relinearize", {"ct": ct3, "evk": evk}, plan.bfv_relinearize(ct3, evk))
+    lo, hi = np.array(scalars, dtype=np.uint64) % np.array(Q, dtype=np.uint64), np.array(scalars[::-1], dtype=np.uint64) % np.array(Q, dtype=np.uint64)
+    for code, nm in ((0, "add"), (1, "mred"), (2, "mred_add")):
+        case("half_scalar:" + nm, {"a": a, "out": c0, "lo": lo, "hi": hi}, ocQ.half_scalar_op(code, a, lo, hi, out=c0), op=code)
     return {"N": N, "Q": [str(q) for q in Q], "P": [str(p) for p in P], "cases": cases,
             "note": "uint64 values as decimal strings, arrays flattened in C order with their shape"}
 

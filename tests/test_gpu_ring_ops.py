@@ -748,3 +748,47 @@ def test_rounding_rescale_on_the_60_bit_rings(gpu_pkg, oracle, logn, path, monke
     got = p.get()
     for b in range(3):
         assert np.array_equal(got[b], oc.rescale_op("oc_div_round_by_last_modulus_ntt", oc.rescale_op("oc_div_round_by_last_modulus_ntt", x[b])))
+
+
+@pytest.mark.parametrize("logn,nlimbs,batch", [(4, 2, 1), (10, 3, 2), (15, 4, 3)])
+def test_half_vector_scalar_ops(gpu_pkg, oracle, logn, nlimbs, batch):
+    """lr_half_scalar_op: the element loops of ckks.Evaluator's AddConst / MultByConst / MultByConstAndAdd / MultByi / DivByi
+    (ckks/evaluator.go:429-828) -- one scalar for the coefficients below N/2, one for the rest, per limb -- against the oracle's
+    restatement, on values at and above q, in place and out of place; and the identity the reference's MultByi rests on:
+    multiplying twice by (psi^(N/2), -psi^(N/2)) negates the polynomial"""
+    N = 1 << logn
+    _, Qf, _ = gpu_pkg.params.ckks_moduli("PN15QP880")
+    Q = list(Qf[:nlimbs])
+    ctx = gpu_pkg.ring.NewContextWithParams(N, Q)
+    oc = oracle.Context(N, Q)
+    x = gpu_pkg.sampling.uniform_poly(Q, N, batch, seed=logn)
+    for i, q in enumerate(Q):
+        x[0, i, :3] = [q, q + 1, 2 * q - 1]
+        x[0, i, N // 2:N // 2 + 2] = [q - 1, q]
+    rng = np.random.default_rng(logn)
+    lo = np.array([int(rng.integers(0, q)) for q in Q], dtype=np.uint64)
+    hi = np.array([int(rng.integers(0, q)) for q in Q], dtype=np.uint64)
+    y0 = gpu_pkg.sampling.uniform_poly(Q, N, batch, seed=logn + 50)
+    for op, code in (("ADD", 0), ("MRED", 1), ("MRED_ADD", 2)):
+        p, o = ctx.NewPoly(batch).set(x), ctx.NewPoly(batch).set(y0)
+        ctx.HalfScalarOp(op, nlimbs - 1, p, lo, hi, o)
+        got = o.get()
+        for b in range(batch):
+            assert np.array_equal(got[b], oc.half_scalar_op(code, x[b], lo, hi, out=y0[b])), (op, b)
+        if op != "MRED_ADD":
+            ctx.HalfScalarOp(op, nlimbs - 1, p, lo, hi, p)          # in place
+            assert np.array_equal(p.get(), got)
+    # MultByi twice = Neg (ckks/evaluator.go:746-785: imag = nttPsi[i][1], Montgomery form of psi^(N/2))
+    imag = np.array([int(oc.ntt_psi[i][1]) for i in range(nlimbs)], dtype=np.uint64)
+    nimag = np.array([q - int(v) for q, v in zip(Q, imag)], dtype=np.uint64)
+    xc = gpu_pkg.sampling.uniform_poly(Q, N, 1, seed=99)
+    p = ctx.NewPoly(1).set(xc)
+    ctx.HalfScalarOp("MRED", nlimbs - 1, p, imag, nimag, p)
+    ctx.HalfScalarOp("MRED", nlimbs - 1, p, imag, nimag, p)
+    want = np.array([[(q - int(v)) % q for v in xc[0, i]] for i, q in enumerate(Q)], dtype=np.uint64)
+    assert np.array_equal(p.get()[0], want)
+    # a level below the top leaves the upper limbs alone
+    if nlimbs > 2:
+        p, o = ctx.NewPoly(batch).set(x), ctx.NewPoly(batch).set(y0)
+        ctx.HalfScalarOp("MRED", nlimbs - 2, p, lo, hi, o)
+        assert np.array_equal(o.get()[:, nlimbs - 1], y0[:, nlimbs - 1])
