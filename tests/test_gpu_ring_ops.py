@@ -772,12 +772,12 @@ def test_half_vector_scalar_ops(gpu_pkg, oracle, logn, nlimbs, batch):
     for op, code in (("ADD", 0), ("MRED", 1), ("MRED_ADD", 2)):
         p, o = ctx.NewPoly(batch).set(x), ctx.NewPoly(batch).set(y0)
         ctx.HalfScalarOp(op, nlimbs - 1, p, lo, hi, o)
-        got = o.get()
+        got = o.get().reshape(batch, nlimbs, N)
         for b in range(batch):
             assert np.array_equal(got[b], oc.half_scalar_op(code, x[b], lo, hi, out=y0[b])), (op, b)
         if op != "MRED_ADD":
             ctx.HalfScalarOp(op, nlimbs - 1, p, lo, hi, p)          # in place
-            assert np.array_equal(p.get(), got)
+            assert np.array_equal(p.get().reshape(batch, nlimbs, N), got)
     # MultByi twice = Neg (ckks/evaluator.go:746-785: imag = nttPsi[i][1], Montgomery form of psi^(N/2))
     imag = np.array([int(oc.ntt_psi[i][1]) for i in range(nlimbs)], dtype=np.uint64)
     nimag = np.array([q - int(v) for q, v in zip(Q, imag)], dtype=np.uint64)
@@ -786,9 +786,9 @@ def test_half_vector_scalar_ops(gpu_pkg, oracle, logn, nlimbs, batch):
     ctx.HalfScalarOp("MRED", nlimbs - 1, p, imag, nimag, p)
     ctx.HalfScalarOp("MRED", nlimbs - 1, p, imag, nimag, p)
     want = np.array([[(q - int(v)) % q for v in xc[0, i]] for i, q in enumerate(Q)], dtype=np.uint64)
-    assert np.array_equal(p.get()[0], want)
+    assert np.array_equal(p.get().reshape(nlimbs, N), want)
     # a level below the top leaves the upper limbs alone
     if nlimbs > 2:
         p, o = ctx.NewPoly(batch).set(x), ctx.NewPoly(batch).set(y0)
         ctx.HalfScalarOp("MRED", nlimbs - 2, p, lo, hi, o)
-        assert np.array_equal(o.get()[:, nlimbs - 1], y0[:, nlimbs - 1])
+        assert np.array_equal(o.get().reshape(batch, nlimbs, N)[:, nlimbs - 1], y0[:, nlimbs - 1])
