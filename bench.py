@@ -325,6 +325,32 @@ def cpu_baseline(make_worker, units_per_call, unit, what, target_seconds):
     }
 
 
+def agreed_leg(name, prepare, run, all_max, world, rank, log=lambda m: None):
+    """A leg after the headline, in two phases.  prepare(): set-up WITHOUT collectives (contexts, allocations, uploads) -> state;
+    run(state): the timing, whose barrier / max-over-ranks are collectives.  All ranks agree on the outcome of prepare (max of an
+    error flag: one all-reduce) before any of them enters run, so a rank that failed in set-up never leaves the others waiting in
+    a collective it will not join; the leg is then reported as failed on every rank.  An exception inside run on a multi-rank job
+    ends this rank with a non-zero code (the launcher stops the others) instead of a 300 s collective timeout."""
+    err, state = None, None
+    try:
+        state = prepare()
+    except Exception as ex:     # noqa: BLE001 -- reported, not swallowed
+        err = "%s: %s" % (type(ex).__name__, ex)
+    if all_max(1.0 if err else 0.0) > 0:
+        res = {"error": err or "set-up failed on another rank"}
+        log("%s leg skipped on every rank: %s" % (name, res["error"]))
+        return res
+    try:
+        return run(state)
+    except Exception as ex:     # noqa: BLE001
+        if world > 1:
+            log("%s leg failed inside its timed part on rank %d: %s: %s -- ending the job" % (name, rank, type(ex).__name__, ex))
+            sys.stderr.flush()
+            os._exit(3)
+        log("%s leg failed: %s: %s" % (name, type(ex).__name__, ex))
+        return {"error": "%s: %s" % (type(ex).__name__, ex)}
+
+
 def launcher_argv(gpus, port, passthrough):
     """The command the parent of a multi-GPU run starts as a child process: one rank per GPU of this node under
     torch.distributed.run, rendezvous on 127.0.0.1 (the container hostname may not resolve)."""
@@ -383,11 +409,23 @@ def launch_check():
     dist.init_process_group(backend="gloo", timeout=datetime.timedelta(seconds=120))
     t = torch.tensor([float(rank)], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    flag = torch.tensor([1.0 if (os.environ.get("LR_BENCH_CHECK_FAIL_RANK") == str(rank)) else 0.0], dtype=torch.float64)
-    dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+    def all_max(v):
+        x = torch.tensor([v], dtype=torch.float64)
+        dist.all_reduce(x, op=dist.ReduceOp.MAX)
+        return float(x.item())
+
+    def prepare_maybe_failing():
+        if os.environ.get("LR_BENCH_CHECK_FAIL_RANK") == str(rank):
+            raise RuntimeError("set-up failure injected on rank %d" % rank)
+        return rank
+
+    # the two-phase legs of the real run, with gloo collectives: one leg whose set-up fails on one rank, one that runs
+    leg_a = agreed_leg("check-a", prepare_maybe_failing, lambda st: {"ran_on": st, "max": all_max(float(st))}, all_max, world, rank)
+    leg_b = agreed_leg("check-b", lambda: 7, lambda st: {"max": all_max(float(st + rank))}, all_max, world, rank)
     dist.barrier()
     if rank == 0:
-        print(json.dumps({"launch_check": True, "world": world, "max_rank": int(t.item()), "a_rank_failed": bool(flag.item()),
+        print(json.dumps({"launch_check": True, "world": world, "max_rank": int(t.item()), "a_rank_failed": "error" in leg_a,
+                          "leg_a": leg_a, "leg_b": leg_b,
                           "master": "%s:%s" % (os.environ.get("MASTER_ADDR"), os.environ.get("MASTER_PORT"))}), flush=True)
     dist.destroy_process_group()
 
@@ -496,30 +534,7 @@ def main():
             return default, "%s: %s" % (type(ex).__name__, ex)
 
     def secondary(name, prepare, run, store=None):
-        """A leg after the headline, in two phases.  prepare(): set-up WITHOUT collectives (contexts, allocations, uploads) -> state;
-        run(state): the timing, whose barrier / max-over-ranks are collectives.  All ranks agree on the outcome of prepare (max of an
-        error flag: one all-reduce) before any of them enters run, so a rank that failed in set-up never leaves the others waiting in
-        a collective it will not join; the leg is then reported as failed on every rank.  An exception inside run on a multi-rank job
-        ends this rank with a non-zero code (the launcher stops the others) instead of a 300 s collective timeout."""
-        err, state = None, None
-        try:
-            state = prepare()
-        except Exception as ex:     # noqa: BLE001 -- reported, not swallowed
-            err = "%s: %s" % (type(ex).__name__, ex)
-        if all_max(1.0 if err else 0.0) > 0:
-            res = {"error": err or "set-up failed on another rank"}
-            progress("%s leg skipped on every rank: %s" % (name, res["error"]))
-        else:
-            try:
-                res = run(state)
-            except Exception as ex:     # noqa: BLE001
-                if world > 1:
-                    progress("%s leg failed inside its timed part on rank %d: %s: %s -- ending the job" % (name, rank, type(ex).__name__, ex))
-                    sys.stderr.flush()
-                    os._exit(3)
-                res = {"error": "%s: %s" % (type(ex).__name__, ex)}
-                progress("%s leg failed: %s" % (name, res["error"]))
-        del state
+        res = agreed_leg(name, prepare, run, all_max, world, rank, progress)
         if rank == 0:
             if store is not None:
                 store.append(res)

@@ -47,12 +47,18 @@ def test_self_launch_relays_one_line_and_the_exit_code():
     lines = [ln for ln in res.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, lines
     d = json.loads(lines[0])
-    assert d == {"launch_check": True, "world": 2, "max_rank": 1, "a_rank_failed": False, "master": d["master"]}
+    assert d["launch_check"] is True and d["world"] == 2 and d["max_rank"] == 1 and d["a_rank_failed"] is False
+    assert d["leg_a"] == {"ran_on": 0, "max": 1.0} and d["leg_b"] == {"max": 8.0}
     assert d["master"].startswith("127.0.0.1:")
-    # a rank that reports a failure is seen by every rank through the agreement all-reduce
+    # a set-up failure on rank 1 only: the agreement all-reduce makes EVERY rank skip that leg (rank 0 reports it although its own
+    # set-up succeeded), nobody is left waiting in the leg's collectives, and the next leg runs on both ranks
     res = run(["--gpus", "2", "--launch-check"], env={"LR_BENCH_CHECK_FAIL_RANK": "1"})
     assert res.returncode == 0, res.stderr[-3000:]
-    assert json.loads(res.stdout.strip().splitlines()[-1])["a_rank_failed"] is True
+    d = json.loads(res.stdout.strip().splitlines()[-1])
+    assert d["a_rank_failed"] is True and d["leg_a"] == {"error": "set-up failed on another rank"} and d["leg_b"] == {"max": 8.0}
+    res = run(["--gpus", "2", "--launch-check"], env={"LR_BENCH_CHECK_FAIL_RANK": "0"})
+    d = json.loads(res.stdout.strip().splitlines()[-1])
+    assert "injected on rank 0" in d["leg_a"]["error"] and d["leg_b"] == {"max": 8.0}
 
 
 def test_under_a_launcher_bench_runs_as_a_rank():
