@@ -1216,7 +1216,11 @@ class Gen:
             for i in range(4):
                 k = 4 * batch + i
                 e("global_load_dwordx4", XQ[i], a2, XR, offset=(k % 4) * 1024, hint="nt")
-                e("global_load_dwordx4", PQ[i], a2, PR, offset=(k % 4) * 1024, hint="nt")
+                # plus: default cache policy, not streaming like x: the rounding rescale's plus operand is ONE table row per limb shared
+                # by every poly of the launch, and with nt each workgroup fetched it from memory again (4.7 GB per launch of 256 polys x
+                # 15 limbs instead of 2.1, profiles/r03/pmc_rescale15.json; Rescale PN15QP880 0.97 -> 0.88 ms per batch of 128); the
+                # per-poly plus rows of MulRelin measure the same either way
+                e("global_load_dwordx4", PQ[i], a2, PR, offset=(k % 4) * 1024)
             for ptr in (XR, PR):
                 e("s_add_u32", ptr.lo(), ptr.lo(), 4096)
                 e("s_addc_u32", ptr.hi(), ptr.hi(), 0)
