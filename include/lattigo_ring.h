@@ -317,6 +317,26 @@ int lr_bfv_relinearize(lr_ckks_plan *plan, const lr_poly *c0, const lr_poly *c1,
 int lr_ckks_mulrelin(lr_ckks_plan *plan, int level, const lr_poly *ct0_c0, const lr_poly *ct0_c1,
                      const lr_poly *ct1_c0, const lr_poly *ct1_c1, const lr_poly *evk,
                      lr_poly *out_c0, lr_poly *out_c1);
+/* Batcher for the reference's concurrency model -- one evaluator per goroutine, one ciphertext per call
+ * (examples/dbfv/psi/psi.go:215-233, examples/ckks: each worker holds its own ckks.Evaluator).  Concurrent calls of
+ * lr_ckks_batcher_mulrelin from any number of host threads are merged into batched launches: a call queues its request, and whichever
+ * caller finds a free lane runs everything queued with the same (level, evk) -- up to max_batch polys, in arrival order -- as ONE
+ * MulRelin (the operands are read in place through a pointer table, the results are copied out to the callers' polys by one kernel),
+ * waits for it and wakes the others.  The call returns when its own result is complete on the device (it may be used on any
+ * stream afterwards); operands are synchronised with the streams of the contexts they were created on before they are queued.
+ * plans[i]: one plan per lane, each over its OWN pair of contexts, same moduli, device and max_batch; the batcher creates one
+ * stream per lane and sets it on the lane's contexts (lr_context_set_stream; destroy puts the library's stream back).  Two lanes
+ * let the next batch's launches overlap the running one.  The plans and contexts stay owned by the caller and must outlive the
+ * batcher; while it exists they are not used for anything else.  evk must be the SAME key image handle in the calls that are to
+ * share a batch (the relinearisation key is shared by the evaluators of one party, ckks/evaluator.go:1016).
+ * Results are the same bits as lr_ckks_mulrelin's.  An error of a batch is returned by every call that was part of it. */
+typedef struct lr_ckks_batcher lr_ckks_batcher;
+int lr_ckks_batcher_create(lr_ckks_plan *const *plans, int n_lanes, lr_ckks_batcher **out);
+void lr_ckks_batcher_destroy(lr_ckks_batcher *batcher);
+int lr_ckks_batcher_mulrelin(lr_ckks_batcher *batcher, int level, const lr_poly *ct0_c0, const lr_poly *ct0_c1,
+                             const lr_poly *ct1_c0, const lr_poly *ct1_c1, const lr_poly *evk, lr_poly *out_c0, lr_poly *out_c1);
+/* launches so far, polys they carried, the largest batch (any of the pointers may be NULL) */
+int lr_ckks_batcher_stats(lr_ckks_batcher *batcher, uint64_t *batches, uint64_t *products, int *largest);
 /* MulRelin with evakey == nil (ckks/evaluator.go:1038-1111): the degree-2 result (out_c0, out_c1, out_c2), no key switch.
  * Outputs may alias the inputs (ctOut == ct0 / ct1: the reference goes through its pools and copies, :1105-1111); ct0 == ct1 is
  * the squaring branch (:1083-1088), whose result equals the regular branch's on the same operands. */

@@ -90,6 +90,10 @@ SYMBOLS = {
     "lr_bfv_switch_keys": [vp, vp, vp, vp, vp],
     "lr_bfv_relinearize": [vp, vp, vp, vp, vp, vp, vp],
     "lr_ckks_mulrelin": [vp, i32, vp, vp, vp, vp, vp, vp, vp],
+    "lr_ckks_batcher_create": [vp, i32, vp],
+    "lr_ckks_batcher_destroy": [vp],
+    "lr_ckks_batcher_mulrelin": [vp, i32, vp, vp, vp, vp, vp, vp, vp],
+    "lr_ckks_batcher_stats": [vp, vp, vp, vp],
     "lr_ckks_rescale": [vp, vp, vp],
     "lr_ckks_mul_norelin": [vp, i32, vp, vp, vp, vp, vp, vp, vp],
     "lr_ckks_mul_plain": [vp, i32, vp, vp, vp, vp, vp],

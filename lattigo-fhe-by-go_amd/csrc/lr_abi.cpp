@@ -7,9 +7,11 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <exception>
 #include <map>
 #include <memory>
@@ -2640,6 +2642,30 @@ extern "C" int lr_ckks_rotate_hoisted(lr_ckks_plan *pl, int level, const lr_poly
     });
 }
 
+namespace {
+
+// ckks/evaluator.go:1080-1104 after the argument checks: T holds the four operands (strided or through a pointer table)
+int mulrelin_core(lr_ckks_plan *pl, int level, int batch, TensorLaunch T, const lr_poly *evk, u64 *o0, u64 *o1, long long o_stride) {
+    lr_context *cQ = pl->cQ;
+    LR_TRY(same_stream(pl->cQ, pl->cP));
+    LR_HIP(hipSetDevice(cQ->device));
+    const int n = (int)cQ->h.N, L1 = level + 1;
+    const long long s = (long long)L1 * n;
+    for (Pool *p : {&pl->c0, &pl->c1, &pl->c2x, &pl->q1, &pl->q2}) LR_TRY(p->ensure(cQ, (size_t)batch * s));
+    // :1080-1095: MForm x2, MulCoeffsMontgomery x3, MulCoeffsMontgomeryAndAdd, one pass
+    T.c0 = pl->c0.d; T.c1 = pl->c1.d; T.c2 = pl->c2x.d;
+    T.c_stride = T.c1_stride = T.c2_stride = s;
+    T.n = n;
+    T.lp = cQ->d_lp;
+    LR_HIP(launch_tensor(T, L1, batch, cQ->stream));
+    // :1101 key switch of the degree-2 part, :1103-1104 the two additions fused into its last pass
+    KeySwitchEpilogue fin{o0, o1, o_stride, pl->c0.d, pl->c1.d, s};
+    LR_TRY(switch_keys_core(pl, level, batch, pl->c2x.d, s, evk, pl->q1.d, s, pl->q2.d, s, &fin));
+    return LR_OK;
+}
+
+}  // namespace
+
 extern "C" int lr_ckks_mulrelin(lr_ckks_plan *pl, int level, const lr_poly *a0, const lr_poly *a1, const lr_poly *b0,
                                 const lr_poly *b1, const lr_poly *evk, lr_poly *o0, lr_poly *o1) {
     return guarded([&]() -> int {
@@ -2648,27 +2674,219 @@ extern "C" int lr_ckks_mulrelin(lr_ckks_plan *pl, int level, const lr_poly *a0, 
     const int batch = a0->batch;
     if (batch > pl->max_batch) return fail(LR_ERR_SHAPE, "batch exceeds the plan's max_batch");
     for (const lr_poly *p : {a0, a1, b0, b1, (const lr_poly *)o0, (const lr_poly *)o1}) LR_TRY(check_ct(pl, level, p, batch));
-    lr_context *cQ = pl->cQ;
-    LR_TRY(same_stream(pl->cQ, pl->cP));
-    LR_HIP(hipSetDevice(cQ->device));
-    const int n = (int)cQ->h.N, L1 = level + 1;
-    const long long s = (long long)L1 * n;
-    for (Pool *p : {&pl->c0, &pl->c1, &pl->c2x, &pl->q1, &pl->q2}) LR_TRY(p->ensure(cQ, (size_t)batch * s));
-    // ckks/evaluator.go:1080-1095: MForm x2, MulCoeffsMontgomery x3, MulCoeffsMontgomeryAndAdd, one pass
     if (o0->stride() != o1->stride()) return fail(LR_ERR_SHAPE, "output polys must share their stride");
-    {
-        TensorLaunch T;
-        T.a0 = a0->d; T.a1 = a1->d; T.b0 = b0->d; T.b1 = b1->d;
-        T.a0_stride = a0->stride(); T.a1_stride = a1->stride(); T.b0_stride = b0->stride(); T.b1_stride = b1->stride();
-        T.c0 = pl->c0.d; T.c1 = pl->c1.d; T.c2 = pl->c2x.d;
-        T.c_stride = T.c1_stride = T.c2_stride = s;
-        T.n = n;
-        T.lp = cQ->d_lp;
-        LR_HIP(launch_tensor(T, L1, batch, cQ->stream));
+    TensorLaunch T;
+    T.a0 = a0->d; T.a1 = a1->d; T.b0 = b0->d; T.b1 = b1->d;
+    T.a0_stride = a0->stride(); T.a1_stride = a1->stride(); T.b0_stride = b0->stride(); T.b1_stride = b1->stride();
+    return mulrelin_core(pl, level, batch, T, evk, o0->d, o1->d, o0->stride());
+    });
+}
+
+// ------------------------------------------------------------------------------------------
+// Batcher: the reference's concurrency model is one evaluator per goroutine, one ciphertext per call
+// (examples/dbfv/psi/psi.go:215-233).  On this device a product of one ciphertext fills a fraction of the chip and the streams of
+// many host threads do not add up (profiles/r03: 16 threads x batch 1 = 9.1k products/s against 21k/s for one batched call).  The
+// batcher turns concurrent calls back into batched launches: a call queues its request; whichever caller finds a free lane takes
+// every queued request with the same (level, key) up to max_batch, runs them as ONE MulRelin whose first kernel reads the operands
+// through a pointer table and whose results are scattered to the callers' polys by one copy kernel, waits for the lane's stream and
+// wakes the callers.  No thread of its own, no timer: while a lane runs, arrivals queue up and form the next batch.
+// ------------------------------------------------------------------------------------------
+struct lr_ckks_batcher {
+    struct Request {
+        int level = 0, polys = 0;
+        const lr_poly *a0 = nullptr, *a1 = nullptr, *b0 = nullptr, *b1 = nullptr, *evk = nullptr;
+        lr_poly *o0 = nullptr, *o1 = nullptr;
+        bool done = false;
+        int status = LR_OK;
+        std::string error;
+    };
+    struct Lane {
+        lr_ckks_plan *plan = nullptr;
+        bool busy = false;
+        u64 **h_table = nullptr;   // pinned: [4 * max_batch] operand pointers, then [2 * max_batch] result pointers
+        u64 **d_table = nullptr;
+        Pool o0, o1;               // staged results
+        hipStream_t stream = nullptr;   // created here, set on the lane's two contexts for the batcher's lifetime
+    };
+    std::vector<Lane> lanes;
+    int max_batch = 0;
+    std::mutex m;
+    std::condition_variable cv;
+    std::deque<Request *> queue;
+    unsigned long long batches = 0, products = 0;
+    int largest = 0;
+};
+
+namespace {
+
+int batcher_run(lr_ckks_batcher *B, lr_ckks_batcher::Lane &lane, const std::vector<lr_ckks_batcher::Request *> &reqs) {
+    lr_ckks_plan *pl = lane.plan;
+    lr_context *cQ = pl->cQ;
+    const int level = reqs[0]->level, L1 = level + 1, n = (int)cQ->h.N;
+    const long long s = (long long)L1 * n;
+    LR_HIP(hipSetDevice(cQ->device));
+    int batch = 0;
+    const int mb = B->max_batch;
+    for (const auto *r : reqs)
+        for (int i = 0; i < r->polys; ++i, ++batch) {
+            lane.h_table[4 * batch + 0] = r->a0->d + i * r->a0->stride();
+            lane.h_table[4 * batch + 1] = r->a1->d + i * r->a1->stride();
+            lane.h_table[4 * batch + 2] = r->b0->d + i * r->b0->stride();
+            lane.h_table[4 * batch + 3] = r->b1->d + i * r->b1->stride();
+            lane.h_table[4 * mb + 2 * batch + 0] = r->o0->d + i * r->o0->stride();
+            lane.h_table[4 * mb + 2 * batch + 1] = r->o1->d + i * r->o1->stride();
+        }
+    LR_TRY(lane.o0.ensure(cQ, (size_t)batch * s));
+    LR_TRY(lane.o1.ensure(cQ, (size_t)batch * s));
+    LR_HIP(hipMemcpyAsync(lane.d_table, lane.h_table, (size_t)6 * mb * sizeof(u64 *), hipMemcpyHostToDevice, cQ->stream));
+    TensorLaunch T{};
+    T.table = (const u64 *const *)lane.d_table;
+    LR_TRY(mulrelin_core(pl, level, batch, T, reqs[0]->evk, lane.o0.d, lane.o1.d, s));
+    ScatterLaunch S{{lane.o0.d, lane.o1.d}, s, lane.d_table + 4 * mb, 2, n};
+    LR_HIP(launch_scatter(S, L1, batch, cQ->stream));
+    LR_HIP(hipStreamSynchronize(cQ->stream));
+    return LR_OK;
+}
+
+}  // namespace
+
+extern "C" int lr_ckks_batcher_create(lr_ckks_plan *const *plans, int n_lanes, lr_ckks_batcher **out) {
+    return guarded([&]() -> int {
+    if (!plans || !out || n_lanes < 1) return fail(LR_ERR_ARG, "plans / out null or no lanes");
+    struct Undo {   // a creation that fails half-way takes the lanes built so far down again (streams, tables)
+        void operator()(lr_ckks_batcher *b) const { lr_ckks_batcher_destroy(b); }
+    };
+    std::unique_ptr<lr_ckks_batcher, Undo> B(new lr_ckks_batcher);
+    B->max_batch = plans[0] ? plans[0]->max_batch : 0;
+    for (int i = 0; i < n_lanes; ++i) {
+        lr_ckks_plan *pl = plans[i];
+        if (!pl) return fail(LR_ERR_ARG, "null plan");
+        if (pl->max_batch != B->max_batch || pl->cQ->h.N != plans[0]->cQ->h.N || pl->cQ->h.q != plans[0]->cQ->h.q ||
+            pl->cP->h.q != plans[0]->cP->h.q || pl->device != plans[0]->device)
+            return fail(LR_ERR_SHAPE, "the lanes' plans differ in ring, device or max_batch");
+        for (int j = 0; j < i; ++j)
+            if (plans[j] == pl || plans[j]->cQ == pl->cQ || plans[j]->cP == pl->cP)
+                return fail(LR_ERR_ARG, "every lane needs its own plan over its own pair of contexts");
     }
-    // :1101 key switch of the degree-2 part, :1103-1104 the two additions fused into its last pass
-    KeySwitchEpilogue fin{o0->d, o1->d, o0->stride(), pl->c0.d, pl->c1.d, s};
-    LR_TRY(switch_keys_core(pl, level, batch, pl->c2x.d, s, evk, pl->q1.d, s, pl->q2.d, s, &fin));
+    LR_HIP(hipSetDevice(plans[0]->device));
+    B->lanes.resize(n_lanes);
+    for (int i = 0; i < n_lanes; ++i) {
+        auto &ln = B->lanes[i];
+        ln.plan = plans[i];
+        LR_HIP(hipStreamCreateWithFlags(&ln.stream, hipStreamNonBlocking));
+        LR_TRY(lr_context_set_stream(ln.plan->cQ, ln.stream));
+        LR_TRY(lr_context_set_stream(ln.plan->cP, ln.stream));
+        LR_HIP(hipHostMalloc((void **)&ln.h_table, (size_t)6 * B->max_batch * sizeof(u64 *)));
+        LR_HIP(hipMalloc((void **)&ln.d_table, (size_t)6 * B->max_batch * sizeof(u64 *)));
+    }
+    *out = B.release();
+    return LR_OK;
+    });
+}
+
+extern "C" void lr_ckks_batcher_destroy(lr_ckks_batcher *B) {
+    if (!B) return;
+    for (auto &ln : B->lanes) {
+        if (ln.stream) {   // back to the library's stream (ordered behind the lane's work), then the lane stream can go
+            (void)lr_context_set_stream(ln.plan->cQ, nullptr);
+            (void)lr_context_set_stream(ln.plan->cP, nullptr);
+            (void)hipStreamSynchronize(ln.stream);
+            (void)hipStreamDestroy(ln.stream);
+        }
+        if (ln.h_table) (void)hipHostFree(ln.h_table);
+        if (ln.d_table) (void)hipFree(ln.d_table);
+    }
+    delete B;
+}
+
+extern "C" int lr_ckks_batcher_stats(lr_ckks_batcher *B, uint64_t *batches, uint64_t *products, int *largest) {
+    return guarded([&]() -> int {
+    if (!B) return fail(LR_ERR_ARG, "null batcher");
+    std::lock_guard<std::mutex> g(B->m);
+    if (batches) *batches = B->batches;
+    if (products) *products = B->products;
+    if (largest) *largest = B->largest;
+    return LR_OK;
+    });
+}
+
+extern "C" int lr_ckks_batcher_mulrelin(lr_ckks_batcher *B, int level, const lr_poly *a0, const lr_poly *a1, const lr_poly *b0,
+                                        const lr_poly *b1, const lr_poly *evk, lr_poly *o0, lr_poly *o1) {
+    return guarded([&]() -> int {
+    if (!B || !a0 || !a1 || !b0 || !b1 || !evk || !o0 || !o1) return fail(LR_ERR_ARG, "null argument");
+    lr_ckks_plan *pl0 = B->lanes[0].plan;
+    if (level < 0 || level + 1 > pl0->cQ->h.L()) return fail(LR_ERR_SHAPE, "level out of range");
+    const int polys = a0->batch;
+    if (polys < 1 || polys > B->max_batch) return fail(LR_ERR_SHAPE, "batch exceeds the batcher's max_batch");
+    for (const lr_poly *p : {a0, a1, b0, b1, (const lr_poly *)o0, (const lr_poly *)o1}) {
+        LR_TRY(check_ct(pl0, level, p, polys));
+        if (p->device != pl0->device) return fail(LR_ERR_ARG, "poly lives on another device than the batcher");
+    }
+    const int beta = (level + 1 + pl0->cP->h.L() - 1) / pl0->cP->h.L();
+    if (evk->N != pl0->cQ->h.N || evk->limbs < pl0->cQ->h.L() + pl0->cP->h.L() || evk->batch < 2 * beta)
+        return fail(LR_ERR_SHAPE, "evaluation key image: limbs or digits");
+    // the operands were produced on the streams of the callers' own contexts: finished before another stream reads them
+    LR_HIP(hipSetDevice(pl0->device));
+    {
+        hipStream_t seen[6];
+        int ns = 0;
+        for (const lr_poly *p : {a0, a1, b0, b1, (const lr_poly *)o0, (const lr_poly *)o1}) {
+            if (!p->ctx) continue;
+            hipStream_t st = p->ctx->stream;
+            bool dup = false;
+            for (int i = 0; i < ns; ++i) dup = dup || seen[i] == st;
+            if (dup) continue;
+            seen[ns++] = st;
+            LR_HIP(hipStreamSynchronize(st));
+        }
+    }
+    lr_ckks_batcher::Request req;
+    req.level = level; req.polys = polys;
+    req.a0 = a0; req.a1 = a1; req.b0 = b0; req.b1 = b1; req.evk = evk; req.o0 = o0; req.o1 = o1;
+    std::unique_lock<std::mutex> lk(B->m);
+    B->queue.push_back(&req);
+    for (;;) {
+        if (req.done) break;
+        int free_lane = -1;
+        for (size_t i = 0; i < B->lanes.size() && free_lane < 0; ++i)
+            if (!B->lanes[i].busy) free_lane = (int)i;
+        if (free_lane < 0 || B->queue.empty()) {
+            B->cv.wait(lk);
+            continue;
+        }
+        // lead: everything queued that shares the head's (level, key), in arrival order, up to max_batch polys
+        auto &lane = B->lanes[free_lane];
+        std::vector<lr_ckks_batcher::Request *> take;
+        int total = 0;
+        const lr_ckks_batcher::Request *head = B->queue.front();
+        for (auto it = B->queue.begin(); it != B->queue.end();) {
+            lr_ckks_batcher::Request *r = *it;
+            if (r->level == head->level && r->evk == head->evk && total + r->polys <= B->max_batch) {
+                take.push_back(r);
+                total += r->polys;
+                it = B->queue.erase(it);
+            } else {
+                ++it;
+            }
+        }
+        lane.busy = true;
+        lk.unlock();
+        int rc = guarded([&]() -> int { return batcher_run(B, lane, take); });
+        const std::string msg = rc == LR_OK ? std::string() : g_error;
+        lk.lock();
+        lane.busy = false;
+        B->batches += 1;
+        B->products += (unsigned long long)total;
+        B->largest = std::max(B->largest, total);
+        for (auto *r : take) {
+            r->status = rc;
+            r->error = msg;
+            r->done = true;
+        }
+        B->cv.notify_all();
+    }
+    lk.unlock();
+    if (req.status != LR_OK) return fail(req.status, req.error);
     return LR_OK;
     });
 }

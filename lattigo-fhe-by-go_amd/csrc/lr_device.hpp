@@ -153,8 +153,18 @@ struct TensorLaunch {
     int n;
     const LimbParams *lp;
     long long c1_stride, c2_stride;
+    const u64 *const *table = nullptr;   // batcher form: the operands of batch poly b are table[4b .. 4b+3] (a0, a1, b0, b1), a*/b* and their strides unused
 };
 hipError_t launch_tensor(const TensorLaunch &L, int limbs, int batch, hipStream_t stream);
+
+// batcher form of a result copy: dst[b] = table[b * per_poly + k] for the per_poly staged polys src[k] (rows [limbs][n], batch stride `stride`)
+struct ScatterLaunch {
+    const u64 *src[2];
+    long long stride;
+    u64 *const *table;
+    int per_poly, n;
+};
+hipError_t launch_scatter(const ScatterLaunch &L, int limbs, int batch, hipStream_t stream);
 
 // out_row[r] = in + adds[r] (optionally CRed)
 struct RowAddLaunch {

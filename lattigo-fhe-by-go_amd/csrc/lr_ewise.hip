@@ -164,10 +164,11 @@ __global__ __launch_bounds__(256) void tensor_kernel(TensorLaunch L) {
     const LimbParams lp = L.lp[limb];
     const u64 q = lp.q;
     const long long row = (long long)limb * L.n;
-    const ulonglong2 *pa0 = reinterpret_cast<const ulonglong2 *>(L.a0 + b * L.a0_stride + row);
-    const ulonglong2 *pa1 = reinterpret_cast<const ulonglong2 *>(L.a1 + b * L.a1_stride + row);
-    const ulonglong2 *pb0 = reinterpret_cast<const ulonglong2 *>(L.b0 + b * L.b0_stride + row);
-    const ulonglong2 *pb1 = reinterpret_cast<const ulonglong2 *>(L.b1 + b * L.b1_stride + row);
+    const u64 *const *tb = L.table ? L.table + 4 * b : nullptr;
+    const ulonglong2 *pa0 = reinterpret_cast<const ulonglong2 *>((tb ? tb[0] : L.a0 + b * L.a0_stride) + row);
+    const ulonglong2 *pa1 = reinterpret_cast<const ulonglong2 *>((tb ? tb[1] : L.a1 + b * L.a1_stride) + row);
+    const ulonglong2 *pb0 = reinterpret_cast<const ulonglong2 *>((tb ? tb[2] : L.b0 + b * L.b0_stride) + row);
+    const ulonglong2 *pb1 = reinterpret_cast<const ulonglong2 *>((tb ? tb[3] : L.b1 + b * L.b1_stride) + row);
     ulonglong2 *pc0 = reinterpret_cast<ulonglong2 *>(L.c0 + b * L.c_stride + row);
     ulonglong2 *pc1 = reinterpret_cast<ulonglong2 *>(L.c1 + b * L.c1_stride + row);
     ulonglong2 *pc2 = reinterpret_cast<ulonglong2 *>(L.c2 + b * L.c2_stride + row);
@@ -320,6 +321,29 @@ hipError_t launch_tensor(const TensorLaunch &L, int limbs, int batch, hipStream_
     const dim3 grid((unsigned)gx, (unsigned)limbs, (unsigned)batch), block(256);
     (void)hipGetLastError();
     hipLaunchKernelGGL(tensor_kernel, grid, block, 0, stream, L);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void scatter_kernel(ScatterLaunch L) {
+    const long long row = (long long)blockIdx.y * L.n;
+    const long long b = blockIdx.z;
+    const int pairs = L.n >> 1;
+    for (int k = 0; k < L.per_poly; ++k) {
+        const ulonglong2 *ps = reinterpret_cast<const ulonglong2 *>(L.src[k] + b * L.stride + row);
+        ulonglong2 *pd = reinterpret_cast<ulonglong2 *>(L.table[b * L.per_poly + k] + row);
+        for (int e = blockIdx.x * 256 + threadIdx.x; e < pairs; e += gridDim.x * 256) st_stream(pd + e, ld_stream(ps + e));
+    }
+}
+
+hipError_t launch_scatter(const ScatterLaunch &L, int limbs, int batch, hipStream_t stream) {
+    if (limbs <= 0 || batch <= 0) return hipSuccess;
+    const int pairs = L.n >> 1;
+    int gx = (pairs + 255) / 256;
+    if (gx > 64) gx = 64;
+    if (gx < 1) gx = 1;
+    const dim3 grid((unsigned)gx, (unsigned)limbs, (unsigned)batch), block(256);
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(scatter_kernel, grid, block, 0, stream, L);
     return hipGetLastError();
 }
 

@@ -624,6 +624,45 @@ class CkksPlan:
         check(lib().lr_ckks_rotate_hoisted(self.h, level, ct0[0].h, ct0[1].h, n, g, keys, o0, o1))
 
 
+class CkksBatcher:
+    """Merges the MulRelin calls of concurrent evaluators -- the reference's model is one evaluator per goroutine, one ciphertext
+    per call (examples/dbfv/psi/psi.go:215-233) -- into batched launches (lr_ckks_batcher_* in include/lattigo_ring.h).
+    One lane = one CkksPlan over its own pair of contexts on its own stream; the batcher builds them."""
+
+    def __init__(self, N, Q, P, max_batch=64, lanes=2, device=0):
+        self.lanes = []
+        for i in range(lanes):
+            cq, cp = Context(N, Q, device=device), Context(N, P, device=device)
+            self.lanes.append((cq, cp, CkksPlan(cq, cp, max_batch)))
+        arr = (C.c_void_p * lanes)(*[ln[2].h for ln in self.lanes])
+        h = C.c_void_p()
+        check(lib().lr_ckks_batcher_create(arr, lanes, C.byref(h)))
+        self.h = h
+        self.max_batch = max_batch
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                lib().lr_ckks_batcher_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def NewSwitchingKey(self):
+        """the key image every calling evaluator passes (one handle: calls share a batch only over the same key)"""
+        return self.lanes[0][2].NewSwitchingKey()
+
+    def MulRelin(self, level, ct0, ct1, evakey, ctOut):
+        """evaluator.MulRelin (ckks/evaluator.go:1016) of two ciphertexts with key; blocks until this call's result is complete.
+        Call it from as many host threads as there are evaluators (ctypes releases the GIL for the call)."""
+        check(lib().lr_ckks_batcher_mulrelin(self.h, level, ct0[0].h, ct0[1].h, ct1[0].h, ct1[1].h, evakey.h, ctOut[0].h, ctOut[1].h))
+
+    def Stats(self):
+        b, p, l = C.c_uint64(), C.c_uint64(), C.c_int()
+        check(lib().lr_ckks_batcher_stats(self.h, C.byref(b), C.byref(p), C.byref(l)))
+        return {"batches": b.value, "products": p.value, "largest": l.value}
+
+
 class BfvPlan:
     """What bfv.NewEvaluator builds around the ring for Mul (bfv/evaluator.go:89-112) and the tensorAndRescale
     call sequence (:278-464) for two degree-1 ciphertexts, device-resident."""

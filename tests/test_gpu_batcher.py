@@ -1,0 +1,116 @@
+"""The MulRelin batcher (lr_ckks_batcher_*): concurrent batch-1 calls from many host threads -- the reference's one evaluator per
+goroutine (examples/dbfv/psi/psi.go:215-233) -- are merged into batched launches.  Every caller must get the product of ITS OWN
+operands, bit-identical to the oracle's MulRelin, whatever batch its request ended up in."""
+import threading
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(gpu_pkg, oracle, logn, nq, np_, max_batch, lanes):
+    N = 1 << logn
+    _, Qf, Pf = gpu_pkg.params.ckks_moduli("PN16QP1761" if logn == 16 or np_ > 3 else "PN15QP880")
+    Q, P = list(Qf[:nq]), list(Pf[:np_])
+    ring = gpu_pkg.ring
+    bat = ring.CkksBatcher(N, Q, P, max_batch=max_batch, lanes=lanes)
+    beta = -(-nq // np_)
+    evk = gpu_pkg.sampling.uniform_poly(Q + P, N, 2 * beta, seed=99)
+    key = bat.NewSwitchingKey().set(evk)
+    oplan = oracle.CkksPlan(oracle.Context(N, Q), oracle.Context(N, P))
+    return N, Q, P, bat, key, oplan, evk.reshape(beta, 2, nq + np_, N)
+
+
+@pytest.mark.parametrize("logn,nq,np_,level,threads,lanes,max_batch", [(12, 6, 2, 5, 8, 2, 4), (12, 6, 2, 4, 6, 1, 8), (14, 7, 3, 6, 8, 2, 16),
+                                                                       (16, 6, 2, 5, 4, 2, 4)])
+def test_concurrent_callers_get_their_own_products(gpu_pkg, oracle, logn, nq, np_, level, threads, lanes, max_batch):
+    N, Q, P, bat, key, oplan, evk = _setup(gpu_pkg, oracle, logn, nq, np_, max_batch, lanes)
+    ring = gpu_pkg.ring
+    rounds = 3
+    errors, results = [], {}
+
+    def evaluator(t):
+        try:
+            cq = ring.NewContextWithParams(N, Q)                      # the caller's own context, like every goroutine's evaluator
+            for r in range(rounds):
+                seed = 1000 * t + 10 * r
+                ops = [gpu_pkg.sampling.uniform_poly(Q[:level + 1], N, 1, seed=seed + k) for k in range(4)]
+                c0 = (cq.NewPolyLvl(level, 1).set(ops[0]), cq.NewPolyLvl(level, 1).set(ops[1]))
+                c1 = (cq.NewPolyLvl(level, 1).set(ops[2]), cq.NewPolyLvl(level, 1).set(ops[3]))
+                out = (cq.NewPolyLvl(level, 1), cq.NewPolyLvl(level, 1))
+                bat.MulRelin(level, c0, c1, key, out)
+                results[(t, r)] = (ops, out[0].get().reshape(level + 1, N), out[1].get().reshape(level + 1, N))
+        except Exception as e:  # noqa: BLE001
+            errors.append((t, repr(e)))
+
+    ths = [threading.Thread(target=evaluator, args=(t,)) for t in range(threads)]
+    for th in ths:
+        th.start()
+    for th in ths:
+        th.join()
+    assert not errors, errors
+    assert len(results) == threads * rounds
+    for (t, r), (ops, g0, g1) in results.items():
+        w0, w1 = oplan.mulrelin(level, np.stack([ops[0].reshape(level + 1, N), ops[1].reshape(level + 1, N)]),
+                                np.stack([ops[2].reshape(level + 1, N), ops[3].reshape(level + 1, N)]), evk)
+        assert np.array_equal(g0, w0), (t, r)
+        assert np.array_equal(g1, w1), (t, r)
+    st = bat.Stats()
+    assert st["products"] == threads * rounds and 1 <= st["largest"] <= max_batch and st["batches"] <= st["products"]
+
+
+def test_requests_with_several_polys_and_mixed_levels(gpu_pkg, oracle):
+    """a request may carry a batch of its own; requests of different levels never share a launch"""
+    logn, nq, np_ = 12, 6, 2
+    N, Q, P, bat, key, oplan, evk = _setup(gpu_pkg, oracle, logn, nq, np_, 8, 2)
+    ring = gpu_pkg.ring
+    errors, results = [], {}
+
+    def evaluator(t):
+        try:
+            level, b = (5, 3) if t % 2 == 0 else (3, 2)
+            cq = ring.NewContextWithParams(N, Q)
+            ops = [gpu_pkg.sampling.uniform_poly(Q[:level + 1], N, b, seed=50 * t + k).reshape(b, level + 1, N) for k in range(4)]
+            mk = lambda x: cq.NewPolyLvl(level, b).set(x)
+            out = (cq.NewPolyLvl(level, b), cq.NewPolyLvl(level, b))
+            bat.MulRelin(level, (mk(ops[0]), mk(ops[1])), (mk(ops[2]), mk(ops[3])), key, out)
+            results[t] = (level, b, ops, out[0].get().reshape(b, level + 1, N), out[1].get().reshape(b, level + 1, N))
+        except Exception as e:  # noqa: BLE001
+            errors.append((t, repr(e)))
+
+    ths = [threading.Thread(target=evaluator, args=(t,)) for t in range(6)]
+    for th in ths:
+        th.start()
+    for th in ths:
+        th.join()
+    assert not errors, errors
+    for t, (level, b, ops, g0, g1) in results.items():
+        for i in range(b):
+            w0, w1 = oplan.mulrelin(level, np.stack([ops[0][i], ops[1][i]]), np.stack([ops[2][i], ops[3][i]]), evk)
+            assert np.array_equal(g0[i], w0) and np.array_equal(g1[i], w1), (t, i)
+
+
+def test_batcher_argument_errors(gpu_pkg):
+    ring = gpu_pkg.ring
+    N = 1 << 12
+    _, Qf, Pf = gpu_pkg.params.ckks_moduli("PN15QP880")
+    Q, P = list(Qf[:4]), list(Pf[:2])
+    bat = ring.CkksBatcher(N, Q, P, max_batch=2, lanes=1)
+    key = bat.NewSwitchingKey()
+    cq = ring.NewContextWithParams(N, Q)
+    mk = lambda b: cq.NewPoly(b)
+    with pytest.raises(ring.LatticeRingError):                        # request larger than max_batch
+        bat.MulRelin(3, (mk(3), mk(3)), (mk(3), mk(3)), key, (mk(3), mk(3)))
+    with pytest.raises(ring.LatticeRingError):                        # level beyond the chain
+        bat.MulRelin(4, (mk(1), mk(1)), (mk(1), mk(1)), key, (mk(1), mk(1)))
+    with pytest.raises(ring.LatticeRingError):                        # batch mismatch between operands
+        bat.MulRelin(3, (mk(1), mk(2)), (mk(1), mk(1)), key, (mk(1), mk(1)))
+    # one plan twice is not two lanes
+    lib, C = gpu_pkg._native.lib(), __import__("ctypes")
+    arr = (C.c_void_p * 2)(bat.lanes[0][2].h, bat.lanes[0][2].h)
+    h = C.c_void_p()
+    assert lib.lr_ckks_batcher_create(arr, 2, C.byref(h)) != 0
+    # still usable afterwards
+    bat.MulRelin(3, (mk(1), mk(1)), (mk(1), mk(1)), key, (mk(1), mk(1)))
+    assert bat.Stats()["products"] == 1
