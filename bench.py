@@ -1023,9 +1023,47 @@ def main():
             rows.append({"threads": T, "streams": T, "batch_per_call": 1, "calls_per_thread": iters, "mulrelin_per_s": T * iters / dt_w,
                          "us_per_product_per_thread": dt_w / iters * 1e6, "bit_exact": bool(ok_t)})
             del workers, ths
+        # the same callers through the batcher (lr_ckks_batcher_*): concurrent batch-1 calls are merged into batched launches on two lanes
+        brows = []
+        bat = ring.CkksBatcher(tN, tQ, tP, max_batch=64, lanes=2, device=local)
+        bkey = bat.NewSwitchingKey().set(tkey_h)
+        callers_ctx = ring.NewContextWithParams(tN, tQ, device=local)
+        for T in (16, 64):
+            callers = []
+            for i in range(T):
+                mk1 = lambda k: callers_ctx.NewPoly(1).set(tops[k])
+                callers.append(((mk1(0), mk1(1)), (mk1(2), mk1(3)), (callers_ctx.NewPoly(1), callers_ctx.NewPoly(1))))
+            bat.MulRelin(tlevel, callers[0][0], callers[0][1], bkey, callers[0][2])      # warm-up: the lanes' pools exist
+            callers_ctx.Sync()
+            before = bat.Stats()
+            iters = 100
+            gate = threading.Barrier(T + 1)
+
+            def bloop(w):
+                gate.wait()
+                for _ in range(iters):
+                    bat.MulRelin(tlevel, w[0], w[1], bkey, w[2])
+            ths = [threading.Thread(target=bloop, args=(w,)) for w in callers]
+            for th in ths:
+                th.start()
+            gate.wait()
+            t_w = time.perf_counter()
+            for th in ths:
+                th.join()
+            dt_w = time.perf_counter() - t_w
+            after = bat.Stats()
+            ok_t = all(np.array_equal(w[2][0].get().reshape(tnq, tN), want_t[0]) and np.array_equal(w[2][1].get().reshape(tnq, tN), want_t[1]) for w in callers)
+            brows.append({"threads": T, "lanes": 2, "batch_per_call": 1, "calls_per_thread": iters, "mulrelin_per_s": T * iters / dt_w,
+                          "launches": after["batches"] - before["batches"], "mean_batch": (after["products"] - before["products"]) / max(1, after["batches"] - before["batches"]),
+                          "largest_batch": after["largest"], "bit_exact": bool(ok_t)})
+            del callers, ths
+        del bat
         out["evaluator_threads"] = {"params": "PN15QP880, level 17, batch 1 per call, one plan + contexts + stream per host thread", "rows": rows,
+                                    "batcher_rows": brows,
+                                    "batcher": "the same batch-1 calls through lr_ckks_batcher_mulrelin: queued requests run as one batched MulRelin per free lane",
                                     "reference_model": "one evaluator per goroutine (examples/dbfv/psi/psi.go:215-233)"}
-        progress("evaluator-per-thread MulRelin: " + ", ".join("T=%d %.0f/s" % (r["threads"], r["mulrelin_per_s"]) for r in rows))
+        progress("evaluator-per-thread MulRelin: " + ", ".join("T=%d %.0f/s" % (r["threads"], r["mulrelin_per_s"]) for r in rows) +
+                 "; through the batcher: " + ", ".join("T=%d %.0f/s (mean batch %.1f)" % (r["threads"], r["mulrelin_per_s"], r["mean_batch"]) for r in brows))
 
     if not args.no_extras and rank == 0:
         # the other kernels BASELINE.json's north_star asks throughput for, same ring, same resident batch; after timing,

@@ -64,6 +64,32 @@ func (eval *evaluator) dev() *deviceState {
 	return actual.(*deviceState)
 }
 
+// deviceBatcher, when set, takes the ciphertext x ciphertext MulRelin calls of EVERY evaluator over the same moduli: upstream's
+// concurrency model is one evaluator per goroutine and one ciphertext per call (examples/dbfv/psi/psi.go:215-233), which leaves the
+// device mostly idle per call; the batcher runs the calls that are in flight together as one batched pipeline
+// (ring.CkksBatcher, lr_ckks_batcher_* in lattigo_ring.h).  Set it once, before the goroutines start.
+var deviceBatcher *ring.CkksBatcher
+
+// EnableDeviceBatcher builds the shared batcher for a parameter set: maxBatch polys per launch, `lanes` launches in flight (2).
+func EnableDeviceBatcher(params *Parameters, maxBatch, lanes int) {
+	c := newContext(params)
+	deviceBatcher = ring.NewCkksBatcher(c.n, c.contextQ.Modulus, c.contextP.Modulus, maxBatch, lanes)
+}
+
+func (eval *evaluator) batcher() *ring.CkksBatcher {
+	b := deviceBatcher
+	q := eval.ckksContext.contextQ
+	if b == nil || eval.baseconverter == nil || b.N != q.N || len(b.Q) != len(q.Modulus) {
+		return nil
+	}
+	for i, qi := range q.Modulus {
+		if b.Q[i] != qi {
+			return nil
+		}
+	}
+	return b
+}
+
 func (eval *evaluator) keyImage(k *SwitchingKey) *ring.Poly {
 	s := eval.dev()
 	if img, ok := s.keys[k]; ok {
@@ -151,6 +177,10 @@ func (eval *evaluator) MulRelin(op0, op1 Operand, evakey *EvaluationKey, ctOut *
 	eval.resident(el1.value...)
 	eval.resident(elOut.value...)
 	// the pipeline works on its own temporaries, so ctOut may be either operand (upstream routes that case through ringpool, :1071-1076)
+	if b := eval.batcher(); b != nil && evakey != nil && el0.Degree() == 1 && el1.Degree() == 1 {
+		b.MulRelin(eval.ckksContext.contextQ, level, el0.value, el1.value, b.KeyImage(evakey.evakey.evakey), elOut.value)
+		return
+	}
 	eval.dev().plan.MulRelin(level, el0.value, el1.value, key, elOut.value)
 }
 

@@ -6,6 +6,7 @@ import "C"
 
 import (
 	"runtime"
+	"sync"
 	"unsafe"
 )
 
@@ -173,6 +174,74 @@ func (p *CkksPlan) BfvRelinearize(ct [3]*Poly, evakey *Poly, ctOut [2]*Poly) {
 	p.contextQ.want(ctOut[0], ctOut[1])
 	call(func() C.int { return C.lr_bfv_relinearize(p.h, ct[0].d, ct[1].d, ct[2].d, evakey.d, ctOut[0].d, ctOut[1].d) })
 	done(ctOut[0], ctOut[1])
+}
+
+// CkksBatcher merges the MulRelin calls of the evaluators of many goroutines -- upstream's concurrency model is one evaluator per
+// goroutine, one ciphertext per call (examples/dbfv/psi/psi.go:215-233) -- into batched device launches (lr_ckks_batcher_* in
+// lattigo_ring.h).  One batcher per parameter set, shared by the evaluators; each lane is a plan over its own pair of contexts.
+type CkksBatcher struct {
+	Q, P   []uint64
+	N      uint64
+	lanes  []*CkksPlan
+	h      *C.lr_ckks_batcher
+	mu     sync.Mutex
+	images map[*Poly]*Poly // key image per SwitchingKey (its first poly identifies it): ONE handle for all evaluators, so that their calls share batches
+}
+
+func NewCkksBatcher(N uint64, Q, P []uint64, maxBatch, lanes int) *CkksBatcher {
+	b := &CkksBatcher{N: N, Q: Q, P: P, images: map[*Poly]*Poly{}}
+	raw := C.malloc(C.size_t(lanes) * C.size_t(unsafe.Sizeof(uintptr(0))))
+	defer C.free(raw)
+	arr := (*[1 << 20]*C.lr_ckks_plan)(raw)[:lanes:lanes]
+	for i := 0; i < lanes; i++ {
+		cq, err := NewContextWithParams(N, Q)
+		if err != nil {
+			panic(err)
+		}
+		cp, err := NewContextWithParams(N, P)
+		if err != nil {
+			panic(err)
+		}
+		plan := NewCkksPlan(cq, cp, maxBatch)
+		b.lanes = append(b.lanes, plan)
+		arr[i] = plan.h
+	}
+	call(func() C.int { return C.lr_ckks_batcher_create((**C.lr_ckks_plan)(raw), C.int(lanes), &b.h) })
+	runtime.SetFinalizer(b, func(b *CkksBatcher) { C.lr_ckks_batcher_destroy(b.h) })
+	return b
+}
+
+// KeyImage: the device image of a switching key, uploaded once and shared by every caller.
+func (b *CkksBatcher) KeyImage(evakey [][2]*Poly) *Poly {
+	b.mu.Lock()
+	defer b.mu.Unlock()
+	if img, ok := b.images[evakey[0][0]]; ok {
+		return img
+	}
+	img := b.lanes[0].SwitchingKeyImage(evakey)
+	b.lanes[0].contextQ.Sync()
+	b.images[evakey[0][0]] = img
+	return img
+}
+
+// MulRelin = evaluator.MulRelin (ckks/evaluator.go:1016) of two degree-1 ciphertexts with key; callerQ: the calling evaluator's
+// contextQ (its polys are bound to it).  Blocks until this call's result is complete; safe from any number of goroutines.
+func (b *CkksBatcher) MulRelin(callerQ *Context, level uint64, ct0, ct1 []*Poly, evakey *Poly, ctOut []*Poly) {
+	callerQ.use(ct0...)
+	callerQ.use(ct1...)
+	callerQ.want(ctOut...)
+	call(func() C.int {
+		return C.lr_ckks_batcher_mulrelin(b.h, C.int(level), ct0[0].d, ct0[1].d, ct1[0].d, ct1[1].d, evakey.d, ctOut[0].d, ctOut[1].d)
+	})
+	done(ctOut...)
+}
+
+// Stats: launches so far, polys they carried, the largest batch.
+func (b *CkksBatcher) Stats() (batches, products uint64, largest int) {
+	var nb, np C.uint64_t
+	var l C.int
+	call(func() C.int { return C.lr_ckks_batcher_stats(b.h, &nb, &np, &l) })
+	return uint64(nb), uint64(np), int(l)
 }
 
 // BfvPlan: what bfv.NewEvaluator builds for Mul (bfv/evaluator.go:89-112) and tensorAndRescale (:278-464).
