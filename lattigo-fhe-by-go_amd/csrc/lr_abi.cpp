@@ -2707,6 +2707,8 @@ struct lr_ckks_batcher {
         u64 **d_table = nullptr;
         Pool o0, o1;               // staged results
         hipStream_t stream = nullptr;   // created here, set on the lane's two contexts for the batcher's lifetime
+        std::vector<Request *> take;    // the batch being run; reserved at creation, so that forming a batch allocates nothing (a request
+                                        // taken off the queue is always completed: nothing can throw between the two)
     };
     std::vector<Lane> lanes;
     int max_batch = 0;
@@ -2773,6 +2775,7 @@ extern "C" int lr_ckks_batcher_create(lr_ckks_plan *const *plans, int n_lanes, l
     for (int i = 0; i < n_lanes; ++i) {
         auto &ln = B->lanes[i];
         ln.plan = plans[i];
+        ln.take.reserve((size_t)std::max(1, B->max_batch));
         LR_HIP(hipStreamCreateWithFlags(&ln.stream, hipStreamNonBlocking));
         LR_TRY(lr_context_set_stream(ln.plan->cQ, ln.stream));
         LR_TRY(lr_context_set_stream(ln.plan->cP, ln.stream));
@@ -2856,7 +2859,8 @@ extern "C" int lr_ckks_batcher_mulrelin(lr_ckks_batcher *B, int level, const lr_
         }
         // lead: everything queued that shares the head's (level, key), in arrival order, up to max_batch polys
         auto &lane = B->lanes[free_lane];
-        std::vector<lr_ckks_batcher::Request *> take;
+        std::vector<lr_ckks_batcher::Request *> &take = lane.take;
+        take.clear();
         int total = 0;
         const lr_ckks_batcher::Request *head = B->queue.front();
         for (auto it = B->queue.begin(); it != B->queue.end();) {
@@ -2872,7 +2876,10 @@ extern "C" int lr_ckks_batcher_mulrelin(lr_ckks_batcher *B, int level, const lr_
         lane.busy = true;
         lk.unlock();
         int rc = guarded([&]() -> int { return batcher_run(B, lane, take); });
-        const std::string msg = rc == LR_OK ? std::string() : g_error;
+        std::string msg;
+        if (rc != LR_OK) {
+            try { msg = g_error; } catch (...) {}
+        }
         lk.lock();
         lane.busy = false;
         B->batches += 1;
@@ -2880,7 +2887,9 @@ extern "C" int lr_ckks_batcher_mulrelin(lr_ckks_batcher *B, int level, const lr_
         B->largest = std::max(B->largest, total);
         for (auto *r : take) {
             r->status = rc;
-            r->error = msg;
+            if (rc != LR_OK) {
+                try { r->error = msg; } catch (...) {}
+            }
             r->done = true;
         }
         B->cv.notify_all();
