@@ -26,6 +26,13 @@ func NewCkksPlan(contextQ, contextP *Context, maxBatch int) *CkksPlan {
 	return p
 }
 
+// Stats: diagnostics of the plan's small-batch paths (lr_ckks_plan_stats): forks, grouped digit extensions.
+func (p *CkksPlan) Stats() (forks, groupedExtensions uint64) {
+	var f, g C.uint64_t
+	call(func() C.int { return C.lr_ckks_plan_stats(p.h, &f, &g) })
+	return uint64(f), uint64(g)
+}
+
 // SwitchingKeyImage lays SwitchingKey.evakey ([beta][2]*ring.Poly over QP, ckks/keygen.go:68-70) out as one device
 // polynomial with batch = 2*beta, which is what the key-switching entry points take.
 func (p *CkksPlan) SwitchingKeyImage(evakey [][2]*Poly) *Poly {

@@ -296,6 +296,13 @@ int lr_div_round_by_last_modulus_many(lr_context *ctx, lr_poly *p0, int nb_resca
  * lr_ckks_plan owns what ckks.NewEvaluator builds: FastBasisExtender, Decomposer and the
  * scratch pools (ckks/evaluator.go:81-112). */
 int lr_ckks_plan_create(lr_context *ctxQ, lr_context *ctxP, int max_batch, lr_ckks_plan **out);
+/* Diagnostics of the small-batch paths of the key switch (no reference counterpart).  forks: how often two independent launches of a
+ * pipeline (the digits' P rows beside their Q rows; ModDown's two components) went out side by side on the plan's auxiliary stream
+ * instead of in order -- done while the forked launch is far from filling the chip AND the plan is the only one alive on its device
+ * (a lone evaluator) or a batcher's lane whose batcher has room; LR_NO_FORK=1 at plan creation switches it off.  grouped_extensions:
+ * launches that carried the basis extensions of all digits of a key switch at once (LR_NO_EXT_GROUP=1: one launch per digit).
+ * Results are the same bits either way.  Either pointer may be NULL. */
+int lr_ckks_plan_stats(const lr_ckks_plan *plan, uint64_t *forks, uint64_t *grouped_extensions);
 int lr_ckks_plan_destroy(lr_ckks_plan *plan);
 /* switchKeysInPlace (ckks/evaluator.go:1475): cx over Q[0..level], NTT domain;
  * evk = SwitchingKey.evakey as one poly, batch = beta*2, limbs = |Q|+|P|

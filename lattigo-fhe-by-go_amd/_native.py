@@ -86,6 +86,7 @@ SYMBOLS = {
     "lr_div_round_by_last_modulus_many": [vp, vp, i32, i32],
     "lr_ckks_plan_create": [vp, vp, i32, C.POINTER(vp)],
     "lr_ckks_plan_destroy": [vp],
+    "lr_ckks_plan_stats": [vp, vp, vp],
     "lr_ckks_switch_keys": [vp, i32, vp, vp, vp, vp],
     "lr_bfv_switch_keys": [vp, vp, vp, vp, vp],
     "lr_bfv_relinearize": [vp, vp, vp, vp, vp, vp, vp],

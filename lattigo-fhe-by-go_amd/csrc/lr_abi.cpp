@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
@@ -157,6 +158,8 @@ lr::Options lr::Options::from_env() {
     o.ext_narrow = std::getenv("LR_EXT_NARROW") != nullptr;
     o.asm14_1024 = std::getenv("LR_ASM_14_1024") != nullptr;
     o.no_exttop = std::getenv("LR_NO_EXTTOP") != nullptr;
+    o.no_ext_group = std::getenv("LR_NO_EXT_GROUP") != nullptr;
+    o.no_fork = std::getenv("LR_NO_FORK") != nullptr;
     o.no_invfuse = std::getenv("LR_NO_INVFUSE") != nullptr;
     o.keymac_narrow = std::getenv("LR_KEYMAC_NARROW") != nullptr;
     o.timeline = std::getenv("LR_NTT_TIMELINE") != nullptr;
@@ -366,6 +369,12 @@ struct lr_ckks_plan {
     Pool bfvP;             // bfv relinearize: keyswitchpool[2], [3] (two polys over Q)
     Pool zerosQ;           // one poly of zeros over Q: the `plus` operand of the NTT epilogue where a caller has none
     Pool stageQ, stageP;   // N = 2^16: the extensions land here and the transforms go out of place (fused top stage, see ks_decompose)
+    // small batches: independent launches of one pipeline side by side (PlanFork); stream and events are created at the first fork
+    hipStream_t aux = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    bool fork_failed = false;
+    unsigned long long forks = 0, grouped_ext = 0;     // diagnostics (lr_ckks_plan_stats)
+    const std::atomic<int> *lanes_running = nullptr;   // set while the plan is a batcher's lane: that batcher's batches on the device
 };
 
 // ------------------------------------------------------------------------------------------
@@ -934,6 +943,11 @@ EpiLimb make_epi_limb(const lr_context *c, int l, u64 cc) {
     return e;
 }
 
+// Fork: launches of the calling thread that go to a plan's auxiliary stream instead of the context's (PlanFork, below): two independent
+// transforms of a small batch run side by side instead of one after the other.  Only forward transforms are forked (they lease no scratch).
+thread_local hipStream_t g_fork_stream = nullptr;
+inline hipStream_t stream_of(const lr_context *c) { return g_fork_stream ? g_fork_stream : c->stream; }
+
 int run_ntt_launch(lr_context *c, bool inverse, Rows in, Rows out, int mod0, int mod_step, int count, int batch, int hole,
                    int group, const NttEpilogue *epi, bool pretop);
 
@@ -1027,29 +1041,29 @@ int run_ntt_launch(lr_context *c, bool inverse, Rows in, Rows out, int mod0, int
         a.epi_plus_stride = epi->plus_stride;
         a.epi_consts = epi->consts;
         if (logn == 16)
-            LR_HIP(launch_ntt_asm16(a, 0, pretop ? 'p' : 's', c->asm_fwd == 3 ? 4 : 5, c->stream, kn, c->opt.stagger));
+            LR_HIP(launch_ntt_asm16(a, 0, pretop ? 'p' : 's', c->asm_fwd == 3 ? 4 : 5, stream_of(c), kn, c->opt.stagger));
         else
-            LR_HIP(launch_ntt_asm(a, (int)logn, 0, c->asm_fwd == 3 ? 4 : 5, c->stream, c->opt.asm14_1024, kn, false, c->opt.stagger));
+            LR_HIP(launch_ntt_asm(a, (int)logn, 0, c->asm_fwd == 3 ? 4 : 5, stream_of(c), c->opt.asm14_1024, kn, false, c->opt.stagger));
         return LR_OK;
     }
     if (logn == 16 && variant >= 0 && c->use_asm && ntt_asm_available(16)) {
         // two 2^15 sub-blocks per limb on the assembly kernels + the streaming stage over bit 15
         if (!inverse) {
             if (pretop) {
-                LR_HIP(launch_ntt_asm16(a, 0, 'p', variant, c->stream, kn, c->opt.stagger));
+                LR_HIP(launch_ntt_asm16(a, 0, 'p', variant, stream_of(c), kn, c->opt.stagger));
                 return LR_OK;
             }
             if (ntt_rows_disjoint(a, 16)) {
-                LR_HIP(launch_ntt_asm16(a, 0, 's', variant, c->stream, kn, c->opt.stagger));     // top stage fused into the loads
+                LR_HIP(launch_ntt_asm16(a, 0, 's', variant, stream_of(c), kn, c->opt.stagger));     // top stage fused into the loads
                 return LR_OK;
             }
-            LR_HIP(launch_ntt_top(a, 0, c->stream));
+            LR_HIP(launch_ntt_top(a, 0, stream_of(c)));
             NttLaunch sub = a;
             sub.in = a.out;                      // continue in place on the output rows
             sub.in_poly_stride = a.out_poly_stride;
             sub.in_limb0 = a.out_limb0;
             sub.in_limb_step = a.out_limb_step;
-            LR_HIP(launch_ntt_asm16(sub, 0, 'p', variant, c->stream, kn, c->opt.stagger));
+            LR_HIP(launch_ntt_asm16(sub, 0, 'p', variant, stream_of(c), kn, c->opt.stagger));
             return LR_OK;
         }
         if (!c->opt.no_invfuse && hole == 0) {
@@ -1058,18 +1072,18 @@ int run_ntt_launch(lr_context *c, bool inverse, Rows in, Rows out, int mod0, int
             ScratchLease flags;
             const size_t flag_bytes = (size_t)batch * (size_t)count * 16 * sizeof(u32);
             LR_TRY(flags.take(&c->scratch, (flag_bytes + 7) / 8));
-            LR_HIP(hipMemsetAsync(flags.d(), 0, flag_bytes, c->stream));
+            LR_HIP(hipMemsetAsync(flags.d(), 0, flag_bytes, stream_of(c)));
             a.epi_x = flags.d();
-            LR_HIP(launch_ntt_asm16(a, 1, 'f', variant, c->stream, kn, c->opt.stagger));
+            LR_HIP(launch_ntt_asm16(a, 1, 'f', variant, stream_of(c), kn, c->opt.stagger));
             return LR_OK;
         }
-        LR_HIP(launch_ntt_asm16(a, 1, 's', variant, c->stream, kn, c->opt.stagger));
+        LR_HIP(launch_ntt_asm16(a, 1, 's', variant, stream_of(c), kn, c->opt.stagger));
         NttLaunch top = a;
         top.in = a.out;
         top.in_poly_stride = a.out_poly_stride;
         top.in_limb0 = a.out_limb0;
         top.in_limb_step = a.out_limb_step;
-        LR_HIP(launch_ntt_top(top, 1, c->stream));
+        LR_HIP(launch_ntt_top(top, 1, stream_of(c)));
         return LR_OK;
     }
     if (pretop) return fail(LR_ERR_ARG, "pre-applied top stage: only for forward N = 2^16 launches on the assembly kernels");
@@ -1078,7 +1092,7 @@ int run_ntt_launch(lr_context *c, bool inverse, Rows in, Rows out, int mod0, int
             // diagnostics: the stamped build of the same kernel; stamps land in the context's buffer (lr_context_timeline)
             const size_t words = (size_t)batch * (size_t)count * 16 * 16;
             if (words > c->stamp_words) {
-                LR_HIP(hipStreamSynchronize(c->stream));
+                LR_HIP(hipStreamSynchronize(stream_of(c)));
                 if (c->d_stamps) LR_HIP(hipFree(c->d_stamps));
                 c->d_stamps = nullptr;
                 c->stamp_words = 0;
@@ -1087,14 +1101,14 @@ int run_ntt_launch(lr_context *c, bool inverse, Rows in, Rows out, int mod0, int
             }
             c->stamp_used = words;
             a.epi_x = reinterpret_cast<const u64 *>(c->d_stamps);
-            LR_HIP(launch_ntt_asm(a, (int)logn, inverse, variant, c->stream, false, kn, true, c->opt.stagger, ntt_persist(c, a, logn, inverse)));
+            LR_HIP(launch_ntt_asm(a, (int)logn, inverse, variant, stream_of(c), false, kn, true, c->opt.stagger, ntt_persist(c, a, logn, inverse)));
             return LR_OK;
         }
-        LR_HIP(launch_ntt_asm(a, (int)logn, inverse, variant, c->stream, c->opt.asm14_1024, kn, false, c->opt.stagger, ntt_persist(c, a, logn, inverse)));
+        LR_HIP(launch_ntt_asm(a, (int)logn, inverse, variant, stream_of(c), c->opt.asm14_1024, kn, false, c->opt.stagger, ntt_persist(c, a, logn, inverse)));
         return LR_OK;
     }
     std::snprintf(c->last_ntt_kernel, sizeof c->last_ntt_kernel, "ntt_%s_kernel<%u>", inverse ? "inv" : "fwd", logn);
-    LR_HIP(launch_ntt(a, (int)logn, inverse, c->ntt_mode, c->stream));
+    LR_HIP(launch_ntt(a, (int)logn, inverse, c->ntt_mode, stream_of(c)));
     return LR_OK;
 }
 
@@ -1473,8 +1487,38 @@ namespace {
 
 ExtSegment segment(u64 *out, long long stride, int limb0, int col0, int count);
 
+// extensions recorded instead of launched (ks_decompose: the digits of one key switch go out as one grouped launch)
+struct ExtPending {
+    ExtLaunch L;
+    int n_in;
+};
+
+int flush_ext(lr_context *c, std::vector<ExtPending> &pending, int batch, unsigned long long *grouped_launches = nullptr) {
+    size_t i = 0;
+    while (i < pending.size()) {
+        size_t j = i + 1;
+        while (j < pending.size() && pending[j].n_in == pending[i].n_in && j - i < (size_t)kExtGroupMax) ++j;
+        bool grouped = false;
+        if (j - i > 1) {
+            ExtLaunch Ls[kExtGroupMax];
+            for (size_t k = i; k < j; ++k) Ls[k - i] = pending[k].L;
+            const hipError_t e = launch_ext_group(Ls, (int)(j - i), pending[i].n_in, batch, c->stream);
+            if (e == hipSuccess) {
+                grouped = true;
+                if (grouped_launches) *grouped_launches += 1;
+            }
+            else if (e != hipErrorNotSupported) return fail(LR_ERR_HIP, std::string("launch_ext_group: ") + hipGetErrorString(e));
+        }
+        if (!grouped)
+            for (size_t k = i; k < j; ++k) LR_HIP(launch_ext(pending[k].L, pending[k].n_in, batch, c->stream));
+        i = j;
+    }
+    pending.clear();
+    return LR_OK;
+}
+
 int run_ext(lr_context *c, const DevModup &m, int n_in, Rows in, int batch, ExtSegment s0, ExtSegment s1,
-            const ExtSegment *s2 = nullptr) {
+            const ExtSegment *s2 = nullptr, std::vector<ExtPending> *collect = nullptr) {
     if (n_in < 1 || n_in > 40 || n_in > (int)m.h.Q.size()) return fail(LR_ERR_UNSUPPORTED, "basis extension from 1..40 limbs");
     ExtLaunch L;
     L.t = m.tables();
@@ -1485,6 +1529,10 @@ int run_ext(lr_context *c, const DevModup &m, int n_in, Rows in, int batch, ExtS
     L.seg[0] = s0;
     L.seg[1] = s1;
     L.seg[2] = s2 ? *s2 : segment(nullptr, 0, 0, 0, 0);
+    if (collect) {
+        collect->push_back(ExtPending{L, n_in});
+        return LR_OK;
+    }
     LR_HIP(launch_ext(L, n_in, batch, c->stream));
     return LR_OK;
 }
@@ -1880,7 +1928,7 @@ bool digit_is_extended(const lr_decomposer *d, int level, int crt) {
 // extended digits only -- the caller checks digit_is_extended and ext_top_supported)
 // skip_own: do not write the rows the digit owns (the key switch reads them from the NTT-domain input, or copies them in)
 int decompose_core(lr_decomposer *d, int level, int crt, Rows in, int batch, u64 *outQ, long long outQ_stride, u64 *outP,
-                   long long outP_stride, bool split, bool top = false, bool skip_own = false) {
+                   long long outP_stride, bool split, bool top = false, bool skip_own = false, std::vector<ExtPending> *collect = nullptr) {
     lr_context *c = d->cQ;
     if (crt < 0 || crt >= d->beta) return fail(LR_ERR_SHAPE, "crtDecompLevel out of range");
     if (level < 0 || level + 1 > d->nQ) return fail(LR_ERR_SHAPE, "level out of range");
@@ -1930,9 +1978,9 @@ int decompose_core(lr_decomposer *d, int level, int crt, Rows in, int batch, u64
         ExtSegment hi = segment(outQ, outQ_stride, own_end, own_end, level + 1 - own_end);
         lo.top_tw = hi.top_tw = sq.top_tw;
         hi.top_mod0 = own_end;
-        return run_ext(c, m, index + 2, digit, batch, lo, hi, &sp);
+        return run_ext(c, m, index + 2, digit, batch, lo, hi, &sp, collect);
     }
-    return run_ext(c, m, index + 2, digit, batch, sq, sp);
+    return run_ext(c, m, index + 2, digit, batch, sq, sp, nullptr, collect);
 }
 
 }  // namespace
@@ -2182,6 +2230,14 @@ extern "C" int lr_div_round_by_last_modulus_many(lr_context *c, lr_poly *p0, int
 // ------------------------------------------------------------------------------------------
 // ckks.Evaluator call sequences
 // ------------------------------------------------------------------------------------------
+namespace {
+// live plans per device that are not lanes of a batcher: one = a lone evaluator, whose small launches may run side by side (PlanFork)
+std::atomic<int> &standalone_plans(int device) {
+    static std::atomic<int> counts[64];
+    return counts[device >= 0 && device < 64 ? device : 0];
+}
+}  // namespace
+
 extern "C" int lr_ckks_plan_create(lr_context *cQ, lr_context *cP, int max_batch, lr_ckks_plan **out) {
     return guarded([&]() -> int {
     if (!cQ || !cP || !out) return fail(LR_ERR_ARG, "null argument");
@@ -2200,7 +2256,17 @@ extern "C" int lr_ckks_plan_create(lr_context *cQ, lr_context *cP, int max_batch
         lr_bext_destroy(p->bext);
         return rc;
     }
+    standalone_plans(p->device).fetch_add(1);
     *out = p.release();
+    return LR_OK;
+    });
+}
+
+extern "C" int lr_ckks_plan_stats(const lr_ckks_plan *p, uint64_t *forks, uint64_t *grouped_extensions) {
+    return guarded([&]() -> int {
+    if (!p) return fail(LR_ERR_ARG, "null plan");
+    if (forks) *forks = p->forks;
+    if (grouped_extensions) *grouped_extensions = p->grouped_ext;
     return LR_OK;
     });
 }
@@ -2212,12 +2278,71 @@ extern "C" int lr_ckks_plan_destroy(lr_ckks_plan *p) {
     (void)hipDeviceSynchronize();   // the handle's work may be on its contexts' caller-supplied stream
     lr_bext_destroy(p->bext);
     lr_decomposer_destroy(p->dec);
+    if (p->ev_fork) (void)hipEventDestroy(p->ev_fork);
+    if (p->ev_join) (void)hipEventDestroy(p->ev_join);
+    if (p->aux) (void)hipStreamDestroy(p->aux);
+    if (!p->lanes_running) standalone_plans(p->device).fetch_sub(1);
     delete p;
     return LR_OK;
     });
 }
 
 namespace {
+
+// Two independent launches of one pipeline side by side: between the constructor and join() the calling thread's forward transforms go
+// to the plan's auxiliary stream, which starts behind everything enqueued on the contexts' stream so far; join() makes the contexts'
+// stream wait for them.  Worth it only while the device has room: the forked launch's workgroups times the pipelines that share the
+// device stay below kForkBelow.  Who shares the device is a structural count, not a momentary one (a momentary count of calls being
+// enqueued let sixteen threads fork most of the time and halved their rate; auxiliary streams shared between plans serialised
+// unrelated pipelines behind each other's fork events: profiles/r03/fork_policies.txt):
+//   a plan of its own  -- forks when it is the only such plan alive on its device (the lone evaluator: latency is what it has);
+//   a batcher's lane   -- counts the lanes of its batcher that have a batch on the device.
+// Capturable: the auxiliary stream joins the capture at the fork and leaves it at the join (it is created by the first fork, i.e. in
+// the warm-up call the capture contract asks for).
+constexpr int kForkBelow = 256;
+struct PlanFork {
+    lr_ckks_plan *pl;
+    bool on = false;
+    int rc = LR_OK;
+    PlanFork(lr_ckks_plan *p, int workgroups) : pl(p) {
+        if (pl->opt.no_fork || pl->fork_failed || g_fork_stream) return;
+        const int sharers = pl->lanes_running ? std::max(1, pl->lanes_running->load(std::memory_order_relaxed))
+                                              : (standalone_plans(pl->device).load(std::memory_order_relaxed) == 1 ? 1 : kForkBelow);
+        if ((long long)workgroups * sharers >= kForkBelow) return;
+        if (!pl->aux) {
+            if (hipStreamCreateWithFlags(&pl->aux, hipStreamNonBlocking) != hipSuccess ||
+                hipEventCreateWithFlags(&pl->ev_fork, hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&pl->ev_join, hipEventDisableTiming) != hipSuccess) {
+                (void)hipGetLastError();
+                pl->fork_failed = true;   // the pipelines stay in order on one stream
+                return;
+            }
+        }
+        hipError_t e = hipEventRecord(pl->ev_fork, pl->cQ->stream);
+        if (e == hipSuccess) e = hipStreamWaitEvent(pl->aux, pl->ev_fork, 0);
+        if (e != hipSuccess) {
+            rc = fail(LR_ERR_HIP, std::string("fork: ") + hipGetErrorString(e));
+            return;
+        }
+        on = true;
+        pl->forks += 1;
+        g_fork_stream = pl->aux;
+    }
+    // the launches that follow go to the contexts' stream again (and run beside the forked ones until join())
+    void back() {
+        if (on) g_fork_stream = nullptr;
+    }
+    int join() {
+        if (!on) return LR_OK;
+        on = false;
+        g_fork_stream = nullptr;
+        hipError_t e = hipEventRecord(pl->ev_join, pl->aux);
+        if (e == hipSuccess) e = hipStreamWaitEvent(pl->cQ->stream, pl->ev_join, 0);
+        if (e != hipSuccess) return fail(LR_ERR_HIP, std::string("join: ") + hipGetErrorString(e));
+        return LR_OK;
+    }
+    ~PlanFork() { (void)join(); }   // error paths: the contexts' stream still waits for whatever was forked
+};
 
 // switchKeysInPlace, ckks/evaluator.go:1475-1558, on raw buffers: cx/p0/p1 have `q_stride` between batch polys
 // `fin` (optional): the ModDown results go to fin->out0/out1 with fin->plus0/plus1 added (CRed), i.e. the two
@@ -2295,10 +2420,13 @@ int ks_decompose(lr_ckks_plan *pl, int level, int batch, const u64 *cx, long lon
         c2r = cxr;
     }
     int full = 0;   // leading digits that own exactly alpha limbs at this level: their transforms share one launch
+    std::vector<ExtPending> pending;   // the digits' extensions: independent, same shape -> one grouped launch (copy-branch digits launch at once)
+    pending.reserve((size_t)beta);
     for (int i = 0; i < beta; ++i) {
         u64 *dq = pl->c2QiQ.d + (long long)i * dQ;
         // decomposeAndSplitNTT, :1561-1591
-        LR_TRY(decompose_core(dec, level, i, c2r, batch, srcQ + (long long)i * dQ, sQ, srcP + (long long)i * dP, sP, true, exttop, true));
+        LR_TRY(decompose_core(dec, level, i, c2r, batch, srcQ + (long long)i * dQ, sQ, srcP + (long long)i * dP, sP, true, exttop, true,
+                              pl->opt.no_ext_group ? nullptr : &pending));
         const int d0 = i * alpha;
         int d1 = d0 + dec->xalpha[i];
         if (d1 > level + 1) d1 = level + 1;
@@ -2307,6 +2435,16 @@ int ks_decompose(lr_ckks_plan *pl, int level, int batch, const u64 *cx, long lon
                              sQ, nullptr, d0));
         if (d1 - d0 == alpha && full == i) ++full;
     }
+    LR_TRY(flush_ext(cQ, pending, batch, &pl->grouped_ext));
+    // the digits' P rows beside their Q rows (another kernel variant, so another launch: at a small batch each fills a fraction of the chip)
+    PlanFork forkP(pl, nP * beta * batch);
+    LR_TRY(forkP.rc);
+    if (forkP.on) {
+        Rows pr{pl->c2QiP.d, sP, 0, 1}, pr_in{srcP, sP, 0, 1};                   // :1590, every digit's P rows
+        LR_TRY(run_ntt(cP, false, pr_in, pr, 0, 1, nP, beta * batch, 0, 0, nullptr, exttop));
+        forkP.back();
+    }
+    const bool p_rows_done = forkP.on;
     if (full > 0 && level + 1 - alpha > 0) {
         // limbs outside each digit's own block, all full digits at once (grid z = digit)
         Rows in{srcQ, sQ, 0, 1}, all{pl->c2QiQ.d, sQ, 0, 1};
@@ -2322,11 +2460,11 @@ int ks_decompose(lr_ckks_plan *pl, int level, int batch, const u64 *cx, long lon
         Rows hi{dq, sQ, d1, 1}, hi_in{sq, sQ, d1, 1};
         LR_TRY(run_ntt(cQ, false, hi_in, hi, d1, 1, level + 1 - d1, batch, 0, 0, nullptr, exttop));     // limbs above the digit
     }
-    {
+    if (!p_rows_done) {
         Rows pr{pl->c2QiP.d, sP, 0, 1}, pr_in{srcP, sP, 0, 1};                   // :1590, every digit's P rows
         LR_TRY(run_ntt(cP, false, pr_in, pr, 0, 1, nP, beta * batch, 0, 0, nullptr, exttop));
     }
-    return LR_OK;
+    return forkP.join();
 }
 
 // exact 128-bit sums in the key inner product: beta products below q^2 each must stay below q * 2^64
@@ -2455,14 +2593,19 @@ int ks_accumulate(lr_ckks_plan *pl, int level, int batch, const u64 *digQ, const
                 int l1 = l0 + 1;
                 while (l1 <= level && ntt_epilogue_limb(cQ, l1) == fpc) ++l1;
                 if (fpc) {
-                    for (int k = 0; k < 2; ++k) {
+                    // the two components are independent launches: side by side while one alone leaves most of the chip idle
+                    PlanFork fork1(pl, (l1 - l0) * batch);
+                    LR_TRY(fork1.rc);
+                    for (int k = 1; k >= 0; --k) {
                         Rows src{ext_out + (long long)k * batch * sQ, sQ, l0, 1};
                         Rows dst{outs[k], out_strides[k], l0, 1};
                         const u64 *plus = pluses[k];
                         const NttEpilogue ep{k == 0 ? p0 : p1, k == 0 ? p0_stride : p1_stride, plus ? plus : pl->zerosQ.d,
                                              plus ? plus_stride : 0, bx->d_moddown_pq_epi};
                         LR_TRY(run_ntt(cQ, false, src, dst, l0, 1, l1 - l0, batch, 0, 0, &ep, exttop));
+                        fork1.back();
                     }
+                    LR_TRY(fork1.join());
                 } else {
                     Rows src{ext_out, sQ, l0, 1}, dst{bx->poolQ.d, sQ, l0, 1};
                     LR_TRY(run_ntt(cQ, false, src, dst, l0, 1, l1 - l0, 2 * batch, 0, 0, nullptr, exttop));
@@ -2717,6 +2860,7 @@ struct lr_ckks_batcher {
     std::deque<Request *> queue;
     unsigned long long batches = 0, products = 0;
     int largest = 0;
+    std::atomic<int> running{0};   // lanes with a batch on the device (the lanes' plans read it: PlanFork)
 };
 
 namespace {
@@ -2743,6 +2887,11 @@ int batcher_run(lr_ckks_batcher *B, lr_ckks_batcher::Lane &lane, const std::vect
     LR_HIP(hipMemcpyAsync(lane.d_table, lane.h_table, (size_t)6 * mb * sizeof(u64 *), hipMemcpyHostToDevice, cQ->stream));
     TensorLaunch T{};
     T.table = (const u64 *const *)lane.d_table;
+    struct Running {   // until the batch has left the device
+        std::atomic<int> &n;
+        explicit Running(std::atomic<int> &c) : n(c) { n.fetch_add(1, std::memory_order_relaxed); }
+        ~Running() { n.fetch_sub(1, std::memory_order_relaxed); }
+    } running(B->running);
     LR_TRY(mulrelin_core(pl, level, batch, T, reqs[0]->evk, lane.o0.d, lane.o1.d, s));
     ScatterLaunch S{{lane.o0.d, lane.o1.d}, s, lane.d_table + 4 * mb, 2, n};
     LR_HIP(launch_scatter(S, L1, batch, cQ->stream));
@@ -2769,12 +2918,15 @@ extern "C" int lr_ckks_batcher_create(lr_ckks_plan *const *plans, int n_lanes, l
         for (int j = 0; j < i; ++j)
             if (plans[j] == pl || plans[j]->cQ == pl->cQ || plans[j]->cP == pl->cP)
                 return fail(LR_ERR_ARG, "every lane needs its own plan over its own pair of contexts");
+        if (pl->lanes_running) return fail(LR_ERR_ARG, "a plan can be the lane of one batcher only");
     }
     LR_HIP(hipSetDevice(plans[0]->device));
     B->lanes.resize(n_lanes);
     for (int i = 0; i < n_lanes; ++i) {
         auto &ln = B->lanes[i];
         ln.plan = plans[i];
+        if (!ln.plan->lanes_running) standalone_plans(ln.plan->device).fetch_sub(1);
+        ln.plan->lanes_running = &B->running;
         ln.take.reserve((size_t)std::max(1, B->max_batch));
         LR_HIP(hipStreamCreateWithFlags(&ln.stream, hipStreamNonBlocking));
         LR_TRY(lr_context_set_stream(ln.plan->cQ, ln.stream));
@@ -2790,6 +2942,10 @@ extern "C" int lr_ckks_batcher_create(lr_ckks_plan *const *plans, int n_lanes, l
 extern "C" void lr_ckks_batcher_destroy(lr_ckks_batcher *B) {
     if (!B) return;
     for (auto &ln : B->lanes) {
+        if (ln.plan && ln.plan->lanes_running == &B->running) {
+            ln.plan->lanes_running = nullptr;
+            standalone_plans(ln.plan->device).fetch_add(1);
+        }
         if (ln.stream) {   // back to the library's stream (ordered behind the lane's work), then the lane stream can go
             (void)lr_context_set_stream(ln.plan->cQ, nullptr);
             (void)lr_context_set_stream(ln.plan->cP, nullptr);

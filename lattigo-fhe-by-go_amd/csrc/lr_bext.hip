@@ -212,7 +212,7 @@ struct ExtColumn {
 };
 
 template <int NIN, int W, bool TOP>
-__global__ __launch_bounds__(256) void ext_sum_kernel(ExtLaunch L) {
+__device__ __forceinline__ void ext_sum_body(const ExtLaunch &L) {
     constexpr int C = TOP ? 2 * W : W;                         // coefficient columns per thread
     const int xw = blockIdx.x * 256 + threadIdx.x;
     const int span = TOP ? L.n >> 1 : L.n;
@@ -333,6 +333,18 @@ __global__ __launch_bounds__(256) void ext_sum_kernel(ExtLaunch L) {
 // About 6 VALU instructions per term instead of the ~23 of an exact Shoup product with its share of the Barrett steps.
 __device__ __forceinline__ void mad_carry(u32 c, u32 y, u64 &acc, u32 &carries) {
     asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc" : "+v"(acc), "+v"(carries) : "s"(c), "v"(y) : "vcc");
+}
+
+template <int NIN, int W, bool TOP>
+__global__ __launch_bounds__(256) void ext_sum_kernel(ExtLaunch L) {
+    ext_sum_body<NIN, W, TOP>(L);
+}
+
+// the same on several extensions at once (grid z): the digits of one key switch are independent launches of the same shape, and at a
+// small batch each alone fills a quarter of the chip.  The launch records travel in the kernel-argument block and are read by index.
+template <int NIN, int W, bool TOP>
+__global__ __launch_bounds__(256) void ext_sum_group_kernel(ExtGroupLaunch G) {
+    ext_sum_body<NIN, W, TOP>(G.L[blockIdx.z]);
 }
 
 // G = terms per Montgomery reduction (G * max q_i < 2^64); NIN > G: the partial residues (each below p_j) are added up.
@@ -530,6 +542,55 @@ hipError_t launch_ext(const ExtLaunch &L, int n_in, int batch, hipStream_t strea
         LR_EXT(33) LR_EXT(34) LR_EXT(35) LR_EXT(36) LR_EXT(37) LR_EXT(38) LR_EXT(39) LR_EXT(40)
 #undef LR_EXT
     default: return hipErrorInvalidValue;
+    }
+}
+
+// Several extensions of one shape in one launch.  Only the sum-form kernel (what every key-switch digit of the default parameter sets
+// takes) has the grouped form; hipErrorNotSupported tells the caller to launch the records one by one.
+template <int NIN>
+static hipError_t launch_group_n(const ExtLaunch *Ls, int count, int batch, hipStream_t stream) {
+    if constexpr (NIN > 8) {
+        return hipErrorNotSupported;
+    } else {
+        const ExtLaunch &L0 = Ls[0];
+        const bool top = L0.seg[0].top_tw != nullptr;
+        for (int k = 0; k < count; ++k) {
+            const ExtLaunch &L = Ls[k];
+            if ((L.n & 1) != 0 || L.n != L0.n || L.t.exact_terms < 4 || !L.t.fast_div_ok || (L.seg[0].top_tw != nullptr) != top ||
+                !(L.t.lazy_terms >= (NIN < 2 ? 2 : NIN) && L.t.word_barrett))
+                return hipErrorNotSupported;
+        }
+        ExtGroupLaunch G;
+        for (int k = 0; k < count; ++k) G.L[k] = Ls[k];
+        for (int k = count; k < kExtGroupMax; ++k) G.L[k] = Ls[0];
+        (void)hipGetLastError();
+        const dim3 block(256);
+        if (top) {
+            constexpr int WT = NIN <= 3 ? 2 : 1;
+            const dim3 grid((unsigned)((L0.n / 2 / WT + 255) / 256), (unsigned)batch, (unsigned)count);
+            hipLaunchKernelGGL((ext_sum_group_kernel<NIN, WT, true>), grid, block, 0, stream, G);
+        } else {
+            constexpr int W = 2;
+            const dim3 grid((unsigned)((L0.n / W + 255) / 256), (unsigned)batch, (unsigned)count);
+            hipLaunchKernelGGL((ext_sum_group_kernel<NIN, W, false>), grid, block, 0, stream, G);
+        }
+        return hipGetLastError();
+    }
+}
+
+hipError_t launch_ext_group(const ExtLaunch *Ls, int count, int n_in, int batch, hipStream_t stream) {
+    if (batch <= 0 || count <= 0) return hipSuccess;
+    if (count > kExtGroupMax) return hipErrorNotSupported;
+    switch (n_in) {
+    case 1: return launch_group_n<1>(Ls, count, batch, stream);
+    case 2: return launch_group_n<2>(Ls, count, batch, stream);
+    case 3: return launch_group_n<3>(Ls, count, batch, stream);
+    case 4: return launch_group_n<4>(Ls, count, batch, stream);
+    case 5: return launch_group_n<5>(Ls, count, batch, stream);
+    case 6: return launch_group_n<6>(Ls, count, batch, stream);
+    case 7: return launch_group_n<7>(Ls, count, batch, stream);
+    case 8: return launch_group_n<8>(Ls, count, batch, stream);
+    default: return hipErrorNotSupported;
     }
 }
 

@@ -39,6 +39,8 @@ struct Options {
     bool timeline = false;         // LR_NTT_TIMELINE: plain 2^15 launches (forward / inverse, integer variant 1 and dual variant 3) run the stamped diagnostics builds
     bool keymac_narrow = false;    // LR_KEYMAC_NARROW: one Montgomery product per term in the key inner product instead of the 128-bit sums
     bool no_invfuse = false;       // LR_NO_INVFUSE: N = 2^16 inverse transforms as lazy sub-blocks + the separate last-stage pass (ntt_top_kernel) instead of the pair-flag kernels
+    bool no_fork = false;          // LR_NO_FORK: the key switch's independent launches in order on one stream at every batch size
+    bool no_ext_group = false;     // LR_NO_EXT_GROUP: one extension launch per key-switch digit instead of one grouped launch
     bool no_exttop = false;        // LR_NO_EXTTOP: N = 2^16 key switch with staged extensions and fused-top transforms instead of the top stage inside the extension
     int persist = -1;              // LR_NTT_PERSIST: polys per workgroup of the persistent forward 2^15 kernels (0 = one-poly workgroups, -1 = default)
     int stagger = -1;              // LR_NTT_STAGGER: start-up stagger of the assembly NTT kernels in kilo-clocks per step (0 = off)
@@ -295,6 +297,11 @@ struct ExtLaunch {
     ExtSegment seg[kExtSegments];   // unused segments have count == 0
 };
 
+constexpr int kExtGroupMax = 9;    // extensions per grouped launch (the digits of one key switch: beta = 9 at PN16QP1761)
+struct ExtGroupLaunch {
+    ExtLaunch L[kExtGroupMax];
+};
+
 #if defined(__HIPCC__)
 // Tables that no kernel writes, read at wave-uniform addresses: through the constant address space, so that the
 // compiler keeps using scalar loads after the kernel has started storing (it cannot prove that the stores do not
@@ -342,6 +349,8 @@ hipError_t launch_submul(const SubMulLaunch &L, int limbs, int batch, hipStream_
 hipError_t launch_rowadd(const RowAddLaunch &L, int rows, int batch, hipStream_t stream);
 hipError_t launch_half_scalar(const HalfScalarLaunch &L, int limbs, int batch, hipStream_t stream);
 hipError_t launch_ext(const ExtLaunch &L, int n_in, int batch, hipStream_t stream);
+// `count` extensions of the same shape (n_in input limbs each) as one launch; hipErrorNotSupported when the shape has no grouped form
+hipError_t launch_ext_group(const ExtLaunch *Ls, int count, int n_in, int batch, hipStream_t stream);
 bool ext_top_supported(const ExtTables &t, int n_in, int n);
 bool ext_epilogue_supported(const ExtTables &t, int n_in, int n);
 hipError_t launch_div_selftest(u64 seed, int blocks, int per_thread, unsigned long long *d_mismatches, hipStream_t stream);

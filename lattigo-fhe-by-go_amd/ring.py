@@ -548,6 +548,12 @@ class CkksPlan:
         except Exception:
             pass
 
+    def Stats(self):
+        """diagnostics: forks (independent launches of a small batch side by side), grouped digit extensions (lr_ckks_plan_stats)"""
+        f, g = C.c_uint64(), C.c_uint64()
+        check(lib().lr_ckks_plan_stats(self.h, C.byref(f), C.byref(g)))
+        return {"forks": f.value, "grouped_extensions": g.value}
+
     def NewSwitchingKey(self, batch=1):
         """Storage for SwitchingKey.evakey (ckks/keygen.go:68-70): beta x 2 polys over Q||P."""
         nQ, nP = len(self.contextQ.Modulus), len(self.contextP.Modulus)
