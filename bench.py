@@ -469,6 +469,11 @@ def main():
     def emit(obj):
         os.write(json_fd, (json.dumps(obj) + "\n").encode())
 
+    # Streams are bound to hardware queues when they are created, four per priority class by default; two streams on one queue run one
+    # after the other, and which ones collide depends on every stream the process has created (profiles/r03/hw_queues.txt).
+    # Only the evaluator-per-thread rows have more than one stream with work; the setting is reported there.  The runtime reads it once,
+    # at its initialisation, hence here.
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
     import numpy as np
     import torch
 
@@ -1021,7 +1026,9 @@ def main():
                     tlevel, np.stack([tops[0][0], tops[1][0]]), np.stack([tops[2][0], tops[3][0]]), tkey_h.reshape(tbeta, 2, tnq + tnp, tN))
             ok_t = all(np.array_equal(w[7][0].get().reshape(tnq, tN), want_t[0]) and np.array_equal(w[7][1].get().reshape(tnq, tN), want_t[1]) for w in workers)
             rows.append({"threads": T, "streams": T, "batch_per_call": 1, "calls_per_thread": iters, "mulrelin_per_s": T * iters / dt_w,
-                         "us_per_product_per_thread": dt_w / iters * 1e6, "bit_exact": bool(ok_t)})
+                         "us_per_product_per_thread": dt_w / iters * 1e6, "bit_exact": bool(ok_t),
+                         # a lone plan runs the key switch's independent small launches side by side (lr_ckks_plan_stats); several plans do not
+                         "forks_per_call": workers[0][3].Stats()["forks"] / (iters + 1)})
             del workers, ths
         # the same callers through the batcher (lr_ckks_batcher_*): concurrent batch-1 calls are merged into batched launches on two lanes
         brows = []
@@ -1059,6 +1066,7 @@ def main():
             del callers, ths
         del bat
         out["evaluator_threads"] = {"params": "PN15QP880, level 17, batch 1 per call, one plan + contexts + stream per host thread", "rows": rows,
+                                    "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES"),
                                     "batcher_rows": brows,
                                     "batcher": "the same batch-1 calls through lr_ckks_batcher_mulrelin: queued requests run as one batched MulRelin per free lane",
                                     "reference_model": "one evaluator per goroutine (examples/dbfv/psi/psi.go:215-233)"}

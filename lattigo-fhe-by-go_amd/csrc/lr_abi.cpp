@@ -77,6 +77,22 @@ int to_device(T **dst, const T *src, size_t count) {
 // One stream per device, shared by every handle on that device and never destroyed: operations of
 // related handles (contextQ / contextP / basis extender / plan) are ordered by construction, and a
 // poly can be released safely whatever order a garbage-collected host language frees handles in.
+// The library's own streams.  The runtime binds a stream to one of a few hardware queues per priority class when it is created (four
+// per class unless GPU_MAX_HW_QUEUES says otherwise), in an order that depends on every stream the process has created before; two
+// streams on one hardware queue run one after the other.  Streams that must overlap -- a batcher's lanes, a plan's auxiliary stream
+// beside the caller's -- therefore get different priority CLASSES, the one way to be sure of different queues (profiles/r03/
+// hw_queues.txt: the same two lanes gave 10.8 k or 13.6 k products/s depending on what earlier legs of the process had created).
+// cls: 0 = the default class (hipStreamCreateWithFlags), 1 = the device's greatest priority, 2 = its least.
+hipError_t create_stream(hipStream_t *s, int cls = 0) {
+    if (cls == 0) return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
+    int least = 0, greatest = 0;
+    if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess || least == greatest) {
+        (void)hipGetLastError();
+        return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
+    }
+    return hipStreamCreateWithPriority(s, hipStreamNonBlocking, cls == 1 ? greatest : least);
+}
+
 hipStream_t shared_stream(int device) {
     static std::mutex mu;
     static std::map<int, hipStream_t> streams;
@@ -84,7 +100,7 @@ hipStream_t shared_stream(int device) {
     auto it = streams.find(device);
     if (it != streams.end()) return it->second;
     hipStream_t s = nullptr;
-    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) {
+    if (hipSetDevice(device) != hipSuccess || create_stream(&s) != hipSuccess) {
         (void)hipGetLastError();
         return nullptr;
     }
@@ -374,7 +390,7 @@ struct lr_ckks_plan {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool fork_failed = false;
     unsigned long long forks = 0, grouped_ext = 0;     // diagnostics (lr_ckks_plan_stats)
-    const std::atomic<int> *lanes_running = nullptr;   // set while the plan is a batcher's lane: that batcher's batches on the device
+    const void *lane_of = nullptr;   // the batcher this plan is a lane of (lanes never fork: their batcher keeps the device busy)
 };
 
 // ------------------------------------------------------------------------------------------
@@ -2281,7 +2297,7 @@ extern "C" int lr_ckks_plan_destroy(lr_ckks_plan *p) {
     if (p->ev_fork) (void)hipEventDestroy(p->ev_fork);
     if (p->ev_join) (void)hipEventDestroy(p->ev_join);
     if (p->aux) (void)hipStreamDestroy(p->aux);
-    if (!p->lanes_running) standalone_plans(p->device).fetch_sub(1);
+    if (!p->lane_of) standalone_plans(p->device).fetch_sub(1);
     delete p;
     return LR_OK;
     });
@@ -2291,12 +2307,15 @@ namespace {
 
 // Two independent launches of one pipeline side by side: between the constructor and join() the calling thread's forward transforms go
 // to the plan's auxiliary stream, which starts behind everything enqueued on the contexts' stream so far; join() makes the contexts'
-// stream wait for them.  Worth it only while the device has room: the forked launch's workgroups times the pipelines that share the
-// device stay below kForkBelow.  Who shares the device is a structural count, not a momentary one (a momentary count of calls being
-// enqueued let sixteen threads fork most of the time and halved their rate; auxiliary streams shared between plans serialised
-// unrelated pipelines behind each other's fork events: profiles/r03/fork_policies.txt):
-//   a plan of its own  -- forks when it is the only such plan alive on its device (the lone evaluator: latency is what it has);
-//   a batcher's lane   -- counts the lanes of its batcher that have a batch on the device.
+// stream wait for them.  Worth it only on an otherwise idle device and while the forked launch is far from filling it (kForkBelow
+// workgroups).  "Otherwise idle" is a structural test, not a momentary one: the plan is the only one alive on its device that is not a
+// batcher's lane -- the lone evaluator, for whom latency is what there is.
+// Tried and dropped (profiles/r03/fork_policies.txt): forking whenever the launch is small (sixteen threads with a plan each lose a
+// quarter of their rate), counting the calls being enqueued at the moment (the count is below the threads most of the time), auxiliary
+// streams shared between plans (unrelated pipelines queue behind each other's fork events), an auxiliary stream created with every
+// plan (twice the streams on the runtime's four hardware queues: slower without a single fork), lanes of a batcher that fork while
+// they are the only lane running (13.4 k products/s against 12.5 k from a C++ host at sixteen callers, 10.5 k against 13.6 k from
+// Python threads: the extra streams share hardware queues with the lanes' own, see GPU_MAX_HW_QUEUES in DESIGN 9).
 // Capturable: the auxiliary stream joins the capture at the fork and leaves it at the join (it is created by the first fork, i.e. in
 // the warm-up call the capture contract asks for).
 constexpr int kForkBelow = 256;
@@ -2306,11 +2325,9 @@ struct PlanFork {
     int rc = LR_OK;
     PlanFork(lr_ckks_plan *p, int workgroups) : pl(p) {
         if (pl->opt.no_fork || pl->fork_failed || g_fork_stream) return;
-        const int sharers = pl->lanes_running ? std::max(1, pl->lanes_running->load(std::memory_order_relaxed))
-                                              : (standalone_plans(pl->device).load(std::memory_order_relaxed) == 1 ? 1 : kForkBelow);
-        if ((long long)workgroups * sharers >= kForkBelow) return;
+        if (pl->lane_of || standalone_plans(pl->device).load(std::memory_order_relaxed) != 1 || workgroups >= kForkBelow) return;
         if (!pl->aux) {
-            if (hipStreamCreateWithFlags(&pl->aux, hipStreamNonBlocking) != hipSuccess ||
+            if (create_stream(&pl->aux, 1) != hipSuccess ||
                 hipEventCreateWithFlags(&pl->ev_fork, hipEventDisableTiming) != hipSuccess ||
                 hipEventCreateWithFlags(&pl->ev_join, hipEventDisableTiming) != hipSuccess) {
                 (void)hipGetLastError();
@@ -2860,7 +2877,6 @@ struct lr_ckks_batcher {
     std::deque<Request *> queue;
     unsigned long long batches = 0, products = 0;
     int largest = 0;
-    std::atomic<int> running{0};   // lanes with a batch on the device (the lanes' plans read it: PlanFork)
 };
 
 namespace {
@@ -2887,11 +2903,6 @@ int batcher_run(lr_ckks_batcher *B, lr_ckks_batcher::Lane &lane, const std::vect
     LR_HIP(hipMemcpyAsync(lane.d_table, lane.h_table, (size_t)6 * mb * sizeof(u64 *), hipMemcpyHostToDevice, cQ->stream));
     TensorLaunch T{};
     T.table = (const u64 *const *)lane.d_table;
-    struct Running {   // until the batch has left the device
-        std::atomic<int> &n;
-        explicit Running(std::atomic<int> &c) : n(c) { n.fetch_add(1, std::memory_order_relaxed); }
-        ~Running() { n.fetch_sub(1, std::memory_order_relaxed); }
-    } running(B->running);
     LR_TRY(mulrelin_core(pl, level, batch, T, reqs[0]->evk, lane.o0.d, lane.o1.d, s));
     ScatterLaunch S{{lane.o0.d, lane.o1.d}, s, lane.d_table + 4 * mb, 2, n};
     LR_HIP(launch_scatter(S, L1, batch, cQ->stream));
@@ -2918,17 +2929,17 @@ extern "C" int lr_ckks_batcher_create(lr_ckks_plan *const *plans, int n_lanes, l
         for (int j = 0; j < i; ++j)
             if (plans[j] == pl || plans[j]->cQ == pl->cQ || plans[j]->cP == pl->cP)
                 return fail(LR_ERR_ARG, "every lane needs its own plan over its own pair of contexts");
-        if (pl->lanes_running) return fail(LR_ERR_ARG, "a plan can be the lane of one batcher only");
+        if (pl->lane_of) return fail(LR_ERR_ARG, "a plan can be the lane of one batcher only");
     }
     LR_HIP(hipSetDevice(plans[0]->device));
     B->lanes.resize(n_lanes);
     for (int i = 0; i < n_lanes; ++i) {
         auto &ln = B->lanes[i];
         ln.plan = plans[i];
-        if (!ln.plan->lanes_running) standalone_plans(ln.plan->device).fetch_sub(1);
-        ln.plan->lanes_running = &B->running;
+        if (!ln.plan->lane_of) standalone_plans(ln.plan->device).fetch_sub(1);
+        ln.plan->lane_of = B.get();
         ln.take.reserve((size_t)std::max(1, B->max_batch));
-        LR_HIP(hipStreamCreateWithFlags(&ln.stream, hipStreamNonBlocking));
+        LR_HIP(create_stream(&ln.stream, (i + 1) % 3));   // lane 0: greatest priority, lane 1: least, lane 2: default, ...
         LR_TRY(lr_context_set_stream(ln.plan->cQ, ln.stream));
         LR_TRY(lr_context_set_stream(ln.plan->cP, ln.stream));
         LR_HIP(hipHostMalloc((void **)&ln.h_table, (size_t)6 * B->max_batch * sizeof(u64 *)));
@@ -2942,8 +2953,8 @@ extern "C" int lr_ckks_batcher_create(lr_ckks_plan *const *plans, int n_lanes, l
 extern "C" void lr_ckks_batcher_destroy(lr_ckks_batcher *B) {
     if (!B) return;
     for (auto &ln : B->lanes) {
-        if (ln.plan && ln.plan->lanes_running == &B->running) {
-            ln.plan->lanes_running = nullptr;
+        if (ln.plan && ln.plan->lane_of == B) {
+            ln.plan->lane_of = nullptr;
             standalone_plans(ln.plan->device).fetch_add(1);
         }
         if (ln.stream) {   // back to the library's stream (ordered behind the lane's work), then the lane stream can go

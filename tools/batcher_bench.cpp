@@ -71,7 +71,9 @@ int main(int argc, char **argv) {
         CK(lr_context_create(N, Q.data(), nq, 0, &c.cq));
         CK(lr_context_create(N, P.data(), np, 0, &c.cp));
         hipStream_t st = nullptr;
-        if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) return 1;
+        // STREAM_PRIORITY=<p>: created the way torch creates its pool streams (hipStreamCreateWithPriority)
+        const char *prio = std::getenv("STREAM_PRIORITY");
+        if ((prio ? hipStreamCreateWithPriority(&st, hipStreamNonBlocking, std::atoi(prio)) : hipStreamCreateWithFlags(&st, hipStreamNonBlocking)) != hipSuccess) return 1;
         CK(lr_context_set_stream(c.cq, st));
         CK(lr_context_set_stream(c.cp, st));
         CK(lr_ckks_plan_create(c.cq, c.cp, 1, &c.plan));
