@@ -509,6 +509,14 @@ class Gen:
         e("s_lshr_b32", self.WAVE, self.WAVE, 6)
         e("s_waitcnt", "lgkmcnt(0)")
         sc = self.SC
+        if not self.swap_grid:
+            # x = limb of the launch, and consecutive workgroups go to the eight XCDs in turn: the host pads grid x to a multiple of
+            # eight (lr_asm.cpp) so that an XCD keeps seeing the same limbs -- their twiddle tables and the epilogue's shared rows stay in
+            # its L2 -- and the workgroups beyond the launch's n_items (s50) have nothing to do
+            e("s_cmp_lt_u32", self.WGX, s(50))
+            e("s_cbranch_scc1", "L_limb_ok")
+            e("s_endpgm")
+            self.p.label("L_limb_ok")
         self.stagger()
         self.park_stamp_slot()
         if self.sub and self.epi:

@@ -68,6 +68,11 @@ static int stagger_unit(int request, bool one_wg_per_cu, bool dual, unsigned lon
     return request > 0 ? request : 0;
 }
 
+static bool no_grid_padding() {
+    static const bool off = std::getenv("LR_NTT_NO_GRID_PADDING") != nullptr;   // diagnostics: the unpadded grid (read once per process)
+    return off;
+}
+
 bool ntt_asm_available(int logn) { return logn >= 12 && logn <= 16 && kernels_for_current_device() != nullptr; }
 
 // variant = lazy-correction mode of asmgen/gen_ntt.py (forward 0, 1, 2) / gen_intt.py (inverse 0, 1)
@@ -111,7 +116,16 @@ hipError_t launch_ntt_asm(const NttLaunch &a, int logn, int inverse, int variant
         args.fuse_top = persist;
         gy = (gy + (unsigned)persist - 1) / (unsigned)persist;
     }
-    const unsigned gx = swapped ? gy : (unsigned)a.n_items, gyy = swapped ? (unsigned)a.n_items : gy;
+    // x = limb: padded to a multiple of eight when the launch has more limbs than one XCD's L2 holds tables for (32 N bytes per limb
+    // against 4 MiB: four limbs at 2^15, eight at 2^14) and their count is not such a multiple -- otherwise workgroup (x, y) lands on
+    // XCD (x + n_items * y) mod 8 and every XCD sees every limb in turn.  The fifteen limbs of a rounding rescale at 2^15 put 15 MiB of
+    // twiddles and 3.8 MiB of epilogue rows through each 4 MiB L2: 4.16 GB per launch on the fabric against 2.59 GB padded
+    // (profiles/r03/rescale_grid_padding.txt; the time moves by 1 % only -- the misses were Infinity Cache hits).  The padding
+    // workgroups leave at once (gen_ntt.py: L_limb_ok).  Seven limbs at 2^14 fit the L2 as they are: padded, that launch was 5 % slower.
+    unsigned gx_items = (unsigned)a.n_items;
+    if (!swapped && !timeline && !no_grid_padding() && (long long)a.n_items * (32ll << logn) > (4ll << 20) && (a.n_items & 7) != 0)
+        gx_items = ((unsigned)a.n_items + 7u) & ~7u;
+    const unsigned gx = swapped ? gy : gx_items, gyy = swapped ? (unsigned)a.n_items : gy;
     args.stagger_gx = (int)gx;
     args.stagger_unit = stagger_unit(stagger, threads == 1024, swapped, (unsigned long long)gx * gyy * gz);
     return hipModuleLaunchKernel(it->second, gx, gyy, gz, threads, 1, 1, 0, stream, nullptr, extra);

@@ -74,7 +74,7 @@ def emulate(gen, inverse=False, q=None, geom=None):
         words = np.ascontiguousarray(arr).view(np.uint32).ravel()
         mem[addr // 4: addr // 4 + words.size] = words
 
-    gx, gy, gz, hole, group, rows = geom or (0, 0, 0, 0, 0, 1)
+    gx, gy, gz, hole, group, rows = (geom or (0, 0, 0, 0, 0, 1))[:6]
     item = gx + (hole if gx >= gz * hole else 0)
     where = ((gz * group + gy) * rows + item) * 8 * N          # byte offset of the addressed row
     span = ((gz * group + gy + 1) * rows + 1) * 8 * N
@@ -119,7 +119,8 @@ def emulate(gen, inverse=False, q=None, geom=None):
     karg[6] = 0 | (0 << 32)        # mod0, mod_step: one modulus serves every row of this harness
     karg[11] = 0 | (hole << 32)    # sub_log, hole
     karg[12] = group               # group, pad
-    karg[7] = 1 | (1 << 32)        # n_items, batch
+    n_items = geom[6] if geom and len(geom) > 6 else gx + 1   # (a seventh entry: fewer items than x + 1 -- a workgroup of the padded grid)
+    karg[7] = n_items | (1 << 32)  # n_items, batch
     karg[8], karg[9], karg[10] = A_LP, A_TW, A_TWF
     if getattr(gen, "profile", False):
         karg[16] = A_STAMPS
@@ -136,6 +137,9 @@ def emulate(gen, inverse=False, q=None, geom=None):
     m.count_lds = bool(__import__("os").environ.get("LR_EMU_LDS_STATS"))
     m.run(prog)
     got = m.mem[(A_OUT + where) // 4: (A_OUT + where) // 4 + 2 * N].view(np.uint64)
+    if n_items <= gx:                                          # a workgroup of the padded grid: leaves at once, its row stays untouched
+        want = np.zeros(N, dtype=np.uint64)
+        assert sum(n for op, n in m.executed.items() if op.startswith(("global_store", "ds_"))) == 0
     ok = np.array_equal(got, want)
     if m.count_lds:
         gen.lds_stats = m.lds_stats
@@ -439,6 +443,11 @@ def emulate_sub(make_gen, inverse, q, pretop=False, order=(0, 1)):
     return ok, info
 
 
+def GenInv_(*a, **k):
+    from gen_intt import GenInv
+    return GenInv(*a, **k)
+
+
 def selftest(logn, inverse=False, threads=1024):
     ok = True
     for mode in ((0, 1) if inverse else (0, 1, 2)):
@@ -454,6 +463,11 @@ def selftest(logn, inverse=False, threads=1024):
             ok = ok and good
             print("%s logN=%d T=%d mode %d q=%d (%d bits): %s; %s" % ("inverse" if inverse else "forward", logn, threads, mode, q, q.bit_length(),
                                                              "bit-exact vs oracle" if good else "MISMATCH", info), flush=True)
+    # grid x padded to a multiple of eight (lr_asm.cpp): the workgroups beyond n_items store nothing (integer kernels: x = limb)
+    for mk in ([lambda: GenInv_(logn, 1, threads)] if inverse else [lambda: Gen(logn, 1, threads), lambda: Gen(logn, 1, threads, epi=True)]):
+        good, info = emulate(mk(), inverse, test_moduli(logn, 1)[0], (3, 1, 0, 0, 0, 4, 3))
+        ok = ok and good
+        print("%s logN=%d T=%d padding workgroup: %s; %s" % ("inverse" if inverse else "forward", logn, threads, "stores nothing" if good else "WROTE", info), flush=True)
     for q in fp_test_moduli(logn):
         if inverse:
             from gen_intt import GenInv
