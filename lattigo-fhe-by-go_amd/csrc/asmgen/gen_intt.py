@@ -646,6 +646,10 @@ if __name__ == "__main__":
         fused = len(sys.argv) > 5 and sys.argv[5] == "fused"
         open(sys.argv[2], "w").write(kernel_text_for(make(15, 1024, sub=True, fuse_last=fused), "lr_ntt_inv16%s_m%d" % ("f" if fused else "s", mode)))
         sys.exit(0)
+    if len(sys.argv) > 5 and sys.argv[5] == "halves":        # N = 2^15 as two 2^14 sub-blocks with lazy outputs, ntt_top_kernel follows: small launches
+        assert logn == 15
+        open(sys.argv[2], "w").write(kernel_text_for(make(14, 1024, sub=True), "lr_ntt_inv15h_m%d" % mode))
+        sys.exit(0)
     if len(sys.argv) > 5 and sys.argv[5] == "timeline":      # diagnostics build with per-phase clock stamps (Options::timeline)
         open(sys.argv[2], "w").write(kernel_text_for(make(logn, threads, profile=True), "lr_ntt_inv%d_m%dt" % (logn, mode)))
         sys.exit(0)

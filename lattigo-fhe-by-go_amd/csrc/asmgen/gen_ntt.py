@@ -63,10 +63,11 @@ class Gen:
         self.karg_parked = bool(profile and persist)
         self.fuse_last = False        # inverse sub-block kernels (gen_intt.py): the last stage by whichever block of the pair finishes second
         self.mark = None
-        assert not sub or (logn == 15 and threads == 1024)
+        assert not sub or (logn in (14, 15) and threads == 1024)
         self.fused = fused            # forward sub-block kernels: compute the top stage while loading (out of place only)
         # sub: the kernel transforms one 2^15 half ("sub-block" blk = workgroup x & 1) of an N = 2^16 limb; twiddles come
-        # from the 2^16 tables under heap root 2 + blk.  Forward: the stage over bit 15 is computed while loading
+        # from the 2^16 tables under heap root 2 + blk.  (logn = 14: the halves of an N = 2^15 limb, plain form only -- the "h" kernels
+        # that small launches use to put two workgroups on a transform.)  Forward: the stage over bit 15 is computed while loading
         # (X = U + V*psi[1] for blk 0, Y = U - V*psi[1] for blk 1, both blocks read both halves).  Inverse: the
         # outputs stay lazy; ntt_top_kernel finishes with the last stage and the scaling.
         self.sub = sub
@@ -1392,6 +1393,10 @@ if __name__ == "__main__":
         fused = not (len(sys.argv) > 5 and sys.argv[5] == "plain")
         open(sys.argv[2], "w").write(kernel_text_for(make(15, 1024, sub=True, fused=fused),
                                                      "lr_ntt_fwd16%s_m%d" % ("s" if fused else "p", mode)))
+        sys.exit(0)
+    if len(sys.argv) > 5 and sys.argv[5] == "halves":        # N = 2^15 as two 2^14 sub-blocks, plain (the top stage applied before): small launches
+        assert logn == 15
+        open(sys.argv[2], "w").write(kernel_text_for(make(14, 1024, sub=True, fused=False), "lr_ntt_fwd15h_m%d" % mode))
         sys.exit(0)
     if len(sys.argv) > 5 and sys.argv[5] == "timeline":      # diagnostics build with per-phase clock stamps (Options::timeline)
         open(sys.argv[2], "w").write(kernel_text_for(make(logn, threads, profile=True), "lr_ntt_fwd%d_m%dt" % (logn, mode)))

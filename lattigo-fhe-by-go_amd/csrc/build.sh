@@ -79,6 +79,15 @@ gen_p() {  # mode flavour suffix
 }
 for m in 0 1 2 3; do gen_p $m persist "" & gpids+=($!); done
 for m in 1 3; do gen_p $m persist-timeline t & gpids+=($!); done
+# N = 2^15 as two 2^14 sub-blocks ("h": plain forward sub-blocks after the stage over bit 14, lazy inverse ones before it): launches too
+# small to fill the chip with one workgroup per transform
+gen_h() {  # kind mode
+  python3 asmgen/gen_$( [ "$1" = fwd ] && echo ntt || echo intt ).py 15 build/ntt_${1}15h_m$2.s $2 1024 halves
+  $LLVM/clang -x assembler -target amdgcn-amd-amdhsa -mcpu=gfx950 -c build/ntt_${1}15h_m$2.s -o build/ntt_${1}15h_m$2.o
+  $LLVM/ld.lld -shared build/ntt_${1}15h_m$2.o -o build/ntt_${1}15h_m$2.hsaco
+}
+for m in 0 1 2 3 4 5; do gen_h fwd $m & gpids+=($!); done
+for m in 0 1 3; do gen_h inv $m & gpids+=($!); done
 for p in "${gpids[@]}"; do wait $p; done
 python3 - <<'PY'
 out = ['struct lr_asm_blob { const char *name; const unsigned char *data; unsigned long size; };']
@@ -89,6 +98,7 @@ names += [("fwd", n, 4) for n in (14, 15, "12x", "13x", "14x", "16s", "16p")]
 names += [("fwd", n, 5) for n in (14, 15, "12x", "13x", "14x", "16s", "16p")]
 names = [(k, n, str(m)) for k, n, m in names] + [(k, 15, m) for k in ("fwd", "inv") for m in ("1t", "3t")]
 names += [("fwd", "15p", m) for m in ("0", "1", "2", "3", "1t", "3t")]
+names += [("fwd", "15h", m) for m in "012345"] + [("inv", "15h", m) for m in "013"]
 for k, n, m in names:
     data = open("build/ntt_%s%s_m%s.hsaco" % (k, n, m), "rb").read()
     out.append('static const unsigned char blob_%s%s_m%s[] __attribute__((aligned(4096))) = {' % (k, n, m))

@@ -176,6 +176,7 @@ lr::Options lr::Options::from_env() {
     o.no_exttop = std::getenv("LR_NO_EXTTOP") != nullptr;
     o.no_ext_group = std::getenv("LR_NO_EXT_GROUP") != nullptr;
     o.no_fork = std::getenv("LR_NO_FORK") != nullptr;
+    if (const char *sp = std::getenv("LR_NTT_SPLIT15")) o.split15 = std::atoi(sp) != 0 ? 1 : 0;
     o.no_invfuse = std::getenv("LR_NO_INVFUSE") != nullptr;
     o.keymac_narrow = std::getenv("LR_KEYMAC_NARROW") != nullptr;
     o.timeline = std::getenv("LR_NTT_TIMELINE") != nullptr;
@@ -959,6 +960,18 @@ EpiLimb make_epi_limb(const lr_context *c, int l, u64 cc) {
     return e;
 }
 
+// N = 2^15 transforms as two 2^14 sub-blocks (run_ntt_launch): for launches of at most kSplit15Below workgroups -- split, they still fit
+// one round on the 256 CUs.
+constexpr long long kSplit15Below = 128;
+bool ntt_split15(const lr_context *c, long long workgroups) {
+    if (c->h.logN != 15 || !c->use_asm || c->opt.timeline || !ntt_asm_available(15)) return false;
+    const int variant_f = c->asm_fwd, variant_i = c->asm_inv;
+    if (variant_f < 0 || variant_i < 0) return false;
+    if (c->opt.split15 >= 0) return c->opt.split15 == 1;
+    if (c->opt.persist > 0) return false;          // (LR_NTT_PERSIST asks for the persistent one-workgroup kernels: diagnostics)
+    return workgroups <= kSplit15Below;
+}
+
 // Fork: launches of the calling thread that go to a plan's auxiliary stream instead of the context's (PlanFork, below): two independent
 // transforms of a small batch run side by side instead of one after the other.  Only forward transforms are forked (they lease no scratch).
 thread_local hipStream_t g_fork_stream = nullptr;
@@ -989,7 +1002,7 @@ int run_ntt(lr_context *c, bool inverse, Rows in, Rows out, int mod0, int mod_st
     if (count <= 0 || batch <= 0) return LR_OK;
     if (hole > 0 && (group <= 0 || batch % group != 0)) return fail(LR_ERR_ARG, "digit groups must divide the batch");
     // N = 2^16: the streaming top-stage kernel carries poly * limbs on grid.y
-    const int kChunk = c->h.logN == 16 ? std::max(1, 65535 / count) : 65535;
+    const int kChunk = c->h.logN == 16 || (c->h.logN == 15 && c->opt.split15 == 1) ? std::max(1, 65535 / count) : 65535;
     if (hole > 0) {
         if (group > kChunk || batch / group > 65535) return fail(LR_ERR_UNSUPPORTED, "grouped NTT launch: more than 65535 polys per digit group");
         return run_ntt_launch(c, inverse, in, out, mod0, mod_step, count, batch, hole, group, epi, pretop);
@@ -1048,6 +1061,43 @@ int run_ntt_launch(lr_context *c, bool inverse, Rows in, Rows out, int mod0, int
         a.fp_lp = c->d_fp_lp;
     }
     char *kn = c->last_ntt_kernel;
+    // N = 2^15, a launch too small to fill the chip with one workgroup per transform (a one-workgroup 2^15 transform takes ~42 us whatever
+    // surrounds it): two 2^14 sub-blocks per limb on the "h" kernels, twice the workgroups at about half the latency.  The stage over
+    // index bit 14 is the streaming ntt_top_kernel's (forward: before, unless the caller's basis extension has applied it -- pretop;
+    // inverse: after, with the scaling).  A caller that passes pretop has decided for the split itself (ntt_split15).
+    if (logn == 15 && (pretop || (ntt_split15(c, (long long)count * batch) && !(epi && !pretop)))) {
+        if (variant < 0 || !c->use_asm || !ntt_asm_available(15)) return fail(LR_ERR_ARG, "pre-applied top stage: assembly kernels only");
+        if (epi) {
+            if (inverse || hole > 0 || !ntt_epilogue_ok(c)) return fail(LR_ERR_ARG, "NTT epilogue: not available for this launch");
+            a.epi_x = epi->x;
+            a.epi_x_stride = epi->x_stride;
+            a.epi_plus = epi->plus;
+            a.epi_plus_stride = epi->plus_stride;
+            a.epi_consts = epi->consts;
+            LR_HIP(launch_ntt_asm16(a, 0, 'h', c->asm_fwd == 3 ? 4 : 5, stream_of(c), kn, c->opt.stagger, 15));
+            return LR_OK;
+        }
+        if (!inverse) {
+            NttLaunch sub = a;
+            if (!pretop) {
+                LR_HIP(launch_ntt_top(a, 0, stream_of(c), 15));
+                sub.in = a.out;                  // continue in place on the output rows
+                sub.in_poly_stride = a.out_poly_stride;
+                sub.in_limb0 = a.out_limb0;
+                sub.in_limb_step = a.out_limb_step;
+            }
+            LR_HIP(launch_ntt_asm16(sub, 0, 'h', variant, stream_of(c), kn, c->opt.stagger, 15));
+            return LR_OK;
+        }
+        LR_HIP(launch_ntt_asm16(a, 1, 'h', variant, stream_of(c), kn, c->opt.stagger, 15));
+        NttLaunch top = a;
+        top.in = a.out;
+        top.in_poly_stride = a.out_poly_stride;
+        top.in_limb0 = a.out_limb0;
+        top.in_limb_step = a.out_limb_step;
+        LR_HIP(launch_ntt_top(top, 1, stream_of(c), 15));
+        return LR_OK;
+    }
     if (epi) {
         if (inverse || hole > 0 || !ntt_epilogue_ok(c) || (logn == 16 && !pretop && !ntt_rows_disjoint(a, 16)))
             return fail(LR_ERR_ARG, "NTT epilogue: not available for this launch");
@@ -2409,10 +2459,14 @@ int ks_decompose(lr_ckks_plan *pl, int level, int batch, const u64 *cx, long lon
     // launch); in place it needs a separate streaming pass first.  The extensions therefore land in staging buffers of the
     // same shape and the transforms write the pools the consumers read.
     const bool asm16 = cQ->h.logN == 16 && cQ->use_asm && cQ->asm_fwd >= 0 && cP->use_asm && cP->asm_fwd >= 0;
+    // N = 2^15 and a key switch whose largest transform launch is small: the same arrangement on the 2^14 sub-block kernels (the
+    // extension applies the stage over bit 14, run_ntt_launch takes pretop as the decision for the split)
+    const bool asm15 = cQ->h.logN == 15 && ntt_split15(cQ, (long long)std::max(1, level + 1 - alpha) * beta * batch) &&
+                       ntt_split15(cP, (long long)nP * beta * batch);
     // ... or, better, the extension itself applies the stage over index bit 15 (each of its threads holds the coefficients j and
     // j + N/2) and the plain sub-block kernels transform in place, reading their own half only.  Possible when every digit of
     // this level goes through the sum-form extension kernel (no trivial-copy digit).
-    bool exttop = asm16 && !pl->opt.no_exttop;
+    bool exttop = (asm16 || asm15) && !pl->opt.no_exttop;
     for (int i = 0; i < beta && exttop; ++i) {
         if (!digit_is_extended(dec, level, i)) {
             exttop = false;
@@ -2581,7 +2635,8 @@ int ks_accumulate(lr_ckks_plan *pl, int level, int batch, const u64 *digQ, const
         LR_TRY(bx->poolQ.ensure(cQ, (size_t)2 * batch * sQ));
         u64 *ext_out = bx->poolQ.d;
         const bool asm16 = cQ->h.logN == 16 && cQ->use_asm && cQ->asm_fwd >= 0;
-        const bool exttop = asm16 && !pl->opt.no_exttop && ext_top_supported(bx->pq.tables(), nP, n);
+        const bool asm15 = cQ->h.logN == 15 && ntt_split15(cQ, (long long)(level + 1) * batch);     // (one launch per component)
+        const bool exttop = (asm16 || asm15) && !pl->opt.no_exttop && ext_top_supported(bx->pq.tables(), nP, n);
         if (asm16 && !exttop && !pl->opt.no_staging) {
             LR_TRY(pl->stageQ.ensure(cQ, (size_t)2 * batch * sQ));     // (the digits' staging area is free again)
             ext_out = pl->stageQ.d;

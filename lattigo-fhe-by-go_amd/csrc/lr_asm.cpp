@@ -134,11 +134,13 @@ hipError_t launch_ntt_asm(const NttLaunch &a, int logn, int inverse, int variant
 // N = 2^16 runs as two 2^15 sub-blocks per limb (grid x = 2 * n_items).  kind: 's' = forward with the stage over
 // bit 15 fused into the loads (out of place only) / inverse sub-blocks (lazy outputs, ntt_top_kernel follows),
 // 'p' = forward sub-blocks after a separate ntt_top_kernel pass (in place allowed).
-hipError_t launch_ntt_asm16(const NttLaunch &a, int inverse, char kind, int variant, hipStream_t stream, char *kernel_name, int stagger) {
+// full_logn = 15, kind 'h': the same for N = 2^15 as two 2^14 sub-blocks (plain forward / lazy inverse sub-blocks only), which launches
+// too small to fill the chip with one workgroup per transform use (run_ntt_launch).
+hipError_t launch_ntt_asm16(const NttLaunch &a, int inverse, char kind, int variant, hipStream_t stream, char *kernel_name, int stagger, int full_logn) {
     AsmKernels *k = kernels_for_current_device();
     if (!k) return hipErrorNotSupported;
     char name[32];
-    std::snprintf(name, sizeof name, "lr_ntt_%s16%c_m%d", inverse ? "inv" : "fwd", kind, variant);
+    std::snprintf(name, sizeof name, "lr_ntt_%s%d%c_m%d", inverse ? "inv" : "fwd", full_logn, kind, variant);
     auto it = k->fn.find(name);
     if (it == k->fn.end()) return hipErrorNotSupported;
     if (kernel_name) std::snprintf(kernel_name, 32, "%s", name);

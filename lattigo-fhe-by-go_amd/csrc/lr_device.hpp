@@ -39,6 +39,7 @@ struct Options {
     bool timeline = false;         // LR_NTT_TIMELINE: plain 2^15 launches (forward / inverse, integer variant 1 and dual variant 3) run the stamped diagnostics builds
     bool keymac_narrow = false;    // LR_KEYMAC_NARROW: one Montgomery product per term in the key inner product instead of the 128-bit sums
     bool no_invfuse = false;       // LR_NO_INVFUSE: N = 2^16 inverse transforms as lazy sub-blocks + the separate last-stage pass (ntt_top_kernel) instead of the pair-flag kernels
+    int split15 = -1;              // LR_NTT_SPLIT15: N = 2^15 transforms as two 2^14 sub-blocks: 0 never, 1 always, unset = launches of at most kSplit15Below workgroups
     bool no_fork = false;          // LR_NO_FORK: the key switch's independent launches in order on one stream at every batch size
     bool no_ext_group = false;     // LR_NO_EXT_GROUP: one extension launch per key-switch digit instead of one grouped launch
     bool no_exttop = false;        // LR_NO_EXTTOP: N = 2^16 key switch with staged extensions and fused-top transforms instead of the top stage inside the extension
@@ -340,9 +341,9 @@ bool ntt_asm_available(int logn);
 hipError_t launch_ntt_asm(const NttLaunch &a, int logn, int inverse, int variant, hipStream_t stream, bool wide14 = false,
                           char *kernel_name = nullptr, bool timeline = false, int stagger = -1, int persist = 0);
 hipError_t launch_ntt_asm16(const NttLaunch &a, int inverse, char kind, int variant, hipStream_t stream, char *kernel_name = nullptr,
-                            int stagger = -1);
+                            int stagger = -1, int full_logn = 16);
 // N = 2^16 helpers (lr_ntt.hip): the streaming stage over bit 15, and whether no input row of a launch is an output row
-hipError_t launch_ntt_top(const NttLaunch &a, int inverse, hipStream_t stream);
+hipError_t launch_ntt_top(const NttLaunch &a, int inverse, hipStream_t stream, int logn = 16);
 bool ntt_rows_disjoint(const NttLaunch &a, int logn);
 hipError_t launch_ewise(int op, const EwiseLaunch &L, int limbs, int batch, hipStream_t stream);
 hipError_t launch_submul(const SubMulLaunch &L, int limbs, int batch, hipStream_t stream);

@@ -537,11 +537,11 @@ static hipError_t launch_big(const NttLaunch &a, bool inverse, int mode, hipStre
     }
 }
 
-hipError_t launch_ntt_top(const NttLaunch &a, int inverse, hipStream_t stream) {
+hipError_t launch_ntt_top(const NttLaunch &a, int inverse, hipStream_t stream, int logn) {
     if (a.n_items <= 0 || a.batch <= 0) return hipSuccess;
-    const dim3 tgrid(64, (unsigned)(a.n_items * a.batch)), tblock(256);
+    const dim3 tgrid(logn == 16 ? 64 : 32, (unsigned)(a.n_items * a.batch)), tblock(256);
     (void)hipGetLastError();
-    hipLaunchKernelGGL(ntt_top_kernel, tgrid, tblock, 0, stream, a, 16, inverse);
+    hipLaunchKernelGGL(ntt_top_kernel, tgrid, tblock, 0, stream, a, logn, inverse);
     return hipGetLastError();
 }
 

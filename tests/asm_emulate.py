@@ -326,7 +326,8 @@ def emulate_sub(make_gen, inverse, q, pretop=False, order=(0, 1)):
     import __graft_entry__ as graft
     oracle = graft.load_oracle()
     pkg = graft.load_package()
-    N, NF = 1 << 15, 1 << 16
+    N = 1 << make_gen().logn
+    NF = 2 * N
     oc = oracle.Context(NF, [q])
     x = pkg.sampling.random_u64((NF,), seed=9)
     x[:4] = np.uint64(0xFFFFFFFFFFFFFFFF)
@@ -553,9 +554,40 @@ def selftest_sub(inverse=False):
     return ok
 
 
+def selftest_halves(inverse=False):
+    """N = 2^15 as two 2^14 sub-blocks (small launches: twice the workgroups, half the latency): the plain forward sub-block kernels
+    ("h": the stage over bit 14 applied before, by the basis extension or ntt_top_kernel) in every mode incl. the epilogues, the lazy inverse ones"""
+    ok = True
+    sub_q = lambda mode: test_moduli(15, mode)[0]
+    cases = []
+    if inverse:
+        for mode in (0, 1):
+            cases.append(("mode %d" % mode, (lambda mode=mode: GenInv_(14, mode, 1024, sub=True)), sub_q(mode)))
+        for q in fp_test_moduli(15):
+            cases.append(("dual", (lambda: Dual(lambda fp: GenInv_(14, 1, 1024, sub=True, fp=fp, dual=True))), q))
+    else:
+        for mode in (0, 1, 2):
+            cases.append(("mode %d" % mode, (lambda mode=mode: Gen(14, mode, 1024, sub=True, fused=False)), sub_q(mode)))
+        cases.append(("m5", (lambda: Gen(14, 1, 1024, sub=True, fused=False, epi=True)), sub_q(1)))
+        for q in fp_test_moduli(15):
+            cases.append(("dual", (lambda: Dual(lambda fp: Gen(14, 2, 1024, sub=True, fused=False, fp=fp, dual=True))), q))
+            cases.append(("dual epilogue", (lambda: Dual(lambda fp: Gen(14, 2, 1024, sub=True, fused=False, fp=fp, dual=True, epi=True))), q))
+    for label, mk, q in cases:
+        good = True
+        for order in ((0, 1), (1, 0)):
+            g, info = emulate_sub(mk, inverse, q, pretop=not inverse, order=order)
+            good = good and g
+        ok = ok and good
+        print("%s N=2^15 halves %s q=%d (%d bits): %s; %s" % ("inverse" if inverse else "forward", label, q, q.bit_length(),
+                                                          "bit-exact vs oracle" if good else "MISMATCH", info), flush=True)
+    return ok
+
+
 if __name__ == "__main__":
     logn = int(sys.argv[1])
     inverse = len(sys.argv) > 2 and sys.argv[2] == "--selftest-inverse"
+    if len(sys.argv) > 2 and sys.argv[-1] == "--halves":
+        sys.exit(0 if selftest_halves(inverse=inverse) else 1)
     if logn == 16:
         sys.exit(0 if selftest_sub(inverse=inverse) else 1)
     threads = int(sys.argv[3]) if len(sys.argv) > 3 else 1024

@@ -481,3 +481,34 @@ def test_two_plans_alive_do_not_fork(gpu_pkg, oracle):
     gc.collect()
     plan.MulRelin(level, (mk(1), mk(2)), (mk(3), mk(4)), pevk, out)
     assert plan.Stats()["forks"] > 0
+
+
+@pytest.mark.parametrize("nq,np_,level,batch", [(18, 3, 17, 1), (18, 3, 12, 1), (7, 3, 6, 3), (5, 2, 4, 2)])
+def test_mulrelin_2p15_split_paths(gpu_pkg, oracle, nq, np_, level, batch, monkeypatch):
+    """N = 2^15 at a small batch: the key switch's transforms run as two 2^14 sub-blocks per limb -- forward ones behind the top stage the
+    basis extensions apply (digits, ModDown), inverse ones in front of ntt_top_kernel; LR_NTT_SPLIT15=0 keeps one workgroup per transform,
+    =1 splits whatever the size; LR_NO_EXTTOP leaves the forward top stage to ntt_top_kernel.  All against the oracle."""
+    for env in ({}, {"LR_NTT_SPLIT15": "0"}, {"LR_NTT_SPLIT15": "1"}, {"LR_NO_EXTTOP": "1"}, {"LR_NTT_SPLIT15": "1", "LR_NO_FORK": "1", "LR_NO_EXT_GROUP": "1"}):
+        for k in ("LR_NTT_SPLIT15", "LR_NO_EXTTOP", "LR_NO_FORK", "LR_NO_EXT_GROUP"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        N, Q, P, cQ, cP, plan, oplan, evk, pevk = _ckks(gpu_pkg, oracle, 15, nq, np_, batch)
+        mk = lambda s: gpu_pkg.sampling.uniform_poly(Q[:level + 1], N, batch, seed=s).reshape(batch, level + 1, N)
+        ops = [mk(41), mk(42), mk(43), mk(44)]
+        P_ = lambda x: cQ.NewPolyLvl(level, batch).set(x)
+        out = (cQ.NewPolyLvl(level, batch), cQ.NewPolyLvl(level, batch))
+        plan.MulRelin(level, (P_(ops[0]), P_(ops[1])), (P_(ops[2]), P_(ops[3])), pevk, out)
+        # the last launch is ModDown's transform with the epilogue: split only behind an extension that applied the top stage
+        assert ("15h" in cQ.last_ntt_kernel()) == (env.get("LR_NTT_SPLIT15") != "0" and "LR_NO_EXTTOP" not in env), (env, cQ.last_ntt_kernel())
+        for b in range(batch):
+            w0, w1 = oplan.mulrelin(level, np.stack([ops[0][b], ops[1][b]]), np.stack([ops[2][b], ops[3][b]]), evk)
+            assert np.array_equal(out[0].get().reshape(batch, level + 1, N)[b], w0), (env, b)
+            assert np.array_equal(out[1].get().reshape(batch, level + 1, N)[b], w1), (env, b)
+        plan.Rescale(out)                                  # (the rescale's fused-top form exists at 2^16 only: one workgroup per transform here)
+        oc = oracle.Context(N, Q[:level + 1])
+        for b in range(batch):
+            w = oplan.mulrelin(level, np.stack([ops[0][b], ops[1][b]]), np.stack([ops[2][b], ops[3][b]]), evk)
+            for k in range(2):
+                assert np.array_equal(out[k].get().reshape(batch, level, N)[b], oc.rescale_op("oc_div_round_by_last_modulus_ntt", w[k])), (env, b, k)
+        del plan, pevk, out

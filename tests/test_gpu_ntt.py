@@ -231,19 +231,28 @@ def test_cxx_and_asm_paths_agree(gpu_pkg, oracle, logn, kind, force, monkeypatch
         monkeypatch.setenv("LR_ASM_VARIANT", force)
     else:
         monkeypatch.delenv("LR_ASM_VARIANT", raising=False)
-    for no_asm in (False, True):
+    # N = 2^15: a launch this small runs as two 2^14 sub-blocks per limb (the "h" kernels behind ntt_top_kernel) unless LR_NTT_SPLIT15=0
+    # keeps the one-workgroup-per-transform kernels: both
+    for no_asm, split in [(False, "0"), (False, "1"), (True, None)] if logn == 15 else [(False, None), (True, None)]:
         if no_asm:
             monkeypatch.setenv("LR_NO_ASM", "1")
         else:
             monkeypatch.delenv("LR_NO_ASM", raising=False)
+        if split is None:
+            monkeypatch.delenv("LR_NTT_SPLIT15", raising=False)
+        else:
+            monkeypatch.setenv("LR_NTT_SPLIT15", split)
         ctx = gpu_pkg.ring.NewContextWithParams(N, moduli)
         p, r = ctx.NewPoly(2).set(x), ctx.NewPoly(2)
         ctx.NTT(p, r)
         got = r.get()
         for b in range(2):
-            assert np.array_equal(got[b], want[b]), (no_asm, b)
+            assert np.array_equal(got[b], want[b]), (no_asm, split, b)
+        if split is not None:
+            assert ("15h" in ctx.last_ntt_kernel()) == (split == "1"), ctx.last_ntt_kernel()
         ctx.NTT(p, p)      # in place
         assert np.array_equal(p.get(), got)
+    monkeypatch.delenv("LR_NTT_SPLIT15", raising=False)
 
 
 @pytest.mark.parametrize("kind,force", ASM_CASES)
@@ -265,17 +274,23 @@ def test_cxx_and_asm_inverse_paths_agree(gpu_pkg, oracle, logn, kind, force, mon
         monkeypatch.setenv("LR_ASM_VARIANT", force)
     else:
         monkeypatch.delenv("LR_ASM_VARIANT", raising=False)
-    for no_asm in (False, True):
+    for no_asm, split in [(False, "0"), (False, "1"), (True, None)] if logn == 15 else [(False, None), (True, None)]:
         if no_asm:
             monkeypatch.setenv("LR_NO_ASM", "1")
         else:
             monkeypatch.delenv("LR_NO_ASM", raising=False)
+        if split is None:
+            monkeypatch.delenv("LR_NTT_SPLIT15", raising=False)
+        else:
+            monkeypatch.setenv("LR_NTT_SPLIT15", split)
         ctx = gpu_pkg.ring.NewContextWithParams(N, moduli)
         p, r = ctx.NewPoly(2).set(x), ctx.NewPoly(2)
         ctx.InvNTT(p, r)
         got = r.get()
         for b in range(2):
-            assert np.array_equal(got[b], want[b]), (no_asm, b)
+            assert np.array_equal(got[b], want[b]), (no_asm, split, b)
+        if split is not None:
+            assert ("15h" in ctx.last_ntt_kernel()) == (split == "1"), ctx.last_ntt_kernel()
         ctx.InvNTT(p, p)
         assert np.array_equal(p.get(), got)
         # round trip through both assembly kernels

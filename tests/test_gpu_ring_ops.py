@@ -616,8 +616,13 @@ def test_last_ntt_kernel_is_reported(gpu_pkg):
     ctx = ring.NewContextWithParams(N, list(moduli))
     p = ctx.NewPoly(1)
     ctx.NTT(p, p)
-    assert ctx.last_ntt_kernel() == "lr_ntt_fwd15_m1"
+    assert ctx.last_ntt_kernel() == "lr_ntt_fwd15h_m1"      # 16 workgroups would leave the chip idle: two 2^14 sub-blocks per limb
     ctx.InvNTT(p, p)
+    assert ctx.last_ntt_kernel() == "lr_ntt_inv15h_m1"
+    big = ctx.NewPoly(16)                                   # 256 workgroups: one per transform
+    ctx.NTT(big, big)
+    assert ctx.last_ntt_kernel() == "lr_ntt_fwd15_m1"
+    ctx.InvNTT(big, big)
     assert ctx.last_ntt_kernel() == "lr_ntt_inv15_m1"
     small = ring.NewContextWithParams(256, list(params.Qi60()[-2:]))
     q = small.NewPoly(1)
