@@ -298,8 +298,9 @@ int lr_div_round_by_last_modulus_many(lr_context *ctx, lr_poly *p0, int nb_resca
 int lr_ckks_plan_create(lr_context *ctxQ, lr_context *ctxP, int max_batch, lr_ckks_plan **out);
 /* Diagnostics of the small-batch paths of the key switch (no reference counterpart).  forks: how often two independent launches of a
  * pipeline (the digits' P rows beside their Q rows; ModDown's two components) went out side by side on the plan's auxiliary stream
- * instead of in order -- done while the forked launch is far from filling the chip AND the plan is the only one alive on its device
- * that is not a batcher's lane (a lone evaluator); LR_NO_FORK=1 at plan creation switches it off.  grouped_extensions:
+ * instead of in order -- done at N = 2^16 (where one workgroup of such a launch runs long enough to pay for the hand-over) while the
+ * forked launch is far from filling the chip AND the plan is the only one alive on its device that is not a batcher's lane (a lone
+ * evaluator); LR_NO_FORK=1 at plan creation switches it off.  grouped_extensions:
  * launches that carried the basis extensions of all digits of a key switch at once (LR_NO_EXT_GROUP=1: one launch per digit).
  * Results are the same bits either way.  Either pointer may be NULL. */
 int lr_ckks_plan_stats(const lr_ckks_plan *plan, uint64_t *forks, uint64_t *grouped_extensions);

@@ -2375,6 +2375,11 @@ struct PlanFork {
     int rc = LR_OK;
     PlanFork(lr_ckks_plan *p, int workgroups) : pl(p) {
         if (pl->opt.no_fork || pl->fork_failed || g_fork_stream) return;
+        // ... and only where one workgroup of the forked launch runs long enough to pay for the two stream hand-overs (~ 19 us): the
+        // 2^15 sub-blocks of N = 2^16 (42 us).  Since small 2^15 launches run on 2^14 sub-blocks (20 us, like the 2^14 kernels) a fork
+        // there costs more than it hides: PN15QP880 batch 1 4.64 k products/s forked, 5.06 k in order; PN14QP438 6.42 k / 7.30 k;
+        // PN16QP1761 1.69 k / 1.64 k (profiles/r03/fork_policies.txt).
+        if (pl->cQ->h.logN != 16) return;
         if (pl->lane_of || standalone_plans(pl->device).load(std::memory_order_relaxed) != 1 || workgroups >= kForkBelow) return;
         if (!pl->aux) {
             if (create_stream(&pl->aux, 1) != hipSuccess ||
