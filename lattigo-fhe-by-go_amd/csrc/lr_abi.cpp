@@ -177,6 +177,7 @@ lr::Options lr::Options::from_env() {
     o.no_ext_group = std::getenv("LR_NO_EXT_GROUP") != nullptr;
     o.no_fork = std::getenv("LR_NO_FORK") != nullptr;
     if (const char *sp = std::getenv("LR_NTT_SPLIT15")) o.split15 = std::atoi(sp) != 0 ? 1 : 0;
+    o.rescale_unpaired = std::getenv("LR_RESCALE_UNPAIRED") != nullptr;
     o.no_invfuse = std::getenv("LR_NO_INVFUSE") != nullptr;
     o.keymac_narrow = std::getenv("LR_KEYMAC_NARROW") != nullptr;
     o.timeline = std::getenv("LR_NTT_TIMELINE") != nullptr;
@@ -3298,8 +3299,30 @@ extern "C" int lr_context_last_ntt_kernel(const lr_context *c, char *buf, size_t
 extern "C" int lr_ckks_rescale(lr_ckks_plan *pl, lr_poly *c0, lr_poly *c1) {
     return guarded([&]() -> int {
     if (!pl || !c0 || !c1) return fail(LR_ERR_ARG, "null argument");
-    LR_TRY(lr_div_round_by_last_modulus_ntt(pl->cQ, c0));  // ckks/evaluator.go:958-960
-    return lr_div_round_by_last_modulus_ntt(pl->cQ, c1);
+    lr_context *c = pl->cQ;
+    LR_TRY(check_rescale(c, c0));
+    LR_TRY(check_rescale(c, c1));
+    LR_HIP(hipSetDevice(c->device));
+    // ckks/evaluator.go:958-960 divides the two components one after the other.  They are independent, and at a small batch every
+    // launch of one component leaves most of the chip idle: where the two polys can be addressed as ONE batch -- base + p * stride
+    // reaches both, i.e. always for one poly each (stride = the distance between them) and for batches laid out back to back --
+    // every launch carries both (PN15QP880, one ciphertext: 121 -> 66 us).
+    lr_poly *lo = c0->d <= c1->d ? c0 : c1, *hi = lo == c0 ? c1 : c0;
+    const long long gap = hi->d - lo->d;
+    const bool same_shape = c0->limbs == c1->limbs && c0->batch == c1->batch && c0->N == c1->N && c0->d != c1->d;
+    const bool one_each = same_shape && c0->batch == 1 && gap >= (long long)lo->limbs * (long long)lo->N;
+    const bool back_to_back = same_shape && c0->stride() == c1->stride() && gap == (long long)lo->batch * lo->stride();
+    if (!c->opt.rescale_unpaired && (one_each || back_to_back) && (long long)c0->batch * 2 * c0->limbs <= 256) {
+        lr_poly both = *lo;
+        both.owned = false;
+        both.batch = 2 * lo->batch;
+        if (one_each) both.stride_words = gap;
+        LR_TRY(rescale_ntt_domain(c, &both, true));
+        c0->limbs = c1->limbs = both.limbs;
+        return LR_OK;
+    }
+    LR_TRY(rescale_ntt_domain(c, c0, true));
+    return rescale_ntt_domain(c, c1, true);
     });
 }
 

@@ -512,3 +512,46 @@ def test_mulrelin_2p15_split_paths(gpu_pkg, oracle, nq, np_, level, batch, monke
             for k in range(2):
                 assert np.array_equal(out[k].get().reshape(batch, level, N)[b], oc.rescale_op("oc_div_round_by_last_modulus_ntt", w[k])), (env, b, k)
         del plan, pevk, out
+
+
+@pytest.mark.parametrize("logn,nq,np_,batch", [(15, 18, 3, 1), (14, 7, 3, 1), (16, 6, 2, 1), (12, 6, 2, 3)])
+def test_rescale_of_both_components_in_one_set_of_launches(gpu_pkg, oracle, logn, nq, np_, batch, monkeypatch):
+    """lr_ckks_rescale addresses the two components as one batch where base + p * stride reaches both (one poly each: the stride is
+    their distance, whichever lies first; batches laid out back to back): same bits as one after the other (LR_RESCALE_UNPAIRED) and
+    as the oracle, twice in a row (two levels)"""
+    N = 1 << logn
+    _, Qf, Pf = gpu_pkg.params.ckks_moduli("PN16QP1761" if logn == 16 else "PN15QP880")
+    Q = list(Qf[:nq])
+    oc = oracle.Context(N, Q)
+    x = [gpu_pkg.sampling.uniform_poly(Q, N, batch, seed=70 + k).reshape(batch, nq, N) for k in range(2)]
+    want = [[oc.rescale_op("oc_div_round_by_last_modulus_ntt", x[k][b]) for b in range(batch)] for k in range(2)]
+    oc2 = oracle.Context(N, Q[:-1])
+    want2 = [[oc2.rescale_op("oc_div_round_by_last_modulus_ntt", want[k][b]) for b in range(batch)] for k in range(2)]
+    for env, order in (({}, (0, 1)), ({}, (1, 0)), ({"LR_RESCALE_UNPAIRED": "1"}, (0, 1))):
+        monkeypatch.delenv("LR_RESCALE_UNPAIRED", raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        cQ = gpu_pkg.ring.NewContextWithParams(N, Q)
+        cP = gpu_pkg.ring.NewContextWithParams(N, list(Pf[:np_]))
+        plan = gpu_pkg.ring.CkksPlan(cQ, cP, batch)
+        polys = [None, None]
+        for k in order:                                     # allocation order decides which component lies first in memory
+            polys[k] = cQ.NewPoly(batch).set(x[k])
+        whole = None
+        if batch > 1 and not env:
+            # back to back: the two components are the halves of one allocation (wrapped without a copy)
+            whole = cQ.NewPoly(2 * batch).set(np.concatenate([x[order[0]], x[order[1]]]))
+            base = whole.device_ptr
+            polys[order[0]] = gpu_pkg.ring.Poly.wrap(cQ, base, nq, batch)
+            polys[order[1]] = gpu_pkg.ring.Poly.wrap(cQ, base + 8 * batch * nq * N, nq, batch)
+        ct = (polys[0], polys[1])
+        plan.Rescale(ct)
+        for k in range(2):
+            got = ct[k].get().reshape(batch, nq - 1, N)
+            for b in range(batch):
+                assert np.array_equal(got[b], want[k][b]), (env, order, k, b)
+        plan.Rescale(ct)
+        for k in range(2):
+            got = ct[k].get().reshape(batch, nq - 2, N)
+            for b in range(batch):
+                assert np.array_equal(got[b], want2[k][b]), (env, order, k, b)
