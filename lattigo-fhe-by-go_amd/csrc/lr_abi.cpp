@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <atomic>
 #include <condition_variable>
+#include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -178,6 +179,7 @@ lr::Options lr::Options::from_env() {
     o.no_fork = std::getenv("LR_NO_FORK") != nullptr;
     if (const char *sp = std::getenv("LR_NTT_SPLIT15")) o.split15 = std::atoi(sp) != 0 ? 1 : 0;
     o.rescale_unpaired = std::getenv("LR_RESCALE_UNPAIRED") != nullptr;
+    o.no_pair = std::getenv("LR_NO_PAIR") != nullptr;
     o.no_invfuse = std::getenv("LR_NO_INVFUSE") != nullptr;
     o.keymac_narrow = std::getenv("LR_KEYMAC_NARROW") != nullptr;
     o.timeline = std::getenv("LR_NTT_TIMELINE") != nullptr;
@@ -2670,7 +2672,17 @@ int ks_accumulate(lr_ckks_plan *pl, int level, int batch, const u64 *digQ, const
                 const bool fpc = ntt_epilogue_limb(cQ, l0);
                 int l1 = l0 + 1;
                 while (l1 <= level && ntt_epilogue_limb(cQ, l1) == fpc) ++l1;
-                if (fpc) {
+                const bool same_plus = (pluses[0] != nullptr) == (pluses[1] != nullptr);
+                if (fpc && batch == 1 && same_plus && !pl->opt.no_pair && outs[0] != outs[1]) {
+                    // one ciphertext: the two components as a batch of two whose strides are the distances between their operands
+                    // (ext_out holds them back to back; x, plus and the outputs are separate allocations) -- one launch instead of two
+                    auto words = [](const u64 *a, const u64 *b) { return (long long)(((intptr_t)b - (intptr_t)a) / (intptr_t)sizeof(u64)); };
+                    Rows src{ext_out, sQ, l0, 1};
+                    Rows dst{outs[0], words(outs[0], outs[1]), l0, 1};
+                    const NttEpilogue ep{p0, words(p0, p1), pluses[0] ? pluses[0] : pl->zerosQ.d, pluses[0] ? words(pluses[0], pluses[1]) : 0,
+                                         bx->d_moddown_pq_epi};
+                    LR_TRY(run_ntt(cQ, false, src, dst, l0, 1, l1 - l0, 2, 0, 0, &ep, exttop));
+                } else if (fpc) {
                     // the two components are independent launches: side by side while one alone leaves most of the chip idle
                     PlanFork fork1(pl, (l1 - l0) * batch);
                     LR_TRY(fork1.rc);

@@ -488,9 +488,14 @@ def test_mulrelin_2p15_split_paths(gpu_pkg, oracle, nq, np_, level, batch, monke
     """N = 2^15 at a small batch: the key switch's transforms run as two 2^14 sub-blocks per limb -- forward ones behind the top stage the
     basis extensions apply (digits, ModDown), inverse ones in front of ntt_top_kernel; LR_NTT_SPLIT15=0 keeps one workgroup per transform,
     =1 splits whatever the size; LR_NO_EXTTOP leaves the forward top stage to ntt_top_kernel.  All against the oracle."""
-    for env in ({}, {"LR_NTT_SPLIT15": "0"}, {"LR_NTT_SPLIT15": "1"}, {"LR_NO_EXTTOP": "1"}, {"LR_NTT_SPLIT15": "1", "LR_NO_FORK": "1", "LR_NO_EXT_GROUP": "1"}):
-        for k in ("LR_NTT_SPLIT15", "LR_NO_EXTTOP", "LR_NO_FORK", "LR_NO_EXT_GROUP"):
+    # (LR_NO_PAIR: ModDown's two components of a single ciphertext as two launches; by default one launch whose strides are the distances
+    # between the components' operands -- negative when the second output was allocated first, as in the last round)
+    for env in ({}, {"LR_NTT_SPLIT15": "0"}, {"LR_NTT_SPLIT15": "1"}, {"LR_NO_EXTTOP": "1"}, {"LR_NTT_SPLIT15": "1", "LR_NO_FORK": "1", "LR_NO_EXT_GROUP": "1"},
+                {"LR_NO_PAIR": "1"}, {"swap_outputs": "1"}):
+        for k in ("LR_NTT_SPLIT15", "LR_NO_EXTTOP", "LR_NO_FORK", "LR_NO_EXT_GROUP", "LR_NO_PAIR"):
             monkeypatch.delenv(k, raising=False)
+        swap = env.pop("swap_outputs", None) if isinstance(env, dict) else None
+        env = dict(env)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         N, Q, P, cQ, cP, plan, oplan, evk, pevk = _ckks(gpu_pkg, oracle, 15, nq, np_, batch)
@@ -498,6 +503,8 @@ def test_mulrelin_2p15_split_paths(gpu_pkg, oracle, nq, np_, level, batch, monke
         ops = [mk(41), mk(42), mk(43), mk(44)]
         P_ = lambda x: cQ.NewPolyLvl(level, batch).set(x)
         out = (cQ.NewPolyLvl(level, batch), cQ.NewPolyLvl(level, batch))
+        if swap:
+            out = (out[1], out[0])
         plan.MulRelin(level, (P_(ops[0]), P_(ops[1])), (P_(ops[2]), P_(ops[3])), pevk, out)
         # the last launch is ModDown's transform with the epilogue: split only behind an extension that applied the top stage
         assert ("15h" in cQ.last_ntt_kernel()) == (env.get("LR_NTT_SPLIT15") != "0" and "LR_NO_EXTTOP" not in env), (env, cQ.last_ntt_kernel())
