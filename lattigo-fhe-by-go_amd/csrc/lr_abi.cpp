@@ -2672,15 +2672,15 @@ int ks_accumulate(lr_ckks_plan *pl, int level, int batch, const u64 *digQ, const
                 const bool fpc = ntt_epilogue_limb(cQ, l0);
                 int l1 = l0 + 1;
                 while (l1 <= level && ntt_epilogue_limb(cQ, l1) == fpc) ++l1;
-                const bool same_plus = (pluses[0] != nullptr) == (pluses[1] != nullptr);
-                if (fpc && batch == 1 && same_plus && !pl->opt.no_pair && outs[0] != outs[1]) {
+                if (fpc && batch == 1 && !pl->opt.no_pair && outs[0] != outs[1]) {
                     // one ciphertext: the two components as a batch of two whose strides are the distances between their operands
                     // (ext_out holds them back to back; x, plus and the outputs are separate allocations) -- one launch instead of two
                     auto words = [](const u64 *a, const u64 *b) { return (long long)(((intptr_t)b - (intptr_t)a) / (intptr_t)sizeof(u64)); };
                     Rows src{ext_out, sQ, l0, 1};
                     Rows dst{outs[0], words(outs[0], outs[1]), l0, 1};
-                    const NttEpilogue ep{p0, words(p0, p1), pluses[0] ? pluses[0] : pl->zerosQ.d, pluses[0] ? words(pluses[0], pluses[1]) : 0,
-                                         bx->d_moddown_pq_epi};
+                    // (a component without an addend -- the rotations' second one -- adds the row of zeros: one more distance)
+                    const u64 *plus_a = pluses[0] ? pluses[0] : pl->zerosQ.d, *plus_b = pluses[1] ? pluses[1] : pl->zerosQ.d;
+                    const NttEpilogue ep{p0, words(p0, p1), plus_a, words(plus_a, plus_b), bx->d_moddown_pq_epi};
                     LR_TRY(run_ntt(cQ, false, src, dst, l0, 1, l1 - l0, 2, 0, 0, &ep, exttop));
                 } else if (fpc) {
                     // the two components are independent launches: side by side while one alone leaves most of the chip idle
@@ -2825,8 +2825,14 @@ extern "C" int lr_ckks_rotate(lr_ckks_plan *pl, int level, const lr_poly *c0, co
     const int n = (int)cQ->h.N, L1 = level + 1;
     const long long s = (long long)L1 * n;
     for (Pool *p : {&pl->c0, &pl->c2x, &pl->q1, &pl->q2}) LR_TRY(p->ensure(cQ, (size_t)batch * s));
-    LR_TRY(run_permute_ntt(cQ, L1, batch, c0->d, c0->stride(), pl->c0.d, s, gen));    // :1458
-    LR_TRY(run_permute_ntt(cQ, L1, batch, c1->d, c1->stride(), pl->c2x.d, s, gen));   // :1459
+    if (batch == 1 && !pl->opt.no_pair && c0->d != c1->d) {
+        // one ciphertext: both components in one launch, the strides are the distances between them (see ks_accumulate)
+        auto words = [](const u64 *a, const u64 *b) { return (long long)(((intptr_t)b - (intptr_t)a) / (intptr_t)sizeof(u64)); };
+        LR_TRY(run_permute_ntt(cQ, L1, 2, c0->d, words(c0->d, c1->d), pl->c0.d, words(pl->c0.d, pl->c2x.d), gen));    // :1458-1459
+    } else {
+        LR_TRY(run_permute_ntt(cQ, L1, batch, c0->d, c0->stride(), pl->c0.d, s, gen));    // :1458
+        LR_TRY(run_permute_ntt(cQ, L1, batch, c1->d, c1->stride(), pl->c2x.d, s, gen));   // :1459
+    }
     KeySwitchEpilogue fin{o0->d, o1->d, o0->stride(), pl->c0.d, nullptr, s};
     return switch_keys_core(pl, level, batch, pl->c2x.d, s, rotkey, pl->q1.d, s, pl->q2.d, s, &fin);   // :1464-1467
     });

@@ -562,3 +562,31 @@ def test_rescale_of_both_components_in_one_set_of_launches(gpu_pkg, oracle, logn
             got = ct[k].get().reshape(batch, nq - 2, N)
             for b in range(batch):
                 assert np.array_equal(got[b], want2[k][b]), (env, order, k, b)
+
+
+@pytest.mark.parametrize("logn,nq,np_,level,k", [(14, 7, 3, 6, 3), (15, 18, 3, 17, 2), (15, 7, 3, 4, 9), (16, 6, 2, 5, 7), (12, 6, 2, 5, 1)])
+def test_rotate_columns_of_a_single_ciphertext(gpu_pkg, oracle, logn, nq, np_, level, k, monkeypatch):
+    """one ciphertext per call: the two permutations and ModDown's two transforms each go out as one launch whose strides are the
+    distances between the components (the second component's addend is the row of zeros); LR_NO_PAIR keeps separate launches; both
+    against the oracle, also with the outputs allocated in the other order and in place"""
+    for env, swap in (({}, False), ({}, True), ({"LR_NO_PAIR": "1"}, False)):
+        monkeypatch.delenv("LR_NO_PAIR", raising=False)
+        for kk, v in env.items():
+            monkeypatch.setenv(kk, v)
+        N, Q, P, cQ, cP, plan, oplan, evk, pevk = _ckks(gpu_pkg, oracle, logn, nq, np_, 1)
+        mk = lambda s: gpu_pkg.sampling.uniform_poly(Q[:level + 1], N, 1, seed=s).reshape(1, level + 1, N)
+        a0, a1 = mk(31), mk(32)
+        P_ = lambda x: cQ.NewPolyLvl(level, 1).set(x)
+        for gen in (_galois(gpu_pkg, N, k), 2 * N - 1):
+            ct = (P_(a1), P_(a0))[::-1] if swap else (P_(a0), P_(a1))
+            out = (cQ.NewPolyLvl(level, 1), cQ.NewPolyLvl(level, 1))
+            if swap:
+                out = out[::-1]
+            plan.PermuteNTT(level, ct, gen, pevk, out)
+            want = oplan.permute_ntt(level, np.stack([a0[0], a1[0]]), gen, evk)
+            for c in range(2):
+                assert np.array_equal(out[c].get().reshape(level + 1, N), want[c]), (env, swap, gen, c)
+            plan.PermuteNTT(level, ct, gen, pevk, ct)       # ctOut == ct0
+            for c in range(2):
+                assert np.array_equal(ct[c].get().reshape(level + 1, N), want[c]), (env, swap, gen, c)
+        del plan, pevk
