@@ -171,6 +171,17 @@ struct ScatterLaunch {
 };
 hipError_t launch_scatter(const ScatterLaunch &L, int limbs, int batch, hipStream_t stream);
 
+// up to four polys with unrelated addresses copied to / from the slots of one contiguous buffer (BFV Mul at a small batch: the four
+// operand polys become one batch of 4 B, the three results leave one batch of 3 B): poly k = z / batch, batch element z % batch
+struct MultiCopyLaunch {
+    const u64 *src[4];
+    long long src_stride[4];
+    u64 *dst[4];
+    long long dst_stride[4];
+    int count, batch, n;
+};
+hipError_t launch_multicopy(const MultiCopyLaunch &L, int limbs, hipStream_t stream);
+
 // out_row[r] = in + adds[r] (optionally CRed)
 struct RowAddLaunch {
     const u64 *in;   // one row per batch poly

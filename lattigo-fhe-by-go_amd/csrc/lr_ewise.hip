@@ -347,6 +347,28 @@ hipError_t launch_scatter(const ScatterLaunch &L, int limbs, int batch, hipStrea
     return hipGetLastError();
 }
 
+__global__ __launch_bounds__(256) void multicopy_kernel(MultiCopyLaunch L) {
+    const int k = blockIdx.z / L.batch;
+    const long long b = blockIdx.z % L.batch;
+    const long long row = (long long)blockIdx.y * L.n;
+    const ulonglong2 *ps = reinterpret_cast<const ulonglong2 *>(L.src[k] + b * L.src_stride[k] + row);
+    ulonglong2 *pd = reinterpret_cast<ulonglong2 *>(L.dst[k] + b * L.dst_stride[k] + row);
+    const int pairs = L.n >> 1;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < pairs; e += gridDim.x * 256) st_stream(pd + e, ld_stream(ps + e));
+}
+
+hipError_t launch_multicopy(const MultiCopyLaunch &L, int limbs, hipStream_t stream) {
+    if (limbs <= 0 || L.batch <= 0 || L.count <= 0) return hipSuccess;
+    const int pairs = L.n >> 1;
+    int gx = (pairs + 255) / 256;
+    if (gx > 64) gx = 64;
+    if (gx < 1) gx = 1;
+    const dim3 grid((unsigned)gx, (unsigned)limbs, (unsigned)(L.count * L.batch)), block(256);
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(multicopy_kernel, grid, block, 0, stream, L);
+    return hipGetLastError();
+}
+
 hipError_t launch_submul(const SubMulLaunch &L, int limbs, int batch, hipStream_t stream) {
     if (limbs <= 0 || batch <= 0) return hipSuccess;
     const int pairs = L.n >> 1;

@@ -99,6 +99,35 @@ def test_bfv_mul_without_extension_epilogues(gpu_pkg, oracle, name, logn, monkey
     test_bfv_mul(gpu_pkg, oracle, name, logn)
 
 
+@pytest.mark.parametrize("name,logn", [("PN13QP218", 11), ("PN14QP438", 14), ("PN15QP880", 15)])
+def test_bfv_mul_small_batch_and_per_operand_paths(gpu_pkg, oracle, name, logn, monkeypatch):
+    """at a small batch the four operand polys are gathered into one batch of 4 B and the three products leave as one batch of 3 B
+    (every step one launch); LR_BFV_NO_GATHER keeps one set of launches per operand / product as large batches have it.  One ciphertext
+    pair and three, both ways, with and without the extension epilogues, against the oracle; the output may be an operand."""
+    _, Q, P, QMul = gpu_pkg.params.bfv_moduli(name)
+    N, t = 1 << logn, 65537
+    ring = gpu_pkg.ring
+    oplan = oracle.BfvPlan(oracle.Context(N, Q), oracle.Context(N, QMul), t)
+    for batch in (1, 3):
+        mk = lambda s: gpu_pkg.sampling.uniform_poly(Q, N, batch, seed=s).reshape(batch, len(Q), N)
+        a0, a1, b0, b1 = mk(21), mk(22), mk(23), mk(24)
+        wants = [oplan.mul(np.stack([a0[b], a1[b]]), np.stack([b0[b], b1[b]])) for b in range(batch)]
+        for env in ({}, {"LR_BFV_NO_GATHER": "1"}, {"LR_BFV_NO_EXT_EPILOGUE": "1"}):
+            for k in ("LR_BFV_NO_GATHER", "LR_BFV_NO_EXT_EPILOGUE"):
+                monkeypatch.delenv(k, raising=False)
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            cQ, cM = ring.NewContextWithParams(N, Q), ring.NewContextWithParams(N, QMul)
+            plan = ring.BfvPlan(cQ, cM, t, batch)
+            P_ = lambda x: cQ.NewPoly(batch).set(x)
+            ct0, ct1 = (P_(a0), P_(a1)), (P_(b0), P_(b1))
+            out = (ct0[0], ct1[1], cQ.NewPoly(batch))            # two of the outputs are operands
+            plan.Mul(ct0, ct1, out)
+            for b in range(batch):
+                for k in range(3):
+                    assert np.array_equal(out[k].get().reshape(batch, len(Q), N)[b], wants[b][k]), (batch, env, b, k)
+
+
 def _galois(gpu_pkg, N, k):
     """Galois element of a left rotation by k: 5^k mod 2N (ckks/keygen.go:281-286 GenRot... -> ring.PermuteNTTIndex(GaloisGen, k, N))"""
     return pow(5, k, 2 * N)
