@@ -3358,7 +3358,7 @@ struct lr_bfv_plan {
     int max_batch = 0;
     bool no_ext_epilogue = false;     // LR_BFV_NO_EXT_EPILOGUE: separate subtract-multiply / scalar passes after the extensions
     bool no_gather = false;           // LR_BFV_NO_GATHER: every operand / product in launches of its own at every batch size
-    long long gather_below = 512;     // LR_BFV_GATHER_BELOW: workgroups of the four operands' joint transform up to which they are gathered
+XX
     Pool liftQ, liftM;                // the four operand polys over Q and over QMul, slots a0, a1, b0, b1 of [batch][limbs][N] each
     Pool prodQ, prodM;                // the three products, slots c0, c1, c2
     Pool stageIn, stageOut;           // small batches: the operands gathered into one batch of 4 B, the results before they are scattered
@@ -3461,7 +3461,7 @@ extern "C" int lr_bfv_mul(lr_bfv_plan *pl, const lr_poly *a0, const lr_poly *a1,
     lr_bext *bx = pl->bext;
     // A small batch: the four operand polys (unrelated addresses) are gathered into one batch of 4 B and every step of :298-313 runs
     // once on it; the three products go down as one batch of 3 B and are scattered to the callers' polys at the end.  One ciphertext
-    // pair at PN14QP438: 26 launches of 3 - 6 workgroups in a row, 424 us; 11 launches, 3 x fewer us (profiles/r03/bfv_small_batch.txt).
+    // pair at PN14QP438: 26 launches of 3 - 6 workgroups in a row, 424 us; 11 launches, 138 us (profiles/r03/bfv_small_batch.txt).
     // The copies (two passes over 7 polys) buy nothing once a launch of one operand fills the chip.
     const bool gathered = !pl->no_gather && (long long)4 * batch * std::max(nQ, nM) * (n >= (1 << 15) ? 2 : 1) <= pl->gather_below;
     if (gathered) {
