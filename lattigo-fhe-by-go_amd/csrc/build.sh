@@ -12,13 +12,14 @@ link() {
 # developer shortcut: `build.sh lr_abi.cpp lr_ewise.hip` recompiles only the named sources and relinks (everything else must
 # have been built before); without arguments the whole library is built from scratch, which is what __graft_entry__.build() runs
 if [ $# -gt 0 ]; then
+  spids=()
   for f in "$@"; do
     case $f in
-      *.hip) $HIPCC $FLAGS -c $f -o build/${f%.hip}.o & ;;
-      *.cpp) $HIPCC $FLAGS -x hip -c $f -o build/${f%.cpp}.o & ;;
+      *.hip) $HIPCC $FLAGS -c $f -o build/${f%.hip}.o & spids+=($!) ;;
+      *.cpp) $HIPCC $FLAGS -x hip -c $f -o build/${f%.cpp}.o & spids+=($!) ;;
     esac
   done
-  wait
+  for p in "${spids[@]}"; do wait $p; done     # (a failed compile stops here: set -e)
   link
   exit 0
 fi

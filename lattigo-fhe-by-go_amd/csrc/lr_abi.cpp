@@ -3358,7 +3358,8 @@ struct lr_bfv_plan {
     int max_batch = 0;
     bool no_ext_epilogue = false;     // LR_BFV_NO_EXT_EPILOGUE: separate subtract-multiply / scalar passes after the extensions
     bool no_gather = false;           // LR_BFV_NO_GATHER: every operand / product in launches of its own at every batch size
-XX
+    long long gather_below = 1536;    // LR_BFV_GATHER_BELOW: workgroups of the four operands' joint transform up to which they are gathered (PN14QP438:
+                                      // gathered 346 / 565 / 1015 / 1912 us per batch of 16 / 32 / 64 / 128, per operand 490 / 618 / 1081 / 1805)
     Pool liftQ, liftM;                // the four operand polys over Q and over QMul, slots a0, a1, b0, b1 of [batch][limbs][N] each
     Pool prodQ, prodM;                // the three products, slots c0, c1, c2
     Pool stageIn, stageOut;           // small batches: the operands gathered into one batch of 4 B, the results before they are scattered
