@@ -60,6 +60,7 @@ def main():
     assert kname.endswith("t") and (kname.startswith("lr_ntt_%s15_m" % kind) or kname.startswith("lr_ntt_%s15p_m" % kind)), kname
     # the stamped build computes the same transform as the shipped kernel (a second context created without the switch)
     os.environ.pop("LR_NTT_TIMELINE")
+    os.environ["LR_NTT_SPLIT15"] = "0"          # (a launch of two polys would otherwise run on the 2^14 sub-block kernels)
     plain = ring.NewContextWithParams(N, moduli)
     ref = plain.NewPoly(2)
     (plain.InvNTT if inverse else plain.NTT)(plain.NewPoly(2).set(base), ref)
