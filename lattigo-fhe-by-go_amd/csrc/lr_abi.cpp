@@ -2204,7 +2204,31 @@ int rescale_ntt_domain(lr_context *c, lr_poly *p0, bool round) {
             const bool fpc = ntt_epilogue_limb(c, l0);
             int l1 = l0 + 1;
             while (l1 < level && ntt_epilogue_limb(c, l1) == fpc) ++l1;
-            if (fpc) {
+            if (fpc && ntt_split15(c, (long long)(l1 - l0) * batch)) {
+                // N = 2^15, a small launch: the transforms with the epilogue on two workgroups each (2^14 sub-blocks).  Every target
+                // limb has its own top-stage twiddle, so the stage over bit 14 goes to the scratch rows first (the streaming kernel,
+                // the last limb's row broadcast to one row per target limb); the sub-blocks read those and write p0's rows.
+                NttLaunch t;
+                std::memset(&t, 0, sizeof t);
+                t.in = p0->d;
+                t.in_poly_stride = p0->stride();
+                t.in_limb0 = level;
+                t.in_limb_step = 0;
+                t.out = scratch.d();
+                t.out_poly_stride = tmp_stride;
+                t.out_limb0 = l0;
+                t.out_limb_step = 1;
+                t.mod0 = l0;
+                t.mod_step = 1;
+                t.n_items = l1 - l0;
+                t.batch = batch;
+                t.lp = c->d_lp;
+                t.tw = c->d_fwd;
+                LR_HIP(launch_ntt_top(t, 0, stream_of(c), 15));
+                const NttEpilogue ep{p0->d, p0->stride(), plus, 0, ec};
+                Rows src{scratch.d(), tmp_stride, l0, 1}, dst{p0->d, p0->stride(), l0, 1};
+                LR_TRY(run_ntt(c, false, src, dst, l0, 1, l1 - l0, batch, 0, 0, &ep, true));
+            } else if (fpc) {
                 const NttEpilogue ep{p0->d, p0->stride(), plus, 0, ec};
                 Rows dst{p0->d, p0->stride(), l0, 1};
                 LR_TRY(run_ntt(c, false, last, dst, l0, 1, l1 - l0, batch, 0, 0, &ep));
