@@ -180,6 +180,7 @@ lr::Options lr::Options::from_env() {
     if (const char *sp = std::getenv("LR_NTT_SPLIT15")) o.split15 = std::atoi(sp) != 0 ? 1 : 0;
     o.rescale_unpaired = std::getenv("LR_RESCALE_UNPAIRED") != nullptr;
     o.no_pair = std::getenv("LR_NO_PAIR") != nullptr;
+    o.no_ext_chunks = std::getenv("LR_NO_EXT_CHUNKS") != nullptr;
     o.no_invfuse = std::getenv("LR_NO_INVFUSE") != nullptr;
     o.keymac_narrow = std::getenv("LR_KEYMAC_NARROW") != nullptr;
     o.timeline = std::getenv("LR_NTT_TIMELINE") != nullptr;
@@ -1562,6 +1563,54 @@ struct ExtPending {
     int n_in;
 };
 
+// One extension launch, cut into column ranges where that fills the chip better.
+int launch_ext_chunked(lr_context *c, const ExtLaunch &L, int n_in, int batch) {
+    // A small batch: every thread of the extension walks all target columns of its coefficients, and a launch of n / 2 threads per
+    // poly is 32 - 128 workgroups.  The columns are independent: the launch is cut into records over disjoint column ranges that go
+    // out as one grouped launch (grid z = range), e.g. ModDown's extension of one PN15QP880 ciphertext 64 -> 256 workgroups.
+    if (!c->opt.no_ext_chunks && n_in <= 8) {
+        int total = 0;
+        for (int k = 0; k < kExtSegments; ++k) total += L.seg[k].count;
+        const bool top = L.seg[0].top_tw != nullptr;
+        const long long blocks = ((long long)(L.n / (top ? 4 : 2)) + 255) / 256 * batch;
+        int chunks = blocks > 0 && blocks < 128 ? (int)std::min<long long>((256 + blocks - 1) / blocks, kExtGroupMax) : 1;
+        if (chunks > total) chunks = total;
+        if (chunks > 1) {
+            ExtLaunch Ls[kExtGroupMax];
+            int seg = 0, off = 0;               // next column: segment `seg`, offset `off` inside it
+            for (int ch = 0; ch < chunks; ++ch) {
+                int want = total / chunks + (ch < total % chunks ? 1 : 0);
+                ExtLaunch &R = Ls[ch];
+                R = L;
+                for (int k = 0; k < kExtSegments; ++k) R.seg[k].count = 0;
+                int filled = 0;
+                while (want > 0 && seg < kExtSegments) {
+                    const int avail = L.seg[seg].count - off;
+                    if (avail <= 0) {
+                        ++seg;
+                        off = 0;
+                        continue;
+                    }
+                    const int take = std::min(avail, want);
+                    ExtSegment piece = L.seg[seg];
+                    piece.limb0 += off;
+                    piece.col0 += off;
+                    piece.top_mod0 += off;
+                    piece.count = take;
+                    R.seg[filled++] = piece;
+                    off += take;
+                    want -= take;
+                }
+            }
+            const hipError_t e = launch_ext_group(Ls, chunks, n_in, batch, c->stream);
+            if (e == hipSuccess) return LR_OK;
+            if (e != hipErrorNotSupported) return fail(LR_ERR_HIP, std::string("launch_ext_group: ") + hipGetErrorString(e));
+        }
+    }
+    LR_HIP(launch_ext(L, n_in, batch, c->stream));
+    return LR_OK;
+}
+
 int flush_ext(lr_context *c, std::vector<ExtPending> &pending, int batch, unsigned long long *grouped_launches = nullptr) {
     size_t i = 0;
     while (i < pending.size()) {
@@ -1579,7 +1628,7 @@ int flush_ext(lr_context *c, std::vector<ExtPending> &pending, int batch, unsign
             else if (e != hipErrorNotSupported) return fail(LR_ERR_HIP, std::string("launch_ext_group: ") + hipGetErrorString(e));
         }
         if (!grouped)
-            for (size_t k = i; k < j; ++k) LR_HIP(launch_ext(pending[k].L, pending[k].n_in, batch, c->stream));
+            for (size_t k = i; k < j; ++k) LR_TRY(launch_ext_chunked(c, pending[k].L, pending[k].n_in, batch));
         i = j;
     }
     pending.clear();
@@ -1602,8 +1651,7 @@ int run_ext(lr_context *c, const DevModup &m, int n_in, Rows in, int batch, ExtS
         collect->push_back(ExtPending{L, n_in});
         return LR_OK;
     }
-    LR_HIP(launch_ext(L, n_in, batch, c->stream));
-    return LR_OK;
+    return launch_ext_chunked(c, L, n_in, batch);
 }
 
 ExtSegment segment(u64 *out, long long stride, int limb0, int col0, int count) {
@@ -2542,9 +2590,25 @@ int ks_decompose(lr_ckks_plan *pl, int level, int batch, const u64 *cx, long lon
     // the digits' P rows beside their Q rows (another kernel variant, so another launch: at a small batch each fills a fraction of the chip)
     PlanFork forkP(pl, nP * beta * batch);
     LR_TRY(forkP.rc);
+    auto partial_digits = [&]() -> int {   // the digits that own fewer than alpha limbs at this level: their own launches
+        for (int i = full; i < beta; ++i) {
+            u64 *dq = pl->c2QiQ.d + (long long)i * dQ, *sq = srcQ + (long long)i * dQ;
+            const int d0 = i * alpha;
+            int d1 = d0 + dec->xalpha[i];
+            if (d1 > level + 1) d1 = level + 1;
+            Rows lo{dq, sQ, 0, 1}, lo_in{sq, sQ, 0, 1};
+            LR_TRY(run_ntt(cQ, false, lo_in, lo, 0, 1, d0, batch, 0, 0, nullptr, exttop));                  // limbs below the digit
+            Rows hi{dq, sQ, d1, 1}, hi_in{sq, sQ, d1, 1};
+            LR_TRY(run_ntt(cQ, false, hi_in, hi, d1, 1, level + 1 - d1, batch, 0, 0, nullptr, exttop));     // limbs above the digit
+        }
+        return LR_OK;
+    };
     if (forkP.on) {
+        // beside the full digits' grouped launch: the P rows and the partial digits' Q rows (PN16QP1761, one ciphertext: 70 + 34 us
+        // next to 99 us)
         Rows pr{pl->c2QiP.d, sP, 0, 1}, pr_in{srcP, sP, 0, 1};                   // :1590, every digit's P rows
         LR_TRY(run_ntt(cP, false, pr_in, pr, 0, 1, nP, beta * batch, 0, 0, nullptr, exttop));
+        LR_TRY(partial_digits());
         forkP.back();
     }
     const bool p_rows_done = forkP.on;
@@ -2553,7 +2617,7 @@ int ks_decompose(lr_ckks_plan *pl, int level, int batch, const u64 *cx, long lon
         Rows in{srcQ, sQ, 0, 1}, all{pl->c2QiQ.d, sQ, 0, 1};
         LR_TRY(run_ntt(cQ, false, in, all, 0, 1, level + 1 - alpha, full * batch, alpha, batch, nullptr, exttop));
     }
-    for (int i = full; i < beta; ++i) {
+    for (int i = p_rows_done ? beta : full; i < beta; ++i) {
         u64 *dq = pl->c2QiQ.d + (long long)i * dQ, *sq = srcQ + (long long)i * dQ;
         const int d0 = i * alpha;
         int d1 = d0 + dec->xalpha[i];

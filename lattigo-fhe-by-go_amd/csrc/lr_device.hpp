@@ -39,6 +39,7 @@ struct Options {
     bool timeline = false;         // LR_NTT_TIMELINE: plain 2^15 launches (forward / inverse, integer variant 1 and dual variant 3) run the stamped diagnostics builds
     bool keymac_narrow = false;    // LR_KEYMAC_NARROW: one Montgomery product per term in the key inner product instead of the 128-bit sums
     bool no_invfuse = false;       // LR_NO_INVFUSE: N = 2^16 inverse transforms as lazy sub-blocks + the separate last-stage pass (ntt_top_kernel) instead of the pair-flag kernels
+    bool no_ext_chunks = false;    // LR_NO_EXT_CHUNKS: a basis extension of a small batch as one launch over all target columns instead of column ranges on grid z
     bool no_pair = false;          // LR_NO_PAIR: ModDown's two components of a single ciphertext as two launches instead of one with distance strides
     bool rescale_unpaired = false; // LR_RESCALE_UNPAIRED: lr_ckks_rescale divides the two components one after the other at every batch size
     int split15 = -1;              // LR_NTT_SPLIT15: N = 2^15 transforms as two 2^14 sub-blocks: 0 never, 1 always, unset = launches of at most kSplit15Below workgroups

@@ -619,3 +619,24 @@ def test_rotate_columns_of_a_single_ciphertext(gpu_pkg, oracle, logn, nq, np_, l
             for c in range(2):
                 assert np.array_equal(ct[c].get().reshape(level + 1, N), want[c]), (env, swap, gen, c)
         del plan, pevk
+
+
+@pytest.mark.parametrize("logn,nq,np_,level,batch", [(15, 18, 3, 17, 1), (16, 10, 4, 9, 1), (14, 7, 3, 5, 1), (13, 9, 4, 8, 2)])
+def test_small_batch_extensions_in_column_ranges(gpu_pkg, oracle, logn, nq, np_, level, batch, monkeypatch):
+    """the basis extensions of a small batch go out as one grouped launch over disjoint column ranges (grid z = range; the digits
+    of a key switch that do not share a shape with others and ModDown's extension); LR_NO_EXT_CHUNKS keeps one launch over all columns"""
+    for env in ({}, {"LR_NO_EXT_CHUNKS": "1"}):
+        monkeypatch.delenv("LR_NO_EXT_CHUNKS", raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        N, Q, P, cQ, cP, plan, oplan, evk, pevk = _ckks(gpu_pkg, oracle, logn, nq, np_, batch)
+        mk = lambda s: gpu_pkg.sampling.uniform_poly(Q[:level + 1], N, batch, seed=s).reshape(batch, level + 1, N)
+        ops = [mk(51), mk(52), mk(53), mk(54)]
+        P_ = lambda x: cQ.NewPolyLvl(level, batch).set(x)
+        out = (cQ.NewPolyLvl(level, batch), cQ.NewPolyLvl(level, batch))
+        plan.MulRelin(level, (P_(ops[0]), P_(ops[1])), (P_(ops[2]), P_(ops[3])), pevk, out)
+        for b in range(batch):
+            w0, w1 = oplan.mulrelin(level, np.stack([ops[0][b], ops[1][b]]), np.stack([ops[2][b], ops[3][b]]), evk)
+            assert np.array_equal(out[0].get().reshape(batch, level + 1, N)[b], w0), (env, b)
+            assert np.array_equal(out[1].get().reshape(batch, level + 1, N)[b], w1), (env, b)
+        del plan, pevk, out
