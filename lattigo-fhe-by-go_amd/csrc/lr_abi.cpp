@@ -181,6 +181,7 @@ lr::Options lr::Options::from_env() {
     o.rescale_unpaired = std::getenv("LR_RESCALE_UNPAIRED") != nullptr;
     o.no_pair = std::getenv("LR_NO_PAIR") != nullptr;
     o.no_ext_chunks = std::getenv("LR_NO_EXT_CHUNKS") != nullptr;
+    o.no_invtop = std::getenv("LR_NO_INVTOP") != nullptr;
     o.no_invfuse = std::getenv("LR_NO_INVFUSE") != nullptr;
     o.keymac_narrow = std::getenv("LR_KEYMAC_NARROW") != nullptr;
     o.timeline = std::getenv("LR_NTT_TIMELINE") != nullptr;
@@ -244,7 +245,27 @@ struct DevModup {
         *qispj = nullptr, *qpj_inv = nullptr;
     ulonglong2 *qispj_shoup = nullptr;
     double *Qrcp = nullptr;
+    u64 *invtop0 = nullptr, *invtop1 = nullptr;     // set_inverse_top
     int lazy_terms = 0, exact_terms = 0, word_barrett = 0, wide_ok = 0, fast_div_ok = 1;
+    // The table's input limbs are the limbs limb0 .. of ring `hc`: the multipliers that take the lazy halves of an inverse sub-block
+    // transform straight to the y_i (ExtTables::invtop0 / invtop1)
+    int set_inverse_top(const HostContext &hc, int limb0) {
+        const size_t nQ = h.Q.size();
+        if (limb0 < 0 || (size_t)limb0 + nQ > hc.q.size() || hc.N < 2) return LR_OK;
+        std::vector<u64> k0(nQ), k1(nQ);
+        for (size_t i = 0; i < nQ; ++i) {
+            const u64 q = h.Q[i], qinv = h.mredQ[i];
+            if (hc.q[limb0 + i] != q) return LR_OK;      // (not this ring's limbs: the table stays without the multipliers)
+            const u64 n_inv = inv_mform(hc.n_inv[limb0 + i], q, qinv);
+            const u64 psi_inv1 = inv_mform(hc.ntt_psi_inv[(size_t)(limb0 + i) * hc.N + 1], q, qinv);
+            const u64 w1n = (u64)(((u128)psi_inv1 * n_inv) % q);
+            k0[i] = (u64)(((u128)h.qib_mont[i] * n_inv) % q);
+            k1[i] = (u64)(((u128)h.qib_mont[i] * w1n) % q);
+        }
+        LR_TRY(to_device(&invtop0, k0.data(), k0.size()));
+        LR_TRY(to_device(&invtop1, k1.data(), k1.size()));
+        return LR_OK;
+    }
     int init(const std::vector<u64> &Qv, const std::vector<u64> &Pv, bool ext_narrow) {
         h = build_modup(Qv, Pv);
         std::vector<u64> bh(h.P.size());
@@ -310,10 +331,12 @@ struct DevModup {
         t.exact_terms = exact_terms;
         t.word_barrett = word_barrett;
         t.wide_ok = wide_ok;
+        t.invtop0 = invtop0;
+        t.invtop1 = invtop1;
         return t;
     }
     ~DevModup() {
-        for (u64 *p : {Q, mredQ, qib, P, mredP, bredP_hi, qispj, qpj_inv})
+        for (u64 *p : {Q, mredQ, qib, P, mredP, bredP_hi, qispj, qpj_inv, invtop0, invtop1})
             if (p) (void)hipFree(p);
         if (qispj_shoup) (void)hipFree(qispj_shoup);
         if (Qrcp) (void)hipFree(Qrcp);
@@ -982,7 +1005,7 @@ thread_local hipStream_t g_fork_stream = nullptr;
 inline hipStream_t stream_of(const lr_context *c) { return g_fork_stream ? g_fork_stream : c->stream; }
 
 int run_ntt_launch(lr_context *c, bool inverse, Rows in, Rows out, int mod0, int mod_step, int count, int batch, int hole,
-                   int group, const NttEpilogue *epi, bool pretop);
+                   int group, const NttEpilogue *epi, bool pretop, bool lazy);
 
 // Polys per workgroup of the persistent forward 2^15 kernels (0 = the one-poly kernels).  LR_NTT_PERSIST overrides; the default keeps
 // at least four rounds of workgroups on the 256 CUs (the dispatcher balances limbs of different cost -- FP64 and integer bodies in one
@@ -1001,15 +1024,17 @@ int ntt_persist(const lr_context *c, const NttLaunch &a, unsigned logn, bool inv
 // the limit are refused: 65536 ciphertexts in one key switch exceed the device memory by orders of magnitude.
 // pretop (N = 2^16, forward, assembly kernels): the producer of the input rows has already applied the stage over index bit 15
 // (ext_sum_kernel<.., true>); the launch goes straight to the plain sub-block kernels, which read their own half only.
+// lazy (inverse, N = 2^15 / 2^16 on the assembly sub-block kernels): the rows are left as the two halves of every limb before the last
+// Gentleman-Sande stage and the scaling -- for a consumer that applies them itself (the top-stage basis extension, ExtLaunch::inv_top)
 int run_ntt(lr_context *c, bool inverse, Rows in, Rows out, int mod0, int mod_step, int count, int batch, int hole = 0,
-            int group = 0, const NttEpilogue *epi = nullptr, bool pretop = false) {
+            int group = 0, const NttEpilogue *epi = nullptr, bool pretop = false, bool lazy = false) {
     if (count <= 0 || batch <= 0) return LR_OK;
     if (hole > 0 && (group <= 0 || batch % group != 0)) return fail(LR_ERR_ARG, "digit groups must divide the batch");
     // N = 2^16: the streaming top-stage kernel carries poly * limbs on grid.y
     const int kChunk = c->h.logN == 16 || (c->h.logN == 15 && c->opt.split15 == 1) ? std::max(1, 65535 / count) : 65535;
     if (hole > 0) {
         if (group > kChunk || batch / group > 65535) return fail(LR_ERR_UNSUPPORTED, "grouped NTT launch: more than 65535 polys per digit group");
-        return run_ntt_launch(c, inverse, in, out, mod0, mod_step, count, batch, hole, group, epi, pretop);
+        return run_ntt_launch(c, inverse, in, out, mod0, mod_step, count, batch, hole, group, epi, pretop, lazy);
     }
     for (int b0 = 0; b0 < batch; b0 += kChunk) {
         const int nb = std::min(kChunk, batch - b0);
@@ -1022,13 +1047,13 @@ int run_ntt(lr_context *c, bool inverse, Rows in, Rows out, int mod0, int mod_st
             e2.x = epi->x + (long long)b0 * epi->x_stride;
             e2.plus = epi->plus + (long long)b0 * epi->plus_stride;
         }
-        LR_TRY(run_ntt_launch(c, inverse, ci, co, mod0, mod_step, count, nb, 0, 0, epi ? &e2 : nullptr, pretop));
+        LR_TRY(run_ntt_launch(c, inverse, ci, co, mod0, mod_step, count, nb, 0, 0, epi ? &e2 : nullptr, pretop, lazy));
     }
     return LR_OK;
 }
 
 int run_ntt_launch(lr_context *c, bool inverse, Rows in, Rows out, int mod0, int mod_step, int count, int batch, int hole,
-                   int group, const NttEpilogue *epi, bool pretop) {
+                   int group, const NttEpilogue *epi, bool pretop, bool lazy) {
     const unsigned logn = c->h.logN;
     if (logn < 1 || logn > 16)
         return fail(LR_ERR_UNSUPPORTED, "NTT kernels cover 2 <= N <= 2^16");
@@ -1069,7 +1094,9 @@ int run_ntt_launch(lr_context *c, bool inverse, Rows in, Rows out, int mod0, int
     // surrounds it): two 2^14 sub-blocks per limb on the "h" kernels, twice the workgroups at about half the latency.  The stage over
     // index bit 14 is the streaming ntt_top_kernel's (forward: before, unless the caller's basis extension has applied it -- pretop;
     // inverse: after, with the scaling).  A caller that passes pretop has decided for the split itself (ntt_split15).
-    if (logn == 15 && (pretop || (ntt_split15(c, (long long)count * batch) && !(epi && !pretop)))) {
+    if (lazy && !(inverse && !epi && (logn == 15 || logn == 16) && variant >= 0 && c->use_asm && ntt_asm_available((int)logn)))
+        return fail(LR_ERR_ARG, "lazy inverse outputs: assembly sub-block kernels of N = 2^15 / 2^16 only");
+    if (logn == 15 && (pretop || lazy || (ntt_split15(c, (long long)count * batch) && !(epi && !pretop)))) {
         if (variant < 0 || !c->use_asm || !ntt_asm_available(15)) return fail(LR_ERR_ARG, "pre-applied top stage: assembly kernels only");
         if (epi) {
             if (inverse || hole > 0 || !ntt_epilogue_ok(c)) return fail(LR_ERR_ARG, "NTT epilogue: not available for this launch");
@@ -1094,6 +1121,7 @@ int run_ntt_launch(lr_context *c, bool inverse, Rows in, Rows out, int mod0, int
             return LR_OK;
         }
         LR_HIP(launch_ntt_asm16(a, 1, 'h', variant, stream_of(c), kn, c->opt.stagger, 15));
+        if (lazy) return LR_OK;
         NttLaunch top = a;
         top.in = a.out;
         top.in_poly_stride = a.out_poly_stride;
@@ -1134,6 +1162,10 @@ int run_ntt_launch(lr_context *c, bool inverse, Rows in, Rows out, int mod0, int
             sub.in_limb0 = a.out_limb0;
             sub.in_limb_step = a.out_limb_step;
             LR_HIP(launch_ntt_asm16(sub, 0, 'p', variant, stream_of(c), kn, c->opt.stagger));
+            return LR_OK;
+        }
+        if (lazy) {
+            LR_HIP(launch_ntt_asm16(a, 1, 's', variant, stream_of(c), kn, c->opt.stagger));
             return LR_OK;
         }
         if (!c->opt.no_invfuse && hole == 0) {
@@ -1636,7 +1668,7 @@ int flush_ext(lr_context *c, std::vector<ExtPending> &pending, int batch, unsign
 }
 
 int run_ext(lr_context *c, const DevModup &m, int n_in, Rows in, int batch, ExtSegment s0, ExtSegment s1,
-            const ExtSegment *s2 = nullptr, std::vector<ExtPending> *collect = nullptr) {
+            const ExtSegment *s2 = nullptr, std::vector<ExtPending> *collect = nullptr, bool inv_top = false) {
     if (n_in < 1 || n_in > 40 || n_in > (int)m.h.Q.size()) return fail(LR_ERR_UNSUPPORTED, "basis extension from 1..40 limbs");
     ExtLaunch L;
     L.t = m.tables();
@@ -1647,6 +1679,11 @@ int run_ext(lr_context *c, const DevModup &m, int n_in, Rows in, int batch, ExtS
     L.seg[0] = s0;
     L.seg[1] = s1;
     L.seg[2] = s2 ? *s2 : segment(nullptr, 0, 0, 0, 0);
+    L.inv_top = 0;
+    if (inv_top) {
+        if (!L.seg[0].top_tw || !L.t.invtop0 || !L.t.invtop1) return fail(LR_ERR_INTERNAL, "lazy inverse input without the top-stage extension");
+        L.inv_top = 1;
+    }
     if (collect) {
         collect->push_back(ExtPending{L, n_in});
         return LR_OK;
@@ -1728,6 +1765,7 @@ extern "C" int lr_bext_create(lr_context *cQ, lr_context *cP, lr_bext **out) {
     const bool narrow = Options::from_env().ext_narrow;
     LR_TRY(b->qp.init(cQ->h.q, cP->h.q, narrow));
     LR_TRY(b->pq.init(cP->h.q, cQ->h.q, narrow));
+    LR_TRY(b->pq.set_inverse_top(cP->h, 0));
     b->moddown_pq = build_moddown(cQ->h, cP->h);  // genModDownParams(contextQ, contextP), ring_basis_extension.go:66
     b->moddown_qp = build_moddown(cP->h, cQ->h);  // :67
     LR_TRY(to_device(&b->d_moddown_pq, b->moddown_pq.data(), b->moddown_pq.size()));
@@ -2013,6 +2051,7 @@ extern "C" int lr_decomposer_create(lr_context *cQ, lr_context *cP, lr_decompose
             std::vector<u64> Qi(Q.begin() + (size_t)i * d->alpha, Q.begin() + (size_t)i * d->alpha + j + 2);
             std::unique_ptr<DevModup> m(new DevModup());
             LR_TRY(m->init(Qi, QP, narrow));
+            LR_TRY(m->set_inverse_top(cQ->h, i * d->alpha));
             d->modup[i].push_back(std::move(m));
         }
     }
@@ -2045,7 +2084,8 @@ bool digit_is_extended(const lr_decomposer *d, int level, int crt) {
 // extended digits only -- the caller checks digit_is_extended and ext_top_supported)
 // skip_own: do not write the rows the digit owns (the key switch reads them from the NTT-domain input, or copies them in)
 int decompose_core(lr_decomposer *d, int level, int crt, Rows in, int batch, u64 *outQ, long long outQ_stride, u64 *outP,
-                   long long outP_stride, bool split, bool top = false, bool skip_own = false, std::vector<ExtPending> *collect = nullptr) {
+                   long long outP_stride, bool split, bool top = false, bool skip_own = false, std::vector<ExtPending> *collect = nullptr,
+                   bool inv_top = false) {
     lr_context *c = d->cQ;
     if (crt < 0 || crt >= d->beta) return fail(LR_ERR_SHAPE, "crtDecompLevel out of range");
     if (level < 0 || level + 1 > d->nQ) return fail(LR_ERR_SHAPE, "level out of range");
@@ -2095,9 +2135,9 @@ int decompose_core(lr_decomposer *d, int level, int crt, Rows in, int batch, u64
         ExtSegment hi = segment(outQ, outQ_stride, own_end, own_end, level + 1 - own_end);
         lo.top_tw = hi.top_tw = sq.top_tw;
         hi.top_mod0 = own_end;
-        return run_ext(c, m, index + 2, digit, batch, lo, hi, &sp, collect);
+        return run_ext(c, m, index + 2, digit, batch, lo, hi, &sp, collect, inv_top);
     }
-    return run_ext(c, m, index + 2, digit, batch, sq, sp, nullptr, collect);
+    return run_ext(c, m, index + 2, digit, batch, sq, sp, nullptr, collect, inv_top);
 }
 
 }  // namespace
@@ -2564,7 +2604,15 @@ int ks_decompose(lr_ckks_plan *pl, int level, int batch, const u64 *cx, long lon
     u64 *const srcQ = staged ? pl->stageQ.d : pl->c2QiQ.d, *const srcP = staged ? pl->stageP.d : pl->c2QiP.d;
     Rows cxr{const_cast<u64 *>(cx), cx_stride, 0, 1};
     Rows c2r{pl->c2.d, sQ, 0, 1};
-    LR_TRY(run_ntt(cQ, !coeff_input, cxr, c2r, 0, 1, level + 1, batch));  // ckks :1503 (InvNTT) / bfv :753 (NTT)
+    // the digits' extensions apply the top stage of the transforms that follow them (exttop): then they also take the last stage and
+    // the scaling of the inverse transform in front of them (its sub-blocks leave the rows lazy; nothing else reads c2 on this path)
+    bool invtop = exttop && !coeff_input && !pl->opt.no_invtop && cQ->asm_inv >= 0;
+    for (int i = 0; i < beta && invtop; ++i) {
+        const int alphai = dec->xalpha[i];
+        const int index = level >= alphai + i * dec->alpha ? alphai - 2 : (level - 1) % dec->alpha;
+        invtop = dec->modup[i][index]->invtop0 != nullptr && index + 2 <= 8;
+    }
+    LR_TRY(run_ntt(cQ, !coeff_input, cxr, c2r, 0, 1, level + 1, batch, 0, 0, nullptr, false, invtop));  // ckks :1503 (InvNTT) / bfv :753 (NTT)
     if (coeff_input) {
         // the decomposition reads the caller's coefficient-domain rows; the transformed copy serves the digits' own limbs
         if (copy_own) return fail(LR_ERR_UNSUPPORTED, "coefficient-domain key switch: own limbs are read in place");
@@ -2577,7 +2625,7 @@ int ks_decompose(lr_ckks_plan *pl, int level, int batch, const u64 *cx, long lon
         u64 *dq = pl->c2QiQ.d + (long long)i * dQ;
         // decomposeAndSplitNTT, :1561-1591
         LR_TRY(decompose_core(dec, level, i, c2r, batch, srcQ + (long long)i * dQ, sQ, srcP + (long long)i * dP, sP, true, exttop, true,
-                              pl->opt.no_ext_group ? nullptr : &pending));
+                              pl->opt.no_ext_group ? nullptr : &pending, invtop));
         const int d0 = i * alpha;
         int d1 = d0 + dec->xalpha[i];
         if (d1 > level + 1) d1 = level + 1;
@@ -2727,7 +2775,6 @@ int ks_accumulate(lr_ckks_plan *pl, int level, int batch, const u64 *digQ, const
     // ModDownSplitedNTTPQ x2; the two calls share every launch up to the final subtract-multiply
     {
         Rows pr{pool2P, sP, 0, 1};
-        LR_TRY(run_ntt(cP, true, pr, pr, 0, 1, nP, 2 * batch));
         LR_TRY(bx->poolQ.ensure(cQ, (size_t)2 * batch * sQ));
         u64 *ext_out = bx->poolQ.d;
         const bool asm16 = cQ->h.logN == 16 && cQ->use_asm && cQ->asm_fwd >= 0;
@@ -2739,7 +2786,10 @@ int ks_accumulate(lr_ckks_plan *pl, int level, int batch, const u64 *digQ, const
         }
         ExtSegment mseg = segment(ext_out, sQ, 0, 0, level + 1);
         if (exttop) mseg.top_tw = cQ->d_fwd;                           // the ModDown transform's top stage inside the extension
-        LR_TRY(run_ext(cQ, bx->pq, nP, pr, 2 * batch, mseg, segment(nullptr, 0, 0, 0, 0)));
+        // ... and the last stage of the inverse transform in front of it (see ks_decompose)
+        const bool invtop = exttop && !pl->opt.no_invtop && cP->asm_inv >= 0 && bx->pq.invtop0 != nullptr && nP <= 8;
+        LR_TRY(run_ntt(cP, true, pr, pr, 0, 1, nP, 2 * batch, 0, 0, nullptr, false, invtop));
+        LR_TRY(run_ext(cQ, bx->pq, nP, pr, 2 * batch, mseg, segment(nullptr, 0, 0, 0, 0), nullptr, nullptr, invtop));
         Rows qr{bx->poolQ.d, sQ, 0, 1}, qr_in{ext_out, sQ, 0, 1};
         if (ntt_epilogue_ok(cQ)) {
             // the subtract-multiply and the addition of MulRelin / the rotations inside the forward transform's copy-out, for

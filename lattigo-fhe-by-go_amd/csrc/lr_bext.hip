@@ -239,6 +239,27 @@ __device__ __forceinline__ void ext_sum_body(const ExtLaunch &L) {
                 v[h * W] = ld_stream(src);
             }
         }
+        if constexpr (TOP) {
+            if (L.inv_top) {
+                // v[w] / v[W + w] = the halves U, V (below 8q, or 4q for a modulus above 2^60) of the limb before its last inverse stage:
+                // the finished coefficients are (U + V) N^-1 and (U - V) psi_inv[1] N^-1, and both constants ride in the Montgomery
+                // multiplier that turns a coefficient into y_i anyway
+                const u64 bound = (qi >> 60) ? qi << 2 : qi << 3;
+                const u64 k0 = L.t.invtop0[i], k1 = L.t.invtop1[i], qinv = L.t.mredQ[i];
+#pragma unroll
+                for (int w = 0; w < W; ++w) {
+                    const u64 U = v[w], V = v[W + w];
+                    const u64 ya = mred(U + V, k0, qi, qinv), yb = mred(U + bound - V, k1, qi, qinv);
+                    vf[w] += div_by_const((double)ya, (double)qi, qr);
+                    vf[W + w] += div_by_const((double)yb, (double)qi, qr);
+                    y0[w][i] = (u32)ya;
+                    y1[w][i] = (u32)(ya >> 32);
+                    y0[W + w][i] = (u32)yb;
+                    y1[W + w][i] = (u32)(yb >> 32);
+                }
+                continue;
+            }
+        }
 #pragma unroll
         for (int w = 0; w < C; ++w) {
             const u64 y = mred(v[w], L.t.qib_mont[i], qi, L.t.mredQ[i]);

@@ -39,6 +39,7 @@ struct Options {
     bool timeline = false;         // LR_NTT_TIMELINE: plain 2^15 launches (forward / inverse, integer variant 1 and dual variant 3) run the stamped diagnostics builds
     bool keymac_narrow = false;    // LR_KEYMAC_NARROW: one Montgomery product per term in the key inner product instead of the 128-bit sums
     bool no_invfuse = false;       // LR_NO_INVFUSE: N = 2^16 inverse transforms as lazy sub-blocks + the separate last-stage pass (ntt_top_kernel) instead of the pair-flag kernels
+    bool no_invtop = false;        // LR_NO_INVTOP: the inverse transforms in front of a top-stage extension finish with their own last-stage pass
     bool no_ext_chunks = false;    // LR_NO_EXT_CHUNKS: a basis extension of a small batch as one launch over all target columns instead of column ranges on grid z
     bool no_pair = false;          // LR_NO_PAIR: ModDown's two components of a single ciphertext as two launches instead of one with distance strides
     bool rescale_unpaired = false; // LR_RESCALE_UNPAIRED: lr_ckks_rescale divides the two components one after the other at every batch size
@@ -281,6 +282,12 @@ struct ExtTables {        // device pointers; modupParams of ring_basis_extensio
     int exact_terms;      // the same for [0,2p) terms
     int word_barrett;     // every p_j > 2^32: floor(2^64 / p_j) fits one word (ext_sum_kernel's final reduction)
     int wide_ok;          // how many input terms keep n * max q_i below 2^64 (ext_wide_kernel: one Montgomery reduction per group)
+    // inputs that are the LAZY outputs of the inverse sub-block kernels (the two halves U, V of a limb before its last Gentleman-Sande
+    // stage and the scaling): qib_mont[i] * N^-1 and qib_mont[i] * psi_inv[1] * N^-1 mod q_i, so that MRed(U + V, .) and
+    // MRed(U + bound - V, .) are the y_i of the finished coefficients j and j + N/2 -- the last inverse stage costs the extension one
+    // addition per coefficient instead of a pass over the rows (ExtLaunch::inv_top, top-stage variant of the sum-form kernel only);
+    // null where the table was not given a context (set_inverse_top)
+    const u64 *invtop0, *invtop1;
 };
 
 constexpr int kExtSegments = 3;   // key-switch digits: rows below the digit, rows above it, the special primes
@@ -310,6 +317,7 @@ struct ExtLaunch {
     int in_limb0;
     int n;
     ExtSegment seg[kExtSegments];   // unused segments have count == 0
+    int inv_top;                    // 1: the input rows are lazy inverse sub-block outputs (ExtTables::invtop0 / invtop1)
 };
 
 constexpr int kExtGroupMax = 9;    // extensions per grouped launch (the digits of one key switch: beta = 9 at PN16QP1761)

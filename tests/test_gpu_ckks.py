@@ -210,8 +210,8 @@ def test_mulrelin_2p16_paths(gpu_pkg, oracle, nq, np_, level, monkeypatch):
     sub-block kernels in place (default where every digit is extended: (6,2,5), (7,3,5), (10,4,9); (5,2,4) ends in a one-limb
     digit and falls back), staged extensions + fused-top kernels (LR_NO_EXTTOP), in-place transforms behind the separate top-stage
     pass (LR_NO_EXTTOP + LR_NO_STAGING)"""
-    for env in ({}, {"LR_NO_EXTTOP": "1"}, {"LR_NO_EXTTOP": "1", "LR_NO_STAGING": "1"}):
-        for k in ("LR_NO_EXTTOP", "LR_NO_STAGING"):
+    for env in ({}, {"LR_NO_EXTTOP": "1"}, {"LR_NO_EXTTOP": "1", "LR_NO_STAGING": "1"}, {"LR_NO_INVTOP": "1"}):
+        for k in ("LR_NO_EXTTOP", "LR_NO_STAGING", "LR_NO_INVTOP"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -519,9 +519,10 @@ def test_mulrelin_2p15_split_paths(gpu_pkg, oracle, nq, np_, level, batch, monke
     =1 splits whatever the size; LR_NO_EXTTOP leaves the forward top stage to ntt_top_kernel.  All against the oracle."""
     # (LR_NO_PAIR: ModDown's two components of a single ciphertext as two launches; by default one launch whose strides are the distances
     # between the components' operands -- negative when the second output was allocated first, as in the last round)
+    # (LR_NO_INVTOP: the inverse transforms finish with their own last-stage pass instead of leaving it to the extension behind them)
     for env in ({}, {"LR_NTT_SPLIT15": "0"}, {"LR_NTT_SPLIT15": "1"}, {"LR_NO_EXTTOP": "1"}, {"LR_NTT_SPLIT15": "1", "LR_NO_FORK": "1", "LR_NO_EXT_GROUP": "1"},
-                {"LR_NO_PAIR": "1"}, {"swap_outputs": "1"}):
-        for k in ("LR_NTT_SPLIT15", "LR_NO_EXTTOP", "LR_NO_FORK", "LR_NO_EXT_GROUP", "LR_NO_PAIR"):
+                {"LR_NO_PAIR": "1"}, {"swap_outputs": "1"}, {"LR_NO_INVTOP": "1"}, {"LR_NO_INVTOP": "1", "LR_NO_EXT_CHUNKS": "1"}):
+        for k in ("LR_NTT_SPLIT15", "LR_NO_EXTTOP", "LR_NO_FORK", "LR_NO_EXT_GROUP", "LR_NO_PAIR", "LR_NO_INVTOP", "LR_NO_EXT_CHUNKS"):
             monkeypatch.delenv(k, raising=False)
         swap = env.pop("swap_outputs", None) if isinstance(env, dict) else None
         env = dict(env)
