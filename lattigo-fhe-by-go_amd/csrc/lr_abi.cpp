@@ -2270,9 +2270,14 @@ int rescale_ntt_domain(lr_context *c, lr_poly *p0, bool round) {
     ScratchLease scratch;
     LR_TRY(scratch.take(&c->scratch, (size_t)batch * tmp_stride));
     Rows last{p0->d, p0->stride(), level, 0};
-    LR_TRY(run_ntt(c, true, last, last, level, 0, 1, batch));  // :15 / :80
+    // N = 2^15, a small launch whose every target limb takes the epilogue: the last limb's inverse sub-blocks stay lazy and ONE streaming
+    // kernel does what lies between them and the targets' forward sub-blocks (last inverse stage + scaling, + pHalf, forward top stage)
+    bool fuse_mid = round && plus && ntt_epilogue_ok(c) && c->h.logN == 15 && !c->opt.no_invtop && c->asm_inv >= 0 &&
+                    ntt_split15(c, (long long)level * batch);
+    for (int l = 0; l < level && fuse_mid; ++l) fuse_mid = ntt_epilogue_limb(c, l);
+    LR_TRY(run_ntt(c, true, last, last, level, 0, 1, batch, 0, 0, nullptr, false, fuse_mid));  // :15 / :80
     Rows tmp{scratch.d(), tmp_stride, 0, 1};
-    if (round) {
+    if (round && !fuse_mid) {
         const u64 pj = c->h.q[level], phalf = (pj - 1) >> 1;
         RowAddLaunch L;
         L.in = p0->d + (long long)level * n;
@@ -2312,7 +2317,8 @@ int rescale_ntt_domain(lr_context *c, lr_poly *p0, bool round) {
                 t.batch = batch;
                 t.lp = c->d_lp;
                 t.tw = c->d_fwd;
-                LR_HIP(launch_ntt_top(t, 0, stream_of(c), 15));
+                if (fuse_mid) LR_HIP(launch_rescale_mid(t, c->d_inv, level, (c->h.q[level] - 1) >> 1, 15, stream_of(c)));
+                else LR_HIP(launch_ntt_top(t, 0, stream_of(c), 15));
                 const NttEpilogue ep{p0->d, p0->stride(), plus, 0, ec};
                 Rows src{scratch.d(), tmp_stride, l0, 1}, dst{p0->d, p0->stride(), l0, 1};
                 LR_TRY(run_ntt(c, false, src, dst, l0, 1, l1 - l0, batch, 0, 0, &ep, true));

@@ -366,6 +366,8 @@ hipError_t launch_ntt_asm16(const NttLaunch &a, int inverse, char kind, int vari
                             int stagger = -1, int full_logn = 16);
 // N = 2^16 helpers (lr_ntt.hip): the streaming stage over bit 15, and whether no input row of a launch is an output row
 hipError_t launch_ntt_top(const NttLaunch &a, int inverse, hipStream_t stream, int logn = 16);
+// the rescale's three streaming passes between the lazy inverse sub-blocks of the last limb and the forward sub-blocks of the targets (lr_ntt.hip)
+hipError_t launch_rescale_mid(const NttLaunch &a, const Twiddle *tw_inv, int last_mod, u64 phalf, int logn, hipStream_t stream);
 bool ntt_rows_disjoint(const NttLaunch &a, int logn);
 hipError_t launch_ewise(int op, const EwiseLaunch &L, int limbs, int batch, hipStream_t stream);
 hipError_t launch_submul(const SubMulLaunch &L, int limbs, int batch, hipStream_t stream);

@@ -486,6 +486,46 @@ __global__ __launch_bounds__(256) void ntt_top_kernel(NttLaunch a, int logn, int
     }
 }
 
+// Rounding / flooring rescale on the sub-block kernels (small launches at N = 2^15): between the lazy inverse sub-blocks of the last limb
+// (halves U, V below 8q_L) and the forward sub-blocks of every target limb sit the inverse transform's last stage with the scaling, the
+// + pHalf of ring_scaling.go:87-89 and the forward transforms' first stage -- three streaming passes (ntt_top_kernel, rowadd_kernel,
+// ntt_top_kernel) as one: block (x, item + n_items * poly) reads the last limb's pair (j, j + N/2), finishes it under q_L and writes the
+// pair after the forward top stage under the target limb's modulus to that limb's scratch row.
+// a: forward-side addressing (in = the last limb's row with in_limb_step 0, out = one row per target limb, mod0 / mod_step = targets,
+// tw = the forward table); tw_inv: the inverse table; last_mod: the last limb's modulus index.
+__global__ __launch_bounds__(256) void rescale_mid_kernel(NttLaunch a, const Twiddle *tw_inv, int last_mod, u64 phalf, int logn) {
+    const int item = blockIdx.y % a.n_items;
+    const int b = blockIdx.y / a.n_items;
+    const int mod = a.mod0 + item * a.mod_step;
+    const long long n = 1ll << logn, h = n >> 1;
+    const LimbParams lpL = a.lp[last_mod], lp = a.lp[mod];
+    const Twiddle wL = (tw_inv + (long long)last_mod * n)[0];          // psi_inv[1] * N^-1 mod q_L
+    const Twiddle w = (a.tw + (long long)mod * n)[1];
+    const u64 qL = lpL.q, q = lp.q, q4 = q << 2;
+    const u64 bound = (qL >> 60) ? qL << 2 : qL << 3;
+    const u64 *src = a.in + (long long)b * a.in_poly_stride + (long long)a.in_limb0 * n;
+    u64 *dst = a.out + (long long)b * a.out_poly_stride + (long long)(a.out_limb0 + item * a.out_limb_step) * n;
+    for (long long j = (long long)blockIdx.x * 256 + threadIdx.x; j < h; j += (long long)gridDim.x * 256) {
+        const u64 U0 = src[j], V0 = src[j + h];                          // (read by every target limb's blocks: default cache policy)
+        u64 x0 = canon_from_4q(mul_shoup_lazy(U0 + V0, lpL.n_inv, lpL.n_inv_shoup, qL), qL);
+        u64 x1 = canon_from_4q(mul_shoup_lazy(U0 + bound - V0, wL.x, wL.y, qL), qL);
+        x0 = cred(x0 + phalf, qL);
+        x1 = cred(x1 + phalf, qL);
+        u64 U = bred_add(x0, q, lp.bred_hi), V = x1;
+        fwd_bfly<3>(U, V, w.x, w.y, q, q4, true);
+        st_stream(dst + j, U);
+        st_stream(dst + j + h, V);
+    }
+}
+
+hipError_t launch_rescale_mid(const NttLaunch &a, const Twiddle *tw_inv, int last_mod, u64 phalf, int logn, hipStream_t stream) {
+    if (a.n_items <= 0 || a.batch <= 0) return hipSuccess;
+    const dim3 grid(32, (unsigned)(a.n_items * a.batch)), block(256);
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(rescale_mid_kernel, grid, block, 0, stream, a, tw_inv, last_mod, phalf, logn);
+    return hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------------------
 // host launchers
 // ------------------------------------------------------------------------------------------
