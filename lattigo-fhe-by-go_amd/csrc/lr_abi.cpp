@@ -182,6 +182,7 @@ lr::Options lr::Options::from_env() {
     o.no_pair = std::getenv("LR_NO_PAIR") != nullptr;
     o.no_ext_chunks = std::getenv("LR_NO_EXT_CHUNKS") != nullptr;
     o.no_invtop = std::getenv("LR_NO_INVTOP") != nullptr;
+    o.no_wide14_small = std::getenv("LR_ASM_14_NO_WIDE_SMALL") != nullptr;
     o.no_invfuse = std::getenv("LR_NO_INVFUSE") != nullptr;
     o.keymac_narrow = std::getenv("LR_KEYMAC_NARROW") != nullptr;
     o.timeline = std::getenv("LR_NTT_TIMELINE") != nullptr;
@@ -1090,6 +1091,9 @@ int run_ntt_launch(lr_context *c, bool inverse, Rows in, Rows out, int mod0, int
         a.fp_lp = c->d_fp_lp;
     }
     char *kn = c->last_ntt_kernel;
+    // N = 2^14: 512 threads per transform put two workgroups on a CU (best throughput); a launch that does not fill the chip anyway takes
+    // the 1024-thread plan, whose one workgroup is done sooner (PN14QP438, one ciphertext: MulRelin 115 -> 102 us, BFV Mul 136 -> 125 us)
+    const bool wide14 = c->opt.asm14_1024 || (logn == 14 && !c->opt.no_wide14_small && (long long)count * batch <= 256);
     // N = 2^15, a launch too small to fill the chip with one workgroup per transform (a one-workgroup 2^15 transform takes ~42 us whatever
     // surrounds it): two 2^14 sub-blocks per limb on the "h" kernels, twice the workgroups at about half the latency.  The stage over
     // index bit 14 is the streaming ntt_top_kernel's (forward: before, unless the caller's basis extension has applied it -- pretop;
@@ -1141,7 +1145,7 @@ int run_ntt_launch(lr_context *c, bool inverse, Rows in, Rows out, int mod0, int
         if (logn == 16)
             LR_HIP(launch_ntt_asm16(a, 0, pretop ? 'p' : 's', c->asm_fwd == 3 ? 4 : 5, stream_of(c), kn, c->opt.stagger));
         else
-            LR_HIP(launch_ntt_asm(a, (int)logn, 0, c->asm_fwd == 3 ? 4 : 5, stream_of(c), c->opt.asm14_1024, kn, false, c->opt.stagger));
+            LR_HIP(launch_ntt_asm(a, (int)logn, 0, c->asm_fwd == 3 ? 4 : 5, stream_of(c), wide14, kn, false, c->opt.stagger));
         return LR_OK;
     }
     if (logn == 16 && variant >= 0 && c->use_asm && ntt_asm_available(16)) {
@@ -1206,7 +1210,7 @@ int run_ntt_launch(lr_context *c, bool inverse, Rows in, Rows out, int mod0, int
             LR_HIP(launch_ntt_asm(a, (int)logn, inverse, variant, stream_of(c), false, kn, true, c->opt.stagger, ntt_persist(c, a, logn, inverse)));
             return LR_OK;
         }
-        LR_HIP(launch_ntt_asm(a, (int)logn, inverse, variant, stream_of(c), c->opt.asm14_1024, kn, false, c->opt.stagger, ntt_persist(c, a, logn, inverse)));
+        LR_HIP(launch_ntt_asm(a, (int)logn, inverse, variant, stream_of(c), wide14, kn, false, c->opt.stagger, ntt_persist(c, a, logn, inverse)));
         return LR_OK;
     }
     std::snprintf(c->last_ntt_kernel, sizeof c->last_ntt_kernel, "ntt_%s_kernel<%u>", inverse ? "inv" : "fwd", logn);

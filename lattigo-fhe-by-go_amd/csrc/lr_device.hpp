@@ -39,6 +39,7 @@ struct Options {
     bool timeline = false;         // LR_NTT_TIMELINE: plain 2^15 launches (forward / inverse, integer variant 1 and dual variant 3) run the stamped diagnostics builds
     bool keymac_narrow = false;    // LR_KEYMAC_NARROW: one Montgomery product per term in the key inner product instead of the 128-bit sums
     bool no_invfuse = false;       // LR_NO_INVFUSE: N = 2^16 inverse transforms as lazy sub-blocks + the separate last-stage pass (ntt_top_kernel) instead of the pair-flag kernels
+    bool no_wide14_small = false;  // LR_ASM_14_NO_WIDE_SMALL: the 512-thread plan at N = 2^14 for small launches too
     bool no_invtop = false;        // LR_NO_INVTOP: the inverse transforms in front of a top-stage extension finish with their own last-stage pass
     bool no_ext_chunks = false;    // LR_NO_EXT_CHUNKS: a basis extension of a small batch as one launch over all target columns instead of column ranges on grid z
     bool no_pair = false;          // LR_NO_PAIR: ModDown's two components of a single ciphertext as two launches instead of one with distance strides
