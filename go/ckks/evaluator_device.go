@@ -257,6 +257,11 @@ func (eval *evaluator) switchKeysInPlace(level uint64, cx *ring.Poly, evakey *Sw
 func (eval *evaluator) permuteNTT(ct0 *Ciphertext, index []uint64, evakey *SwitchingKey, ctOut *Ciphertext) {
 	eval.resident(ct0.value[0], ct0.value[1], ctOut.value[0], ctOut.value[1])
 	level := utils.MinUint64(ct0.Level(), ctOut.Level())
+	if b := eval.batcher(); b != nil { // the rotations of the evaluators in flight together run as one batched rotation per (level, element, key)
+		b.PermuteNTT(eval.ckksContext.contextQ, level, [2]*ring.Poly{ct0.value[0], ct0.value[1]}, eval.galoisElement(index),
+			b.KeyImage(evakey.evakey), [2]*ring.Poly{ctOut.value[0], ctOut.value[1]})
+		return
+	}
 	eval.dev().plan.PermuteNTT(level, [2]*ring.Poly{ct0.value[0], ct0.value[1]}, eval.galoisElement(index), eval.keyImage(evakey),
 		[2]*ring.Poly{ctOut.value[0], ctOut.value[1]})
 }

@@ -243,6 +243,17 @@ func (b *CkksBatcher) MulRelin(callerQ *Context, level uint64, ct0, ct1 []*Poly,
 	done(ctOut...)
 }
 
+// PermuteNTT = evaluator.permuteNTT (ckks/evaluator.go:1448) through the batcher: calls with the same (level, galEl, key) in flight
+// together run as one batched rotation.
+func (b *CkksBatcher) PermuteNTT(callerQ *Context, level uint64, ct0 [2]*Poly, galEl uint64, rotkey *Poly, ctOut [2]*Poly) {
+	callerQ.use(ct0[0], ct0[1])
+	callerQ.want(ctOut[0], ctOut[1])
+	call(func() C.int {
+		return C.lr_ckks_batcher_rotate(b.h, C.int(level), ct0[0].d, ct0[1].d, C.uint64_t(galEl), rotkey.d, ctOut[0].d, ctOut[1].d)
+	})
+	done(ctOut[0], ctOut[1])
+}
+
 // Stats: launches so far, polys they carried, the largest batch.
 func (b *CkksBatcher) Stats() (batches, products uint64, largest int) {
 	var nb, np C.uint64_t

@@ -343,6 +343,11 @@ int lr_ckks_batcher_create(lr_ckks_plan *const *plans, int n_lanes, lr_ckks_batc
 void lr_ckks_batcher_destroy(lr_ckks_batcher *batcher);
 int lr_ckks_batcher_mulrelin(lr_ckks_batcher *batcher, int level, const lr_poly *ct0_c0, const lr_poly *ct0_c1,
                              const lr_poly *ct1_c0, const lr_poly *ct1_c1, const lr_poly *evk, lr_poly *out_c0, lr_poly *out_c1);
+/* The same for evaluator.permuteNTT (RotateColumns with the key of that rotation, Conjugate; ckks/evaluator.go:1448): calls with the
+ * same (level, Galois element, key image) in flight together run as one batched lr_ckks_rotate.  Same bits as lr_ckks_rotate; the
+ * outputs may be the inputs.  MulRelin and rotation requests never share a launch; they take the lanes in arrival order. */
+int lr_ckks_batcher_rotate(lr_ckks_batcher *batcher, int level, const lr_poly *ct_c0, const lr_poly *ct_c1, uint64_t galois_element,
+                           const lr_poly *rotkey, lr_poly *out_c0, lr_poly *out_c1);
 /* launches so far, polys they carried, the largest batch (any of the pointers may be NULL) */
 int lr_ckks_batcher_stats(lr_ckks_batcher *batcher, uint64_t *batches, uint64_t *products, int *largest);
 /* MulRelin with evakey == nil (ckks/evaluator.go:1038-1111): the degree-2 result (out_c0, out_c1, out_c2), no key switch.

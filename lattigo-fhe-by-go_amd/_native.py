@@ -95,6 +95,7 @@ SYMBOLS = {
     "lr_ckks_batcher_destroy": [vp],
     "lr_ckks_batcher_mulrelin": [vp, i32, vp, vp, vp, vp, vp, vp, vp],
     "lr_ckks_batcher_stats": [vp, vp, vp, vp],
+    "lr_ckks_batcher_rotate": [vp, i32, vp, vp, C.c_uint64, vp, vp, vp],
     "lr_ckks_rescale": [vp, vp, vp],
     "lr_ckks_mul_norelin": [vp, i32, vp, vp, vp, vp, vp, vp, vp],
     "lr_ckks_mul_plain": [vp, i32, vp, vp, vp, vp, vp],

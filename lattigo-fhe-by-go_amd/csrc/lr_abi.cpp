@@ -2552,8 +2552,9 @@ struct KeySwitchEpilogue {
 };
 
 int run_permute_ntt(lr_context *c, int limbs, int batch, const u64 *in, long long in_stride, u64 *out, long long out_stride,
-                    u64 gen) {
+                    u64 gen, const u64 *const *in_table = nullptr) {
     GaloisLaunch L;
+    L.in_table = in_table;
     L.in = in;
     L.out = out;
     L.in_stride = in_stride;
@@ -3081,6 +3082,8 @@ extern "C" int lr_ckks_mulrelin(lr_ckks_plan *pl, int level, const lr_poly *a0, 
 struct lr_ckks_batcher {
     struct Request {
         int level = 0, polys = 0;
+        int kind = 0;              // 0: MulRelin (a0, a1) x (b0, b1); 1: rotation / conjugation of (a0, a1) by `gen` with the key `evk`
+        u64 gen = 0;
         const lr_poly *a0 = nullptr, *a1 = nullptr, *b0 = nullptr, *b1 = nullptr, *evk = nullptr;
         lr_poly *o0 = nullptr, *o1 = nullptr;
         bool done = false;
@@ -3118,19 +3121,39 @@ int batcher_run(lr_ckks_batcher *B, lr_ckks_batcher::Lane &lane, const std::vect
     const int mb = B->max_batch;
     for (const auto *r : reqs)
         for (int i = 0; i < r->polys; ++i, ++batch) {
-            lane.h_table[4 * batch + 0] = r->a0->d + i * r->a0->stride();
-            lane.h_table[4 * batch + 1] = r->a1->d + i * r->a1->stride();
-            lane.h_table[4 * batch + 2] = r->b0->d + i * r->b0->stride();
-            lane.h_table[4 * batch + 3] = r->b1->d + i * r->b1->stride();
+            if (r->kind == 0) {
+                lane.h_table[4 * batch + 0] = r->a0->d + i * r->a0->stride();
+                lane.h_table[4 * batch + 1] = r->a1->d + i * r->a1->stride();
+                lane.h_table[4 * batch + 2] = r->b0->d + i * r->b0->stride();
+                lane.h_table[4 * batch + 3] = r->b1->d + i * r->b1->stride();
+            }
             lane.h_table[4 * mb + 2 * batch + 0] = r->o0->d + i * r->o0->stride();
             lane.h_table[4 * mb + 2 * batch + 1] = r->o1->d + i * r->o1->stride();
         }
     LR_TRY(lane.o0.ensure(cQ, (size_t)batch * s));
     LR_TRY(lane.o1.ensure(cQ, (size_t)batch * s));
+    if (reqs[0]->kind == 1) {
+        // rotations: table rows [0, batch) = the first components, [batch, 2 batch) = the second ones (lr_ckks_rotate, batched)
+        int k = 0;
+        for (const auto *r : reqs)
+            for (int i = 0; i < r->polys; ++i, ++k) {
+                lane.h_table[k] = r->a0->d + i * r->a0->stride();
+                lane.h_table[batch + k] = r->a1->d + i * r->a1->stride();
+            }
+        LR_HIP(hipMemcpyAsync(lane.d_table, lane.h_table, (size_t)6 * mb * sizeof(u64 *), hipMemcpyHostToDevice, cQ->stream));
+        LR_TRY(same_stream(pl->cQ, pl->cP));
+        for (Pool *p : {&pl->c0, &pl->c2x, &pl->q1, &pl->q2}) LR_TRY(p->ensure(cQ, (size_t)batch * s));
+        const u64 *const *tab = (const u64 *const *)lane.d_table;
+        LR_TRY(run_permute_ntt(cQ, L1, batch, nullptr, 0, pl->c0.d, s, reqs[0]->gen, tab));             // ckks/evaluator.go:1458
+        LR_TRY(run_permute_ntt(cQ, L1, batch, nullptr, 0, pl->c2x.d, s, reqs[0]->gen, tab + batch));    // :1459
+        KeySwitchEpilogue fin{lane.o0.d, lane.o1.d, s, pl->c0.d, nullptr, s};
+        LR_TRY(switch_keys_core(pl, level, batch, pl->c2x.d, s, reqs[0]->evk, pl->q1.d, s, pl->q2.d, s, &fin));   // :1464-1467
+    } else {
     LR_HIP(hipMemcpyAsync(lane.d_table, lane.h_table, (size_t)6 * mb * sizeof(u64 *), hipMemcpyHostToDevice, cQ->stream));
     TensorLaunch T{};
     T.table = (const u64 *const *)lane.d_table;
     LR_TRY(mulrelin_core(pl, level, batch, T, reqs[0]->evk, lane.o0.d, lane.o1.d, s));
+    }
     ScatterLaunch S{{lane.o0.d, lane.o1.d}, s, lane.d_table + 4 * mb, 2, n};
     LR_HIP(launch_scatter(S, L1, batch, cQ->stream));
     LR_HIP(hipStreamSynchronize(cQ->stream));
@@ -3207,14 +3230,23 @@ extern "C" int lr_ckks_batcher_stats(lr_ckks_batcher *B, uint64_t *batches, uint
     });
 }
 
-extern "C" int lr_ckks_batcher_mulrelin(lr_ckks_batcher *B, int level, const lr_poly *a0, const lr_poly *a1, const lr_poly *b0,
-                                        const lr_poly *b1, const lr_poly *evk, lr_poly *o0, lr_poly *o1) {
-    return guarded([&]() -> int {
-    if (!B || !a0 || !a1 || !b0 || !b1 || !evk || !o0 || !o1) return fail(LR_ERR_ARG, "null argument");
+namespace {
+
+// kind 0: MulRelin of (a0, a1) x (b0, b1); kind 1: rotation / conjugation of (a0, a1) by the Galois element `gen` (b0 = b1 = null)
+int batcher_submit(lr_ckks_batcher *B, int kind, int level, const lr_poly *a0, const lr_poly *a1, const lr_poly *b0, const lr_poly *b1,
+                   u64 gen, const lr_poly *evk, lr_poly *o0, lr_poly *o1) {
+    if (!B || !a0 || !a1 || (kind == 0 && (!b0 || !b1)) || !evk || !o0 || !o1) return fail(LR_ERR_ARG, "null argument");
     lr_ckks_plan *pl0 = B->lanes[0].plan;
     if (level < 0 || level + 1 > pl0->cQ->h.L()) return fail(LR_ERR_SHAPE, "level out of range");
     const int polys = a0->batch;
     if (polys < 1 || polys > B->max_batch) return fail(LR_ERR_SHAPE, "batch exceeds the batcher's max_batch");
+    if (kind == 0) {
+        b0 = b0 ? b0 : a0;
+        b1 = b1 ? b1 : a1;
+    } else {
+        b0 = a0;      // (checked twice below, never read)
+        b1 = a1;
+    }
     for (const lr_poly *p : {a0, a1, b0, b1, (const lr_poly *)o0, (const lr_poly *)o1}) {
         LR_TRY(check_ct(pl0, level, p, polys));
         if (p->device != pl0->device) return fail(LR_ERR_ARG, "poly lives on another device than the batcher");
@@ -3238,6 +3270,8 @@ extern "C" int lr_ckks_batcher_mulrelin(lr_ckks_batcher *B, int level, const lr_
         }
     }
     lr_ckks_batcher::Request req;
+    req.kind = kind;
+    req.gen = gen;
     req.level = level; req.polys = polys;
     req.a0 = a0; req.a1 = a1; req.b0 = b0; req.b1 = b1; req.evk = evk; req.o0 = o0; req.o1 = o1;
     std::unique_lock<std::mutex> lk(B->m);
@@ -3259,7 +3293,7 @@ extern "C" int lr_ckks_batcher_mulrelin(lr_ckks_batcher *B, int level, const lr_
         const lr_ckks_batcher::Request *head = B->queue.front();
         for (auto it = B->queue.begin(); it != B->queue.end();) {
             lr_ckks_batcher::Request *r = *it;
-            if (r->level == head->level && r->evk == head->evk && total + r->polys <= B->max_batch) {
+            if (r->kind == head->kind && r->gen == head->gen && r->level == head->level && r->evk == head->evk && total + r->polys <= B->max_batch) {
                 take.push_back(r);
                 total += r->polys;
                 it = B->queue.erase(it);
@@ -3291,6 +3325,24 @@ extern "C" int lr_ckks_batcher_mulrelin(lr_ckks_batcher *B, int level, const lr_
     lk.unlock();
     if (req.status != LR_OK) return fail(req.status, req.error);
     return LR_OK;
+}
+
+}  // namespace
+
+extern "C" int lr_ckks_batcher_mulrelin(lr_ckks_batcher *B, int level, const lr_poly *a0, const lr_poly *a1, const lr_poly *b0,
+                                        const lr_poly *b1, const lr_poly *evk, lr_poly *o0, lr_poly *o1) {
+    return guarded([&]() -> int {
+    if (!b0 || !b1) return fail(LR_ERR_ARG, "null argument");
+    return batcher_submit(B, 0, level, a0, a1, b0, b1, 0, evk, o0, o1);
+    });
+}
+
+extern "C" int lr_ckks_batcher_rotate(lr_ckks_batcher *B, int level, const lr_poly *c0, const lr_poly *c1, uint64_t gen, const lr_poly *rotkey,
+                                      lr_poly *o0, lr_poly *o1) {
+    return guarded([&]() -> int {
+    if (!B) return fail(LR_ERR_ARG, "null argument");
+    const u64 two_n = B->lanes[0].plan->cQ->h.N << 1;
+    return batcher_submit(B, 1, level, c0, c1, nullptr, nullptr, gen & (two_n - 1), rotkey, o0, o1);
     });
 }
 

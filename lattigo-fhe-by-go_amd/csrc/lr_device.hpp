@@ -243,6 +243,7 @@ struct GaloisLaunch {
     int ntt_domain;    // 1: PermuteNTT gather, 0: Context.Permute scatter with sign
     u64 gen;           // reduced modulo 2N
     const LimbParams *lp;
+    const u64 *const *in_table = nullptr;   // batcher form: batch poly b is read from in_table[b] (in / in_stride unused)
 };
 hipError_t launch_permute(const GaloisLaunch &L, int limbs, int batch, hipStream_t stream);
 // Context.MultByMonomial (ring/ring.go:663): out = in * X^shift in Z_q[X]/(X^N+1), shift already reduced modulo 2N;

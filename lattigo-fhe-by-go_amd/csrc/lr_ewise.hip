@@ -673,7 +673,7 @@ hipError_t launch_keymac(const KeyMacLaunch &L, int limbs, int batch, hipStream_
 __global__ __launch_bounds__(256) void permute_kernel(GaloisLaunch L) {
     const int limb = blockIdx.y;
     const long long b = blockIdx.z;
-    const u64 *pin = L.in + b * L.in_stride + (long long)limb * L.n;
+    const u64 *pin = (L.in_table ? L.in_table[b] : L.in + b * L.in_stride) + (long long)limb * L.n;
     u64 *pout = L.out + b * L.out_stride + (long long)limb * L.n;
     const u32 n = (u32)L.n, mask2 = 2 * n - 1;
     const int logn = L.logn;

@@ -663,6 +663,11 @@ class CkksBatcher:
         Call it from as many host threads as there are evaluators (ctypes releases the GIL for the call)."""
         check(lib().lr_ckks_batcher_mulrelin(self.h, level, ct0[0].h, ct0[1].h, ct1[0].h, ct1[1].h, evakey.h, ctOut[0].h, ctOut[1].h))
 
+    def PermuteNTT(self, level, ct0, gen, rotkey, ctOut):
+        """evaluator.permuteNTT (ckks/evaluator.go:1448) = RotateColumns with the key of that rotation / Conjugate; blocks until this
+        call's result is complete; calls with the same (level, gen, key) in flight together share a launch"""
+        check(lib().lr_ckks_batcher_rotate(self.h, level, ct0[0].h, ct0[1].h, C.c_uint64(int(gen)), rotkey.h, ctOut[0].h, ctOut[1].h))
+
     def Stats(self):
         b, p, l = C.c_uint64(), C.c_uint64(), C.c_int()
         check(lib().lr_ckks_batcher_stats(self.h, C.byref(b), C.byref(p), C.byref(l)))

@@ -114,3 +114,52 @@ def test_batcher_argument_errors(gpu_pkg):
     # still usable afterwards
     bat.MulRelin(3, (mk(1), mk(1)), (mk(1), mk(1)), key, (mk(1), mk(1)))
     assert bat.Stats()["products"] == 1
+
+
+@pytest.mark.parametrize("logn,nq,np_,level,threads", [(12, 6, 2, 5, 8), (15, 7, 3, 6, 6), (16, 6, 2, 5, 4)])
+def test_concurrent_rotations_and_products_through_one_batcher(gpu_pkg, oracle, logn, nq, np_, level, threads):
+    """lr_ckks_batcher_rotate: rotations of concurrent callers share a launch per (level, Galois element, key); MulRelin requests of other
+    callers go through the same lanes in between.  Every caller gets the rotation / product of its own ciphertext; two Galois elements
+    (a rotation and the conjugation), in place for half of the callers."""
+    N, Q, P, bat, key, oplan, evk = _setup(gpu_pkg, oracle, logn, nq, np_, 8, 2)
+    ring = gpu_pkg.ring
+    rot_h = gpu_pkg.sampling.uniform_poly(Q + P, N, evk.shape[0] * 2, seed=123)
+    rotkey = bat.NewSwitchingKey().set(rot_h)
+    rot_evk = rot_h.reshape(evk.shape[0], 2, nq + np_, N)
+    gens = (pow(5, 3, 2 * N), 2 * N - 1)
+    errors, results = [], {}
+
+    def evaluator(t):
+        try:
+            cq = ring.NewContextWithParams(N, Q)
+            mk = lambda s: gpu_pkg.sampling.uniform_poly(Q[:level + 1], N, 1, seed=s).reshape(1, level + 1, N)
+            for r in range(2):
+                a0, a1 = mk(500 * t + 10 * r), mk(500 * t + 10 * r + 1)
+                ct = (cq.NewPolyLvl(level, 1).set(a0), cq.NewPolyLvl(level, 1).set(a1))
+                if t % 3 == 2:
+                    b0, b1 = mk(500 * t + 10 * r + 2), mk(500 * t + 10 * r + 3)
+                    out = (cq.NewPolyLvl(level, 1), cq.NewPolyLvl(level, 1))
+                    bat.MulRelin(level, ct, (cq.NewPolyLvl(level, 1).set(b0), cq.NewPolyLvl(level, 1).set(b1)), key, out)
+                    want = ("mul", a0, a1, b0, b1)
+                else:
+                    gen = gens[(t + r) % 2]
+                    out = ct if t % 2 == 0 else (cq.NewPolyLvl(level, 1), cq.NewPolyLvl(level, 1))
+                    bat.PermuteNTT(level, ct, gen, rotkey, out)
+                    want = ("rot", a0, a1, gen)
+                results[(t, r)] = (want, out[0].get().reshape(level + 1, N), out[1].get().reshape(level + 1, N))
+        except Exception as e:  # noqa: BLE001
+            errors.append((t, repr(e)))
+
+    ths = [threading.Thread(target=evaluator, args=(t,)) for t in range(threads)]
+    for th in ths:
+        th.start()
+    for th in ths:
+        th.join()
+    assert not errors, errors
+    assert len(results) == 2 * threads
+    for k, (what, g0, g1) in results.items():                          # (the oracle's plan is a single-threaded object: expectations here)
+        if what[0] == "mul":
+            want = oplan.mulrelin(level, np.stack([what[1][0], what[2][0]]), np.stack([what[3][0], what[4][0]]), evk)
+        else:
+            want = oplan.permute_ntt(level, np.stack([what[1][0], what[2][0]]), what[3], rot_evk)
+        assert np.array_equal(g0, want[0]) and np.array_equal(g1, want[1]), (k, what[0])
