@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <random>
+#include <string>
 #include <thread>
 #include <vector>
 
@@ -87,8 +88,13 @@ int main(int argc, char **argv) {
         CK(lr_poly_alloc(c.cq, nq, 1, &c.o0));
         CK(lr_poly_alloc(c.cq, nq, 1, &c.o1));
     }
+    // OP=rotate: RotateColumns by 3 (Galois element 5^3) instead of MulRelin, the "key" standing in for the rotation key
+    const bool rotate = std::getenv("OP") && std::string(std::getenv("OP")) == "rotate";
+    const uint64_t gal = 125 % (2 * N);
     // the answer, from the plain entry point
     std::vector<uint64_t> want0((size_t)nq * N), want1((size_t)nq * N), got((size_t)nq * N);
+    if (rotate) CK(lr_ckks_rotate(cs[0].plan, level, cs[0].a0, cs[0].a1, gal, cs[0].key, cs[0].o0, cs[0].o1));
+    else
     CK(lr_ckks_mulrelin(cs[0].plan, level, cs[0].a0, cs[0].a1, cs[0].b0, cs[0].b1, cs[0].key, cs[0].o0, cs[0].o1));
     CK(lr_poly_download_dense(cs[0].o0, want0.data(), want0.size()));
     CK(lr_poly_download_dense(cs[0].o1, want1.data(), want1.size()));
@@ -111,7 +117,8 @@ int main(int argc, char **argv) {
             CK(lr_poly_zero(c.o1));
             CK(lr_context_sync(c.cq));
         }
-        if (how == 1) CK(lr_ckks_batcher_mulrelin(bat, level, cs[0].a0, cs[0].a1, cs[0].b0, cs[0].b1, bkey, cs[0].o0, cs[0].o1));   // warm-up: pools
+        if (how == 1 && rotate) CK(lr_ckks_batcher_rotate(bat, level, cs[0].a0, cs[0].a1, gal, bkey, cs[0].o0, cs[0].o1));
+        else if (how == 1) CK(lr_ckks_batcher_mulrelin(bat, level, cs[0].a0, cs[0].a1, cs[0].b0, cs[0].b1, bkey, cs[0].o0, cs[0].o1));   // warm-up: pools
         std::atomic<int> ready{0};
         std::atomic<bool> go{false};
         std::vector<std::thread> ths;
@@ -121,7 +128,11 @@ int main(int argc, char **argv) {
                 ready.fetch_add(1);
                 while (!go.load()) std::this_thread::yield();
                 for (int i = 0; i < iters; ++i) {
-                    if (how == 0)
+                    if (rotate && how == 0)
+                        CK(lr_ckks_rotate(c.plan, level, c.a0, c.a1, gal, c.key, c.o0, c.o1));
+                    else if (rotate)
+                        CK(lr_ckks_batcher_rotate(bat, level, c.a0, c.a1, gal, bkey, c.o0, c.o1));
+                    else if (how == 0)
                         CK(lr_ckks_mulrelin(c.plan, level, c.a0, c.a1, c.b0, c.b1, c.key, c.o0, c.o1));
                     else
                         CK(lr_ckks_batcher_mulrelin(bat, level, c.a0, c.a1, c.b0, c.b1, bkey, c.o0, c.o1));
@@ -143,7 +154,7 @@ int main(int argc, char **argv) {
         uint64_t nb = 0, npd = 0;
         int largest = 0;
         CK(lr_ckks_batcher_stats(bat, &nb, &npd, &largest));
-        std::printf("{\"how\": \"%s\", \"threads\": %d, \"calls_per_thread\": %d, \"mulrelin_per_s\": %.1f, \"same_bits_as_lr_ckks_mulrelin\": %s",
+        std::printf("{\"how\": \"%s\", \"threads\": %d, \"calls_per_thread\": %d, \"calls_per_s\": %.1f, \"same_bits_as_the_plain_entry_point\": %s",
                     how == 0 ? "direct" : "batcher", T, iters, (double)T * iters / dt, ok ? "true" : "false");
         if (how == 1) std::printf(", \"lanes\": %d, \"launches\": %llu, \"mean_batch\": %.2f, \"largest_batch\": %d", lanes, (unsigned long long)nb, (double)npd / (double)nb, largest);
         std::printf("}\n");
