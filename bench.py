@@ -1027,7 +1027,7 @@ def main():
             ok_t = all(np.array_equal(w[7][0].get().reshape(tnq, tN), want_t[0]) and np.array_equal(w[7][1].get().reshape(tnq, tN), want_t[1]) for w in workers)
             rows.append({"threads": T, "streams": T, "batch_per_call": 1, "calls_per_thread": iters, "mulrelin_per_s": T * iters / dt_w,
                          "us_per_product_per_thread": dt_w / iters * 1e6, "bit_exact": bool(ok_t),
-                         # a lone plan runs the key switch's independent small launches side by side (lr_ckks_plan_stats); several plans do not
+                         # (lr_ckks_plan_stats; forks are for a lone plan at N = 2^16 only: 0 at this parameter set)
                          "forks_per_call": workers[0][3].Stats()["forks"] / (iters + 1)})
             del workers, ths
         # the same callers through the batcher (lr_ckks_batcher_*): concurrent batch-1 calls are merged into batched launches on two lanes
