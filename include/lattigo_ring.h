@@ -333,7 +333,9 @@ int lr_ckks_mulrelin(lr_ckks_plan *plan, int level, const lr_poly *ct0_c0, const
  * waits for it and wakes the others.  The call returns when its own result is complete on the device (it may be used on any
  * stream afterwards); operands are synchronised with the streams of the contexts they were created on before they are queued.
  * plans[i]: one plan per lane, each over its OWN pair of contexts, same moduli, device and max_batch; the batcher creates one
- * stream per lane and sets it on the lane's contexts (lr_context_set_stream; destroy puts the library's stream back).  Two lanes
+ * stream per lane and sets it on the lane's contexts (lr_context_set_stream; destroy puts the library's stream back).  The lanes'
+ * streams are created in different priority classes (lane 0 the device's greatest priority, lane 1 its least, lane 2 the default,
+ * ...): the runtime binds a stream to a hardware queue of its class, and two lanes on one queue would run one after the other.  Two lanes
  * let the next batch's launches overlap the running one.  The plans and contexts stay owned by the caller and must outlive the
  * batcher; while it exists they are not used for anything else.  evk must be the SAME key image handle in the calls that are to
  * share a batch (the relinearisation key is shared by the evaluators of one party, ckks/evaluator.go:1016).
