@@ -2760,10 +2760,30 @@ int ks_accumulate(lr_ckks_plan *pl, int level, int batch, const u64 *digQ, const
         // the extension reads x where it stores, ExtSegment::epi_mode 1)
         if (fin) return fail(LR_ERR_ARG, "coefficient-domain key switch: no epilogue");
         Rows q0r{p0, p0_stride, 0, 1}, q1r{p1, p1_stride, 0, 1}, pr{pool2P, sP, 0, 1};
-        LR_TRY(run_ntt(cQ, true, q0r, q0r, 0, 1, level + 1, batch));
-        LR_TRY(run_ntt(cQ, true, q1r, q1r, 0, 1, level + 1, batch));
+        // the two accumulators as ONE batch where base + p * stride reaches both: laid out back to back (the relinearisation's pool), or
+        // one poly each at any distance (see lr_ckks_rescale)
+        auto words = [](const u64 *a, const u64 *b) { return (long long)(((intptr_t)b - (intptr_t)a) / (intptr_t)sizeof(u64)); };
+        const bool back_to_back = p0_stride == p1_stride && p1 == p0 + (long long)batch * p0_stride;
+        const bool one_each = batch == 1 && p0 != p1;
+        const bool pair = !pl->opt.no_pair && (back_to_back || one_each);
+        const long long pair_stride = back_to_back ? p0_stride : words(p0, p1);
+        if (pair) {
+            Rows qr{p0, pair_stride, 0, 1};
+            LR_TRY(run_ntt(cQ, true, qr, qr, 0, 1, level + 1, 2 * batch));
+        } else {
+            LR_TRY(run_ntt(cQ, true, q0r, q0r, 0, 1, level + 1, batch));
+            LR_TRY(run_ntt(cQ, true, q1r, q1r, 0, 1, level + 1, batch));
+        }
         LR_TRY(run_ntt(cP, true, pr, pr, 0, 1, nP, 2 * batch));
         const bool fused = !cQ->opt.no_epilogue && ext_epilogue_supported(bx->pq.tables(), nP, n);
+        if (pair && fused) {
+            ExtSegment sd = segment(p0, pair_stride, 0, 0, level + 1);
+            sd.epi_mode = 1;
+            sd.epi_x = p0;
+            sd.epi_x_stride = pair_stride;
+            sd.epi_c = bx->d_moddown_pq;
+            return run_ext(cQ, bx->pq, nP, pr, 2 * batch, sd, segment(nullptr, 0, 0, 0, 0));      // (pool2P / pool3P lie back to back)
+        }
         for (int k = 0; k < 2; ++k) {
             u64 *pq = k == 0 ? p0 : p1;
             const long long pqs = k == 0 ? p0_stride : p1_stride;
@@ -2954,6 +2974,11 @@ extern "C" int lr_bfv_relinearize(lr_ckks_plan *pl, const lr_poly *c0, const lr_
     LR_TRY(pl->bfvP.ensure(cQ, (size_t)2 * batch * sQ));        // keyswitchpool[2], [3] (:489-490)
     u64 *p0 = pl->bfvP.d, *p1 = pl->bfvP.d + (long long)batch * sQ;
     LR_TRY(bfv_switch_keys_core(pl, batch, c2->d, c2->stride(), evk, p0, sQ, p1, sQ));
+    if (batch == 1 && !pl->opt.no_pair && c0->d != c1->d && out0->d != out1->d && out0->d != c1->d && out1->d != c0->d) {
+        // one ciphertext: the two additions as one launch over two "polys" at the distances between the components
+        auto words = [](const u64 *a, const u64 *b) { return (long long)(((intptr_t)b - (intptr_t)a) / (intptr_t)sizeof(u64)); };
+        return run_ewise(cQ, LR_ADD, level + 1, 2, c0->d, words(c0->d, c1->d), p0, sQ, out0->d, words(out0->d, out1->d), nullptr);   // :494-495
+    }
     LR_TRY(run_ewise(cQ, LR_ADD, level + 1, batch, c0->d, c0->stride(), p0, sQ, out0->d, out0->stride(), nullptr));   // :494
     return run_ewise(cQ, LR_ADD, level + 1, batch, c1->d, c1->stride(), p1, sQ, out1->d, out1->stride(), nullptr);    // :495
     });

@@ -641,3 +641,44 @@ def test_small_batch_extensions_in_column_ranges(gpu_pkg, oracle, logn, nq, np_,
             assert np.array_equal(out[0].get().reshape(batch, level + 1, N)[b], w0), (env, b)
             assert np.array_equal(out[1].get().reshape(batch, level + 1, N)[b], w1), (env, b)
         del plan, pevk, out
+
+
+@pytest.mark.parametrize("name,logn", [("PN13QP218", 11), ("PN14QP438", 14), ("PN15QP880", 15)])
+def test_bfv_relinearize_of_a_single_ciphertext(gpu_pkg, oracle, name, logn, monkeypatch):
+    """one degree-2 ciphertext: the coefficient-domain tail runs its two accumulators as one batch (inverse transforms, ModDown's extension
+    in place) and the two additions go out as one launch; LR_NO_PAIR keeps them apart; switchKeys alone with user polys at any distance;
+    in place; against the oracle"""
+    _, Q, P, _ = gpu_pkg.params.bfv_moduli(name)
+    N = 1 << logn
+    ring = gpu_pkg.ring
+    nq, np_ = len(Q), len(P)
+    beta = -(-nq // np_)
+    evk = gpu_pkg.sampling.uniform_poly(Q + P, N, 2 * beta, seed=41)
+    ct = [gpu_pkg.sampling.uniform_poly(Q, N, 1, seed=60 + k).reshape(1, nq, N) for k in range(3)]
+    oplan = oracle.CkksPlan(oracle.Context(N, Q), oracle.Context(N, P))
+    want = oplan.bfv_relinearize(np.stack([ct[0][0], ct[1][0], ct[2][0]]), evk.reshape(beta, 2, nq + np_, N))
+    w0, w1 = oplan.bfv_switch_keys(ct[2][0], evk.reshape(beta, 2, nq + np_, N))
+    for env, swap in (({}, False), ({}, True), ({"LR_NO_PAIR": "1"}, False), ({"LR_NO_EPILOGUE": "1"}, False)):
+        for k in ("LR_NO_PAIR", "LR_NO_EPILOGUE"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        cQ, cP = ring.NewContextWithParams(N, Q), ring.NewContextWithParams(N, P)
+        plan = ring.CkksPlan(cQ, cP, 1)
+        pevk = plan.NewSwitchingKey().set(evk)
+        c = [cQ.NewPoly(1).set(x) for x in ct]
+        out = (cQ.NewPoly(1), cQ.NewPoly(1))
+        if swap:
+            out = out[::-1]
+        plan.BfvRelinearize(c, pevk, out)
+        for k in range(2):
+            assert np.array_equal(out[k].get().reshape(nq, N), want[k]), (env, swap, k)
+        p = (cQ.NewPoly(1), cQ.NewPoly(1))
+        if swap:
+            p = p[::-1]
+        plan.BfvSwitchKeys(c[2], pevk, p[0], p[1])
+        assert np.array_equal(p[0].get().reshape(nq, N), w0) and np.array_equal(p[1].get().reshape(nq, N), w1), (env, swap)
+        plan.BfvRelinearize(c, pevk, (c[0], c[1]))
+        for k in range(2):
+            assert np.array_equal(c[k].get().reshape(nq, N), want[k]), (env, swap, "in place", k)
+        del plan, pevk
