@@ -370,7 +370,21 @@ __global__ __launch_bounds__(256) void ext_sum_group_kernel(ExtGroupLaunch G) {
 
 // G = terms per Montgomery reduction (G * max q_i < 2^64); NIN > G: the partial residues (each below p_j) are added up.
 template <int NIN, int W, int G>
+__device__ __forceinline__ void ext_wide_body(const ExtLaunch &L);
+
+template <int NIN, int W, int G>
 __global__ __launch_bounds__(256) void ext_wide_kernel(ExtLaunch L) {
+    ext_wide_body<NIN, W, G>(L);
+}
+
+// grouped form (grid z = record), as ext_sum_group_kernel: the column ranges of a small launch
+template <int NIN, int W, int G>
+__global__ __launch_bounds__(256) void ext_wide_group_kernel(ExtGroupLaunch Gr) {
+    ext_wide_body<NIN, W, G>(Gr.L[blockIdx.z]);
+}
+
+template <int NIN, int W, int G>
+__device__ __forceinline__ void ext_wide_body(const ExtLaunch &L) {
     const int xw = blockIdx.x * 256 + threadIdx.x;
     if (W * xw >= L.n) return;
     const long long b = blockIdx.y;
@@ -575,12 +589,16 @@ static hipError_t launch_group_n(const ExtLaunch *Ls, int count, int batch, hipS
     } else {
         const ExtLaunch &L0 = Ls[0];
         const bool top = L0.seg[0].top_tw != nullptr;
+        bool sum_form = true, wide_form = !top;     // (launch_n's order of preference: sum-form, per-term Shoup, 128-bit sums over all terms)
         for (int k = 0; k < count; ++k) {
             const ExtLaunch &L = Ls[k];
-            if ((L.n & 1) != 0 || L.n != L0.n || L.t.exact_terms < 4 || !L.t.fast_div_ok || (L.seg[0].top_tw != nullptr) != top ||
-                !(L.t.lazy_terms >= (NIN < 2 ? 2 : NIN) && L.t.word_barrett))
+            if ((L.n & 1) != 0 || L.n != L0.n || L.t.exact_terms < 4 || !L.t.fast_div_ok || (L.seg[0].top_tw != nullptr) != top)
                 return hipErrorNotSupported;
+            const bool sum_ok = L.t.lazy_terms >= (NIN < 2 ? 2 : NIN) && L.t.word_barrett;
+            sum_form = sum_form && sum_ok;
+            wide_form = wide_form && !sum_ok && !(L.t.lazy_terms >= NIN) && L.t.wide_ok >= NIN && !L.inv_top;
         }
+        if (!sum_form && !wide_form) return hipErrorNotSupported;
         ExtGroupLaunch G;
         for (int k = 0; k < count; ++k) G.L[k] = Ls[k];
         for (int k = count; k < kExtGroupMax; ++k) G.L[k] = Ls[0];
@@ -593,7 +611,8 @@ static hipError_t launch_group_n(const ExtLaunch *Ls, int count, int batch, hipS
         } else {
             constexpr int W = 2;
             const dim3 grid((unsigned)((L0.n / W + 255) / 256), (unsigned)batch, (unsigned)count);
-            hipLaunchKernelGGL((ext_sum_group_kernel<NIN, W, false>), grid, block, 0, stream, G);
+            if (sum_form) hipLaunchKernelGGL((ext_sum_group_kernel<NIN, W, false>), grid, block, 0, stream, G);
+            else hipLaunchKernelGGL((ext_wide_group_kernel<NIN, W, NIN>), grid, block, 0, stream, G);
         }
         return hipGetLastError();
     }

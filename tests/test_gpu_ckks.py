@@ -112,8 +112,9 @@ def test_bfv_mul_small_batch_and_per_operand_paths(gpu_pkg, oracle, name, logn, 
         mk = lambda s: gpu_pkg.sampling.uniform_poly(Q, N, batch, seed=s).reshape(batch, len(Q), N)
         a0, a1, b0, b1 = mk(21), mk(22), mk(23), mk(24)
         wants = [oplan.mul(np.stack([a0[b], a1[b]]), np.stack([b0[b], b1[b]])) for b in range(batch)]
-        for env in ({}, {"LR_BFV_NO_GATHER": "1"}, {"LR_BFV_NO_EXT_EPILOGUE": "1"}):
-            for k in ("LR_BFV_NO_GATHER", "LR_BFV_NO_EXT_EPILOGUE"):
+        # (LR_NO_EXT_CHUNKS: the extensions as one launch over all target columns instead of column ranges on grid z)
+        for env in ({}, {"LR_BFV_NO_GATHER": "1"}, {"LR_BFV_NO_EXT_EPILOGUE": "1"}, {"LR_NO_EXT_CHUNKS": "1"}, {"LR_BFV_NO_GATHER": "1", "LR_NO_EXT_CHUNKS": "1"}):
+            for k in ("LR_BFV_NO_GATHER", "LR_BFV_NO_EXT_EPILOGUE", "LR_NO_EXT_CHUNKS"):
                 monkeypatch.delenv(k, raising=False)
             for k, v in env.items():
                 monkeypatch.setenv(k, v)
