@@ -683,3 +683,40 @@ def test_bfv_relinearize_of_a_single_ciphertext(gpu_pkg, oracle, name, logn, mon
         for k in range(2):
             assert np.array_equal(c[k].get().reshape(nq, N), want[k]), (env, swap, "in place", k)
         del plan, pevk
+
+
+@pytest.mark.parametrize("name", ["PN12QP109", "PN13QP218", "PN14QP438", "PN15QP880", "PN16QP1761"])
+def test_one_ciphertext_on_every_default_parameter_set(gpu_pkg, oracle, name):
+    """ckks.DefaultParams at full size, ONE ciphertext per call -- the reference's calling shape, which takes the small-batch paths (grouped
+    and column-chunked extensions, sub-block transforms, lazy inverse outputs, the two components in one launch): MulRelin at the top
+    level and two levels down (a partial last digit where the set has one), Rescale, RotateColumns and Conjugate, each against the oracle"""
+    N, Q, P = gpu_pkg.params.ckks_moduli(name)
+    Q, P = list(Q), list(P)
+    nq, np_ = len(Q), len(P)
+    ring = gpu_pkg.ring
+    cQ, cP = ring.NewContextWithParams(N, Q), ring.NewContextWithParams(N, P)
+    plan = ring.CkksPlan(cQ, cP, 1)
+    oplan = oracle.CkksPlan(oracle.Context(N, Q), oracle.Context(N, P))
+    beta = -(-nq // np_)
+    evk = gpu_pkg.sampling.uniform_poly(Q + P, N, 2 * beta, seed=77)
+    pevk = plan.NewSwitchingKey().set(evk)
+    evk = evk.reshape(beta, 2, nq + np_, N)
+    for level in sorted({nq - 1, max(1, nq - 3)}, reverse=True):
+        mk = lambda s: gpu_pkg.sampling.uniform_poly(Q[:level + 1], N, 1, seed=s).reshape(1, level + 1, N)
+        ops = [mk(81), mk(82), mk(83), mk(84)]
+        P_ = lambda x: cQ.NewPolyLvl(level, 1).set(x)
+        out = (cQ.NewPolyLvl(level, 1), cQ.NewPolyLvl(level, 1))
+        plan.MulRelin(level, (P_(ops[0]), P_(ops[1])), (P_(ops[2]), P_(ops[3])), pevk, out)
+        want = oplan.mulrelin(level, np.stack([ops[0][0], ops[1][0]]), np.stack([ops[2][0], ops[3][0]]), evk)
+        for k in range(2):
+            assert np.array_equal(out[k].get().reshape(level + 1, N), want[k]), (name, level, "mulrelin", k)
+        for gen in (pow(5, 1, 2 * N), 2 * N - 1):
+            rot = (cQ.NewPolyLvl(level, 1), cQ.NewPolyLvl(level, 1))
+            plan.PermuteNTT(level, (P_(ops[0]), P_(ops[1])), gen, pevk, rot)
+            wr = oplan.permute_ntt(level, np.stack([ops[0][0], ops[1][0]]), gen, evk)
+            for k in range(2):
+                assert np.array_equal(rot[k].get().reshape(level + 1, N), wr[k]), (name, level, "rotate", gen, k)
+        plan.Rescale(out)
+        oc = oracle.Context(N, Q[:level + 1])
+        for k in range(2):
+            assert np.array_equal(out[k].get().reshape(level, N), oc.rescale_op("oc_div_round_by_last_modulus_ntt", want[k])), (name, level, "rescale", k)
