@@ -2738,7 +2738,7 @@ int ks_accumulate(lr_ckks_plan *pl, int level, int batch, const u64 *digQ, const
         K.own = own;
         K.own_stride = own_stride;
         K.alpha = own ? alpha : 0;
-        LR_HIP(launch_keymac(K, level + 1, batch, cQ->stream));
+        const KeyMacLaunch KQ = K;
         K.c2 = digP;
         K.c2_digit_stride = dP;
         K.c2_poly_stride = sP;
@@ -2752,7 +2752,15 @@ int ks_accumulate(lr_ckks_plan *pl, int level, int batch, const u64 *digQ, const
         K.own = nullptr;
         K.own_stride = 0;
         K.alpha = 0;
-        LR_HIP(launch_keymac(K, nP, batch, cQ->stream));
+        // a small batch: the Q part and the P part as one launch (they share nothing and each is a few hundred workgroups)
+        hipError_t pe = hipErrorNotSupported;
+        if (!pl->opt.no_pair && (long long)batch * (level + 1) <= 256) pe = launch_keymac_pair(KQ, level + 1, K, nP, batch, cQ->stream);
+        if (pe == hipErrorNotSupported) {
+            LR_HIP(launch_keymac(KQ, level + 1, batch, cQ->stream));
+            LR_HIP(launch_keymac(K, nP, batch, cQ->stream));
+        } else if (pe != hipSuccess) {
+            return fail(LR_ERR_HIP, std::string("launch_keymac_pair: ") + hipGetErrorString(pe));
+        }
     }
     lr_bext *bx = pl->bext;
     if (coeff_out) {

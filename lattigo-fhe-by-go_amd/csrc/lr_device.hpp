@@ -230,6 +230,13 @@ struct KeyMacLaunch {
     int wide;                      // 1: exact 128-bit sums + one Montgomery reduction per output (needs beta * max q < 2^64, q < 2^61)
 };
 hipError_t launch_keymac(const KeyMacLaunch &L, int limbs, int batch, hipStream_t stream);
+// the Q part and the P part of one inner product as ONE launch (grid y = limbs_a + limbs_b; both wide, same beta): two launches of a
+// small batch run one after the other although they share nothing; hipErrorNotSupported: launch them separately
+struct KeyMacPair {
+    KeyMacLaunch a, b;
+    int split;                     // grid y < split: a with limb y; otherwise b with limb y - split
+};
+hipError_t launch_keymac_pair(const KeyMacLaunch &A, int limbs_a, const KeyMacLaunch &B, int limbs_b, int batch, hipStream_t stream);
 
 // Poly.MarshalBinary payload (ring/ring_object.go:146-156,197-207): big-endian words <-> device rows
 hipError_t launch_bswap(const u64 *in, u64 *out, size_t words, hipStream_t stream);

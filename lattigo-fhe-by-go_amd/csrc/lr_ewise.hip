@@ -569,8 +569,21 @@ __device__ __forceinline__ ulonglong2 own_operand(ulonglong2 c, const LimbParams
 }
 
 template <int BETA>
+__device__ __forceinline__ void keymac_wide_body(const KeyMacLaunch &L, int limb);
+
+template <int BETA>
 __global__ __launch_bounds__(256) void keymac_wide_kernel(KeyMacLaunch L) {
-    const int limb = blockIdx.y;
+    keymac_wide_body<BETA>(L, (int)blockIdx.y);
+}
+
+template <int BETA>
+__global__ __launch_bounds__(256) void keymac_wide_pair_kernel(KeyMacPair P) {
+    if ((int)blockIdx.y < P.split) keymac_wide_body<BETA>(P.a, (int)blockIdx.y);
+    else keymac_wide_body<BETA>(P.b, (int)blockIdx.y - P.split);
+}
+
+template <int BETA>
+__device__ __forceinline__ void keymac_wide_body(const KeyMacLaunch &L, int limb) {
     const long long b = L.tile8 ? (long long)(blockIdx.x >> 3) : (long long)blockIdx.x;
     const int chunk = L.tile8 ? (int)(blockIdx.z * 8 + (blockIdx.x & 7)) : (int)blockIdx.z;
     const int chunks = L.tile8 ? (int)gridDim.z * 8 : (int)gridDim.z;
@@ -663,6 +676,28 @@ hipError_t launch_keymac(const KeyMacLaunch &L, int limbs, int batch, hipStream_
         LR_KM(1) LR_KM(2) LR_KM(3) LR_KM(4) LR_KM(5) LR_KM(6) LR_KM(7) LR_KM(8) LR_KM(9) LR_KM(10)
 #undef LR_KM
     default: hipLaunchKernelGGL(keymac_kernel<0>, grid, block, 0, stream, K); break;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_keymac_pair(const KeyMacLaunch &A, int limbs_a, const KeyMacLaunch &B, int limbs_b, int batch, hipStream_t stream) {
+    if (limbs_a <= 0 || limbs_b <= 0 || batch <= 0) return hipErrorNotSupported;
+    if (!A.wide || !B.wide || A.beta != B.beta || A.n != B.n || A.beta < 1 || A.beta > 10) return hipErrorNotSupported;
+    int gx = ((A.n >> 1) + 255) / 256;
+    if (gx > 64) gx = 64;
+    KeyMacPair P;
+    P.a = A;
+    P.b = B;
+    P.split = limbs_a;
+    P.a.tile8 = P.b.tile8 = (gx % 8 == 0 && (long long)batch * 8 < (1ll << 31)) ? 1 : 0;
+    const dim3 grid(P.a.tile8 ? (unsigned)batch * 8u : (unsigned)batch, (unsigned)(limbs_a + limbs_b), P.a.tile8 ? (unsigned)gx / 8u : (unsigned)gx), block(256);
+    (void)hipGetLastError();
+    switch (A.beta) {
+#define LR_KMP(B_) \
+    case B_: hipLaunchKernelGGL(keymac_wide_pair_kernel<B_>, grid, block, 0, stream, P); break;
+        LR_KMP(1) LR_KMP(2) LR_KMP(3) LR_KMP(4) LR_KMP(5) LR_KMP(6) LR_KMP(7) LR_KMP(8) LR_KMP(9) LR_KMP(10)
+#undef LR_KMP
+    default: return hipErrorNotSupported;
     }
     return hipGetLastError();
 }
