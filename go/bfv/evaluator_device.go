@@ -13,8 +13,10 @@
 //	delete  relinearize  :480-501   -> below: degree 2 is ONE call, CkksPlan.BfvRelinearize (key switch + the two Adds); higher degrees
 //	                                   keep upstream's loop over switchKeys
 //	delete  switchKeys   :736-812   -> below: CkksPlan.BfvSwitchKeys (the per-modulus loops over Coeffs at :776-792 live inside the pipeline)
-//	keep    Relinearize :512, SwitchKeys :539, the rotations :560-730 (they call relinearize / switchKeys / Context.Permute), Add / Sub /
-//	        Neg / MulScalar (Context methods)
+//	delete  permute      :711-735   -> below: ONE call, CkksPlan.BfvPermute (Context.Permute x2, the key switch, Add, Copy); RotateRows,
+//	                                   RotateColumns and rotateColumnsPow2 (:579-681, kept) reach the device through it
+//	keep    Relinearize :512, SwitchKeys :539, the rotation front ends :560-709, InnerSum :683, Add / Sub / Neg / MulScalar (Context
+//	        methods)
 package bfv
 
 import (
@@ -110,4 +112,11 @@ func (evaluator *evaluator) relinearize(ct0 *Ciphertext, evakey *EvaluationKey, 
 		context.Add(ctOut.value[1], p1, ctOut.value[1])
 	}
 	ctOut.SetValue(ctOut.value[:2])
+}
+
+// permute (:711): the Galois automorphism on both components, the key switch of the second, Add and Copy, as one call.
+func (evaluator *evaluator) permute(ct0 *Ciphertext, generator uint64, switchKey *SwitchingKey, ctOut *Ciphertext) {
+	evaluator.resident(ct0.value[0], ct0.value[1], ctOut.value[0], ctOut.value[1])
+	evaluator.dev().ks.BfvPermute([2]*ring.Poly{ct0.value[0], ct0.value[1]}, generator, evaluator.keyImage(switchKey),
+		[2]*ring.Poly{ctOut.value[0], ctOut.value[1]})
 }

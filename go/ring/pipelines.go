@@ -183,6 +183,17 @@ func (p *CkksPlan) BfvRelinearize(ct [3]*Poly, evakey *Poly, ctOut [2]*Poly) {
 	done(ctOut[0], ctOut[1])
 }
 
+// BfvPermute = bfv evaluator.permute (bfv/evaluator.go:711-735): Context.Permute of both components by the Galois element, switchKeys
+// of the second with the rotation's key, Add + Copy -- the body of RotateRows (:670) and RotateColumns (:579); ctOut may be ct0.
+func (p *CkksPlan) BfvPermute(ct0 [2]*Poly, generator uint64, switchKey *Poly, ctOut [2]*Poly) {
+	p.contextQ.use(ct0[0], ct0[1])
+	p.contextQ.want(ctOut[0], ctOut[1])
+	call(func() C.int {
+		return C.lr_bfv_rotate(p.h, ct0[0].d, ct0[1].d, C.uint64_t(generator), switchKey.d, ctOut[0].d, ctOut[1].d)
+	})
+	done(ctOut[0], ctOut[1])
+}
+
 // CkksBatcher merges the MulRelin calls of the evaluators of many goroutines -- upstream's concurrency model is one evaluator per
 // goroutine, one ciphertext per call (examples/dbfv/psi/psi.go:215-233) -- into batched device launches (lr_ckks_batcher_* in
 // lattigo_ring.h).  One batcher per parameter set, shared by the evaluators; each lane is a plan over its own pair of contexts.

@@ -320,6 +320,12 @@ int lr_bfv_switch_keys(lr_ckks_plan *plan, const lr_poly *cx, const lr_poly *evk
  * (p0, p1) = switchKeys(c2, evakey.evakey[0]); every poly over Q, coefficient domain; out0 / out1 may be c0 / c1. */
 int lr_bfv_relinearize(lr_ckks_plan *plan, const lr_poly *c0, const lr_poly *c1, const lr_poly *c2, const lr_poly *evk,
                        lr_poly *out0, lr_poly *out1);
+/* bfv.evaluator.permute (bfv/evaluator.go:711-735) = RotateRows (:670) with gen = galElRotRow, RotateColumns (:579) with the key of
+ * that rotation and gen = galElRotColLeft[k], and one step of rotateColumnsPow2 (:636): Context.Permute of both components by the
+ * Galois element `gen` (coefficient domain), switchKeys of the second with `rotkey`, Add + Copy.  Every poly over Q, coefficient
+ * domain; (out_c0, out_c1) may be (c0, c1); out_c0 != out_c1. */
+int lr_bfv_rotate(lr_ckks_plan *plan, const lr_poly *c0, const lr_poly *c1, uint64_t gen, const lr_poly *rotkey,
+                  lr_poly *out_c0, lr_poly *out_c1);
 /* MulRelin (ckks/evaluator.go:1016), ciphertext x ciphertext, with evaluation key.
  * ct0_c0/ct0_c1 etc. are the degree-0/1 components (Ciphertext.Value()[0], [1]). */
 int lr_ckks_mulrelin(lr_ckks_plan *plan, int level, const lr_poly *ct0_c0, const lr_poly *ct0_c1,

@@ -90,6 +90,7 @@ SYMBOLS = {
     "lr_ckks_switch_keys": [vp, i32, vp, vp, vp, vp],
     "lr_bfv_switch_keys": [vp, vp, vp, vp, vp],
     "lr_bfv_relinearize": [vp, vp, vp, vp, vp, vp, vp],
+    "lr_bfv_rotate": [vp, vp, vp, u64, vp, vp, vp],
     "lr_ckks_mulrelin": [vp, i32, vp, vp, vp, vp, vp, vp, vp],
     "lr_ckks_batcher_create": [vp, i32, vp],
     "lr_ckks_batcher_destroy": [vp],

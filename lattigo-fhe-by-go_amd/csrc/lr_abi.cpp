@@ -2992,6 +2992,47 @@ extern "C" int lr_bfv_relinearize(lr_ckks_plan *pl, const lr_poly *c0, const lr_
     });
 }
 
+// bfv.evaluator.permute (bfv/evaluator.go:711-735), the body of RotateRows (:670-681) and of RotateColumns with the key of that
+// rotation (:590-592, and each step of rotateColumnsPow2 :636-662): Context.Permute of both components (coefficient domain, :723-724),
+// switchKeys of the second (:729), Add and Copy (:731-732).  The key switch accumulates straight into the outputs (the reference's
+// keyswitchpool[2], [3] and its Copy are the same values); out may be the input (the reference's polypool branch, :717-721).
+extern "C" int lr_bfv_rotate(lr_ckks_plan *pl, const lr_poly *c0, const lr_poly *c1, uint64_t gen, const lr_poly *rotkey, lr_poly *o0,
+                             lr_poly *o1) {
+    return guarded([&]() -> int {
+    if (!pl || !c0 || !c1 || !rotkey || !o0 || !o1) return fail(LR_ERR_ARG, "null argument");
+    lr_context *cQ = pl->cQ;
+    const int level = cQ->h.L() - 1, batch = c0->batch;
+    if (batch > pl->max_batch) return fail(LR_ERR_SHAPE, "batch exceeds the plan's max_batch");
+    for (const lr_poly *p : {c0, c1, (const lr_poly *)o0, (const lr_poly *)o1}) LR_TRY(check_ct(pl, level, p, batch));
+    if (o0->d == o1->d) return fail(LR_ERR_ARG, "bfv rotate: the two output polys must be distinct");
+    if (cQ->h.N < 2 || cQ->h.logN > 31) return fail(LR_ERR_UNSUPPORTED, "ring degree");
+    LR_TRY(same_stream(pl->cQ, pl->cP));
+    LR_HIP(hipSetDevice(pl->device));
+    const int n = (int)cQ->h.N, L1 = level + 1;
+    const long long s = (long long)L1 * n;
+    for (Pool *p : {&pl->c0, &pl->c2x}) LR_TRY(p->ensure(cQ, (size_t)batch * s));
+    GaloisLaunch G;
+    G.n = n;
+    G.logn = (int)cQ->h.logN;
+    G.ntt_domain = 0;
+    G.gen = gen & ((cQ->h.N << 1) - 1);
+    G.lp = cQ->d_lp;
+    if (batch == 1 && !pl->opt.no_pair && c0->d != c1->d) {
+        // one ciphertext: both components in one launch, the strides are the distances between them (see lr_ckks_rotate)
+        auto words = [](const u64 *a, const u64 *b) { return (long long)(((intptr_t)b - (intptr_t)a) / (intptr_t)sizeof(u64)); };
+        G.in = c0->d; G.in_stride = words(c0->d, c1->d); G.out = pl->c0.d; G.out_stride = words(pl->c0.d, pl->c2x.d);
+        LR_HIP(launch_permute(G, L1, 2, cQ->stream));                                          // :723-724
+    } else {
+        G.in = c0->d; G.in_stride = c0->stride(); G.out = pl->c0.d; G.out_stride = s;
+        LR_HIP(launch_permute(G, L1, batch, cQ->stream));                                      // :723
+        G.in = c1->d; G.in_stride = c1->stride(); G.out = pl->c2x.d;
+        LR_HIP(launch_permute(G, L1, batch, cQ->stream));                                      // :724
+    }
+    LR_TRY(bfv_switch_keys_core(pl, batch, pl->c2x.d, s, rotkey, o0->d, o0->stride(), o1->d, o1->stride()));   // :729 (p1 lands in out1: :732)
+    return run_ewise(cQ, LR_ADD, L1, batch, pl->c0.d, s, o0->d, o0->stride(), o0->d, o0->stride(), nullptr);   // :731
+    });
+}
+
 extern "C" int lr_ckks_rotate(lr_ckks_plan *pl, int level, const lr_poly *c0, const lr_poly *c1, uint64_t gen, const lr_poly *rotkey,
                               lr_poly *o0, lr_poly *o1) {
     return guarded([&]() -> int {

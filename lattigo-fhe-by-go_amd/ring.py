@@ -573,6 +573,26 @@ class CkksPlan:
         """bfv.evaluator.Relinearize (bfv/evaluator.go:512) of a degree-2 ciphertext: ct = (c0, c1, c2), ctOut = (out0, out1)"""
         check(lib().lr_bfv_relinearize(self.h, ct[0].h, ct[1].h, ct[2].h, evakey.h, ctOut[0].h, ctOut[1].h))
 
+    def BfvPermute(self, ct0, generator, switchKey, ctOut):
+        """bfv.evaluator.permute (bfv/evaluator.go:711): the body of RotateRows (generator = galElRotRow) and of RotateColumns with
+        the key of that rotation (galElRotColLeft[k]); ct0, ctOut: pairs of Poly over Q, coefficient domain; ctOut may be ct0"""
+        check(lib().lr_bfv_rotate(self.h, ct0[0].h, ct0[1].h, C.c_uint64(int(generator)), switchKey.h, ctOut[0].h, ctOut[1].h))
+
+    def BfvRotateColumnsPow2(self, ct0, generator, k, pow2_keys, ctOut):
+        """bfv.evaluator.rotateColumnsPow2 (bfv/evaluator.go:636-662): rotation by k as the chain of the power-of-two rotations in
+        its binary expansion; pow2_keys: {2^i: SwitchingKey image}; generator = GaloisGen (left) or its inverse mod 2N (right)"""
+        mask = (self.contextQ.N << 1) - 1
+        if ctOut[0] is not ct0[0]:
+            self.contextQ.Copy(ct0[0], ctOut[0])                     # :647-648
+            self.contextQ.Copy(ct0[1], ctOut[1])
+        idx = 1
+        while k > 0:
+            if k & 1:
+                self.BfvPermute(ctOut, generator, pow2_keys[idx], ctOut)   # :655
+            generator = (generator * generator) & mask                     # :658-659
+            idx <<= 1
+            k >>= 1
+
     def MulRelin(self, level, ct0, ct1, evakey, ctOut):
         """evaluator.MulRelin (ckks/evaluator.go:1016).  ct0, ct1: tuples of Poly -- (value[0], value[1]) for a ciphertext,
         (value[0],) for a plaintext; ctOut: pair, or triple when evakey is None and both operands are ciphertexts

@@ -1031,6 +1031,21 @@ void oc_bfv_relinearize(oc_ckks_plan *p, const u64 *ct, const u64 *evk, u64 *out
     free(p0); free(p1);
 }
 
+/* bfv.evaluator.permute, bfv/evaluator.go:711-735 (the body of RotateRows :670-681 and of RotateColumns with the key of that rotation
+ * :590-592): ct = [2][nQ][N] coefficient domain, evk as for oc_bfv_switch_keys, out = [2][nQ][N].  oc_permute is declared below. */
+void oc_permute(const oc_context *c, const u64 *in, u64 gen, u64 *out);
+void oc_bfv_permute(oc_ckks_plan *p, const u64 *ct, u64 gen, const u64 *evk, u64 *out) {
+    const oc_context *cQ = p->cQ;
+    const size_t sz = (size_t)cQ->L * cQ->N;
+    u64 *el0 = (u64 *)malloc(sz * 8), *el1 = (u64 *)malloc(sz * 8), *p0 = (u64 *)malloc(sz * 8), *p1 = (u64 *)malloc(sz * 8);
+    oc_permute(cQ, ct, gen, el0);                                             /* :723 */
+    oc_permute(cQ, ct + sz, gen, el1);                                        /* :724 */
+    oc_bfv_switch_keys(p, el1, evk, p0, p1);                                  /* :729 */
+    oc_ewise(cQ, OC_ADD, cQ->L - 1, el0, p0, out, NULL);                      /* :731 */
+    memcpy(out + sz, p1, sz * 8);                                             /* :732 Copy */
+    free(el0); free(el1); free(p0); free(p1);
+}
+
 /* MulRelin, ckks/evaluator.go:1016-1133 (ct x ct, regular case, with evaluation key) */
 void oc_ckks_mulrelin(oc_ckks_plan *p, int level, const u64 *ct0, const u64 *ct1, const u64 *evk, u64 *out) {
     const oc_context *cQ = p->cQ;

@@ -184,6 +184,9 @@ void oc_half_scalar_op(const oc_context *c, int op, int level, const uint64_t *i
  * coefficient domain.  oc_bfv_relinearize (:480-501) on a degree-2 ciphertext ct = [3][|Q|][N] -> out = [2][|Q|][N]. */
 void oc_bfv_switch_keys(oc_ckks_plan *p, const uint64_t *cx, const uint64_t *evk, uint64_t *p0, uint64_t *p1);
 void oc_bfv_relinearize(oc_ckks_plan *p, const uint64_t *ct, const uint64_t *evk, uint64_t *out);
+/* bfv.evaluator.permute (bfv/evaluator.go:711-735): Context.Permute of both components, switchKeys of the second, Add + Copy;
+ * ct, out = [2][|Q|][N] coefficient domain */
+void oc_bfv_permute(oc_ckks_plan *p, const uint64_t *ct, uint64_t gen, const uint64_t *evk, uint64_t *out);
 /* MulRelin (:1016), degree-1 x degree-1, regular (non-squaring) case with evaluation key.
  * ct0, ct1, out = [2][level+1][N]. */
 void oc_ckks_mulrelin(oc_ckks_plan *p, int level, const uint64_t *ct0, const uint64_t *ct1,

@@ -146,6 +146,7 @@ def _bind(L):
     sig("oc_half_scalar_op", None, vp, i, i, vp, vp, vp, vp)
     sig("oc_bfv_switch_keys", None, vp, vp, vp, vp, vp)
     sig("oc_bfv_relinearize", None, vp, vp, vp, vp)
+    sig("oc_bfv_permute", None, vp, vp, C.c_uint64, vp, vp)
     sig("oc_ckks_permute_ntt", None, vp, i, vp, u64, vp, vp)
     sig("oc_ckks_mul_norelin", None, vp, i, vp, vp, i, vp)
     sig("oc_ckks_mul_plain", None, vp, i, vp, vp, vp)
@@ -570,6 +571,13 @@ class CkksPlan:
         ct, evk = _arr(ct), _arr(evk)
         out = np.zeros((2, self.cQ.L, self.cQ.N), dtype=np.uint64)
         lib().oc_bfv_relinearize(self.h, _ptr(ct), _ptr(evk), _ptr(out))
+        return out
+
+    def bfv_permute(self, ct, gen, evk):
+        """bfv.evaluator.permute (bfv/evaluator.go:711): RotateRows / RotateColumns with the key of that rotation; ct [2, |Q|, N]"""
+        ct, evk = _arr(ct), _arr(evk)
+        out = np.zeros((2, self.cQ.L, self.cQ.N), dtype=np.uint64)
+        lib().oc_bfv_permute(self.h, _ptr(ct), C.c_uint64(int(gen)), _ptr(evk), _ptr(out))
         return out
 
     def permute_ntt(self, level, ct, gen, evk):

@@ -74,6 +74,11 @@ def build():
     lo, hi = np.array(scalars, dtype=np.uint64) % np.array(Q, dtype=np.uint64), np.array(scalars[::-1], dtype=np.uint64) % np.array(Q, dtype=np.uint64)
     for code, nm in ((0, "add"), (1, "mred"), (2, "mred_add")):
         case("half_scalar:" + nm, {"a": a, "out": c0, "lo": lo, "hi": hi}, ocQ.half_scalar_op(code, a, lo, hi, out=c0), op=code)
+    # round 4: the BFV rotation body (bfv/evaluator.go:711-735) on the same toy key-switch parameters, column and row generators
+    ct2 = np.stack([rnd(Q, 34), rnd(Q, 35)])
+    ct2[0][:, 2] = 0
+    for nm, g in (("col", pow(5, 3, 2 * N)), ("row", 2 * N - 1)):
+        case("bfv_permute:" + nm, {"ct": ct2, "evk": evk}, plan.bfv_permute(ct2, g, evk), gen=g)
     return {"N": N, "Q": [str(q) for q in Q], "P": [str(p) for p in P], "cases": cases,
             "note": "uint64 values as decimal strings, arrays flattened in C order with their shape"}
 

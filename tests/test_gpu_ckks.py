@@ -720,3 +720,79 @@ def test_one_ciphertext_on_every_default_parameter_set(gpu_pkg, oracle, name):
         oc = oracle.Context(N, Q[:level + 1])
         for k in range(2):
             assert np.array_equal(out[k].get().reshape(level, N), oc.rescale_op("oc_div_round_by_last_modulus_ntt", want[k])), (name, level, "rescale", k)
+
+
+# ---- bfv rotations end to end (bfv/evaluator.go:579-735) ------------------------------------------------------------------------
+@pytest.mark.parametrize("name,logn,batch", [("PN12QP109", 12, 2), ("PN13QP218", 11, 3), ("PN14QP438", 14, 2), ("PN14QP438", 14, 1), ("PN15QP880", 13, 1)])
+def test_bfv_rotation_sequence(gpu_pkg, oracle, name, logn, batch, monkeypatch):
+    """bfv.evaluator.permute (bfv/evaluator.go:711-735) = the body of RotateRows and RotateColumns: Context.Permute of both components,
+    switchKeys of the second, Add, Copy -- the composed sequence through ONE C-ABI call (lr_bfv_rotate), against the oracle's restatement
+    (oc_bfv_permute) at PN14QP438 full size (BASELINE config 4's set) and the other BFV sets; column generator 5^k, row generator 2N - 1;
+    in place (the reference's polypool branch, :717-721); a batch of one with its two components in one launch and with LR_NO_PAIR"""
+    _, Q, P, _ = gpu_pkg.params.bfv_moduli(name)
+    N = 1 << logn
+    ring = gpu_pkg.ring
+    nq, np_ = len(Q), len(P)
+    beta = -(-nq // np_)
+    evk = gpu_pkg.sampling.uniform_poly(Q + P, N, 2 * beta, seed=43)
+    ct = [gpu_pkg.sampling.uniform_poly(Q, N, batch, seed=70 + k).reshape(batch, nq, N) for k in range(2)]
+    ct[0][0, :, 3] = 0                                      # a zero coefficient whose sign flips becomes q (ring_galois.go:121)
+    ct[1][0, :, 5] = 0
+    oplan = oracle.CkksPlan(oracle.Context(N, Q), oracle.Context(N, P))
+    gens = [pow(5, 1, 2 * N), pow(5, 37, 2 * N), 2 * N - 1]        # GaloisGen^k (bfv/bfv.go galElRotColLeft), galElRotRow
+    for env in ({}, {"LR_NO_PAIR": "1"}) if batch == 1 else ({},):
+        monkeypatch.delenv("LR_NO_PAIR", raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        cQ, cP = ring.NewContextWithParams(N, Q), ring.NewContextWithParams(N, P)
+        plan = ring.CkksPlan(cQ, cP, batch)
+        pevk = plan.NewSwitchingKey().set(evk)
+        for gen in gens:
+            want = [oplan.bfv_permute(np.stack([ct[0][b], ct[1][b]]), gen, evk.reshape(beta, 2, nq + np_, N)) for b in range(batch)]
+            c = (cQ.NewPoly(batch).set(ct[0]), cQ.NewPoly(batch).set(ct[1]))
+            out = (cQ.NewPoly(batch), cQ.NewPoly(batch))
+            plan.BfvPermute(c, gen, pevk, out)
+            for b in range(batch):
+                for k in range(2):
+                    assert np.array_equal(out[k].get().reshape(batch, nq, N)[b], want[b][k]), (env, gen, b, k)
+            assert np.array_equal(c[0].get().reshape(batch, nq, N), ct[0])          # the input is left alone
+            plan.BfvPermute(c, gen, pevk, c)                                          # ct0 == ctOut
+            for k in range(2):
+                assert np.array_equal(c[k].get(), out[k].get()), (env, gen, "in place", k)
+        del plan, pevk
+
+
+def test_bfv_rotate_columns_pow2_chain_and_argument_errors(gpu_pkg, oracle):
+    """rotateColumnsPow2 (bfv/evaluator.go:636-662): k = 5 = 1 + 4 as the chain of the power-of-two rotations with the generator squared at
+    every step, through the host mirror, against the oracle applying bfv_permute step by step; and the entry point's argument checks"""
+    _, Q, P, _ = gpu_pkg.params.bfv_moduli("PN13QP218")
+    N = 1 << 12
+    ring = gpu_pkg.ring
+    nq, np_ = len(Q), len(P)
+    beta = -(-nq // np_)
+    keys_h = {1 << i: gpu_pkg.sampling.uniform_poly(Q + P, N, 2 * beta, seed=90 + i) for i in range(3)}
+    ct = [gpu_pkg.sampling.uniform_poly(Q, N, 1, seed=95 + k).reshape(nq, N) for k in range(2)]
+    cQ, cP = ring.NewContextWithParams(N, Q), ring.NewContextWithParams(N, P)
+    plan = ring.CkksPlan(cQ, cP, 1)
+    keys = {i: plan.NewSwitchingKey().set(k) for i, k in keys_h.items()}
+    c = (cQ.NewPoly(1).set(ct[0]), cQ.NewPoly(1).set(ct[1]))
+    out = (cQ.NewPoly(1), cQ.NewPoly(1))
+    plan.BfvRotateColumnsPow2(c, 5, 5, keys, out)
+    oplan = oracle.CkksPlan(oracle.Context(N, Q), oracle.Context(N, P))
+    want = np.stack(ct)
+    gen, idx, k = 5, 1, 5
+    while k:
+        if k & 1:
+            want = oplan.bfv_permute(want, gen, keys_h[idx].reshape(beta, 2, nq + np_, N))
+        gen = (gen * gen) & (2 * N - 1)
+        idx <<= 1
+        k >>= 1
+    for j in range(2):
+        assert np.array_equal(out[j].get().reshape(nq, N), want[j]), j
+    err = gpu_pkg._native.LatticeRingError
+    with pytest.raises(err):
+        plan.BfvPermute(c, 5, keys[1], (out[0], out[0]))                              # one output poly twice
+    with pytest.raises(err):
+        plan.BfvPermute((cQ.NewPoly(2), cQ.NewPoly(2)), 5, keys[1], (cQ.NewPoly(2), cQ.NewPoly(2)))   # batch beyond the plan's max_batch
+    with pytest.raises(err):
+        plan.BfvPermute((cQ.NewPolyLvl(nq - 2, 1), c[1]), 5, keys[1], out)            # a component with fewer limbs than Q

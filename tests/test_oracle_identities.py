@@ -364,3 +364,70 @@ def test_bfv_relinearize_decrypts_like_the_degree_two_ciphertext(oracle):
     # and the two halves separately: relinearize = (c0 + p0, c1 + p1) with (p0, p1) = switchKeys(c2)
     p0, p1 = plan.bfv_switch_keys(ct[2], evk)
     assert np.array_equal(out[0], add(ct[0], p0, Q)) and np.array_equal(out[1], add(ct[1], p1, Q))
+
+
+@pytest.mark.parametrize("gen_kind", ["column", "row"])
+def test_bfv_permute_decrypts_to_the_automorphism_of_the_plaintext(oracle, gen_kind):
+    """Pins the restatement of bfv.evaluator.permute (bfv/evaluator.go:711-735; no vectors in the reference): with a rotation key built the
+    way genrotKey builds it (a switching key from phi(s) to s: digit i holds (-a_i*s + e_i + P*phi(s) on its own limbs, a_i) over Q||P,
+    NTT + Montgomery form), out0 + out1*s must equal phi(c0 + c1*s) up to a small noise that is one integer polynomial modulo every q_i.
+    phi (X -> X^gen) is evaluated here on Python integers, independently of oc_permute."""
+    import __graft_entry__ as graft
+    pkg = graft.load_package()
+    N = 1 << 6
+    Q, P = list(pkg.params.Qi60()[:4]), list(pkg.params.Pi60()[:2])
+    QP = Q + P
+    nq, np_ = len(Q), len(P)
+    alpha, beta = np_, -(-nq // np_)
+    gen = pow(5, 3, 2 * N) if gen_kind == "column" else 2 * N - 1
+    ocQ, ocP, ocQP = oracle.Context(N, Q), oracle.Context(N, P), oracle.Context(N, QP)
+    plan = oracle.CkksPlan(ocQ, ocP)
+    rng = np.random.default_rng(11)
+
+    def phi(v):                                   # integer polynomial, X^i -> X^(i*gen) in Z[X]/(X^N + 1)
+        out = [0] * N
+        for i, x in enumerate(v):
+            e = (i * gen) % (2 * N)
+            out[e % N] += -int(x) if e >= N else int(x)
+        return out
+    res = lambda v, mods: np.array([[int(x) % q for x in v] for q in mods], dtype=np.uint64)
+    mul = lambda a, b, mods: np.array([[int(x) * int(y) % q for x, y in zip(a[i], b[i])] for i, q in enumerate(mods)], dtype=np.uint64)
+    add = lambda a, b, mods: np.array([[(int(x) + int(y)) % q for x, y in zip(a[i], b[i])] for i, q in enumerate(mods)], dtype=np.uint64)
+    neg = lambda a, mods: np.array([[(q - int(x)) % q for x in a[i]] for i, q in enumerate(mods)], dtype=np.uint64)
+    mont = lambda a, mods: np.array([[(int(x) << 64) % q for x in a[i]] for i, q in enumerate(mods)], dtype=np.uint64)
+    Pprod = P[0] * P[1]
+    s = [int(x) for x in rng.integers(-1, 2, size=N)]
+    s_ntt = ocQP.ntt(res(s, QP))
+    phis_ntt = ocQP.ntt(res(phi(s), QP))
+    evk = np.zeros((beta, 2, nq + np_, N), dtype=np.uint64)
+    for i in range(beta):
+        a_i = pkg.sampling.uniform_poly(QP, N, 1, seed=400 + i)[0]
+        e_i = ocQP.ntt(res(rng.integers(-6, 7, size=N), QP))
+        k0 = add(neg(mul(a_i, s_ntt, QP), QP), e_i, QP)
+        for j in range(alpha):
+            idx = i * alpha + j
+            if idx < nq:
+                q = QP[idx]
+                k0[idx] = np.array([(int(x) + (Pprod % q) * int(y)) % q for x, y in zip(k0[idx], phis_ntt[idx])], dtype=np.uint64)
+        evk[i, 0], evk[i, 1] = mont(k0, QP), mont(a_i, QP)
+    ct = pkg.sampling.uniform_poly(Q, N, 2, seed=17)                      # any degree-1 "ciphertext", coefficient domain
+    ct[0][:, 1] = 0                                                       # a zero whose sign flips (q, not 0, in the reference)
+    out = plan.bfv_permute(ct, gen, evk)
+    sq = s_ntt[:nq]
+    lhs = ocQ.intt(add(ocQ.ntt(out[0]), mul(ocQ.ntt(out[1]), sq, Q), Q))
+    dec = ocQ.intt(add(ocQ.ntt(ct[0]), mul(ocQ.ntt(ct[1]), sq, Q), Q))  # c0 + c1*s, per limb
+    noise = None
+    for i, q in enumerate(Q):
+        want = [x % q for x in phi([int(x) for x in dec[i]])]
+        d = [((int(x) - y) % q + q // 2) % q - q // 2 for x, y in zip(lhs[i], want)]
+        assert max(abs(v) for v in d) < 1 << 24, (i, max(abs(v) for v in d))
+        if noise is None:
+            noise = d
+        assert d == noise
+    # the halves: out1 = p1 and out0 = Permute(c0) + p0 with (p0, p1) = switchKeys(Permute(c1)); Permute against phi on integers
+    perm1 = ocQ.permute(ct[1], gen)
+    for i, q in enumerate(Q):
+        assert [int(x) % q for x in perm1[i]] == [x % q for x in phi([int(x) for x in ct[1][i]])]
+    p0, p1 = plan.bfv_switch_keys(perm1, evk)
+    assert np.array_equal(out[1], p1)
+    assert np.array_equal(out[0], add(ocQ.permute(ct[0], gen), p0, Q))

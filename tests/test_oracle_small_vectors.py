@@ -99,3 +99,10 @@ def test_device_reproduces_the_committed_vectors(gpu_pkg):
         o = up(cQ, inp(name, "out"))
         cQ.HalfScalarOp({"add": "ADD", "mred": "MRED", "mred_add": "MRED_ADD"}[nm], len(Q) - 1, up(cQ, inp(name, "a")), inp(name, "lo"), inp(name, "hi"), o)
         assert np.array_equal(o.get(), out(name)), name
+    # round 4: the BFV rotation body on the toy key-switch plan
+    for nm in ("col", "row"):
+        name = "bfv_permute:" + nm
+        c2 = inp(name, "ct")
+        rot = (cQ.NewPoly(1), cQ.NewPoly(1))
+        plan.BfvPermute((up(cQ, c2[0]), up(cQ, c2[1])), CASES[name]["gen"], key, rot)
+        assert np.array_equal(np.stack([rot[0].get(), rot[1].get()]), out(name)), name
