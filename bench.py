@@ -259,6 +259,108 @@ def measure_pipeline(script_args, run_ms_per_product):
     return traffic, {"FETCH_SIZE_KB_per_product": tot["FETCH_SIZE"], "WRITE_SIZE_KB_per_product": tot["WRITE_SIZE"]}, valu
 
 
+def sample_power(step, sync, seconds=1.6):
+    """package power and shader clock while `step` loops for `seconds`: rocm-smi polled from a thread (each poll is a process start, a few
+    per second); -> {"package_W": max seen, "sclk_MHz": median seen, "samples": n} or {"error": ...}.  The kernels of this path run the
+    package into its 1.4 kW limit and the clock comes down to stay there: these two numbers are that statement, per run."""
+    import re
+    import shutil
+    import statistics
+    import subprocess
+    import threading
+    exe = shutil.which("rocm-smi") or "/opt/rocm/bin/rocm-smi"
+    if not os.path.exists(exe):
+        return {"error": "rocm-smi not found"}
+    seen, stop = [], [False]
+
+    def poll():
+        while not stop[0]:
+            try:
+                txt = subprocess.run([exe, "--showpower", "--showclocks", "--json"], capture_output=True, text=True, timeout=10).stdout
+                card = next(iter(json.loads(txt).values()))
+                w = [float(v) for k, v in card.items() if "ower" in k and "(W)" in k and re.match(r"^[0-9.]+$", str(v))]
+                mhz = [int(m.group(1)) for k, v in card.items() if k.startswith("sclk") for m in [re.search(r"\((\d+)Mhz\)", str(v))] if m]
+                if w and mhz:
+                    seen.append((max(w), mhz[0]))
+            except Exception:     # noqa: BLE001 -- a failed poll is a missing sample
+                pass
+            time.sleep(0.05)
+    th = threading.Thread(target=poll)
+    th.start()
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        for _ in range(20):
+            step()
+        sync()
+    stop[0] = True
+    th.join()
+    seen = seen[1:] if len(seen) > 2 else seen          # the first poll starts before the load has built up
+    if not seen:
+        return {"error": "rocm-smi gave no power / clock reading"}
+    return {"package_W": max(w for w, _ in seen), "sclk_MHz_smi": statistics.median(m for _, m in seen), "samples": len(seen),
+            "how": "rocm-smi --showpower --showclocks polled while the headline launch loops for %.1f s" % seconds}
+
+
+def load_bench_legs():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_legs", os.path.join(ROOT, "tools", "bench_legs.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def measure_legs(names, run_ms):
+    """Counters of the pipeline legs, all in three child passes: tools/dbg/legs_pmc.py runs every leg between marker kernels
+    (div_selftest_kernel: marker, call, marker, call, marker per leg), the dispatch list is cut at the markers and leg i's measured call is
+    segment 3i + 2.  -> {leg: (traffic bytes per call, detail, valu object, [(kernel, launches, microseconds)])} or (None, reason)."""
+    per = {}
+    order = None
+    try:
+        for counters in PMC_PASSES:
+            rows, stdout = _pmc_pass(counters, [_tool("legs_pmc.py")] + list(names), timeout=600)
+            legs = [ln.split()[1] for ln in stdout.splitlines() if ln.startswith("LEG ")]
+            if not legs or "END" not in stdout:
+                raise RuntimeError("the leg script did not finish: %s" % stdout[-300:])
+            order = legs
+            disp = {}
+            for r in rows:
+                disp.setdefault(int(r["Dispatch_Id"]), []).append(r)
+            segs, cur = [], []
+            for did in sorted(disp):
+                if "div_selftest" in disp[did][0]["Kernel_Name"]:
+                    segs.append(cur)
+                    cur = []
+                else:
+                    cur.append(disp[did])
+            segs.append(cur)
+            if len(segs) < 3 * len(legs) + 1:
+                raise RuntimeError("%d marker segments for %d legs" % (len(segs), len(legs)))
+            for i, name in enumerate(legs):
+                mine = [d for d in segs[3 * i + 2] if "rocclr" not in d[0]["Kernel_Name"]]
+                acc = per.setdefault(name, {})
+                for c in counters:
+                    acc[c] = sum(float(r["Counter_Value"]) for d in mine for r in d if r["Counter_Name"] == c)
+                if "GRBM_GUI_ACTIVE" in counters:
+                    ks = {}
+                    for d in mine:
+                        r = d[0]
+                        k = ks.setdefault(r["Kernel_Name"].split("(")[0][-72:], [0, 0.0])
+                        k[0] += 1
+                        k[1] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-3
+                    acc["dur"] = sum(v[1] for v in ks.values()) * 1e-6
+                    acc["kernels"] = sorted(([k, v[0], round(v[1], 1)] for k, v in ks.items()), key=lambda t: -t[2])[:6]
+    except Exception as ex:     # noqa: BLE001 -- the measurement is optional, the reason is reported
+        return None, str(ex)
+    out = {}
+    for name in order:
+        a = per[name]
+        traffic = 2 * a["FETCH_SIZE"] * 1024 + a["WRITE_SIZE"] * 1024
+        valu = _valu_object(a["SQ_INSTS_VALU"], a["SQ_WAVES"], a["GRBM_GUI_ACTIVE"] / 8, a["dur"], run_ms.get(name, 0.0) * 1e-3 or a["dur"])
+        valu["per"] = "call"
+        out[name] = (traffic, {"FETCH_SIZE_KB_per_call": a["FETCH_SIZE"], "WRITE_SIZE_KB_per_call": a["WRITE_SIZE"]}, valu, a["kernels"])
+    return out, None
+
+
 def finish_roofline(r, traffic, detail, valu, how, algorithmic):
     """fills traffic / traffic_source / valu of a roofline object and names the binding roof: whichever of the HBM fraction and the
     vector-issue fraction (at the clock the chip sustained) is nearer 1"""
@@ -311,7 +413,7 @@ def cpu_baseline(make_worker, units_per_call, unit, what, target_seconds):
 
     t_round = run(1)                                    # one call on every thread, concurrently
     per_thread = max(1, min(8192, int(target_seconds / max(t_round, 1e-6))))
-    dt = run(per_thread)
+    dt = run(per_thread) if per_thread > 1 else t_round  # (a call that already fills the sample is the sample)
     calls = cores * per_thread
     progress("cpu baseline: %s done" % what)
     return {
@@ -446,6 +548,11 @@ def main():
     ap.add_argument("--no-ckks", action="store_true", help="skip the CKKS MulRelin / BFV Mul legs")
     ap.add_argument("--no-threads", action="store_true", help="skip the evaluator-per-host-thread MulRelin leg (T = 1, 4, 16 threads, batch 1 each)")
     ap.add_argument("--no-config5", action="store_true", help="skip the PN16QP1761 sharded MulRelin + gather leg")
+    ap.add_argument("--no-pipelines", action="store_true", help="skip the legs of tools/bench_legs.py other than bfv_mul (ModDown, DivFloor / DivRound, Rescale, Relin, "
+                    "rotations, hoisted rotations, pk-encrypt, decrypt, BFV Relin / rotations, SimpleScaler, marshal ingest)")
+    ap.add_argument("--pipelines", default="", help="comma-separated subset of the legs to run")
+    ap.add_argument("--hw-queues", type=int, default=16, help="GPU_MAX_HW_QUEUES for this process (0: leave the runtime's default of 4 per priority class); "
+                    "only the evaluator_threads rows have more than one busy stream")
     ap.add_argument("--ckks-batch", type=int, default=128)
     ap.add_argument("--config5-units", type=int, default=128, help="PN16QP1761 ciphertext products per GPU")
     ap.add_argument("--config5-chunk", type=int, default=32, help="products per lr_ckks_mulrelin call")
@@ -473,7 +580,8 @@ def main():
     # after the other, and which ones collide depends on every stream the process has created (profiles/r03/hw_queues.txt).
     # Only the evaluator-per-thread rows have more than one stream with work; the setting is reported there.  The runtime reads it once,
     # at its initialisation, hence here.
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+    if args.hw_queues > 0:
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", str(args.hw_queues))
     import numpy as np
     import torch
 
@@ -854,6 +962,7 @@ def main():
     kernel_name = ctx.last_ntt_kernel()
     progress("headline NTT timed: %.4f ms per launch, kernel %s" % (kernel_ms, kernel_name))
 
+    power = sample_power(step, ctx.Sync) if (rank == 0 and world == 1 and not args.no_traffic) else None
     # parity spot-check inside the bench: first and last poly against the oracle (checker only)
     bit_exact = None
     oc = None
@@ -888,7 +997,7 @@ def main():
                      "frac": achieved / HBM_PEAK_GBS,
                      # PMC counters need their own rocprofv3 passes: filled at the end of the run by two child runs on the same
                      # kernel and shape (measure_hbm_traffic); null if that is skipped or fails, the committed figure is in the file
-                     "traffic": None, "traffic_profile": "profiles/r02/pmc_hbm.json",
+                     "traffic": None, "traffic_profile": "profiles/r04/pmc_hbm.json",
                      "kernel": kernel_name, "asm_variant": fwd_variant, "kernel_ms": kernel_ms,
                      "algorithmic_bytes_per_launch": ntt_bytes(N, L, my_polys),
                      # the north star says "HBM-read roofline"; `achieved` counts read + write, this is the read half
@@ -908,6 +1017,7 @@ def main():
             fn()
         return c.TimerStop() / reps
 
+    pipeline_ms = {}
     if rank == 0 and not args.no_ckks:
         # second half of BASELINE.json's metric: CKKS MulRelin (ckks/evaluator.go:1016) at DefaultParams[PN15QP880],
         # device-resident batch of independent ciphertexts, synthetic operands and evaluation key
@@ -937,8 +1047,8 @@ def main():
                                 "params": "PN15QP880 (N=2^15, 18 Q limbs + 3 P limbs, beta=6), level 17",
                                 "bit_exact": bool(np.array_equal(got0, want[0]) and np.array_equal(got1, want[1])),
                                 "roofline": {"bound": "hbm", "achieved": alg, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / HBM_PEAK_GBS,
-                                             "traffic": None, "traffic_profile": "profiles/r02/mulrelin_pmc_hbm.json",
-                                             "kernel": "pipeline of launches; per-kernel split in profiles/r02/mulrelin_kernel_stats.csv",
+                                             "traffic": None, "traffic_profile": "profiles/r04/mulrelin_pmc_hbm.json",
+                                             "kernel": "pipeline of launches; per-kernel split in profiles/r04/mulrelin_kernel_stats.csv",
                                              "pipeline_ms": cms, "algorithmic_bytes_per_product": mulrelin_bytes(cN, nq, np_)}}
         if want_cpu:
             def mk_mulrelin(i):
@@ -948,32 +1058,43 @@ def main():
             out["ckks_mulrelin"]["cpu_baseline"] = cpu_baseline(mk_mulrelin, 1, "MulRelin/s", "oracle MulRelin PN15QP880 level 17", 4.0)
         del plan, ct0, ct1, cto, evk
 
-        # BASELINE.json config 4: BFV DefaultParams[PN14QP438] Evaluator.Mul (tensorAndRescale, bfv/evaluator.go:278),
-        # degree-1 x degree-1 -> degree-2, coefficient-domain operands, device-resident batch
-        bN, bQ, _, bQMul = params.bfv_moduli("PN14QP438")
-        bB = args.ckks_batch
-        bcQ, bcM = ring.NewContextWithParams(bN, bQ, device=local), ring.NewContextWithParams(bN, bQMul, device=local)
-        bplan = ring.BfvPlan(bcQ, bcM, 65537, bB)
-        bbase = [sampling.uniform_poly(bQ, bN, 2, seed=5 + k) for k in range(4)]
-        btile = lambda x: np.concatenate([x] * (-(-bB // 2)))[:bB]
-        b0 = (bcQ.NewPoly(bB).set(btile(bbase[0])), bcQ.NewPoly(bB).set(btile(bbase[1])))
-        b1 = (bcQ.NewPoly(bB).set(btile(bbase[2])), bcQ.NewPoly(bB).set(btile(bbase[3])))
-        bo = (bcQ.NewPoly(bB), bcQ.NewPoly(bB), bcQ.NewPoly(bB))
-        bms = timed_on(bcQ, lambda: bplan.Mul(b0, b1, bo), 10)
-        progress("bfv Mul PN14QP438 timed: %.3f ms per batch of %d" % (bms, bB))
-        obplan = oracle.BfvPlan(oracle.Context(bN, bQ), oracle.Context(bN, bQMul), 65537)
-        bidx = bB - 1
-        bwant = obplan.mul(np.stack([bbase[0][bidx % 2], bbase[1][bidx % 2]]), np.stack([bbase[2][bidx % 2], bbase[3][bidx % 2]]))
-        bok = all(np.array_equal(bo[k].get().reshape(bB, len(bQ), bN)[bidx], bwant[k]) for k in range(3))
-        out["bfv_mul"] = {"value": bB / (bms * 1e-3), "unit": "Mul/s", "batch": bB, "ms_per_batch": bms,
-                          "params": "PN14QP438 (N=2^14, 6 Q limbs, 6 QMul limbs, t=65537)", "bit_exact": bool(bok)}
-        if want_cpu:
-            def mk_bfv(i):
-                op = oracle.BfvPlan(oracle.Context(bN, bQ), oracle.Context(bN, bQMul), 65537)
-                a, b = np.stack([bbase[0][0], bbase[1][0]]), np.stack([bbase[2][0], bbase[3][0]])
-                return lambda: op.mul(a, b)
-            out["bfv_mul"]["cpu_baseline"] = cpu_baseline(mk_bfv, 1, "Mul/s", "oracle bfv Mul PN14QP438", 3.0)
-        del bplan, b0, b1, bo
+        # BASELINE.json config 4 (BFV DefaultParams[PN14QP438] Evaluator.Mul) and every other pipeline entry point the reference benchmarks
+        # (tools/bench_legs.py: ring/ring_benchmark_test.go:310-404, ckks/ckks_benchmarks_test.go:79-240, bfv/bfv_benchmark_test.go:133-162):
+        # one timed call over a device-resident batch each, oracle check of the last unit, CPU oracle beside it
+        bench_legs = load_bench_legs()
+        only = {"bfv_mul"} if (world > 1 or args.no_pipelines) else (set(x for x in args.pipelines.split(",") if x) or None)
+        kits, groups = bench_legs.build_legs(pkg, oracle, device=local, only=only)
+        pipes = {}
+        for gname, make in groups:
+            for leg in make():
+                ms = timed_on(leg.sync, leg.run, leg.reps)
+                leg.after()
+                ok, err = checked(leg.check, None)
+                leg.after()
+                units = leg.units_per_call
+                ach = leg.bytes_per_unit * units / (ms * 1e-3) / 1e9
+                obj = {"value": units / (ms * 1e-3), "unit": leg.unit, "batch": leg.batch, "ms_per_batch": ms, "params": leg.params,
+                       "reference_benchmark": leg.ref, "bit_exact": ok,
+                       "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                                    "kernel": "pipeline of launches (per-kernel split in `kernels` once the counters ran)", "pipeline_ms": ms,
+                                    "algorithmic_bytes_per_unit": leg.bytes_per_unit, "units_per_call": units}}
+                if err:
+                    obj["check_error"] = err
+                if leg.note:
+                    obj["note"] = leg.note
+                if leg.host_bytes_per_unit:
+                    obj["pcie_inclusive"] = {"host_bytes_per_unit": leg.host_bytes_per_unit, "GB_per_s_through_the_entry_point": leg.host_bytes_per_unit * units / (ms * 1e-3) / 1e9}
+                if want_cpu:
+                    obj["cpu_baseline"] = cpu_baseline(leg.cpu, leg.cpu_units, leg.unit, "oracle %s, one call = %d unit(s)" % (leg.name, leg.cpu_units), 1.0)
+                pipes[leg.name] = obj
+                pipeline_ms[leg.name] = ms
+                progress("%s: %.3f ms per call of %d, %.0f %s, %.3f of the HBM roofline, bit_exact %s" % (leg.name, ms, units, obj["value"], leg.unit, obj["roofline"]["frac"], ok))
+            kits.drop(gname)
+        if "bfv_mul" in pipes:
+            out["bfv_mul"] = pipes.pop("bfv_mul")
+        if pipes:
+            out["pipelines"] = pipes
+        del kits, groups
 
     if rank == 0 and world == 1 and not args.no_ckks and not args.no_threads:
         # The reference's concurrency model (examples/dbfv/psi/psi.go:215-233): one evaluator per goroutine, one ciphertext each.  Here: T
@@ -1223,6 +1344,21 @@ def main():
                 finish_roofline(mr, mt, md, mv, "rocprofv3 --pmc child passes over tools/dbg/mulrelin_pmc.py %s %d %d in this run, all kernels summed, per product" % (pname, pb, pk),
                                 mr["algorithmic_bytes_per_product"])
                 progress("%s traffic: %s" % (pname, ("%.1f MB per product = %.3f x algorithmic" % (mt / 1e6, mt / mr["algorithmic_bytes_per_product"])) if mt is not None else md))
+        if pipeline_ms:
+            progress("counters of the %d pipeline legs: three rocprofv3 --pmc child runs over tools/dbg/legs_pmc.py" % len(pipeline_ms))
+            res, why = measure_legs(list(pipeline_ms), pipeline_ms)
+            for name in pipeline_ms:
+                obj = out["bfv_mul"] if name == "bfv_mul" else out["pipelines"][name]
+                r = obj["roofline"]
+                per_call = r["algorithmic_bytes_per_unit"] * r["units_per_call"]
+                if res and name in res:
+                    t, d, v, ks = res[name]
+                    finish_roofline(r, t, d, v, "rocprofv3 --pmc child passes over tools/dbg/legs_pmc.py in this run: the leg's measured call between marker kernels, "
+                                    "all its kernels summed; 2 x FETCH_SIZE + WRITE_SIZE (KB)", per_call)
+                    r["kernels"] = [{"kernel": k, "launches": n, "us_under_the_profiler": us} for k, n, us in ks]
+                else:
+                    finish_roofline(r, None, why or "the leg is missing from the counter run", None, "", per_call)
+            progress("pipeline legs counted" if res else "pipeline legs not counted: %s" % why)
 
     if want_cpu:
         def mk_ntt(i):
@@ -1231,6 +1367,46 @@ def main():
             return lambda: lib.oc_ntt_lvl(oc.h, L - 1, a.ctypes.data, b.ctypes.data)
         out["cpu_baseline"] = cpu_baseline(mk_ntt, L, "limb-NTT/s", "oracle Context.NTT on R15 (N=2^%d, %d limbs), one poly per call" % (args.logn, L), 10.0)
     if rank == 0:
+        r = out["roofline"]
+        v = r.get("valu") or {}
+        if v.get("instr_per_wave") and v.get("issue_frac_sustained"):
+            # why the 60-bit transform sits at 0.40: the four numbers it follows from
+            cpi_ubench = 5.2      # clocks per instruction of an alternating v_mad_u64_u32 / v_add_u32 stream, one wave per SIMD (profiles/r02/asm_energy.txt)
+            per_simd = v["instructions"] / SIMDS
+            sclk = v["sclk_MHz"] * 1e6
+            r["floor"] = {"valu_instructions_per_wave": v["instr_per_wave"], "waves": v["waves"], "simds": SIMDS,
+                          "clocks_per_instruction_in_run": 4.0 / v["issue_frac_sustained"],
+                          "clocks_per_instruction_of_the_multiply_mix_alone": cpi_ubench,
+                          "sclk_MHz_sustained": v["sclk_MHz"], "sclk_MHz_peak": NOMINAL_SCLK_HZ / 1e6, "package_power": power,
+                          "model_ms": per_simd * cpi_ubench / sclk * 1e3, "measured_ms": r["kernel_ms"],
+                          "frac_of_the_model": r["algorithmic_bytes_per_launch"] / (per_simd * cpi_ubench / sclk) / 1e9 / HBM_PEAK_GBS,
+                          "reading": "instructions per SIMD x clocks per instruction of the butterfly's multiply mix / the clock the package power limit leaves = the "
+                                     "launch time to within a few percent: the kernel is at its vector-issue floor, and 9 of the 14 butterfly instructions are the 32-bit "
+                                     "multiplies a 60-bit Shoup product needs (DESIGN.md 3.1)"}
+        elif power:
+            r["floor"] = {"package_power": power, "note": "counters not collected in this run"}
+        # the figures a reader of the LAST kilobytes of this line needs (the driver keeps a 10 KB tail): fractions of the HBM roofline
+        ex = out.get("extras", {})
+        frac = lambda o: round(o["roofline"]["frac"], 4) if isinstance(o, dict) and "roofline" in o else None
+        ratio = lambda o: (round(o["roofline"]["traffic_source"]["ratio_to_algorithmic"], 3)
+                           if isinstance(o, dict) and isinstance(o.get("roofline", {}).get("traffic_source"), dict) and "ratio_to_algorithmic" in o["roofline"]["traffic_source"] else None)
+        summary = {"ntt_fwd_R15": {"limb_ntt_per_s": round(out["value"]), "frac": round(r["frac"], 4), "traffic_ratio": ratio(out), "bit_exact": out["bit_exact"]}}
+        for key, name in (("intt", "ntt_inv_R15"), ("ntt_ckks_moduli", "ntt_fwd_ckks_moduli"), ("intt_ckks_moduli", "ntt_inv_ckks_moduli"), ("modup_split_qp", "modup_R15")):
+            if key in ex:
+                summary[name] = {"frac": frac(ex[key]), "traffic_ratio": ratio(ex[key]), "bit_exact": ex[key].get("bit_exact")}
+        for key in ("mulcoeffs_montgomery", "div_round_by_last_modulus_ntt"):
+            if key in ex:
+                summary[key + "_R15"] = {"frac": round(ex[key]["frac_hbm"], 4), "bit_exact": ex[key].get("bit_exact")}
+        for key in ("ckks_mulrelin", "bfv_mul", "config5"):
+            if isinstance(out.get(key), dict) and "roofline" in out[key]:
+                summary[key] = {"per_s": round(out[key]["value"], 1), "frac": frac(out[key]), "traffic_ratio": ratio(out[key]), "bit_exact": out[key].get("bit_exact")}
+        for key, o in out.get("pipelines", {}).items():
+            summary[key] = {"per_s": round(o["value"], 1), "frac": frac(o), "traffic_ratio": ratio(o), "bit_exact": o.get("bit_exact"),
+                            "cpu_per_s": round(o["cpu_baseline"]["value"], 1) if "cpu_baseline" in o else None}
+        summary["runtime"] = {"GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES"), "note": "set by bench.py before HIP initialises (--hw-queues); only the "
+                              "evaluator_threads rows have more than one busy stream"}
+        r["companions"] = {k: v for k, v in summary.items() if k != "runtime"}      # (the driver's parsed record keeps the roofline object whole)
+        out["summary"] = summary
         emit(out)
     if use_dist:
         import torch.distributed as dist

@@ -51,6 +51,45 @@ def test_one_json_line_with_roofline_and_cpu_baseline():
     assert r["bound"] == ("valu" if v["issue_frac_sustained"] > r["frac"] else "hbm")
 
 
+def test_every_benchmarked_pipeline_has_a_roofline_and_a_cpu_baseline():
+    """every pipeline entry point the reference benchmarks carries `roofline` (in-run traffic, bound, vector issue, kernel
+    split) and `cpu_baseline` in the line, bfv_mul (BASELINE config 4) included; the short `summary` object is the LAST key (it survives a
+    tail of the line) and the headline roofline carries `floor` and `companions`"""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "5", "--warmup", "2", "--no-config5", "--no-rings", "--no-extras", "--no-threads"]
+    res = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [l for l in res.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_legs", os.path.join(ROOT, "tools", "bench_legs.py"))
+    bl = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bl)
+    legs = dict(d["pipelines"], bfv_mul=d["bfv_mul"], ckks_mulrelin=d["ckks_mulrelin"])
+    assert set(bl.LEG_NAMES) <= set(legs), sorted(set(bl.LEG_NAMES) - set(legs))
+    for name, o in legs.items():
+        assert o["bit_exact"] is True, (name, o.get("check_error"))
+        r, c = o["roofline"], o["cpu_baseline"]
+        assert r["bound"] in ("hbm", "valu") and r["unit"] == "GB/s" and r["peak"] == 8000.0 and 0 < r["frac"] < 1.0, name
+        assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12, name
+        assert r["traffic"] is not None and r["traffic_source"]["ratio_to_algorithmic"] > 0.5, (name, r.get("traffic_source"))
+        assert r["valu"]["issue_frac_sustained"] > 0, name
+        assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == o["unit"], name
+        if name != "ckks_mulrelin":
+            assert r["kernels"] and "reference_benchmark" in o, name
+            assert abs(r["achieved"] - r["algorithmic_bytes_per_unit"] * r["units_per_call"] / (r["pipeline_ms"] * 1e-3) / 1e9) / r["achieved"] < 1e-9, name
+    assert list(d)[-1] == "summary"
+    s = d["summary"]
+    for name in list(bl.LEG_NAMES) + ["ckks_mulrelin", "ntt_fwd_R15"]:
+        assert s[name]["frac"] is not None and s[name]["bit_exact"] is True, name
+    assert len(json.dumps(s)) < 6000                       # it has to fit the tail of the line
+    f = d["roofline"]["floor"]
+    assert 4300 < f["valu_instructions_per_wave"] < 4450 and 3.9 < f["clocks_per_instruction_in_run"] < 8 and 1000 < f["sclk_MHz_sustained"] <= 2500
+    assert 0.5 < f["model_ms"] / f["measured_ms"] < 1.5
+    assert d["roofline"]["companions"]["ckks_mulrelin"]["frac"] == s["ckks_mulrelin"]["frac"]
+    assert "traffic_profile" not in d["roofline"] or "r04" in d["roofline"]["traffic_profile"]
+
+
 def test_secondary_legs_carry_their_roofs_and_the_rescale_leg():
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "5", "--warmup", "2", "--no-config5", "--no-rings", "--no-ckks", "--no-cpu-baseline"]
     res = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600)

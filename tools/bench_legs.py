@@ -1,0 +1,439 @@
+"""The pipeline legs of bench.py: every ring / ckks / bfv entry point the reference benchmarks beyond the headline transforms, each as
+one timed call over a device-resident batch (working set far above the 256 MiB Infinity Cache), with its algorithmic HBM bytes per unit
+(SURVEY.md 8(d)'s accounting: operands read once, results written once, a switching key counted once per unit), an oracle comparison
+of the last unit and a CPU-oracle worker for the baseline.
+
+    ring/ring_benchmark_test.go:310-404   ModDown / ModDownNTT, DivFloor / DivFloorNTT / DivRound (DivRoundNTT is in bench.py's extras)
+    ckks/ckks_benchmarks_test.go:79-240   Encrypt (pk), Decrypt, Rescale, Mul, Relin, Conjugate, Rotate, RotateHoisted
+    bfv/bfv_benchmark_test.go:133-162     Mul, Relin, RotateRows, RotateCols
+    ring/ring_scaling.go:275              SimpleScaler.Scale (bfv decoding);  ring/ring_object.go:252  Poly.UnmarshalBinary (ingest)
+
+bench.py times the legs and tools/dbg/legs_pmc.py replays them under `rocprofv3 --pmc` (one call per leg between marker kernels), so
+both see the same shapes.  Nothing here is product code: the product is the C ABI these legs call through lattigo-fhe-by-go_amd/ring.py.
+"""
+import numpy as np
+
+
+class Leg:
+    def __init__(self, name, unit, units_per_call, bytes_per_unit, params, ref, run, check, cpu, batch, reps=10, note=None, sync=None, host_bytes_per_unit=0,
+                 after=None, cpu_units=1):
+        self.name, self.unit, self.units_per_call, self.bytes_per_unit = name, unit, units_per_call, bytes_per_unit
+        self.params, self.ref, self.run, self.check, self.cpu, self.batch, self.reps, self.note = params, ref, run, check, cpu, batch, reps, note
+        self.sync = sync                       # the context whose stream the leg runs on (TimerStart / TimerStop / Sync)
+        self.host_bytes_per_unit = host_bytes_per_unit   # > 0: the entry point takes host buffers (PCIe inside the timed call)
+        self.after = after or (lambda: None)   # puts shared operands back into the shape the next leg expects
+        self.cpu_units = cpu_units             # units one call of the CPU worker processes
+
+
+class Kits:
+    """Operands of one parameter set, built once and shared by its legs."""
+
+    def __init__(self, pkg, device=0):
+        self.pkg, self.device = pkg, device
+        self.ring, self.params, self.sampling = pkg.ring, pkg.params, pkg.sampling
+        self._kits = {}
+
+    def fill(self, ctx, dst, pair):
+        """two distinct polys (host [2, limbs, N]) tiled over dst's batch on the device: even units take pair[0], odd ones pair[1]"""
+        limbs, N = pair.shape[1], pair.shape[2]
+        if dst.batch == 1:
+            return dst.set(pair[:1])
+        for k in range(2):
+            cnt = (dst.batch - k + 1) // 2
+            src = self.ring.Poly(ctx, limbs, 1).set(pair[k:k + 1])
+            view = self.ring.Poly.wrap_strided(ctx, dst.device_ptr + k * limbs * N * 8, limbs, cnt, 2 * limbs)
+            ctx.CopyLvl(limbs - 1, src, view)
+        ctx.Sync()
+        return dst
+
+    def kit(self, name):
+        if name not in self._kits:
+            self._kits[name] = getattr(self, "_kit_" + name)()
+        return self._kits[name]
+
+    def drop(self, name):
+        self._kits.pop(name, None)
+
+    # ring.DefaultParamsQi / Pi [15]: the reference's benchmark ring of the headline
+    def _kit_ring15(self):
+        ring, params, sampling = self.ring, self.params, self.sampling
+        N, Q = params.DefaultParamsQi(15)
+        _, P = params.DefaultParamsPi(15)
+        B = (1 << 30) // (8 * N * len(Q))
+        cq, cp = ring.NewContextWithParams(N, Q, device=self.device), ring.NewContextWithParams(N, P, device=self.device)
+        pq, pp = sampling.uniform_poly(Q, N, 2, seed=0x51), sampling.uniform_poly(P, N, 2, seed=0x52)
+        a, p = self.fill(cq, cq.NewPoly(B), pq), self.fill(cp, cp.NewPoly(B), pp)
+        return dict(N=N, Q=Q, P=P, B=B, cq=cq, cp=cp, be=ring.NewFastBasisExtender(cq, cp), pq=pq, pp=pp, a=a, p=p, w=cq.NewPoly(B), wp=cp.NewPoly(B))
+
+    def _kit_ckks15(self):
+        ring, params, sampling = self.ring, self.params, self.sampling
+        N, Q, P = params.ckks_moduli("PN15QP880")
+        Q, P = list(Q), list(P)
+        nq, np_ = len(Q), len(P)
+        B = 128
+        cq, cp = ring.NewContextWithParams(N, Q, device=self.device), ring.NewContextWithParams(N, P, device=self.device)
+        plan = ring.CkksPlan(cq, cp, B)
+        beta = -(-nq // np_)
+        keys_h = [sampling.uniform_poly(Q + P, N, 2 * beta, seed=9 + r) for r in range(8)]
+        keys = [plan.NewSwitchingKey().set(k) for k in keys_h]
+        comp_h = [sampling.uniform_poly(Q, N, 2, seed=3 + k) for k in range(4)]             # a0, a1, b0, b1: two distinct ciphertext pairs
+        comp = [self.fill(cq, cq.NewPoly(B), c) for c in comp_h]
+        return dict(N=N, Q=Q, P=P, nq=nq, np_=np_, B=B, level=nq - 1, beta=beta, cq=cq, cp=cp, plan=plan, keys_h=keys_h, keys=keys,
+                    comp_h=comp_h, comp=comp, out=[cq.NewPoly(B) for _ in range(3)])
+
+    def _kit_bfv14(self):
+        ring, params, sampling = self.ring, self.params, self.sampling
+        N, Q, P, QM = params.bfv_moduli("PN14QP438")
+        Q, P, QM = list(Q), list(P), list(QM)
+        nq, np_ = len(Q), len(P)
+        B = 256
+        cq, cp, cm = (ring.NewContextWithParams(N, m, device=self.device) for m in (Q, P, QM))
+        plan = ring.CkksPlan(cq, cp, B)                 # the key-switch half of bfv.NewEvaluator (bfv/evaluator.go:100-112)
+        mul = ring.BfvPlan(cq, cm, 65537, B)
+        beta = -(-nq // np_)
+        key_h = sampling.uniform_poly(Q + P, N, 2 * beta, seed=19)
+        key = plan.NewSwitchingKey().set(key_h)
+        comp_h = [sampling.uniform_poly(Q, N, 2, seed=5 + k) for k in range(4)]
+        comp = [self.fill(cq, cq.NewPoly(B), c) for c in comp_h]
+        return dict(N=N, Q=Q, P=P, QM=QM, nq=nq, np_=np_, B=B, beta=beta, cq=cq, cp=cp, cm=cm, plan=plan, mul=mul, key_h=key_h, key=key,
+                    comp_h=comp_h, comp=comp, out=[cq.NewPoly(B) for _ in range(3)])
+
+
+def _last(poly, batch, limbs, N, b=None):
+    """unit b (default: the last) of a device poly as [limbs, N]"""
+    return np.stack(poly.get_limb_slices(batch - 1 if b is None else b, limbs))
+
+
+def build_legs(pkg, oracle, device=0, only=None):
+    """-> (kits, [Leg]); oracle may be None (the counter replay does no checks and no CPU baselines: check / cpu are then unusable).
+    Legs are built lazily by group: iterate with `for leg in legs:` and call kits.drop(<group>) between groups to release HBM."""
+    kits = Kits(pkg, device)
+    ring, params, sampling, nat = pkg.ring, pkg.params, pkg.sampling, pkg._native
+    legs = []
+    want = lambda n: only is None or n in only
+
+    # ------------------------------------------------------------------------------------------------ ring level, R15
+    def ring_legs():
+        k = kits.kit("ring15")
+        N, Q, P, B, cq, cp, be, a, p, w, wp = (k[x] for x in ("N", "Q", "P", "B", "cq", "cp", "be", "a", "p", "w", "wp"))
+        L, K = len(Q), len(P)
+        level = L - 1
+        tag = "ring.DefaultParamsQi/Pi[15] (N=2^15, %d Q + %d P limbs of 60 bits), %d polys" % (L, K, B)
+        last = (B - 1) % 2
+        ocq = lambda: oracle.Context(N, Q)
+        obe = lambda: oracle.BasisExtender(oracle.Context(N, Q), oracle.Context(N, P))
+
+        def reset():
+            cq.Copy(a, w)
+            cp.Copy(p, wp)
+
+        def md_check(fn, ofn):
+            reset()
+            fn()
+            return bool(np.array_equal(_last(w, B, L, N), ofn(obe())(level, k["pq"][last], k["pp"][last])))
+
+        def md_cpu(ofn):
+            def mk(i):
+                be_i = obe()
+                f, x, y = ofn(be_i), k["pq"][0].copy(), k["pp"][0].copy()
+                return lambda: f(level, x, y)
+            return mk
+        # the reference calls ModDownSplited*(level, p0, p1, p0): in place on the Q part (ring_benchmark_test.go:335-345)
+        out = []
+        if want("moddown_ntt"):
+            reset()
+            out.append(Leg("moddown_ntt", "poly/s", B, 8 * N * (2 * L + K), tag, "ring/ring_benchmark_test.go:341-345 (ModDownNTT = ModDownSplitedNTTPQ, in place)",
+                           lambda: be.ModDownSplitedNTTPQ(level, w, wp, w),
+                           lambda: md_check(lambda: be.ModDownSplitedNTTPQ(level, w, wp, w), lambda o: o.moddown_split_ntt_pq),
+                           md_cpu(lambda o: o.moddown_split_ntt_pq), B, sync=cq,
+                           note="reads the Q part and the P part, writes the Q part; the P part is also left inverse-transformed in place (8N*K more written, not counted)"))
+        if want("moddown"):
+            out.append(Leg("moddown", "poly/s", B, 8 * N * (2 * L + K), tag, "ring/ring_benchmark_test.go:335-339 (ModDown = ModDownSplitedPQ, in place)",
+                           lambda: be.ModDownSplitedPQ(level, w, wp, w),
+                           lambda: md_check(lambda: be.ModDownSplitedPQ(level, w, wp, w), lambda o: o.moddown_split_pq),
+                           md_cpu(lambda o: o.moddown_split_pq), B, sync=cq))
+        for nm, meth, oname, ref in (("div_floor_ntt", "DivFloorByLastModulusNTT", "oc_div_floor_by_last_modulus_ntt", ":365-373 (FloorNTT)"),
+                                     ("div_floor", "DivFloorByLastModulus", "oc_div_floor_by_last_modulus", ":354-362 (Floor)"),
+                                     ("div_round", "DivRoundByLastModulus", "oc_div_round_by_last_modulus", ":376-384 (Round)")):
+            if not want(nm):
+                continue
+
+            def run(meth=meth):
+                nat.check(nat.lib().lr_poly_set_limbs(w.h, L))      # in place, drops the last limb: the count goes back up per call
+                getattr(cq, meth)(w)
+
+            def check(meth=meth, oname=oname):
+                nat.check(nat.lib().lr_poly_set_limbs(w.h, L))
+                cq.Copy(a, w)
+                getattr(cq, meth)(w)
+                got = _last(w, B, L - 1, N)
+                nat.check(nat.lib().lr_poly_set_limbs(w.h, L))
+                return bool(np.array_equal(got, ocq().rescale_op(oname, k["pq"][last])))
+
+            def cpu(i, oname=oname):
+                oc_i, x = ocq(), k["pq"][0].copy()
+                return lambda: oc_i.rescale_op(oname, x)
+            out.append(Leg(nm, "poly/s", B, 8 * N * (2 * L - 1), tag, "ring/ring_benchmark_test.go" + ref, run, check, cpu, B, sync=cq,
+                           after=lambda: nat.check(nat.lib().lr_poly_set_limbs(w.h, L))))
+        return out
+
+    # ------------------------------------------------------------------------------------------------ ckks, PN15QP880
+    def ckks_legs():
+        k = kits.kit("ckks15")
+        N, Q, P, nq, np_, B, level, beta, cq, cp, plan, keys, comp, outp = (k[x] for x in (
+            "N", "Q", "P", "nq", "np_", "B", "level", "beta", "cq", "cp", "plan", "keys", "comp", "out"))
+        l, kP = nq, np_
+        keyb = 2 * beta * (l + kP)                       # limbs of one switching key
+        tag = "ckks.DefaultParams[PN15QP880] (N=2^15, %d Q + %d P limbs, beta=%d), level %d, %d ciphertexts" % (nq, np_, beta, level, B)
+        last = (B - 1) % 2
+        oplan = lambda: oracle.CkksPlan(oracle.Context(N, Q), oracle.Context(N, P))
+        ct_h = lambda j, u: np.stack([k["comp_h"][2 * j][u], k["comp_h"][2 * j + 1][u]])
+        key_h = lambda r: k["keys_h"][r].reshape(beta, 2, nq + np_, N)
+        out = []
+
+        def two(p0, p1, want):
+            return bool(np.array_equal(_last(p0, B, want[0].shape[0], N), want[0]) and np.array_equal(_last(p1, B, want[1].shape[0], N), want[1]))
+
+        if want("ckks_rescale"):
+            w0, w1 = outp[0], outp[1]
+
+            def run():
+                nat.check(nat.lib().lr_poly_set_limbs(w0.h, nq))
+                nat.check(nat.lib().lr_poly_set_limbs(w1.h, nq))
+                plan.Rescale((w0, w1))
+
+            def check():
+                nat.check(nat.lib().lr_poly_set_limbs(w0.h, nq))
+                nat.check(nat.lib().lr_poly_set_limbs(w1.h, nq))
+                cq.Copy(comp[0], w0)
+                cq.Copy(comp[1], w1)
+                plan.Rescale((w0, w1))
+                oc = oracle.Context(N, Q)
+                ok = two(w0, w1, [oc.rescale_op("oc_div_round_by_last_modulus_ntt", ct_h(0, last)[j]) for j in range(2)])
+                nat.check(nat.lib().lr_poly_set_limbs(w0.h, nq))
+                nat.check(nat.lib().lr_poly_set_limbs(w1.h, nq))
+                return ok
+
+            def cpu(i):
+                oc, x = oracle.Context(N, Q), ct_h(0, 0).copy()
+                return lambda: (oc.rescale_op("oc_div_round_by_last_modulus_ntt", x[0]), oc.rescale_op("oc_div_round_by_last_modulus_ntt", x[1]))
+            cq.Copy(comp[0], w0)
+            cq.Copy(comp[1], w1)
+            out.append(Leg("ckks_rescale", "Rescale/s", B, 2 * 8 * N * (2 * l - 1), tag, "ckks/ckks_benchmarks_test.go:152-164 (Rescale: DivRoundByLastModulusNTT on both components)",
+                           run, check, cpu, B, sync=cq,
+                           after=lambda: (nat.check(nat.lib().lr_poly_set_limbs(w0.h, nq)), nat.check(nat.lib().lr_poly_set_limbs(w1.h, nq)))))
+        if want("ckks_mul"):
+            def check():
+                plan.MulRelin(level, (comp[0], comp[1]), (comp[2], comp[3]), None, outp)
+                wantv = oplan().mul_norelin(level, ct_h(0, last), ct_h(1, last))
+                return bool(all(np.array_equal(_last(outp[j], B, nq, N), wantv[j]) for j in range(3)))
+
+            def cpu(i):
+                op, x, y = oplan(), ct_h(0, 0), ct_h(1, 0)
+                return lambda: op.mul_norelin(level, x, y)
+            out.append(Leg("ckks_mul", "Mul/s", B, 8 * N * 7 * l, tag, "ckks/ckks_benchmarks_test.go:166-170 (Mul: MulRelin with evakey == nil, degree-2 result)",
+                           lambda: plan.MulRelin(level, (comp[0], comp[1]), (comp[2], comp[3]), None, outp), check, cpu, B, reps=20, sync=cq))
+        if want("ckks_relinearize"):
+            # Relinearize (ckks/evaluator.go:1144-1162) as the Go overlay runs it: switchKeysInPlace of the degree-2 part, then the two AddLvl
+            def run():
+                plan.SwitchKeysInPlace(level, comp[2], keys[0], outp[0], outp[1])
+                cq.AddLvl(level, comp[0], outp[0], outp[0])
+                cq.AddLvl(level, comp[1], outp[1], outp[1])
+
+            def check():
+                run()
+                p0, p1 = oplan().switch_keys(level, k["comp_h"][2][last], key_h(0))
+                oc = oracle.Context(N, Q)
+                return two(outp[0], outp[1], [oc.ewise("ADD", k["comp_h"][0][last], p0), oc.ewise("ADD", k["comp_h"][1][last], p1)])
+
+            def cpu(i):
+                op, oc, c = oplan(), oracle.Context(N, Q), [k["comp_h"][j][0] for j in range(3)]
+                kk = key_h(0)
+
+                def f():
+                    p0, p1 = op.switch_keys(level, c[2], kk)
+                    oc.ewise("ADD", c[0], p0)
+                    oc.ewise("ADD", c[1], p1)
+                return f
+            out.append(Leg("ckks_relinearize", "Relin/s", B, 8 * N * (3 * l + keyb + 2 * l), tag,
+                           "ckks/ckks_benchmarks_test.go:178-182 (Relin: switchKeysInPlace of the degree-2 part + two AddLvl, ckks/evaluator.go:1144-1162)",
+                           run, check, cpu, B, sync=cq))
+        for nm, gen, ref in (("ckks_rotate", pow(5, 1, 2 * N), ":190-194 (Rotate: RotateColumns by 1 = permuteNTT with GaloisGen)"),
+                             ("ckks_conjugate", 2 * N - 1, ":184-188 (Conjugate = permuteNTT with 2N - 1)")):
+            if not want(nm):
+                continue
+
+            def check(gen=gen):
+                plan.PermuteNTT(level, (comp[0], comp[1]), gen, keys[1], (outp[0], outp[1]))
+                return two(outp[0], outp[1], oplan().permute_ntt(level, ct_h(0, last), gen, key_h(1)))
+
+            def cpu(i, gen=gen):
+                op, x, kk = oplan(), ct_h(0, 0), key_h(1)
+                return lambda: op.permute_ntt(level, x, gen, kk)
+            out.append(Leg(nm, "rotation/s", B, 8 * N * (4 * l + keyb), tag, "ckks/ckks_benchmarks_test.go" + ref,
+                           lambda gen=gen: plan.PermuteNTT(level, (comp[0], comp[1]), gen, keys[1], (outp[0], outp[1])), check, cpu, B, sync=cq))
+        if want("ckks_rotate_hoisted"):
+            R = 8
+            gens = [pow(5, r + 1, 2 * N) for r in range(R)]
+            Bh = 32                                        # 8 output ciphertexts per input: 32 x (2 + 16) components of 4.7 MB
+            hin = (kits.fill(cq, cq.NewPoly(Bh), k["comp_h"][0]), kits.fill(cq, cq.NewPoly(Bh), k["comp_h"][1]))
+            houts = [(cq.NewPoly(Bh), cq.NewPoly(Bh)) for _ in range(R)]
+            hplan = ring.CkksPlan(cq, cp, Bh)
+            hlast = (Bh - 1) % 2
+            k["hoisted"] = (hin, houts, hplan)
+
+            def check():
+                hplan.RotateHoisted(level, hin, gens, keys, houts)
+                wantv = oplan().rotate_hoisted(level, ct_h(0, hlast), gens, [key_h(r) for r in range(R)])
+                return bool(all(np.array_equal(_last(houts[r][j], Bh, nq, N), wantv[r][j]) for r in range(R) for j in range(2)))
+
+            def cpu(i):
+                op, x, kk = oplan(), ct_h(0, 0), [key_h(r) for r in range(R)]
+                return lambda: op.rotate_hoisted(level, x, gens, kk)
+            out.append(Leg("ckks_rotate_hoisted", "rotation/s", Bh * R, 8 * N * (2 * l + R * (keyb + 2 * l)) // R,
+                           tag.replace("%d ciphertexts" % B, "%d ciphertexts x %d rotations each" % (Bh, R)),
+                           "ckks/ckks_benchmarks_test.go:199-240 (DecomposeNTT once + switchKeyHoisted per rotation = evaluator.RotateHoisted, ckks/evaluator.go:1252)",
+                           lambda: hplan.RotateHoisted(level, hin, gens, keys, houts), check, cpu, Bh, reps=5, sync=cq, cpu_units=R,
+                           note="bytes per rotation: the shared input ciphertext divided over the %d rotations, one key and one output ciphertext each" % R))
+        if want("ckks_encrypt_pk") or want("ckks_decrypt"):
+            QP = Q + P
+            cqp = ring.NewContextWithParams(N, QP, device=device)     # only to tile the Q||P operands on the device
+            qp_h = [sampling.uniform_poly(QP, N, 2, seed=21 + j) for j in range(3)]                  # u, e0, e1
+            pk_h = [sampling.uniform_poly(QP, N, 1, seed=31 + j) for j in range(2)]
+            QPpoly = lambda b: ring.Poly(cq, nq + np_, b)
+            u, e0, e1 = (kits.fill(cqp, QPpoly(B), h) for h in qp_h)
+            pk = (QPpoly(1).set(pk_h[0]), QPpoly(1).set(pk_h[1]))
+            sk_h = sampling.uniform_poly(Q, N, 1, seed=8)
+            sk = cq.NewPoly(1).set(sk_h)
+            k["enc"] = (u, e0, e1, pk, sk, cqp)
+            if want("ckks_encrypt_pk"):
+                def check():
+                    plan.EncryptPk(level, u, pk, (e0, e1), comp[0], (outp[0], outp[1]))
+                    wantv = oplan().encrypt_pk(oracle.Context(N, QP), level, qp_h[0][last], pk_h[0][0], pk_h[1][0], qp_h[1][last], qp_h[2][last], k["comp_h"][0][last])
+                    return two(outp[0], outp[1], wantv)
+
+                def cpu(i):
+                    op, ocqp = oplan(), oracle.Context(N, QP)
+                    return lambda: op.encrypt_pk(ocqp, level, qp_h[0][0], pk_h[0][0], pk_h[1][0], qp_h[1][0], qp_h[2][0], k["comp_h"][0][0])
+                out.append(Leg("ckks_encrypt_pk", "Encrypt/s", B, 8 * N * (5 * (l + kP) + 3 * l), tag,
+                               "ckks/ckks_benchmarks_test.go:79-100 (Encrypt with the public key, the branch through the special primes ckks/encryptor.go:205-234, after the sampling)",
+                               lambda: plan.EncryptPk(level, u, pk, (e0, e1), comp[0], (outp[0], outp[1])), check, cpu, B, sync=cq,
+                               note="u, e0, e1 and the public key over Q||P, the plaintext over Q, two components out; sampling stays on the host (SURVEY 8(f)2)"))
+            if want("ckks_decrypt"):
+                def check():
+                    plan.Decrypt(level, (comp[0], comp[1]), sk, outp[2])
+                    return bool(np.array_equal(_last(outp[2], B, nq, N), oplan().decrypt(level, ct_h(0, last), sk_h[0])))
+
+                def cpu(i):
+                    op, x = oplan(), ct_h(0, 0)
+                    return lambda: op.decrypt(level, x, sk_h[0])
+                out.append(Leg("ckks_decrypt", "Decrypt/s", B, 8 * N * 4 * l, tag, "ckks/ckks_benchmarks_test.go:103-118 (Decrypt of a degree-1 ciphertext, ckks/decryptor.go:53-78)",
+                               lambda: plan.Decrypt(level, (comp[0], comp[1]), sk, outp[2]), check, cpu, B, reps=20, sync=cq))
+        if want("marshal_ingest"):
+            # Poly.UnmarshalBinary (ring/ring_object.go:252) of one ciphertext component per call: the big-endian bytes cross PCIe as they are
+            # and are swapped on the device (lr_poly_unmarshal); the entry point takes a host buffer and synchronises
+            blob = bytes([15, nq]) + k["comp_h"][0][0].astype(">u8").tobytes()
+            dst = cq.NewPoly(8)
+            cnt = [0]
+
+            def run():
+                for b in range(8):
+                    dst.UnmarshalBinary(blob, b)
+
+            def check():
+                run()
+                return bool(np.array_equal(_last(dst, 8, nq, N), k["comp_h"][0][0]))
+
+            def cpu(i):
+                # the reference's DecodeCoeffs loop (ring/ring_object.go:197-207): big-endian words into [][]uint64
+                buf = np.frombuffer(blob, dtype=">u8", offset=2)
+                return lambda: buf.astype(np.uint64).reshape(nq, N)
+            out.append(Leg("marshal_ingest", "poly/s", 8, 16 * N * l, "one PN15QP880 ciphertext component (18 limbs, %.1f MB serialized) per call, host buffer in" % (len(blob) / 1e6),
+                           "ring/ring_object.go:252-270 (Poly.UnmarshalBinary), :197-207 (DecodeCoeffs)", run, check, cpu, 8, reps=3, sync=cq,
+                           host_bytes_per_unit=len(blob),
+                           note="PCIe-inclusive by construction (the boundary hands over host bytes); the device part is the byte-swap kernel, 16N*L bytes"))
+        return out
+
+    # ------------------------------------------------------------------------------------------------ bfv, PN14QP438
+    def bfv_legs():
+        k = kits.kit("bfv14")
+        N, Q, P, QM, nq, np_, B, beta, cq, cp, cm, plan, mul, key, comp, outp = (k[x] for x in (
+            "N", "Q", "P", "QM", "nq", "np_", "B", "beta", "cq", "cp", "cm", "plan", "mul", "key", "comp", "out"))
+        l, kP = nq, np_
+        keyb = 2 * beta * (l + kP)
+        tag = "bfv.DefaultParams[PN14QP438] (N=2^14, %d Q + %d P limbs, %d QMul limbs, t=65537), %d ciphertexts" % (nq, np_, len(QM), B)
+        last = (B - 1) % 2
+        oks = lambda: oracle.CkksPlan(oracle.Context(N, Q), oracle.Context(N, P))
+        kh = k["key_h"].reshape(beta, 2, nq + np_, N)
+        ct_h = lambda j, u: np.stack([k["comp_h"][2 * j][u], k["comp_h"][2 * j + 1][u]])
+        out = []
+        if want("bfv_mul"):
+            def check():
+                mul.Mul((comp[0], comp[1]), (comp[2], comp[3]), outp)
+                wantv = oracle.BfvPlan(oracle.Context(N, Q), oracle.Context(N, QM), 65537).mul(ct_h(0, last), ct_h(1, last))
+                return bool(all(np.array_equal(_last(outp[j], B, nq, N), wantv[j]) for j in range(3)))
+
+            def cpu(i):
+                op, x, y = oracle.BfvPlan(oracle.Context(N, Q), oracle.Context(N, QM), 65537), ct_h(0, 0), ct_h(1, 0)
+                return lambda: op.mul(x, y)
+            out.append(Leg("bfv_mul", "Mul/s", B, 8 * N * 7 * l, tag, "bfv/bfv_benchmark_test.go:133-137 (Mul = tensorAndRescale, bfv/evaluator.go:278-464); BASELINE.json config 4",
+                           lambda: mul.Mul((comp[0], comp[1]), (comp[2], comp[3]), outp), check, cpu, B, sync=cq))
+        if want("bfv_relinearize"):
+            def check():
+                plan.BfvRelinearize((comp[0], comp[1], comp[2]), key, (outp[0], outp[1]))
+                wantv = oks().bfv_relinearize(np.stack([k["comp_h"][j][last] for j in range(3)]), kh)
+                return bool(all(np.array_equal(_last(outp[j], B, nq, N), wantv[j]) for j in range(2)))
+
+            def cpu(i):
+                op, x = oks(), np.stack([k["comp_h"][j][0] for j in range(3)])
+                return lambda: op.bfv_relinearize(x, kh)
+            out.append(Leg("bfv_relinearize", "Relin/s", B, 8 * N * (3 * l + keyb + 2 * l), tag, "bfv/bfv_benchmark_test.go:145-149 (Relin of a degree-2 ciphertext, bfv/evaluator.go:480-501)",
+                           lambda: plan.BfvRelinearize((comp[0], comp[1], comp[2]), key, (outp[0], outp[1])), check, cpu, B, sync=cq))
+        for nm, gen, ref in (("bfv_rotate_rows", 2 * N - 1, ":151-155 (RotateRows: permute with galElRotRow = 2N - 1)"),
+                             ("bfv_rotate_columns", pow(5, 1, 2 * N), ":157-161 (RotateCols by 1: permute with GaloisGen)")):
+            if not want(nm):
+                continue
+
+            def check(gen=gen):
+                plan.BfvPermute((comp[0], comp[1]), gen, key, (outp[0], outp[1]))
+                wantv = oks().bfv_permute(ct_h(0, last), gen, kh)
+                return bool(all(np.array_equal(_last(outp[j], B, nq, N), wantv[j]) for j in range(2)))
+
+            def cpu(i, gen=gen):
+                op, x = oks(), ct_h(0, 0)
+                return lambda: op.bfv_permute(x, gen, kh)
+            out.append(Leg(nm, "rotation/s", B, 8 * N * (4 * l + keyb), tag, "bfv/bfv_benchmark_test.go" + ref + ", bfv/evaluator.go:711-735",
+                           lambda gen=gen: plan.BfvPermute((comp[0], comp[1]), gen, key, (outp[0], outp[1])), check, cpu, B, sync=cq))
+        if want("simple_scaler"):
+            # SimpleScaler.Scale (ring/ring_scaling.go:275): the decoding step of bfv (bfv/encoder.go:142), every limb of Q in, one limb (contextT) out
+            ct_ctx = ring.NewContextWithParams(N, [65537], device=device)
+            sc = ring.NewSimpleScaler(65537, cq)
+            so = ct_ctx.NewPoly(B)
+            k["scaler"] = (ct_ctx, sc, so)
+
+            def check():
+                sc.Scale(comp[0], so)
+                wantv = oracle.SimpleScaler(65537, oracle.Context(N, Q)).scale(k["comp_h"][0][last], 1)
+                return bool(np.array_equal(_last(so, B, 1, N), wantv))
+
+            def cpu(i):
+                s, x = oracle.SimpleScaler(65537, oracle.Context(N, Q)), k["comp_h"][0][0]
+                return lambda: s.scale(x, 1)
+            out.append(Leg("simple_scaler", "poly/s", B, 8 * N * (l + 1), tag.replace("ciphertexts", "polys"), "ring/ring_scaling.go:275-300 (SimpleScaler.Scale; bfv/encoder.go:142 decodes with it)",
+                           lambda: sc.Scale(comp[0], so), check, cpu, B, reps=20, sync=cq))
+        return out
+
+    def gated(gname, make):
+        # a group none of whose legs is wanted builds nothing (its kit is a few GB of HBM and some seconds of sampling)
+        return lambda: make() if only is None or (set(only) & set(GROUPS[gname])) else []
+    groups = tuple((g, gated(g, m)) for g, m in (("ring15", ring_legs), ("ckks15", ckks_legs), ("bfv14", bfv_legs)))
+    return kits, groups
+
+
+GROUPS = {"ring15": ["moddown_ntt", "moddown", "div_floor_ntt", "div_floor", "div_round"],
+          "ckks15": ["ckks_rescale", "ckks_mul", "ckks_relinearize", "ckks_rotate", "ckks_conjugate", "ckks_rotate_hoisted", "ckks_encrypt_pk", "ckks_decrypt",
+                     "marshal_ingest"],
+          "bfv14": ["bfv_mul", "bfv_relinearize", "bfv_rotate_rows", "bfv_rotate_columns", "simple_scaler"]}
+LEG_NAMES = ["moddown_ntt", "moddown", "div_floor_ntt", "div_floor", "div_round", "ckks_rescale", "ckks_mul", "ckks_relinearize", "ckks_rotate",
+             "ckks_conjugate", "ckks_rotate_hoisted", "ckks_encrypt_pk", "ckks_decrypt", "marshal_ingest", "bfv_mul", "bfv_relinearize",
+             "bfv_rotate_rows", "bfv_rotate_columns", "simple_scaler"]
