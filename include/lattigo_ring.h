@@ -30,7 +30,9 @@
  *  - threads: an lr_context is immutable after creation and may be shared by threads, each with its own polys / extender /
  *    decomposer / plan (the reference's goroutine-per-evaluator model); its temporaries are leased per call.  Every other handle
  *    is single-threaded, like the reference's FastBasisExtender and evaluators (their scratch polys, ring_basis_extension.go:16-17).
- *  - the LR_* environment switches of INTEGRATION.md section 7 are read once per handle, at its creation.
+ *  - configuration is an lr_options struct handed to the *_create_ex entry points (below); the plain *_create forms use the defaults.
+ *    The LR_* environment variables of INTEGRATION.md section 7 are a TEST-ONLY override of the same fields, read in one place
+ *    (lr::Options::apply_env) when a handle is created; a deployment sets none of them.
  */
 #ifndef LATTIGO_RING_H
 #define LATTIGO_RING_H
@@ -66,11 +68,68 @@ int lr_device_count(int *count);
 /* version / build info: "lattigo_ring <ver> gfx950 hip" */
 const char *lr_build_info(void);
 
+/* ------------------------------------------------------------------ options ---------- */
+/* Every switch selects between code paths that give THE SAME BITS (each has a parity test that runs both); the defaults are the measured
+ * best on MI355X.  A caller fills the struct with lr_options_init and changes what it wants; `struct_size` lets a library newer than its
+ * caller tell which fields the caller knows (fields beyond struct_size take their defaults), `version` must be LR_OPTIONS_VERSION.
+ * Flags: 0 = the default path, non-zero = the alternative the field names.  Thresholds: 0 = the built-in default (in parentheses;
+ * measured on PN15QP880 / PN16QP1761 / PN14QP438, DESIGN.md "decision table").  INTEGRATION.md section 7 maps every LR_* test variable
+ * to its field. */
+#define LR_OPTIONS_VERSION 1
+typedef struct lr_options {
+    uint32_t struct_size;           /* sizeof(lr_options) as the caller compiled it                                                   */
+    uint32_t version;               /* LR_OPTIONS_VERSION                                                                             */
+    /* --- transforms (lr_context) */
+    int32_t no_asm;                 /* C++ NTT kernels only (lr_ntt.hip) instead of the gfx950 assembly code objects                  */
+    int32_t no_fp;                  /* integer butterflies for every modulus (no FP64 body for the limbs below 2^46)                  */
+    int32_t ntt_mode;               /* -1 = by modulus size; 0 / 3: a more conservative lazy-correction mode of the C++ kernels       */
+    int32_t asm_variant;            /* -1 = by modulus size; 0 / 1: a more conservative integer variant of the assembly kernels       */
+    int32_t asm14_1024;             /* N = 2^14: the 1024-thread kernels at every launch size                                         */
+    int32_t no_wide14_small;        /* N = 2^14: the 512-thread kernels for small launches too                                        */
+    int32_t wide14_max_items;       /* N = 2^14: launches of at most this many transforms use the 1024-thread kernels (256)           */
+    int32_t ntt_split15;            /* N = 2^15 as two 2^14 sub-blocks: -1 = launches of at most split15_max_workgroups, 0 never, 1 always */
+    int32_t split15_max_workgroups; /* (128)                                                                                          */
+    int32_t no_invfuse;             /* N = 2^16 inverse: lazy sub-blocks + a separate last-stage pass instead of the pair-flag kernels */
+    int32_t no_grid_padding;        /* assembly launches with the limb count on grid x as it is (not padded to a multiple of eight)   */
+    int32_t ntt_stagger;            /* -1 / 0 = off; kilo-clocks per step of a start-up stagger of the first round of workgroups      */
+    int32_t ntt_persist;            /* diagnostics builds only (LR_BUILD_DIAG): polys per workgroup of the persistent forward kernels */
+    int32_t ntt_timeline;           /* diagnostics builds only: 2^15 launches run the clock-stamping builds (lr_context_timeline)     */
+    /* --- epilogues and the rescale (lr_context) */
+    int32_t no_epilogue;            /* separate subtract-multiply passes instead of the forward kernels' / extensions' epilogues      */
+    int32_t no_int_epilogue;        /* the epilogue on the FP64 bodies only                                                           */
+    int32_t rescale_unfused;        /* rounding rescale with explicit shifted copies                                                  */
+    int32_t rescale_unpaired;       /* lr_ckks_rescale: the two components one after the other at every batch size                    */
+    int32_t pair_max_workgroups;    /* two components of one ciphertext as ONE launch while it has at most this many workgroups (256) */
+    /* --- basis extension (lr_bext, lr_decomposer: taken from their first context) */
+    int32_t ext_narrow;             /* one Montgomery product per term instead of the 128-bit column sums                             */
+    int32_t ext_ieee_div;           /* IEEE division in the float correction instead of the reciprocal + two residual steps           */
+    int32_t no_ext_chunks;          /* a small batch's extension as one launch over all target columns                                */
+    /* --- key switch and the pipelines built on it (lr_ckks_plan) */
+    int32_t no_staging;             /* N = 2^16: in-place forward transforms after the digits' extensions                             */
+    int32_t no_exttop;              /* the top transform stage as its own pass instead of inside the extension                        */
+    int32_t no_invtop;              /* the inverse transform's last stage as its own pass instead of inside the extension             */
+    int32_t no_ext_group;           /* one extension launch per digit instead of one grouped launch                                   */
+    int32_t keymac_narrow;          /* one Montgomery product per term in the key inner product                                       */
+    int32_t no_pair;                /* a single ciphertext's two components as two launches                                           */
+    int32_t no_fork;                /* never run two independent launches of a lone plan side by side on an auxiliary stream          */
+    int32_t fork_below_workgroups;  /* fork only while the forked launch has fewer workgroups than this (256)                         */
+    /* --- bfv Mul (lr_bfv_plan) */
+    int32_t bfv_no_ext_epilogue;    /* SubScalarBigint / MulScalar as separate passes                                                 */
+    int32_t bfv_no_gather;          /* never gather the four operand polys of a small batch into one buffer                           */
+    int64_t bfv_gather_below;       /* gather while the joint transform has fewer workgroups than this (1536)                         */
+} lr_options;
+/* fills *opt with the defaults (struct_size = sizeof(lr_options) of THIS library, version = LR_OPTIONS_VERSION) */
+int lr_options_init(lr_options *opt);
+/* the options a handle ended up with, after the test-only environment override (diagnostics; struct_size / version of the library) */
+int lr_context_get_options(const lr_context *ctx, lr_options *out);
+
 /* ------------------------------------------------------------------ Context ---------- */
 /* ring.NewContextWithParams = SetParameters + GenNTTParams (ring/ring_context.go:60,68,129).
  * Computes every constant and psi table on the host exactly as the reference does
  * (incl. primitiveRoot's search order, ring/utils.go:182) and uploads them to `device`. */
 int lr_context_create(uint64_t N, const uint64_t *moduli, int n_moduli, int device, lr_context **out);
+/* the same with explicit options (NULL = defaults).  LR_ERR_ARG for a version this library does not know. */
+int lr_context_create_ex(uint64_t N, const uint64_t *moduli, int n_moduli, int device, const lr_options *opt, lr_context **out);
 int lr_context_destroy(lr_context *ctx);
 /* diagnostics: the assembly NTT variant the context's moduli select (forward, inverse): 0..2 = integer lazy-correction modes,
  * 3 = dual kernels (FP64 butterflies for the limbs below 2^46, integer body for the others), -1 = C++ kernels only */
@@ -296,6 +355,8 @@ int lr_div_round_by_last_modulus_many(lr_context *ctx, lr_poly *p0, int nb_resca
  * lr_ckks_plan owns what ckks.NewEvaluator builds: FastBasisExtender, Decomposer and the
  * scratch pools (ckks/evaluator.go:81-112). */
 int lr_ckks_plan_create(lr_context *ctxQ, lr_context *ctxP, int max_batch, lr_ckks_plan **out);
+/* the same with explicit options; NULL = the options of ctxQ (what lr_ckks_plan_create does) */
+int lr_ckks_plan_create_ex(lr_context *ctxQ, lr_context *ctxP, int max_batch, const lr_options *opt, lr_ckks_plan **out);
 /* Diagnostics of the small-batch paths of the key switch (no reference counterpart).  forks: how often two independent launches of a
  * pipeline (the digits' P rows beside their Q rows; ModDown's two components) went out side by side on the plan's auxiliary stream
  * instead of in order -- done at N = 2^16 (where one workgroup of such a launch runs long enough to pay for the hand-over) while the
@@ -396,6 +457,8 @@ int lr_ckks_rotate_hoisted(lr_ckks_plan *plan, int level, const lr_poly *c0, con
  * NewFastBasisExtender(contextQ, contextQMul), pHalf = (prod QMul) >> 1 and the scratch pools (bfv/evaluator.go:89-112). */
 typedef struct lr_bfv_plan lr_bfv_plan;
 int lr_bfv_plan_create(lr_context *ctxQ, lr_context *ctxQMul, uint64_t t, int max_batch, lr_bfv_plan **out);
+/* the same with explicit options; NULL = the options of ctxQ */
+int lr_bfv_plan_create_ex(lr_context *ctxQ, lr_context *ctxQMul, uint64_t t, int max_batch, const lr_options *opt, lr_bfv_plan **out);
 int lr_bfv_plan_destroy(lr_bfv_plan *plan);
 /* operands and results over Q in the coefficient domain, as BFV ciphertexts are; out has degree 2 */
 int lr_bfv_mul(lr_bfv_plan *plan, const lr_poly *ct0_c0, const lr_poly *ct0_c1, const lr_poly *ct1_c0,

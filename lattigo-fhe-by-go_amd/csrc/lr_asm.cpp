@@ -68,18 +68,13 @@ static int stagger_unit(int request, bool one_wg_per_cu, bool dual, unsigned lon
     return request > 0 ? request : 0;
 }
 
-static bool no_grid_padding() {
-    static const bool off = std::getenv("LR_NTT_NO_GRID_PADDING") != nullptr;   // diagnostics: the unpadded grid (read once per process)
-    return off;
-}
-
 bool ntt_asm_available(int logn) { return logn >= 12 && logn <= 16 && kernels_for_current_device() != nullptr; }
 
 // variant = lazy-correction mode of asmgen/gen_ntt.py (forward 0, 1, 2) / gen_intt.py (inverse 0, 1)
 // persist > 0 (forward 2^15, variants 0..3, no epilogue): the persistent kernels lr_ntt_fwd15p_*, `persist` polys per workgroup in a loop
 // with the next poly's column loads prefetched (gen_ntt.py: persist)
 hipError_t launch_ntt_asm(const NttLaunch &a, int logn, int inverse, int variant, hipStream_t stream, bool wide14, char *kernel_name, bool timeline,
-                          int stagger, int persist) {
+                          int stagger, int persist, bool pad_grid) {
     AsmKernels *k = kernels_for_current_device();
     if (!k || logn < 12 || logn > 15) return hipErrorNotSupported;
     if (persist > 0 && (logn != 15 || inverse || variant > 3)) persist = 0;     // (no persistent form of the epilogue kernels m4 / m5)
@@ -123,7 +118,7 @@ hipError_t launch_ntt_asm(const NttLaunch &a, int logn, int inverse, int variant
     // (profiles/r03/rescale_grid_padding.txt; the time moves by 1 % only -- the misses were Infinity Cache hits).  The padding
     // workgroups leave at once (gen_ntt.py: L_limb_ok).  Seven limbs at 2^14 fit the L2 as they are: padded, that launch was 5 % slower.
     unsigned gx_items = (unsigned)a.n_items;
-    if (!swapped && !timeline && !no_grid_padding() && (long long)a.n_items * (32ll << logn) > (4ll << 20) && (a.n_items & 7) != 0)
+    if (!swapped && !timeline && pad_grid && (long long)a.n_items * (32ll << logn) > (4ll << 20) && (a.n_items & 7) != 0)
         gx_items = ((unsigned)a.n_items + 7u) & ~7u;
     const unsigned gx = swapped ? gy : gx_items, gyy = swapped ? (unsigned)a.n_items : gy;
     args.stagger_gx = (int)gx;

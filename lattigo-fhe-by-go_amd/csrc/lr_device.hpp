@@ -24,9 +24,10 @@ struct LimbParams {
 
 constexpr int kMaxLimbs = 64;
 
-// Testing / diagnostic switches.  The environment is read ONCE PER HANDLE, when the handle is created
-// (lr_context_create, lr_bext_create, lr_decomposer_create, lr_*_plan_create): a caller's environment cannot change the code
-// path of a live handle in the middle of a run.
+// The library's configuration, one copy per handle, fixed when the handle is created: the internal image of the public lr_options
+// (include/lattigo_ring.h; from_public / to_public in lr_abi_core.cpp).  A deployment configures through lr_options and the *_create_ex
+// entry points; the LR_* environment variables named below are a TEST-ONLY override of the same fields, read in exactly one place
+// (apply_env) at handle creation -- a caller's environment cannot change the code path of a live handle in the middle of a run.
 struct Options {
     bool no_asm = false;           // LR_NO_ASM: C++ NTT kernels only
     bool no_fp = false;            // LR_NO_FP: integer bodies for every modulus
@@ -52,7 +53,22 @@ struct Options {
     int stagger = -1;              // LR_NTT_STAGGER: start-up stagger of the assembly NTT kernels in kilo-clocks per step (0 = off)
     int ntt_mode = -1;             // LR_NTT_MODE
     int asm_variant = -1;          // LR_ASM_VARIANT
-    static Options from_env();
+    bool ext_ieee_div = false;     // LR_EXT_IEEE_DIV: IEEE division in the extension's float correction (the reference-shaped kernel)
+    bool no_grid_padding = false;  // LR_NTT_NO_GRID_PADDING: assembly launches with the limb count on grid x unpadded
+    bool bfv_no_ext_epilogue = false;  // LR_BFV_NO_EXT_EPILOGUE
+    bool bfv_no_gather = false;    // LR_BFV_NO_GATHER
+    // launch-shape thresholds (measured defaults: DESIGN.md decision table)
+    int split15_max_workgroups = 128;   // LR_NTT_SPLIT15_BELOW: N = 2^15 launches of at most this many workgroups run as 2^14 sub-blocks
+    int wide14_max_items = 256;         // N = 2^14 launches of at most this many transforms use the 1024-thread kernels
+    int pair_max_workgroups = 256;      // two components of one ciphertext / the Q and P parts of one inner product as one launch up to here
+    int fork_below_workgroups = 256;    // LR_FORK_BELOW: a lone plan forks a launch below this many workgroups
+    long long bfv_gather_below = 1536;  // LR_BFV_GATHER_BELOW
+    void apply_env();              // the test-only override: the ONE place that reads LR_* variables
+    static Options from_env() {    // defaults + the override: what the plain *_create entry points use
+        Options o;
+        o.apply_env();
+        return o;
+    }
 };
 // small per-limb host values travelling in the kernel-argument segment (no host->device copy)
 struct LimbScalars { u64 v[kMaxLimbs]; };
@@ -370,7 +386,7 @@ bool ntt_asm_available(int logn);
 // kernel_name (optional, >= 32 bytes): receives the name of the code object that was launched
 // stagger: Options::stagger (kilo-clocks per step; 0 = off, -1 = the launcher's default for the kernel)
 hipError_t launch_ntt_asm(const NttLaunch &a, int logn, int inverse, int variant, hipStream_t stream, bool wide14 = false,
-                          char *kernel_name = nullptr, bool timeline = false, int stagger = -1, int persist = 0);
+                          char *kernel_name = nullptr, bool timeline = false, int stagger = -1, int persist = 0, bool pad_grid = true);
 hipError_t launch_ntt_asm16(const NttLaunch &a, int inverse, char kind, int variant, hipStream_t stream, char *kernel_name = nullptr,
                             int stagger = -1, int full_logn = 16);
 // N = 2^16 helpers (lr_ntt.hip): the streaming stage over bit 15, and whether no input row of a launch is an output row
