@@ -18,12 +18,35 @@ i32 = C.c_int
 STATUS = {0: "LR_OK", 1: "LR_ERR_INVALID_DEGREE", 2: "LR_ERR_NOT_NTT_FRIENDLY", 3: "LR_ERR_SHAPE",
           4: "LR_ERR_ARG", 5: "LR_ERR_HIP", 6: "LR_ERR_UNSUPPORTED", 7: "LR_ERR_NOMEM", 8: "LR_ERR_INTERNAL"}
 
+class Options(C.Structure):
+    """lr_options (include/lattigo_ring.h), field for field.  Options() is lr_options_init's image: every switch at its default."""
+    _fields_ = [("struct_size", C.c_uint32), ("version", C.c_uint32)] + [(n, C.c_int32) for n in (
+        "no_asm", "no_fp", "ntt_mode", "asm_variant", "asm14_1024", "no_wide14_small", "wide14_max_items", "ntt_split15", "split15_max_workgroups",
+        "no_invfuse", "no_grid_padding", "ntt_stagger", "ntt_persist", "ntt_timeline", "no_epilogue", "no_int_epilogue", "rescale_unfused",
+        "rescale_unpaired", "pair_max_workgroups", "ext_narrow", "ext_ieee_div", "no_ext_chunks", "no_staging", "no_exttop", "no_invtop",
+        "no_ext_group", "keymac_narrow", "no_pair", "no_fork", "fork_below_workgroups", "bfv_no_ext_epilogue", "bfv_no_gather")] + [("bfv_gather_below", C.c_int64)]
+
+    def __init__(self, **fields):
+        super().__init__()
+        check(lib().lr_options_init(C.byref(self)))
+        for k, v in fields.items():
+            if k not in dict(self._fields_):
+                raise AttributeError("lr_options has no field %r" % k)
+            setattr(self, k, int(v))
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
 # every symbol declared in include/lattigo_ring.h: name -> argtypes
 SYMBOLS = {
     "lr_last_error_string": [],
     "lr_device_count": [C.POINTER(i32)],
     "lr_build_info": [],
+    "lr_options_init": [vp],
+    "lr_context_get_options": [vp, vp],
     "lr_context_create": [u64, u64p, i32, i32, C.POINTER(vp)],
+    "lr_context_create_ex": [u64, u64p, i32, i32, vp, C.POINTER(vp)],
     "lr_context_destroy": [vp],
     "lr_context_ntt_variants": [vp, C.POINTER(i32), C.POINTER(i32)],
     "lr_context_set_stream": [vp, vp],
@@ -85,6 +108,7 @@ SYMBOLS = {
     "lr_div_floor_by_last_modulus_many": [vp, vp, i32, i32],
     "lr_div_round_by_last_modulus_many": [vp, vp, i32, i32],
     "lr_ckks_plan_create": [vp, vp, i32, C.POINTER(vp)],
+    "lr_ckks_plan_create_ex": [vp, vp, i32, vp, C.POINTER(vp)],
     "lr_ckks_plan_destroy": [vp],
     "lr_ckks_plan_stats": [vp, vp, vp],
     "lr_ckks_switch_keys": [vp, i32, vp, vp, vp, vp],
@@ -108,6 +132,7 @@ SYMBOLS = {
     "lr_ckks_rotate": [vp, i32, vp, vp, u64, vp, vp, vp],
     "lr_ckks_rotate_hoisted": [vp, i32, vp, vp, i32, u64p, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)],
     "lr_bfv_plan_create": [vp, vp, u64, i32, C.POINTER(vp)],
+    "lr_bfv_plan_create_ex": [vp, vp, u64, i32, vp, C.POINTER(vp)],
     "lr_bfv_plan_destroy": [vp],
     "lr_bfv_mul": [vp, vp, vp, vp, vp, vp, vp, vp],
     "lr_timer_start": [vp],

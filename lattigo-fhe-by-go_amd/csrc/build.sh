@@ -4,6 +4,9 @@ set -e
 cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -I../../include -I. -Wall -Wno-unused-function"
+# LR_BUILD_DIAG=1: the diagnostics build -- adds the clock-stamping ("t") and persistent ("p") code objects of the negative-result
+# experiments and lets lr_options::ntt_timeline / ntt_persist select them; the default build ships neither
+[ -n "$LR_BUILD_DIAG" ] && FLAGS="$FLAGS -DLR_BUILD_DIAG=1"
 mkdir -p build
 link() {
   $HIPCC --offload-arch=gfx950 -shared -fPIC -o ../liblattigo_ring_hip.so build/lr_ntt.o build/lr_ewise.o build/lr_bext.o build/lr_abi.o build/lr_precompute.o build/lr_asm.o build/lr_asm_blob.o
@@ -71,15 +74,17 @@ gen_tl() {  # kind mode
   $LLVM/clang -x assembler -target amdgcn-amd-amdhsa -mcpu=gfx950 -c build/ntt_${1}15_m${2}t.s -o build/ntt_${1}15_m${2}t.o
   $LLVM/ld.lld -shared build/ntt_${1}15_m${2}t.o -o build/ntt_${1}15_m${2}t.hsaco
 }
-for k in fwd inv; do for m in 1 3; do gen_tl $k $m & gpids+=($!); done; done
+if [ -n "$LR_BUILD_DIAG" ]; then for k in fwd inv; do for m in 1 3; do gen_tl $k $m & gpids+=($!); done; done; fi
 # persistent forward 2^15 kernels (several polys per workgroup, next poly's loads prefetched) and their timeline builds
 gen_p() {  # mode flavour suffix
   python3 asmgen/gen_ntt.py 15 build/ntt_fwd15p_m$1$3.s $1 1024 $2
   $LLVM/clang -x assembler -target amdgcn-amd-amdhsa -mcpu=gfx950 -c build/ntt_fwd15p_m$1$3.s -o build/ntt_fwd15p_m$1$3.o
   $LLVM/ld.lld -shared build/ntt_fwd15p_m$1$3.o -o build/ntt_fwd15p_m$1$3.hsaco
 }
-for m in 0 1 2 3; do gen_p $m persist "" & gpids+=($!); done
-for m in 1 3; do gen_p $m persist-timeline t & gpids+=($!); done
+if [ -n "$LR_BUILD_DIAG" ]; then
+  for m in 0 1 2 3; do gen_p $m persist "" & gpids+=($!); done
+  for m in 1 3; do gen_p $m persist-timeline t & gpids+=($!); done
+fi
 # N = 2^15 as two 2^14 sub-blocks ("h": plain forward sub-blocks after the stage over bit 14, lazy inverse ones before it): launches too
 # small to fill the chip with one workgroup per transform
 gen_h() {  # kind mode
@@ -97,8 +102,11 @@ names += [("fwd", n, m) for n in ("12x", "13x", "14x", "16s", "16p") for m in (0
 names += [("fwd", n, 3) for n in (14, 15, "12x", "13x", "14x", "16s", "16p")] + [("inv", n, 3) for n in (14, 15, "12x", "13x", "14x", "16s", "16f")]
 names += [("fwd", n, 4) for n in (14, 15, "12x", "13x", "14x", "16s", "16p")]
 names += [("fwd", n, 5) for n in (14, 15, "12x", "13x", "14x", "16s", "16p")]
-names = [(k, n, str(m)) for k, n, m in names] + [(k, 15, m) for k in ("fwd", "inv") for m in ("1t", "3t")]
-names += [("fwd", "15p", m) for m in ("0", "1", "2", "3", "1t", "3t")]
+import os
+names = [(k, n, str(m)) for k, n, m in names]
+if os.environ.get("LR_BUILD_DIAG"):
+    names += [(k, 15, m) for k in ("fwd", "inv") for m in ("1t", "3t")]
+    names += [("fwd", "15p", m) for m in ("0", "1", "2", "3", "1t", "3t")]
 names += [("fwd", "15h", m) for m in "012345"] + [("inv", "15h", m) for m in "013"]
 for k, n, m in names:
     data = open("build/ntt_%s%s_m%s.hsaco" % (k, n, m), "rb").read()

@@ -164,33 +164,127 @@ struct ScratchLease {
 
 }  // namespace
 
-lr::Options lr::Options::from_env() {
+// The test-only override: the ONE place of the library that reads LR_* environment variables.  A flag
+// variable that is set switches its alternative ON (it never switches a caller's choice off); a value variable replaces the field.
+void lr::Options::apply_env() {
+    auto flag = [](const char *name, bool &field) {
+        if (std::getenv(name) != nullptr) field = true;
+    };
+    auto num = [](const char *name, int &field) {
+        if (const char *v = std::getenv(name)) field = std::atoi(v);
+    };
+    flag("LR_NO_ASM", no_asm);
+    flag("LR_NO_FP", no_fp);
+    flag("LR_NO_EPILOGUE", no_epilogue);
+    flag("LR_NO_INT_EPILOGUE", no_int_epilogue);
+    flag("LR_RESCALE_UNFUSED", rescale_unfused);
+    flag("LR_NO_STAGING", no_staging);
+    flag("LR_EXT_NARROW", ext_narrow);
+    flag("LR_ASM_14_1024", asm14_1024);
+    flag("LR_NO_EXTTOP", no_exttop);
+    flag("LR_NO_EXT_GROUP", no_ext_group);
+    flag("LR_NO_FORK", no_fork);
+    if (const char *sp = std::getenv("LR_NTT_SPLIT15")) split15 = std::atoi(sp) != 0 ? 1 : 0;
+    flag("LR_RESCALE_UNPAIRED", rescale_unpaired);
+    flag("LR_NO_PAIR", no_pair);
+    flag("LR_NO_EXT_CHUNKS", no_ext_chunks);
+    flag("LR_NO_INVTOP", no_invtop);
+    flag("LR_ASM_14_NO_WIDE_SMALL", no_wide14_small);
+    flag("LR_NO_INVFUSE", no_invfuse);
+    flag("LR_KEYMAC_NARROW", keymac_narrow);
+    flag("LR_NTT_TIMELINE", timeline);
+    num("LR_NTT_MODE", ntt_mode);
+    num("LR_NTT_STAGGER", stagger);
+    num("LR_NTT_PERSIST", persist);
+    num("LR_ASM_VARIANT", asm_variant);
+    flag("LR_EXT_IEEE_DIV", ext_ieee_div);
+    flag("LR_NTT_NO_GRID_PADDING", no_grid_padding);
+    flag("LR_BFV_NO_EXT_EPILOGUE", bfv_no_ext_epilogue);
+    flag("LR_BFV_NO_GATHER", bfv_no_gather);
+    if (const char *gb = std::getenv("LR_BFV_GATHER_BELOW")) bfv_gather_below = std::atoll(gb);
+    num("LR_NTT_SPLIT15_BELOW", split15_max_workgroups);
+    num("LR_FORK_BELOW", fork_below_workgroups);
+}
+
+namespace {
+
+// public struct -> internal image.  The caller's struct may be shorter than this library's (an older header): only the first
+// struct_size bytes are read, the rest keeps the defaults.  A threshold of 0 means "the built-in default".
+int options_from_public(const lr_options *pub, Options *out) {
     Options o;
-    o.no_asm = std::getenv("LR_NO_ASM") != nullptr;
-    o.no_fp = std::getenv("LR_NO_FP") != nullptr;
-    o.no_epilogue = std::getenv("LR_NO_EPILOGUE") != nullptr;
-    o.no_int_epilogue = std::getenv("LR_NO_INT_EPILOGUE") != nullptr;
-    o.rescale_unfused = std::getenv("LR_RESCALE_UNFUSED") != nullptr;
-    o.no_staging = std::getenv("LR_NO_STAGING") != nullptr;
-    o.ext_narrow = std::getenv("LR_EXT_NARROW") != nullptr;
-    o.asm14_1024 = std::getenv("LR_ASM_14_1024") != nullptr;
-    o.no_exttop = std::getenv("LR_NO_EXTTOP") != nullptr;
-    o.no_ext_group = std::getenv("LR_NO_EXT_GROUP") != nullptr;
-    o.no_fork = std::getenv("LR_NO_FORK") != nullptr;
-    if (const char *sp = std::getenv("LR_NTT_SPLIT15")) o.split15 = std::atoi(sp) != 0 ? 1 : 0;
-    o.rescale_unpaired = std::getenv("LR_RESCALE_UNPAIRED") != nullptr;
-    o.no_pair = std::getenv("LR_NO_PAIR") != nullptr;
-    o.no_ext_chunks = std::getenv("LR_NO_EXT_CHUNKS") != nullptr;
-    o.no_invtop = std::getenv("LR_NO_INVTOP") != nullptr;
-    o.no_wide14_small = std::getenv("LR_ASM_14_NO_WIDE_SMALL") != nullptr;
-    o.no_invfuse = std::getenv("LR_NO_INVFUSE") != nullptr;
-    o.keymac_narrow = std::getenv("LR_KEYMAC_NARROW") != nullptr;
-    o.timeline = std::getenv("LR_NTT_TIMELINE") != nullptr;
-    if (const char *v = std::getenv("LR_NTT_MODE")) o.ntt_mode = std::atoi(v);
-    if (const char *v = std::getenv("LR_NTT_STAGGER")) o.stagger = std::atoi(v);
-    if (const char *v = std::getenv("LR_NTT_PERSIST")) o.persist = std::atoi(v);
-    if (const char *v = std::getenv("LR_ASM_VARIANT")) o.asm_variant = std::atoi(v);
-    return o;
+    if (pub) {
+        if (pub->struct_size < 2 * sizeof(uint32_t)) return fail(LR_ERR_ARG, "lr_options: struct_size is not set (use lr_options_init)");
+        if (pub->version != LR_OPTIONS_VERSION) return fail(LR_ERR_ARG, "lr_options: unknown version");
+        lr_options p;
+        (void)lr_options_init(&p);
+        std::memcpy(&p, pub, std::min<size_t>(pub->struct_size, sizeof p));
+        o.no_asm = p.no_asm != 0;
+        o.no_fp = p.no_fp != 0;
+        o.ntt_mode = p.ntt_mode;
+        o.asm_variant = p.asm_variant;
+        o.asm14_1024 = p.asm14_1024 != 0;
+        o.no_wide14_small = p.no_wide14_small != 0;
+        if (p.wide14_max_items > 0) o.wide14_max_items = p.wide14_max_items;
+        o.split15 = p.ntt_split15 < 0 ? -1 : (p.ntt_split15 != 0 ? 1 : 0);
+        if (p.split15_max_workgroups > 0) o.split15_max_workgroups = p.split15_max_workgroups;
+        o.no_invfuse = p.no_invfuse != 0;
+        o.no_grid_padding = p.no_grid_padding != 0;
+        o.stagger = p.ntt_stagger;
+        o.persist = p.ntt_persist;
+        o.timeline = p.ntt_timeline != 0;
+        o.no_epilogue = p.no_epilogue != 0;
+        o.no_int_epilogue = p.no_int_epilogue != 0;
+        o.rescale_unfused = p.rescale_unfused != 0;
+        o.rescale_unpaired = p.rescale_unpaired != 0;
+        if (p.pair_max_workgroups > 0) o.pair_max_workgroups = p.pair_max_workgroups;
+        o.ext_narrow = p.ext_narrow != 0;
+        o.ext_ieee_div = p.ext_ieee_div != 0;
+        o.no_ext_chunks = p.no_ext_chunks != 0;
+        o.no_staging = p.no_staging != 0;
+        o.no_exttop = p.no_exttop != 0;
+        o.no_invtop = p.no_invtop != 0;
+        o.no_ext_group = p.no_ext_group != 0;
+        o.keymac_narrow = p.keymac_narrow != 0;
+        o.no_pair = p.no_pair != 0;
+        o.no_fork = p.no_fork != 0;
+        if (p.fork_below_workgroups > 0) o.fork_below_workgroups = p.fork_below_workgroups;
+        o.bfv_no_ext_epilogue = p.bfv_no_ext_epilogue != 0;
+        o.bfv_no_gather = p.bfv_no_gather != 0;
+        if (p.bfv_gather_below > 0) o.bfv_gather_below = p.bfv_gather_below;
+    }
+    o.apply_env();
+#ifndef LR_BUILD_DIAG
+    if (o.timeline || o.persist > 0)
+        return fail(LR_ERR_UNSUPPORTED, "ntt_timeline / ntt_persist need the diagnostics build of the library (LR_BUILD_DIAG=1 csrc/build.sh): "
+                                        "the clock-stamping and persistent code objects are not part of the default build");
+#endif
+    *out = o;
+    return LR_OK;
+}
+
+void options_to_public(const Options &o, lr_options *p) {
+    (void)lr_options_init(p);
+    p->no_asm = o.no_asm; p->no_fp = o.no_fp; p->ntt_mode = o.ntt_mode; p->asm_variant = o.asm_variant; p->asm14_1024 = o.asm14_1024;
+    p->no_wide14_small = o.no_wide14_small; p->wide14_max_items = o.wide14_max_items; p->ntt_split15 = o.split15;
+    p->split15_max_workgroups = o.split15_max_workgroups; p->no_invfuse = o.no_invfuse; p->no_grid_padding = o.no_grid_padding;
+    p->ntt_stagger = o.stagger; p->ntt_persist = o.persist; p->ntt_timeline = o.timeline; p->no_epilogue = o.no_epilogue;
+    p->no_int_epilogue = o.no_int_epilogue; p->rescale_unfused = o.rescale_unfused; p->rescale_unpaired = o.rescale_unpaired;
+    p->pair_max_workgroups = o.pair_max_workgroups; p->ext_narrow = o.ext_narrow; p->ext_ieee_div = o.ext_ieee_div;
+    p->no_ext_chunks = o.no_ext_chunks; p->no_staging = o.no_staging; p->no_exttop = o.no_exttop; p->no_invtop = o.no_invtop;
+    p->no_ext_group = o.no_ext_group; p->keymac_narrow = o.keymac_narrow; p->no_pair = o.no_pair; p->no_fork = o.no_fork;
+    p->fork_below_workgroups = o.fork_below_workgroups; p->bfv_no_ext_epilogue = o.bfv_no_ext_epilogue; p->bfv_no_gather = o.bfv_no_gather;
+    p->bfv_gather_below = o.bfv_gather_below;
+}
+
+}  // namespace
+
+extern "C" int lr_options_init(lr_options *opt) {
+    if (!opt) return LR_ERR_ARG;
+    std::memset(opt, 0, sizeof *opt);
+    opt->struct_size = (uint32_t)sizeof *opt;
+    opt->version = LR_OPTIONS_VERSION;
+    opt->ntt_mode = opt->asm_variant = opt->ntt_split15 = opt->ntt_stagger = opt->ntt_persist = -1;
+    return LR_OK;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -267,7 +361,7 @@ struct DevModup {
         LR_TRY(to_device(&invtop1, k1.data(), k1.size()));
         return LR_OK;
     }
-    int init(const std::vector<u64> &Qv, const std::vector<u64> &Pv, bool ext_narrow) {
+    int init(const std::vector<u64> &Qv, const std::vector<u64> &Pv, bool ext_narrow, bool ieee_div = false) {
         h = build_modup(Qv, Pv);
         std::vector<u64> bh(h.P.size());
         for (size_t j = 0; j < bh.size(); ++j) bh[j] = h.bredP[j].hi;
@@ -303,7 +397,7 @@ struct DevModup {
                 const u64 frac = bits & (((u64)1 << 52) - 1);
                 if (h.Q[i] < 2 || frac == (((u64)1 << 52) - 1)) fast_div_ok = 0;
             }
-            if (std::getenv("LR_EXT_IEEE_DIV")) fast_div_ok = 0;       // testing aid: force the fallback
+            if (ieee_div) fast_div_ok = 0;                             // Options::ext_ieee_div: the reference-shaped kernel
             LR_TRY(to_device(&Qrcp, rc.data(), rc.size()));
         }
         const u128 room = ((u128)1 << 64) - pmax;
@@ -427,7 +521,11 @@ struct lr_ckks_plan {
 // ------------------------------------------------------------------------------------------
 extern "C" const char *lr_last_error_string(void) { return g_error.c_str(); }
 
-extern "C" const char *lr_build_info(void) { return "lattigo_ring 0.1 gfx950 hip"; }
+#ifdef LR_BUILD_DIAG
+extern "C" const char *lr_build_info(void) { return "lattigo_ring 0.2 gfx950 hip diag"; }   // + the clock-stamping and persistent code objects
+#else
+extern "C" const char *lr_build_info(void) { return "lattigo_ring 0.2 gfx950 hip"; }
+#endif
 
 extern "C" int lr_device_count(int *count) {
     return guarded([&]() -> int {
@@ -447,9 +545,23 @@ extern "C" int lr_device_count(int *count) {
 // Context
 // ------------------------------------------------------------------------------------------
 extern "C" int lr_context_create(uint64_t N, const uint64_t *moduli, int n_moduli, int device, lr_context **out) {
+    return lr_context_create_ex(N, moduli, n_moduli, device, nullptr, out);
+}
+
+extern "C" int lr_context_get_options(const lr_context *c, lr_options *out) {
+    return guarded([&]() -> int {
+    if (!c || !out) return fail(LR_ERR_ARG, "null argument");
+    options_to_public(c->opt, out);
+    return LR_OK;
+    });
+}
+
+extern "C" int lr_context_create_ex(uint64_t N, const uint64_t *moduli, int n_moduli, int device, const lr_options *options, lr_context **out) {
     return guarded([&]() -> int {
     if (!out) return fail(LR_ERR_ARG, "out is null");
     *out = nullptr;
+    Options parsed;
+    LR_TRY(options_from_public(options, &parsed));
     if (!moduli || n_moduli <= 0 || n_moduli > kMaxLimbs) return fail(LR_ERR_ARG, "bad modulus list (1..64 moduli)");
     std::unique_ptr<lr_context> c(new (std::nothrow) lr_context());
     if (!c) return fail(LR_ERR_ARG, "out of host memory");
@@ -459,7 +571,7 @@ extern "C" int lr_context_create(uint64_t N, const uint64_t *moduli, int n_modul
     for (u64 q : c->h.q)
         if (q >> 61) return fail(LR_ERR_UNSUPPORTED, "modulus must be below 2^61 (the reference's lazy NTT has the same limit)");
     c->device = device;
-    c->opt = Options::from_env();
+    c->opt = parsed;
     {
         u64 qmax = 0, qmin = ~(u64)0;
         for (u64 q : c->h.q) {
@@ -988,16 +1100,15 @@ EpiLimb make_epi_limb(const lr_context *c, int l, u64 cc) {
     return e;
 }
 
-// N = 2^15 transforms as two 2^14 sub-blocks (run_ntt_launch): for launches of at most kSplit15Below workgroups -- split, they still fit
+// N = 2^15 transforms as two 2^14 sub-blocks (run_ntt_launch): for launches of at most Options::split15_max_workgroups (128) workgroups -- split, they still fit
 // one round on the 256 CUs.
-constexpr long long kSplit15Below = 128;
 bool ntt_split15(const lr_context *c, long long workgroups) {
     if (c->h.logN != 15 || !c->use_asm || c->opt.timeline || !ntt_asm_available(15)) return false;
     const int variant_f = c->asm_fwd, variant_i = c->asm_inv;
     if (variant_f < 0 || variant_i < 0) return false;
     if (c->opt.split15 >= 0) return c->opt.split15 == 1;
     if (c->opt.persist > 0) return false;          // (LR_NTT_PERSIST asks for the persistent one-workgroup kernels: diagnostics)
-    return workgroups <= kSplit15Below;
+    return workgroups <= c->opt.split15_max_workgroups;
 }
 
 // Fork: launches of the calling thread that go to a plan's auxiliary stream instead of the context's (PlanFork, below): two independent
@@ -1093,7 +1204,7 @@ int run_ntt_launch(lr_context *c, bool inverse, Rows in, Rows out, int mod0, int
     char *kn = c->last_ntt_kernel;
     // N = 2^14: 512 threads per transform put two workgroups on a CU (best throughput); a launch that does not fill the chip anyway takes
     // the 1024-thread plan, whose one workgroup is done sooner (PN14QP438, one ciphertext: MulRelin 115 -> 102 us, BFV Mul 136 -> 125 us)
-    const bool wide14 = c->opt.asm14_1024 || (logn == 14 && !c->opt.no_wide14_small && (long long)count * batch <= 256);
+    const bool wide14 = c->opt.asm14_1024 || (logn == 14 && !c->opt.no_wide14_small && (long long)count * batch <= c->opt.wide14_max_items);
     // N = 2^15, a launch too small to fill the chip with one workgroup per transform (a one-workgroup 2^15 transform takes ~42 us whatever
     // surrounds it): two 2^14 sub-blocks per limb on the "h" kernels, twice the workgroups at about half the latency.  The stage over
     // index bit 14 is the streaming ntt_top_kernel's (forward: before, unless the caller's basis extension has applied it -- pretop;
@@ -1145,7 +1256,7 @@ int run_ntt_launch(lr_context *c, bool inverse, Rows in, Rows out, int mod0, int
         if (logn == 16)
             LR_HIP(launch_ntt_asm16(a, 0, pretop ? 'p' : 's', c->asm_fwd == 3 ? 4 : 5, stream_of(c), kn, c->opt.stagger));
         else
-            LR_HIP(launch_ntt_asm(a, (int)logn, 0, c->asm_fwd == 3 ? 4 : 5, stream_of(c), wide14, kn, false, c->opt.stagger));
+            LR_HIP(launch_ntt_asm(a, (int)logn, 0, c->asm_fwd == 3 ? 4 : 5, stream_of(c), wide14, kn, false, c->opt.stagger, 0, !c->opt.no_grid_padding));
         return LR_OK;
     }
     if (logn == 16 && variant >= 0 && c->use_asm && ntt_asm_available(16)) {
@@ -1207,10 +1318,10 @@ int run_ntt_launch(lr_context *c, bool inverse, Rows in, Rows out, int mod0, int
             }
             c->stamp_used = words;
             a.epi_x = reinterpret_cast<const u64 *>(c->d_stamps);
-            LR_HIP(launch_ntt_asm(a, (int)logn, inverse, variant, stream_of(c), false, kn, true, c->opt.stagger, ntt_persist(c, a, logn, inverse)));
+            LR_HIP(launch_ntt_asm(a, (int)logn, inverse, variant, stream_of(c), false, kn, true, c->opt.stagger, ntt_persist(c, a, logn, inverse), !c->opt.no_grid_padding));
             return LR_OK;
         }
-        LR_HIP(launch_ntt_asm(a, (int)logn, inverse, variant, stream_of(c), wide14, kn, false, c->opt.stagger, ntt_persist(c, a, logn, inverse)));
+        LR_HIP(launch_ntt_asm(a, (int)logn, inverse, variant, stream_of(c), wide14, kn, false, c->opt.stagger, ntt_persist(c, a, logn, inverse), !c->opt.no_grid_padding));
         return LR_OK;
     }
     std::snprintf(c->last_ntt_kernel, sizeof c->last_ntt_kernel, "ntt_%s_kernel<%u>", inverse ? "inv" : "fwd", logn);
@@ -1766,9 +1877,10 @@ extern "C" int lr_bext_create(lr_context *cQ, lr_context *cP, lr_bext **out) {
     b->cQ = cQ;
     b->cP = cP;
     b->device = cQ->device;
-    const bool narrow = Options::from_env().ext_narrow;
-    LR_TRY(b->qp.init(cQ->h.q, cP->h.q, narrow));
-    LR_TRY(b->pq.init(cP->h.q, cQ->h.q, narrow));
+    Options o = cQ->opt;         // the extender takes its options from its first context (+ the test-only override, as at every creation)
+    o.apply_env();
+    LR_TRY(b->qp.init(cQ->h.q, cP->h.q, o.ext_narrow, o.ext_ieee_div));
+    LR_TRY(b->pq.init(cP->h.q, cQ->h.q, o.ext_narrow, o.ext_ieee_div));
     LR_TRY(b->pq.set_inverse_top(cP->h, 0));
     b->moddown_pq = build_moddown(cQ->h, cP->h);  // genModDownParams(contextQ, contextP), ring_basis_extension.go:66
     b->moddown_qp = build_moddown(cP->h, cQ->h);  // :67
@@ -2049,12 +2161,14 @@ extern "C" int lr_decomposer_create(lr_context *cQ, lr_context *cP, lr_decompose
     std::vector<u64> QP(Q);
     QP.insert(QP.end(), P.begin(), P.end());
     d->modup.resize(d->beta);
-    const bool narrow = Options::from_env().ext_narrow;
+    Options o = cQ->opt;
+    o.apply_env();
+    const bool narrow = o.ext_narrow;
     for (int i = 0; i < d->beta; ++i) {
         for (int j = 0; j + 1 < d->xalpha[i]; ++j) {
             std::vector<u64> Qi(Q.begin() + (size_t)i * d->alpha, Q.begin() + (size_t)i * d->alpha + j + 2);
             std::unique_ptr<DevModup> m(new DevModup());
-            LR_TRY(m->init(Qi, QP, narrow));
+            LR_TRY(m->init(Qi, QP, narrow, o.ext_ieee_div));
             LR_TRY(m->set_inverse_top(cQ->h, i * d->alpha));
             d->modup[i].push_back(std::move(m));
         }
@@ -2430,9 +2544,15 @@ std::atomic<int> &standalone_plans(int device) {
 }  // namespace
 
 extern "C" int lr_ckks_plan_create(lr_context *cQ, lr_context *cP, int max_batch, lr_ckks_plan **out) {
+    return lr_ckks_plan_create_ex(cQ, cP, max_batch, nullptr, out);
+}
+
+extern "C" int lr_ckks_plan_create_ex(lr_context *cQ, lr_context *cP, int max_batch, const lr_options *options, lr_ckks_plan **out) {
     return guarded([&]() -> int {
     if (!cQ || !cP || !out) return fail(LR_ERR_ARG, "null argument");
     *out = nullptr;
+    Options parsed;
+    LR_TRY(options_from_public(options, &parsed));
     if (max_batch < 1) return fail(LR_ERR_ARG, "max_batch must be >= 1");
     LR_TRY(same_degree(cQ, cP));
     std::unique_ptr<lr_ckks_plan> p(new lr_ckks_plan());
@@ -2440,7 +2560,7 @@ extern "C" int lr_ckks_plan_create(lr_context *cQ, lr_context *cP, int max_batch
     p->cP = cP;
     p->device = cQ->device;
     p->max_batch = max_batch;
-    p->opt = Options::from_env();
+    p->opt = parsed;
     LR_TRY(lr_bext_create(cQ, cP, &p->bext));
     int rc = lr_decomposer_create(cQ, cP, &p->dec);
     if (rc != LR_OK) {
@@ -2482,8 +2602,8 @@ namespace {
 
 // Two independent launches of one pipeline side by side: between the constructor and join() the calling thread's forward transforms go
 // to the plan's auxiliary stream, which starts behind everything enqueued on the contexts' stream so far; join() makes the contexts'
-// stream wait for them.  Worth it only on an otherwise idle device and while the forked launch is far from filling it (kForkBelow
-// workgroups).  "Otherwise idle" is a structural test, not a momentary one: the plan is the only one alive on its device that is not a
+// stream wait for them.  Worth it only on an otherwise idle device and while the forked launch is far from filling it
+// (Options::fork_below_workgroups, 256).  "Otherwise idle" is a structural test, not a momentary one: the plan is the only one alive on its device that is not a
 // batcher's lane -- the lone evaluator, for whom latency is what there is.
 // Tried and dropped (profiles/r03/fork_policies.txt): forking whenever the launch is small (sixteen threads with a plan each lose a
 // quarter of their rate), counting the calls being enqueued at the moment (the count is below the threads most of the time), auxiliary
@@ -2493,7 +2613,6 @@ namespace {
 // Python threads: the extra streams share hardware queues with the lanes' own, see GPU_MAX_HW_QUEUES in DESIGN 9).
 // Capturable: the auxiliary stream joins the capture at the fork and leaves it at the join (it is created by the first fork, i.e. in
 // the warm-up call the capture contract asks for).
-constexpr int kForkBelow = 256;
 struct PlanFork {
     lr_ckks_plan *pl;
     bool on = false;
@@ -2505,7 +2624,7 @@ struct PlanFork {
         // there costs more than it hides: PN15QP880 batch 1 4.64 k products/s forked, 5.06 k in order; PN14QP438 6.42 k / 7.30 k;
         // PN16QP1761 1.69 k / 1.64 k (profiles/r03/fork_policies.txt).
         if (pl->cQ->h.logN != 16) return;
-        if (pl->lane_of || standalone_plans(pl->device).load(std::memory_order_relaxed) != 1 || workgroups >= kForkBelow) return;
+        if (pl->lane_of || standalone_plans(pl->device).load(std::memory_order_relaxed) != 1 || workgroups >= pl->opt.fork_below_workgroups) return;
         if (!pl->aux) {
             if (create_stream(&pl->aux, 1) != hipSuccess ||
                 hipEventCreateWithFlags(&pl->ev_fork, hipEventDisableTiming) != hipSuccess ||
@@ -2754,7 +2873,7 @@ int ks_accumulate(lr_ckks_plan *pl, int level, int batch, const u64 *digQ, const
         K.alpha = 0;
         // a small batch: the Q part and the P part as one launch (they share nothing and each is a few hundred workgroups)
         hipError_t pe = hipErrorNotSupported;
-        if (!pl->opt.no_pair && (long long)batch * (level + 1) <= 256) pe = launch_keymac_pair(KQ, level + 1, K, nP, batch, cQ->stream);
+        if (!pl->opt.no_pair && (long long)batch * (level + 1) <= pl->opt.pair_max_workgroups) pe = launch_keymac_pair(KQ, level + 1, K, nP, batch, cQ->stream);
         if (pe == hipErrorNotSupported) {
             LR_HIP(launch_keymac(KQ, level + 1, batch, cQ->stream));
             LR_HIP(launch_keymac(K, nP, batch, cQ->stream));
@@ -3604,7 +3723,7 @@ extern "C" int lr_ckks_rescale(lr_ckks_plan *pl, lr_poly *c0, lr_poly *c1) {
     const bool same_shape = c0->limbs == c1->limbs && c0->batch == c1->batch && c0->N == c1->N && c0->d != c1->d;
     const bool one_each = same_shape && c0->batch == 1 && gap >= (long long)lo->limbs * (long long)lo->N;
     const bool back_to_back = same_shape && c0->stride() == c1->stride() && gap == (long long)lo->batch * lo->stride();
-    if (!c->opt.rescale_unpaired && (one_each || back_to_back) && (long long)c0->batch * 2 * c0->limbs <= 256) {
+    if (!c->opt.rescale_unpaired && (one_each || back_to_back) && (long long)c0->batch * 2 * c0->limbs <= c->opt.pair_max_workgroups) {
         lr_poly both = *lo;
         both.owned = false;
         both.batch = 2 * lo->batch;
@@ -3630,9 +3749,9 @@ struct lr_bfv_plan {
     LimbScalars t_mont;               // MForm(t mod q_i), bfv/evaluator.go:462
     u64 *d_phalf_q = nullptr, *d_phalf_m = nullptr, *d_t_mont = nullptr;   // the same as device arrays (extension epilogues)
     int max_batch = 0;
-    bool no_ext_epilogue = false;     // LR_BFV_NO_EXT_EPILOGUE: separate subtract-multiply / scalar passes after the extensions
-    bool no_gather = false;           // LR_BFV_NO_GATHER: every operand / product in launches of its own at every batch size
-    long long gather_below = 1536;    // LR_BFV_GATHER_BELOW: workgroups of the four operands' joint transform up to which they are gathered (PN14QP438:
+    bool no_ext_epilogue = false;     // Options::bfv_no_ext_epilogue: separate subtract-multiply / scalar passes after the extensions
+    bool no_gather = false;           // Options::bfv_no_gather: every operand / product in launches of its own at every batch size
+    long long gather_below = 1536;    // Options::bfv_gather_below: workgroups of the four operands' joint transform up to which they are gathered (PN14QP438:
                                       // gathered 346 / 565 / 1015 / 1912 us per batch of 16 / 32 / 64 / 128, per operand 490 / 618 / 1081 / 1805)
     Pool liftQ, liftM;                // the four operand polys over Q and over QMul, slots a0, a1, b0, b1 of [batch][limbs][N] each
     Pool prodQ, prodM;                // the three products, slots c0, c1, c2
@@ -3667,9 +3786,15 @@ void half_product_residues(const std::vector<u64> &moduli, const std::vector<u64
 }  // namespace
 
 extern "C" int lr_bfv_plan_create(lr_context *cQ, lr_context *cM, uint64_t t, int max_batch, lr_bfv_plan **out) {
+    return lr_bfv_plan_create_ex(cQ, cM, t, max_batch, nullptr, out);
+}
+
+extern "C" int lr_bfv_plan_create_ex(lr_context *cQ, lr_context *cM, uint64_t t, int max_batch, const lr_options *options, lr_bfv_plan **out) {
     return guarded([&]() -> int {
     if (!cQ || !cM || !out) return fail(LR_ERR_ARG, "null argument");
     *out = nullptr;
+    Options parsed;
+    LR_TRY(options_from_public(options, &parsed));
     if (max_batch < 1) return fail(LR_ERR_ARG, "max_batch must be >= 1");
     LR_TRY(same_degree(cQ, cM));
     std::unique_ptr<lr_bfv_plan> p(new lr_bfv_plan());
@@ -3687,9 +3812,9 @@ extern "C" int lr_bfv_plan_create(lr_context *cQ, lr_context *cM, uint64_t t, in
     LR_TRY(to_device(&p->d_phalf_q, p->phalf_q.v, (size_t)cQ->h.L()));
     LR_TRY(to_device(&p->d_phalf_m, p->phalf_m.v, (size_t)cM->h.L()));
     LR_TRY(to_device(&p->d_t_mont, p->t_mont.v, (size_t)cQ->h.L()));
-    p->no_ext_epilogue = std::getenv("LR_BFV_NO_EXT_EPILOGUE") != nullptr;
-    p->no_gather = std::getenv("LR_BFV_NO_GATHER") != nullptr;
-    if (const char *gb = std::getenv("LR_BFV_GATHER_BELOW")) p->gather_below = std::atoll(gb);
+    p->no_ext_epilogue = parsed.bfv_no_ext_epilogue;
+    p->no_gather = parsed.bfv_no_gather;
+    p->gather_below = parsed.bfv_gather_below;
     LR_TRY(lr_bext_create(cQ, cM, &p->bext));
     *out = p.release();
     return LR_OK;

@@ -18,7 +18,7 @@ import ctypes as C
 import numpy as np
 
 from . import _native as nat
-from ._native import LatticeRingError, check, lib
+from ._native import LatticeRingError, Options, check, lib
 
 # lr_ewise_op (include/lattigo_ring.h)
 OPS = ["ADD", "ADD_NOMOD", "SUB", "SUB_NOMOD", "NEG", "REDUCE", "MUL_COEFFS", "MUL_COEFFS_AND_ADD",
@@ -148,13 +148,22 @@ class Poly:
 class Context:
     """ring.Context (ring/ring_context.go:18-51)."""
 
-    def __init__(self, N, Moduli, device=0):
+    def __init__(self, N, Moduli, device=0, options=None):
         self.N = int(N)
         self.Modulus = [int(m) for m in Moduli]
         self.device = device
         h = C.c_void_p()
-        check(lib().lr_context_create(self.N, _u64(self.Modulus), len(self.Modulus), device, C.byref(h)))
+        if options is None:
+            check(lib().lr_context_create(self.N, _u64(self.Modulus), len(self.Modulus), device, C.byref(h)))
+        else:
+            check(lib().lr_context_create_ex(self.N, _u64(self.Modulus), len(self.Modulus), device, C.byref(options), C.byref(h)))
         self.h = h
+
+    def GetOptions(self):
+        """the lr_options this context ended up with (after the test-only LR_* override), as an Options"""
+        o = Options()
+        check(lib().lr_context_get_options(self.h, C.byref(o)))
+        return o
 
     def __del__(self):
         try:
@@ -411,10 +420,10 @@ def PermuteNTT(context, polIn, gen, polOut):
     context.PermuteNTTLvl(polIn.limbs - 1, polIn, gen, polOut)
 
 
-def NewContextWithParams(N, Moduli, device=0):
+def NewContextWithParams(N, Moduli, device=0, options=None):
     """ring.NewContextWithParams (ring/ring_context.go:60).  Raises LatticeRingError
-    LR_ERR_NOT_NTT_FRIENDLY where the reference returns its error value."""
-    return Context(N, Moduli, device)
+    LR_ERR_NOT_NTT_FRIENDLY where the reference returns its error value.  options: an Options (lr_options) or None for the defaults."""
+    return Context(N, Moduli, device, options)
 
 
 class FastBasisExtender:
@@ -534,10 +543,13 @@ class CkksPlan:
     """What ckks.NewEvaluator builds around the ring (ckks/evaluator.go:81-112) plus the
     MulRelin / switchKeysInPlace / Rescale call sequences (:1016, :1475, :933), device-resident."""
 
-    def __init__(self, contextQ, contextP, max_batch=1):
+    def __init__(self, contextQ, contextP, max_batch=1, options=None):
         self.contextQ, self.contextP = contextQ, contextP
         h = C.c_void_p()
-        check(lib().lr_ckks_plan_create(contextQ.h, contextP.h, max_batch, C.byref(h)))
+        if options is None:
+            check(lib().lr_ckks_plan_create(contextQ.h, contextP.h, max_batch, C.byref(h)))
+        else:
+            check(lib().lr_ckks_plan_create_ex(contextQ.h, contextP.h, max_batch, C.byref(options), C.byref(h)))
         self.h = h
 
     def __del__(self):
@@ -698,10 +710,13 @@ class BfvPlan:
     """What bfv.NewEvaluator builds around the ring for Mul (bfv/evaluator.go:89-112) and the tensorAndRescale
     call sequence (:278-464) for two degree-1 ciphertexts, device-resident."""
 
-    def __init__(self, contextQ, contextQMul, t, max_batch=1):
+    def __init__(self, contextQ, contextQMul, t, max_batch=1, options=None):
         self.contextQ, self.contextQMul, self.t = contextQ, contextQMul, int(t)
         h = C.c_void_p()
-        check(lib().lr_bfv_plan_create(contextQ.h, contextQMul.h, self.t, max_batch, C.byref(h)))
+        if options is None:
+            check(lib().lr_bfv_plan_create(contextQ.h, contextQMul.h, self.t, max_batch, C.byref(h)))
+        else:
+            check(lib().lr_bfv_plan_create_ex(contextQ.h, contextQMul.h, self.t, max_batch, C.byref(options), C.byref(h)))
         self.h = h
 
     def __del__(self):

@@ -431,6 +431,9 @@ def test_persistent_forward_kernels(gpu_pkg, oracle, kind, per_wg, monkeypatch):
     """LR_NTT_PERSIST: the forward 2^15 kernels that transform several polys per workgroup and prefetch the next poly's column loads
     (lr_ntt_fwd15p_m*; measured no faster than the one-poly kernels at the package power limit and therefore off by default, DESIGN
     3.1): every output against the oracle, with a batch that leaves a short last chunk (7 polys), in place and out of place"""
+    if b"diag" not in gpu_pkg._native.lib().lr_build_info():
+        pytest.skip("the persistent code objects are part of the diagnostics build only (LR_BUILD_DIAG=1 csrc/build.sh); "
+                    "tests/test_options.py checks that the default build refuses the request by name")
     monkeypatch.setenv("LR_NTT_PERSIST", str(per_wg))
     ring, params, sampling = gpu_pkg.ring, gpu_pkg.params, gpu_pkg.sampling
     N = 1 << 15
@@ -452,3 +455,24 @@ def test_persistent_forward_kernels(gpu_pkg, oracle, kind, per_wg, monkeypatch):
         assert np.array_equal(got[b], oc.ntt(x[b])), b
     ctx.NTT(src, src)
     assert np.array_equal(src.get(), got)
+
+
+def test_timeline_build_stamps_every_wave(gpu_pkg, oracle):
+    """diagnostics build only: lr_options::ntt_timeline runs the clock-stamping build of the 2^15 kernel -- same results, and 13 increasing
+    stamps per wave (lr_context_timeline; tools/timeline.py names the phases)"""
+    if b"diag" not in gpu_pkg._native.lib().lr_build_info():
+        pytest.skip("the clock-stamping code objects are part of the diagnostics build only (LR_BUILD_DIAG=1 csrc/build.sh)")
+    ring, params, sampling = gpu_pkg.ring, gpu_pkg.params, gpu_pkg.sampling
+    N, Q = params.DefaultParamsQi(15)
+    Q = list(Q[:2])
+    ctx = ring.NewContextWithParams(N, Q, options=ring.Options(ntt_timeline=1))
+    x = sampling.uniform_poly(Q, N, 2, seed=2)
+    src, dst = ctx.NewPoly(2).set(x), ctx.NewPoly(2)
+    ctx.NTT(src, dst)
+    assert ctx.last_ntt_kernel() == "lr_ntt_fwd15_m1t"
+    oc = oracle.Context(N, Q)
+    assert np.array_equal(dst.get(), np.stack([oc.ntt(x[b]) for b in range(2)]))
+    st = ctx.timeline().astype(np.int64)
+    assert st.shape == (4, 16, 16)
+    d = (st[:, :, 1:13] - st[:, :, 0:12]) & 0xFFFFFFFF
+    assert (d > 0).all() and (d < (1 << 24)).all()
