@@ -103,7 +103,7 @@ func (c *Context) GenNTTParams() error {
 		c.h = nil
 	}
 	rc, msg := status(func() C.int {
-		return C.lr_context_create(C.uint64_t(c.N), (*C.uint64_t)(unsafe.Pointer(&c.Modulus[0])), C.int(len(c.Modulus)), C.int(c.device), &c.h)
+		return C.lr_context_create_ex(C.uint64_t(c.N), (*C.uint64_t)(unsafe.Pointer(&c.Modulus[0])), C.int(len(c.Modulus)), C.int(c.device), DefaultOptions.ptr(), &c.h)
 	})
 	switch rc {
 	case C.LR_OK:

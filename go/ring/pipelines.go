@@ -21,7 +21,7 @@ type CkksPlan struct {
 
 func NewCkksPlan(contextQ, contextP *Context, maxBatch int) *CkksPlan {
 	p := &CkksPlan{contextQ: contextQ, contextP: contextP}
-	call(func() C.int { return C.lr_ckks_plan_create(contextQ.h, contextP.h, C.int(maxBatch), &p.h) })
+	call(func() C.int { return C.lr_ckks_plan_create_ex(contextQ.h, contextP.h, C.int(maxBatch), DefaultOptions.ptr(), &p.h) })
 	runtime.SetFinalizer(p, func(p *CkksPlan) { C.lr_ckks_plan_destroy(p.h) })
 	return p
 }
@@ -281,7 +281,9 @@ type BfvPlan struct {
 
 func NewBfvPlan(contextQ, contextQMul *Context, t uint64, maxBatch int) *BfvPlan {
 	p := &BfvPlan{contextQ: contextQ}
-	call(func() C.int { return C.lr_bfv_plan_create(contextQ.h, contextQMul.h, C.uint64_t(t), C.int(maxBatch), &p.h) })
+	call(func() C.int {
+		return C.lr_bfv_plan_create_ex(contextQ.h, contextQMul.h, C.uint64_t(t), C.int(maxBatch), DefaultOptions.ptr(), &p.h)
+	})
 	runtime.SetFinalizer(p, func(p *BfvPlan) { C.lr_bfv_plan_destroy(p.h) })
 	return p
 }

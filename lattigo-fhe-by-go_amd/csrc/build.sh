@@ -8,11 +8,13 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-ma
 # experiments and lets lr_options::ntt_timeline / ntt_persist select them; the default build ships neither
 [ -n "$LR_BUILD_DIAG" ] && FLAGS="$FLAGS -DLR_BUILD_DIAG=1"
 mkdir -p build
+# the C ABI, one translation unit per handle family (lr_host.hpp is what they share)
+ABI_UNITS="lr_abi_core lr_abi_ring lr_abi_bext lr_abi_ckks lr_abi_batcher lr_abi_bfv"
 link() {
-  $HIPCC --offload-arch=gfx950 -shared -fPIC -o ../liblattigo_ring_hip.so build/lr_ntt.o build/lr_ewise.o build/lr_bext.o build/lr_abi.o build/lr_precompute.o build/lr_asm.o build/lr_asm_blob.o
+  $HIPCC --offload-arch=gfx950 -shared -fPIC -o ../liblattigo_ring_hip.so build/lr_ntt.o build/lr_ewise.o build/lr_bext.o $(for u in $ABI_UNITS; do echo build/$u.o; done) build/lr_precompute.o build/lr_asm.o build/lr_asm_blob.o
   echo "built $(cd .. && pwd)/liblattigo_ring_hip.so"
 }
-# developer shortcut: `build.sh lr_abi.cpp lr_ewise.hip` recompiles only the named sources and relinks (everything else must
+# developer shortcut: `build.sh lr_abi_ckks.cpp lr_ewise.hip` recompiles only the named sources and relinks (everything else must
 # have been built before); without arguments the whole library is built from scratch, which is what __graft_entry__.build() runs
 if [ $# -gt 0 ]; then
   spids=()
@@ -125,8 +127,10 @@ for f in lr_ntt.hip lr_ewise.hip lr_bext.hip; do
   $HIPCC $FLAGS -c $f -o build/${f%.hip}.o &
   pids+=($!)
 done
-$HIPCC $FLAGS -x hip -c lr_abi.cpp -o build/lr_abi.o &
-pids+=($!)
+for u in $ABI_UNITS; do
+  $HIPCC $FLAGS -x hip -c $u.cpp -o build/$u.o &
+  pids+=($!)
+done
 $HIPCC $FLAGS -x hip -c lr_precompute.cpp -o build/lr_precompute.o &
 pids+=($!)
 $HIPCC $FLAGS -x hip -c lr_asm.cpp -o build/lr_asm.o &

@@ -84,7 +84,7 @@ struct FpLimb {
 };
 
 // constant of the forward kernels' epilogue, 16 bytes per limb: (c, RN(c / q)) as doubles for a limb the FP64 body takes, the Shoup pair
-// (c, floor(c 2^64 / q)) as two u64 in the same bytes for a limb on an integer body (make_epi_limb, lr_abi.cpp)
+// (c, floor(c 2^64 / q)) as two u64 in the same bytes for a limb on an integer body (make_epi_limb, lr_abi_ring.cpp)
 struct EpiLimb { double c, c_over_q; };
 
 // Addressing of one NTT launch.  Work item (b, i): batch element b, i-th limb of the launch.

@@ -43,7 +43,7 @@ def emulate(gen, inverse=False, q=None, geom=None):
     canon = np.array([[int(val) % q for val in x]], dtype=np.uint64)
     want = (oc.intt(canon) if inverse else oc.ntt(canon))[0]
 
-    # host-side tables exactly as lr_abi.cpp builds them
+    # host-side tables exactly as lr_abi_core.cpp builds them
     table = oc.ntt_psi_inv[0] if inverse else oc.ntt_psi[0]
     psi = [int(oracle.inv_mform(int(w), q)) for w in table]
     n_inv = pow(N, -1, q)
@@ -274,7 +274,7 @@ def selftest_persist(threads=1024):
 
 
 def fp_tables(np, q, n_inv, tw, twf, put):
-    """what lr_abi.cpp builds for the FP body: every (w, floor(w 2^64 / q)) becomes the pair of doubles (w, RN(w / q));
+    """what lr_abi_core.cpp builds for the FP body: every (w, floor(w 2^64 / q)) becomes the pair of doubles (w, RN(w / q));
     FpLimb = {q, RN(1/q), N^-1 mod q, RN(N^-1 / q)}, all zero for a modulus the FP body does not take"""
     def conv(t):
         w = t[..., 0].astype(np.float64)
@@ -338,7 +338,7 @@ def emulate_sub(make_gen, inverse, q, pretop=False, order=(0, 1)):
     table = oc.ntt_psi_inv[0] if inverse else oc.ntt_psi[0]
     psi = [int(oracle.inv_mform(int(w), q)) for w in table]
     n_inv = pow(NF, -1, q)
-    psi[0] = psi[1] * n_inv % q if inverse else q - psi[1]     # lr_abi.cpp fills the unused heap entry 0 like this
+    psi[0] = psi[1] * n_inv % q if inverse else q - psi[1]     # lr_abi_core.cpp fills the unused heap entry 0 like this
     tw = np.zeros((NF, 2), dtype=np.uint64)
     for i, w in enumerate(psi):
         tw[i, 0] = w

@@ -88,7 +88,9 @@ def test_every_c_call_matches_the_header():
                                          "lr_ntt_limb", "lr_intt_limb", "lr_bext_get_table", "lr_simple_scaler_tables", "lr_context_timeline", "lr_selftest_division",
                                          # the pointer-array forms serve C / C++ / Python callers; a go 1.13 cgo caller may not store Go pointers in a C
                                          # array and uses the per-limb forms (lr_poly_upload_limb, lr_poly_download_limb, lr_ntt_host_limb)
-                                         "lr_poly_upload", "lr_poly_download", "lr_ntt_host", "lr_intt_host"})
+                                         "lr_poly_upload", "lr_poly_download", "lr_ntt_host", "lr_intt_host",
+                                         # the shim creates its handles through the *_create_ex forms (DefaultOptions; nil = the defaults, which is what these do)
+                                         "lr_context_create", "lr_ckks_plan_create", "lr_bfv_plan_create"})
     assert not unused, unused
 
 

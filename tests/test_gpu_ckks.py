@@ -465,7 +465,7 @@ def test_bfv_relinearize_refuses_aliased_operands(gpu_pkg):
         plan.BfvSwitchKeys(c, key, c, a)
 
 
-# ---- small batches: grouped digit extensions, independent launches side by side (PlanFork in lr_abi.cpp) -------------------------
+# ---- small batches: grouped digit extensions, independent launches side by side (PlanFork in lr_abi_ckks.cpp) -------------------------
 @pytest.mark.parametrize("logn,nq,np_,level,batch", [(14, 7, 3, 6, 1), (14, 7, 3, 5, 3), (15, 18, 3, 17, 1), (16, 6, 2, 5, 1), (16, 10, 4, 9, 2), (12, 10, 4, 9, 2)])
 def test_small_batch_paths_give_the_same_bits(gpu_pkg, oracle, logn, nq, np_, level, batch, monkeypatch):
     """a lone plan at a small batch sends the digits' extensions out as one launch and, at N = 2^16, forks the digits' P-row transforms
@@ -490,7 +490,7 @@ def test_small_batch_paths_give_the_same_bits(gpu_pkg, oracle, logn, nq, np_, le
             assert np.array_equal(out[0].get().reshape(batch, level + 1, N)[b], w0), (env, b)
             assert np.array_equal(out[1].get().reshape(batch, level + 1, N)[b], w1), (env, b)
         st = plan.Stats()
-        assert (st["forks"] > 0) == ("LR_NO_FORK" not in env and logn == 16), (env, st)       # (forks pay at N = 2^16 only: lr_abi.cpp, PlanFork)
+        assert (st["forks"] > 0) == ("LR_NO_FORK" not in env and logn == 16), (env, st)       # (forks pay at N = 2^16 only: lr_abi_ckks.cpp, PlanFork)
         full_digits = (level + 1) // np_
         assert (st["grouped_extensions"] > 0) == ("LR_NO_EXT_GROUP" not in env and full_digits > 1), (env, st)   # full digits share a shape
         del plan, pevk, out

@@ -187,7 +187,7 @@ def test_full_size_properties_r15(gpu_pkg):
 
 
 def _asm_moduli(pkg, kind, logn):
-    """modulus sets that select each variant of the assembly kernels (lr_abi.cpp: asm_fwd / asm_inv)"""
+    """modulus sets that select each variant of the assembly kernels (lr_abi_core.cpp: asm_fwd / asm_inv)"""
     P = pkg.params
     if kind == "qi60":                      # forward variant 1 (q <= 2^60), inverse variant 1
         return list(P.Qi60()[-2:]) + [P.Qi60()[0]]
