@@ -47,6 +47,18 @@ func (evaluator *evaluator) dev() *deviceState {
 	return actual.(*deviceState)
 }
 
+// ReleaseDevice drops the evaluator's device state (plans, key images) and its entry in deviceStates; see the ckks overlay.
+func (evaluator *evaluator) ReleaseDevice() {
+	if s, ok := deviceStates.Load(evaluator); ok {
+		st := s.(*deviceState)
+		for k := range st.keys {
+			delete(st.keys, k)
+		}
+		st.mul, st.ks = nil, nil
+		deviceStates.Delete(evaluator)
+	}
+}
+
 func (evaluator *evaluator) keyImage(k *SwitchingKey) *ring.Poly {
 	s := evaluator.dev()
 	if img, ok := s.keys[k]; ok {

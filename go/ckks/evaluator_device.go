@@ -90,6 +90,20 @@ func (eval *evaluator) batcher() *ring.CkksBatcher {
 	return b
 }
 
+// ReleaseDevice drops what this evaluator holds on the device -- its plan (pools, decomposer tables) and its key images -- and its
+// entry in deviceStates; the handles' finalizers free the device memory.  Call it when the goroutine that owns the evaluator is done
+// (the evaluator struct cannot carry a finalizer of its own: the map holds it alive).  A later call on the evaluator builds a new state.
+func (eval *evaluator) ReleaseDevice() {
+	if s, ok := deviceStates.Load(eval); ok {
+		st := s.(*deviceState)
+		for k := range st.keys {
+			delete(st.keys, k)
+		}
+		st.plan = nil
+		deviceStates.Delete(eval)
+	}
+}
+
 func (eval *evaluator) keyImage(k *SwitchingKey) *ring.Poly {
 	s := eval.dev()
 	if img, ok := s.keys[k]; ok {
@@ -166,10 +180,6 @@ func (eval *evaluator) MulRelin(op0, op1 Operand, evakey *EvaluationKey, ctOut *
 		panic("cannot MulRelin: op1 must be in NTT")
 	}
 	elOut.SetScale(el0.Scale() * el1.Scale())
-	var key *ring.Poly
-	if evakey != nil {
-		key = eval.keyImage(evakey.evakey)
-	}
 	if el0.Degree()+el1.Degree() == 2 && evakey == nil {
 		elOut.Resize(eval.params, 2) // degree-2 result, :1061-1066 / :1107-1111
 	}
@@ -180,6 +190,12 @@ func (eval *evaluator) MulRelin(op0, op1 Operand, evakey *EvaluationKey, ctOut *
 	if b := eval.batcher(); b != nil && evakey != nil && el0.Degree() == 1 && el1.Degree() == 1 {
 		b.MulRelin(eval.ckksContext.contextQ, level, el0.value, el1.value, b.KeyImage(evakey.evakey.evakey), elOut.value)
 		return
+	}
+	// (after the batcher branch: an evaluator whose products go through the batcher never uploads a private image of the key --
+	// 360 MB at PN16QP1761, times the goroutines)
+	var key *ring.Poly
+	if evakey != nil {
+		key = eval.keyImage(evakey.evakey)
 	}
 	eval.dev().plan.MulRelin(level, el0.value, el1.value, key, elOut.value)
 }

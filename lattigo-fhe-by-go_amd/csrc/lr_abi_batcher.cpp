@@ -119,6 +119,7 @@ extern "C" int lr_ckks_batcher_create(lr_ckks_plan *const *plans, int n_lanes, l
         ln.plan = plans[i];
         if (!ln.plan->lane_of) standalone_plans(ln.plan->device).fetch_sub(1);
         ln.plan->lane_of = B.get();
+        ln.plan->cQ->lane_of = ln.plan->cP->lane_of = B.get();
         ln.take.reserve((size_t)std::max(1, B->max_batch));
         LR_HIP(create_stream(&ln.stream, (i + 1) % 3));   // lane 0: greatest priority, lane 1: least, lane 2: default, ...
         LR_TRY(lr_context_set_stream(ln.plan->cQ, ln.stream));
@@ -138,9 +139,20 @@ extern "C" void lr_ckks_batcher_destroy(lr_ckks_batcher *B) {
             ln.plan->lane_of = nullptr;
             standalone_plans(ln.plan->device).fetch_add(1);
         }
+        if (ln.plan) {
+            for (lr_context *c : {ln.plan->cQ, ln.plan->cP})
+                if (c->lane_of == B) c->lane_of = nullptr;
+        }
         if (ln.stream) {   // back to the library's stream (ordered behind the lane's work), then the lane stream can go
-            (void)lr_context_set_stream(ln.plan->cQ, nullptr);
-            (void)lr_context_set_stream(ln.plan->cP, nullptr);
+            for (lr_context *c : {ln.plan->cQ, ln.plan->cP}) {
+                if (lr_context_set_stream(c, nullptr) != LR_OK && c->stream == ln.stream) {
+                    // the ordered hand-over failed: drain the device and put the library's stream back by hand, so that the context
+                    // does not keep a handle to the stream destroyed below
+                    (void)hipDeviceSynchronize();
+                    (void)hipGetLastError();
+                    c->stream = shared_stream(c->device);
+                }
+            }
             (void)hipStreamSynchronize(ln.stream);
             (void)hipStreamDestroy(ln.stream);
         }
@@ -238,6 +250,12 @@ int batcher_submit(lr_ckks_batcher *B, int kind, int level, const lr_poly *a0, c
         std::string msg;
         if (rc != LR_OK) {
             try { msg = g_error; } catch (...) {}
+            // a batch that failed half-way may have kernels queued that read the callers' operands through d_table, and the copy out of
+            // the pinned h_table may be pending: nothing of it may outlive this point -- the callers are about to be woken, and the next
+            // batch on this lane rewrites the table and the plan's pools (only the success path ends in a synchronisation of its own)
+            (void)hipSetDevice(lane.plan->device);
+            (void)hipStreamSynchronize(lane.stream);
+            (void)hipGetLastError();
         }
         lk.lock();
         lane.busy = false;
@@ -276,7 +294,3 @@ extern "C" int lr_ckks_batcher_rotate(lr_ckks_batcher *B, int level, const lr_po
     return batcher_submit(B, 1, level, c0, c1, nullptr, nullptr, gen & (two_n - 1), rotkey, o0, o1);
     });
 }
-
-// MulRelin with evakey == nil (ckks/evaluator.go:1038-1111): the degree-2 tensor, no key switch.  The squaring branch
-// (:1083-1088, c1 = 2 c0 c1 by AddLvl) and the regular one (:1090-1096, MulCoeffsMontgomeryAndAddLvl) produce the same canonical
-// residues when ct0 == ct1, so one kernel serves both.  Outputs may alias the inputs (the reference goes through its pools then).

@@ -263,6 +263,33 @@ int moddown_pq_core(lr_bext *b, int level, const u64 *p1Q, long long p1Q_stride,
     }
     LR_TRY(b->poolQ.ensure(cQ, (size_t)batch * pool_stride));
     LR_TRY(run_ext(cQ, b->pq, nP, pP, batch, segment(b->poolQ.d, pool_stride, 0, 0, level + 1), segment(nullptr, 0, 0, 0, 0)));
+    if (ntt && ntt_epilogue_ok(cQ) && !cQ->opt.no_epilogue) {
+        // NTT domain: the subtract-multiply rides in the forward transform's copy-out (the kernels the key switch uses for its ModDown,
+        // ks_accumulate) for every run of limbs that takes the epilogue; the other limbs keep the separate pass.  Nothing is added.
+        if (b->zerosQ.words < (size_t)pool_stride) {
+            LR_TRY(b->zerosQ.ensure(cQ, (size_t)pool_stride));
+            LR_HIP(hipMemsetAsync(b->zerosQ.d, 0, (size_t)pool_stride * sizeof(u64), cQ->stream));
+        }
+        const long long n64 = (long long)cQ->h.N;
+        int l0 = 0;
+        while (l0 <= level) {
+            const bool fpc = ntt_epilogue_limb(cQ, l0);
+            int l1 = l0 + 1;
+            while (l1 <= level && ntt_epilogue_limb(cQ, l1) == fpc) ++l1;
+            Rows src{b->poolQ.d, pool_stride, l0, 1};
+            if (fpc) {
+                const NttEpilogue ep{p1Q, p1Q_stride, b->zerosQ.d, 0, b->d_moddown_pq_epi};
+                Rows dst{p2->d, p2->stride(), l0, 1};
+                LR_TRY(run_ntt(cQ, false, src, dst, l0, 1, l1 - l0, batch, 0, 0, &ep));
+            } else {
+                LR_TRY(run_ntt(cQ, false, src, src, l0, 1, l1 - l0, batch));
+                LR_TRY(run_submul(cQ, l1 - l0, batch, p1Q + l0 * n64, p1Q_stride, b->poolQ.d + l0 * n64, pool_stride, n64, p2->d + l0 * n64,
+                                  p2->stride(), b->d_moddown_pq + l0, false, nullptr, nullptr, 0, nullptr, l0));
+            }
+            l0 = l1;
+        }
+        return LR_OK;
+    }
     if (ntt) {
         Rows pr{b->poolQ.d, pool_stride, 0, 1};
         LR_TRY(run_ntt(cQ, false, pr, pr, 0, 1, level + 1, batch));

@@ -55,6 +55,7 @@ extern "C" int lr_ckks_plan_stats(const lr_ckks_plan *p, uint64_t *forks, uint64
 extern "C" int lr_ckks_plan_destroy(lr_ckks_plan *p) {
     return guarded([&]() -> int {
     if (!p) return LR_OK;
+    if (p->lane_of) return fail(LR_ERR_ARG, "this plan is a lane of a live batcher: destroy the batcher first (it holds the plan and its contexts)");
     (void)hipSetDevice(p->device);
     (void)hipDeviceSynchronize();   // the handle's work may be on its contexts' caller-supplied stream
     lr_bext_destroy(p->bext);
@@ -62,7 +63,7 @@ extern "C" int lr_ckks_plan_destroy(lr_ckks_plan *p) {
     if (p->ev_fork) (void)hipEventDestroy(p->ev_fork);
     if (p->ev_join) (void)hipEventDestroy(p->ev_join);
     if (p->aux) (void)hipStreamDestroy(p->aux);
-    if (!p->lane_of) standalone_plans(p->device).fetch_sub(1);
+    standalone_plans(p->device).fetch_sub(1);
     delete p;
     return LR_OK;
     });
@@ -725,6 +726,9 @@ extern "C" int lr_ckks_mulrelin(lr_ckks_plan *pl, int level, const lr_poly *a0, 
 }
 
 
+// MulRelin with evakey == nil (ckks/evaluator.go:1038-1111): the degree-2 tensor, no key switch.  The squaring branch
+// (:1083-1088, c1 = 2 c0 c1 by AddLvl) and the regular one (:1090-1096, MulCoeffsMontgomeryAndAddLvl) produce the same canonical
+// residues when ct0 == ct1, so one kernel serves both.  Outputs may alias the inputs (the reference goes through its pools then).
 extern "C" int lr_ckks_mul_norelin(lr_ckks_plan *pl, int level, const lr_poly *a0, const lr_poly *a1, const lr_poly *b0,
                                    const lr_poly *b1, lr_poly *o0, lr_poly *o1, lr_poly *o2) {
     return guarded([&]() -> int {
@@ -836,6 +840,27 @@ extern "C" int lr_ckks_decrypt(lr_ckks_plan *pl, int level, const lr_poly *const
     if (sk->N != cQ->h.N || sk->limbs < L1 || (sk->batch != batch && sk->batch != 1)) return fail(LR_ERR_SHAPE, "secret key: limbs or batch");
     LR_HIP(hipSetDevice(cQ->device));
     const long long ss = sk->batch == 1 && batch > 1 ? 0 : sk->stride();
+    bool aliased = false;      // the fused pass reads every ct[i] where it writes pt: fine for ct[degree] == pt only if nothing else is pt
+    for (int i = 0; i < degree; ++i) aliased = aliased || ct[i]->d == pt->d;
+    if (degree <= kHornerMaxDegree && !aliased && !pl->opt.no_epilogue) {
+        // one pass: every component and the key read once, the plaintext written once (the element operations and the reduction
+        // cadence are the reference's, HornerLaunch); Options::no_epilogue keeps the call-by-call form below
+        HornerLaunch H;
+        std::memset(&H, 0, sizeof H);
+        for (int i = 0; i <= degree; ++i) {
+            H.ct[i] = ct[i]->d;
+            H.ct_stride[i] = ct[i]->stride();
+        }
+        H.sk = sk->d;
+        H.sk_stride = ss;
+        H.out = pt->d;
+        H.out_stride = pt->stride();
+        H.degree = degree;
+        H.n = (int)cQ->h.N;
+        H.lp = cQ->d_lp;
+        LR_HIP(launch_horner(H, L1, batch, cQ->stream));
+        return LR_OK;
+    }
     LR_TRY(run_ewise(cQ, LR_COPY, L1, batch, ct[degree]->d, ct[degree]->stride(), nullptr, 0, pt->d, pt->stride(), nullptr));   // :61
     for (int i = degree; i > 0; --i) {
         LR_TRY(run_ewise(cQ, LR_MUL_MONT, L1, batch, pt->d, pt->stride(), sk->d, ss, pt->d, pt->stride(), nullptr));            // :67
@@ -846,9 +871,6 @@ extern "C" int lr_ckks_decrypt(lr_ckks_plan *pl, int level, const lr_poly *const
     return LR_OK;
     });
 }
-
-// diagnostics: the basis extension's division by a table constant (lr_bext.hip: div_by_const) against the IEEE division of
-// ring/ring_basis_extension.go:372 on `samples` pseudo-random and adversarial operand pairs; *mismatches must come back 0
 
 extern "C" int lr_ckks_rescale(lr_ckks_plan *pl, lr_poly *c0, lr_poly *c1) {
     return guarded([&]() -> int {

@@ -211,6 +211,7 @@ extern "C" int lr_context_create_ex(uint64_t N, const uint64_t *moduli, int n_mo
         if (q >> 61) return fail(LR_ERR_UNSUPPORTED, "modulus must be below 2^61 (the reference's lazy NTT has the same limit)");
     c->device = device;
     c->opt = parsed;
+    c->scratch.owner_stream = &c->stream;
     {
         u64 qmax = 0, qmin = ~(u64)0;
         for (u64 q : c->h.q) {
@@ -356,6 +357,7 @@ extern "C" int lr_context_ntt_variants(const lr_context *c, int *forward, int *i
 extern "C" int lr_context_destroy(lr_context *c) {
     return guarded([&]() -> int {
     if (!c) return LR_OK;
+    if (c->lane_of) return fail(LR_ERR_ARG, "this context belongs to a lane of a live batcher: destroy the batcher first");
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();   // whatever stream the handle last ran on (its own, the shared one, a caller's)
     for (void *p : {(void *)c->d_lp, (void *)c->d_fwd, (void *)c->d_inv, (void *)c->d_fwd_fin, (void *)c->d_inv_fin, (void *)c->d_rescale,
@@ -364,6 +366,7 @@ extern "C" int lr_context_destroy(lr_context *c) {
     if (c->d_stamps) (void)hipFree(c->d_stamps);
     for (auto &kv : c->rescale_round) {
         if (kv.second.plus) (void)hipFree(kv.second.plus);
+        if (kv.second.zeros) (void)hipFree(kv.second.zeros);
         if (kv.second.epi) (void)hipFree(kv.second.epi);
     }
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -386,7 +389,14 @@ extern "C" int lr_context_set_stream(lr_context *c, void *hip_stream) {
         hipError_t e1 = hipEventRecord(ev, c->stream);
         hipError_t e2 = e1 == hipSuccess ? hipStreamWaitEvent(next, ev, 0) : e1;
         (void)hipEventDestroy(ev);
-        if (e2 != hipSuccess) return fail(LR_ERR_HIP, std::string("set_stream: ") + hipGetErrorString(e2));
+        if (e1 != hipSuccess) {
+            // the old stream is gone (a caller-owned stream destroyed before the switch: whatever it carried has completed or was
+            // dropped with it): no event can order against it -- drain the device instead and install the new stream all the same
+            (void)hipGetLastError();
+            LR_HIP(hipDeviceSynchronize());
+        } else if (e2 != hipSuccess) {
+            return fail(LR_ERR_HIP, std::string("set_stream: ") + hipGetErrorString(e2));
+        }
         c->stream = next;
     }
     return LR_OK;

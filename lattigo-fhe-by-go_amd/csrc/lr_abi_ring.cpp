@@ -757,22 +757,24 @@ int rescale_coeff_domain(lr_context *c, lr_poly *p0, bool round) {
 // polynomial is transformed as it is (one source row for all limbs, like the floor variant) and the constant vector joins
 // the subtract-multiply as its `plus` operand, already multiplied by -rescaleParams[i]: the same canonical residue without the
 // pass that writes `level` shifted copies of the row.  The table depends on the level only and is built once.
-int rescale_round_table(lr_context *c, int level, const u64 **out, const EpiLimb **epi_out) {
+int rescale_round_table(lr_context *c, int level, const u64 **out, const EpiLimb **epi_out, const u64 **zeros_out) {
     std::lock_guard<std::mutex> lock(c->rescale_mu);
     auto it = c->rescale_round.find(level);
     if (it != c->rescale_round.end()) {
         *out = it->second.plus;
         *epi_out = it->second.epi;
+        if (zeros_out) *zeros_out = it->second.zeros;
         return LR_OK;
     }
     // built into locals; the cache only ever holds complete tables (a failure below leaves no entry behind)
     const int n = (int)c->h.N;
     const long long words = (long long)level * n;
     struct Guard {
-        u64 *table = nullptr;
+        u64 *table = nullptr, *zeros = nullptr;
         EpiLimb *epi = nullptr;
         ~Guard() {
             if (table) (void)hipFree(table);
+            if (zeros) (void)hipFree(zeros);
             if (epi) (void)hipFree(epi);
         }
     } g;
@@ -780,6 +782,9 @@ int rescale_round_table(lr_context *c, int level, const u64 **out, const EpiLimb
     LR_TRY(tmpbuf.take(&c->scratch, (size_t)words));
     LR_HIP(hipMalloc((void **)&g.table, (size_t)words * sizeof(u64)));
     LR_HIP(hipMemsetAsync(g.table, 0, (size_t)words * sizeof(u64), c->stream));
+    // the flooring division (DivFloorByLastModulusNTT) takes the same epilogue with nothing to add: rows of zeros in the same layout
+    LR_HIP(hipMalloc((void **)&g.zeros, (size_t)words * sizeof(u64)));
+    LR_HIP(hipMemsetAsync(g.zeros, 0, (size_t)words * sizeof(u64), c->stream));
     const u64 pj = c->h.q[level], phalf = (pj - 1) >> 1;
     RowAddLaunch M;
     M.in = g.table;                     // a row of zeros
@@ -804,10 +809,12 @@ int rescale_round_table(lr_context *c, int level, const u64 **out, const EpiLimb
         }
         LR_TRY(to_device(&g.epi, ec.data(), ec.size()));
     }
-    c->rescale_round[level] = lr_context::RoundTable{g.table, g.epi};
+    c->rescale_round[level] = lr_context::RoundTable{g.table, g.epi, g.zeros};
     *out = g.table;
     *epi_out = g.epi;
+    if (zeros_out) *zeros_out = g.zeros;
     g.table = nullptr;
+    g.zeros = nullptr;
     g.epi = nullptr;
     return LR_OK;
 }
@@ -815,9 +822,11 @@ int rescale_round_table(lr_context *c, int level, const u64 **out, const EpiLimb
 int rescale_ntt_domain(lr_context *c, lr_poly *p0, bool round) {
     const int level = p0->limbs - 1, n = (int)c->h.N, batch = p0->batch;
     const long long tmp_stride = (long long)level * n;
-    const u64 *plus = nullptr;
+    const u64 *plus = nullptr, *zeros = nullptr;
     const EpiLimb *ec = nullptr;
-    if (round && !c->opt.rescale_unfused) LR_TRY(rescale_round_table(c, level, &plus, &ec));
+    if (!c->opt.rescale_unfused && (round || ntt_epilogue_ok(c))) LR_TRY(rescale_round_table(c, level, &plus, &ec, &zeros));
+    if (!round) plus = nullptr;       // (the rounding's addend; the flooring division adds the rows of zeros in the epilogue, nothing elsewhere)
+    const u64 *const epi_plus = round ? plus : zeros;
     ScratchLease scratch;
     LR_TRY(scratch.take(&c->scratch, (size_t)batch * tmp_stride));
     Rows last{p0->d, p0->stride(), level, 0};
@@ -840,7 +849,7 @@ int rescale_ntt_domain(lr_context *c, lr_poly *p0, bool round) {
         L.adds.v[0] = phalf;
         LR_HIP(launch_rowadd(L, 1, batch, c->stream));            // :87-89
     }
-    if (round && plus && ntt_epilogue_ok(c)) {
+    if (epi_plus && ntt_epilogue_ok(c)) {
         // (x - NTT_i(t)) * rescaleParams[i] + plus inside the forward transform's copy-out for the runs of limbs below 2^46
         const long long n64 = (long long)n;
         int l0 = 0;
@@ -870,11 +879,11 @@ int rescale_ntt_domain(lr_context *c, lr_poly *p0, bool round) {
                 t.tw = c->d_fwd;
                 if (fuse_mid) LR_HIP(launch_rescale_mid(t, c->d_inv, level, (c->h.q[level] - 1) >> 1, 15, stream_of(c)));
                 else LR_HIP(launch_ntt_top(t, 0, stream_of(c), 15));
-                const NttEpilogue ep{p0->d, p0->stride(), plus, 0, ec};
+                const NttEpilogue ep{p0->d, p0->stride(), epi_plus, 0, ec};
                 Rows src{scratch.d(), tmp_stride, l0, 1}, dst{p0->d, p0->stride(), l0, 1};
                 LR_TRY(run_ntt(c, false, src, dst, l0, 1, l1 - l0, batch, 0, 0, &ep, true));
             } else if (fpc) {
-                const NttEpilogue ep{p0->d, p0->stride(), plus, 0, ec};
+                const NttEpilogue ep{p0->d, p0->stride(), epi_plus, 0, ec};
                 Rows dst{p0->d, p0->stride(), l0, 1};
                 LR_TRY(run_ntt(c, false, last, dst, l0, 1, l1 - l0, batch, 0, 0, &ep));
             } else {
@@ -882,7 +891,7 @@ int rescale_ntt_domain(lr_context *c, lr_poly *p0, bool round) {
                 LR_TRY(run_ntt(c, false, last, dst, l0, 1, l1 - l0, batch));
                 LR_TRY(run_submul(c, l1 - l0, batch, p0->d + l0 * n64, p0->stride(), scratch.d() + l0 * n64, tmp_stride, n64,
                                   p0->d + l0 * n64, p0->stride(), c->d_rescale + (size_t)(level - 1) * c->h.L() + l0, false, nullptr,
-                                  plus + l0 * n64, 0, nullptr, l0));
+                                  plus ? plus + l0 * n64 : nullptr, 0, nullptr, l0));
             }
             l0 = l1;
         }
@@ -966,6 +975,8 @@ extern "C" int lr_div_round_by_last_modulus_many(lr_context *c, lr_poly *p0, int
 }
 
 
+// diagnostics: the basis extension's division by a table constant (lr_bext.hip: div_by_const) against the IEEE division of
+// ring/ring_basis_extension.go:372 on `samples` pseudo-random and adversarial operand pairs; *mismatches must come back 0
 extern "C" int lr_selftest_division(lr_context *c, uint64_t samples, uint64_t seed, uint64_t *mismatches) {
     return guarded([&]() -> int {
         if (!c || !mismatches) return fail(LR_ERR_ARG, "null argument");

@@ -181,6 +181,22 @@ struct TensorLaunch {
 };
 hipError_t launch_tensor(const TensorLaunch &L, int limbs, int batch, hipStream_t stream);
 
+// decryptor.Decrypt (ckks/decryptor.go:53-78) in one pass: Horner evaluation of ct[0..degree] at the secret key with the reference's
+// element operations and reduction cadence -- acc = ct[degree]; for i = degree..1: acc = CRed(MRed(acc, sk) + ct[i-1]), BRedAdd when
+// i & 7 == 7; a final BRedAdd unless degree & 7 == 7 -- every operand read once, the result written once
+constexpr int kHornerMaxDegree = 8;
+struct HornerLaunch {
+    const u64 *ct[kHornerMaxDegree + 1];
+    long long ct_stride[kHornerMaxDegree + 1];
+    const u64 *sk;
+    long long sk_stride;            // 0: one key for the whole batch
+    u64 *out;
+    long long out_stride;
+    int degree, n;
+    const LimbParams *lp;
+};
+hipError_t launch_horner(const HornerLaunch &L, int limbs, int batch, hipStream_t stream);
+
 // batcher form of a result copy: dst[b] = table[b * per_poly + k] for the per_poly staged polys src[k] (rows [limbs][n], batch stride `stride`)
 struct ScatterLaunch {
     const u64 *src[2];

@@ -194,6 +194,49 @@ __global__ __launch_bounds__(256) void tensor_kernel(TensorLaunch L) {
     }
 }
 
+// decryptor.Decrypt, ckks/decryptor.go:61-77 (HornerLaunch): the copy, degree x (MulCoeffsMontgomeryLvl, AddLvl), the ReduceLvl cadence
+__global__ __launch_bounds__(256) void horner_kernel(HornerLaunch L) {
+    const int limb = blockIdx.y;
+    const long long b = blockIdx.z;
+    const LimbParams lp = L.lp[limb];
+    const u64 q = lp.q;
+    const long long row = (long long)limb * L.n;
+    const ulonglong2 *ps = reinterpret_cast<const ulonglong2 *>(L.sk + b * L.sk_stride + row);
+    ulonglong2 *po = reinterpret_cast<ulonglong2 *>(L.out + b * L.out_stride + row);
+    const int pairs = L.n >> 1;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < pairs; e += gridDim.x * 256) {
+        const ulonglong2 s = L.degree > 0 ? ps[e] : make_ulonglong2(0, 0);        // (the key is shared by the batch: through the caches)
+        ulonglong2 acc = ld_stream(reinterpret_cast<const ulonglong2 *>(L.ct[L.degree] + b * L.ct_stride[L.degree] + row) + e);    // :61 CopyLvl
+        for (int i = L.degree; i > 0; --i) {
+            const ulonglong2 c = ld_stream(reinterpret_cast<const ulonglong2 *>(L.ct[i - 1] + b * L.ct_stride[i - 1] + row) + e);
+            acc.x = cred(mred(acc.x, s.x, q, lp.qinv) + c.x, q);                 // :67-68
+            acc.y = cred(mred(acc.y, s.y, q, lp.qinv) + c.y, q);
+            if ((i & 7) == 7) {                                                  // :70-72
+                acc.x = bred_add(acc.x, q, lp.bred_hi);
+                acc.y = bred_add(acc.y, q, lp.bred_hi);
+            }
+        }
+        if ((L.degree & 7) != 7) {                                               // :75-77
+            acc.x = bred_add(acc.x, q, lp.bred_hi);
+            acc.y = bred_add(acc.y, q, lp.bred_hi);
+        }
+        st_stream(po + e, acc);
+    }
+}
+
+hipError_t launch_horner(const HornerLaunch &L, int limbs, int batch, hipStream_t stream) {
+    if (limbs <= 0 || batch <= 0) return hipSuccess;
+    if (L.degree < 0 || L.degree > kHornerMaxDegree) return hipErrorInvalidValue;
+    const int pairs = L.n >> 1;
+    int gx = (pairs + 255) / 256;
+    if (gx > 64) gx = 64;
+    if (gx < 1) gx = 1;
+    const dim3 grid((unsigned)gx, (unsigned)limbs, (unsigned)batch), block(256);
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(horner_kernel, grid, block, 0, stream, L);
+    return hipGetLastError();
+}
+
 __global__ __launch_bounds__(256) void bswap_kernel(const u64 *in, u64 *out, size_t words) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < words; i += (size_t)gridDim.x * 256)
         out[i] = __builtin_bswap64(in[i]);

@@ -95,12 +95,22 @@ struct ScratchPool {
     struct Buf { u64 *d; size_t words; };
     std::mutex mu;
     std::vector<Buf> free_list;
+    const hipStream_t *owner_stream = nullptr;   // the owning context's stream (read at acquire: is a capture in progress?)
+    bool pinned = false;                         // a lease was handed out during a stream capture: its address may be baked into a graph
     int acquire(size_t words, Buf *out) {
         out->d = nullptr;
         out->words = 0;
         if (words == 0) return LR_OK;
+        bool capturing = false;
+        if (owner_stream && *owner_stream) {
+            hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+            if (hipStreamIsCapturing(*owner_stream, &st) == hipSuccess) capturing = st != hipStreamCaptureStatusNone;
+            else (void)hipGetLastError();
+        }
+        std::vector<Buf> drop;
         {
             std::lock_guard<std::mutex> lock(mu);
+            if (capturing) pinned = true;
             size_t best = free_list.size();
             for (size_t i = 0; i < free_list.size(); ++i)
                 if (free_list[i].words >= words && (best == free_list.size() || free_list[i].words < free_list[best].words)) best = i;
@@ -109,10 +119,13 @@ struct ScratchPool {
                 free_list.erase(free_list.begin() + (long)best);
                 return LR_OK;
             }
-            // nothing fits: the pool grows by one buffer.  Idle buffers are NOT freed while the context lives: their addresses may be
-            // baked into a captured HIP graph (the pair-flag memset node and the temporaries of a captured pipeline call), and work
-            // enqueued on a stream the caller installed later may still use them; everything goes in the destructor.
+            // nothing fits: the pool grows by one buffer.  Once a lease has been handed out during a stream capture the idle buffers stay
+            // for the context's life: their addresses may be baked into a HIP graph (the pair-flag memset node and the temporaries of a
+            // captured pipeline call).  Otherwise the idle buffers -- every one of them too small for this request -- go now, so that a
+            // context that sees growing sizes does not keep every earlier buffer (hipFree waits for the work that still uses them).
+            if (!pinned) drop.swap(free_list);
         }
+        for (Buf &b : drop) (void)hipFree(b.d);
         LR_HIP(hipMalloc((void **)&out->d, words * sizeof(u64)));
         out->words = words;
         return LR_OK;
@@ -163,7 +176,7 @@ struct lr_context {
     size_t stamp_words = 0, stamp_used = 0;
     // DivRoundByLastModulusNTT: per level, -(pHalfNegQi[i] * NTT_i(1 + X + ... + X^(N-1))) * rescaleParams[i] for i < level,
     // [level][N], built on first use (rescale_round_table)
-    struct RoundTable { u64 *plus; EpiLimb *epi; };
+    struct RoundTable { u64 *plus; EpiLimb *epi; u64 *zeros; };   // zeros: [level][N], the `plus` operand of the flooring division's epilogue
     std::map<int, RoundTable> rescale_round;    // per level; epi = rescaleParams as (c, c / q) doubles for the NTT epilogue
     std::mutex rescale_mu;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -173,6 +186,7 @@ struct lr_context {
     // variant 3 = dual kernels: FP64 body for the limbs below 2^46, integer body (mode 2) for the others
     Twiddle *d_fwd_fp = nullptr, *d_inv_fp = nullptr, *d_fwd_fin_fp = nullptr, *d_inv_fin_fp = nullptr;
     FpLimb *d_fp_lp = nullptr;
+    const void *lane_of = nullptr;   // the batcher whose lane runs on this context (its stream is the lane's): not destroyed while that lives
 };
 
 struct lr_poly {
@@ -325,6 +339,7 @@ struct lr_bext {
     // and RN(c / q_i) as doubles (zero for the limbs of 2^46 and more, which stay on the separate subtract-multiply)
     EpiLimb *d_moddown_pq_epi = nullptr;
     Pool poolQ, poolP;
+    Pool zerosQ;              // one poly of zeros over Q: the `plus` operand of the forward kernels' epilogue in the NTT-domain ModDown
     ~lr_bext() {
         if (d_moddown_pq_epi) (void)hipFree(d_moddown_pq_epi);
         if (d_moddown_pq) (void)hipFree(d_moddown_pq);
@@ -425,7 +440,7 @@ int check_pair(const lr_context *c, int level, const lr_poly *in, const lr_poly 
 Rows rows_of(const lr_poly *p, int limb0 = 0, int step = 1, bool broadcast_ok = false, int target_batch = 0);
 int run_ewise(lr_context *c, int op, int limbs, int batch, const u64 *a, long long a_stride, const u64 *b, long long b_stride, u64 *out, long long out_stride, const LimbScalars *sc, int lp_offset = 0);
 int rescale_ntt_domain(lr_context *c, lr_poly *p0, bool round);
-int rescale_round_table(lr_context *c, int level, const u64 **out, const EpiLimb **epi_out);
+int rescale_round_table(lr_context *c, int level, const u64 **out, const EpiLimb **epi_out, const u64 **zeros_out = nullptr);
 int check_rescale(lr_context *c, lr_poly *p0);
 // lr_abi_bext.cpp: basis extension and decomposition on raw rows
 ExtSegment segment(u64 *out, long long stride, int limb0, int col0, int count);

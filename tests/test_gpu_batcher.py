@@ -163,3 +163,53 @@ def test_concurrent_rotations_and_products_through_one_batcher(gpu_pkg, oracle, 
         else:
             want = oplan.permute_ntt(level, np.stack([what[1][0], what[2][0]]), what[3], rot_evk)
         assert np.array_equal(g0, want[0]) and np.array_equal(g1, want[1]), (k, what[0])
+
+
+def test_lanes_cannot_be_destroyed_under_a_live_batcher(gpu_pkg, oracle):
+    """a lane's plan and contexts belong to the batcher while it lives (its destroy dereferences them and the contexts run on the lane's
+    stream): destroying one first is refused with LR_ERR_ARG and changes nothing; after the batcher is gone the same calls succeed"""
+    N, Q, P, bat, key, oplan, evk = _setup(gpu_pkg, oracle, 12, 4, 2, 4, 2)
+    lib = gpu_pkg._native.lib()
+    cq, cp, plan = bat.lanes[0]
+    assert lib.lr_ckks_plan_destroy(plan.h) == 4 and b"batcher" in lib.lr_last_error_string()
+    assert lib.lr_context_destroy(cq.h) == 4 and lib.lr_context_destroy(cp.h) == 4
+    ring = gpu_pkg.ring
+    level = len(Q) - 1
+    ctx = ring.NewContextWithParams(N, Q)
+    ops = [gpu_pkg.sampling.uniform_poly(Q, N, 1, seed=70 + k) for k in range(4)]
+    mk = lambda k: ctx.NewPoly(1).set(ops[k])
+    out = (ctx.NewPoly(1), ctx.NewPoly(1))
+    bat.MulRelin(level, (mk(0), mk(1)), (mk(2), mk(3)), key, out)          # the refused calls left the lanes intact
+    want = oplan.mulrelin(level, np.stack([ops[0][0], ops[1][0]]), np.stack([ops[2][0], ops[3][0]]), evk)
+    assert np.array_equal(out[0].get(), want[0]) and np.array_equal(out[1].get(), want[1])
+    h = bat.h
+    bat.h = None
+    lib.lr_ckks_batcher_destroy(h)
+    assert lib.lr_ckks_plan_destroy(plan.h) == 0
+    plan.h = None
+    # the contexts are back on the library's stream and usable
+    p = cq.NewPoly(1).set(ops[0])
+    cq.NTT(p, p)
+    assert np.array_equal(p.get(), oracle.Context(N, Q).ntt(ops[0][0]))
+
+
+def test_set_stream_survives_a_stream_that_was_destroyed_first(gpu_pkg, oracle):
+    """lr_context_set_stream orders the hand-over with an event on the OLD stream; when a caller has already destroyed that stream (a
+    framework stream dropped before SetStream(None)) the event cannot be recorded: the library drains the device instead and installs
+    the new stream all the same (before round 4 the context stayed bound to the dead handle)"""
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    st = ctypes.c_void_p()
+    assert hip.hipStreamCreate(ctypes.byref(st)) == 0
+    ring = gpu_pkg.ring
+    N, Q = gpu_pkg.params.DefaultParamsQi(12)
+    ctx = ring.NewContextWithParams(N, Q)
+    x = gpu_pkg.sampling.uniform_poly(Q, N, 1, seed=4)
+    a, b = ctx.NewPoly(1).set(x), ctx.NewPoly(1)
+    ctx.SetStream(st.value)
+    ctx.NTT(a, b)
+    ctx.Sync()
+    assert hip.hipStreamDestroy(st) == 0
+    ctx.SetStream(None)                                    # the old stream is gone
+    ctx.InvNTT(b, b)
+    assert np.array_equal(b.get(), x[0])

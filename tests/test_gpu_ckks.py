@@ -796,3 +796,35 @@ def test_bfv_rotate_columns_pow2_chain_and_argument_errors(gpu_pkg, oracle):
         plan.BfvPermute((cQ.NewPoly(2), cQ.NewPoly(2)), 5, keys[1], (cQ.NewPoly(2), cQ.NewPoly(2)))   # batch beyond the plan's max_batch
     with pytest.raises(err):
         plan.BfvPermute((cQ.NewPolyLvl(nq - 2, 1), c[1]), 5, keys[1], out)            # a component with fewer limbs than Q
+
+
+@pytest.mark.parametrize("degree", [1, 2, 7, 8, 9])
+def test_decrypt_fused_pass_against_the_call_by_call_form(gpu_pkg, oracle, degree, monkeypatch):
+    """lr_ckks_decrypt as ONE pass (horner_kernel: every component and the key read once) against the oracle and against the call-by-call
+    form (Copy, MulCoeffsMontgomery, Add, Reduce launches: LR_NO_EPILOGUE, and degree 9 which the fused kernel does not take); operands
+    anywhere in [0, 2^64) (the reference's Reduce cadence decides what comes out); the plaintext in place of the top component (a plaintext that IS a
+    lower component keeps the reference's call-by-call order, whose Copy overwrites that component first)"""
+    logn, nq, np_, batch = 11, 4, 2, 3
+    N, Q, P, cQ, cP, plan, oplan, evk, pevk = _ckks(gpu_pkg, oracle, logn, nq, np_, batch)
+    level = nq - 1
+    sk = gpu_pkg.sampling.uniform_poly(Q, N, 1, seed=1).reshape(1, nq, N)
+    ct = gpu_pkg.sampling.random_u64((degree + 1, batch, nq, N), seed=degree)        # full 64-bit words, as NewCiphertextRandom fills them
+    ct[0] = gpu_pkg.sampling.uniform_poly(Q, N, batch, seed=50).reshape(batch, nq, N)
+    want = [oplan.decrypt(level, ct[:, b], sk[0]) for b in range(batch)]
+    got = []
+    for env in ({}, {"LR_NO_EPILOGUE": "1"}):
+        monkeypatch.delenv("LR_NO_EPILOGUE", raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        cq = gpu_pkg.ring.NewContextWithParams(N, Q)
+        pl = gpu_pkg.ring.CkksPlan(cq, gpu_pkg.ring.NewContextWithParams(N, P), batch)
+        psk = cq.NewPoly(1).set(sk)
+        polys = [cq.NewPoly(batch).set(ct[i]) for i in range(degree + 1)]
+        out = cq.NewPoly(batch)
+        pl.Decrypt(level, polys, psk, out)
+        got.append(out.get().reshape(batch, nq, N))
+        for b in range(batch):
+            assert np.array_equal(got[-1][b], want[b]), (env, b)
+        pl.Decrypt(level, polys, psk, polys[degree])                                    # plaintext.value is the top component
+        assert np.array_equal(polys[degree].get().reshape(batch, nq, N), got[-1]), env
+    assert np.array_equal(got[0], got[1])

@@ -797,3 +797,61 @@ def test_half_vector_scalar_ops(gpu_pkg, oracle, logn, nlimbs, batch):
         p, o = ctx.NewPoly(batch).set(x), ctx.NewPoly(batch).set(y0)
         ctx.HalfScalarOp("MRED", nlimbs - 2, p, lo, hi, o)
         assert np.array_equal(o.get().reshape(batch, nlimbs, N)[:, nlimbs - 1], y0[:, nlimbs - 1])
+
+
+# ---- round 4: NTT-domain ModDown and the flooring NTT-domain rescale through the forward kernels' epilogue -------------------------
+@pytest.mark.parametrize("logn,kind", [(12, "qi60"), (13, "ckks"), (14, "qi60"), (15, "qi60"), (15, "ckks"), (15, "q61"), (16, "ckks"), (16, "qi60")])
+def test_moddown_ntt_and_div_floor_ntt_take_the_epilogue(gpu_pkg, oracle, logn, kind, monkeypatch):
+    """ModDownSplitedNTTPQ / ModDownNTTPQ (ring_basis_extension.go:163-246) and DivFloorByLastModulusNTT (ring_scaling.go:9-35) with the
+    subtract-multiply inside the forward transform's copy-out (kernels m4 / m5: 60-bit rings and CKKS-size moduli; moduli above 2^60 keep
+    the separate pass), out of place and in place on the Q part (the reference's benchmark calls ModDownSplitedNTTPQ(level, p0, p1, p0)),
+    at a level below the top, against the oracle and against the separate-pass form (LR_NO_EPILOGUE)"""
+    N = 1 << logn
+    params, ring, sampling = gpu_pkg.params, gpu_pkg.ring, gpu_pkg.sampling
+    if kind == "qi60":
+        Q, P = list(params.Qi60()[-5:]), list(params.Pi60()[-3:])
+    elif kind == "ckks":
+        _, Qf, Pf = params.ckks_moduli("PN15QP880" if logn <= 15 else "PN16QP1761")
+        Q, P = list(params.GenerateNTTPrimes(40, logn, 4)) + [params.GenerateNTTPrimes(50, logn, 1)[0]], list(params.GenerateNTTPrimes(51, logn, 2))
+    else:
+        big = [p for p in params.GenerateNTTPrimes(60, logn, 8) if p > (1 << 60)]
+        Q, P = big[:4], big[4:6]
+    nq, np_ = len(Q), len(P)
+    B = 3
+    xq, xp = sampling.uniform_poly(Q, N, B, seed=logn), sampling.uniform_poly(P, N, B, seed=logn + 1)
+    obe = oracle.BasisExtender(oracle.Context(N, Q), oracle.Context(N, P))
+    oc = oracle.Context(N, Q)
+    got = {}
+    for env in ({}, {"LR_NO_EPILOGUE": "1"}):
+        monkeypatch.delenv("LR_NO_EPILOGUE", raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        cQ, cP = ring.NewContextWithParams(N, Q), ring.NewContextWithParams(N, P)
+        be = ring.NewFastBasisExtender(cQ, cP)
+        for level in (nq - 1, nq - 3):
+            pq, pp, out = cQ.NewPoly(B).set(xq), cP.NewPoly(B).set(xp), cQ.NewPolyLvl(level, B)
+            be.ModDownSplitedNTTPQ(level, pq, pp, out)
+            g = out.get().reshape(B, level + 1, N)
+            for b in range(B):
+                assert np.array_equal(g[b], obe.moddown_split_ntt_pq(level, xq[b], xp[b])), (env, level, b)
+            pp.set(xp)
+            be.ModDownSplitedNTTPQ(level, pq, pp, pq)                        # in place on the Q part
+            assert np.array_equal(pq.get().reshape(B, nq, N)[:, :level + 1], g), (env, level, "in place")
+            if level < nq - 1:
+                assert np.array_equal(pq.get().reshape(B, nq, N)[:, level + 1:], xq[:, level + 1:])      # limbs above the level are left alone
+            joined = ring.Poly(cQ, nq + np_, B).set(np.concatenate([xq, xp], axis=1))
+            be.ModDownNTTPQ(level, joined, out)
+            assert np.array_equal(out.get().reshape(B, level + 1, N), g), (env, level, "joined")
+            got[(bool(env), level)] = g
+        p = cQ.NewPoly(B).set(xq)
+        cQ.DivFloorByLastModulusNTT(p)
+        f = p.get().reshape(B, nq - 1, N)
+        for b in range(B):
+            assert np.array_equal(f[b], oc.rescale_op("oc_div_floor_by_last_modulus_ntt", xq[b])), (env, b)
+        cQ.DivFloorByLastModulusNTT(p)                                          # one level further down (another table)
+        f2 = p.get().reshape(B, nq - 2, N)
+        for b in range(B):
+            assert np.array_equal(f2[b], oc.rescale_op("oc_div_floor_by_last_modulus_ntt", oc.rescale_op("oc_div_floor_by_last_modulus_ntt", xq[b]))), (env, b)
+        got[(bool(env), "floor")] = f
+    for k in [k for k in got if not k[0]]:
+        assert np.array_equal(got[k], got[(True, k[1])]), k
