@@ -142,7 +142,11 @@ int lr_context_ntt_variants(const lr_context *ctx, int *forward, int *inverse);
  * Handles built over two contexts (lr_bext, lr_ckks_plan, lr_bfv_plan) interleave launches of both: set the same stream on both
  * contexts, or the pipeline entry points return LR_ERR_ARG.  Switching is ordered on the device: the new stream waits for an
  * event recorded on the old one (work already enqueued, and the scratch later calls reuse, stay in order); change streams between
- * calls, not while another thread is inside a call on this context.
+ * calls, not while another thread is inside a call on this context.  THE OLD STREAM MUST STILL BE ALIVE when the switch is made: a
+ * caller that owns the stream calls lr_context_set_stream(ctx, NULL) (or installs its next stream) BEFORE destroying it -- recording
+ * an event on a destroyed hipStream_t is a use-after-free inside the HIP runtime (it crashes, it does not return an error; measured in
+ * round 4), so the library cannot detect it.  If the runtime does report an error for the old stream, the library drains the device
+ * instead and installs the new stream all the same.
  * HIP graphs: a pipeline call captured after one warm-up call bakes the addresses of the context's pooled scratch into the graph;
  * the pool never frees a buffer while the context lives, so replays stay valid until lr_context_destroy. */
 int lr_context_set_stream(lr_context *ctx, void *hip_stream);

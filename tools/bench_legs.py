@@ -315,10 +315,11 @@ def build_legs(pkg, oracle, device=0, only=None):
                 def cpu(i):
                     op, ocqp = oplan(), oracle.Context(N, QP)
                     return lambda: op.encrypt_pk(ocqp, level, qp_h[0][0], pk_h[0][0], pk_h[1][0], qp_h[1][0], qp_h[2][0], k["comp_h"][0][0])
-                out.append(Leg("ckks_encrypt_pk", "Encrypt/s", B, 8 * N * (5 * (l + kP) + 3 * l), tag,
+                out.append(Leg("ckks_encrypt_pk", "Encrypt/s", B, 8 * N * (3 * (l + kP) + 3 * l), tag,
                                "ckks/ckks_benchmarks_test.go:79-100 (Encrypt with the public key, the branch through the special primes ckks/encryptor.go:205-234, after the sampling)",
                                lambda: plan.EncryptPk(level, u, pk, (e0, e1), comp[0], (outp[0], outp[1])), check, cpu, B, sync=cq,
-                               note="u, e0, e1 and the public key over Q||P, the plaintext over Q, two components out; sampling stays on the host (SURVEY 8(f)2)"))
+                               note="u, e0, e1 over Q||P and the plaintext over Q in, two components out; the public key is one pair of polys shared by the "
+                                    "whole batch (read once per call, not counted per unit); sampling stays on the host (SURVEY 8(f)2)"))
             if want("ckks_decrypt"):
                 def check():
                     plan.Decrypt(level, (comp[0], comp[1]), sk, outp[2])
@@ -327,8 +328,9 @@ def build_legs(pkg, oracle, device=0, only=None):
                 def cpu(i):
                     op, x = oplan(), ct_h(0, 0)
                     return lambda: op.decrypt(level, x, sk_h[0])
-                out.append(Leg("ckks_decrypt", "Decrypt/s", B, 8 * N * 4 * l, tag, "ckks/ckks_benchmarks_test.go:103-118 (Decrypt of a degree-1 ciphertext, ckks/decryptor.go:53-78)",
-                               lambda: plan.Decrypt(level, (comp[0], comp[1]), sk, outp[2]), check, cpu, B, reps=20, sync=cq))
+                out.append(Leg("ckks_decrypt", "Decrypt/s", B, 8 * N * 3 * l, tag, "ckks/ckks_benchmarks_test.go:103-118 (Decrypt of a degree-1 ciphertext, ckks/decryptor.go:53-78)",
+                               lambda: plan.Decrypt(level, (comp[0], comp[1]), sk, outp[2]), check, cpu, B, reps=20, sync=cq,
+                               note="two components in, the plaintext out; the secret key is one poly shared by the batch (not counted per unit)"))
         if want("marshal_ingest"):
             # Poly.UnmarshalBinary (ring/ring_object.go:252) of one ciphertext component per call: the big-endian bytes cross PCIe as they are
             # and are swapped on the device (lr_poly_unmarshal); the entry point takes a host buffer and synchronises
