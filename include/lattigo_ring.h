@@ -468,6 +468,28 @@ int lr_bfv_plan_destroy(lr_bfv_plan *plan);
 int lr_bfv_mul(lr_bfv_plan *plan, const lr_poly *ct0_c0, const lr_poly *ct0_c1, const lr_poly *ct1_c0,
                const lr_poly *ct1_c1, lr_poly *out_c0, lr_poly *out_c1, lr_poly *out_c2);
 
+/* ------------------------------------------------------------------ multi-device ------ */
+/* a batch of independent ciphertexts shards across the GPUs of a node by contiguous blocks (replicated contexts, tables
+ * and keys, created per device with lr_context_create(..., device, ...)); nothing crosses devices but finished results.  The reference's
+ * parallel model is goroutines in ONE process, one evaluator each (examples/dbfv/psi/psi.go:215-233): here one host thread per device,
+ * every handle bound to its device, and these three entry points for the exchange -- no second process, no collective library.
+ *
+ * lr_poly_copy_peer: polys [src_index, src_index + count) of src -> slots [dst_index, ...) of dst (same N and limb count; any two devices
+ * of the process, or the same one).  Asynchronous and ordered on the devices: the copy runs on a copy stream the library keeps per
+ * (destination device, source device) pair -- xGMI is point-to-point, so the copies from different peers into one root use different links
+ * at once -- behind an event recorded NOW on src_ctx's stream (it waits for everything enqueued through src_ctx before this call, e.g. the
+ * kernels that produce the chunk), and overlaps whatever src_ctx is given next.  Nothing is enqueued on dst_ctx's stream: the consumer
+ * calls lr_context_wait_peer_copies(dst_ctx) when it wants to read -- dst_ctx's stream then waits (on the device) for every copy into its
+ * device enqueued so far.  Callable from any thread; the source must not be overwritten before the copy has run (the caller's ordering:
+ * later work of src_ctx on those polys must follow an lr_context_wait_peer_copies / lr_context_sync of the consumer).
+ *
+ * lr_gather_blocks: the whole gather in one call: block r = the first counts[r] polys of srcs[r], placed in dst one behind the other in
+ * block order (= global unit order under contiguous-block sharding), then lr_context_wait_peer_copies(dst_ctx).  A producer that works in
+ * chunks calls lr_poly_copy_peer per chunk instead and overlaps the copies with the next chunk's kernels (tools/multi_gpu_bench.cpp). */
+int lr_poly_copy_peer(lr_context *dst_ctx, lr_poly *dst, int dst_index, lr_context *src_ctx, const lr_poly *src, int src_index, int count);
+int lr_context_wait_peer_copies(lr_context *ctx);
+int lr_gather_blocks(lr_context *dst_ctx, lr_poly *dst, lr_context *const *src_ctxs, const lr_poly *const *srcs, const int *counts, int n_blocks);
+
 /* ------------------------------------------------------------------ measurement ------- */
 /* HIP events on the context's stream (bench.py's roofline leg). */
 int lr_timer_start(lr_context *ctx);

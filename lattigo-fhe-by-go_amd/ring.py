@@ -390,6 +390,24 @@ class Context:
     def DivRoundByLastModulusMany(self, p0, nb): check(lib().lr_div_round_by_last_modulus_many(self.h, p0.h, nb, 0))
     def DivRoundByLastModulusManyNTT(self, p0, nb): check(lib().lr_div_round_by_last_modulus_many(self.h, p0.h, nb, 1))
 
+    # --- multi-device (one process, one thread per device): SURVEY 8(e) ---------------------------
+    def CopyPeer(self, dst, dst_index, src_ctx, src, src_index, count):
+        """polys [src_index, +count) of src (on src_ctx's device) -> slots [dst_index, ...) of dst (on this context's device), on the copy
+        stream of that device pair, behind what src_ctx has enqueued so far (lr_poly_copy_peer); asynchronous"""
+        check(lib().lr_poly_copy_peer(self.h, dst.h, dst_index, src_ctx.h, src.h, src_index, count))
+
+    def WaitPeerCopies(self):
+        """this context's stream waits (on the device) for every peer copy into its device enqueued so far"""
+        check(lib().lr_context_wait_peer_copies(self.h))
+
+    def GatherBlocks(self, dst, blocks):
+        """blocks: [(src_ctx, src_poly, count)] -> dst, one behind the other in block order, then WaitPeerCopies (lr_gather_blocks)"""
+        n = len(blocks)
+        ctxs = (C.c_void_p * n)(*[b[0].h.value for b in blocks])
+        polys = (C.c_void_p * n)(*[b[1].h.value for b in blocks])
+        counts = (C.c_int * n)(*[int(b[2]) for b in blocks])
+        check(lib().lr_gather_blocks(self.h, dst.h, ctxs, polys, counts, n))
+
     # --- measurement -------------------------------------------------------------------------
     def TimerStart(self):
         check(lib().lr_timer_start(self.h))

@@ -90,7 +90,10 @@ def test_every_c_call_matches_the_header():
                                          # array and uses the per-limb forms (lr_poly_upload_limb, lr_poly_download_limb, lr_ntt_host_limb)
                                          "lr_poly_upload", "lr_poly_download", "lr_ntt_host", "lr_intt_host",
                                          # the shim creates its handles through the *_create_ex forms (DefaultOptions; nil = the defaults, which is what these do)
-                                         "lr_context_create", "lr_ckks_plan_create", "lr_bfv_plan_create"})
+                                         "lr_context_create", "lr_ckks_plan_create", "lr_bfv_plan_create",
+                                         # a Go Poly is one polynomial (its own lr_poly): the shim's GatherTo is lr_poly_copy_peer per poly +
+                                         # lr_context_wait_peer_copies; the one-call block form serves batched callers (C++, Python)
+                                         "lr_gather_blocks"})
     assert not unused, unused
 
 
