@@ -97,8 +97,8 @@ def test_chunked_copies_overlap_and_the_consumer_waits_on_the_device(gpu_pkg, or
 
 def test_peer_copy_argument_checks(gpu_pkg):
     ring, params = gpu_pkg.ring, gpu_pkg.params
-    N, Q = params.DefaultParamsQi(12)
-    a, b = ring.NewContextWithParams(N, Q), ring.NewContextWithParams(N, Q[:2])
+    N, Q = params.DefaultParamsQi(14)
+    a, b = ring.NewContextWithParams(N, Q[:4]), ring.NewContextWithParams(N, Q[:2])
     pa, pb = a.NewPoly(4), b.NewPoly(4)
     err = gpu_pkg._native.LatticeRingError
     with pytest.raises(err):

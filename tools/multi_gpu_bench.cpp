@@ -2,7 +2,8 @@
 // direct HIP call): a batch of independent CKKS MulRelin at DefaultParams[PN16QP1761], sharded over the GPUs of the node by contiguous
 // blocks -- one host thread per device, each with its own contexts, plan, key image and operands, the stand-in of one goroutine with its own
 // evaluator (examples/dbfv/psi/psi.go:215-233) -- and the results gathered to device 0 by lr_poly_copy_peer per chunk, so that a chunk
-// crosses xGMI while the next one is computed; lr_context_wait_peer_copies on the root at the end of the step.
+// crosses xGMI while the next one is computed (device 0 computes straight into its block of the root buffers); lr_context_wait_peer_copies
+// on the root at the end of the step.
 //
 //   build: tools/dbg/multi_gpu_bench.py --build     (g++ against the in-tree liblattigo_ring_hip.so)
 //   run  : tools/build/multi_gpu_bench [--gpus G] [--units U] [--chunk C] [--steps K] [--warmup W] [--set PN16QP1761|PN15QP880|PN14QP438] [--logn n]
@@ -184,7 +185,17 @@ int main(int argc, char **argv) {
         // operands: four distinct units per device (seeded by device and unit), tiled over the block ON THE DEVICE: unit u takes pattern u % 4
         const int distinct = std::min(units, 4);
         for (int k = 0; k < 4; ++k) CK(lr_poly_alloc(d.cq, nq, units, &d.in[k]));
-        for (int k = 0; k < 2; ++k) CK(lr_poly_alloc(d.cq, nq, units, &d.out[k]));
+        // device 0 computes straight into its block of the root buffers (the first `units` slots): its share of the gather costs nothing
+        if (g == 0) {
+            for (int k = 0; k < 2; ++k) CK(lr_poly_alloc(d.cq, nq, total, &root[k]));
+            for (int k = 0; k < 2; ++k) {
+                void *base = nullptr;
+                CK(lr_poly_info(root[k], nullptr, nullptr, nullptr, &base));
+                CK(lr_poly_wrap(d.cq, base, nq, units, &d.out[k]));
+            }
+        } else {
+            for (int k = 0; k < 2; ++k) CK(lr_poly_alloc(d.cq, nq, units, &d.out[k]));
+        }
         {
             std::vector<uint64_t> h(poly_words);
             lr_poly *one = nullptr;
@@ -224,8 +235,6 @@ int main(int argc, char **argv) {
                 d.vout[k].push_back(v);
             }
         }
-        if (g == 0)
-            for (int k = 0; k < 2; ++k) CK(lr_poly_alloc(d.cq, nq, total, &root[k]));
         CK(lr_context_sync(d.cq));
         bar.wait();
         lr_context *rootctx = dev[0].cq;
@@ -235,7 +244,7 @@ int main(int argc, char **argv) {
             for (int u0 = 0; u0 < units; u0 += chunk, ++c) {
                 const int nb = std::min(chunk, units - u0);
                 CK(lr_ckks_mulrelin(d.plan, level, d.vin[0][c], d.vin[1][c], d.vin[2][c], d.vin[3][c], d.key, d.vout[0][c], d.vout[1][c]));
-                if (gather)
+                if (gather && g != 0)
                     for (int k = 0; k < 2; ++k) CK(lr_poly_copy_peer(rootctx, root[k], g * units + u0, d.cq, d.out[k], u0, nb));
             }
         };
@@ -260,8 +269,13 @@ int main(int argc, char **argv) {
         }
         // placement: poison the root, one more step, compare sampled units of every block with their producer's own output
         if (g == 0) {
-            std::vector<uint64_t> ff((size_t)total * poly_words, ~0ull);
-            for (int k = 0; k < 2; ++k) CK(lr_poly_upload_dense(root[k], ff.data(), ff.size()));
+            std::vector<uint64_t> ff(poly_words, ~0ull);
+            lr_poly *one = nullptr;
+            CK(lr_poly_alloc(d.cq, nq, 1, &one));
+            CK(lr_poly_upload_dense(one, ff.data(), ff.size()));
+            for (int k = 0; k < 2; ++k) CK(lr_ewise(d.cq, LR_COPY, level, one, nullptr, root[k], nullptr));     // broadcast over all `total` slots
+            CK(lr_context_sync(d.cq));
+            CK(lr_poly_free(one));
         }
         bar.wait();
         step(true);
