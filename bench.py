@@ -1315,6 +1315,23 @@ def main():
         secondary("config5", config5_prepare, lambda c: config5_run(c, 3, 1))
         progress("config 5 leg done")
 
+    if rank == 0 and world == 1 and not use_dist and not args.no_config5 and not args.no_ckks:
+        # the same leg from a plain C++ host: ONE process, one host thread per device, the C ABI only, lr_poly_copy_peer for the gather
+        # (tools/multi_gpu_bench.cpp; SURVEY 8(e), the reference's goroutine-per-evaluator model).  G = min(8, devices visible to this process).
+        def single_process_leg():
+            import importlib.util
+            spec = importlib.util.spec_from_file_location("multi_gpu_bench", _tool("multi_gpu_bench.py"))
+            mod = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(mod)
+            res = mod.run(["--gpus", 8, "--units", args.config5_units, "--chunk", args.config5_chunk, "--steps", 3, "--warmup", 1], timeout=600)
+            if res.returncode != 0:
+                raise RuntimeError("multi_gpu_bench exited with %d: %s" % (res.returncode, res.stderr[-300:]))
+            return json.loads(res.stdout.strip().splitlines()[-1])
+        out["config5_single_process"], err = checked(single_process_leg, None)
+        if err:
+            out["config5_single_process"] = {"error": err}
+        progress("config 5 from one process through the C ABI: %s" % (out["config5_single_process"].get("value") or out["config5_single_process"].get("error")))
+
     if rank == 0 and world == 1 and not use_dist and not args.no_traffic and B == (1 << 30) // (8 * N * L):
         # counters need their own rocprofv3 passes: three child runs per kernel / pipeline (FETCH_SIZE, WRITE_SIZE, and the vector-issue
         # set SQ_INSTS_VALU + SQ_WAVES + GRBM_GUI_ACTIVE) on the same shapes, after all timing
@@ -1397,6 +1414,10 @@ def main():
         for key in ("mulcoeffs_montgomery", "div_round_by_last_modulus_ntt"):
             if key in ex:
                 summary[key + "_R15"] = {"frac": round(ex[key]["frac_hbm"], 4), "bit_exact": ex[key].get("bit_exact")}
+        if isinstance(out.get("config5_single_process"), dict) and "value" in out["config5_single_process"]:
+            c5s = out["config5_single_process"]
+            summary["config5_single_process"] = {"per_s": round(c5s["value"], 1), "n_gpus": c5s["n_gpus"], "placement_ok": c5s["placement_ok"],
+                                                 "frac": round(c5s["roofline"]["frac"], 4)}
         for key in ("ckks_mulrelin", "bfv_mul", "config5"):
             if isinstance(out.get(key), dict) and "roofline" in out[key]:
                 summary[key] = {"per_s": round(out[key]["value"], 1), "frac": frac(out[key]), "traffic_ratio": ratio(out[key]), "bit_exact": out[key].get("bit_exact")}
