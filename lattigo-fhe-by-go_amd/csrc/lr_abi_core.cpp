@@ -18,7 +18,8 @@ hipError_t create_stream(hipStream_t *s, int cls) {
 
 hipStream_t shared_stream(int device) {
     static std::mutex mu;
-    static std::map<int, hipStream_t> streams;
+    static std::map<int, hipStream_t> &streams = *new std::map<int, hipStream_t>();   // never destroyed, like the streams it holds: handles may be
+                                                                                    // released by a garbage-collected host after main() returns
     std::lock_guard<std::mutex> lock(mu);
     auto it = streams.find(device);
     if (it != streams.end()) return it->second;

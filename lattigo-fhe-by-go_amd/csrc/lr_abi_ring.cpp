@@ -135,7 +135,17 @@ int run_ntt_launch(lr_context *c, bool inverse, Rows in, Rows out, int mod0, int
         a.fp_fin_delta = (const char *)(inverse ? c->d_inv_fin_fp : c->d_fwd_fin_fp) - (const char *)a.tw_fin;
         a.fp_lp = c->d_fp_lp;
     }
-    char *kn = c->last_ntt_kernel;
+    // the launcher writes the kernel's name into a local buffer; it reaches the context under its diagnostics mutex on every way out
+    struct KernelNote {
+        lr_context *c;
+        char buf[32];
+        ~KernelNote() {
+            if (!buf[0]) return;
+            std::lock_guard<std::mutex> lock(c->diag_mu);
+            std::memcpy(c->last_ntt_kernel, buf, sizeof buf);
+        }
+    } note{c, ""};
+    char *kn = note.buf;
     // N = 2^14: 512 threads per transform put two workgroups on a CU (best throughput); a launch that does not fill the chip anyway takes
     // the 1024-thread plan, whose one workgroup is done sooner (PN14QP438, one ciphertext: MulRelin 115 -> 102 us, BFV Mul 136 -> 125 us)
     const bool wide14 = c->opt.asm14_1024 || (logn == 14 && !c->opt.no_wide14_small && (long long)count * batch <= c->opt.wide14_max_items);
@@ -258,7 +268,7 @@ int run_ntt_launch(lr_context *c, bool inverse, Rows in, Rows out, int mod0, int
         LR_HIP(launch_ntt_asm(a, (int)logn, inverse, variant, stream_of(c), wide14, kn, false, c->opt.stagger, ntt_persist(c, a, logn, inverse), !c->opt.no_grid_padding));
         return LR_OK;
     }
-    std::snprintf(c->last_ntt_kernel, sizeof c->last_ntt_kernel, "ntt_%s_kernel<%u>", inverse ? "inv" : "fwd", logn);
+    std::snprintf(note.buf, sizeof note.buf, "ntt_%s_kernel<%u>", inverse ? "inv" : "fwd", logn);
     LR_HIP(launch_ntt(a, (int)logn, inverse, c->ntt_mode, stream_of(c)));
     return LR_OK;
 }
@@ -1013,6 +1023,7 @@ extern "C" int lr_context_timeline(lr_context *c, uint32_t *dst, size_t capacity
 extern "C" int lr_context_last_ntt_kernel(const lr_context *c, char *buf, size_t capacity) {
     return guarded([&]() -> int {
     if (!c || !buf || capacity == 0) return fail(LR_ERR_ARG, "null argument");
+    std::lock_guard<std::mutex> lock(c->diag_mu);
     std::snprintf(buf, capacity, "%s", c->last_ntt_kernel);
     return LR_OK;
     });

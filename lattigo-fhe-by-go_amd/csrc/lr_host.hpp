@@ -171,7 +171,8 @@ struct lr_context {
     u64 *d_rescale = nullptr;   // [L][L]
     Options opt;                // environment switches, read once at creation
     ScratchPool scratch;        // rescale / staging temporaries, leased per call (thread-safe)
-    char last_ntt_kernel[32] = "";   // name of the kernel the last NTT launch of this context dispatched (diagnostics, bench.py)
+    char last_ntt_kernel[32] = "";   // name of the kernel the last NTT launch of this context dispatched (diagnostics, bench.py); a context may be
+    mutable std::mutex diag_mu;      // shared by threads, so the name is written and read under diag_mu (found by ThreadSanitizer, round 4)
     u32 *d_stamps = nullptr;    // timeline builds (Options::timeline): [workgroup][wave 16][stamp 16] of the last stamped launch
     size_t stamp_words = 0, stamp_used = 0;
     // DivRoundByLastModulusNTT: per level, -(pHalfNegQi[i] * NTT_i(1 + X + ... + X^(N-1))) * rescaleParams[i] for i < level,
