@@ -1194,6 +1194,87 @@ def main():
         progress("evaluator-per-thread MulRelin: " + ", ".join("T=%d %.0f/s" % (r["threads"], r["mulrelin_per_s"]) for r in rows) +
                  "; through the batcher: " + ", ".join("T=%d %.0f/s (mean batch %.1f)" % (r["threads"], r["mulrelin_per_s"], r["mean_batch"]) for r in brows))
 
+    if rank == 0 and world == 1 and not args.no_ckks and not args.no_threads:
+        # The same for the workload the reference itself pools: every task of examples/dbfv/psi/psi.go:219-228 runs evaluator.Mul and
+        # evaluator.Relinearize on one BFV ciphertext pair.  T host threads, each with its own contexts, plans and stream, one pair per call
+        # (direct), and the same callers through lr_bfv_batcher_* (two lanes).  PN14QP438 (BASELINE config 4's set), pairs per second.
+        import threading
+        fN, fQ, fP, fM = params.bfv_moduli("PN14QP438")
+        fQ, fP, fM = list(fQ), list(fP), list(fM)
+        fnq, fnp = len(fQ), len(fP)
+        fbeta = -(-fnq // fnp)
+        fkey_h = sampling.uniform_poly(fQ + fP, fN, 2 * fbeta, seed=19)
+        fops = [sampling.uniform_poly(fQ, fN, 1, seed=80 + k) for k in range(4)]
+        want_mul = oracle.BfvPlan(oracle.Context(fN, fQ), oracle.Context(fN, fM), 65537).mul(np.stack([fops[0][0], fops[1][0]]), np.stack([fops[2][0], fops[3][0]]))
+        want_lin = oracle.CkksPlan(oracle.Context(fN, fQ), oracle.Context(fN, fP)).bfv_relinearize(want_mul, fkey_h.reshape(fbeta, 2, fnq + fnp, fN))
+
+        def run_threads(T, make, iters):
+            workers = [make(i) for i in range(T)]
+            gate = threading.Barrier(T + 1)
+
+            def loop(w):
+                gate.wait()
+                for _ in range(iters):
+                    w["call"]()
+                w["ctx"].Sync()
+            ths = [threading.Thread(target=loop, args=(w,)) for w in workers]
+            for th in ths:
+                th.start()
+            gate.wait()
+            t_w = time.perf_counter()
+            for th in ths:
+                th.join()
+            dt_w = time.perf_counter() - t_w
+            ok = all(np.array_equal(w["lin"][k].get().reshape(fnq, fN), want_lin[k]) for w in workers for k in range(2))
+            return T * iters / dt_w, bool(ok)
+
+        def make_direct(i):
+            st_i = torch.cuda.Stream()
+            cq, cp, cm = (ring.NewContextWithParams(fN, m, device=local) for m in (fQ, fP, fM))
+            for c in (cq, cp, cm):
+                c.SetStream(st_i.cuda_stream)
+            mul, ks = ring.BfvPlan(cq, cm, 65537, 1), ring.CkksPlan(cq, cp, 1)
+            key = ks.NewSwitchingKey().set(fkey_h)
+            c0, c1 = (cq.NewPoly(1).set(fops[0]), cq.NewPoly(1).set(fops[1])), (cq.NewPoly(1).set(fops[2]), cq.NewPoly(1).set(fops[3]))
+            d2, lin = (cq.NewPoly(1), cq.NewPoly(1), cq.NewPoly(1)), (cq.NewPoly(1), cq.NewPoly(1))
+
+            def call():
+                mul.Mul(c0, c1, d2)
+                ks.BfvRelinearize(d2, key, lin)
+            call()
+            cq.Sync()
+            return {"call": call, "ctx": cq, "lin": lin, "keep": (st_i, cp, cm, mul, ks, key, c0, c1, d2)}
+        frows = []
+        for T in (1, 4, 16):
+            rate, ok = run_threads(T, make_direct, 200 if T == 1 else 100)
+            frows.append({"threads": T, "streams": T, "pairs_per_call": 1, "mul_relin_per_s": rate, "bit_exact": ok})
+        fbat = ring.BfvBatcher(fN, fQ, fP, fM, 65537, max_batch=64, lanes=2, device=local)
+        fbkey = fbat.NewSwitchingKey().set(fkey_h)
+        fctx = ring.NewContextWithParams(fN, fQ, device=local)
+
+        def make_batched(i):
+            c0, c1 = (fctx.NewPoly(1).set(fops[0]), fctx.NewPoly(1).set(fops[1])), (fctx.NewPoly(1).set(fops[2]), fctx.NewPoly(1).set(fops[3]))
+            d2, lin = (fctx.NewPoly(1), fctx.NewPoly(1), fctx.NewPoly(1)), (fctx.NewPoly(1), fctx.NewPoly(1))
+
+            def call():
+                fbat.Mul(c0, c1, d2)
+                fbat.Relinearize(d2, fbkey, lin)
+            call()
+            return {"call": call, "ctx": fctx, "lin": lin, "keep": (c0, c1, d2)}
+        fbrows = []
+        for T in (16, 64):
+            before = fbat.Stats()
+            rate, ok = run_threads(T, make_batched, 100)
+            after = fbat.Stats()
+            fbrows.append({"threads": T, "lanes": 2, "pairs_per_call": 1, "mul_relin_per_s": rate, "bit_exact": ok,
+                           "mean_batch": (after["products"] - before["products"]) / max(1, after["batches"] - before["batches"]), "largest_batch": after["largest"]})
+        del fbat
+        out["evaluator_threads_bfv"] = {"params": "bfv PN14QP438, one ciphertext pair per call: evaluator.Mul then evaluator.Relinearize", "rows": frows, "batcher_rows": fbrows,
+                                        "batched_call_of_256": "bfv_mul + pipelines.bfv_relinearize of this line: one call over 256 pairs",
+                                        "reference_model": "the pooled task of examples/dbfv/psi/psi.go:219-228"}
+        progress("evaluator-per-thread BFV Mul + Relinearize: " + ", ".join("T=%d %.0f/s" % (r["threads"], r["mul_relin_per_s"]) for r in frows) +
+                 "; through the batcher: " + ", ".join("T=%d %.0f/s (mean batch %.1f)" % (r["threads"], r["mul_relin_per_s"], r["mean_batch"]) for r in fbrows))
+
     if not args.no_extras and rank == 0:
         # the other kernels BASELINE.json's north_star asks throughput for, same ring, same resident batch; after timing,
         # the last poly of every output is compared with the oracle

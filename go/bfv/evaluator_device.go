@@ -33,6 +33,31 @@ type deviceState struct {
 
 var deviceStates sync.Map // *evaluator -> *deviceState
 
+// deviceBatcher, when set, takes the degree-1 x degree-1 Mul and the degree-2 Relinearize calls of EVERY evaluator over the same moduli:
+// upstream's own pooled workload (examples/dbfv/psi/psi.go:215-233: one evaluator per goroutine, Mul + Relinearize per task) leaves the
+// device mostly idle per call; the batcher runs the calls that are in flight together as one batched pipeline (ring.BfvBatcher).
+var deviceBatcher *ring.BfvBatcher
+
+// EnableDeviceBatcher builds the shared batcher for a parameter set: maxBatch ciphertexts per launch, `lanes` launches in flight (2).
+func EnableDeviceBatcher(params *Parameters, maxBatch, lanes int) {
+	c := newBFVContext(params)
+	deviceBatcher = ring.NewBfvBatcher(c.n, c.contextQ.Modulus, c.contextP.Modulus, c.contextQMul.Modulus, params.T, maxBatch, lanes)
+}
+
+func (evaluator *evaluator) batcher() *ring.BfvBatcher {
+	b := deviceBatcher
+	q := evaluator.bfvContext.contextQ
+	if b == nil || evaluator.baseconverterQ1P == nil || b.N != q.N || len(b.Q) != len(q.Modulus) || b.T != evaluator.params.T {
+		return nil
+	}
+	for i, qi := range q.Modulus {
+		if b.Q[i] != qi {
+			return nil
+		}
+	}
+	return b
+}
+
 func (evaluator *evaluator) dev() *deviceState {
 	if s, ok := deviceStates.Load(evaluator); ok {
 		return s.(*deviceState)
@@ -81,6 +106,11 @@ func (evaluator *evaluator) Mul(op0 *Ciphertext, op1 Operand, ctOut *Ciphertext)
 	el0, el1, elOut := evaluator.getElemAndCheckBinary(op0, op1, ctOut, op0.Degree()+op1.Degree())
 	if el0.Degree() == 1 && el1.Degree() == 1 {
 		evaluator.resident(el0.value[0], el0.value[1], el1.value[0], el1.value[1], elOut.value[0], elOut.value[1], elOut.value[2])
+		if b := evaluator.batcher(); b != nil {
+			b.Mul(evaluator.bfvContext.contextQ, [2]*ring.Poly{el0.value[0], el0.value[1]}, [2]*ring.Poly{el1.value[0], el1.value[1]},
+				[3]*ring.Poly{elOut.value[0], elOut.value[1], elOut.value[2]})
+			return
+		}
 		evaluator.dev().mul.Mul([2]*ring.Poly{el0.value[0], el0.value[1]}, [2]*ring.Poly{el1.value[0], el1.value[1]},
 			[3]*ring.Poly{elOut.value[0], elOut.value[1], elOut.value[2]})
 		return
@@ -108,6 +138,12 @@ func (evaluator *evaluator) relinearize(ct0 *Ciphertext, evakey *EvaluationKey, 
 	context := evaluator.bfvContext.contextQ
 	if ct0.Degree() == 2 {
 		evaluator.resident(ct0.value[0], ct0.value[1], ct0.value[2], ctOut.value[0], ctOut.value[1])
+		if b := evaluator.batcher(); b != nil {
+			b.Relinearize(context, [3]*ring.Poly{ct0.value[0], ct0.value[1], ct0.value[2]}, b.KeyImage(evakey.evakey[0].evakey),
+				[2]*ring.Poly{ctOut.value[0], ctOut.value[1]})
+			ctOut.SetValue(ctOut.value[:2])
+			return
+		}
 		evaluator.dev().ks.BfvRelinearize([3]*ring.Poly{ct0.value[0], ct0.value[1], ct0.value[2]}, evaluator.keyImage(evakey.evakey[0]),
 			[2]*ring.Poly{ctOut.value[0], ctOut.value[1]})
 		ctOut.SetValue(ctOut.value[:2])

@@ -468,6 +468,28 @@ int lr_bfv_plan_destroy(lr_bfv_plan *plan);
 int lr_bfv_mul(lr_bfv_plan *plan, const lr_poly *ct0_c0, const lr_poly *ct0_c1, const lr_poly *ct1_c0,
                const lr_poly *ct1_c1, lr_poly *out_c0, lr_poly *out_c1, lr_poly *out_c2);
 
+/* The batcher for the workload the reference itself pools: every task of examples/dbfv/psi/psi.go:215-233 runs evaluator.Mul and
+ * evaluator.Relinearize on one BFV ciphertext pair.  Concurrent calls from any number of host threads are merged into batched launches
+ * as by lr_ckks_batcher: a call queues its request, whichever caller finds a free lane runs everything queued of the same kind (and, for
+ * Relinearize, the same key image handle) -- up to max_batch polys, in arrival order -- and wakes the others; the call returns when its own
+ * result is complete on the device.  The callers' polys are read and written in place through a pointer table (one gather and one
+ * scatter kernel around the staged pipeline).  mul_plans[i] / ks_plans[i]: one lr_bfv_plan over (contextQ_i, contextQMul_i) and one
+ * lr_ckks_plan over the SAME contextQ_i and (contextQ_i, contextP_i) per lane -- the two halves of what bfv.NewEvaluator builds
+ * (bfv/evaluator.go:89-112) -- each lane over its own contexts, same moduli, device, t and max_batch; ks_plans may be NULL (no
+ * Relinearize).  The batcher sets one stream per lane on the lane's contexts; plans and contexts stay owned by the caller, must outlive
+ * the batcher and are used for nothing else while it exists (destroying one first is LR_ERR_ARG).  Same bits as lr_bfv_mul /
+ * lr_bfv_relinearize; an error of a batch is returned by every call that was part of it. */
+typedef struct lr_bfv_batcher lr_bfv_batcher;
+int lr_bfv_batcher_create(lr_bfv_plan *const *mul_plans, lr_ckks_plan *const *ks_plans, int n_lanes, lr_bfv_batcher **out);
+void lr_bfv_batcher_destroy(lr_bfv_batcher *batcher);
+/* evaluator.Mul (bfv/evaluator.go:467) of two degree-1 ciphertexts: coefficient domain, degree-2 result */
+int lr_bfv_batcher_mul(lr_bfv_batcher *batcher, const lr_poly *ct0_c0, const lr_poly *ct0_c1, const lr_poly *ct1_c0, const lr_poly *ct1_c1,
+                       lr_poly *out_c0, lr_poly *out_c1, lr_poly *out_c2);
+/* evaluator.Relinearize (bfv/evaluator.go:512) of a degree-2 ciphertext with the key image evk (one handle for all callers) */
+int lr_bfv_batcher_relinearize(lr_bfv_batcher *batcher, const lr_poly *c0, const lr_poly *c1, const lr_poly *c2, const lr_poly *evk,
+                               lr_poly *out0, lr_poly *out1);
+int lr_bfv_batcher_stats(lr_bfv_batcher *batcher, uint64_t *batches, uint64_t *products, int *largest);
+
 /* ------------------------------------------------------------------ multi-device ------ */
 /* a batch of independent ciphertexts shards across the GPUs of a node by contiguous blocks (replicated contexts, tables
  * and keys, created per device with lr_context_create(..., device, ...)); nothing crosses devices but finished results.  The reference's

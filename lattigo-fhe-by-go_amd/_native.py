@@ -135,6 +135,11 @@ SYMBOLS = {
     "lr_bfv_plan_create_ex": [vp, vp, u64, i32, vp, C.POINTER(vp)],
     "lr_bfv_plan_destroy": [vp],
     "lr_bfv_mul": [vp, vp, vp, vp, vp, vp, vp, vp],
+    "lr_bfv_batcher_create": [vp, vp, i32, vp],
+    "lr_bfv_batcher_destroy": [vp],
+    "lr_bfv_batcher_mul": [vp, vp, vp, vp, vp, vp, vp, vp],
+    "lr_bfv_batcher_relinearize": [vp, vp, vp, vp, vp, vp, vp],
+    "lr_bfv_batcher_stats": [vp, vp, vp, vp],
     "lr_poly_copy_peer": [vp, vp, i32, vp, vp, i32, i32],
     "lr_context_wait_peer_copies": [vp],
     "lr_gather_blocks": [vp, vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(i32), i32],

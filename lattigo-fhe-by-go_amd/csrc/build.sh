@@ -9,7 +9,7 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-ma
 [ -n "$LR_BUILD_DIAG" ] && FLAGS="$FLAGS -DLR_BUILD_DIAG=1"
 mkdir -p build
 # the C ABI, one translation unit per handle family (lr_host.hpp is what they share)
-ABI_UNITS="lr_abi_core lr_abi_ring lr_abi_bext lr_abi_ckks lr_abi_batcher lr_abi_bfv lr_abi_peer"
+ABI_UNITS="lr_abi_core lr_abi_ring lr_abi_bext lr_abi_ckks lr_abi_batcher lr_abi_bfv lr_abi_bfv_batcher lr_abi_peer"
 link() {
   $HIPCC --offload-arch=gfx950 -shared -fPIC -o ../liblattigo_ring_hip.so build/lr_ntt.o build/lr_ewise.o build/lr_bext.o $(for u in $ABI_UNITS; do echo build/$u.o; done) build/lr_precompute.o build/lr_asm.o build/lr_asm_blob.o
   echo "built $(cd .. && pwd)/liblattigo_ring_hip.so"

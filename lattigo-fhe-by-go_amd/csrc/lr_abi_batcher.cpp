@@ -10,34 +10,31 @@
 // through a pointer table and whose results are scattered to the callers' polys by one copy kernel, waits for the lane's stream and
 // wakes the callers.  No thread of its own, no timer: while a lane runs, arrivals queue up and form the next batch.
 // ------------------------------------------------------------------------------------------
-struct lr_ckks_batcher {
-    struct Request {
-        int level = 0, polys = 0;
-        int kind = 0;              // 0: MulRelin (a0, a1) x (b0, b1); 1: rotation / conjugation of (a0, a1) by `gen` with the key `evk`
-        u64 gen = 0;
-        const lr_poly *a0 = nullptr, *a1 = nullptr, *b0 = nullptr, *b1 = nullptr, *evk = nullptr;
-        lr_poly *o0 = nullptr, *o1 = nullptr;
-        bool done = false;
-        int status = LR_OK;
-        std::string error;
-    };
-    struct Lane {
-        lr_ckks_plan *plan = nullptr;
-        bool busy = false;
-        u64 **h_table = nullptr;   // pinned: [4 * max_batch] operand pointers, then [2 * max_batch] result pointers
-        u64 **d_table = nullptr;
-        Pool o0, o1;               // staged results
-        hipStream_t stream = nullptr;   // created here, set on the lane's two contexts for the batcher's lifetime
-        std::vector<Request *> take;    // the batch being run; reserved at creation, so that forming a batch allocates nothing (a request
-                                        // taken off the queue is always completed: nothing can throw between the two)
-    };
-    std::vector<Lane> lanes;
-    int max_batch = 0;
-    std::mutex m;
-    std::condition_variable cv;
-    std::deque<Request *> queue;
-    unsigned long long batches = 0, products = 0;
-    int largest = 0;
+struct lr_ckks_batcher_request {
+    int level = 0, polys = 0;
+    int kind = 0;              // 0: MulRelin (a0, a1) x (b0, b1); 1: rotation / conjugation of (a0, a1) by `gen` with the key `evk`
+    u64 gen = 0;
+    const lr_poly *a0 = nullptr, *a1 = nullptr, *b0 = nullptr, *b1 = nullptr, *evk = nullptr;
+    lr_poly *o0 = nullptr, *o1 = nullptr;
+    bool done = false;
+    int status = LR_OK;
+    std::string error;
+    // requests that may share a launch: same operation, level and key image
+    bool same_batch(const lr_ckks_batcher_request &o) const { return kind == o.kind && gen == o.gen && level == o.level && evk == o.evk; }
+};
+struct lr_ckks_batcher_lane {
+    lr_ckks_plan *plan = nullptr;
+    bool busy = false;
+    u64 **h_table = nullptr;   // pinned: [4 * max_batch] operand pointers, then [2 * max_batch] result pointers
+    u64 **d_table = nullptr;
+    Pool o0, o1;               // staged results
+    hipStream_t stream = nullptr;   // created here, set on the lane's two contexts for the batcher's lifetime
+    std::vector<lr_ckks_batcher_request *> take;    // the batch being run; reserved at creation, so that forming a batch allocates nothing
+    int device() const { return plan ? plan->device : 0; }
+};
+struct lr_ckks_batcher : BatchQueue<lr_ckks_batcher_request, lr_ckks_batcher_lane> {
+    typedef lr_ckks_batcher_request Request;
+    typedef lr_ckks_batcher_lane Lane;
 };
 
 namespace lr_host {
@@ -217,63 +214,7 @@ int batcher_submit(lr_ckks_batcher *B, int kind, int level, const lr_poly *a0, c
     req.gen = gen;
     req.level = level; req.polys = polys;
     req.a0 = a0; req.a1 = a1; req.b0 = b0; req.b1 = b1; req.evk = evk; req.o0 = o0; req.o1 = o1;
-    std::unique_lock<std::mutex> lk(B->m);
-    B->queue.push_back(&req);
-    for (;;) {
-        if (req.done) break;
-        int free_lane = -1;
-        for (size_t i = 0; i < B->lanes.size() && free_lane < 0; ++i)
-            if (!B->lanes[i].busy) free_lane = (int)i;
-        if (free_lane < 0 || B->queue.empty()) {
-            B->cv.wait(lk);
-            continue;
-        }
-        // lead: everything queued that shares the head's (level, key), in arrival order, up to max_batch polys
-        auto &lane = B->lanes[free_lane];
-        std::vector<lr_ckks_batcher::Request *> &take = lane.take;
-        take.clear();
-        int total = 0;
-        const lr_ckks_batcher::Request *head = B->queue.front();
-        for (auto it = B->queue.begin(); it != B->queue.end();) {
-            lr_ckks_batcher::Request *r = *it;
-            if (r->kind == head->kind && r->gen == head->gen && r->level == head->level && r->evk == head->evk && total + r->polys <= B->max_batch) {
-                take.push_back(r);
-                total += r->polys;
-                it = B->queue.erase(it);
-            } else {
-                ++it;
-            }
-        }
-        lane.busy = true;
-        lk.unlock();
-        int rc = guarded([&]() -> int { return batcher_run(B, lane, take); });
-        std::string msg;
-        if (rc != LR_OK) {
-            try { msg = g_error; } catch (...) {}
-            // a batch that failed half-way may have kernels queued that read the callers' operands through d_table, and the copy out of
-            // the pinned h_table may be pending: nothing of it may outlive this point -- the callers are about to be woken, and the next
-            // batch on this lane rewrites the table and the plan's pools (only the success path ends in a synchronisation of its own)
-            (void)hipSetDevice(lane.plan->device);
-            (void)hipStreamSynchronize(lane.stream);
-            (void)hipGetLastError();
-        }
-        lk.lock();
-        lane.busy = false;
-        B->batches += 1;
-        B->products += (unsigned long long)total;
-        B->largest = std::max(B->largest, total);
-        for (auto *r : take) {
-            r->status = rc;
-            if (rc != LR_OK) {
-                try { r->error = msg; } catch (...) {}
-            }
-            r->done = true;
-        }
-        B->cv.notify_all();
-    }
-    lk.unlock();
-    if (req.status != LR_OK) return fail(req.status, req.error);
-    return LR_OK;
+    return B->submit(req, [B](lr_ckks_batcher::Lane &lane, const std::vector<lr_ckks_batcher::Request *> &take) { return batcher_run(B, lane, take); });
 }
 
 }  // namespace lr_host

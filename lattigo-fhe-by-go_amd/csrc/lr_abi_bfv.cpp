@@ -4,28 +4,6 @@
 // ------------------------------------------------------------------------------------------
 // bfv.Evaluator.Mul (tensorAndRescale, bfv/evaluator.go:278-464)
 // ------------------------------------------------------------------------------------------
-struct lr_bfv_plan {
-    int device = 0;
-    lr_context *cQ = nullptr, *cM = nullptr;
-    lr_bext *bext = nullptr;
-    u64 t = 0;
-    LimbScalars phalf_q, phalf_m;     // pHalf = (prod QMul) >> 1 reduced modulo each prime
-    LimbScalars t_mont;               // MForm(t mod q_i), bfv/evaluator.go:462
-    u64 *d_phalf_q = nullptr, *d_phalf_m = nullptr, *d_t_mont = nullptr;   // the same as device arrays (extension epilogues)
-    int max_batch = 0;
-    bool no_ext_epilogue = false;     // Options::bfv_no_ext_epilogue: separate subtract-multiply / scalar passes after the extensions
-    bool no_gather = false;           // Options::bfv_no_gather: every operand / product in launches of its own at every batch size
-    long long gather_below = 1536;    // Options::bfv_gather_below: workgroups of the four operands' joint transform up to which they are gathered (PN14QP438:
-                                      // gathered 346 / 565 / 1015 / 1912 us per batch of 16 / 32 / 64 / 128, per operand 490 / 618 / 1081 / 1805)
-    Pool liftQ, liftM;                // the four operand polys over Q and over QMul, slots a0, a1, b0, b1 of [batch][limbs][N] each
-    Pool prodQ, prodM;                // the three products, slots c0, c1, c2
-    Pool stageIn, stageOut;           // small batches: the operands gathered into one batch of 4 B, the results before they are scattered
-    ~lr_bfv_plan() {
-        for (u64 *p : {d_phalf_q, d_phalf_m, d_t_mont})
-            if (p) (void)hipFree(p);
-    }
-};
-
 namespace lr_host {
 // (prod of moduli) >> 1, then reduced modulo every prime of `targets` (little-endian multi-precision)
 void half_product_residues(const std::vector<u64> &moduli, const std::vector<u64> &targets, LimbScalars &out) {
@@ -88,6 +66,7 @@ extern "C" int lr_bfv_plan_create_ex(lr_context *cQ, lr_context *cM, uint64_t t,
 extern "C" int lr_bfv_plan_destroy(lr_bfv_plan *p) {
     return guarded([&]() -> int {
     if (!p) return LR_OK;
+    if (p->lane_of) return fail(LR_ERR_ARG, "this plan is a lane of a live batcher: destroy the batcher first");
     (void)hipSetDevice(p->device);
     (void)hipDeviceSynchronize();   // the handle's work may be on its contexts' caller-supplied stream
     lr_bext_destroy(p->bext);

@@ -199,12 +199,20 @@ hipError_t launch_horner(const HornerLaunch &L, int limbs, int batch, hipStream_
 
 // batcher form of a result copy: dst[b] = table[b * per_poly + k] for the per_poly staged polys src[k] (rows [limbs][n], batch stride `stride`)
 struct ScatterLaunch {
-    const u64 *src[2];
+    const u64 *src[4];          // per_poly <= 4 of them are used
     long long stride;
     u64 *const *table;
     int per_poly, n;
 };
 hipError_t launch_scatter(const ScatterLaunch &L, int limbs, int batch, hipStream_t stream);
+// the other way round (the BFV batcher's operands): dst[k] + b * stride <- table[b * per_poly + k], k < per_poly <= 4
+struct GatherLaunch {
+    u64 *dst[4];
+    long long stride;
+    const u64 *const *table;
+    int per_poly, n;
+};
+hipError_t launch_gather(const GatherLaunch &L, int limbs, int batch, hipStream_t stream);
 
 // up to four polys with unrelated addresses copied to / from the slots of one contiguous buffer (BFV Mul at a small batch: the four
 // operand polys become one batch of 4 B, the three results leave one batch of 3 B): poly k = z / batch, batch element z % batch

@@ -380,6 +380,7 @@ __global__ __launch_bounds__(256) void scatter_kernel(ScatterLaunch L) {
 
 hipError_t launch_scatter(const ScatterLaunch &L, int limbs, int batch, hipStream_t stream) {
     if (limbs <= 0 || batch <= 0) return hipSuccess;
+    if (L.per_poly < 1 || L.per_poly > 4) return hipErrorInvalidValue;
     const int pairs = L.n >> 1;
     int gx = (pairs + 255) / 256;
     if (gx > 64) gx = 64;
@@ -387,6 +388,30 @@ hipError_t launch_scatter(const ScatterLaunch &L, int limbs, int batch, hipStrea
     const dim3 grid((unsigned)gx, (unsigned)limbs, (unsigned)batch), block(256);
     (void)hipGetLastError();
     hipLaunchKernelGGL(scatter_kernel, grid, block, 0, stream, L);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void gather_kernel(GatherLaunch L) {
+    const long long row = (long long)blockIdx.y * L.n;
+    const long long b = blockIdx.z;
+    const int pairs = L.n >> 1;
+    for (int k = 0; k < L.per_poly; ++k) {
+        const ulonglong2 *ps = reinterpret_cast<const ulonglong2 *>(L.table[b * L.per_poly + k] + row);
+        ulonglong2 *pd = reinterpret_cast<ulonglong2 *>(L.dst[k] + b * L.stride + row);
+        for (int e = blockIdx.x * 256 + threadIdx.x; e < pairs; e += gridDim.x * 256) st_stream(pd + e, ld_stream(ps + e));
+    }
+}
+
+hipError_t launch_gather(const GatherLaunch &L, int limbs, int batch, hipStream_t stream) {
+    if (limbs <= 0 || batch <= 0) return hipSuccess;
+    if (L.per_poly < 1 || L.per_poly > 4) return hipErrorInvalidValue;
+    const int pairs = L.n >> 1;
+    int gx = (pairs + 255) / 256;
+    if (gx > 64) gx = 64;
+    if (gx < 1) gx = 1;
+    const dim3 grid((unsigned)gx, (unsigned)limbs, (unsigned)batch), block(256);
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(gather_kernel, grid, block, 0, stream, L);
     return hipGetLastError();
 }
 

@@ -388,6 +388,110 @@ struct lr_ckks_plan {
     const void *lane_of = nullptr;   // the batcher this plan is a lane of (lanes never fork: their batcher keeps the device busy)
 };
 
+// what bfv.NewEvaluator builds for Mul (bfv/evaluator.go:89-112): lr_abi_bfv.cpp
+struct lr_bfv_plan {
+    int device = 0;
+    lr_context *cQ = nullptr, *cM = nullptr;
+    lr_bext *bext = nullptr;
+    u64 t = 0;
+    LimbScalars phalf_q, phalf_m;     // pHalf = (prod QMul) >> 1 reduced modulo each prime
+    LimbScalars t_mont;               // MForm(t mod q_i), bfv/evaluator.go:462
+    u64 *d_phalf_q = nullptr, *d_phalf_m = nullptr, *d_t_mont = nullptr;   // the same as device arrays (extension epilogues)
+    int max_batch = 0;
+    bool no_ext_epilogue = false;     // Options::bfv_no_ext_epilogue: separate subtract-multiply / scalar passes after the extensions
+    bool no_gather = false;           // Options::bfv_no_gather: every operand / product in launches of its own at every batch size
+    long long gather_below = 1536;    // Options::bfv_gather_below: workgroups of the four operands' joint transform up to which they are gathered (PN14QP438:
+                                      // gathered 346 / 565 / 1015 / 1912 us per batch of 16 / 32 / 64 / 128, per operand 490 / 618 / 1081 / 1805)
+    Pool liftQ, liftM;                // the four operand polys over Q and over QMul, slots a0, a1, b0, b1 of [batch][limbs][N] each
+    Pool prodQ, prodM;                // the three products, slots c0, c1, c2
+    Pool stageIn, stageOut;           // small batches: the operands gathered into one batch of 4 B, the results before they are scattered
+    const void *lane_of = nullptr;    // the batcher this plan is a lane of (not destroyed while that lives)
+    ~lr_bfv_plan() {
+        for (u64 *p : {d_phalf_q, d_phalf_m, d_t_mont})
+            if (p) (void)hipFree(p);
+    }
+};
+
+
+// The queue behind the batchers (lr_abi_batcher.cpp, lr_abi_bfv_batcher.cpp): concurrent one-ciphertext calls of many host threads -- the
+// reference's one evaluator per goroutine (examples/dbfv/psi/psi.go:215-233) -- merged into batched launches.  A call queues its request;
+// whichever caller finds a free lane takes every queued request that may share a launch with the head of the queue (Request::same_batch),
+// in arrival order, up to max_batch polys, runs them as ONE pipeline call (`run`, which ends with a synchronisation of the lane's
+// stream), and wakes the others.  No thread of its own, no timer: while a lane runs, arrivals queue up and form the next batch.
+//   Request: int polys; bool done; int status; std::string error; bool same_batch(const Request &) const
+//   Lane   : bool busy; hipStream_t stream; std::vector<Request *> take (reserved at creation); int device() const
+template <class Request, class Lane>
+struct BatchQueue {
+    std::vector<Lane> lanes;
+    int max_batch = 0;
+    std::mutex m;
+    std::condition_variable cv;
+    std::deque<Request *> queue;
+    unsigned long long batches = 0, products = 0;
+    int largest = 0;
+
+    template <class Run>
+    int submit(Request &req, Run run) {
+        std::unique_lock<std::mutex> lk(m);
+        queue.push_back(&req);
+        for (;;) {
+            if (req.done) break;
+            int free_lane = -1;
+            for (size_t i = 0; i < lanes.size() && free_lane < 0; ++i)
+                if (!lanes[i].busy) free_lane = (int)i;
+            if (free_lane < 0 || queue.empty()) {
+                cv.wait(lk);
+                continue;
+            }
+            // lead: everything queued that may share the head's launch, in arrival order, up to max_batch polys
+            Lane &lane = lanes[free_lane];
+            std::vector<Request *> &take = lane.take;
+            take.clear();
+            int total = 0;
+            const Request *head = queue.front();
+            for (auto it = queue.begin(); it != queue.end();) {
+                Request *r = *it;
+                if (r->same_batch(*head) && total + r->polys <= max_batch) {
+                    take.push_back(r);      // (capacity reserved at creation: a request taken off the queue is always completed, nothing throws in between)
+                    total += r->polys;
+                    it = queue.erase(it);
+                } else {
+                    ++it;
+                }
+            }
+            lane.busy = true;
+            lk.unlock();
+            int rc = guarded([&]() -> int { return run(lane, take); });
+            std::string msg;
+            if (rc != LR_OK) {
+                try { msg = g_error; } catch (...) {}
+                // a batch that failed half-way may have kernels queued that read the callers' operands through the lane's pointer table, and
+                // the copy out of the pinned table may be pending: nothing of it may outlive this point -- the callers are about to be woken,
+                // and the next batch on this lane rewrites the table and the plan's pools (only the success path ends in a synchronisation)
+                (void)hipSetDevice(lane.device());
+                (void)hipStreamSynchronize(lane.stream);
+                (void)hipGetLastError();
+            }
+            lk.lock();
+            lane.busy = false;
+            batches += 1;
+            products += (unsigned long long)total;
+            largest = std::max(largest, total);
+            for (auto *r : take) {
+                r->status = rc;
+                if (rc != LR_OK) {
+                    try { r->error = msg; } catch (...) {}
+                }
+                r->done = true;
+            }
+            cv.notify_all();
+        }
+        lk.unlock();
+        if (req.status != LR_OK) return fail(req.status, req.error);
+        return LR_OK;
+    }
+};
+
 namespace lr_host {
 
 struct Rows {  // a strided view of rows inside a batch buffer

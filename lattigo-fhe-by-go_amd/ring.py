@@ -753,3 +753,47 @@ class BfvPlan:
         """the key-switch half of bfv.NewEvaluator (decomposer, baseconverterQ1P, keyswitchpool: bfv/evaluator.go:100-112) over
         (contextQ, contextP): a CkksPlan, whose BfvRelinearize / BfvSwitchKeys / NewSwitchingKey serve Evaluator.Relinearize"""
         return CkksPlan(self.contextQ, contextP, max_batch)
+
+
+class BfvBatcher:
+    """Merges the Mul and Relinearize calls of concurrent BFV evaluators -- the reference's own pooled workload: every task of
+    examples/dbfv/psi/psi.go:215-233 calls evaluator.Mul and evaluator.Relinearize on one ciphertext pair -- into batched launches
+    (lr_bfv_batcher_* in include/lattigo_ring.h).  One lane = a BfvPlan over (contextQ, contextQMul) and the key-switch plan over
+    (contextQ, contextP) on their own stream; the batcher builds them."""
+
+    def __init__(self, N, Q, P, QMul, t, max_batch=64, lanes=2, device=0):
+        self.lanes = []
+        for i in range(lanes):
+            cq, cp, cm = Context(N, Q, device=device), Context(N, P, device=device), Context(N, QMul, device=device)
+            self.lanes.append((cq, cp, cm, BfvPlan(cq, cm, t, max_batch), CkksPlan(cq, cp, max_batch)))
+        muls = (C.c_void_p * lanes)(*[ln[3].h for ln in self.lanes])
+        kss = (C.c_void_p * lanes)(*[ln[4].h for ln in self.lanes])
+        h = C.c_void_p()
+        check(lib().lr_bfv_batcher_create(muls, kss, lanes, C.byref(h)))
+        self.h = h
+        self.max_batch = max_batch
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                lib().lr_bfv_batcher_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def NewSwitchingKey(self):
+        """the relinearisation key image every calling evaluator passes (one handle: calls share a batch only over the same key)"""
+        return self.lanes[0][4].NewSwitchingKey()
+
+    def Mul(self, ct0, ct1, ctOut):
+        """evaluator.Mul (bfv/evaluator.go:467) of two degree-1 ciphertexts -> degree 2; blocks until this call's result is complete"""
+        check(lib().lr_bfv_batcher_mul(self.h, ct0[0].h, ct0[1].h, ct1[0].h, ct1[1].h, ctOut[0].h, ctOut[1].h, ctOut[2].h))
+
+    def Relinearize(self, ct, evakey, ctOut):
+        """evaluator.Relinearize (bfv/evaluator.go:512) of a degree-2 ciphertext"""
+        check(lib().lr_bfv_batcher_relinearize(self.h, ct[0].h, ct[1].h, ct[2].h, evakey.h, ctOut[0].h, ctOut[1].h))
+
+    def Stats(self):
+        b, p, l = C.c_uint64(), C.c_uint64(), C.c_int()
+        check(lib().lr_bfv_batcher_stats(self.h, C.byref(b), C.byref(p), C.byref(l)))
+        return {"batches": b.value, "products": p.value, "largest": l.value}

@@ -175,6 +175,18 @@ hipError_t launch_scatter(const ScatterLaunch &L, int limbs, int batch, hipStrea
         }
     return hipSuccess;
 }
+hipError_t launch_gather(const GatherLaunch &L, int limbs, int batch, hipStream_t) {
+    g_stub_launches.fetch_add(1);
+    for (int b = 0; b < batch; ++b)
+        for (int k = 0; k < L.per_poly; ++k) {
+            const u64 *s = L.table[b * L.per_poly + k];
+            u64 *d = L.dst[k] + b * L.stride;
+            rows_r(s, 0, 0, 1, limbs, 1, L.n);
+            rows_w(d, 0, 0, 1, limbs, 1, L.n);
+            d[0] = s[0];
+        }
+    return hipSuccess;
+}
 hipError_t launch_multicopy(const MultiCopyLaunch &L, int limbs, hipStream_t) {
     g_stub_launches.fetch_add(1);
     for (int k = 0; k < L.count; ++k) {

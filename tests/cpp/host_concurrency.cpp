@@ -99,6 +99,21 @@ int main(int argc, char **argv) {
     CHECK(lr_ckks_plan_destroy(lplan[0]) == LR_ERR_ARG);          // a lane cannot go while its batcher lives
     CHECK(lr_context_destroy(lq[1]) == LR_ERR_ARG);
     lr_poly *key = poly(lq[0], NQ + NP, 2 * BETA, 7), *small_key = poly(lq[0], NQ + NP, 1, 7);
+    // ---- the BFV batcher (Mul + Relinearize, the reference's own pooled workload): two lanes, each a Mul plan and a key-switch plan over one contextQ
+    lr_context *bq[LANES], *bp[LANES], *bm[LANES];
+    lr_bfv_plan *bmul[LANES];
+    lr_ckks_plan *bks[LANES];
+    for (int i = 0; i < LANES; ++i) {
+        OK(lr_context_create(N, Qm, NQ, 0, &bq[i]));
+        OK(lr_context_create(N, Pm, NP, 0, &bp[i]));
+        OK(lr_context_create(N, Qm16, NQ, 0, &bm[i]));              // (any other NTT-friendly basis of the same length stands in for QMul)
+        OK(lr_bfv_plan_create(bq[i], bm[i], 65537, MAXB, &bmul[i]));
+        OK(lr_ckks_plan_create(bq[i], bp[i], MAXB, &bks[i]));
+    }
+    lr_bfv_batcher *bbat = nullptr;
+    OK(lr_bfv_batcher_create(bmul, bks, LANES, &bbat));
+    CHECK(lr_bfv_plan_destroy(bmul[1]) == LR_ERR_ARG && lr_ckks_plan_destroy(bks[0]) == LR_ERR_ARG && lr_context_destroy(bm[0]) == LR_ERR_ARG);
+    lr_poly *bkey = poly(bq[0], NQ + NP, 2 * BETA, 11);
     // ---- contexts shared by all threads (immutable after creation; their scratch is leased per call), on both "devices"
     lr_context *sq = nullptr, *sp = nullptr, *rq = nullptr;
     OK(lr_context_create(N, Qm, NQ, 0, &sq));
@@ -120,7 +135,7 @@ int main(int argc, char **argv) {
         lr_poly *o0 = poly(mq, NQ, 1, 0), *o1 = poly(mq, NQ, 1, 0);
         lr_poly *s0 = poly(sq, NQ, 2, base + 5), *s1 = poly(sq, NQ, 2, base + 7), *so0 = poly(sq, NQ, 2, 0), *so1 = poly(sq, NQ, 2, 0);
         for (int it = 0; it < ITERS; ++it) {
-            switch (rng() % 8) {
+            switch (rng() % 9) {
             case 0:
             case 1: {   // MulRelin through the batcher: whatever batch the request lands in, the tags of THIS caller come back
                 const int rc = lr_ckks_batcher_mulrelin(bat, LEVEL, a0, a1, b0, b1, key, o0, o1);
@@ -181,6 +196,19 @@ int main(int argc, char **argv) {
                 OK(lr_ckks_plan_destroy(tmp));
                 break;
             }
+            case 7: {   // BFV Mul then Relinearize through the BFV batcher (the stubs' Mul moves no tag: what is checked is that the calls come back,
+                        // in order, with the staging and the pointer tables of the right size under the sanitizers)
+                lr_poly *d2 = poly(mq, NQ, 1, 0);
+                OK(lr_bfv_batcher_mul(bbat, a0, a1, b0, b1, o0, o1, d2));
+                OK(lr_bfv_batcher_relinearize(bbat, o0, o1, d2, bkey, a1, b1));
+                CHECK(lr_bfv_batcher_mul(bbat, a0, a1, b0, b1, o0, o0, d2) == LR_ERR_ARG);
+                OK(lr_poly_free(d2));
+                OK(lr_poly_free(a1));                                   // (a1 / b1 were overwritten: fresh tags for the other cases)
+                OK(lr_poly_free(b1));
+                a1 = poly(mq, NQ, 1, base + 2);
+                b1 = poly(mq, NQ, 1, base + 4);
+                break;
+            }
             default: {  // a finished result goes to its slot on the other "device"
                 OK(lr_poly_copy_peer(rq, root, t, mq, a0, 0, 1));
                 break;
@@ -211,6 +239,19 @@ int main(int argc, char **argv) {
         OK(lr_ckks_batcher_mulrelin(bat, LEVEL, a, a, a, a, key, o, o2));
         CHECK(tag_of(o, 0, NQ, N) == 42);
         for (lr_poly *x : {a, o, o2}) OK(lr_poly_free(x));
+    }
+    {
+        uint64_t bb = 0, bpn = 0;
+        int bl = 0;
+        OK(lr_bfv_batcher_stats(bbat, &bb, &bpn, &bl));
+        CHECK(bl <= MAXB && bpn >= bb);
+    }
+    lr_bfv_batcher_destroy(bbat);
+    OK(lr_poly_free(bkey));
+    for (int i = 0; i < LANES; ++i) {
+        OK(lr_bfv_plan_destroy(bmul[i]));
+        OK(lr_ckks_plan_destroy(bks[i]));
+        for (lr_context *c : {bq[i], bp[i], bm[i]}) OK(lr_context_destroy(c));
     }
     lr_ckks_batcher_destroy(bat);
     for (lr_poly *x : {key, small_key, skey, root}) OK(lr_poly_free(x));

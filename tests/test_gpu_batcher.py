@@ -191,3 +191,66 @@ def test_lanes_cannot_be_destroyed_under_a_live_batcher(gpu_pkg, oracle):
     p = cq.NewPoly(1).set(ops[0])
     cq.NTT(p, p)
     assert np.array_equal(p.get(), oracle.Context(N, Q).ntt(ops[0][0]))
+
+
+# ---- the BFV batcher: the reference's own pooled workload (examples/dbfv/psi/psi.go:219-228: evaluator.Mul + evaluator.Relinearize per task) ----
+@pytest.mark.parametrize("name,logn,threads,lanes,max_batch", [("PN13QP218", 12, 8, 2, 4), ("PN14QP438", 14, 6, 2, 8), ("PN12QP109", 12, 5, 1, 3)])
+def test_bfv_batcher_serves_mul_and_relinearize_per_caller(gpu_pkg, oracle, name, logn, threads, lanes, max_batch):
+    """concurrent one-ciphertext callers, each running Mul then Relinearize on ITS operands through lr_bfv_batcher_*: every result against
+    the oracle's bfv Mul / Relinearize, whatever batch a request ended up in (PN14QP438 = BASELINE config 4's set at full size)"""
+    _, Q, P, QM = gpu_pkg.params.bfv_moduli(name)
+    Q, P, QM = list(Q), list(P), list(QM)
+    N = 1 << logn
+    ring = gpu_pkg.ring
+    nq, np_ = len(Q), len(P)
+    beta = -(-nq // np_)
+    bat = ring.BfvBatcher(N, Q, P, QM, 65537, max_batch=max_batch, lanes=lanes)
+    evk = gpu_pkg.sampling.uniform_poly(Q + P, N, 2 * beta, seed=17)
+    key = bat.NewSwitchingKey().set(evk)
+    omul = oracle.BfvPlan(oracle.Context(N, Q), oracle.Context(N, QM), 65537)
+    oks = oracle.CkksPlan(oracle.Context(N, Q), oracle.Context(N, P))
+    rounds = 2
+    errors, results = [], {}
+
+    def evaluator(t):
+        try:
+            cq = ring.NewContextWithParams(N, Q)
+            for r in range(rounds):
+                seed = 500 * t + 10 * r
+                ops = [gpu_pkg.sampling.uniform_poly(Q, N, 1, seed=seed + k) for k in range(4)]
+                mk = lambda k: cq.NewPoly(1).set(ops[k])
+                deg2 = (cq.NewPoly(1), cq.NewPoly(1), cq.NewPoly(1))
+                bat.Mul((mk(0), mk(1)), (mk(2), mk(3)), deg2)
+                lin = (cq.NewPoly(1), cq.NewPoly(1))
+                bat.Relinearize(deg2, key, lin)
+                results[(t, r)] = (ops, [p.get() for p in deg2], [p.get() for p in lin])
+        except Exception as e:  # noqa: BLE001
+            errors.append((t, repr(e)))
+
+    ths = [threading.Thread(target=evaluator, args=(t,)) for t in range(threads)]
+    for th in ths:
+        th.start()
+    for th in ths:
+        th.join()
+    assert not errors, errors
+    assert len(results) == threads * rounds
+    for (t, r), (ops, deg2, lin) in results.items():
+        want2 = omul.mul(np.stack([ops[0][0], ops[1][0]]), np.stack([ops[2][0], ops[3][0]]))
+        for k in range(3):
+            assert np.array_equal(deg2[k], want2[k]), (t, r, "mul", k)
+        want1 = oks.bfv_relinearize(want2, evk.reshape(beta, 2, nq + np_, N))
+        for k in range(2):
+            assert np.array_equal(lin[k], want1[k]), (t, r, "relin", k)
+    st = bat.Stats()
+    assert st["products"] == 2 * threads * rounds and 1 <= st["largest"] <= max_batch
+    # refused requests, and lanes that cannot be destroyed under the live batcher
+    cq = ring.NewContextWithParams(N, Q)
+    a = cq.NewPoly(1)
+    err = gpu_pkg._native.LatticeRingError
+    with pytest.raises(err):
+        bat.Mul((a, a), (a, a), (a, a, cq.NewPoly(1)))                       # result polys must be distinct
+    with pytest.raises(err):
+        big = cq.NewPoly(max_batch + 1)
+        bat.Mul((big, big), (big, big), (cq.NewPoly(max_batch + 1), cq.NewPoly(max_batch + 1), cq.NewPoly(max_batch + 1)))
+    lib = gpu_pkg._native.lib()
+    assert lib.lr_bfv_plan_destroy(bat.lanes[0][3].h) == 4 and lib.lr_ckks_plan_destroy(bat.lanes[0][4].h) == 4 and lib.lr_context_destroy(bat.lanes[0][2].h) == 4
