@@ -287,7 +287,7 @@ bool keymac_wide_ok(const lr_ckks_plan *pl, const lr_context *c, int beta) {
 // copied (nullptr: inside digQ).
 int ks_accumulate(lr_ckks_plan *pl, int level, int batch, const u64 *digQ, const u64 *digP, const u64 *own, long long own_stride,
                   const lr_poly *evk, u64 *p0, long long p0_stride, u64 *p1, long long p1_stride, const KeySwitchEpilogue *fin,
-                  bool coeff_out) {
+                  bool coeff_out, u64 perm_gen) {
     lr_context *cQ = pl->cQ, *cP = pl->cP;
     const int nQ = cQ->h.L(), nP = cP->h.L(), n = (int)cQ->h.N;
     const int alpha = pl->dec->alpha;
@@ -302,6 +302,9 @@ int ks_accumulate(lr_ckks_plan *pl, int level, int batch, const u64 *digQ, const
         KeyMacLaunch K;
         K.tile8 = 0;
         K.wide = 0;
+        K.perm_gen = (unsigned)(perm_gen & ((cQ->h.N << 1) - 1));      // hoisted rotations: the digits through the Galois permutation
+        K.logn = (int)cQ->h.logN;
+        if (K.perm_gen != 0 && own) return fail(LR_ERR_ARG, "permuted digits carry their own limbs");
         K.key = evk->d;
         K.key_poly_stride = evk->stride();
         K.n = n;
@@ -672,14 +675,23 @@ extern "C" int lr_ckks_rotate_hoisted(lr_ckks_plan *pl, int level, const lr_poly
     }
     LR_TRY(ks_decompose(pl, level, batch, c1->d, c1->stride(), true));                         // :1258-1272
     for (Pool *p : {&pl->c0, &pl->q1, &pl->q2}) LR_TRY(p->ensure(cQ, (size_t)batch * s));
-    LR_TRY(pl->permQ.ensure(cQ, (size_t)beta * batch * sQ));
-    LR_TRY(pl->permP.ensure(cQ, (size_t)beta * batch * sP));
+    if (pl->opt.no_epilogue) {
+        LR_TRY(pl->permQ.ensure(cQ, (size_t)beta * batch * sQ));
+        LR_TRY(pl->permP.ensure(cQ, (size_t)beta * batch * sP));
+    }
     for (int r = 0; r < n_rot; ++r) {
         LR_TRY(run_permute_ntt(cQ, L1, batch, c0->d, c0->stride(), pl->c0.d, s, gens[r]));     // :1314-1318
-        LR_TRY(run_permute_ntt(cQ, L1, beta * batch, pl->c2QiQ.d, sQ, pl->permQ.d, sQ, gens[r]));   // :1346, all digits
-        LR_TRY(run_permute_ntt(cP, nP, beta * batch, pl->c2QiP.d, sP, pl->permP.d, sP, gens[r]));   // :1347
         KeySwitchEpilogue fin{outs0[r]->d, outs1[r]->d, outs0[r]->stride(), pl->c0.d, nullptr, s};   // :1389-1390
-        LR_TRY(ks_accumulate(pl, level, batch, pl->permQ.d, pl->permP.d, nullptr, 0, rotkeys[r], pl->q1.d, s, pl->q2.d, s, &fin));
+        if (pl->opt.no_epilogue) {
+            // the reference's shape: permuted copies of every digit (:1346-1347), then the inner product over them
+            LR_TRY(run_permute_ntt(cQ, L1, beta * batch, pl->c2QiQ.d, sQ, pl->permQ.d, sQ, gens[r]));
+            LR_TRY(run_permute_ntt(cP, nP, beta * batch, pl->c2QiP.d, sP, pl->permP.d, sP, gens[r]));
+            LR_TRY(ks_accumulate(pl, level, batch, pl->permQ.d, pl->permP.d, nullptr, 0, rotkeys[r], pl->q1.d, s, pl->q2.d, s, &fin));
+        } else {
+            // the permutation of the digits rides on the inner product's loads (KeyMacLaunch::perm_gen): same values, 2 x beta x (|Q| + |P|)
+            // rows per rotation less to write and read back
+            LR_TRY(ks_accumulate(pl, level, batch, pl->c2QiQ.d, pl->c2QiP.d, nullptr, 0, rotkeys[r], pl->q1.d, s, pl->q2.d, s, &fin, false, gens[r]));
+        }
     }
     return LR_OK;
     });

@@ -268,6 +268,10 @@ struct KeyMacLaunch {
     long long out1_stride;         // of out1 (the two outputs of lr_ckks_switch_keys may have different allocations)
     int tile8;                     // set by the launcher: grid x = poly * 8 + (chunk mod 8) (one XCD per key tile)
     int wide;                      // 1: exact 128-bit sums + one Montgomery reduction per output (needs beta * max q < 2^64, q < 2^61)
+    // hoisted rotations (ckks/evaluator.go:1346-1347): the digits are read THROUGH ring.PermuteNTT's index for the Galois element perm_gen
+    // (reduced modulo 2N; 0 = as they are) instead of from permuted copies; needs own == nullptr (the digits carry their own limbs)
+    unsigned perm_gen;
+    int logn;
 };
 hipError_t launch_keymac(const KeyMacLaunch &L, int limbs, int batch, hipStream_t stream);
 // the Q part and the P part of one inner product as ONE launch (grid y = limbs_a + limbs_b; both wide, same beta): two launches of a

@@ -521,6 +521,24 @@ hipError_t launch_half_scalar(const HalfScalarLaunch &L, int limbs, int batch, h
 // never travel through HBM.
 // BETA > 0: the digit count is known at compile time, so all of a coefficient pair's digit and key loads are issued
 // before the first multiply (memory-level parallelism instead of one load round trip per digit); BETA = 0: generic.
+// ring.PermuteNTT's index (ring/ring_galois.go:29-50): out[j] = in[perm_index(j)], computed on the fly (two bit reversals)
+__device__ __forceinline__ u32 perm_index(u32 j, u32 gen, int shift, u32 mask2) {
+    const u32 t1 = 2 * (__brev(j) >> shift) + 1;
+    const u32 t2 = (((gen * t1) & mask2) - 1) >> 1;
+    return __brev(t2) >> shift;
+}
+// the digit operand of a coefficient pair: the caller's own row, the permuted digit (hoisted rotations: the Galois automorphism of the
+// digits rides on the inner product's loads instead of a pass that writes permuted copies of every digit), or the plain digit
+#define LR_KEYMAC_OPERAND_SETUP                                                                                                   \
+    const u32 pgen = L.perm_gen;                                                                                                  \
+    const int pshift = 32 - L.logn;                                                                                               \
+    const u32 pmask2 = 2u * (u32)L.n - 1u;                                                                                        \
+    const u64 *pc64 = reinterpret_cast<const u64 *>(pc);
+#define LR_KEYMAC_OPERAND(i_)                                                                                                     \
+    ((i_) == own_digit ? ld_stream(pown + e)                                                                                      \
+                       : pgen ? make_ulonglong2(pc64[(long long)(i_) * L.c2_digit_stride + ix0], pc64[(long long)(i_) * L.c2_digit_stride + ix1]) \
+                              : ld_stream(pc + e + (i_) * cd))
+
 template <int BETA>
 __global__ __launch_bounds__(256) void keymac_kernel(KeyMacLaunch L) {
     // x = poly of the batch (fastest): the workgroups that run together share one tile of the key, which therefore
@@ -543,7 +561,9 @@ __global__ __launch_bounds__(256) void keymac_kernel(KeyMacLaunch L) {
     const int own_digit = L.alpha > 0 ? limb / L.alpha : -1;
     const int pairs = L.n >> 1;
     const int beta = BETA > 0 ? BETA : L.beta;
+    LR_KEYMAC_OPERAND_SETUP
     for (int e = chunk * 256 + threadIdx.x; e < pairs; e += chunks * 256) {
+        const u32 ix0 = pgen ? perm_index(2u * (u32)e, pgen, pshift, pmask2) : 0u, ix1 = pgen ? perm_index(2u * (u32)e + 1u, pgen, pshift, pmask2) : 0u;
         u64 a0x = 0, a0y = 0, a1x = 0, a1y = 0;
         if constexpr (BETA > 0) {
             // groups of at most G digits: all loads of a group are in flight before its first multiply; beyond six digits one
@@ -558,7 +578,7 @@ __global__ __launch_bounds__(256) void keymac_kernel(KeyMacLaunch L) {
                 for (int u = 0; u < G; ++u) {
                     const int i = g0 + u;
                     if (i < BETA) {
-                        c[u] = ld_stream(i == own_digit ? pown + e : pc + e + i * cd);
+                        c[u] = LR_KEYMAC_OPERAND(i);
                         k0[u] = pk[e + (2 * i) * kd];
                         k1[u] = pk[e + (2 * i + 1) * kd];
                     }
@@ -583,7 +603,7 @@ __global__ __launch_bounds__(256) void keymac_kernel(KeyMacLaunch L) {
             }
         } else {
             for (int i = 0; i < beta; ++i) {
-                const ulonglong2 c = ld_stream(i == own_digit ? pown + e : pc + e + i * cd);
+                const ulonglong2 c = LR_KEYMAC_OPERAND(i);
                 const ulonglong2 k0 = pk[e + (2 * i) * kd], k1 = pk[e + (2 * i + 1) * kd];
                 a0x += mred(k0.x, c.x, lp.q, lp.qinv);
                 a0y += mred(k0.y, c.y, lp.q, lp.qinv);
@@ -667,7 +687,9 @@ __device__ __forceinline__ void keymac_wide_body(const KeyMacLaunch &L, int limb
     const int pairs = L.n >> 1;
     const int beta = BETA > 0 ? BETA : L.beta;
     constexpr int G = BETA > 0 ? (BETA <= 6 ? BETA : (BETA + 1) / 2) : 1;      // digits whose loads are in flight together
+    LR_KEYMAC_OPERAND_SETUP
     for (int e = chunk * 256 + threadIdx.x; e < pairs; e += chunks * 256) {
+        const u32 ix0 = pgen ? perm_index(2u * (u32)e, pgen, pshift, pmask2) : 0u, ix1 = pgen ? perm_index(2u * (u32)e + 1u, pgen, pshift, pmask2) : 0u;
         u64 lo[4] = {0, 0, 0, 0}, mid[4] = {0, 0, 0, 0}, hi[4] = {0, 0, 0, 0};
         u32 cy[4] = {0, 0, 0, 0};
         if constexpr (BETA > 0) {
@@ -678,7 +700,7 @@ __device__ __forceinline__ void keymac_wide_body(const KeyMacLaunch &L, int limb
                 for (int u = 0; u < G; ++u) {
                     const int i = g0 + u;
                     if (i < BETA) {
-                        c[u] = ld_stream(i == own_digit ? pown + e : pc + e + i * cd);
+                        c[u] = LR_KEYMAC_OPERAND(i);
                         k0[u] = pk[e + (2 * i) * kd];
                         k1[u] = pk[e + (2 * i + 1) * kd];
                     }
@@ -702,7 +724,7 @@ __device__ __forceinline__ void keymac_wide_body(const KeyMacLaunch &L, int limb
             }
         } else {
             for (int i = 0; i < beta; ++i) {
-                ulonglong2 c = ld_stream(i == own_digit ? pown + e : pc + e + i * cd);
+                ulonglong2 c = LR_KEYMAC_OPERAND(i);
                 if (i == own_digit) c = own_operand(c, lp);
                 const ulonglong2 k0 = pk[e + (2 * i) * kd], k1 = pk[e + (2 * i + 1) * kd];
                 mac128(k0.x, c.x, lo[0], mid[0], hi[0], cy[0]);
@@ -722,6 +744,7 @@ __device__ __forceinline__ void keymac_wide_body(const KeyMacLaunch &L, int limb
 
 hipError_t launch_keymac(const KeyMacLaunch &L, int limbs, int batch, hipStream_t stream) {
     if (limbs <= 0 || batch <= 0) return hipSuccess;
+    if (L.perm_gen != 0 && (L.alpha > 0 || L.logn < 1 || L.logn > 31 || (1 << L.logn) != L.n)) return hipErrorInvalidValue;   // permuted digits carry their own limbs
     int gx = ((L.n >> 1) + 255) / 256;
     if (gx > 64) gx = 64;
     KeyMacLaunch K = L;
@@ -751,6 +774,7 @@ hipError_t launch_keymac(const KeyMacLaunch &L, int limbs, int batch, hipStream_
 hipError_t launch_keymac_pair(const KeyMacLaunch &A, int limbs_a, const KeyMacLaunch &B, int limbs_b, int batch, hipStream_t stream) {
     if (limbs_a <= 0 || limbs_b <= 0 || batch <= 0) return hipErrorNotSupported;
     if (!A.wide || !B.wide || A.beta != B.beta || A.n != B.n || A.beta < 1 || A.beta > 10) return hipErrorNotSupported;
+    if ((A.perm_gen != 0 && A.alpha > 0) || (B.perm_gen != 0 && B.alpha > 0)) return hipErrorInvalidValue;
     int gx = ((A.n >> 1) + 255) / 256;
     if (gx > 64) gx = 64;
     KeyMacPair P;

@@ -828,3 +828,31 @@ def test_decrypt_fused_pass_against_the_call_by_call_form(gpu_pkg, oracle, degre
         pl.Decrypt(level, polys, psk, polys[degree])                                    # plaintext.value is the top component
         assert np.array_equal(polys[degree].get().reshape(batch, nq, N), got[-1]), env
     assert np.array_equal(got[0], got[1])
+
+
+@pytest.mark.parametrize("env", [{}, {"LR_NO_EPILOGUE": "1"}, {"LR_KEYMAC_NARROW": "1"}, {"LR_NO_PAIR": "1", "LR_KEYMAC_NARROW": "1"}])
+@pytest.mark.parametrize("logn,nq,np_,level,batch", [(12, 6, 2, 5, 3), (15, 18, 3, 17, 1), (13, 7, 3, 3, 2)])
+def test_rotate_hoisted_reads_the_digits_through_the_permutation(gpu_pkg, oracle, logn, nq, np_, level, batch, env, monkeypatch):
+    """round 4: the Galois automorphism of the digits (ckks/evaluator.go:1346-1347) rides on the key inner product's loads (KeyMacLaunch::
+    perm_gen) instead of a pass that writes permuted copies of every digit; LR_NO_EPILOGUE keeps the copies, LR_KEYMAC_NARROW takes the
+    per-term kernel through the same loads; every way against the oracle's switchKeyHoisted, PN15QP880 at full size with one ciphertext
+    (the paired Q + P launch) included"""
+    for k in ("LR_NO_EPILOGUE", "LR_KEYMAC_NARROW", "LR_NO_PAIR"):
+        monkeypatch.delenv(k, raising=False)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    N, Q, P, cQ, cP, plan, oplan, evk0, pevk0 = _ckks(gpu_pkg, oracle, logn, nq, np_, batch)
+    beta = -(-nq // np_)
+    gens = [_galois(gpu_pkg, N, 1), _galois(gpu_pkg, N, 7), 2 * N - 1]                 # two column rotations and the conjugation
+    evks = [gpu_pkg.sampling.uniform_poly(Q + P, N, 2 * beta, seed=400 + k) for k in range(3)]
+    pevks = [plan.NewSwitchingKey().set(e) for e in evks]
+    mk = lambda s: gpu_pkg.sampling.uniform_poly(Q[:level + 1], N, batch, seed=s).reshape(batch, level + 1, N)
+    a0, a1 = mk(43), mk(44)
+    ct = (cQ.NewPolyLvl(level, batch).set(a0), cQ.NewPolyLvl(level, batch).set(a1))
+    outs = [(cQ.NewPolyLvl(level, batch), cQ.NewPolyLvl(level, batch)) for _ in gens]
+    plan.RotateHoisted(level, ct, gens, pevks, outs)
+    for b in range(batch):
+        want = oplan.rotate_hoisted(level, np.stack([a0[b], a1[b]]), gens, [e.reshape(beta, 2, nq + np_, N) for e in evks])
+        for r in range(len(gens)):
+            for k in range(2):
+                assert np.array_equal(outs[r][k].get().reshape(batch, level + 1, N)[b], want[r][k]), (env, r, b, k)
