@@ -1294,6 +1294,12 @@ def main():
                           "frac_hbm": ntt_bytes(N, L, my_polys) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                           "roofline": leg_roofline(ntt_bytes(N, L, my_polys), ms, ctx.last_ntt_kernel()),
                           "bit_exact": bool(np.array_equal(dst.get().reshape(my_polys, L, N)[last], oc.intt(x_last)))}
+        if want_cpu:
+            def mk_intt(i):
+                a, b = x_last.copy(), np.empty_like(x_last)
+                lib = oracle.lib()
+                return lambda: lib.oc_intt_lvl(oc.h, L - 1, a.ctypes.data, b.ctypes.data)
+            extras["intt"]["cpu_baseline"] = cpu_baseline(mk_intt, L, "limb-NTT/s", "oracle Context.InvNTT on R15, one poly per call", 1.0)
         ctx.Copy(src, dst)
         ms = timed(lambda: ctx.MulCoeffsMontgomery(src, dst, dst))
         # the timed calls chain dst <- MRed(src, dst) an unknown number of times (clock warm-up by time): the check starts over from
@@ -1370,6 +1376,13 @@ def main():
                                                  "asm_variants": list(ctxC.ntt_variants()), "kernel": ctxC.last_ntt_kernel(),
                                                  "roofline": leg_roofline(ntt_bytes(N, L, my_polys), ms, ctxC.last_ntt_kernel()),
                                                  "bit_exact": bool(np.array_equal(cdst.get().reshape(my_polys, L, N)[last], ofn(cb[last % cb.shape[0]])))}
+                if want_cpu:
+                    def mk_c(i, name=name):
+                        a, b = cb[0].copy(), np.empty_like(cb[0])
+                        lib = oracle.lib()
+                        f = lib.oc_ntt_lvl if name == "ntt" else lib.oc_intt_lvl
+                        return lambda: f(occ.h, L - 1, a.ctypes.data, b.ctypes.data)
+                    extras[name + "_ckks_moduli"]["cpu_baseline"] = cpu_baseline(mk_c, L, "limb-NTT/s", "oracle Context.%s on the CKKS moduli, one poly per call" % ("NTT" if name == "ntt" else "InvNTT"), 1.0)
             del csrc, cdst, ctxC
         out["extras"] = extras
         progress("extras timed")
@@ -1469,18 +1482,29 @@ def main():
         v = r.get("valu") or {}
         if v.get("instr_per_wave") and v.get("issue_frac_sustained"):
             # why the 60-bit transform sits at 0.40: the four numbers it follows from
-            cpi_ubench = 5.2      # clocks per instruction of an alternating v_mad_u64_u32 / v_add_u32 stream, one wave per SIMD (profiles/r02/asm_energy.txt)
+            cpi_mix = 5.2         # clocks per instruction of an alternating v_mad_u64_u32 / v_add_u32 stream, one wave per SIMD (profiles/r02/asm_energy.txt)
             per_simd = v["instructions"] / SIMDS
-            sclk = v["sclk_MHz"] * 1e6
+            cpi_run = 4.0 / v["issue_frac_sustained"]                      # shader clocks of the launch x SIMDs / instructions: independent of the clock
+            smi = (power or {}).get("sclk_MHz_smi")
+            sclk_run = (smi or v["sclk_MHz"]) * 1e6                        # the clock of the TIMED launches (rocm-smi beside them); the profiled pass runs lower
+            ms = lambda cpi, hz: per_simd * cpi / hz * 1e3
+            fr = lambda t_ms: r["algorithmic_bytes_per_launch"] / (t_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
             r["floor"] = {"valu_instructions_per_wave": v["instr_per_wave"], "waves": v["waves"], "simds": SIMDS,
-                          "clocks_per_instruction_in_run": 4.0 / v["issue_frac_sustained"],
-                          "clocks_per_instruction_of_the_multiply_mix_alone": cpi_ubench,
-                          "sclk_MHz_sustained": v["sclk_MHz"], "sclk_MHz_peak": NOMINAL_SCLK_HZ / 1e6, "package_power": power,
-                          "model_ms": per_simd * cpi_ubench / sclk * 1e3, "measured_ms": r["kernel_ms"],
-                          "frac_of_the_model": r["algorithmic_bytes_per_launch"] / (per_simd * cpi_ubench / sclk) / 1e9 / HBM_PEAK_GBS,
-                          "reading": "instructions per SIMD x clocks per instruction of the butterfly's multiply mix / the clock the package power limit leaves = the "
-                                     "launch time to within a few percent: the kernel is at its vector-issue floor, and 9 of the 14 butterfly instructions are the 32-bit "
-                                     "multiplies a 60-bit Shoup product needs (DESIGN.md 3.1)"}
+                          "clocks_per_instruction": {"in_this_run": cpi_run, "of_the_multiply_mix_alone": cpi_mix, "issue_minimum": 4.0},
+                          "clocks_per_instruction_in_run": cpi_run,
+                          "sclk_MHz": {"timed_launches_rocm_smi": smi, "under_the_profiler": v["sclk_MHz"], "peak": NOMINAL_SCLK_HZ / 1e6},
+                          "sclk_MHz_sustained": smi or v["sclk_MHz"],
+                          "package_power": power,
+                          "ms": {"measured": r["kernel_ms"], "instructions_x_cpi_in_this_run_at_the_timed_clock": ms(cpi_run, sclk_run),
+                                 "instructions_x_cpi_of_the_multiply_mix_at_the_timed_clock": ms(cpi_mix, sclk_run),
+                                 "instructions_x_4_clocks_at_the_timed_clock": ms(4.0, sclk_run), "instructions_x_4_clocks_at_the_peak_clock": ms(4.0, NOMINAL_SCLK_HZ)},
+                          "model_ms": ms(cpi_run, sclk_run), "measured_ms": r["kernel_ms"],
+                          "frac": {"measured": r["frac"], "if_every_instruction_issued_in_4_clocks_at_the_timed_clock": fr(ms(4.0, sclk_run)),
+                                   "if_every_instruction_issued_in_4_clocks_at_the_peak_clock": fr(ms(4.0, NOMINAL_SCLK_HZ))},
+                          "reading": "four numbers give the launch time: vector instructions per wave (x waves / 1024 SIMDs), clocks per instruction (the butterfly's "
+                                     "multiply mix costs 5.2 alone; 9 of its 14 instructions are the 32-bit multiplies a 60-bit Shoup product needs), the clock the "
+                                     "1.4 kW package power limit leaves, and nothing else -- HBM traffic is 1.00 x algorithmic and far from its roof.  0.50 of the HBM "
+                                     "roofline would take 4-clock issue of every instruction at more than the sustained clock (DESIGN.md 3.1)"}
         elif power:
             r["floor"] = {"package_power": power, "note": "counters not collected in this run"}
         # the figures a reader of the LAST kilobytes of this line needs (the driver keeps a 10 KB tail): fractions of the HBM roofline
