@@ -116,6 +116,8 @@ ExtSegment segment(u64 *out, long long stride, int limb0, int col0, int count) {
     s.epi_mode = 0;
     s.epi_x = nullptr;
     s.epi_x_stride = 0;
+    s.epi_x2 = nullptr;
+    s.epi_x2_stride = 0;
     s.epi_c = s.epi_s = nullptr;
     return s;
 }
@@ -248,7 +250,10 @@ namespace lr_host {
 
 // shared tail of the four ModDown...PQ variants: P part (coefficient domain, rows p_limb0.. of pP)
 // -> poolQ[0..level] by modUpExact, optional NTT, then p2 = MRed(p1Q + (q - pool), P^-1)
-int moddown_pq_core(lr_bext *b, int level, const u64 *p1Q, long long p1Q_stride, Rows pP, int batch, lr_poly *p2, bool ntt) {
+// x2 (coefficient-domain form only, optional): the Q part is CRed(p1Q + x2) -- the residues SampleAndAdd adds in front of the ModDown of
+// pkEncryptor.encrypt, folded into the extension's epilogue; false in *x2_taken when the kernel in use has no epilogue (the caller adds first)
+int moddown_pq_core(lr_bext *b, int level, const u64 *p1Q, long long p1Q_stride, Rows pP, int batch, lr_poly *p2, bool ntt, const u64 *x2,
+                    long long x2_stride) {
     lr_context *cQ = b->cQ;
     const int nP = b->cP->h.L();
     const long long pool_stride = (long long)cQ->h.L() * (long long)cQ->h.N;
@@ -258,9 +263,12 @@ int moddown_pq_core(lr_bext *b, int level, const u64 *p1Q, long long p1Q_stride,
         sd.epi_mode = 1;
         sd.epi_x = p1Q;
         sd.epi_x_stride = p1Q_stride;
+        sd.epi_x2 = x2;
+        sd.epi_x2_stride = x2_stride;
         sd.epi_c = b->d_moddown_pq;
         return run_ext(cQ, b->pq, nP, pP, batch, sd, segment(nullptr, 0, 0, 0, 0));
     }
+    if (x2) return fail(LR_ERR_INTERNAL, "moddown_pq_core: the addend form needs the extension epilogue (moddown_epilogue_available)");
     LR_TRY(b->poolQ.ensure(cQ, (size_t)batch * pool_stride));
     LR_TRY(run_ext(cQ, b->pq, nP, pP, batch, segment(b->poolQ.d, pool_stride, 0, 0, level + 1), segment(nullptr, 0, 0, 0, 0)));
     if (ntt && ntt_epilogue_ok(cQ) && !cQ->opt.no_epilogue) {
@@ -296,6 +304,10 @@ int moddown_pq_core(lr_bext *b, int level, const u64 *p1Q, long long p1Q_stride,
     }
     return run_submul(cQ, level + 1, batch, p1Q, p1Q_stride, b->poolQ.d, pool_stride, (long long)cQ->h.N, p2->d,
                       p2->stride(), b->d_moddown_pq, false, nullptr);
+}
+
+bool moddown_epilogue_available(const lr_bext *b) {
+    return !b->cQ->opt.no_epilogue && ext_epilogue_supported(b->pq.tables(), b->cP->h.L(), (int)b->cQ->h.N);
 }
 
 }  // namespace lr_host

@@ -810,24 +810,44 @@ extern "C" int lr_ckks_encrypt_pk(lr_ckks_plan *pl, int level, const lr_poly *u,
     u64 *const pool[2] = {pl->encQ.d, pl->encQ.d + (long long)batch * sQP};
     const lr_poly *pk[2] = {pk0, pk1}, *e[2] = {e0, e1};
     lr_poly *outs[2] = {o0, o1};
-    for (int k = 0; k < 2; ++k) {
-        const long long ks = pk[k]->batch == 1 && batch > 1 ? 0 : pk[k]->stride();
-        // :209-211 contextQP.MulCoeffsMontgomery(u, pk[k], pool[k]): the Q rows under contextQ's moduli, the P rows under contextP's
-        LR_TRY(run_ewise(cQ, LR_MUL_MONT, nQ, batch, u->d, u->stride(), pk[k]->d, ks, pool[k], sQP, nullptr));
-        LR_TRY(run_ewise(cP, LR_MUL_MONT, nP, batch, u->d + offP, u->stride(), pk[k]->d + offP, ks, pool[k] + offP, sQP, nullptr));
+    const bool fused = !pl->opt.no_epilogue;     // Options::no_epilogue: the reference's call-by-call shape (one launch per Context call)
+    if (fused) {
+        // :209-211 both products with the public key in one pass over u (Q rows under contextQ's moduli, P rows under contextP's)
+        Mul2Launch M;
+        M.a = u->d; M.a_stride = u->stride();
+        M.b0 = pk0->d; M.b0_stride = pk0->batch == 1 && batch > 1 ? 0 : pk0->stride();
+        M.b1 = pk1->d; M.b1_stride = pk1->batch == 1 && batch > 1 ? 0 : pk1->stride();
+        M.out0 = pool[0]; M.out1 = pool[1];
+        M.out0_stride = M.out1_stride = sQP;
+        M.n = n;
+        M.lp = cQ->d_lp;
+        LR_HIP(launch_mul2(M, nQ, batch, cQ->stream));
+        M.a += offP; M.b0 += offP; M.b1 += offP; M.out0 += offP; M.out1 += offP;
+        M.lp = cP->d_lp;
+        LR_HIP(launch_mul2(M, nP, batch, cQ->stream));
+    } else {
+        for (int k = 0; k < 2; ++k) {
+            const long long ks = pk[k]->batch == 1 && batch > 1 ? 0 : pk[k]->stride();
+            // :209-211 contextQP.MulCoeffsMontgomery(u, pk[k], pool[k]): the Q rows under contextQ's moduli, the P rows under contextP's
+            LR_TRY(run_ewise(cQ, LR_MUL_MONT, nQ, batch, u->d, u->stride(), pk[k]->d, ks, pool[k], sQP, nullptr));
+            LR_TRY(run_ewise(cP, LR_MUL_MONT, nP, batch, u->d + offP, u->stride(), pk[k]->d + offP, ks, pool[k] + offP, sQP, nullptr));
+        }
     }
     {   // :214-215 contextQP.InvNTT, both polys in one launch per basis
         Rows q{pool[0], sQP, 0, 1}, p{pool[0], sQP, nQ, 1};
         LR_TRY(run_ntt(cQ, true, q, q, 0, 1, nQ, 2 * batch));
         LR_TRY(run_ntt(cP, true, p, p, 0, 1, nP, 2 * batch));
     }
+    // the Q rows' share of SampleAndAdd rides in the ModDown's extension epilogue (x = CRed(pool + e) where the extension reads x) when the
+    // call is at the top level (below it the reference's ModDownPQ reads rows level+1.. of Q as its "P part": those rows need their e first)
+    const bool add_in_ext = fused && level == nQ - 1 && moddown_epilogue_available(pl->bext);
     for (int k = 0; k < 2; ++k) {
         // :218-220 SampleAndAdd: CRed(x + e) per coefficient (ring/gaussianSampler.go:268)
-        LR_TRY(run_ewise(cQ, LR_ADD, nQ, batch, pool[k], sQP, e[k]->d, e[k]->stride(), pool[k], sQP, nullptr));
+        if (!add_in_ext) LR_TRY(run_ewise(cQ, LR_ADD, nQ, batch, pool[k], sQP, e[k]->d, e[k]->stride(), pool[k], sQP, nullptr));
         LR_TRY(run_ewise(cP, LR_ADD, nP, batch, pool[k] + offP, sQP, e[k]->d + offP, e[k]->stride(), pool[k] + offP, sQP, nullptr));
         // :223-226 ModDownPQ(level, pool[k], ct[k]): the P part is read at rows level+1.. (ring_basis_extension.go:255)
         Rows pP{pool[k], sQP, level + 1, 1};
-        LR_TRY(moddown_pq_core(pl->bext, level, pool[k], sQP, pP, batch, outs[k], false));
+        LR_TRY(moddown_pq_core(pl->bext, level, pool[k], sQP, pP, batch, outs[k], false, add_in_ext ? e[k]->d : nullptr, e[k]->stride()));
         Rows r = rows_of(outs[k]);
         LR_TRY(run_ntt(cQ, false, r, r, 0, 1, level + 1, batch));                                                     // :229-230
     }

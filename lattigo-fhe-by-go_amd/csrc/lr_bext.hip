@@ -331,8 +331,13 @@ __device__ __forceinline__ void ext_sum_body(const ExtLaunch &L) {
                 const int col = sg.col0 + jj;
                 const u64 pinv = ld_const(L.t.mredP + col), ec = ld_const(sg.epi_c + col), es = sg.epi_s ? ld_const(sg.epi_s + col) : 0;
                 const u64 *px = sg.epi_x + b * sg.epi_x_stride + (long long)(sg.limb0 + jj) * L.n + W * xw;
+                const u64 *px2 = sg.epi_x2 ? sg.epi_x2 + b * sg.epi_x2_stride + (long long)(sg.limb0 + jj) * L.n + W * xw : nullptr;
 #pragma unroll
-                for (int w = 0; w < W; ++w) r[w] = ext_epilogue(sg.epi_mode, r[w], sg.epi_mode == 1 ? ld_stream(px + w) : 0, pj, pinv, ec, es);
+                for (int w = 0; w < W; ++w) {
+                    u64 x = sg.epi_mode == 1 ? ld_stream(px + w) : 0;
+                    if (sg.epi_mode == 1 && px2) x = cred(x + ld_stream(px2 + w), pj);
+                    r[w] = ext_epilogue(sg.epi_mode, r[w], x, pj, pinv, ec, es);
+                }
             }
 #pragma unroll
             for (int h = 0; h < C / W; ++h) {
@@ -464,8 +469,13 @@ __device__ __forceinline__ void ext_wide_body(const ExtLaunch &L) {
             if (sg.epi_mode) {
                 const u64 ec = ld_const(sg.epi_c + col), es = sg.epi_s ? ld_const(sg.epi_s + col) : 0;
                 const u64 *px = sg.epi_x + b * sg.epi_x_stride + (long long)(sg.limb0 + jj) * L.n + W * xw;
+                const u64 *px2 = sg.epi_x2 ? sg.epi_x2 + b * sg.epi_x2_stride + (long long)(sg.limb0 + jj) * L.n + W * xw : nullptr;
 #pragma unroll
-                for (int w = 0; w < W; ++w) r[w] = ext_epilogue(sg.epi_mode, r[w], sg.epi_mode == 1 ? ld_stream(px + w) : 0, pj, pinv, ec, es);
+                for (int w = 0; w < W; ++w) {
+                    u64 x = sg.epi_mode == 1 ? ld_stream(px + w) : 0;
+                    if (sg.epi_mode == 1 && px2) x = cred(x + ld_stream(px2 + w), pj);
+                    r[w] = ext_epilogue(sg.epi_mode, r[w], x, pj, pinv, ec, es);
+                }
             }
             if (W == 2) st_stream(reinterpret_cast<ulonglong2 *>(out + (long long)jj * L.n), make_ulonglong2(r[0], r[W - 1]));
             else st_stream(out + (long long)jj * L.n, r[0]);

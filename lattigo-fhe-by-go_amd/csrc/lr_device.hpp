@@ -197,6 +197,16 @@ struct HornerLaunch {
 };
 hipError_t launch_horner(const HornerLaunch &L, int limbs, int batch, hipStream_t stream);
 
+// out0 = MRed(a, b0), out1 = MRed(a, b1): the two products of pkEncryptor.encrypt with the public key (ckks/encryptor.go:209-211) reading u once
+struct Mul2Launch {
+    const u64 *a, *b0, *b1;
+    u64 *out0, *out1;
+    long long a_stride, b0_stride, b1_stride, out0_stride, out1_stride;     // between batch polys (0 = broadcast)
+    int n;
+    const LimbParams *lp;
+};
+hipError_t launch_mul2(const Mul2Launch &L, int limbs, int batch, hipStream_t stream);
+
 // batcher form of a result copy: dst[b] = table[b * per_poly + k] for the per_poly staged polys src[k] (rows [limbs][n], batch stride `stride`)
 struct ScatterLaunch {
     const u64 *src[4];          // per_poly <= 4 of them are used
@@ -360,6 +370,10 @@ struct ExtSegment {       // rows [limb0, limb0+count) of `out` receive table co
     int epi_mode;               // 0 = none
     const u64 *epi_x;
     long long epi_x_stride;
+    // mode 1 only, optional: x = CRed(x + x2) first -- the Gaussian residues SampleAndAdd adds to the Q rows in front of the ModDown of
+    // pkEncryptor.encrypt (ckks/encryptor.go:218-226), read at the output's position like x
+    const u64 *epi_x2;
+    long long epi_x2_stride;
     const u64 *epi_c, *epi_s;   // device arrays over the table columns (epi_s == nullptr: zeros)
 };
 

@@ -391,6 +391,38 @@ hipError_t launch_scatter(const ScatterLaunch &L, int limbs, int batch, hipStrea
     return hipGetLastError();
 }
 
+// pkEncryptor.encrypt, ckks/encryptor.go:209-211: MulCoeffsMontgomery(u, pk[0]) and (u, pk[1]) in one pass over u
+__global__ __launch_bounds__(256) void mul2_kernel(Mul2Launch L) {
+    const int limb = blockIdx.y;
+    const long long b = blockIdx.z;
+    const LimbParams lp = L.lp[limb];
+    const long long row = (long long)limb * L.n;
+    const ulonglong2 *pa = reinterpret_cast<const ulonglong2 *>(L.a + b * L.a_stride + row);
+    const ulonglong2 *pb0 = reinterpret_cast<const ulonglong2 *>(L.b0 + b * L.b0_stride + row);
+    const ulonglong2 *pb1 = reinterpret_cast<const ulonglong2 *>(L.b1 + b * L.b1_stride + row);
+    ulonglong2 *po0 = reinterpret_cast<ulonglong2 *>(L.out0 + b * L.out0_stride + row);
+    ulonglong2 *po1 = reinterpret_cast<ulonglong2 *>(L.out1 + b * L.out1_stride + row);
+    const int pairs = L.n >> 1;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < pairs; e += gridDim.x * 256) {
+        const ulonglong2 a = ld_stream(pa + e);
+        const ulonglong2 k0 = L.b0_stride ? ld_stream(pb0 + e) : pb0[e], k1 = L.b1_stride ? ld_stream(pb1 + e) : pb1[e];     // (a key shared by the batch: through the caches)
+        st_stream(po0 + e, make_ulonglong2(mred(a.x, k0.x, lp.q, lp.qinv), mred(a.y, k0.y, lp.q, lp.qinv)));
+        st_stream(po1 + e, make_ulonglong2(mred(a.x, k1.x, lp.q, lp.qinv), mred(a.y, k1.y, lp.q, lp.qinv)));
+    }
+}
+
+hipError_t launch_mul2(const Mul2Launch &L, int limbs, int batch, hipStream_t stream) {
+    if (limbs <= 0 || batch <= 0) return hipSuccess;
+    const int pairs = L.n >> 1;
+    int gx = (pairs + 255) / 256;
+    if (gx > 64) gx = 64;
+    if (gx < 1) gx = 1;
+    const dim3 grid((unsigned)gx, (unsigned)limbs, (unsigned)batch), block(256);
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(mul2_kernel, grid, block, 0, stream, L);
+    return hipGetLastError();
+}
+
 __global__ __launch_bounds__(256) void gather_kernel(GatherLaunch L) {
     const long long row = (long long)blockIdx.y * L.n;
     const long long b = blockIdx.z;

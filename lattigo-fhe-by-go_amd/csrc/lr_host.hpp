@@ -555,7 +555,9 @@ int run_submul(lr_context *c, int limbs, int batch, const u64 *a, long long a_st
 int same_degree(const lr_context *a, const lr_context *b);
 int same_stream(const lr_context *a, const lr_context *b);
 bool digit_is_extended(const lr_decomposer *d, int level, int crt);
-int moddown_pq_core(lr_bext *b, int level, const u64 *p1Q, long long p1Q_stride, Rows pP, int batch, lr_poly *p2, bool ntt);
+int moddown_pq_core(lr_bext *b, int level, const u64 *p1Q, long long p1Q_stride, Rows pP, int batch, lr_poly *p2, bool ntt, const u64 *x2 = nullptr,
+                    long long x2_stride = 0);
+bool moddown_epilogue_available(const lr_bext *b);
 int decompose_core(lr_decomposer *d, int level, int crt, Rows in, int batch, u64 *outQ, long long outQ_stride, u64 *outP, long long outP_stride, bool split, bool top = false, bool skip_own = false, std::vector<ExtPending> *collect = nullptr, bool inv_top = false);
 // lr_abi_ckks.cpp: the key switch and the pipelines over it
 std::atomic<int> &standalone_plans(int device);

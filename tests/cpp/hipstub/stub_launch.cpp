@@ -175,6 +175,15 @@ hipError_t launch_scatter(const ScatterLaunch &L, int limbs, int batch, hipStrea
         }
     return hipSuccess;
 }
+hipError_t launch_mul2(const Mul2Launch &L, int limbs, int batch, hipStream_t) {
+    g_stub_launches.fetch_add(1);
+    rows_r(L.a, L.a_stride, 0, 1, limbs, batch, L.n);
+    rows_r(L.b0, L.b0_stride, 0, 1, limbs, batch, L.n);
+    rows_r(L.b1, L.b1_stride, 0, 1, limbs, batch, L.n);
+    rows_w(L.out0, L.out0_stride, 0, 1, limbs, batch, L.n);
+    rows_w(L.out1, L.out1_stride, 0, 1, limbs, batch, L.n);
+    return hipSuccess;
+}
 hipError_t launch_gather(const GatherLaunch &L, int limbs, int batch, hipStream_t) {
     g_stub_launches.fetch_add(1);
     for (int b = 0; b < batch; ++b)
@@ -259,6 +268,7 @@ static void ext_touch(const ExtLaunch &L, int n_in, int batch) {
         const ExtSegment &g = L.seg[s];
         if (g.count <= 0) continue;
         if (g.epi_mode && g.epi_x) rows_r(g.epi_x, g.epi_x_stride, g.limb0, 1, g.count, batch, L.n);
+        if (g.epi_mode && g.epi_x2) rows_r(g.epi_x2, g.epi_x2_stride, g.limb0, 1, g.count, batch, L.n);
         rows_w(g.out, g.stride, g.limb0, 1, g.count, batch, L.n);
     }
 }

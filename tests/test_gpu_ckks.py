@@ -856,3 +856,33 @@ def test_rotate_hoisted_reads_the_digits_through_the_permutation(gpu_pkg, oracle
         for r in range(len(gens)):
             for k in range(2):
                 assert np.array_equal(outs[r][k].get().reshape(batch, level + 1, N)[b], want[r][k]), (env, r, b, k)
+
+
+@pytest.mark.parametrize("env", [{}, {"LR_NO_EPILOGUE": "1"}, {"LR_EXT_NARROW": "1"}])
+@pytest.mark.parametrize("logn,nq,np_,level,batch", [(12, 4, 2, 3, 3), (15, 18, 3, 17, 2), (13, 6, 3, 3, 2), (14, 7, 3, 6, 1)])
+def test_encrypt_pk_fused_steps_against_the_call_by_call_form(gpu_pkg, oracle, logn, nq, np_, level, batch, env, monkeypatch):
+    """round 4: pkEncryptor.encrypt's two products with the public key in one pass over u (mul2_kernel) and the Q rows' share of SampleAndAdd
+    inside the ModDown's extension epilogue (ExtSegment::epi_x2), at the top level; LR_NO_EPILOGUE keeps one launch per Context call, a
+    level below the top keeps the separate additions (the reference's ModDownPQ reads rows of Q as its P part there), LR_EXT_NARROW takes
+    an extension kernel without the epilogue; every way against the oracle, residues equal to q included"""
+    for k in ("LR_NO_EPILOGUE", "LR_EXT_NARROW"):
+        monkeypatch.delenv(k, raising=False)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    N, Q, P, cQ, cP, plan, oplan, evk, pevk = _ckks(gpu_pkg, oracle, logn, nq, np_, batch)
+    QP = Q + P
+    ocQP = oracle.Context(N, QP)
+    uni = lambda s, n: gpu_pkg.sampling.uniform_poly(QP, N, n, seed=s).reshape(n, nq + np_, N)
+    u, e0, e1 = uni(11, batch), uni(12, batch), uni(13, batch)
+    for i, q in enumerate(QP):
+        e0[0, i, 0] = q
+        e1[batch - 1, i, N - 1] = q
+    pk0, pk1 = uni(14, 1), uni(15, 1)
+    pt = gpu_pkg.sampling.uniform_poly(Q[:level + 1], N, batch, seed=16).reshape(batch, level + 1, N)
+    QPpoly = lambda x: gpu_pkg.ring.Poly(cQ, nq + np_, x.shape[0]).set(x)
+    ct = (cQ.NewPolyLvl(level, batch), cQ.NewPolyLvl(level, batch))
+    plan.EncryptPk(level, QPpoly(u), (QPpoly(pk0), QPpoly(pk1)), (QPpoly(e0), QPpoly(e1)), cQ.NewPolyLvl(level, batch).set(pt), ct)
+    for b in range(batch):
+        want = oplan.encrypt_pk(ocQP, level, u[b], pk0[0], pk1[0], e0[b], e1[b], pt[b])
+        for k in range(2):
+            assert np.array_equal(ct[k].get().reshape(batch, level + 1, N)[b], want[k]), (env, b, k)
