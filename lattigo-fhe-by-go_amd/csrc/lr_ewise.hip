@@ -850,8 +850,49 @@ __global__ __launch_bounds__(256) void permute_kernel(GaloisLaunch L) {
     }
 }
 
+// Context.Permute (ring/ring_galois.go:106-127), coefficient domain, for rows that fit the LDS (N <= 2^14: 128 KiB of the CU's 160): the
+// scatter out[i * gen mod N] = +-in[i] writes 8-byte words at a stride of gen words (a rotation by one column: 40 bytes), which the
+// memory system pays per touched line -- PN14QP438 RotateCols spent 454 us in it against 162 us for the row swap (gen = 2N - 1: reversed
+// but contiguous).  Here a workgroup reads one row coalesced into LDS and writes it out coalesced, taking output j from LDS word
+// (j * gen^-1 mod 2N) mod N, negated when that product is >= N: the same map read from the other side, same values (0 negated is q).
+__global__ __launch_bounds__(1024) void permute_coeff_lds_kernel(GaloisLaunch L, u32 ginv) {
+    extern __shared__ u64 lr_permute_row[];
+    const int limb = blockIdx.x;
+    const long long b = blockIdx.y;
+    const u32 n = (u32)L.n, mask2 = 2 * n - 1;
+    const ulonglong2 *pin = reinterpret_cast<const ulonglong2 *>(L.in + b * L.in_stride + (long long)limb * L.n);
+    ulonglong2 *pout = reinterpret_cast<ulonglong2 *>(L.out + b * L.out_stride + (long long)limb * L.n);
+    for (u32 e = threadIdx.x; e < n / 2; e += 1024) {
+        const ulonglong2 v = ld_stream(pin + e);
+        lr_permute_row[2 * e] = v.x;
+        lr_permute_row[2 * e + 1] = v.y;
+    }
+    __syncthreads();
+    const u64 q = L.lp[limb].q;
+    for (u32 e = threadIdx.x; e < n / 2; e += 1024) {
+        const u32 t0 = ((2 * e) * ginv) & mask2, t1 = ((2 * e + 1) * ginv) & mask2;
+        const u64 x0 = lr_permute_row[t0 & (n - 1)], x1 = lr_permute_row[t1 & (n - 1)];
+        st_stream(pout + e, make_ulonglong2(t0 >= n ? q - x0 : x0, t1 >= n ? q - x1 : x1));
+    }
+}
+
 hipError_t launch_permute(const GaloisLaunch &L, int limbs, int batch, hipStream_t stream) {
     if (limbs <= 0 || batch <= 0) return hipSuccess;
+    if (!L.ntt_domain && !L.in_table && (L.gen & 1) && L.logn >= 11 && L.logn <= 14 && batch <= 65535) {
+        // gen^-1 modulo 2N (gen odd): Newton's iteration doubles the correct low bits
+        const u32 mask2 = 2u * (u32)L.n - 1u, g = (u32)L.gen & mask2;
+        u32 inv = g;
+        for (int it = 0; it < 5; ++it) inv *= 2u - g * inv;
+        inv &= mask2;
+        const size_t lds = (size_t)L.n * sizeof(u64);
+        static hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(permute_coeff_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+        if (attr == hipSuccess) {
+            (void)hipGetLastError();
+            hipLaunchKernelGGL(permute_coeff_lds_kernel, dim3((unsigned)limbs, (unsigned)batch), dim3(1024), lds, stream, L, inv);
+            return hipGetLastError();
+        }
+        (void)hipGetLastError();     // (the attribute was refused: the scatter form below)
+    }
     int gx = (L.n + 255) / 256;
     if (gx > 64) gx = 64;
     const dim3 grid((unsigned)gx, (unsigned)limbs, (unsigned)batch), block(256);

@@ -265,7 +265,7 @@ def test_rescale_many(gpu_pkg, oracle, ntt, rounding):
         assert np.array_equal(got[b], oc.rescale_op("oc_div_%s_by_last_modulus_many" % rounding.lower(), x[b], nb=3, ntt=ntt))
 
 
-@pytest.mark.parametrize("logn", [4, 10, 13])
+@pytest.mark.parametrize("logn", [4, 10, 11, 13, 14, 15])
 def test_galois(gpu_pkg, oracle, logn):
     """ring/ring_galois.go: PermuteNTT / PermuteNTTIndex / Context.Permute, and the identity the reference's
     testGaloisShift relies on: NTT(Permute(x)) == PermuteNTT(NTT(x))."""
@@ -277,7 +277,9 @@ def test_galois(gpu_pkg, oracle, logn):
     x = gpu_pkg.sampling.uniform_poly(moduli, N, 2, seed=logn)
     x[0, 0, 3] = 0                                # a zero whose sign flips becomes q in Context.Permute
     px, po = ctx.NewPoly(2).set(x), ctx.NewPoly(2)
-    for gen in (5, pow(5, 3, 2 * N), 2 * N - 1):
+    # (round 4: Context.Permute at N = 2^11 ... 2^14 stages the row through LDS and reads the map from the other side, the other degrees
+    # keep the scatter; an even "generator" -- not an automorphism, the reference still computes something -- keeps the scatter too)
+    for gen in (5, pow(5, 3, 2 * N), 2 * N - 1, 2 * N + 5, pow(5, N // 4 + 1, 2 * N)):
         ring.PermuteNTT(ctx, px, gen, po)
         for b in range(2):
             assert np.array_equal(po.get()[b], oc.permute_ntt(x[b], gen))
