@@ -3,6 +3,8 @@
 // HBM-bound (16-24 B per coefficient): 16 B per lane per access, limb index on blockIdx.y so the
 // per-modulus constants are wave-uniform (SGPRs), batch on blockIdx.z.  An operand whose batch
 // is 1 is broadcast (poly stride 0).
+#include <atomic>
+
 #include "lattigo_ring.h"
 #include "lr_device.hpp"
 
@@ -885,8 +887,15 @@ hipError_t launch_permute(const GaloisLaunch &L, int limbs, int batch, hipStream
         for (int it = 0; it < 5; ++it) inv *= 2u - g * inv;
         inv &= mask2;
         const size_t lds = (size_t)L.n * sizeof(u64);
-        static hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(permute_coeff_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-        if (attr == hipSuccess) {
+        // more than 64 KiB of dynamic LDS is an attribute of the function ON THE CURRENT DEVICE: asked for once per device of the process
+        static std::atomic<int> lds_ok[64];      // 0 = not asked yet, 1 = granted, 2 = refused
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        std::atomic<int> &state = lds_ok[dev >= 0 && dev < 64 ? dev : 0];
+        if (state.load(std::memory_order_acquire) == 0)
+            state.store(hipFuncSetAttribute(reinterpret_cast<const void *>(permute_coeff_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) == hipSuccess ? 1 : 2,
+                        std::memory_order_release);
+        if (state.load(std::memory_order_acquire) == 1) {
             (void)hipGetLastError();
             hipLaunchKernelGGL(permute_coeff_lds_kernel, dim3((unsigned)limbs, (unsigned)batch), dim3(1024), lds, stream, L, inv);
             return hipGetLastError();
