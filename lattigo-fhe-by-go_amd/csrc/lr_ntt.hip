@@ -16,6 +16,7 @@
 //   copy-out : canonical reduction fused with a coalesced 16 B/lane store.
 // The inverse transform is the mirror image (copy-in, LDS passes low bits first, pass A last,
 // scaling by N^-1 fused into the final store).
+#include <atomic>
 #include "lr_device.hpp"
 
 namespace lr {
@@ -534,12 +535,19 @@ static hipError_t launch_fwd(const NttLaunch &a, hipStream_t stream) {
     using P = Plan<LOGN>;
     constexpr int M = (1 << LOGN) / P::HALVES;
     constexpr size_t lds_bytes = (size_t)lds_words(M) * sizeof(u64);
-    static bool configured = false;
     auto fn = ntt_fwd_kernel<LOGN, MODE>;
-    if (!configured) {
-        hipError_t e = hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        if (e != hipSuccess) return e;
-        configured = true;
+    {
+        // the dynamic-LDS limit is an attribute of the function on the CURRENT device: set once per device of the process (one process may
+        // drive several devices, one host thread each)
+        static std::atomic<bool> configured[64];
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        std::atomic<bool> &done = configured[dev >= 0 && dev < 64 ? dev : 0];
+        if (!done.load(std::memory_order_acquire)) {
+            hipError_t e = hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+            if (e != hipSuccess) return e;
+            done.store(true, std::memory_order_release);
+        }
     }
     const dim3 grid((unsigned)((a.n_items << a.sub_log) * a.batch)), block(1u << P::LOGT);
     (void)hipGetLastError();  // drop stale (non-sticky) errors of unrelated earlier calls
@@ -552,12 +560,19 @@ static hipError_t launch_inv(const NttLaunch &a, hipStream_t stream) {
     using P = Plan<LOGN>;
     constexpr int M = (1 << LOGN) / P::HALVES;
     constexpr size_t lds_bytes = (size_t)lds_words(M) * sizeof(u64);
-    static bool configured = false;
     auto fn = ntt_inv_kernel<LOGN, BIGQ>;
-    if (!configured) {
-        hipError_t e = hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        if (e != hipSuccess) return e;
-        configured = true;
+    {
+        // the dynamic-LDS limit is an attribute of the function on the CURRENT device: set once per device of the process (one process may
+        // drive several devices, one host thread each)
+        static std::atomic<bool> configured[64];
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        std::atomic<bool> &done = configured[dev >= 0 && dev < 64 ? dev : 0];
+        if (!done.load(std::memory_order_acquire)) {
+            hipError_t e = hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+            if (e != hipSuccess) return e;
+            done.store(true, std::memory_order_release);
+        }
     }
     const dim3 grid((unsigned)((a.n_items << a.sub_log) * a.batch)), block(1u << P::LOGT);
     (void)hipGetLastError();
