@@ -191,3 +191,132 @@ def test_mulrelin_rescale_fuzz(gpu_pkg, oracle, seed):
     for b in range(batch):
         for k, got in ((0, r0), (1, r1)):
             assert np.array_equal(got[b], oc.rescale_op("oc_div_round_by_last_modulus_ntt", wants[b][k])), ("rescale", logn, level, b, k)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_rotation_encrypt_decrypt_fuzz(gpu_pkg, oracle, seed):
+    """round 4's fused forms at random shapes: permuteNTT with a random Galois element, RotateHoisted over a random set of rotations (the
+    digits read through the permutation), EncryptPk (both products in one pass, the Q rows of the error in the ModDown's epilogue at the top
+    level, the call-by-call form below it) and Decrypt of a random degree (one Horner pass up to degree 8)"""
+    rng = np.random.default_rng(6000 + seed)
+    logn = int(rng.integers(4, 13)) if seed < 6 else 12 + seed % 5
+    N = 1 << logn
+    nq, np_ = int(rng.integers(2, 9)), int(rng.integers(1, 5))
+    _, Qf, Pf = gpu_pkg.params.ckks_moduli("PN16QP1761" if logn == 16 or np_ > 3 else "PN15QP880")
+    Q, P = Qf[:nq], Pf[:np_]
+    QP = Q + P
+    batch = int(rng.integers(1, 4))
+    level = int(rng.integers(0, nq))
+    ring = gpu_pkg.ring
+    cQ, cP = ring.NewContextWithParams(N, Q), ring.NewContextWithParams(N, P)
+    plan = ring.CkksPlan(cQ, cP, batch)
+    oplan = oracle.CkksPlan(oracle.Context(N, Q), oracle.Context(N, P))
+    beta = -(-nq // np_)
+    mk = lambda s: gpu_pkg.sampling.uniform_poly(Q[:level + 1], N, batch, seed=s).reshape(batch, level + 1, N)
+    P_ = lambda x: cQ.NewPolyLvl(level, batch).set(x)
+    a0, a1 = mk(seed + 11), mk(seed + 12)
+
+    rots = sorted(set(int(k) for k in rng.integers(1, N // 2, size=int(rng.integers(1, 5)))))
+    gens = [pow(5, k, 2 * N) for k in rots]
+    if rng.integers(0, 2):
+        gens[-1] = 2 * N - 1                                        # conjugation
+    evks = [gpu_pkg.sampling.uniform_poly(QP, N, 2 * beta, seed=seed + 300 + i) for i in range(len(gens))]
+    pevks = [plan.NewSwitchingKey().set(e) for e in evks]
+    evk4 = [e.reshape(beta, 2, nq + np_, N) for e in evks]
+    out = (cQ.NewPolyLvl(level, batch), cQ.NewPolyLvl(level, batch))
+    plan.PermuteNTT(level, (P_(a0), P_(a1)), gens[0], pevks[0], out)
+    g0, g1 = out[0].get().reshape(batch, level + 1, N), out[1].get().reshape(batch, level + 1, N)
+    for b in range(batch):
+        want = oplan.permute_ntt(level, np.stack([a0[b], a1[b]]), gens[0], evk4[0])
+        assert np.array_equal(g0[b], want[0]) and np.array_equal(g1[b], want[1]), ("permuteNTT", logn, nq, np_, level, gens[0], b)
+    outs = [(cQ.NewPolyLvl(level, batch), cQ.NewPolyLvl(level, batch)) for _ in gens]
+    plan.RotateHoisted(level, (P_(a0), P_(a1)), gens, pevks, outs)
+    got = [(o[0].get().reshape(batch, level + 1, N), o[1].get().reshape(batch, level + 1, N)) for o in outs]
+    for b in range(batch):
+        want = oplan.rotate_hoisted(level, np.stack([a0[b], a1[b]]), gens, evk4)
+        for r in range(len(gens)):
+            assert np.array_equal(got[r][0][b], want[r][0]) and np.array_equal(got[r][1][b], want[r][1]), ("hoisted", logn, nq, np_, level, gens, r, b)
+
+    ocQP = oracle.Context(N, QP)
+    uni = lambda s, n: gpu_pkg.sampling.uniform_poly(QP, N, n, seed=s).reshape(n, nq + np_, N)
+    u, e0, e1, pk0, pk1 = uni(seed + 21, batch), uni(seed + 22, batch), uni(seed + 23, batch), uni(seed + 24, 1), uni(seed + 25, 1)
+    pt = mk(seed + 26)
+    QPpoly = lambda x: ring.Poly(cQ, nq + np_, x.shape[0]).set(x)
+    ct = (cQ.NewPolyLvl(level, batch), cQ.NewPolyLvl(level, batch))
+    plan.EncryptPk(level, QPpoly(u), (QPpoly(pk0), QPpoly(pk1)), (QPpoly(e0), QPpoly(e1)), P_(pt), ct)
+    c0, c1 = ct[0].get().reshape(batch, level + 1, N), ct[1].get().reshape(batch, level + 1, N)
+    for b in range(batch):
+        want = oplan.encrypt_pk(ocQP, level, u[b], pk0[0], pk1[0], e0[b], e1[b], pt[b])
+        assert np.array_equal(c0[b], want[0][:level + 1]) and np.array_equal(c1[b], want[1][:level + 1]), ("encrypt", logn, nq, np_, level, b)
+
+    degree = int(rng.integers(1, 10))
+    comps = [mk(seed + 40 + i) for i in range(degree + 1)]
+    sk = gpu_pkg.sampling.uniform_poly(Q[:level + 1], N, 1, seed=seed + 60).reshape(1, level + 1, N)
+    dec = cQ.NewPolyLvl(level, batch)
+    plan.Decrypt(level, tuple(P_(c) for c in comps), cQ.NewPolyLvl(level, 1).set(sk), dec)
+    d = dec.get().reshape(batch, level + 1, N)
+    for b in range(batch):
+        assert np.array_equal(d[b], oplan.decrypt(level, np.stack([c[b] for c in comps]), sk[0])), ("decrypt", logn, level, degree, b)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_moddown_divfloor_permute_fuzz(gpu_pkg, oracle, seed):
+    """the ModDown family (NTT-domain form on the transform's epilogue where the kernels have one), DivFloor / DivRound in both domains
+    and Context.Permute / PermuteNTT with random generators at random degrees, limb counts, levels and batches"""
+    rng = np.random.default_rng(7000 + seed)
+    logn = int(rng.integers(4, 13)) if seed < 6 else 11 + seed % 6
+    N = 1 << logn
+    nq, np_ = int(rng.integers(2, 9)), int(rng.integers(1, 5))
+    batch = int(rng.integers(1, 4))
+    level = int(rng.integers(0, nq))
+    if seed % 3 == 0:
+        _, Qf, Pf = gpu_pkg.params.ckks_moduli("PN16QP1761" if logn == 16 or np_ > 3 else "PN15QP880")
+        Q, P = Qf[:nq], Pf[:np_]
+    elif seed % 3 == 1:
+        Q, P = list(gpu_pkg.params.Qi60()[-nq:]), list(gpu_pkg.params.Pi60()[-np_:])
+    else:
+        mods = _moduli(gpu_pkg, rng, max(logn, 4), nq + np_)
+        Q, P = mods[:nq], mods[nq:]
+    ring = gpu_pkg.ring
+    cQ, cP = ring.NewContextWithParams(N, Q), ring.NewContextWithParams(N, P)
+    be = ring.NewFastBasisExtender(cQ, cP)
+    ocQ, ocP = oracle.Context(N, Q), oracle.Context(N, P)
+    obe = oracle.BasisExtender(ocQ, ocP)
+    xq = gpu_pkg.sampling.uniform_poly(Q, N, batch, seed=seed + 1).reshape(batch, nq, N)
+    xp = gpu_pkg.sampling.uniform_poly(P, N, batch, seed=seed + 2).reshape(batch, np_, N)
+    pq, pp, out = cQ.NewPoly(batch).set(xq), cP.NewPoly(batch).set(xp), cQ.NewPolyLvl(level, batch)
+    be.ModDownSplitedNTTPQ(level, pq, pp, out)
+    got = out.get().reshape(batch, level + 1, N)
+    for b in range(batch):
+        assert np.array_equal(got[b], obe.moddown_split_ntt_pq(level, xq[b], xp[b])), ("moddown ntt", logn, nq, np_, level, b)
+    pp.set(xp)
+    be.ModDownSplitedPQ(level, pq, pp, out)
+    got = out.get().reshape(batch, level + 1, N)
+    for b in range(batch):
+        assert np.array_equal(got[b], obe.moddown_split_pq(level, xq[b], xp[b])), ("moddown", logn, nq, np_, level, b)
+    pq.set(xq)
+    be.ModDownSplitedNTTPQ(level, pq, cP.NewPoly(batch).set(xp), pq)           # in place on the Q part
+    got = pq.get().reshape(batch, nq, N)
+    for b in range(batch):
+        assert np.array_equal(got[b, :level + 1], obe.moddown_split_ntt_pq(level, xq[b], xp[b])), ("moddown ntt in place", logn, nq, np_, level, b)
+
+    names = {"DivFloorByLastModulusNTT": "oc_div_floor_by_last_modulus_ntt", "DivFloorByLastModulus": "oc_div_floor_by_last_modulus",
+             "DivRoundByLastModulusNTT": "oc_div_round_by_last_modulus_ntt", "DivRoundByLastModulus": "oc_div_round_by_last_modulus"}
+    for name, oname in names.items():
+        pr = cQ.NewPoly(batch).set(xq)
+        getattr(cQ, name)(pr)
+        got = pr.get().reshape(batch, nq - 1, N)
+        for b in range(batch):
+            assert np.array_equal(got[b], ocQ.rescale_op(oname, xq[b])), (name, logn, nq, b)
+
+    po = cQ.NewPoly(batch)
+    pq.set(xq)
+    for gen in (pow(5, int(rng.integers(1, N)), 2 * N), 2 * N - 1, int(rng.integers(0, N)) * 2 + 1):
+        ring.PermuteNTT(cQ, pq, gen, po)
+        got = po.get().reshape(batch, nq, N)
+        for b in range(batch):
+            assert np.array_equal(got[b], ocQ.permute_ntt(xq[b], gen)), ("permute ntt", logn, gen, b)
+        cQ.Permute(pq, gen, po)
+        got = po.get().reshape(batch, nq, N)
+        for b in range(batch):
+            assert np.array_equal(got[b], ocQ.permute(xq[b], gen)), ("permute", logn, gen, b)
