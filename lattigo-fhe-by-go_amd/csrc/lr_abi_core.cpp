@@ -655,13 +655,15 @@ extern "C" int lr_poly_unmarshal(lr_poly *p, int batch_index, const uint8_t *dat
     const size_t words = (size_t)limbs * p->N;
     if (len - 2 != words * 8) return fail(LR_ERR_ARG, "error : invalid polynomial encoding");   // :262-264
     LR_HIP(hipSetDevice(p->device));
-    u64 *stage = nullptr;
-    LR_HIP(hipMalloc((void **)&stage, words * 8 + 8));
-    hipError_t e = hipMemcpyAsync(stage, data + 2, words * 8, hipMemcpyHostToDevice, p->ctx->stream);
-    if (e == hipSuccess) e = launch_bswap(stage, p->d + (long long)batch_index * p->stride(), words, p->ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(p->ctx->stream);
-    (void)hipFree(stage);
+    // the big-endian image lands in a buffer of the context's scratch pool (no allocation, and no hipFree with its device-wide wait, per
+    // call); the lease goes back after the synchronisation below
+    ScratchLease stage;
+    LR_TRY(stage.take(&p->ctx->scratch, words + 1));
+    LR_HIP(hipMemcpyAsync(stage.d(), data + 2, words * 8, hipMemcpyHostToDevice, p->ctx->stream));
+    hipError_t e = launch_bswap(stage.d(), p->d + (long long)batch_index * p->stride(), words, p->ctx->stream);
+    const hipError_t es = hipStreamSynchronize(p->ctx->stream);
     LR_HIP(e);
+    LR_HIP(es);
     return LR_OK;
     });
 }
@@ -678,13 +680,13 @@ extern "C" int lr_poly_marshal(const lr_poly *p, int batch_index, uint8_t *data,
     data[0] = (uint8_t)logn;                                                                              // :168
     data[1] = (uint8_t)p->limbs;                                                                          // :169
     LR_HIP(hipSetDevice(p->device));
-    u64 *stage = nullptr;
-    LR_HIP(hipMalloc((void **)&stage, words * 8 + 8));
-    hipError_t e = launch_bswap(p->d + (long long)batch_index * p->stride(), stage, words, p->ctx->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(data + 2, stage, words * 8, hipMemcpyDeviceToHost, p->ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(p->ctx->stream);
-    (void)hipFree(stage);
+    ScratchLease stage;
+    LR_TRY(stage.take(&p->ctx->scratch, words + 1));
+    hipError_t e = launch_bswap(p->d + (long long)batch_index * p->stride(), stage.d(), words, p->ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(data + 2, stage.d(), words * 8, hipMemcpyDeviceToHost, p->ctx->stream);
+    const hipError_t es = hipStreamSynchronize(p->ctx->stream);     // also on the error path: the lease must not return while work is queued
     LR_HIP(e);
+    LR_HIP(es);
     if (written) *written = words * 8 + 2;
     return LR_OK;
     });

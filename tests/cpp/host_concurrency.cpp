@@ -179,6 +179,13 @@ int main(int argc, char **argv) {
                 OK(lr_div_floor_by_last_modulus(sq, r));
                 OK(lr_poly_set_limbs(r, NQ));
                 OK(lr_mult_by_monomial(sq, r, 3, r));
+                // wire image out and back in: the big-endian staging buffer is a lease of the shared context's pool
+                std::vector<uint8_t> image((size_t)NQ * N * 8 + 2);
+                size_t written = 0;
+                OK(lr_poly_marshal(r, 1, image.data(), image.size(), &written));
+                CHECK(written == image.size() && image[1] == NQ);
+                OK(lr_poly_unmarshal(r, 0, image.data(), written));
+                CHECK(lr_poly_unmarshal(r, 0, image.data(), written - 8) != LR_OK);
                 OK(lr_poly_free(r));
                 break;
             }
