@@ -96,9 +96,16 @@ extern "C" int lr_bfv_mul(lr_bfv_plan *pl, const lr_poly *a0, const lr_poly *a1,
     LR_TRY(pl->prodQ.ensure(cQ, (size_t)3 * batch * sQ));
     LR_TRY(pl->prodM.ensure(cQ, (size_t)3 * batch * sM));
     const long long slotQ = (long long)batch * sQ, slotM = (long long)batch * sM;
+    // ct0 == ct1 (:306, :334 "squaring case"): the second operand is not lifted and transformed again.  Its tensor (c0 = c0[0]^2,
+    // c1 = 2 c0[0] c0[1] by AddNoMod, c2 = c0[1]^2) and the regular one give the same canonical polys after the InvNTT -- MRed(MForm(x), y)
+    // and MRed(MForm(y), x) are the same residue below q --, so the tensor kernel simply reads the first operand's slots twice.
+    const bool square = a0 == b0 && a1 == b1;
+    const int sides = square ? 1 : 2;
     // slots: a0, a1, b0, b1
-    u64 *const aQ[2] = {pl->liftQ.d, pl->liftQ.d + slotQ}, *const bQ[2] = {pl->liftQ.d + 2 * slotQ, pl->liftQ.d + 3 * slotQ};
-    u64 *const aM[2] = {pl->liftM.d, pl->liftM.d + slotM}, *const bM[2] = {pl->liftM.d + 2 * slotM, pl->liftM.d + 3 * slotM};
+    u64 *const aQ[2] = {pl->liftQ.d, pl->liftQ.d + slotQ};
+    u64 *const aM[2] = {pl->liftM.d, pl->liftM.d + slotM};
+    u64 *const bQ[2] = {square ? aQ[0] : pl->liftQ.d + 2 * slotQ, square ? aQ[1] : pl->liftQ.d + 3 * slotQ};
+    u64 *const bM[2] = {square ? aM[0] : pl->liftM.d + 2 * slotM, square ? aM[1] : pl->liftM.d + 3 * slotM};
     u64 *const cQ3[3] = {pl->prodQ.d, pl->prodQ.d + slotQ, pl->prodQ.d + 2 * slotQ};
     u64 *const cM3[3] = {pl->prodM.d, pl->prodM.d + slotM, pl->prodM.d + 2 * slotM};
     lr_bext *bx = pl->bext;
@@ -112,24 +119,25 @@ extern "C" int lr_bfv_mul(lr_bfv_plan *pl, const lr_poly *a0, const lr_poly *a1,
         LR_TRY(pl->stageOut.ensure(cQ, (size_t)3 * batch * sQ));
         MultiCopyLaunch G;
         const lr_poly *srcs[4] = {a0, a1, b0, b1};
+        const int polys = 2 * sides;
         for (int k = 0; k < 4; ++k) {
-            G.src[k] = srcs[k]->d;
-            G.src_stride[k] = srcs[k]->stride();
-            G.dst[k] = pl->stageIn.d + k * slotQ;
-            G.dst_stride[k] = sQ;
+            G.src[k] = k < polys ? srcs[k]->d : nullptr;
+            G.src_stride[k] = k < polys ? srcs[k]->stride() : 0;
+            G.dst[k] = k < polys ? pl->stageIn.d + k * slotQ : nullptr;
+            G.dst_stride[k] = k < polys ? sQ : 0;
         }
-        G.count = 4;
+        G.count = polys;
         G.batch = batch;
         G.n = n;
         LR_HIP(launch_multicopy(G, nQ, cQ->stream));
         Rows in4{pl->stageIn.d, sQ, 0, 1};
-        LR_TRY(run_ext(cQ, bx->qp, nQ, in4, 4 * batch, segment(pl->liftM.d, sM, 0, 0, nM), segment(nullptr, 0, 0, 0, 0)));
-        LR_TRY(run_ntt(cQ, false, in4, Rows{pl->liftQ.d, sQ, 0, 1}, 0, 1, nQ, 4 * batch));
-        LR_TRY(run_ntt(cM, false, Rows{pl->liftM.d, sM, 0, 1}, Rows{pl->liftM.d, sM, 0, 1}, 0, 1, nM, 4 * batch));
+        LR_TRY(run_ext(cQ, bx->qp, nQ, in4, polys * batch, segment(pl->liftM.d, sM, 0, 0, nM), segment(nullptr, 0, 0, 0, 0)));
+        LR_TRY(run_ntt(cQ, false, in4, Rows{pl->liftQ.d, sQ, 0, 1}, 0, 1, nQ, polys * batch));
+        LR_TRY(run_ntt(cM, false, Rows{pl->liftM.d, sM, 0, 1}, Rows{pl->liftM.d, sM, 0, 1}, 0, 1, nM, polys * batch));
     } else {
         // :298-313  basis extension Q -> QMul, then NTT in both bases
         for (int i = 0; i < 2; ++i) {
-            for (int side = 0; side < 2; ++side) {
+            for (int side = 0; side < sides; ++side) {
                 const lr_poly *src = side == 0 ? A[i] : B[i];
                 u64 *dQ = side == 0 ? aQ[i] : bQ[i];
                 u64 *dM = side == 0 ? aM[i] : bM[i];

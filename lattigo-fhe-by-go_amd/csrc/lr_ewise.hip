@@ -176,7 +176,9 @@ __global__ __launch_bounds__(256) void tensor_kernel(TensorLaunch L) {
     ulonglong2 *pc2 = reinterpret_cast<ulonglong2 *>(L.c2 + b * L.c2_stride + row);
     const int pairs = L.n >> 1;
     for (int e = blockIdx.x * 256 + threadIdx.x; e < pairs; e += gridDim.x * 256) {
-        const ulonglong2 a0 = ld_stream(pa0 + e), a1 = ld_stream(pa1 + e), b0 = ld_stream(pb0 + e), b1 = ld_stream(pb1 + e);
+        // (the squaring case -- ct0 == ct1, ckks/evaluator.go:1083, bfv/evaluator.go:334 -- reads its one operand once: block-uniform)
+        const ulonglong2 a0 = ld_stream(pa0 + e), a1 = ld_stream(pa1 + e);
+        const ulonglong2 b0 = pb0 == pa0 ? a0 : ld_stream(pb0 + e), b1 = pb1 == pa1 ? a1 : ld_stream(pb1 + e);
         ulonglong2 c0, c1, c2;
         {
             const u64 m0 = mform(a0.x, q, lp.bred_hi, lp.bred_lo), m1 = mform(a1.x, q, lp.bred_hi, lp.bred_lo);

@@ -1187,6 +1187,47 @@ void oc_bfv_mul(oc_bext *b, u64 t, const u64 *phalf_q, const u64 *phalf_qm, cons
     free(c0Q1); free(c0Q2); free(c1Q1); free(c1Q2); free(c2Q1); free(c2Q2); free(c00Q); free(c00M); free(c01Q); free(c01M);
 }
 
+/* tensorAndRescale with ct0 == ct1, bfv/evaluator.go:278-464: the operand is lifted and transformed once (:298-305, :306 skips the
+ * second loop) and the tensor is the squaring case of :334-349 (c1 = 2 c0[0] c0[1] by AddNoMod). */
+void oc_bfv_square(oc_bext *b, u64 t, const u64 *phalf_q, const u64 *phalf_qm, const u64 *ct0, u64 *out) {
+    const oc_context *cQ = b->cQ, *cM = b->cP;
+    const u64 N = cQ->N;
+    const int nQ = cQ->L, nM = cM->L;
+    const int lQ = nQ - 1, lM = nM - 1;
+    size_t sQ = (size_t)nQ * N, sM = (size_t)nM * N;
+    u64 *c0Q1 = (u64 *)malloc(2 * sQ * 8), *c0Q2 = (u64 *)malloc(2 * sM * 8);
+    u64 *c2Q1 = (u64 *)malloc(3 * sQ * 8), *c2Q2 = (u64 *)malloc(3 * sM * 8);
+    u64 *c00Q = (u64 *)malloc(sQ * 8), *c00M = (u64 *)malloc(sM * 8), *c01Q = (u64 *)malloc(sQ * 8), *c01M = (u64 *)malloc(sM * 8);
+    for (int i = 0; i < 2; i++) {                                            /* :298-304 */
+        oc_modup_split_qp(b, lQ, ct0 + i * sQ, c0Q2 + i * sM);
+        oc_ntt_lvl(cQ, lQ, ct0 + i * sQ, c0Q1 + i * sQ);
+        oc_ntt_lvl(cM, lM, c0Q2 + i * sM, c0Q2 + i * sM);
+    }
+    oc_ewise(cQ, OC_MFORM, lQ, c0Q1, NULL, c00Q, NULL);                       /* :327-331 */
+    oc_ewise(cM, OC_MFORM, lM, c0Q2, NULL, c00M, NULL);
+    oc_ewise(cQ, OC_MFORM, lQ, c0Q1 + sQ, NULL, c01Q, NULL);
+    oc_ewise(cM, OC_MFORM, lM, c0Q2 + sM, NULL, c01M, NULL);
+    oc_ewise(cQ, OC_MUL_MONT, lQ, c00Q, c0Q1, c2Q1, NULL);                    /* :337-338 */
+    oc_ewise(cM, OC_MUL_MONT, lM, c00M, c0Q2, c2Q2, NULL);
+    oc_ewise(cQ, OC_MUL_MONT, lQ, c00Q, c0Q1 + sQ, c2Q1 + sQ, NULL);          /* :341-342 */
+    oc_ewise(cM, OC_MUL_MONT, lM, c00M, c0Q2 + sM, c2Q2 + sM, NULL);
+    oc_ewise(cQ, OC_ADD_NOMOD, lQ, c2Q1 + sQ, c2Q1 + sQ, c2Q1 + sQ, NULL);    /* :344-345 */
+    oc_ewise(cM, OC_ADD_NOMOD, lM, c2Q2 + sM, c2Q2 + sM, c2Q2 + sM, NULL);
+    oc_ewise(cQ, OC_MUL_MONT, lQ, c01Q, c0Q1 + sQ, c2Q1 + 2 * sQ, NULL);      /* :348-349 */
+    oc_ewise(cM, OC_MUL_MONT, lM, c01M, c0Q2 + sM, c2Q2 + 2 * sM, NULL);
+    for (int i = 0; i < 3; i++) {                                            /* :423-463 */
+        u64 *q1 = c2Q1 + i * sQ, *q2 = c2Q2 + i * sM, *o = out + i * sQ;
+        oc_intt_lvl(cQ, lQ, q1, q1);
+        oc_intt_lvl(cM, lM, q2, q2);
+        oc_moddown_split_qp(b, lQ, lM, q1, q2, q2);
+        oc_ewise(cM, OC_ADD_SCALAR_LIMBS, lM, q2, NULL, q2, phalf_qm);
+        oc_modup_split_pq(b, lM, q2, o);
+        oc_ewise(cQ, OC_SUB_SCALAR_LIMBS, lQ, o, NULL, o, phalf_q);
+        oc_ewise(cQ, OC_MUL_SCALAR, lQ, o, NULL, o, &t);
+    }
+    free(c0Q1); free(c0Q2); free(c2Q1); free(c2Q2); free(c00Q); free(c00M); free(c01Q); free(c01M);
+}
+
 /* ========================= ring/ring_galois.go ============================ */
 static int log2_u64(u64 n) { int l = 0; while (((u64)1 << l) < n) l++; return l; }
 

@@ -222,6 +222,8 @@ void oc_permute(const oc_context *c, const uint64_t *in, uint64_t gen, uint64_t 
  * pHalf = (prod QMul) >> 1 (:100) modulo the Q and QMul primes; t = plaintext modulus. */
 void oc_bfv_mul(oc_bext *b, uint64_t t, const uint64_t *phalf_q, const uint64_t *phalf_qm,
                 const uint64_t *ct0, const uint64_t *ct1, uint64_t *out);
+/* the same with ct0 == ct1: the squaring case of bfv/evaluator.go:306,334-349 */
+void oc_bfv_square(oc_bext *b, uint64_t t, const uint64_t *phalf_q, const uint64_t *phalf_qm, const uint64_t *ct0, uint64_t *out);
 
 /* ---- Float128 (ring/float128.go) and SimpleScaler (ring/ring_scaling.go:166-300) ---- */
 void     oc_f128_set_uint53(uint64_t i, double r[2]);

@@ -154,6 +154,7 @@ def _bind(L):
     sig("oc_ckks_decrypt", None, vp, i, vp, i, vp, vp)
     sig("oc_ckks_rotate_hoisted", None, vp, i, vp, i, vp, vp, vp)
     sig("oc_bfv_mul", None, vp, u64, vp, vp, vp, vp, vp)
+    sig("oc_bfv_square", None, vp, u64, vp, vp, vp, vp)
     sig("oc_permute_ntt_index", None, u64, u64, u64, vp)
     sig("oc_permute_ntt", None, vp, u64, vp, i, u64)
     sig("oc_permute_ntt_with_index", None, vp, vp, vp, i, u64)
@@ -504,6 +505,15 @@ class BfvPlan:
         pq = np.array([self.p_half % m for m in self.cQ.moduli], dtype=np.uint64)
         pm = np.array([self.p_half % m for m in self.cM.moduli], dtype=np.uint64)
         lib().oc_bfv_mul(self.bext.h, self.t, _ptr(pq), _ptr(pm), _ptr(ct0), _ptr(ct1), _ptr(out))
+        return out
+
+    def square(self, ct0):
+        """evaluator.Mul(ct, ct, .) = tensorAndRescale's squaring case (bfv/evaluator.go:306,334-349)"""
+        ct0 = _arr(ct0)
+        out = np.zeros((3, self.cQ.L, self.cQ.N), dtype=np.uint64)
+        pq = np.array([self.p_half % m for m in self.cQ.moduli], dtype=np.uint64)
+        pm = np.array([self.p_half % m for m in self.cM.moduli], dtype=np.uint64)
+        lib().oc_bfv_square(self.bext.h, self.t, _ptr(pq), _ptr(pm), _ptr(ct0), _ptr(out))
         return out
 
 

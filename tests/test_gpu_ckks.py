@@ -91,6 +91,41 @@ def test_bfv_mul(gpu_pkg, oracle, name, logn):
             assert np.array_equal(out[k].get()[b], want[k]), (b, k)
 
 
+@pytest.mark.parametrize("env", [{}, {"LR_BFV_NO_GATHER": "1"}])
+@pytest.mark.parametrize("name,logn,batch", [("PN12QP109", 12, 2), ("PN13QP218", 11, 3), ("PN14QP438", 14, 1), ("PN14QP438", 14, 80)])
+def test_bfv_square(gpu_pkg, oracle, name, logn, batch, env, monkeypatch):
+    """evaluator.Mul(ct, ct, .) (the reference's Square benchmark, bfv/bfv_benchmark_test.go:139): the operand is lifted and transformed
+    once (bfv/evaluator.go:306) and the tensor kernel reads its slots for both factors; against the oracle's restatement of the squaring case, on the gathered
+    small-batch path and on the per-operand one (batch 80 at N = 2^14 is above the gather threshold)"""
+    monkeypatch.delenv("LR_BFV_NO_GATHER", raising=False)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    _, Q, P, QMul = gpu_pkg.params.bfv_moduli(name)
+    N, t = 1 << logn, 65537
+    ring = gpu_pkg.ring
+    cQ, cM = ring.NewContextWithParams(N, Q), ring.NewContextWithParams(N, QMul)
+    plan = ring.BfvPlan(cQ, cM, t, batch)
+    oplan = oracle.BfvPlan(oracle.Context(N, Q), oracle.Context(N, QMul), t)
+    mk = lambda s: gpu_pkg.sampling.uniform_poly(Q, N, batch, seed=s).reshape(batch, len(Q), N)
+    a0, a1 = mk(31), mk(32)
+    ct = (cQ.NewPoly(batch).set(a0), cQ.NewPoly(batch).set(a1))
+    out = (cQ.NewPoly(batch), cQ.NewPoly(batch), cQ.NewPoly(batch))
+    plan.Mul(ct, ct, out)
+    got = [o.get().reshape(batch, len(Q), N) for o in out]
+    for b in sorted({0, batch - 1}):
+        want = oplan.square(np.stack([a0[b], a1[b]]))
+        for k in range(3):
+            assert np.array_equal(got[k][b], want[k]), (b, k)
+    if batch > 2:                                                   # every unit: against the regular path on two copies of the operand
+        ct2 = (cQ.NewPoly(batch).set(a0), cQ.NewPoly(batch).set(a1))
+        out2 = (cQ.NewPoly(batch), cQ.NewPoly(batch), cQ.NewPoly(batch))
+        plan.Mul(ct, ct2, out2)
+        for k in range(3):
+            assert np.array_equal(out2[k].get(), out[k].get()), k
+    plan.Mul(ct, ct, (ct[0], ct[1], out[2]))                        # the result over the operand
+    assert np.array_equal(ct[0].get().reshape(batch, len(Q), N), got[0]) and np.array_equal(ct[1].get().reshape(batch, len(Q), N), got[1])
+
+
 @pytest.mark.parametrize("name,logn", [("PN13QP218", 11), ("PN14QP438", 14)])
 def test_bfv_mul_without_extension_epilogues(gpu_pkg, oracle, name, logn, monkeypatch):
     """the same with the subtract-multiply of the ModDown and the SubScalar / MulScalar tail as separate passes instead of in the

@@ -431,3 +431,19 @@ def test_bfv_permute_decrypts_to_the_automorphism_of_the_plaintext(oracle, gen_k
     p0, p1 = plan.bfv_switch_keys(perm1, evk)
     assert np.array_equal(out[1], p1)
     assert np.array_equal(out[0], add(ocQ.permute(ct[0], gen), p0, Q))
+
+
+def test_bfv_square_branch_equals_the_regular_tensor_on_equal_operands(oracle):
+    """tensorAndRescale's squaring case (bfv/evaluator.go:306,334-349: the operand lifted once, c1 = 2 c0[0] c0[1] by AddNoMod) and the
+    regular case fed the same ciphertext twice give the same three polys: MRed(MForm(x), y) and MRed(MForm(y), x) are the same canonical
+    residue, and everything after the tensor is exact.  The device library relies on this to read the first operand's slots twice."""
+    from importlib import import_module  # noqa: F401
+    for name, logn in (("PN12QP109", 8), ("PN13QP218", 9), ("PN14QP438", 10)):
+        _, Q, _, M = params.bfv_moduli(name)
+        N = 1 << logn
+        plan = oracle.BfvPlan(oracle.Context(N, list(Q)), oracle.Context(N, list(M)), 65537)
+        rng = np.random.default_rng(logn)
+        ct = np.stack([np.array([rng.integers(0, q, size=N, dtype=np.uint64) for q in Q]) for _ in range(2)])
+        sq, reg = plan.square(ct), plan.mul(ct, ct.copy())
+        assert np.array_equal(sq, reg), name
+        assert sq.any()

@@ -63,7 +63,9 @@ class Kits:
         cq, cp = ring.NewContextWithParams(N, Q, device=self.device), ring.NewContextWithParams(N, P, device=self.device)
         pq, pp = sampling.uniform_poly(Q, N, 2, seed=0x51), sampling.uniform_poly(P, N, 2, seed=0x52)
         a, p = self.fill(cq, cq.NewPoly(B), pq), self.fill(cp, cp.NewPoly(B), pp)
-        return dict(N=N, Q=Q, P=P, B=B, cq=cq, cp=cp, be=ring.NewFastBasisExtender(cq, cp), pq=pq, pp=pp, a=a, p=p, w=cq.NewPoly(B), wp=cp.NewPoly(B))
+        pq2 = sampling.uniform_poly(Q, N, 2, seed=0x53)
+        return dict(N=N, Q=Q, P=P, B=B, cq=cq, cp=cp, be=ring.NewFastBasisExtender(cq, cp), pq=pq, pp=pp, a=a, p=p, w=cq.NewPoly(B), wp=cp.NewPoly(B),
+                    pq2=pq2, a2=self.fill(cq, cq.NewPoly(B), pq2))
 
     def _kit_ckks15(self):
         ring, params, sampling = self.ring, self.params, self.sampling
@@ -175,6 +177,61 @@ def build_legs(pkg, oracle, device=0, only=None):
                 return lambda: oc_i.rescale_op(oname, x)
             out.append(Leg(nm, "poly/s", B, 8 * N * (2 * L - 1), tag, "ring/ring_benchmark_test.go" + ref, run, check, cpu, B, sync=cq,
                            after=lambda: nat.check(nat.lib().lr_poly_set_limbs(w.h, L))))
+        # the coefficient-wise family as the reference benchmarks it (ring_benchmark_test.go:132-308): in place on the first operand,
+        # p0 <- op(p0, p1) / p0 <- op(p0); one streaming kernel each (lr_ewise.hip), three or two polys of traffic per poly
+        a2 = k["a2"]
+        s1, s2 = 0xFFFFFFFFFFFFFFC5, 0xFFFFFFFFFFFFFF43                       # "RandUniform(2^64 - 1)" scalars of benchMulScalar, fixed
+        big = s1 * s2
+        big_res = [big % q for q in Q]
+        ew = (("ew_mform", "MFORM", 2, None, ":140-144 (MForm)"), ("ew_inv_mform", "INV_MFORM", 2, None, ":146-150 (InvMForm)"),
+              ("ew_mulcoeffs_barrett", "MUL_COEFFS", 3, None, ":197-201 (MulCoeffs, Barrett)"),
+              ("ew_mulcoeffs_barrett_constant", "MUL_COEFFS_CONSTANT", 3, None, ":203-207 (MulCoeffsConstant)"),
+              ("ew_mulcoeffs_montgomery_constant", "MUL_MONT_CONSTANT", 3, None, ":215-219 (MulCoeffsMontgomeryConstant)"),
+              ("ew_add", "ADD", 3, None, ":231-235 (Add)"), ("ew_add_nomod", "ADD_NOMOD", 3, None, ":237-241 (AddNoMod)"),
+              ("ew_sub", "SUB", 3, None, ":253-257 (Sub)"), ("ew_sub_nomod", "SUB_NOMOD", 3, None, ":259-263 (SubNoMod)"),
+              ("ew_neg", "NEG", 2, None, ":274-278 (Neg)"),
+              ("ew_mulscalar", "MUL_SCALAR", 2, [s1], ":296-300 (MulScalar, uint64)"),
+              ("ew_mulscalar_bigint", "MUL_SCALAR_LIMBS", 2, big_res, ":302-306 (MulScalarBigint)"))
+        for nm, op, operands, scalars, ref in ew:
+            if not want(nm):
+                continue
+
+            def run(op=op, operands=operands, scalars=scalars):
+                cq._ew(op, level, w, a2 if operands == 3 else None, w, scalars)
+
+            def check(op=op, operands=operands, scalars=scalars, run=run):
+                cq.Copy(a, w)
+                run()
+                wantv = ocq().ewise(op, k["pq"][last], k["pq2"][last] if operands == 3 else None, scalars=scalars)
+                return bool(np.array_equal(_last(w, B, L, N), wantv))
+
+            def cpu(i, op=op, operands=operands, scalars=scalars):
+                oc_i, x, y = ocq(), k["pq"][0].copy(), k["pq2"][0].copy() if operands == 3 else None
+                return lambda: oc_i.ewise(op, x, y, out=x, scalars=scalars)
+            out.append(Leg(nm, "poly/s", B, 8 * N * L * operands, tag, "ring/ring_benchmark_test.go" + ref + ", in place on the first operand", run, check, cpu, B,
+                           reps=20, sync=cq, after=lambda: cq.Copy(a, w)))
+        if want("marshal"):
+            # Poly.MarshalBinary (ring/ring_object.go:222) of one poly per call: swapped to big-endian words on the device, then across PCIe into the caller's buffer
+            import ctypes as C
+            mbuf = (C.c_uint8 * (2 + 8 * L * N))()                       # the caller's []byte, allocated once
+            mlen = C.c_size_t(0)
+
+            def run_m():
+                for b in range(8):
+                    nat.check(nat.lib().lr_poly_marshal(w.h, b, mbuf, len(mbuf), C.byref(mlen)))
+
+            def check_m():
+                cq.Copy(a, w)
+                blob = w.MarshalBinary(B - 1)
+                return bool(blob[:2] == bytes([15, L]) and np.array_equal(np.frombuffer(blob, dtype=">u8", offset=2).astype(np.uint64).reshape(L, N), k["pq"][last]))
+
+            def cpu_m(i):
+                x = k["pq"][0]
+                return lambda: bytes([15, L]) + x.astype(">u8").tobytes()            # WriteCoeffsTo's loop (ring/ring_object.go:178-192): big-endian words out
+            out.append(Leg("marshal", "poly/s", 8, 16 * N * L, "one R15 poly (16 limbs, %.1f MB serialized) per call, host buffer out" % ((16 * N * 8 + 2) / 1e6),
+                           "ring/ring_benchmark_test.go:52-58 (Marshal/Poly), ring/ring_object.go:222-229, :178-192 (WriteCoeffsTo)", run_m, check_m, cpu_m, 8, reps=3, sync=cq,
+                           host_bytes_per_unit=16 * N * 8 + 2,
+                           note="PCIe-inclusive by construction (the boundary hands back host bytes); the device part is the byte-swap kernel, 16N*L bytes"))
         return out
 
     # ------------------------------------------------------------------------------------------------ ckks, PN15QP880
@@ -233,6 +290,38 @@ def build_legs(pkg, oracle, device=0, only=None):
                 return lambda: op.mul_norelin(level, x, y)
             out.append(Leg("ckks_mul", "Mul/s", B, 8 * N * 7 * l, tag, "ckks/ckks_benchmarks_test.go:166-170 (Mul: MulRelin with evakey == nil, degree-2 result)",
                            lambda: plan.MulRelin(level, (comp[0], comp[1]), (comp[2], comp[3]), None, outp), check, cpu, B, reps=20, sync=cq))
+        if want("ckks_square"):
+            def check_sq():
+                plan.MulRelin(level, (comp[0], comp[1]), (comp[0], comp[1]), None, outp)
+                wantv = oplan().mul_norelin(level, ct_h(0, last), ct_h(0, last), squaring=True)
+                return bool(all(np.array_equal(_last(outp[j], B, nq, N), wantv[j]) for j in range(3)))
+
+            def cpu_sq(i):
+                op, x = oplan(), ct_h(0, 0)
+                return lambda: op.mul_norelin(level, x, x, squaring=True)
+            out.append(Leg("ckks_square", "Square/s", B, 8 * N * 5 * l, tag, "ckks/ckks_benchmarks_test.go:172-176 (Square: MulRelin(ct, ct, nil), the squaring case ckks/evaluator.go:1083-1088)",
+                           lambda: plan.MulRelin(level, (comp[0], comp[1]), (comp[0], comp[1]), None, outp), check_sq, cpu_sq, B, reps=20, sync=cq,
+                           note="two components in, three out"))
+        if want("ckks_add"):
+            # evaluator.Add (ckks/evaluator.go:123-131 -> evaluateInPlace :208-243): ctx.AddLvl per component, in place on the first operand
+            w0, w1 = outp[0], outp[1]
+
+            def run_add():
+                cq.AddLvl(level, w0, comp[2], w0)
+                cq.AddLvl(level, w1, comp[3], w1)
+
+            def check_add():
+                cq.Copy(comp[0], w0)
+                cq.Copy(comp[1], w1)
+                run_add()
+                oc = oracle.Context(N, Q)
+                return two(w0, w1, [oc.ewise("ADD", k["comp_h"][j][last], k["comp_h"][2 + j][last]) for j in range(2)])
+
+            def cpu_add(i):
+                oc, c = oracle.Context(N, Q), [k["comp_h"][j][0].copy() for j in range(4)]
+                return lambda: (oc.ewise("ADD", c[0], c[2], out=c[0]), oc.ewise("ADD", c[1], c[3], out=c[1]))
+            out.append(Leg("ckks_add", "Add/s", B, 8 * N * 6 * l, tag, "ckks/ckks_benchmarks_test.go:134-138 (Add: evaluateInPlace, one AddLvl per component, in place)",
+                           run_add, check_add, cpu_add, B, reps=20, sync=cq))
         if want("ckks_relinearize"):
             # Relinearize (ckks/evaluator.go:1144-1162) as the Go overlay runs it: switchKeysInPlace of the degree-2 part, then the two AddLvl
             def run():
@@ -380,6 +469,18 @@ def build_legs(pkg, oracle, device=0, only=None):
                 return lambda: op.mul(x, y)
             out.append(Leg("bfv_mul", "Mul/s", B, 8 * N * 7 * l, tag, "bfv/bfv_benchmark_test.go:133-137 (Mul = tensorAndRescale, bfv/evaluator.go:278-464); BASELINE.json config 4",
                            lambda: mul.Mul((comp[0], comp[1]), (comp[2], comp[3]), outp), check, cpu, B, sync=cq))
+        if want("bfv_square"):
+            def check_sq():
+                mul.Mul((comp[0], comp[1]), (comp[0], comp[1]), outp)
+                wantv = oracle.BfvPlan(oracle.Context(N, Q), oracle.Context(N, QM), 65537).square(ct_h(0, last))
+                return bool(all(np.array_equal(_last(outp[j], B, nq, N), wantv[j]) for j in range(3)))
+
+            def cpu_sq(i):
+                op, x = oracle.BfvPlan(oracle.Context(N, Q), oracle.Context(N, QM), 65537), ct_h(0, 0)
+                return lambda: op.square(x)
+            out.append(Leg("bfv_square", "Square/s", B, 8 * N * 5 * l, tag, "bfv/bfv_benchmark_test.go:139-143 (Square = tensorAndRescale with ct0 == ct1, bfv/evaluator.go:306,334-349)",
+                           lambda: mul.Mul((comp[0], comp[1]), (comp[0], comp[1]), outp), check_sq, cpu_sq, B, sync=cq,
+                           note="two components in, three out; the operand is lifted to QMul and transformed once"))
         if want("bfv_relinearize"):
             def check():
                 plan.BfvRelinearize((comp[0], comp[1], comp[2]), key, (outp[0], outp[1]))
@@ -432,10 +533,10 @@ def build_legs(pkg, oracle, device=0, only=None):
     return kits, groups
 
 
-GROUPS = {"ring15": ["moddown_ntt", "moddown", "div_floor_ntt", "div_floor", "div_round"],
-          "ckks15": ["ckks_rescale", "ckks_mul", "ckks_relinearize", "ckks_rotate", "ckks_conjugate", "ckks_rotate_hoisted", "ckks_encrypt_pk", "ckks_decrypt",
+EWISE = ["ew_mform", "ew_inv_mform", "ew_mulcoeffs_barrett", "ew_mulcoeffs_barrett_constant", "ew_mulcoeffs_montgomery_constant", "ew_add", "ew_add_nomod",
+         "ew_sub", "ew_sub_nomod", "ew_neg", "ew_mulscalar", "ew_mulscalar_bigint"]
+GROUPS = {"ring15": ["moddown_ntt", "moddown", "div_floor_ntt", "div_floor", "div_round"] + EWISE + ["marshal"],
+          "ckks15": ["ckks_rescale", "ckks_mul", "ckks_square", "ckks_add", "ckks_relinearize", "ckks_rotate", "ckks_conjugate", "ckks_rotate_hoisted", "ckks_encrypt_pk", "ckks_decrypt",
                      "marshal_ingest"],
-          "bfv14": ["bfv_mul", "bfv_relinearize", "bfv_rotate_rows", "bfv_rotate_columns", "simple_scaler"]}
-LEG_NAMES = ["moddown_ntt", "moddown", "div_floor_ntt", "div_floor", "div_round", "ckks_rescale", "ckks_mul", "ckks_relinearize", "ckks_rotate",
-             "ckks_conjugate", "ckks_rotate_hoisted", "ckks_encrypt_pk", "ckks_decrypt", "marshal_ingest", "bfv_mul", "bfv_relinearize",
-             "bfv_rotate_rows", "bfv_rotate_columns", "simple_scaler"]
+          "bfv14": ["bfv_mul", "bfv_square", "bfv_relinearize", "bfv_rotate_rows", "bfv_rotate_columns", "simple_scaler"]}
+LEG_NAMES = GROUPS["ring15"] + GROUPS["ckks15"] + GROUPS["bfv14"]

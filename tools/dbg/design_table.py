@@ -10,8 +10,23 @@ ROWS = [("moddown_ntt", "ModDownNTT (`ModDownSplitedNTTPQ`, in place), R15 16 + 
         ("div_floor_ntt", "DivFloorByLastModulusNTT, R15", "`:365`"),
         ("div_floor", "DivFloorByLastModulus, R15", "`:354`"),
         ("div_round", "DivRoundByLastModulus, R15", "`:376`"),
+        ("ew_mform", "MForm, R15 (in place, like every row of this family)", "`:140`"),
+        ("ew_inv_mform", "InvMForm", "`:146`"),
+        ("ew_mulcoeffs_barrett", "MulCoeffs (Barrett)", "`:197`"),
+        ("ew_mulcoeffs_barrett_constant", "MulCoeffsConstant", "`:203`"),
+        ("ew_mulcoeffs_montgomery_constant", "MulCoeffsMontgomeryConstant (MulCoeffsMontgomery itself: §6.1)", "`:215`"),
+        ("ew_add", "Add", "`:231`"),
+        ("ew_add_nomod", "AddNoMod", "`:237`"),
+        ("ew_sub", "Sub", "`:253`"),
+        ("ew_sub_nomod", "SubNoMod", "`:259`"),
+        ("ew_neg", "Neg", "`:274`"),
+        ("ew_mulscalar", "MulScalar (uint64)", "`:296`"),
+        ("ew_mulscalar_bigint", "MulScalarBigint", "`:302`"),
+        ("marshal", "Poly.MarshalBinary, one 4.2 MB R15 poly per call (host bytes out: PCIe-inclusive)", "`:52`"),
         ("ckks_rescale", "CKKS Rescale (both components), PN15QP880", "`ckks/ckks_benchmarks_test.go:152`"),
         ("ckks_mul", "CKKS Mul (no key, degree-2 result)", "`:166`"),
+        ("ckks_square", "CKKS Square (no key)", "`:172`"),
+        ("ckks_add", "CKKS Add (both components, in place)", "`:134`"),
         ("ckks_relinearize", "CKKS Relin (switchKeysInPlace + 2 AddLvl)", "`:178`"),
         ("ckks_rotate", "CKKS Rotate (RotateColumns by 1)", "`:190`"),
         ("ckks_conjugate", "CKKS Conjugate", "`:184`"),
@@ -20,6 +35,7 @@ ROWS = [("moddown_ntt", "ModDownNTT (`ModDownSplitedNTTPQ`, in place), R15 16 + 
         ("ckks_decrypt", "CKKS Decrypt (degree 1)", "`:103`"),
         ("marshal_ingest", "Poly.UnmarshalBinary, one 4.7 MB component per call (host bytes in: PCIe-inclusive)", "`ring/ring_object.go:252`"),
         ("bfv_mul", "**BFV Mul, PN14QP438** (BASELINE config 4)", "`bfv/bfv_benchmark_test.go:133`"),
+        ("bfv_square", "BFV Square (operand lifted once)", "`:139`"),
         ("bfv_relinearize", "BFV Relin", "`:145`"),
         ("bfv_rotate_rows", "BFV RotateRows", "`:151`"),
         ("bfv_rotate_columns", "BFV RotateCols by 1", "`:157`"),

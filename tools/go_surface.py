@@ -30,7 +30,7 @@ KEPT = {
 }
 # exported identifiers of replaced files that the shim deliberately does not provide
 OMITTED = {
-    "Context.NTTBarrett": "benchmark-only alternative (\"For benchmark purposes only\", ring/ntt.go:141); Context.NTT returns the same values",
+    "Context.NTTBarrett": "benchmark-only (\"For benchmark purposes only\", ring/ntt.go:141; no caller in bfv/ ckks/ dbfv/ dckks/): Barrett products with the Montgomery-form table, so its outputs are not a transform any caller could use",
     "Context.InvNTTBarrett": "benchmark-only alternative (ring/ntt.go:141)",
     "ButterflyBarrett": "benchmark-only (ring/ntt.go:155)",
     "InvButterflyBarrett": "benchmark-only",
