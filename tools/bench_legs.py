@@ -322,6 +322,32 @@ def build_legs(pkg, oracle, device=0, only=None):
                 return lambda: (oc.ewise("ADD", c[0], c[2], out=c[0]), oc.ewise("ADD", c[1], c[3], out=c[1]))
             out.append(Leg("ckks_add", "Add/s", B, 8 * N * 6 * l, tag, "ckks/ckks_benchmarks_test.go:134-138 (Add: evaluateInPlace, one AddLvl per component, in place)",
                            run_add, check_add, cpu_add, B, reps=20, sync=cq))
+        for nm, op, comps_n, ref in (("ckks_add_const", "ADD", 1, ":140-144 (AddScalar = AddConst: CRed(x + s) on the first component, ckks/evaluator.go:429-445)"),
+                                     ("ckks_mult_by_const", "MRED", 2, ":146-150 (MulScalar = MultByConst: MRed(x, s) on both components, ckks/evaluator.go:712-730)")):
+            if not want(nm):
+                continue
+            # the constants the reference derives from the complex scalar (scaleUpExact + MForm): any residues do for the element loop
+            lo_s = np.array([(0x9E3779B97F4A7C15 * (i + 1)) % q for i, q in enumerate(Q)], dtype=np.uint64)
+            hi_s = np.array([(0xC2B2AE3D27D4EB4F * (i + 3)) % q for i, q in enumerate(Q)], dtype=np.uint64)
+            hw = (outp[0], outp[1])
+
+            def run_h(op=op, comps_n=comps_n):
+                for u in range(comps_n):
+                    cq.HalfScalarOp(op, level, hw[u], lo_s, hi_s, hw[u])
+
+            def check_h(op=op, comps_n=comps_n, run_h=run_h):
+                cq.Copy(comp[0], hw[0])
+                cq.Copy(comp[1], hw[1])
+                run_h()
+                oc = oracle.Context(N, Q)
+                opn = {"ADD": 0, "MRED": 1}[op]
+                return bool(all(np.array_equal(_last(hw[u], B, nq, N), oc.half_scalar_op(opn, k["comp_h"][u][last], lo_s, hi_s)) for u in range(comps_n)))
+
+            def cpu_h(i, op=op, comps_n=comps_n):
+                oc, c = oracle.Context(N, Q), [k["comp_h"][u][0].copy() for u in range(2)]
+                opn = {"ADD": 0, "MRED": 1}[op]
+                return lambda: [oc.half_scalar_op(opn, c[u], lo_s, hi_s) for u in range(comps_n)]
+            out.append(Leg(nm, "op/s", B, 8 * N * 2 * l * comps_n, tag, "ckks/ckks_benchmarks_test.go" + ref, run_h, check_h, cpu_h, B, reps=20, sync=cq))
         if want("ckks_relinearize"):
             # Relinearize (ckks/evaluator.go:1144-1162) as the Go overlay runs it: switchKeysInPlace of the degree-2 part, then the two AddLvl
             def run():
@@ -481,6 +507,34 @@ def build_legs(pkg, oracle, device=0, only=None):
             out.append(Leg("bfv_square", "Square/s", B, 8 * N * 5 * l, tag, "bfv/bfv_benchmark_test.go:139-143 (Square = tensorAndRescale with ct0 == ct1, bfv/evaluator.go:306,334-349)",
                            lambda: mul.Mul((comp[0], comp[1]), (comp[0], comp[1]), outp), check_sq, cpu_sq, B, sync=cq,
                            note="two components in, three out; the operand is lifted to QMul and transformed once"))
+        for nm, ref in (("bfv_add", ":121-125 (Add: contextQ.Add per component, in place, bfv/evaluator.go:173-176)"),
+                        ("bfv_mulscalar", ":127-131 (MulScalar: contextQ.MulScalar per component, in place, bfv/evaluator.go:264-268)")):
+            if not want(nm):
+                continue
+            bw = (outp[0], outp[1])
+
+            def run_b(nm=nm):
+                for u in range(2):
+                    if nm == "bfv_add":
+                        cq.Add(bw[u], comp[2 + u], bw[u])
+                    else:
+                        cq.MulScalar(bw[u], 5, bw[u])
+
+            def check_b(nm=nm, run_b=run_b):
+                cq.Copy(comp[0], bw[0])
+                cq.Copy(comp[1], bw[1])
+                run_b()
+                oc = oracle.Context(N, Q)
+                wantv = [oc.ewise("ADD", k["comp_h"][u][last], k["comp_h"][2 + u][last]) if nm == "bfv_add" else
+                         oc.ewise("MUL_SCALAR", k["comp_h"][u][last], scalars=[5]) for u in range(2)]
+                return bool(all(np.array_equal(_last(bw[u], B, nq, N), wantv[u]) for u in range(2)))
+
+            def cpu_b(i, nm=nm):
+                oc, c = oracle.Context(N, Q), [k["comp_h"][u][0].copy() for u in range(4)]
+                if nm == "bfv_add":
+                    return lambda: [oc.ewise("ADD", c[u], c[2 + u], out=c[u]) for u in range(2)]
+                return lambda: [oc.ewise("MUL_SCALAR", c[u], out=c[u], scalars=[5]) for u in range(2)]
+            out.append(Leg(nm, "op/s", B, 8 * N * l * (6 if nm == "bfv_add" else 4), tag, "bfv/bfv_benchmark_test.go" + ref, run_b, check_b, cpu_b, B, reps=20, sync=cq))
         if want("bfv_relinearize"):
             def check():
                 plan.BfvRelinearize((comp[0], comp[1], comp[2]), key, (outp[0], outp[1]))
@@ -536,7 +590,7 @@ def build_legs(pkg, oracle, device=0, only=None):
 EWISE = ["ew_mform", "ew_inv_mform", "ew_mulcoeffs_barrett", "ew_mulcoeffs_barrett_constant", "ew_mulcoeffs_montgomery_constant", "ew_add", "ew_add_nomod",
          "ew_sub", "ew_sub_nomod", "ew_neg", "ew_mulscalar", "ew_mulscalar_bigint"]
 GROUPS = {"ring15": ["moddown_ntt", "moddown", "div_floor_ntt", "div_floor", "div_round"] + EWISE + ["marshal"],
-          "ckks15": ["ckks_rescale", "ckks_mul", "ckks_square", "ckks_add", "ckks_relinearize", "ckks_rotate", "ckks_conjugate", "ckks_rotate_hoisted", "ckks_encrypt_pk", "ckks_decrypt",
+          "ckks15": ["ckks_rescale", "ckks_mul", "ckks_square", "ckks_add", "ckks_add_const", "ckks_mult_by_const", "ckks_relinearize", "ckks_rotate", "ckks_conjugate", "ckks_rotate_hoisted", "ckks_encrypt_pk", "ckks_decrypt",
                      "marshal_ingest"],
-          "bfv14": ["bfv_mul", "bfv_square", "bfv_relinearize", "bfv_rotate_rows", "bfv_rotate_columns", "simple_scaler"]}
+          "bfv14": ["bfv_mul", "bfv_square", "bfv_add", "bfv_mulscalar", "bfv_relinearize", "bfv_rotate_rows", "bfv_rotate_columns", "simple_scaler"]}
 LEG_NAMES = GROUPS["ring15"] + GROUPS["ckks15"] + GROUPS["bfv14"]

@@ -27,6 +27,8 @@ ROWS = [("moddown_ntt", "ModDownNTT (`ModDownSplitedNTTPQ`, in place), R15 16 + 
         ("ckks_mul", "CKKS Mul (no key, degree-2 result)", "`:166`"),
         ("ckks_square", "CKKS Square (no key)", "`:172`"),
         ("ckks_add", "CKKS Add (both components, in place)", "`:134`"),
+        ("ckks_add_const", "CKKS AddScalar (`AddConst`, first component)", "`:140`"),
+        ("ckks_mult_by_const", "CKKS MulScalar (`MultByConst`, both components)", "`:146`"),
         ("ckks_relinearize", "CKKS Relin (switchKeysInPlace + 2 AddLvl)", "`:178`"),
         ("ckks_rotate", "CKKS Rotate (RotateColumns by 1)", "`:190`"),
         ("ckks_conjugate", "CKKS Conjugate", "`:184`"),
@@ -36,6 +38,8 @@ ROWS = [("moddown_ntt", "ModDownNTT (`ModDownSplitedNTTPQ`, in place), R15 16 + 
         ("marshal_ingest", "Poly.UnmarshalBinary, one 4.7 MB component per call (host bytes in: PCIe-inclusive)", "`ring/ring_object.go:252`"),
         ("bfv_mul", "**BFV Mul, PN14QP438** (BASELINE config 4)", "`bfv/bfv_benchmark_test.go:133`"),
         ("bfv_square", "BFV Square (operand lifted once)", "`:139`"),
+        ("bfv_add", "BFV Add (both components, in place)", "`:121`"),
+        ("bfv_mulscalar", "BFV MulScalar (both components)", "`:127`"),
         ("bfv_relinearize", "BFV Relin", "`:145`"),
         ("bfv_rotate_rows", "BFV RotateRows", "`:151`"),
         ("bfv_rotate_columns", "BFV RotateCols by 1", "`:157`"),
