@@ -464,7 +464,8 @@ int lr_bfv_plan_create(lr_context *ctxQ, lr_context *ctxQMul, uint64_t t, int ma
 /* the same with explicit options; NULL = the options of ctxQ */
 int lr_bfv_plan_create_ex(lr_context *ctxQ, lr_context *ctxQMul, uint64_t t, int max_batch, const lr_options *opt, lr_bfv_plan **out);
 int lr_bfv_plan_destroy(lr_bfv_plan *plan);
-/* operands and results over Q in the coefficient domain, as BFV ciphertexts are; out has degree 2 */
+/* operands and results over Q in the coefficient domain, as BFV ciphertexts are; out has degree 2.  ct0 == ct1 (the same two handles: the
+ * reference's squaring case, bfv/evaluator.go:306,334-349) lifts and transforms the operand once; outputs may be operands. */
 int lr_bfv_mul(lr_bfv_plan *plan, const lr_poly *ct0_c0, const lr_poly *ct0_c1, const lr_poly *ct1_c0,
                const lr_poly *ct1_c1, lr_poly *out_c0, lr_poly *out_c1, lr_poly *out_c2);
 
