@@ -320,3 +320,62 @@ def test_moddown_divfloor_permute_fuzz(gpu_pkg, oracle, seed):
         got = po.get().reshape(batch, nq, N)
         for b in range(batch):
             assert np.array_equal(got[b], ocQ.permute(xq[b], gen)), ("permute", logn, gen, b)
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_bfv_pipelines_fuzz(gpu_pkg, oracle, seed):
+    """the BFV caller sequences at random degrees, limb counts (prefixes of the reference's parameter sets, so that |QMul| = |Q| as
+    bfv/params.go has it) and batches: Mul, Square (the operand lifted once), Relinearize, RotateRows / RotateColumns with a random
+    Galois element -- gathered small-batch launches and the per-operand form alike"""
+    rng = np.random.default_rng(8000 + seed)
+    name = ("PN12QP109", "PN13QP218", "PN14QP438", "PN15QP880")[seed % 4]
+    Nfull, Qf, Pf, Mf = gpu_pkg.params.bfv_moduli(name)
+    top = Nfull.bit_length() - 1
+    logn = int(rng.integers(6, top + 1)) if seed < 6 else min(top, 12 + seed % 4)
+    N = 1 << logn
+    nq = int(rng.integers(2, len(Qf) + 1)) if len(Qf) > 2 else len(Qf)
+    nq = min(nq, 7)
+    np_ = int(rng.integers(1, len(Pf) + 1))
+    Q, P, M = list(Qf[:nq]), list(Pf[:np_]), list(Mf[:nq])
+    batch = int(rng.integers(1, 4))
+    t = 65537
+    ring = gpu_pkg.ring
+    cQ, cP, cM = ring.NewContextWithParams(N, Q), ring.NewContextWithParams(N, P), ring.NewContextWithParams(N, M)
+    mul, ks = ring.BfvPlan(cQ, cM, t, batch), ring.CkksPlan(cQ, cP, batch)
+    omul = oracle.BfvPlan(oracle.Context(N, Q), oracle.Context(N, M), t)
+    oks = oracle.CkksPlan(oracle.Context(N, Q), oracle.Context(N, P))
+    beta = -(-nq // np_)
+    evk = gpu_pkg.sampling.uniform_poly(Q + P, N, 2 * beta, seed=seed + 90)
+    evk4 = evk.reshape(beta, 2, nq + np_, N)
+    key = ks.NewSwitchingKey().set(evk)
+    mk = lambda s: gpu_pkg.sampling.uniform_poly(Q, N, batch, seed=s).reshape(batch, nq, N)
+    a0, a1, b0, b1 = mk(seed + 1), mk(seed + 2), mk(seed + 3), mk(seed + 4)
+    P_ = lambda x: cQ.NewPoly(batch).set(x)
+    ct0, ct1 = (P_(a0), P_(a1)), (P_(b0), P_(b1))
+    d2 = (cQ.NewPoly(batch), cQ.NewPoly(batch), cQ.NewPoly(batch))
+    mul.Mul(ct0, ct1, d2)
+    g2 = [p.get().reshape(batch, nq, N) for p in d2]
+    want2 = [omul.mul(np.stack([a0[b], a1[b]]), np.stack([b0[b], b1[b]])) for b in range(batch)]
+    for b in range(batch):
+        for k in range(3):
+            assert np.array_equal(g2[k][b], want2[b][k]), ("mul", name, logn, nq, np_, b, k)
+    sq = (cQ.NewPoly(batch), cQ.NewPoly(batch), cQ.NewPoly(batch))
+    mul.Mul(ct0, ct0, sq)
+    gs = [p.get().reshape(batch, nq, N) for p in sq]
+    for b in range(batch):
+        wants = omul.square(np.stack([a0[b], a1[b]]))
+        for k in range(3):
+            assert np.array_equal(gs[k][b], wants[k]), ("square", name, logn, nq, b, k)
+    lin = (cQ.NewPoly(batch), cQ.NewPoly(batch))
+    ks.BfvRelinearize(d2, key, lin)
+    gl = [p.get().reshape(batch, nq, N) for p in lin]
+    for b in range(batch):
+        want1 = oks.bfv_relinearize(want2[b], evk4)
+        assert np.array_equal(gl[0][b], want1[0]) and np.array_equal(gl[1][b], want1[1]), ("relinearize", name, logn, nq, np_, b)
+    gen = 2 * N - 1 if rng.integers(0, 2) else pow(5, int(rng.integers(1, N // 2)), 2 * N)
+    rot = (cQ.NewPoly(batch), cQ.NewPoly(batch))
+    ks.BfvPermute(ct0, gen, key, rot)
+    gr = [p.get().reshape(batch, nq, N) for p in rot]
+    for b in range(batch):
+        wantr = oks.bfv_permute(np.stack([a0[b], a1[b]]), gen, evk4)
+        assert np.array_equal(gr[0][b], wantr[0]) and np.array_equal(gr[1][b], wantr[1]), ("permute", name, logn, nq, np_, gen, b)

@@ -17,7 +17,7 @@ count = int(sys.argv[2]) if len(sys.argv) > 2 else 200
 fails = 0
 t0 = time.time()
 for name in ("test_ntt_and_elementwise_fuzz", "test_basis_extension_and_rescale_fuzz", "test_key_switch_fuzz", "test_dual_kernel_fuzz", "test_mulrelin_rescale_fuzz",
-             "test_rotation_encrypt_decrypt_fuzz", "test_moddown_divfloor_permute_fuzz"):
+             "test_rotation_encrypt_decrypt_fuzz", "test_moddown_divfloor_permute_fuzz", "test_bfv_pipelines_fuzz"):
     fn = getattr(F, name)
     done = 0
     for seed in range(first, first + count):
