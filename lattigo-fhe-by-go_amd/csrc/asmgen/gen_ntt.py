@@ -1221,9 +1221,17 @@ class Gen:
             e("ds_read_b128", regs[i], a0, offset=i * 1152)
         XQ = [v(self.tw_base + 8 * i, 4) for i in range(4)]
         PQ = [v(self.tw_base + 8 * i + 4, 4) for i in range(4)]
+        # LR_GEN_EXPERIMENT=noepiload (measurement only, wrong results): the epilogue's operands come from nowhere -- what the launch gains is
+        # everything their loads cost, bandwidth and exposed latency together (profiles/r04/epilogue_load_cost.txt)
+        noload = os.environ.get("LR_GEN_EXPERIMENT") == "noepiload"
         for batch in range(2):
             for i in range(4):
                 k = 4 * batch + i
+                if noload:
+                    for r in range(4):
+                        e("v_mov_b32", v(self.tw_base + 8 * i + r), 0)
+                        e("v_mov_b32", v(self.tw_base + 8 * i + 4 + r), 0)
+                    continue
                 e("global_load_dwordx4", XQ[i], a2, XR, offset=(k % 4) * 1024, hint="nt")
                 # plus: default cache policy, not streaming like x: the rounding rescale's plus operand is ONE table row per limb shared
                 # by every poly of the launch, and with nt each workgroup fetched it from memory again (4.7 GB per launch of 256 polys x
@@ -1238,7 +1246,7 @@ class Gen:
                 r = regs[k]
                 # loads return in order: at most the 2*(3-i) younger loads of this batch may still be out (stores issued
                 # in between can only make the wait longer)
-                e("s_waitcnt", "vmcnt(%d) lgkmcnt(%d)" % (2 * (3 - i), n - 1 - k))
+                e("s_waitcnt", ("lgkmcnt(%d)" % (n - 1 - k)) if noload else "vmcnt(%d) lgkmcnt(%d)" % (2 * (3 - i), n - 1 - k))
                 epi = self.ops_epilogue if self.fp else self.ops_epilogue_int
                 self.zip_emit([(lambda ts, y=r.sub(0, 2), x=XQ[i].sub(0, 2), pp=PQ[i].sub(0, 2): epi(ts, y, x, pp, EC)),
                                (lambda ts, y=r.sub(2, 2), x=XQ[i].sub(2, 2), pp=PQ[i].sub(2, 2): epi(ts, y, x, pp, EC))])
