@@ -1275,6 +1275,22 @@ def main():
         progress("evaluator-per-thread BFV Mul + Relinearize: " + ", ".join("T=%d %.0f/s" % (r["threads"], r["mul_relin_per_s"]) for r in frows) +
                  "; through the batcher: " + ", ".join("T=%d %.0f/s (mean batch %.1f)" % (r["threads"], r["mul_relin_per_s"], r["mean_batch"]) for r in fbrows))
 
+    if rank == 0 and world == 1 and not args.no_ckks and not args.no_threads:
+        # The same calling shape from a plain C++ host (tools/batcher_bench.cpp over include/lattigo_ring.h: no interpreter, no GIL in the
+        # loop): the Python threads above lose throughput from T = 4 to T = 16, a C++ host does not.  Built with g++ at run time, run as a
+        # child process; skipped with its reason if the toolchain is missing.
+        try:
+            import subprocess
+            tool = _tool("batcher_bench.py")
+            subprocess.run([sys.executable, tool, "--build"], check=True, timeout=120, capture_output=True)
+            res = subprocess.run([sys.executable, tool, "PN15QP880", "1,4,16,64", "60", "2", "64"], check=True, timeout=240, capture_output=True, text=True)
+            nrows = [json.loads(ln) for ln in res.stdout.splitlines() if ln.startswith("{")]
+            out["evaluator_threads_native"] = {"params": "PN15QP880, level 17, batch 1 per call; C++ host threads (tools/batcher_bench.cpp), 60 calls per thread",
+                                               "rows": nrows, "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES")}
+            progress("the same from a C++ host: " + ", ".join("%s T=%d %.0f/s" % (r["how"], r["threads"], r["calls_per_s"]) for r in nrows))
+        except Exception as ex:     # noqa: BLE001 -- optional leg
+            out["evaluator_threads_native"] = {"skipped": str(ex)[-300:]}
+
     if not args.no_extras and rank == 0:
         # the other kernels BASELINE.json's north_star asks throughput for, same ring, same resident batch; after timing,
         # the last poly of every output is compared with the oracle
@@ -1529,9 +1545,17 @@ def main():
         for key, o in out.get("pipelines", {}).items():
             summary[key] = {"per_s": round(o["value"], 1), "frac": frac(o), "traffic_ratio": ratio(o), "bit_exact": o.get("bit_exact"),
                             "cpu_per_s": round(o["cpu_baseline"]["value"], 1) if "cpu_baseline" in o else None}
+        et, en = out.get("evaluator_threads"), out.get("evaluator_threads_native")
+        if isinstance(et, dict) and "rows" in et:
+            th = {"python_threads_direct": {str(x["threads"]): round(x["mulrelin_per_s"]) for x in et["rows"]},
+                  "python_threads_batcher": {str(x["threads"]): round(x["mulrelin_per_s"]) for x in et["batcher_rows"]}}
+            if isinstance(en, dict) and "rows" in en:
+                for how in ("direct", "batcher"):
+                    th["cpp_threads_" + how] = {str(x["threads"]): round(x["calls_per_s"]) for x in en["rows"] if x["how"] == how}
+            summary["mulrelin_batch1_per_s_by_threads"] = th
         summary["runtime"] = {"GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES"), "note": "set by bench.py before HIP initialises (--hw-queues); only the "
                               "evaluator_threads rows have more than one busy stream"}
-        r["companions"] = {k: v for k, v in summary.items() if k != "runtime"}      # (the driver's parsed record keeps the roofline object whole)
+        r["companions"] = {k: v for k, v in summary.items() if k not in ("runtime", "mulrelin_batch1_per_s_by_threads")}      # (the driver's parsed record keeps the roofline object whole)
         out["summary"] = summary
         emit(out)
     if use_dist:
