@@ -504,7 +504,9 @@ int lr_bfv_batcher_stats(lr_bfv_batcher *batcher, uint64_t *batches, uint64_t *p
  * kernels that produce the chunk), and overlaps whatever src_ctx is given next.  Nothing is enqueued on dst_ctx's stream: the consumer
  * calls lr_context_wait_peer_copies(dst_ctx) when it wants to read -- dst_ctx's stream then waits (on the device) for every copy into its
  * device enqueued so far.  Callable from any thread; the source must not be overwritten before the copy has run (the caller's ordering:
- * later work of src_ctx on those polys must follow an lr_context_wait_peer_copies / lr_context_sync of the consumer).
+ * later work of src_ctx on those polys must follow an lr_context_wait_peer_copies / lr_context_sync of the consumer), and the destination
+ * slots must not be in use by work still queued on dst_ctx when the call is made (the copy is not ordered behind dst_ctx's stream, so that a
+ * root which computes its own share into other slots of the same poly keeps overlapping with the incoming copies).
  *
  * lr_gather_blocks: the whole gather in one call: block r = the first counts[r] polys of srcs[r], placed in dst one behind the other in
  * block order (= global unit order under contiguous-block sharding), then lr_context_wait_peer_copies(dst_ctx).  A producer that works in
