@@ -24,6 +24,12 @@ counter each) execute the same kernel / pipeline on the same shape at the end; n
 cannot run (--no-traffic skips it; tools/collect_profiles.sh writes the committed figures named in `traffic_profile`).  `cpu_baseline` objects time the CPU oracle
 (C restatement of the Go algorithm, rebuilt -O2 -march=native on this machine; Go itself is not installable here) on the
 host cores, rank 0 at N=1 only, on bounded samples.
+
+Beside the headline the line carries (N = 1): `extras` / `rings` / `mulrelin_sets` (the other ring operations and sizes), `ckks_mulrelin`, `bfv_mul`
+(BASELINE config 4) and `pipelines` -- one timed call per entry point of the reference's ring, ckks-evaluator and bfv-evaluator benchmark lists
+(tools/bench_legs.py), each with roofline, in-run traffic, vector issue, kernel split, bit_exact and cpu_baseline --, `evaluator_threads`,
+`evaluator_threads_bfv` (one evaluator per host thread, direct and through the batchers, Python threads), `evaluator_threads_native` (the same
+from a C++ host, tools/batcher_bench.cpp), `config5` / `config5_single_process`, and last `summary`: the short form a reader of the line's tail needs.
 """
 import argparse
 import json
