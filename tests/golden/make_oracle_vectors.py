@@ -79,6 +79,26 @@ def build():
     ct2[0][:, 2] = 0
     for nm, g in (("col", pow(5, 3, 2 * N)), ("row", 2 * N - 1)):
         case("bfv_permute:" + nm, {"ct": ct2, "evk": evk}, plan.bfv_permute(ct2, g, evk), gen=g)
+    # round 4, second half: the remaining caller sequences of SURVEY 8(f)1-2 and the squaring cases on the same toy parameters --
+    # permuteNTT / RotateHoisted (ckks/evaluator.go:1448, 1252), MulRelin without key (regular and squaring, :1038-1111), plaintext x
+    # ciphertext (:1113-1131), pk-encrypt after the sampling (ckks/encryptor.go:205-234), Decrypt of degree 2 (ckks/decryptor.go:53-78),
+    # BFV Mul(ct, ct) (bfv/evaluator.go:306,334-349)
+    gens = [pow(5, 3, 2 * N), 2 * N - 1]
+    evk2 = pkg.sampling.uniform_poly(Q + P[:1], N, 6, seed=10).reshape(3, 2, 4, N)
+    case("ckks_rotate", {"ct": ct0, "evk": evk}, plan.permute_ntt(2, ct0, gens[0], evk), level=2, gen=gens[0])
+    case("ckks_rotate_hoisted", {"ct": ct0, "evk0": evk, "evk1": evk2}, plan.rotate_hoisted(2, ct0, gens, [evk, evk2]), level=2, gens=gens)
+    case("ckks_mul_norelin", {"ct0": ct0, "ct1": ct1}, plan.mul_norelin(2, ct0, ct1), level=2)
+    case("ckks_square", {"ct0": ct0}, plan.mul_norelin(2, ct0, ct0, squaring=True), level=2)
+    case("ckks_mul_plain", {"pt": a, "ct": ct1}, plan.mul_plain(2, a, ct1), level=2)
+    QP1 = Q + P[:1]
+    u, e0, e1, pk0, pk1 = (rnd(QP1, 41 + i) for i in range(5))
+    for i, q in enumerate(QP1):
+        e0[i, 0] = q                                   # SampleAndAdd's residue of -0 (ring/gaussianSampler.go:268)
+    enc_out = plan.encrypt_pk(oracle.Context(N, QP1), 2, u, pk0, pk1, e0, e1, b)
+    case("ckks_encrypt_pk", {"u": u, "pk0": pk0, "pk1": pk1, "e0": e0, "e1": e1, "pt": b}, enc_out, level=2)
+    sk = rnd(Q, 46)
+    case("ckks_decrypt", {"ct": ct3, "sk": sk}, plan.decrypt(2, ct3, sk), level=2)
+    case("bfv_square", {"ct0": b0}, np.stack(bplan.square(b0)), t=65537)
     return {"N": N, "Q": [str(q) for q in Q], "P": [str(p) for p in P], "cases": cases,
             "note": "uint64 values as decimal strings, arrays flattened in C order with their shape"}
 

@@ -106,3 +106,36 @@ def test_device_reproduces_the_committed_vectors(gpu_pkg):
         rot = (cQ.NewPoly(1), cQ.NewPoly(1))
         plan.BfvPermute((up(cQ, c2[0]), up(cQ, c2[1])), CASES[name]["gen"], key, rot)
         assert np.array_equal(np.stack([rot[0].get(), rot[1].get()]), out(name)), name
+    # round 4, second half: rotations with key, hoisted rotations, products without key (regular, squaring, plaintext), encrypt, decrypt, BFV square
+    c = CASES["ckks_rotate"]
+    ctr = inp("ckks_rotate", "ct")
+    rot = (cQ.NewPoly(1), cQ.NewPoly(1))
+    plan.PermuteNTT(2, (up(cQ, ctr[0]), up(cQ, ctr[1])), c["gen"], key, rot)
+    assert np.array_equal(np.stack([rot[0].get(), rot[1].get()]), out("ckks_rotate"))
+    c = CASES["ckks_rotate_hoisted"]
+    key2 = plan.NewSwitchingKey().set(inp("ckks_rotate_hoisted", "evk1").reshape(6, len(Q) + 1, N))
+    outs = [(cQ.NewPoly(1), cQ.NewPoly(1)) for _ in c["gens"]]
+    plan.RotateHoisted(2, (up(cQ, ctr[0]), up(cQ, ctr[1])), c["gens"], [key, key2], outs)
+    assert np.array_equal(np.stack([np.stack([o[0].get(), o[1].get()]) for o in outs]), out("ckks_rotate_hoisted"))
+    m0, m1 = inp("ckks_mul_norelin", "ct0"), inp("ckks_mul_norelin", "ct1")
+    A, B_ = (up(cQ, m0[0]), up(cQ, m0[1])), (up(cQ, m1[0]), up(cQ, m1[1]))
+    d2 = (cQ.NewPoly(1), cQ.NewPoly(1), cQ.NewPoly(1))
+    plan.MulRelin(2, A, B_, None, d2)
+    assert np.array_equal(np.stack([x.get() for x in d2]), out("ckks_mul_norelin"))
+    plan.MulRelin(2, A, A, None, d2)
+    assert np.array_equal(np.stack([x.get() for x in d2]), out("ckks_square"))
+    d1 = (cQ.NewPoly(1), cQ.NewPoly(1))
+    mp = inp("ckks_mul_plain", "ct")
+    plan.MulRelin(2, (up(cQ, inp("ckks_mul_plain", "pt")),), (up(cQ, mp[0]), up(cQ, mp[1])), None, d1)
+    assert np.array_equal(np.stack([x.get() for x in d1]), out("ckks_mul_plain"))
+    QPp = lambda k: ring.Poly(cQ, len(Q) + 1, 1).set(inp("ckks_encrypt_pk", k).reshape(1, len(Q) + 1, N))
+    plan.EncryptPk(2, QPp("u"), (QPp("pk0"), QPp("pk1")), (QPp("e0"), QPp("e1")), up(cQ, inp("ckks_encrypt_pk", "pt")), d1)
+    assert np.array_equal(np.stack([x.get() for x in d1]), out("ckks_encrypt_pk"))
+    dc = inp("ckks_decrypt", "ct")
+    ptd = cQ.NewPoly(1)
+    plan.Decrypt(2, tuple(up(cQ, dc[k]) for k in range(3)), up(cQ, inp("ckks_decrypt", "sk")), ptd)
+    assert np.array_equal(ptd.get(), out("ckks_decrypt"))
+    s0 = inp("bfv_square", "ct0")
+    S = (up(bq, s0[0]), up(bq, s0[1]))
+    bplan.Mul(S, S, bo)
+    assert np.array_equal(np.stack([x.get() for x in bo]), out("bfv_square"))
